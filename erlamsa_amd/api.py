@@ -1,0 +1,106 @@
+"""Option-map level API mirroring erlamsa_main:fuzzer/1 and erlamsa_app:fuzz/1,2.
+
+Option keys are the reference's Dict keys (erlamsa_main.erl:127-163):
+  seed        {A,B,C} tuple                      (default: os.urandom, like gen_urandom_seed/0)
+  mutations   [(name, pri)] or "-m" string       (default erlamsa_mutations:default/1)
+  patterns    [(name, pri)] or "-p" string       (default erlamsa_patterns:default/0)
+  generators  [(name, pri)]                      (default: what paths=[direct] leaves: direct=500, random=1)
+  n           number of cases                    (default 1)
+  input       bytes                              (paths = [direct])
+  blockscale  float
+  skip        first cases are computed but dropped (erlamsa_main.erl:191-196)
+Only `paths => [direct]`, `output => return` is served by the GPU path.
+"""
+import os
+
+import numpy as np
+
+from .engine import CASE_OK, Engine, mutator_table, pattern_table
+
+_engines = {}
+
+
+def _engine(device=0):
+    e = _engines.get(device)
+    if e is None:
+        e = _engines[device] = Engine(device)
+    return e
+
+
+def default_mutations():
+    """erlamsa_mutations:default/1 -> [(name, pri)] (erlamsa_mutations.erl:1358-1359)"""
+    return [(n, p) for n, p, _ in mutator_table()]
+
+
+def default_patterns():
+    """erlamsa_patterns:default/0 (erlamsa_patterns.erl:407-408)"""
+    return [(n, p) for n, p, _ in pattern_table()]
+
+
+def actions_to_string(lst):
+    if lst is None or isinstance(lst, str):
+        return lst
+    return ",".join("%s=%d" % (n, p) for n, p in lst)
+
+
+def pack_corpus(inputs):
+    """list[bytes] -> (uint8 arena, uint64 off[n+1])  — the packed offset/length arena"""
+    off = np.zeros(len(inputs) + 1, dtype=np.uint64)
+    if inputs:
+        off[1:] = np.cumsum([len(b) for b in inputs], dtype=np.uint64)
+    joined = b"".join(inputs)
+    data = np.frombuffer(joined, dtype=np.uint8).copy() if joined else np.zeros(1, dtype=np.uint8)
+    return data, off
+
+
+def _seed_of(opts):
+    s = opts.get("seed")
+    if s is None:  # gen_urandom_seed/0 erlamsa_rnd.erl:50-62: three 16-bit values
+        raw = os.urandom(6)
+        s = tuple(int.from_bytes(raw[2 * i:2 * i + 2], "big") for i in range(3))
+    return tuple(int(x) for x in s)
+
+
+def _configure(eng, opts):
+    eng.configure(mutations=actions_to_string(opts.get("mutations")), patterns=actions_to_string(opts.get("patterns")),
+                  generators=actions_to_string(opts.get("generators")), blockscale=float(opts.get("blockscale", 1.0)),
+                  ssrf_host=opts.get("ssrf_host"), ssrf_port=int(opts.get("ssrf_port", 0)),
+                  max_case_bytes=int(opts.get("max_case_bytes", 0)), out_capacity=int(opts.get("out_capacity", 0)),
+                  max_slots=int(opts.get("max_slots", 0)))
+
+
+def fuzz_batch(inputs, opts=None, return_status=False, device=0):
+    """Case I (1-based) of ONE fuzzer/1 run mutates inputs[I-1].  -> list[bytes] (and statuses)."""
+    opts = dict(opts or {})
+    eng = _engine(device)
+    _configure(eng, opts)
+    data, off = pack_corpus(list(inputs))
+    eng.upload_corpus(data, off)
+    eng.fuzz_batch(seed=_seed_of(opts), first_case=int(opts.get("first_case", 1)), n=len(inputs))
+    outs, status = eng.download()
+    return (outs, status) if return_status else outs
+
+
+def fuzzer(opts):
+    """erlamsa_main:fuzzer/1 for paths=[direct], output=return: the same input N times.
+    Like record_result/2 (erlamsa_main.erl:120-122) empty results are dropped."""
+    opts = dict(opts)
+    if opts.get("paths", ["direct"]) != ["direct"] or opts.get("output", "return") != "return":
+        raise ValueError("only paths=[direct], output=return is served by the GPU path")
+    n = int(opts.get("n", 1))
+    skip = int(opts.get("skip", 0))
+    outs, status = fuzz_batch([bytes(opts.get("input", b""))] * n, opts, return_status=True, device=int(opts.get("device", 0)))
+    res = []
+    for i, (o, s) in enumerate(zip(outs, status)):
+        if i < skip:
+            continue
+        if s == CASE_OK and len(o) > 0:
+            res.append(o)
+    return res
+
+
+def fuzz(data, opts=None):
+    """erlamsa_app:fuzz/1,2: one case; returns the mutated binary ([] when the result is empty,
+    like extract_function/1 on an empty list, erlamsa_utils.erl:96-99)."""
+    r = fuzzer(dict(opts or {}, input=bytes(data), n=1))
+    return r[0] if r else []

@@ -1,0 +1,107 @@
+// eh_common.h — ids, tables and plain structs shared by the host API and the
+// device kernels of liberlamsa_hip.so.
+#pragma once
+#include <stdint.h>
+
+namespace eh {
+
+// Mutator ids in the table order of erlamsa_mutations:mutations/1
+// (reference src/erlamsa_mutations.erl:1291-1331).
+enum MutaId : int {
+  M_SGM, M_JS, M_UW, M_UI, M_AB, M_AD, M_TR2, M_TD, M_NUM, M_TS1, M_TR, M_TS2, M_BD, M_BEI, M_BED,
+  M_BF, M_BI, M_BER, M_BR, M_SP, M_SR, M_SD, M_SNAND, M_SRND, M_LD, M_LDS, M_LR2, M_LRI, M_LR,
+  M_LS, M_LP, M_LIS, M_LRS, M_FT, M_FN, M_FO, M_LEN, M_B64, M_URI, M_ZIP, M_NIL, M_COUNT
+};
+// Pattern ids in the table order of erlamsa_patterns:patterns/0 (erlamsa_patterns.erl:395-405).
+enum PatId : int { P_OD, P_ND, P_BU, P_SK, P_SZ, P_CS, P_AR, P_CP, P_CO, P_NU, P_COUNT };
+enum GenId : int { G_DIRECT = 0, G_RANDOM = 1 };
+
+enum CaseStatus : int { CASE_OK = 0, CASE_CRASHED = 1, CASE_OVERFLOW = 2, CASE_UNSUPPORTED = 3 };
+
+constexpr int MAX_FS = 64;          // mux_fuzzers list entries (one per lane of the wavefront)
+constexpr int MAX_BLOCKS = 2048;    // block-list entries per case
+constexpr int MAX_EMITS = 4096;     // deferred output pieces per case
+constexpr int MAX_FRAMES = 16;      // nested sizer/csum wrappers
+
+// erlamsa.hrl:44-58
+constexpr uint32_t INITIAL_IP = 24;
+constexpr uint32_t AVG_BLOCK_SIZE = 2048;
+constexpr uint32_t MIN_BLOCK_SIZE = 256;
+constexpr uint32_t MAX_BLOCK_SIZE = 4096;
+constexpr uint32_t ABSMAXHALF_BINARY_BLOCK = 500000;
+constexpr uint32_t ABSMAX_BINARY_BLOCK = 1000000;
+constexpr uint32_t SIZER_MAX_FIRST_BYTES = 512;
+constexpr uint32_t PREAMBLE_MAX_BYTES = 32;
+
+// A block (binary) of the case's lazy list: generic pointer + length.
+struct Blk {
+  uint64_t ptr;
+  uint32_t len;
+  uint32_t aux;
+};
+
+// Result of the per-run setup of erlamsa_main:fuzzer/1 (:134-158): parent PRNG state after the
+// setup draws, generator choice, and the initial mux_fuzzers list in list order.
+struct RunState {
+  uint32_t a1, a2, a3;       // parent stream state after setup (next draws = ThreadSeeds)
+  int32_t gen;               // GenId
+  int32_t nfs;
+  int32_t snand_mask;        // 0 nand, 1 or, 2 xor
+  uint8_t fs_name[MAX_FS];   // MutaId per list position
+  uint8_t fs_score[MAX_FS];
+  uint32_t fs_pri[MAX_FS];
+};
+
+struct DevConfig {
+  // selected mutators in TABLE order (make_mutator folds over the table): name id, pri
+  int32_t nsel;
+  uint8_t sel_name[MAX_FS];
+  uint32_t sel_pri[MAX_FS];
+  // patterns after erlamsa_utils:sort_by_priority (erlamsa_utils.erl:113-117)
+  int32_t npat;
+  int32_t pat_total;
+  uint8_t pat_id[P_COUNT];
+  uint32_t pat_pri[P_COUNT];
+  // generators after sort_by_priority
+  int32_t ngen;
+  int32_t gen_total;
+  uint8_t gen_id[2];
+  uint32_t gen_pri[2];
+  uint32_t max_block_scaled;  // round(MAX_BLOCK_SIZE * blockscale)
+  uint32_t min_block_scaled;  // round(MIN_BLOCK_SIZE * blockscale)
+  // SSRF endpoint strings pre-rendered on the host
+  char ssrf_host[64];
+  char ssrf_port[12];
+};
+
+struct KParams {
+  const uint8_t* corpus;
+  const uint64_t* coff;
+  uint64_t corpus_first;
+  uint64_t n;
+  uint64_t first_case;        // 1-based case number of case 0 (mode 0)
+  int32_t mode;               // 0 batch (one parent seed), 1 per-call seeds
+  const RunState* run;        // mode 0
+  const int64_t* seeds;       // mode 1: 3n
+  DevConfig cfg;
+  // per-slot memory
+  uint8_t* slot_base;
+  uint64_t slot_stride;
+  uint64_t work_cap;          // bytes of the linear work area
+  // outputs
+  uint8_t* out;
+  uint64_t out_cap;
+  unsigned long long* out_cursor;
+  uint64_t* out_off;
+  uint64_t* out_len;
+  int32_t* status;
+  uint64_t* draws;
+  int32_t* lastm;
+  unsigned long long* ticket;
+  unsigned long long* in_bytes;
+};
+
+struct MutaInfo { const char* name; int pri; int on_gpu; };
+struct PatInfo { const char* name; int pri; int on_gpu; };
+
+}  // namespace eh

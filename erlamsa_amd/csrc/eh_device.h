@@ -1,0 +1,507 @@
+// eh_device.h — device-side building blocks of the batch mutation engine (gfx950, wave64).
+//
+// Execution model: ONE WAVEFRONT PER CASE, workgroup = 1 wavefront (64 threads).
+//  * All decision state (PRNG, block list, mutator scores) is wave-uniform; every lane
+//    evaluates the same scalar program, so branches are uniform and the compiler keeps
+//    integer state in SGPRs.  The FP64 part of AS183 runs on the VALU.
+//  * Draw *runs* whose length is known up front (weighted_permutations keys, random
+//    blocks, permutation keys) are evaluated lane-parallel with AS183 jump-ahead:
+//    state after k draws = (A1*171^k mod 30269, A2*172^k mod 30307, A3*170^k mod 30323),
+//    so lane l computes draw l+1 directly ("counter-based" use of erlamsa_rnd).
+//  * Byte work (copies, fills, compares, scans) is spread over the 64 lanes with 16-byte
+//    accesses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "eh_common.h"
+
+namespace eh {
+
+#define EH_LANE ((int)threadIdx.x)
+#define EH_DEV __device__ __forceinline__
+
+EH_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+EH_DEV uint64_t uni64(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
+EH_DEV void wave_sync() { __syncthreads(); }  // workgroup == one wavefront
+
+// ---------------------------------------------------------------------------------------------
+// AS183 jump tables: T?[k] = mult^k mod prime, k = 0..64  (filled by the host at load time)
+// ---------------------------------------------------------------------------------------------
+__constant__ uint16_t c_T1[65];
+__constant__ uint16_t c_T2[65];
+__constant__ uint16_t c_T3[65];
+// funny_unicode/0 table (erlamsa_mutations.erl:1053-1078): [len, b0..b3] per entry
+__constant__ uint8_t c_funny[192][5];
+__constant__ int c_nfunny;
+
+constexpr uint32_t P1 = 30269, P2 = 30307, P3 = 30323;
+
+EH_DEV uint32_t modpow(uint32_t base, uint64_t e, uint32_t p) {
+  uint32_t r = 1;
+  while (e) { if (e & 1) r = (r * base) % p; base = (base * base) % p; e >>= 1; }
+  return r;
+}
+
+struct Rng {
+  uint32_t a1, a2, a3;
+  uint64_t draws;
+};
+
+// U from a POST-STEP state: R = B1/30269 + B2/30307 + B3/30323 ; U = R - trunc(R)
+EH_DEV double u_of(uint32_t b1, uint32_t b2, uint32_t b3) {
+  double q1 = (double)b1 / 30269.0;
+  double q2 = (double)b2 / 30307.0;
+  double q3 = (double)b3 / 30323.0;
+  double r = (q1 + q2) + q3;
+  return r - trunc(r);
+}
+EH_DEV void rng_seed(Rng& r, int64_t s1, int64_t s2, int64_t s3) {  // random:seed/3
+  uint64_t x1 = (uint64_t)(s1 < 0 ? -s1 : s1), x2 = (uint64_t)(s2 < 0 ? -s2 : s2), x3 = (uint64_t)(s3 < 0 ? -s3 : s3);
+  r.a1 = (uint32_t)(x1 % (P1 - 1)) + 1;
+  r.a2 = (uint32_t)(x2 % (P2 - 1)) + 1;
+  r.a3 = (uint32_t)(x3 % (P3 - 1)) + 1;
+}
+EH_DEV double rng_uniform(Rng& r) {
+  r.a1 = (r.a1 * 171u) % P1;
+  r.a2 = (r.a2 * 172u) % P2;
+  r.a3 = (r.a3 * 170u) % P3;
+  r.draws++;
+  return u_of(r.a1, r.a2, r.a3);
+}
+// advance by k draws (k <= 64 via table, else modpow)
+EH_DEV void rng_skip(Rng& r, uint64_t k) {
+  if (k <= 64) {
+    r.a1 = (r.a1 * (uint32_t)c_T1[k]) % P1; r.a2 = (r.a2 * (uint32_t)c_T2[k]) % P2; r.a3 = (r.a3 * (uint32_t)c_T3[k]) % P3;
+  } else {
+    r.a1 = (r.a1 * modpow(171, k, P1)) % P1; r.a2 = (r.a2 * modpow(172, k, P2)) % P2; r.a3 = (r.a3 * modpow(170, k, P3)) % P3;
+  }
+  r.draws += k;
+}
+// the j-th (1-based, j <= 64) NEXT uniform without advancing the state: per-lane j allowed
+EH_DEV double rng_peek(const Rng& r, uint32_t j) {
+  uint32_t b1 = (r.a1 * (uint32_t)c_T1[j]) % P1, b2 = (r.a2 * (uint32_t)c_T2[j]) % P2, b3 = (r.a3 * (uint32_t)c_T3[j]) % P3;
+  return u_of(b1, b2, b3);
+}
+// erlamsa_rnd:rand/1 (erlamsa_rnd.erl:77): rand(0) = 0 without a draw
+EH_DEV uint32_t rng_rand(Rng& r, uint32_t n) {
+  if (n == 0) return 0;
+  double x = rng_uniform(r) * (double)n;
+  return uni((uint32_t)x);
+}
+EH_DEV uint64_t rng_rand64(Rng& r, uint64_t n) {  // n < 2^53
+  if (n == 0) return 0;
+  double x = rng_uniform(r) * (double)n;
+  return uni64((uint64_t)x);
+}
+EH_DEV uint32_t rng_erand(Rng& r, uint32_t n) { return n == 0 ? 0 : rng_rand(r, n) + 1; }  // :82
+EH_DEV uint32_t rng_range(Rng& r, int64_t lo, int64_t hi) {                                  // :87-92
+  if (hi > lo) return rng_rand(r, (uint32_t)(hi - lo)) + (uint32_t)lo;
+  if (hi == lo) return (uint32_t)lo;
+  return 0;
+}
+EH_DEV int rng_bit(Rng& r) { return uni(rng_uniform(r) >= 0.5 ? 1u : 0u); }                   // :105 round/1
+EH_DEV int rng_delta(Rng& r) { return rng_bit(r) == 0 ? 1 : -1; }                             // :224-231
+EH_DEV bool rng_occurs(Rng& r, uint32_t nom, uint32_t den) {                                  // :123-130
+  uint32_t n = rng_rand(r, den);
+  return nom == 1 ? (n != 0) : (n < nom);
+}
+// rand_log(n) for n <= 32 (values < 2^31): rand_nbit(rand(n))  :134-143
+EH_DEV uint32_t rng_log(Rng& r, uint32_t n) {
+  if (n == 0) return 0;
+  uint32_t k = rng_rand(r, n);
+  if (k == 0) return 0;
+  uint32_t hi = 1u << (k - 1);
+  return hi | rng_rand(r, hi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-parallel byte movers (generic pointers: HBM arena or slot work memory)
+// ---------------------------------------------------------------------------------------------
+EH_DEV void wave_copy(uint8_t* dst, const uint8_t* src, uint32_t n) {
+  const int l = EH_LANE;
+  // head: bring dst to 16-byte alignment
+  uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+  if (head > n) head = n;
+  if ((uint32_t)l < head) dst[l] = src[l];
+  dst += head; src += head; n -= head;
+  uint32_t nv = n >> 4;
+  for (uint32_t i = l; i < nv; i += 64) {
+    uint4 v;
+    __builtin_memcpy(&v, src + 16 * (size_t)i, 16);  // unaligned dwordx4 load
+    *reinterpret_cast<uint4*>(dst + 16 * (size_t)i) = v;
+  }
+  uint32_t done = nv << 4;
+  if (done + l < n) dst[done + l] = src[done + l];
+}
+// dst[i] = pat[i % plen], i < total
+EH_DEV void wave_fill_periodic(uint8_t* dst, const uint8_t* pat, uint32_t plen, uint64_t total) {
+  const int l = EH_LANE;
+  if (plen == 1) {
+    uint8_t b = pat[0];
+    for (uint64_t i = l; i < total; i += 64) dst[i] = b;
+    return;
+  }
+  if (plen >= 256) {  // long pattern: copy it repeatedly with the vector mover
+    uint64_t reps = total / plen;
+    for (uint64_t r = 0; r < reps; r++) wave_copy(dst + r * plen, pat, plen);
+    return;
+  }
+  uint32_t ph = (uint32_t)l % plen, step = 64u % plen;
+  for (uint64_t i = l; i < total; i += 64) { dst[i] = pat[ph]; ph += step; if (ph >= plen) ph -= plen; }
+}
+// returns true if the two byte ranges are equal
+EH_DEV bool wave_equal(const uint8_t* a, const uint8_t* b, uint32_t n) {
+  const int l = EH_LANE;
+  bool ne = false;
+  uint32_t nv = n >> 4;
+  for (uint32_t i = l; i < nv; i += 64) {
+    uint4 x, y;
+    __builtin_memcpy(&x, a + 16 * (size_t)i, 16);
+    __builtin_memcpy(&y, b + 16 * (size_t)i, 16);
+    ne |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+  }
+  uint32_t done = nv << 4;
+  if (done + l < n) ne |= a[done + l] != b[done + l];
+  return __ballot(ne) == 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-case context (all wave-uniform)
+// ---------------------------------------------------------------------------------------------
+struct Ctx {
+  Rng rng;
+  const KParams* p;
+  // block list: bl[cur..nb) is the list handed to the mutator; bl[0..cur) already emitted
+  Blk* bl;
+  Blk* bl2;
+  int nb, cur;
+  Blk* em;
+  int nem;
+  // linear work allocator
+  uint8_t* ws;
+  uint64_t ws_used, ws_cap;
+  int status;
+  int lastm;
+  // mutator result (candidate new head of the list)
+  int r_kind;          // R_SAME: list unchanged ; R_NEW: r_ptr/r_len replace bl[cur]
+  uint8_t* r_ptr;
+  uint32_t r_len;
+  int r_flush;         // result goes through flush_bvecs/2
+  int r_drop_next;     // fn consumed the following block
+  // per-lane mux_fuzzers entry (lane i = list position i)
+  uint32_t e_pri;
+  uint32_t e_meta;     // score | fn<<8 | name<<16 | mask<<24
+  int nfs;
+};
+enum { R_SAME = 0, R_NEW = 1 };
+
+EH_DEV uint8_t* ws_alloc(Ctx& c, uint64_t n) {
+  uint64_t need = (n + 15) & ~(uint64_t)15;
+  if (c.ws_used + need > c.ws_cap) { c.status = CASE_OVERFLOW; return nullptr; }
+  uint8_t* p = c.ws + c.ws_used;
+  c.ws_used += need;
+  return p;
+}
+EH_DEV Blk blk_load(const Blk* t, int i) {
+  Blk b = t[i];
+  b.ptr = uni64(b.ptr); b.len = uni(b.len); b.aux = 0;
+  return b;
+}
+EH_DEV void blk_store(Blk* t, int i, uint64_t ptr, uint32_t len) {
+  if (EH_LANE == 0) { t[i].ptr = ptr; t[i].len = len; t[i].aux = 0; }
+}
+
+// random_block/1 (erlamsa_rnd.erl:165,173-174) / random_numbers(256, N) (:178-183): N draws of
+// rand(256), list built by prepending => draw j (0-based) lands at byte N-1-j.  Lane-parallel.
+EH_DEV void random_block_rev(Ctx& c, uint8_t* dst, uint32_t n) {
+  const int l = EH_LANE;
+  for (uint32_t base = 0; base < n; base += 64) {
+    uint32_t chunk = n - base < 64 ? n - base : 64;
+    if ((uint32_t)l < chunk) {
+      double u = rng_peek(c.rng, (uint32_t)l + 1);
+      dst[n - 1 - (base + l)] = (uint8_t)(uint32_t)(u * 256.0);
+    }
+    rng_skip(c.rng, chunk);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-byte mutators  (erlamsa_mutations.erl:56-61,176-223) and UTF-8 (:1081-1099)
+// ---------------------------------------------------------------------------------------------
+EH_DEV int muta_byte(Ctx& c, int fn) {
+  Blk h = blk_load(c.bl, c.cur);
+  const uint8_t* src = (const uint8_t*)h.ptr;
+  uint32_t L = h.len;
+  uint32_t p = rng_rand(c.rng, L);
+  int d = rng_delta(c.rng);
+  uint32_t ins_idx = 0;
+  if (fn == M_UI) ins_idx = rng_rand(c.rng, (uint32_t)c_nfunny);  // rand_elem(funny_unicode()) is drawn even for <<>>
+  c.r_kind = R_SAME;
+  if (L == 0) return d;  // edit_byte_vector(<<>>, _, _) -> <<>>
+  uint32_t b = uni(src[p]);
+  uint32_t nb0 = 0, nb1 = 0;  // replacement bytes
+  uint32_t repl = 1;          // number of bytes that replace byte p
+  switch (fn) {
+    case M_BD: repl = 0; break;
+    case M_BEI: nb0 = (b + 1) & 255; break;
+    case M_BED: nb0 = (b - 1) & 255; break;
+    case M_BR: nb0 = b; nb1 = b; repl = 2; break;
+    case M_BF: nb0 = b ^ (1u << rng_rand(c.rng, 8)); break;
+    case M_BI: nb0 = rng_rand(c.rng, 256); nb1 = b; repl = 2; break;
+    case M_BER: nb0 = rng_rand(c.rng, 256); break;
+    case M_UW:
+      if (b == (b & 0x3f)) { nb0 = 0xC0; nb1 = b | 0x80; repl = 2; } else return d;  // unchanged
+      break;
+    case M_UI: break;
+  }
+  if (fn == M_UI) {
+    uint32_t il = c_funny[ins_idx][0];
+    uint8_t* dst = ws_alloc(c, (uint64_t)L + il);
+    if (!dst) return d;
+    wave_copy(dst, src, p + 1);
+    if ((uint32_t)EH_LANE < il) dst[p + 1 + EH_LANE] = c_funny[ins_idx][1 + EH_LANE];
+    wave_copy(dst + p + 1 + il, src + p + 1, L - p - 1);
+    c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = L + il;
+    return d;
+  }
+  if (repl == 1 && nb0 == b) return d;  // same byte value: hd(Mll) == hd(Ll)
+  uint32_t nl = L - 1 + repl;
+  uint8_t* dst = ws_alloc(c, nl);
+  if (!dst) return d;
+  wave_copy(dst, src, p);
+  if (EH_LANE == 0) { if (repl >= 1) dst[p] = (uint8_t)nb0; if (repl == 2) dst[p + 1] = (uint8_t)nb1; }
+  wave_copy(dst + p + repl, src + p + 1, L - p - 1);
+  c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = nl;
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-wide bitonic sort of n_pow2 (hi,lo) 128-bit keys, ascending by hi then lo.  Padding
+// entries carry hi = ~0.
+// ---------------------------------------------------------------------------------------------
+struct Key2 { uint64_t hi, lo; };
+EH_DEV void wave_sort_key2(Key2* k, uint32_t n_pow2) {
+  const int l = EH_LANE;
+  for (uint32_t size = 2; size <= n_pow2; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      wave_sync();
+      for (uint32_t t = l; t < (n_pow2 >> 1); t += 64) {
+        uint32_t i = 2 * t - (t & (stride - 1));  // lower index of the pair
+        uint32_t j = i + stride;
+        bool up = ((i & size) == 0);
+        Key2 a = k[i], b = k[j];
+        bool gt = a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo);
+        if (gt == up) { k[i] = b; k[j] = a; }
+      }
+    }
+  }
+  wave_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-byte mutators (erlamsa_mutations.erl:232-318)
+// ---------------------------------------------------------------------------------------------
+EH_DEV int muta_seq(Ctx& c, int fn, int mask_fun) {
+  Blk hb = blk_load(c.bl, c.cur);
+  const uint8_t* src = (const uint8_t*)hb.ptr;
+  uint32_t B = hb.len;
+  c.r_kind = R_SAME;
+  if (B == 0) return -1;                                   // Self([<<>>|BTail], Meta)
+  uint32_t S = rng_rand(c.rng, B);
+  uint32_t Lp = rng_range(c.rng, 1, (int64_t)B - S + 1);
+  const uint8_t* P = src + S;
+  uint32_t tl = B - S - Lp;
+  const int l = EH_LANE;
+  switch (fn) {
+    case M_SD: {                                           // :273-276
+      uint8_t* dst = ws_alloc(c, B - Lp);
+      if (dst) { wave_copy(dst, src, S); wave_copy(dst + S, P + Lp, tl); c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = B - Lp; }
+      break;
+    }
+    case M_SR: {                                           // :263-270
+      uint32_t n = rng_log(c.rng, 10); if (n < 2) n = 2;
+      uint64_t nl = (uint64_t)S + (uint64_t)Lp * n + tl;
+      uint8_t* dst = nl > 0xFFFFFFFFull ? (c.status = CASE_OVERFLOW, nullptr) : ws_alloc(c, nl);
+      if (dst) {
+        wave_copy(dst, src, S);
+        wave_fill_periodic(dst + S, P, Lp, (uint64_t)Lp * n);
+        wave_copy(dst + S + (uint64_t)Lp * n, P + Lp, tl);
+        c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)nl;
+      }
+      break;
+    }
+    case M_SP: {                                           // :253-260 + random_permutation erlamsa_rnd.erl:190-196
+      uint8_t* dst = ws_alloc(c, B);
+      if (!dst) break;
+      wave_copy(dst, src, S);
+      wave_copy(dst + S + Lp, P + Lp, tl);
+      if (Lp == 2) {
+        uint32_t sw = rng_rand(c.rng, 2);
+        if (l == 0) { dst[S] = sw == 1 ? P[1] : P[0]; dst[S + 1] = sw == 1 ? P[0] : P[1]; }
+      } else {
+        // keys {uniform(), X}: lists:sort/1 ascending by float, ties by byte.  IEEE bits of a
+        // non-negative double order like the value.
+        uint32_t np2 = 1; while (np2 < Lp) np2 <<= 1;
+        uint64_t mark = c.ws_used;
+        Key2* keys = (Key2*)ws_alloc(c, (uint64_t)np2 * sizeof(Key2));
+        if (!keys) break;
+        for (uint32_t base = 0; base < np2; base += 64) {
+          uint32_t idx = base + l;
+          if (idx < Lp) {
+            double u = rng_peek(c.rng, (uint32_t)l + 1);
+            keys[idx].hi = (uint64_t)__double_as_longlong(u); keys[idx].lo = P[idx];
+          } else if (idx < np2) { keys[idx].hi = ~(uint64_t)0; keys[idx].lo = 0; }
+          if (base < Lp) rng_skip(c.rng, Lp - base < 64 ? Lp - base : 64);
+        }
+        wave_sort_key2(keys, np2);
+        for (uint32_t i = l; i < Lp; i += 64) dst[S + i] = (uint8_t)keys[i].lo;
+        wave_sync();
+        c.ws_used = mark;  // release the key array (dst was allocated before it)
+      }
+      c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = B;
+      break;
+    }
+    case M_SNAND:
+    case M_SRND: {                                         // randmask :281-307 — sequential draw chain
+      uint8_t* dst = ws_alloc(c, B);
+      if (!dst) break;
+      wave_copy(dst, src, S);
+      wave_copy(dst + S + Lp, P + Lp, tl);
+      uint32_t prob = rng_erand(c.rng, 100);
+      bool occ = rng_occurs(c.rng, prob, 100);
+      for (uint32_t base = 0; base < Lp; base += 64) {
+        uint32_t chunk = Lp - base < 64 ? Lp - base : 64;
+        uint32_t mine = (uint32_t)l < chunk ? P[base + l] : 0;
+        for (uint32_t j = 0; j < chunk; j++) {
+          bool next = rng_occurs(c.rng, prob, 100);        // drawn before MaskFun(H) (argument order)
+          if (occ) {
+            uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)j);
+            uint32_t nbv;
+            if (mask_fun == 3) nbv = rng_rand(c.rng, 256);
+            else {
+              uint32_t m = 1u << rng_rand(c.rng, 8);
+              nbv = mask_fun == 0 ? (b & ~m) : (mask_fun == 1 ? (b | m) : (b ^ m));
+            }
+            if ((uint32_t)l == j) mine = nbv & 255;
+          }
+          occ = next;
+        }
+        if ((uint32_t)l < chunk) dst[S + base + l] = (uint8_t)mine;
+      }
+      c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = B;
+      break;
+    }
+  }
+  wave_sync();
+  return rng_delta(c.rng);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scheduler: weighted_permutations + mux_fuzzers_loop  (erlamsa_mutations.erl:1244-1280)
+// ---------------------------------------------------------------------------------------------
+EH_DEV uint32_t em_score(uint32_t m) { return m & 0xFF; }
+EH_DEV uint32_t em_fn(uint32_t m) { return (m >> 8) & 0xFF; }
+EH_DEV uint32_t em_name(uint32_t m) { return (m >> 16) & 0xFF; }
+EH_DEV uint32_t em_mask(uint32_t m) { return (m >> 24) & 0xFF; }
+EH_DEV uint32_t em_pack(uint32_t score, uint32_t fn, uint32_t name, uint32_t mask) { return score | (fn << 8) | (name << 16) | (mask << 24); }
+
+EH_DEV int run_mutator(Ctx& c, uint32_t fn, uint32_t mask) {
+  switch (fn) {
+    case M_BD: case M_BEI: case M_BED: case M_BF: case M_BI: case M_BER: case M_BR: case M_UW: case M_UI:
+      return muta_byte(c, (int)fn);
+    case M_SP: case M_SR: case M_SD: case M_SNAND: case M_SRND:
+      return muta_seq(c, (int)fn, (int)mask);
+    case M_NIL: c.r_kind = R_SAME; return -1;               // nomutation :1104-1105
+    default: c.status = CASE_UNSUPPORTED; c.r_kind = R_SAME; return 0;
+  }
+}
+
+// Applies the candidate to the block list: bl[cur] is replaced (possibly by several flush_bvecs
+// chunks) and, for fn, bl[cur+1] is dropped.
+EH_DEV void commit_result(Ctx& c) {
+  uint32_t chunks = 1;
+  if (c.r_flush) chunks = c.r_len / AVG_BLOCK_SIZE + 1;     // flush_bvecs: k full blocks + remainder (may be <<>>)
+  int drop = 1 + (c.r_drop_next && c.cur + 1 < c.nb ? 1 : 0);
+  int tail = c.nb - c.cur - drop;
+  int newnb = c.cur + (int)chunks + tail;
+  if (newnb > MAX_BLOCKS) { c.status = CASE_OVERFLOW; return; }
+  if (chunks != (uint32_t)drop) {                           // move the tail
+    const int l = EH_LANE;
+    for (int i = l; i < tail; i += 64) c.bl2[i] = c.bl[c.cur + drop + i];
+    wave_sync();
+    for (int i = l; i < tail; i += 64) c.bl[c.cur + (int)chunks + i] = c.bl2[i];
+  }
+  for (uint32_t k = EH_LANE; k < chunks; k += 64) {
+    uint64_t off = (uint64_t)k * AVG_BLOCK_SIZE;
+    uint32_t len = c.r_flush ? (k + 1 < chunks ? AVG_BLOCK_SIZE : c.r_len - (uint32_t)off) : c.r_len;
+    c.bl[c.cur + k].ptr = (uint64_t)(c.r_ptr + off); c.bl[c.cur + k].len = len; c.bl[c.cur + k].aux = 0;
+  }
+  c.nb = newnb;
+  wave_sync();
+}
+
+// One call of the mux_fuzzers closure on the list bl[cur..nb).
+EH_DEV void mux_fuzzers(Ctx& c) {
+  const int l = EH_LANE;
+  if (c.nb - c.cur == 1 && blk_load(c.bl, c.cur).len == 0) return;   // L([<<>>], Meta)
+  if (c.nb - c.cur <= 0) { c.status = CASE_CRASHED; return; }
+  const int nfs = c.nfs;
+  // --- weighted_permutations: key_i = rand(trunc(Score*Pri)) in list order, lane-parallel jump-ahead
+  uint32_t nkey = (l < nfs) ? em_score(c.e_meta) * c.e_pri : 0;
+  unsigned long long drawing = __ballot(nkey > 0);
+  uint32_t my_idx = (uint32_t)__popcll(drawing & ((1ull << l) - 1));
+  uint32_t ndraw = (uint32_t)__popcll(drawing);
+  uint32_t key = 0;
+  if (nkey > 0) key = (uint32_t)(rng_peek(c.rng, my_idx + 1) * (double)nkey);
+  rng_skip(c.rng, ndraw);
+  // --- stable descending sort => rank per lane
+  uint32_t rank = 0;
+  for (int j = 0; j < nfs; j++) {
+    uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
+    rank += (kj > key || (kj == key && j < l)) ? 1u : 0u;
+  }
+  // --- mux_fuzzers_loop
+  int tried = 0; bool used = false; bool dropped = false;
+  Blk h0 = blk_load(c.bl, c.cur);
+  for (int r = 0; r < nfs; r++) {
+    if (h0.len > ABSMAX_BINARY_BLOCK) { dropped = true; break; }                 // :1269-1270
+    unsigned long long who = __ballot(l < nfs && rank == (uint32_t)r);
+    int j = (int)__builtin_ctzll(who);
+    uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)c.e_meta, j);
+    uint32_t fn = em_fn(meta), name = em_name(meta);
+    c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0;
+    uint64_t mark = c.ws_used;
+    int delta = run_mutator(c, fn, em_mask(meta));
+    if (c.status != CASE_OK) return;
+    // adjust_priority :1238-1242
+    uint32_t sc = em_score(meta);
+    if (delta != 0) { int ns = (int)sc + delta; ns = ns < 2 ? 2 : (ns > 10 ? 10 : ns); sc = (uint32_t)ns; }
+    uint32_t nfn = (fn == M_URI) ? (uint32_t)M_B64 : fn;                          // :784 (sic)
+    if (l == j) c.e_meta = em_pack(sc, nfn, name, em_mask(meta));
+    tried++;
+    bool changed = false;
+    if (c.r_kind == R_NEW) {
+      uint32_t hd_len = c.r_flush && c.r_len >= AVG_BLOCK_SIZE ? AVG_BLOCK_SIZE : c.r_len;
+      changed = hd_len != h0.len || !wave_equal(c.r_ptr, (const uint8_t*)h0.ptr, hd_len);
+    }
+    if (changed) { c.lastm = (int)name; commit_result(c); used = true; break; }
+    c.ws_used = mark;                                                             // discard candidate
+  }
+  // --- new list: reverse(tried) ++ untried (sorted order)   :1268,1270,1279
+  // dropped (:1270): the entry at sorted position `tried` leaves the list.
+  (void)used;
+  int newpos = l;
+  if (l < nfs) {
+    int rk = (int)rank;
+    if (rk < tried) newpos = tried - 1 - rk;
+    else if (!dropped) newpos = rk;
+    else newpos = rk == tried ? nfs - 1 : rk - 1;
+  }
+  // ds_permute (forward): lane i sends its value to lane newpos (a bijection)
+  c.e_meta = (uint32_t)__builtin_amdgcn_ds_permute(newpos << 2, (int)c.e_meta);
+  c.e_pri = (uint32_t)__builtin_amdgcn_ds_permute(newpos << 2, (int)c.e_pri);
+  if (dropped) c.nfs = nfs - 1;
+}
+
+}  // namespace eh

@@ -1,0 +1,781 @@
+// eh_engine.hip — kernels + C ABI of liberlamsa_hip.so (see include/erlamsa_hip.h).
+//
+// Kernels (gfx950 only):
+//   eh_setup_kernel   : per-run setup of erlamsa_main:fuzzer/1 (one wavefront)
+//   eh_mutate_kernel  : persistent grid, one wavefront per case, cases pulled from a ticket
+//                       counter; runs generator -> pattern -> mux_fuzzers -> mutators and
+//                       writes each case's output into a bump-allocated arena.
+//
+// Reference call path restated here (src/ of the reference):
+//   erlamsa_main.erl:125-247  fuzzer/1 (setup draw order, per-case ThreadSeed, worker body)
+//   erlamsa_gen.erl:43-56,152-199  finish/1, direct_generator/2, random_stream/1, mux_generators/2
+//   erlamsa_patterns.erl:45-60,146-161,265-442  split, skipper, mutate_once(_loop), od/nd/bu/co/nu, mux_patterns
+//   erlamsa_mutations.erl  (see eh_device.h)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/erlamsa_hip.h"
+#include "eh_device.h"
+
+namespace eh {
+
+// =============================================================================================
+// device: per-run setup  (erlamsa_main.erl:134-158)
+// =============================================================================================
+EH_DEV void setup_run(const DevConfig& cfg, int64_t s1, int64_t s2, int64_t s3, Rng& rng, int& gen, int& snand_mask,
+                      uint32_t& e_pri, uint32_t& e_meta, int& nfs) {
+  const int l = EH_LANE;
+  rng.draws = 0;
+  rng_seed(rng, s1, s2, s3);                                   // erlamsa_rnd:seed/1 :134
+  // mutations/1 evaluates construct_sed_bytes_randmask twice: rand_elem over 3, then over 1 funs
+  snand_mask = (int)rng_rand(rng, 3);                          // erlamsa_mutations.erl:311-312,1313
+  (void)rng_rand(rng, 1);                                      // :1314
+  // make_mutator (:1370-1383): Mutas = selected entries in REVERSE table order;
+  // mutators_mutator (:1391-1395) draws rand(10) along that list and prepends => list in table order.
+  nfs = cfg.nsel;
+  uint32_t score = 0;
+  if (l < nfs) {
+    double u = rng_peek(rng, (uint32_t)(nfs - 1 - l) + 1);
+    uint32_t n = (uint32_t)(u * 10.0);
+    score = n < 2 ? 2 : n;
+  }
+  rng_skip(rng, (uint64_t)nfs);
+  uint32_t name = l < nfs ? cfg.sel_name[l] : 0;
+  e_pri = l < nfs ? cfg.sel_pri[l] : 0;
+  uint32_t mask = name == M_SNAND ? (uint32_t)snand_mask : 3u;
+  e_meta = em_pack(score, name, name, mask);
+  // mux_generators (erlamsa_gen.erl:194-199): rand(N) over the priority-sorted list
+  uint32_t g = rng_rand(rng, (uint32_t)cfg.gen_total);
+  gen = cfg.gen_id[cfg.ngen - 1];
+  for (int i = 0; i < cfg.ngen; i++) {                         // choose_pri erlamsa_utils.erl:155-161
+    if (g == 0 || g < cfg.gen_pri[i]) { gen = cfg.gen_id[i]; break; }
+    g -= cfg.gen_pri[i];
+  }
+}
+
+__global__ void __launch_bounds__(64) eh_setup_kernel(DevConfig cfg, int64_t s1, int64_t s2, int64_t s3, RunState* out) {
+  Rng rng; int gen, mask, nfs; uint32_t e_pri, e_meta;
+  setup_run(cfg, s1, s2, s3, rng, gen, mask, e_pri, e_meta, nfs);
+  const int l = EH_LANE;
+  if (l == 0) { out->a1 = rng.a1; out->a2 = rng.a2; out->a3 = rng.a3; out->gen = gen; out->nfs = nfs; out->snand_mask = mask; }
+  if (l < nfs) { out->fs_name[l] = (uint8_t)em_name(e_meta); out->fs_score[l] = (uint8_t)em_score(e_meta); out->fs_pri[l] = e_pri; }
+}
+
+// =============================================================================================
+// device: emit list, split, patterns
+// =============================================================================================
+EH_DEV void emit_ref(Ctx& c, uint64_t ptr, uint32_t len) {
+  if (len == 0) return;
+  if (c.nem >= MAX_EMITS) { c.status = CASE_OVERFLOW; return; }
+  blk_store(c.em, c.nem, ptr, len);
+  c.nem++;
+}
+EH_DEV void emit_all(Ctx& c) {
+  for (int i = c.cur; i < c.nb; i++) { Blk b = blk_load(c.bl, i); emit_ref(c, b.ptr, b.len); }
+  c.cur = c.nb;
+}
+// split/1 + split_into_maxblocks/2 (erlamsa_patterns.erl:45-60) on the head of bl[cur..nb)
+EH_DEV void split_head(Ctx& c) {
+  if (c.cur >= c.nb) return;
+  Blk h = blk_load(c.bl, c.cur);
+  if (h.len <= ABSMAX_BINARY_BLOCK) return;
+  // rare path: lane-uniform rebuild through bl2
+  int tail = c.nb - c.cur - 1;
+  for (int i = EH_LANE; i < tail; i += 64) c.bl2[i] = c.bl[c.cur + 1 + i];
+  wave_sync();
+  int k = c.cur; uint64_t ptr = h.ptr; uint32_t rem = h.len;
+  while (rem > ABSMAX_BINARY_BLOCK) {
+    uint32_t as = ABSMAXHALF_BINARY_BLOCK + rng_rand(c.rng, ABSMAXHALF_BINARY_BLOCK) - 1;
+    if (k + 1 + tail >= MAX_BLOCKS) { c.status = CASE_OVERFLOW; return; }
+    blk_store(c.bl, k++, ptr, as); ptr += as; rem -= as;
+  }
+  blk_store(c.bl, k++, ptr, rem);
+  if (k + tail > MAX_BLOCKS) { c.status = CASE_OVERFLOW; return; }
+  wave_sync();
+  for (int i = EH_LANE; i < tail; i += 64) c.bl[k + i] = c.bl2[i];
+  c.nb = k + tail;
+  wave_sync();
+}
+
+enum Act { A_RUN_PAT, A_MUTATE_ONCE, A_LOOP, A_CONT, A_TERMINAL, A_DONE };
+enum ContKind { C_EMIT, C_ND, C_BU, C_PAT };
+
+EH_DEV void run_patterns(Ctx& c, int pat) {
+  int act = A_RUN_PAT, cont = C_EMIT, contpat = 0; uint32_t ip = 0;
+  int guard = 0;
+  while (act != A_DONE && c.status == CASE_OK) {
+    if (++guard > 1000000) { c.status = CASE_OVERFLOW; break; }
+    switch (act) {
+      case A_RUN_PAT:
+        switch (pat) {
+          case P_OD: cont = C_EMIT; act = A_MUTATE_ONCE; break;                       // :306-309
+          case P_ND: cont = C_ND; act = A_MUTATE_ONCE; break;                         // :323-326
+          case P_BU: cont = C_BU; act = A_MUTATE_ONCE; break;                         // :346-349
+          case P_CO: pat = rng_erand(c.rng, 2) == 1 ? P_NU : P_OD; break;             // :378-384
+          case P_NU: split_head(c); emit_all(c); act = A_TERMINAL; break;             // :386-390
+          case P_SK: {                                                                // make_complex_pat :351-357 + skipper :146-161
+            contpat = (int)rng_rand(c.rng, P_COUNT);                                  // rand_elem(patterns())
+            cont = C_PAT;
+            ip = rng_rand(c.rng, INITIAL_IP);
+            if (c.cur >= c.nb) { c.status = CASE_CRASHED; break; }                    // size(false)
+            Blk b = blk_load(c.bl, c.cur);
+            uint32_t len = rng_rand(c.rng, b.len / 2);
+            emit_ref(c, b.ptr, len);
+            blk_store(c.bl, c.cur, b.ptr + len, b.len - len);
+            wave_sync();
+            split_head(c);
+            act = A_LOOP;
+            break;
+          }
+          default: c.status = CASE_UNSUPPORTED; break;
+        }
+        break;
+      case A_MUTATE_ONCE:                                                             // mutate_once/4 :265-278
+        if (c.nb - c.cur == 1 && blk_load(c.bl, c.cur).len == 0) { c.cur = c.nb; act = A_TERMINAL; break; }
+        ip = rng_rand(c.rng, INITIAL_IP);
+        if (c.cur >= c.nb) { act = A_CONT; break; }                                   // Cont([], ...)
+        split_head(c);
+        act = A_LOOP;
+        break;
+      case A_LOOP: {                                                                  // mutate_once_loop/6 :281-296
+        uint32_t n = rng_rand(c.rng, ip);
+        if (n == 0 || c.nb - c.cur == 1) { mux_fuzzers(c); act = A_CONT; }
+        else { Blk b = blk_load(c.bl, c.cur); emit_ref(c, b.ptr, b.len); c.cur++; }
+        break;
+      }
+      case A_CONT:
+        switch (cont) {
+          case C_EMIT: emit_all(c); act = A_TERMINAL; break;
+          case C_ND:                                                                  // pat_many_dec_cont :313-321
+            if (rng_occurs(c.rng, 4, 5)) act = A_MUTATE_ONCE; else { emit_all(c); act = A_TERMINAL; }
+            break;
+          case C_BU: {                                                                // pat_burst_cont :331-344
+            int n = 1;
+            while (c.status == CASE_OK) {
+              bool p = rng_occurs(c.rng, 4, 5);
+              if (p || n < 2) { mux_fuzzers(c); n++; } else { emit_all(c); act = A_TERMINAL; break; }
+              if (++guard > 1000000) { c.status = CASE_OVERFLOW; break; }
+            }
+            break;
+          }
+          case C_PAT: pat = contpat; act = A_RUN_PAT; break;
+        }
+        break;
+      case A_TERMINAL: act = A_DONE; break;
+    }
+  }
+}
+
+// =============================================================================================
+// device: generators
+// =============================================================================================
+EH_DEV void gen_direct(Ctx& c, const uint8_t* in, uint32_t L) {       // erlamsa_gen.erl:152-164 (split_binary guard never holds)
+  const DevConfig& cfg = c.p->cfg;
+  (void)rng_rand(c.rng, cfg.max_block_scaled);                         // rand_block_size :55-56
+  blk_store(c.bl, 0, (uint64_t)in, L);
+  c.nb = 1;
+  uint32_t n = rng_rand(c.rng, L + 1);                                 // finish/1 :43-51
+  if (n == L) {
+    uint32_t bits = rng_range(c.rng, 1, 16);
+    uint32_t nlen = rng_rand(c.rng, 1u << bits);
+    if (nlen > 0) {                                                    // check_empty
+      uint8_t* dst = ws_alloc(c, nlen);
+      if (!dst) return;
+      random_block_rev(c, dst, nlen);
+      blk_store(c.bl, 1, (uint64_t)dst, nlen);
+      c.nb = 2;
+    }
+  }
+  wave_sync();
+}
+EH_DEV void gen_random(Ctx& c) {                                       // random_stream/1 :167-178
+  const DevConfig& cfg = c.p->cfg;
+  c.nb = 0;
+  while (c.status == CASE_OK) {
+    uint32_t n = rng_range(c.rng, 32, cfg.max_block_scaled);
+    uint8_t* dst = ws_alloc(c, n);
+    if (!dst) return;
+    random_block_rev(c, dst, n);
+    if (c.nb >= MAX_BLOCKS) { c.status = CASE_OVERFLOW; return; }
+    blk_store(c.bl, c.nb++, (uint64_t)dst, n);
+    uint32_t ip = rng_range(c.rng, 1, 100);
+    if (rng_rand(c.rng, ip) == 0) break;
+  }
+  wave_sync();
+}
+
+// =============================================================================================
+// the mutate kernel
+// =============================================================================================
+__global__ void __launch_bounds__(64) eh_mutate_kernel(KParams p) {
+  const int l = EH_LANE;
+  Ctx c;
+  c.p = &p;
+  uint8_t* slot = p.slot_base + (uint64_t)blockIdx.x * p.slot_stride;
+  c.bl = (Blk*)slot;
+  c.bl2 = c.bl + MAX_BLOCKS;
+  c.em = c.bl2 + MAX_BLOCKS;
+  c.ws = (uint8_t*)(c.em + MAX_EMITS);
+  c.ws_cap = p.work_cap;
+
+  // mode 0: the run state is shared by all cases
+  Rng parent; int gen0 = 0; uint32_t pri0 = 0, meta0 = 0; int nfs0 = 0;
+  if (p.mode == 0) {
+    const RunState* rs = p.run;
+    parent.a1 = rs->a1; parent.a2 = rs->a2; parent.a3 = rs->a3; parent.draws = 0;
+    gen0 = rs->gen; nfs0 = rs->nfs;
+    if (l < nfs0) {
+      uint32_t name = rs->fs_name[l];
+      pri0 = rs->fs_pri[l];
+      meta0 = em_pack(rs->fs_score[l], name, name, name == M_SNAND ? (uint32_t)rs->snand_mask : 3u);
+    }
+  }
+
+  while (true) {
+    unsigned long long t = 0;
+    if (l == 0) t = atomicAdd(p.ticket, 1ull);
+    uint64_t i = uni64(t);
+    if (i >= p.n) break;
+
+    c.status = CASE_OK; c.lastm = -1; c.nb = 0; c.cur = 0; c.nem = 0; c.ws_used = 0;
+    c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0;
+    int gen;
+    Rng pr;
+    if (p.mode == 0) {
+      // ThreadSeed of case I = parent draws 3(I-1)+1..3(I-1)+3   (erlamsa_main.erl:179, erlamsa_rnd.erl:65)
+      pr = parent;
+      rng_skip(pr, 3 * (p.first_case + i - 1));
+      gen = gen0; c.e_pri = pri0; c.e_meta = meta0; c.nfs = nfs0;
+    } else {
+      int mask;
+      setup_run(p.cfg, p.seeds[3 * i], p.seeds[3 * i + 1], p.seeds[3 * i + 2], pr, gen, mask, c.e_pri, c.e_meta, c.nfs);
+    }
+    int64_t t1 = (int64_t)rng_erand(pr, 99999), t2 = (int64_t)rng_erand(pr, 99999), t3 = (int64_t)rng_erand(pr, 99999);
+    c.rng.draws = 0;
+    rng_seed(c.rng, t1, t2, t3);                                        // worker: erlamsa_rnd:seed(ThreadSeed) :183
+
+    uint64_t o0 = p.coff[p.corpus_first + i], o1 = p.coff[p.corpus_first + i + 1];
+    o0 = uni64(o0); o1 = uni64(o1);
+    if (gen == G_DIRECT) gen_direct(c, p.corpus + o0, (uint32_t)(o1 - o0)); else gen_random(c);   // DataGen() :185
+
+    if (c.status == CASE_OK) {
+      // choose_pattern_fun (erlamsa_patterns.erl:431-434) + choose_pri
+      uint32_t r = rng_rand(c.rng, (uint32_t)p.cfg.pat_total);
+      int pat = p.cfg.npat > 0 ? p.cfg.pat_id[p.cfg.npat - 1] : -1;
+      for (int k = 0; k < p.cfg.npat; k++) {
+        if (r == 0 || r < p.cfg.pat_pri[k]) { pat = p.cfg.pat_id[k]; break; }
+        r -= p.cfg.pat_pri[k];
+      }
+      if (pat < 0) c.status = CASE_CRASHED; else run_patterns(c, pat);  // Pat(Ll, CurMuta, Meta) :189
+    }
+
+    // ---- erlamsa_out:output/4: concatenate the written blocks into the output arena
+    uint64_t total = 0;
+    if (c.status == CASE_OK) for (int k = 0; k < c.nem; k++) total += blk_load(c.em, k).len;
+    else total = 0;
+    unsigned long long base = 0;
+    if (total > 0) {
+      if (l == 0) base = atomicAdd(p.out_cursor, (unsigned long long)((total + 15) & ~15ull));
+      base = uni64(base);
+      if (base + total > p.out_cap) { c.status = CASE_OVERFLOW; total = 0; }
+    }
+    if (total > 0) {
+      uint64_t pos = base;
+      for (int k = 0; k < c.nem; k++) { Blk b = blk_load(c.em, k); wave_copy(p.out + pos, (const uint8_t*)b.ptr, b.len); pos += b.len; }
+    }
+    if (l == 0) {
+      p.out_off[i] = base; p.out_len[i] = total; p.status[i] = c.status;
+      p.draws[i] = c.rng.draws; p.lastm[i] = c.lastm;
+    }
+    wave_sync();
+  }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static const MutaInfo MUTAS[M_COUNT] = {
+    {"sgm", 10, 0}, {"js", 3, 0},  {"uw", 1, 1},   {"ui", 2, 1},  {"ab", 1, 0},  {"ad", 1, 0},  {"tr2", 1, 0}, {"td", 1, 0},
+    {"num", 3, 0},  {"ts1", 2, 0}, {"tr", 2, 0},   {"ts2", 2, 0}, {"bd", 1, 1},  {"bei", 1, 1}, {"bed", 1, 1}, {"bf", 1, 1},
+    {"bi", 1, 1},   {"ber", 1, 1}, {"br", 1, 1},   {"sp", 1, 1},  {"sr", 1, 1},  {"sd", 1, 1},  {"snand", 1, 1}, {"srnd", 1, 1},
+    {"ld", 1, 0},   {"lds", 1, 0}, {"lr2", 1, 0},  {"lri", 1, 0}, {"lr", 1, 0},  {"ls", 1, 0},  {"lp", 1, 0},  {"lis", 1, 0},
+    {"lrs", 1, 0},  {"ft", 2, 0},  {"fn", 1, 0},   {"fo", 2, 0},  {"len", 2, 0}, {"b64", 7, 0}, {"uri", 1, 0}, {"zip", 1, 0},
+    {"nil", 0, 1}};
+static const PatInfo PATS[P_COUNT] = {{"od", 1, 1}, {"nd", 2, 1}, {"bu", 1, 1}, {"sk", 2, 1}, {"sz", 2, 0},
+                                      {"cs", 1, 0}, {"ar", 1, 0}, {"cp", 1, 0}, {"co", 0, 1}, {"nu", 0, 1}};
+
+}  // namespace eh
+
+using namespace eh;
+
+struct eh_ctx {
+  int device = 0;
+  int cus = 0;
+  std::string err;
+  bool configured = false;
+  DevConfig cfg;
+  uint64_t max_case_bytes = 0, out_capacity_opt = 0;
+  uint32_t max_slots_opt = 0, flags = 0;
+  // corpus
+  uint8_t* d_corpus = nullptr; uint64_t* d_coff = nullptr; bool own_corpus = false;
+  uint64_t n_corpus = 0, corpus_bytes = 0;
+  std::vector<uint64_t> h_coff;  // host copy of offsets (for totals)
+  // slots
+  uint8_t* d_slots = nullptr; uint64_t slot_stride = 0, work_cap = 0; uint32_t nslots = 0;
+  // outputs
+  uint8_t* d_out = nullptr; uint64_t out_cap = 0;
+  uint64_t* d_off = nullptr; uint64_t* d_len = nullptr; int32_t* d_status = nullptr; uint64_t* d_draws = nullptr; int32_t* d_lastm = nullptr;
+  uint64_t res_cap = 0;
+  unsigned long long* d_counters = nullptr;  // [0] ticket, [1] out cursor
+  RunState* d_run = nullptr;
+  int64_t* d_seeds = nullptr; uint64_t seeds_cap = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t last_stream = nullptr;
+  uint64_t last_n = 0, last_in_bytes = 0;
+  bool have_result = false;
+};
+
+#define HIPCHK(ctx, call)                                                                             \
+  do {                                                                                                \
+    hipError_t e_ = (call);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                 \
+      return EH_E_HIP;                                                                                \
+    }                                                                                                 \
+  } while (0)
+
+namespace {
+
+// --- OTP lists:sort/2 (stdlib lists.erl fsplit_*/fmergel/rfmergel), needed because
+// erlamsa_utils:sort_by_priority/1 (erlamsa_utils.erl:113-117) passes a strict '>' as the
+// ordering fun, so the order of equal priorities is whatever that merge sort produces.
+struct PItem { uint32_t pri; int id; };
+typedef std::vector<PItem> PL;
+static bool gt(const PItem& a, const PItem& b) { return a.pri > b.pri; }
+static PL merge_runs(const PL& t1, const PL& l2, bool rmerge) {
+  // fmerge2_*: take from T1 while Fun(H1,H2); rfmerge2_*: take from [H2|T2] while Fun(H1,H2).
+  // Both accumulate in reverse, i.e. return reverse(merged).
+  PL m; size_t i = 0, j = 0;
+  while (i < t1.size() && j < l2.size()) {
+    bool f = gt(t1[i], l2[j]);
+    if (f != rmerge) m.push_back(t1[i++]); else m.push_back(l2[j++]);
+  }
+  while (i < t1.size()) m.push_back(t1[i++]);
+  while (j < l2.size()) m.push_back(l2[j++]);
+  return PL(m.rbegin(), m.rend());
+}
+static PL mergel(std::vector<PL> ls, bool rphase, bool asc) {
+  // alternating fmergel / rfmergel passes until one list remains
+  while (true) {
+    std::vector<PL> acc;
+    size_t k = 0;
+    for (; k + 1 < ls.size(); k += 2) {
+      // fmergel asc: (T1=ls[k], L2=ls[k+1]); fmergel desc: (T1=ls[k+1], L2=ls[k]);
+      // rfmergel asc: (T1=ls[k+1], L2=ls[k]); rfmergel desc: (T1=ls[k], L2=ls[k+1]).
+      bool first_is_t1 = (asc != rphase);
+      const PL& t1 = first_is_t1 ? ls[k] : ls[k + 1];
+      const PL& l2 = first_is_t1 ? ls[k + 1] : ls[k];
+      acc.insert(acc.begin(), merge_runs(t1, l2, rphase));
+    }
+    if (k < ls.size()) {
+      if (!rphase && acc.empty()) return ls[k];           // fmergel([L], [], ..) -> L
+      acc.insert(acc.begin(), PL(ls[k].rbegin(), ls[k].rend()));
+    }
+    ls.swap(acc);
+    rphase = !rphase;
+  }
+}
+static PL otp_sort_desc_strict(const PL& in) {
+  if (in.size() < 2) return in;
+  std::vector<PL> rs;
+  PItem x = in[0], y = in[1];
+  bool asc = gt(x, y);
+  auto step = [&](const PItem& a, const PItem& b) { return asc ? gt(a, b) : !gt(a, b); };
+  PL r; bool have_s = false; PItem s{};
+  for (size_t pos = 2; pos < in.size(); pos++) {
+    PItem z = in[pos];
+    if (step(y, z)) { r.insert(r.begin(), x); x = y; y = z; }
+    else if (step(x, z)) { r.insert(r.begin(), x); x = z; }
+    else if (!have_s && r.empty()) r.push_back(z);
+    else if (!have_s) { have_s = true; s = z; }
+    else {
+      PL run{y, x}; run.insert(run.end(), r.begin(), r.end());
+      rs.insert(rs.begin(), run); r.clear();
+      if (step(s, z)) { y = z; x = s; } else { y = s; x = z; }
+      have_s = false;
+    }
+  }
+  PL run{y, x}; run.insert(run.end(), r.begin(), r.end());
+  std::vector<PL> all;
+  if (have_s) all.push_back(PL{s});
+  all.push_back(run);
+  all.insert(all.end(), rs.begin(), rs.end());
+  return mergel(all, /*rphase=*/asc, asc);
+}
+
+static int lookup(const char* name, bool muta) {
+  if (muta) { for (int i = 0; i < M_COUNT; i++) if (!strcmp(name, MUTAS[i].name)) return i; }
+  else { for (int i = 0; i < P_COUNT; i++) if (!strcmp(name, PATS[i].name)) return i; }
+  return -1;
+}
+// "-m"/"-p" list syntax: erlamsa_cmdparse:string_to_actions/3 (erlamsa_cmdparse.erl:232-257)
+static int parse_actions(eh_ctx* ctx, const char* s, bool muta, std::vector<long>& pri /* -1 = not selected */) {
+  int count = muta ? (int)M_COUNT : (int)P_COUNT;
+  pri.assign(count, -1);
+  if (!s) { for (int i = 0; i < count; i++) pri[i] = muta ? MUTAS[i].pri : PATS[i].pri; return EH_OK; }
+  std::string str(s); size_t pos = 0;
+  while (pos <= str.size()) {
+    size_t e = str.find(',', pos); if (e == std::string::npos) e = str.size();
+    std::string tok = str.substr(pos, e - pos); pos = e + 1;
+    if (tok.empty()) continue;
+    size_t eq = tok.find('=');
+    std::string name = eq == std::string::npos ? tok : tok.substr(0, eq);
+    int id = lookup(name.c_str(), muta);
+    if (id < 0) { ctx->err = std::string("No such ") + (muta ? "mutations" : "patterns") + ": " + name; return EH_E_INVALID; }
+    long p = muta ? MUTAS[id].pri : PATS[id].pri;
+    if (eq != std::string::npos) { char* endp = nullptr; p = strtol(tok.c_str() + eq + 1, &endp, 10); if (*endp || p < 0 || p > 1000000) { ctx->err = "Invalid priority: " + tok; return EH_E_INVALID; } }
+    pri[id] = p;
+  }
+  return EH_OK;
+}
+
+static void init_tables(uint16_t* t1, uint16_t* t2, uint16_t* t3) {
+  uint32_t a = 1, b = 1, c = 1;
+  for (int k = 0; k <= 64; k++) { t1[k] = (uint16_t)a; t2[k] = (uint16_t)b; t3[k] = (uint16_t)c; a = a * 171 % 30269; b = b * 172 % 30307; c = c * 170 % 30323; }
+}
+// funny_unicode/0 (erlamsa_mutations.erl:1053-1078): 17 hand-written sequences, then the UTF-8
+// encodings of the code points produced by folding (with prepend) over the Codes list.
+static int build_funny(uint8_t (*out)[5]) {
+  static const uint8_t manual[17][5] = {{3, 239, 191, 191}, {4, 240, 144, 128, 128}, {3, 0xef, 0xbb, 0xbf}, {2, 0xfe, 0xff}, {2, 0xff, 0xfe},
+                                        {4, 0, 0, 0xff, 0xff}, {4, 0xff, 0xff, 0, 0}, {4, 43, 47, 118, 56}, {4, 43, 47, 118, 57},
+                                        {4, 43, 47, 118, 43}, {4, 43, 47, 118, 47}, {3, 247, 100, 76}, {4, 221, 115, 102, 115},
+                                        {3, 14, 254, 255}, {3, 251, 238, 40}, {4, 251, 238, 40, 255}, {4, 132, 49, 149, 51}};
+  static const uint32_t codes[][2] = {{0x0009, 0x000d}, {0x008D, 0x008D}, {0x00a0, 0x00a0}, {0x1680, 0x1680}, {0x180e, 0x180e},
+                                      {0x2000, 0x200a}, {0x2028, 0x2028}, {0x2029, 0x2029}, {0x202f, 0x202f}, {0x205f, 0x205f},
+                                      {0x3000, 0x3000}, {0x200e, 0x200f}, {0x202a, 0x202e}, {0x200c, 0x200d}, {0x0345, 0x0345},
+                                      {0x00b7, 0x00b7}, {0x02d0, 0x02d1}, {0xff70, 0xff70}, {0x02b0, 0x02b8}, {0xfdd0, 0xfdd0},
+                                      {0x034f, 0x034f}, {0x115f, 0x1160}, {0x2065, 0x2069}, {0x3164, 0x3164}, {0xffa0, 0xffa0},
+                                      {0xe0001, 0xe0001}, {0xe0020, 0xe007f}, {0x0e40, 0x0e44}, {0x1f4a9, 0x1f4a9}};
+  int n = 0;
+  for (int i = 0; i < 17; i++, n++) memcpy(out[n], manual[i], 5);
+  const int ng = (int)(sizeof(codes) / sizeof(codes[0]));
+  for (int g = ng - 1; g >= 0; g--)
+    for (uint32_t p = codes[g][0]; p <= codes[g][1]; p++, n++) {
+      uint8_t* e = out[n];
+      auto ext = [](uint32_t v) { return (uint8_t)((v & 0x3f) | 0x80); };
+      if (p < 0x80) { e[0] = 1; e[1] = (uint8_t)p; }
+      else if (p < 0x800) { e[0] = 2; e[1] = (uint8_t)(0xc0 | (0x1f & (p >> 6))); e[2] = ext(p); }
+      else if (p < 0x10000) { e[0] = 3; e[1] = (uint8_t)(0xe0 | (0x0f & (p >> 12))); e[2] = ext(p >> 6); e[3] = ext(p); }
+      else { e[0] = 4; e[1] = (uint8_t)(0xf0 | (0x7 & (p >> 18))); e[2] = ext(p >> 12); e[3] = ext(p >> 6); e[4] = ext(p); }
+    }
+  return n;
+}
+
+static int ensure_results(eh_ctx* ctx, uint64_t n) {
+  if (n <= ctx->res_cap) return EH_OK;
+  if (ctx->d_off) { (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len); (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); }
+  HIPCHK(ctx, hipMalloc(&ctx->d_off, n * 8));
+  HIPCHK(ctx, hipMalloc(&ctx->d_len, n * 8));
+  HIPCHK(ctx, hipMalloc(&ctx->d_status, n * 4));
+  HIPCHK(ctx, hipMalloc(&ctx->d_draws, n * 8));
+  HIPCHK(ctx, hipMalloc(&ctx->d_lastm, n * 4));
+  ctx->res_cap = n;
+  return EH_OK;
+}
+
+static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_case, uint64_t corpus_first, uint64_t n, hipStream_t st) {
+  if (!ctx->configured || !ctx->d_corpus) { ctx->err = "configure and load a corpus first"; return EH_E_STATE; }
+  if (corpus_first + n > ctx->n_corpus || (mode == 0 && first_case < 1)) { ctx->err = "case range outside the corpus"; return EH_E_INVALID; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_results(ctx, n ? n : 1);
+  if (rc) return rc;
+  // slots
+  uint32_t want_slots = ctx->max_slots_opt ? ctx->max_slots_opt : (uint32_t)ctx->cus * 16u;
+  if (want_slots > n) want_slots = (uint32_t)(n ? n : 1);
+  uint64_t work_cap = ctx->max_case_bytes ? ctx->max_case_bytes : (8ull << 20);
+  uint64_t stride = (uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + work_cap;
+  stride = (stride + 255) & ~255ull;
+  if (!ctx->d_slots || ctx->nslots < want_slots || ctx->work_cap != work_cap) {
+    if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    ctx->d_slots = nullptr;
+    HIPCHK(ctx, hipMalloc(&ctx->d_slots, stride * want_slots));
+    ctx->nslots = want_slots; ctx->work_cap = work_cap; ctx->slot_stride = stride;
+  }
+  // output arena
+  uint64_t in_bytes = 0;
+  if (!ctx->h_coff.empty()) in_bytes = ctx->h_coff[corpus_first + n] - ctx->h_coff[corpus_first];
+  uint64_t want_out = ctx->out_capacity_opt ? ctx->out_capacity_opt : (2 * (in_bytes ? in_bytes : ctx->corpus_bytes) + (256ull << 20));
+  if (!ctx->d_out || ctx->out_cap < want_out) {
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    ctx->d_out = nullptr;
+    HIPCHK(ctx, hipMalloc(&ctx->d_out, want_out));
+    ctx->out_cap = want_out;
+  }
+  if (!ctx->d_counters) { HIPCHK(ctx, hipMalloc(&ctx->d_counters, 64)); HIPCHK(ctx, hipMalloc(&ctx->d_run, sizeof(RunState))); }
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 64, st));
+
+  KParams p;
+  memset(&p, 0, sizeof(p));
+  p.corpus = ctx->d_corpus; p.coff = ctx->d_coff; p.corpus_first = corpus_first; p.n = n; p.first_case = first_case;
+  p.mode = mode; p.run = ctx->d_run; p.seeds = ctx->d_seeds; p.cfg = ctx->cfg;
+  p.slot_base = ctx->d_slots; p.slot_stride = ctx->slot_stride; p.work_cap = ctx->work_cap;
+  p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
+  p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm;
+  p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2;
+
+  if (mode == 0) hipLaunchKernelGGL(eh_setup_kernel, dim3(1), dim3(64), 0, st, ctx->cfg, seed[0], seed[1], seed[2], ctx->d_run);
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
+  if (n > 0) hipLaunchKernelGGL(eh_mutate_kernel, dim3(ctx->nslots < n ? ctx->nslots : (uint32_t)n), dim3(64), 0, st, p);
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, st));
+  HIPCHK(ctx, hipGetLastError());
+  ctx->last_stream = st; ctx->last_n = n; ctx->last_in_bytes = in_bytes; ctx->have_result = true;
+  return EH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t eh_abi_version(void) { return EH_ABI_VERSION; }
+int eh_mutator_count(void) { return M_COUNT; }
+const char* eh_mutator_name(int id) { return id >= 0 && id < M_COUNT ? MUTAS[id].name : nullptr; }
+int eh_mutator_default_pri(int id) { return id >= 0 && id < M_COUNT ? MUTAS[id].pri : -1; }
+int eh_mutator_on_gpu(int id) { return id >= 0 && id < M_COUNT ? MUTAS[id].on_gpu : 0; }
+int eh_pattern_count(void) { return P_COUNT; }
+const char* eh_pattern_name(int id) { return id >= 0 && id < P_COUNT ? PATS[id].name : nullptr; }
+int eh_pattern_default_pri(int id) { return id >= 0 && id < P_COUNT ? PATS[id].pri : -1; }
+int eh_pattern_on_gpu(int id) { return id >= 0 && id < P_COUNT ? PATS[id].on_gpu : 0; }
+const char* eh_kernel_name(void) { return "eh_mutate_kernel"; }
+
+const char* eh_strerror(int code) {
+  switch (code) {
+    case EH_OK: return "ok";
+    case EH_E_INVALID: return "invalid argument";
+    case EH_E_NODEVICE: return "no usable HIP device";
+    case EH_E_HIP: return "HIP runtime error";
+    case EH_E_NOMEM: return "out of memory";
+    case EH_E_STATE: return "wrong call order";
+    case EH_E_UNSUPPORTED: return "mutator/pattern not available on the GPU in this build";
+  }
+  return "unknown error";
+}
+const char* eh_last_error(eh_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int eh_create(int device, eh_ctx** out) {
+  if (!out) return EH_E_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return EH_E_NODEVICE;
+  eh_ctx* ctx = new (std::nothrow) eh_ctx();
+  if (!ctx) return EH_E_NOMEM;
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete ctx; return EH_E_NODEVICE; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return EH_E_NODEVICE; }
+  ctx->cus = prop.multiProcessorCount;
+  uint16_t t1[65], t2[65], t3[65];
+  init_tables(t1, t2, t3);
+  static uint8_t funny[192][5];
+  memset(funny, 0, sizeof(funny));
+  int nf = build_funny(funny);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_T1), t1, sizeof(t1)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_T2), t2, sizeof(t2)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(c_T3), t3, sizeof(t3)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_funny), funny, sizeof(funny)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(c_nfunny), &nf, sizeof(nf)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
+      hipEventCreate(&ctx->ev1) != hipSuccess) {
+    delete ctx;
+    return EH_E_HIP;
+  }
+  *out = ctx;
+  return EH_OK;
+}
+
+void eh_destroy(eh_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  if (ctx->own_corpus) { (void)hipFree(ctx->d_corpus); (void)hipFree(ctx->d_coff); }
+  (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
+  (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_counters);
+  (void)hipFree(ctx->d_run); (void)hipFree(ctx->d_seeds);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  delete ctx;
+}
+
+int eh_configure(eh_ctx* ctx, const eh_options* o) {
+  if (!ctx || !o) return EH_E_INVALID;
+  if (o->abi_version != EH_ABI_VERSION) { ctx->err = "eh_options.abi_version mismatch"; return EH_E_INVALID; }
+  DevConfig cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  std::vector<long> mp, pp;
+  int rc = parse_actions(ctx, o->mutations, true, mp); if (rc) return rc;
+  rc = parse_actions(ctx, o->patterns, false, pp); if (rc) return rc;
+  for (int i = 0; i < M_COUNT; i++) if (mp[i] >= 0) {
+    if (!MUTAS[i].on_gpu) { ctx->err = std::string("mutator '") + MUTAS[i].name + "' is not available on the GPU in this build"; return EH_E_UNSUPPORTED; }
+    cfg.sel_name[cfg.nsel] = (uint8_t)i; cfg.sel_pri[cfg.nsel] = (uint32_t)mp[i]; cfg.nsel++;
+  }
+  // make_pattern (erlamsa_patterns.erl:416-428): foldl prepends => reversed table order, then sort_by_priority
+  PL pl;
+  for (int i = P_COUNT - 1; i >= 0; i--) if (pp[i] >= 0) {
+    if (!PATS[i].on_gpu) { ctx->err = std::string("pattern '") + PATS[i].name + "' is not available on the GPU in this build"; return EH_E_UNSUPPORTED; }
+    pl.push_back({(uint32_t)pp[i], i});
+  }
+  PL sp = otp_sort_desc_strict(pl);
+  cfg.npat = (int)sp.size();
+  for (size_t i = 0; i < sp.size(); i++) { cfg.pat_id[i] = (uint8_t)sp[i].id; cfg.pat_pri[i] = sp[i].pri; cfg.pat_total += (int)sp[i].pri; }
+  if (cfg.npat == 0) { ctx->err = "no patterns selected"; return EH_E_INVALID; }
+  // generators: table order of erlamsa_gen:generators/0 is random(1) ... direct(500)
+  long gr = 1, gd = 500;
+  if (o->generators) {
+    gr = -1; gd = -1;
+    std::string str(o->generators); size_t pos = 0;
+    while (pos <= str.size()) {
+      size_t e = str.find(',', pos); if (e == std::string::npos) e = str.size();
+      std::string tok = str.substr(pos, e - pos); pos = e + 1;
+      if (tok.empty()) continue;
+      size_t eq = tok.find('=');
+      std::string name = eq == std::string::npos ? tok : tok.substr(0, eq);
+      long p = -1; if (eq != std::string::npos) p = strtol(tok.c_str() + eq + 1, nullptr, 10);
+      if (name == "random") gr = p < 0 ? 1 : p; else if (name == "direct") gd = p < 0 ? 500 : p;
+      else { ctx->err = "generator '" + name + "' is host-side I/O and not part of the GPU path"; return EH_E_UNSUPPORTED; }
+    }
+  }
+  PL gl;
+  if (gr >= 0) gl.push_back({(uint32_t)gr, G_RANDOM});
+  if (gd >= 0) gl.push_back({(uint32_t)gd, G_DIRECT});
+  if (gl.empty()) { ctx->err = "No generators!"; return EH_E_INVALID; }
+  PL sg = otp_sort_desc_strict(gl);
+  cfg.ngen = (int)sg.size();
+  for (size_t i = 0; i < sg.size(); i++) { cfg.gen_id[i] = (uint8_t)sg[i].id; cfg.gen_pri[i] = sg[i].pri; cfg.gen_total += (int)sg[i].pri; }
+  double bs = o->blockscale == 0 ? 1.0 : o->blockscale;
+  cfg.max_block_scaled = (uint32_t)llround(MAX_BLOCK_SIZE * bs);
+  cfg.min_block_scaled = (uint32_t)llround(MIN_BLOCK_SIZE * bs);
+  snprintf(cfg.ssrf_host, sizeof(cfg.ssrf_host), "%s", o->ssrf_host ? o->ssrf_host : "localhost");
+  snprintf(cfg.ssrf_port, sizeof(cfg.ssrf_port), "%d", o->ssrf_port ? o->ssrf_port : 51234);
+  ctx->cfg = cfg;
+  ctx->max_case_bytes = o->max_case_bytes; ctx->out_capacity_opt = o->out_capacity; ctx->max_slots_opt = o->max_slots; ctx->flags = o->flags;
+  ctx->configured = true;
+  return EH_OK;
+}
+
+static int set_corpus(eh_ctx* ctx, uint8_t* d, uint64_t* doff, bool own, uint64_t n, uint64_t nbytes) {
+  if (ctx->own_corpus) { (void)hipFree(ctx->d_corpus); (void)hipFree(ctx->d_coff); }
+  ctx->d_corpus = d; ctx->d_coff = doff; ctx->own_corpus = own; ctx->n_corpus = n; ctx->corpus_bytes = nbytes;
+  return EH_OK;
+}
+int eh_corpus_upload(eh_ctx* ctx, const uint8_t* data, const uint64_t* off, uint64_t n) {
+  if (!ctx || !off || (!data && off[n] > 0)) return EH_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  uint64_t nbytes = off[n];
+  uint8_t* d = nullptr; uint64_t* doff = nullptr;
+  HIPCHK(ctx, hipMalloc(&d, nbytes ? nbytes : 16));
+  HIPCHK(ctx, hipMalloc(&doff, (n + 1) * 8));
+  if (nbytes) HIPCHK(ctx, hipMemcpy(d, data, nbytes, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(doff, off, (n + 1) * 8, hipMemcpyHostToDevice));
+  ctx->h_coff.assign(off, off + n + 1);
+  return set_corpus(ctx, d, doff, true, n, nbytes);
+}
+int eh_corpus_attach(eh_ctx* ctx, const void* d_data, const void* d_off, uint64_t n, uint64_t nbytes) {
+  if (!ctx || !d_off) return EH_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->h_coff.resize(n + 1);
+  HIPCHK(ctx, hipMemcpy(ctx->h_coff.data(), d_off, (n + 1) * 8, hipMemcpyDeviceToHost));
+  if (ctx->h_coff[n] != nbytes) { ctx->err = "off[n] != nbytes"; return EH_E_INVALID; }
+  return set_corpus(ctx, (uint8_t*)d_data, (uint64_t*)d_off, false, n, nbytes);
+}
+
+int eh_fuzz_batch(eh_ctx* ctx, const int64_t seed[3], uint64_t first_case, uint64_t corpus_first, uint64_t n, void* stream) {
+  if (!ctx || !seed) return EH_E_INVALID;
+  return launch(ctx, 0, seed, first_case, corpus_first, n, (hipStream_t)stream);
+}
+int eh_fuzz_calls(eh_ctx* ctx, const int64_t* seeds, uint64_t corpus_first, uint64_t n, void* stream) {
+  if (!ctx || !seeds) return EH_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (n > ctx->seeds_cap) {
+    if (ctx->d_seeds) (void)hipFree(ctx->d_seeds);
+    ctx->d_seeds = nullptr;
+    HIPCHK(ctx, hipMalloc(&ctx->d_seeds, n * 24));
+    ctx->seeds_cap = n;
+  }
+  if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->d_seeds, seeds, n * 24, hipMemcpyHostToDevice, (hipStream_t)stream));
+  int64_t dummy[3] = {0, 0, 0};
+  return launch(ctx, 1, dummy, 1, corpus_first, n, (hipStream_t)stream);
+}
+int eh_sync(eh_ctx* ctx) {
+  if (!ctx) return EH_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->last_stream));
+  return EH_OK;
+}
+
+int eh_result_device(eh_ctx* ctx, const uint8_t** d_data, const uint64_t** d_off, const uint64_t** d_len, const int32_t** d_status, uint64_t* total) {
+  if (!ctx) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  int rc = eh_sync(ctx); if (rc) return rc;
+  if (d_data) *d_data = ctx->d_out;
+  if (d_off) *d_off = ctx->d_off;
+  if (d_len) *d_len = ctx->d_len;
+  if (d_status) *d_status = ctx->d_status;
+  if (total) { unsigned long long cur = 0; HIPCHK(ctx, hipMemcpy(&cur, ctx->d_counters + 1, 8, hipMemcpyDeviceToHost)); *total = cur; }
+  return EH_OK;
+}
+int eh_result_totals(eh_ctx* ctx, uint64_t* in_bytes, uint64_t* out_bytes, uint64_t* n_cases) {
+  if (!ctx) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  int rc = eh_sync(ctx); if (rc) return rc;
+  uint64_t n = ctx->last_n;
+  if (out_bytes) {
+    std::vector<uint64_t> len(n ? n : 1);
+    if (n) HIPCHK(ctx, hipMemcpy(len.data(), ctx->d_len, n * 8, hipMemcpyDeviceToHost));
+    uint64_t s = 0; for (uint64_t i = 0; i < n; i++) s += len[i];
+    *out_bytes = s;
+  }
+  if (in_bytes) *in_bytes = ctx->last_in_bytes;
+  if (n_cases) *n_cases = n;
+  return EH_OK;
+}
+int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, int32_t* status) {
+  if (!ctx) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  int rc = eh_sync(ctx); if (rc) return rc;
+  uint64_t n = ctx->last_n;
+  std::vector<uint64_t> o(n ? n : 1), len(n ? n : 1);
+  if (n) { HIPCHK(ctx, hipMemcpy(o.data(), ctx->d_off, n * 8, hipMemcpyDeviceToHost)); HIPCHK(ctx, hipMemcpy(len.data(), ctx->d_len, n * 8, hipMemcpyDeviceToHost)); }
+  if (status && n) HIPCHK(ctx, hipMemcpy(status, ctx->d_status, n * 4, hipMemcpyDeviceToHost));
+  uint64_t total = 0; for (uint64_t i = 0; i < n; i++) total += len[i];
+  if (off) { uint64_t p = 0; for (uint64_t i = 0; i < n; i++) { off[i] = p; p += len[i]; } off[n] = p; }
+  if (data) {
+    if (total > cap) { ctx->err = "download buffer too small"; return EH_E_INVALID; }
+    unsigned long long cur = 0;
+    HIPCHK(ctx, hipMemcpy(&cur, ctx->d_counters + 1, 8, hipMemcpyDeviceToHost));
+    if (cur > ctx->out_cap) cur = ctx->out_cap;
+    std::vector<uint8_t> arena(cur ? cur : 1);
+    if (cur) HIPCHK(ctx, hipMemcpy(arena.data(), ctx->d_out, cur, hipMemcpyDeviceToHost));
+    uint64_t p = 0;
+    for (uint64_t i = 0; i < n; i++) { if (len[i]) memcpy(data + p, arena.data() + o[i], len[i]); p += len[i]; }
+  }
+  return EH_OK;
+}
+int eh_result_diag(eh_ctx* ctx, uint64_t* draws, int32_t* last_mutator) {
+  if (!ctx) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  int rc = eh_sync(ctx); if (rc) return rc;
+  uint64_t n = ctx->last_n;
+  if (draws && n) HIPCHK(ctx, hipMemcpy(draws, ctx->d_draws, n * 8, hipMemcpyDeviceToHost));
+  if (last_mutator && n) HIPCHK(ctx, hipMemcpy(last_mutator, ctx->d_lastm, n * 4, hipMemcpyDeviceToHost));
+  return EH_OK;
+}
+int eh_last_kernel_ms(eh_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+  HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return EH_OK;
+}
+
+}  // extern "C"

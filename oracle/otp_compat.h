@@ -1,0 +1,403 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (never linked into the product library).
+//
+// otp_compat.h: CPU restatement of the pieces of Erlang/OTP stdlib that
+// erlamsa's hot path depends on but which live OUTSIDE /root/reference
+// (un-vendored, OTP version unpinned: reference README.md:32 "OTP 18.0+",
+// .travis.yml:5-11 matrix 18.0..23.0).
+//
+//   * `random` (AS183, Wichmann-Hill 1982)  -- used at erlamsa_rnd.erl:73,78,83,101,105,151,196
+//   * `lists:sort/2` merge-sort tie behaviour -- erlamsa_mutations.erl:1249, erlamsa_utils.erl:115
+//   * erts big_to_double (bignum -> float)   -- erlamsa_rnd.erl:78 with bignum N
+//   * `base64`, `erlang:crc32`               -- erlamsa_mutations.erl:667,674; erlamsa_field_predict.erl:148,165
+//
+// PARITY UNPINNED: these are restated from the published algorithms / recalled
+// OTP sources; no Erlang runtime exists on this image to check them against and
+// the reference's own tests (erlamsa_mutations_test.erl) pin no byte-exact
+// vectors (they seed from now()).  See DESIGN.md "Oracle".
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace otp {
+
+// A crash of the Erlang worker process (badmatch / function_clause / badarith ...).
+// erlamsa_main.erl:211-220: the case's result is then <<>>.
+struct ErlCrash : std::runtime_error {
+  explicit ErlCrash(const char* why) : std::runtime_error(why) {}
+};
+
+// ---------------------------------------------------------------------------
+// random.erl (AS183).  seed/3: Ai := (|x| rem (Pi-1)) + 1 ; uniform/0:
+//   B1=(A1*171) rem 30269, B2=(A2*172) rem 30307, B3=(A3*170) rem 30323,
+//   R = B1/30269 + B2/30307 + B3/30323,  U = R - trunc(R)
+// ---------------------------------------------------------------------------
+struct Random {
+  uint32_t a1 = 3172, a2 = 9814, a3 = 20125;  // seed0()
+  uint64_t draws = 0;                          // diagnostic only
+  void seed(int64_t s1, int64_t s2, int64_t s3) {
+    a1 = (uint32_t)((s1 < 0 ? -s1 : s1) % 30268) + 1;
+    a2 = (uint32_t)((s2 < 0 ? -s2 : s2) % 30306) + 1;
+    a3 = (uint32_t)((s3 < 0 ? -s3 : s3) % 30322) + 1;
+  }
+  double uniform() {
+    a1 = (a1 * 171u) % 30269u;
+    a2 = (a2 * 172u) % 30307u;
+    a3 = (a3 * 170u) % 30323u;
+    ++draws;
+    volatile double q1 = (double)a1 / 30269.0;
+    volatile double q2 = (double)a2 / 30307.0;
+    volatile double q3 = (double)a3 / 30323.0;
+    volatile double r = q1 + q2;
+    r = r + q3;
+    return r - std::trunc(r);
+  }
+  // random:uniform(N) = trunc(uniform() * N) + 1 for machine-size N.
+  uint64_t uniform_n(uint64_t n) {
+    volatile double x = uniform() * (double)n;
+    return (uint64_t)std::trunc(x) + 1;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// lists:sort/2 — stdlib lists.erl (fsplit_* / fmergel / rfmergel family),
+// restated 1:1 so that orderings with a non-total "=<" fun (erlamsa_utils.erl:115
+// uses a strict '>') come out as on BEAM.
+// ---------------------------------------------------------------------------
+template <class T>
+class ListsSort {
+  using L = std::vector<T>;
+  using F = std::function<bool(const T&, const T&)>;
+  F fun;
+  static L cons(const T& h, const L& t) {
+    L r; r.reserve(t.size() + 1); r.push_back(h); r.insert(r.end(), t.begin(), t.end()); return r;
+  }
+  static L rev_onto(const L& a, const L& tail) {  // lists:reverse(A, Tail)
+    L r(a.rbegin(), a.rend()); r.insert(r.end(), tail.begin(), tail.end()); return r;
+  }
+  // fmerge2_1(T1, H2, Fun, T2, M) etc. operate on index cursors to avoid copying.
+  L fmerge2(const L& t1, const L& l2) {  // l2 = [H2|T2]; result is REVERSED (acc list M)
+    L m; size_t i = 0, j = 0;
+    // state 1: have H2=l2[j]; compare t1[i] with H2
+    // fmerge2_1([H1|T1],H2,..): Fun(H1,H2) ? push H1 : (push H2 -> fmerge2_2)
+    // fmerge2_2(H1,T1,Fun,[H2|T2],M): Fun(H1,H2) ? push H1 -> fmerge2_1 : push H2 -> fmerge2_2
+    // Both states apply the same comparison rule; only the exhausted-list exits differ.
+    while (true) {
+      if (i == t1.size()) {  // fmerge2_1([], H2, _, T2, M) -> reverse(T2, [H2|M])
+        L rest(l2.begin() + j, l2.end());
+        // M currently reversed accumulation; result list = reverse(T2) ++ [H2|M]
+        L out(rest.rbegin(), rest.rend());
+        out.insert(out.end(), m.rbegin(), m.rend());
+        return out;
+      }
+      if (j == l2.size()) {  // fmerge2_2(H1, T1, _, [], M) -> reverse(T1, [H1|M])
+        L rest(t1.begin() + i, t1.end());
+        L out(rest.rbegin(), rest.rend());
+        out.insert(out.end(), m.rbegin(), m.rend());
+        return out;
+      }
+      if (fun(t1[i], l2[j])) m.push_back(t1[i++]); else m.push_back(l2[j++]);
+    }
+  }
+  L rfmerge2(const L& t1, const L& l2) {  // rfmerge2_1/2_2: Fun(H1,H2) ? push H2 : push H1
+    L m; size_t i = 0, j = 0;
+    while (true) {
+      if (i == t1.size()) {
+        L rest(l2.begin() + j, l2.end());
+        L out(rest.rbegin(), rest.rend());
+        out.insert(out.end(), m.rbegin(), m.rend());
+        return out;
+      }
+      if (j == l2.size()) {
+        L rest(t1.begin() + i, t1.end());
+        L out(rest.rbegin(), rest.rend());
+        out.insert(out.end(), m.rbegin(), m.rend());
+        return out;
+      }
+      if (fun(t1[i], l2[j])) m.push_back(l2[j++]); else m.push_back(t1[i++]);
+    }
+  }
+  // NOTE: m above is kept in push order; the Erlang M is the reverse of it, hence
+  // out = reverse(rest) ++ reverse(m_pushorder)  ==  lists:reverse(Rest, [..|M]).
+  L fmergel(std::vector<L> ls, std::vector<L> acc, bool asc);
+  L rfmergel(std::vector<L> ls, std::vector<L> acc, bool asc);
+
+ public:
+  explicit ListsSort(F f) : fun(std::move(f)) {}
+  L sort(const L& in);
+};
+
+template <class T>
+typename ListsSort<T>::L ListsSort<T>::fmergel(std::vector<L> ls, std::vector<L> acc, bool asc) {
+  // acc is a cons-list: new elements are pushed at the FRONT.
+  while (true) {
+    if (ls.size() >= 2) {
+      if (asc) {  // fmergel([T1,[H2|T2]|L],Acc,Fun,asc)
+        L merged = fmerge2(ls[0], ls[1]);
+        acc.insert(acc.begin(), merged);
+      } else {  // fmergel([[H2|T2],T1|L],Acc,Fun,desc)
+        L merged = fmerge2(ls[1], ls[0]);
+        acc.insert(acc.begin(), merged);
+      }
+      ls.erase(ls.begin(), ls.begin() + 2);
+      continue;
+    }
+    if (ls.size() == 1) {
+      if (acc.empty()) return ls[0];
+      L r(ls[0].rbegin(), ls[0].rend());
+      acc.insert(acc.begin(), r);
+      return rfmergel(acc, {}, asc);
+    }
+    return rfmergel(acc, {}, asc);
+  }
+}
+
+template <class T>
+typename ListsSort<T>::L ListsSort<T>::rfmergel(std::vector<L> ls, std::vector<L> acc, bool asc) {
+  while (true) {
+    if (ls.size() >= 2) {
+      if (asc) {  // rfmergel([[H2|T2],T1|L],Acc,Fun,asc)
+        L merged = rfmerge2(ls[1], ls[0]);
+        acc.insert(acc.begin(), merged);
+      } else {  // rfmergel([T1,[H2|T2]|L],Acc,Fun,desc)
+        L merged = rfmerge2(ls[0], ls[1]);
+        acc.insert(acc.begin(), merged);
+      }
+      ls.erase(ls.begin(), ls.begin() + 2);
+      continue;
+    }
+    if (ls.size() == 1) {
+      L r(ls[0].rbegin(), ls[0].rend());
+      acc.insert(acc.begin(), r);
+      return fmergel(acc, {}, asc);
+    }
+    return fmergel(acc, {}, asc);
+  }
+}
+
+template <class T>
+typename ListsSort<T>::L ListsSort<T>::sort(const L& in) {
+  if (in.size() < 2) return in;
+  // Runs are cons-lists built by prepending; we keep them as vectors in list order.
+  std::vector<L> rs;  // Rs (front = most recent)
+  size_t pos = 2;
+  T x = in[0], y = in[1];
+  bool asc = fun(x, y);  // true -> fsplit_1, false -> fsplit_2
+  // `ok(a,b)`: the comparison that continues the current run direction.
+  auto step = [&](const T& a, const T& b) { return asc ? fun(a, b) : !fun(a, b); };
+  L r;  // R as cons-list, front = most recently pushed
+  bool have_s = false; T s{};
+  while (true) {
+    if (pos == in.size()) {
+      // end of input
+      L run; run.push_back(y); run.push_back(x); run.insert(run.end(), r.begin(), r.end());
+      std::vector<L> all;
+      if (have_s) all.push_back(L{s});
+      all.push_back(run);
+      all.insert(all.end(), rs.begin(), rs.end());
+      return asc ? rfmergel(all, {}, true) : fmergel(all, {}, false);
+    }
+    const T z = in[pos++];
+    if (step(y, z)) {            // Fun(Y,Z) continues the run: fsplit(Z, Y, [X|R])
+      r.insert(r.begin(), x); x = y; y = z;
+    } else if (step(x, z)) {     // fsplit(Y, Z, [X|R])
+      r.insert(r.begin(), x); x = z;
+    } else if (!have_s && r.empty()) {  // fsplit(Y, X, L, [Z], Rs)
+      r.push_back(z);
+    } else if (!have_s) {        // -> fsplit_x_1 with S = Z
+      have_s = true; s = z;
+    } else {                     // in fsplit_x_1: third comparison against S
+      L run; run.push_back(y); run.push_back(x); run.insert(run.end(), r.begin(), r.end());
+      rs.insert(rs.begin(), run);
+      r.clear();
+      if (step(s, z)) { y = z; x = s; } else { y = s; x = z; }
+      have_s = false;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// erlang:crc32/1 — zlib CRC-32 (reflected 0xEDB88320, init/xorout 0xFFFFFFFF)
+// ---------------------------------------------------------------------------
+inline uint32_t crc32(const uint8_t* p, size_t n) {
+  static uint32_t tab[256]; static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; tab[i] = c; }
+    init = true;
+  }
+  uint32_t c = 0xFFFFFFFFu;
+  for (size_t i = 0; i < n; i++) c = tab[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+
+// ---------------------------------------------------------------------------
+// Minimal sign-magnitude bignum (base 2^32) with the Erlang semantics needed by
+// sed_num (erlamsa_mutations.erl:93-169): decimal parse/print, +, -, *2,
+// float conversion as erts big_to_double (d = d*2^64 + digit, 64-bit digits),
+// and trunc(float) -> integer.
+// ---------------------------------------------------------------------------
+struct Big {
+  bool neg = false;
+  std::vector<uint32_t> mag;  // little endian, no leading zero limbs; empty = 0
+  Big() {}
+  Big(int64_t v) { neg = v < 0; uint64_t u = neg ? (uint64_t)(-(v + 1)) + 1 : (uint64_t)v; while (u) { mag.push_back((uint32_t)u); u >>= 32; } }
+  static Big from_u64(uint64_t u) { Big b; while (u) { b.mag.push_back((uint32_t)u); u >>= 32; } return b; }
+  bool is_zero() const { return mag.empty(); }
+  void trim() { while (!mag.empty() && mag.back() == 0) mag.pop_back(); if (mag.empty()) neg = false; }
+  static int cmp_mag(const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) {
+    if (a.size() != b.size()) return a.size() < b.size() ? -1 : 1;
+    for (size_t i = a.size(); i-- > 0;) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+    return 0;
+  }
+  static std::vector<uint32_t> add_mag(const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) {
+    std::vector<uint32_t> r; uint64_t c = 0; size_t n = std::max(a.size(), b.size());
+    for (size_t i = 0; i < n; i++) { uint64_t s = c + (i < a.size() ? a[i] : 0) + (i < b.size() ? b[i] : 0); r.push_back((uint32_t)s); c = s >> 32; }
+    if (c) r.push_back((uint32_t)c);
+    return r;
+  }
+  static std::vector<uint32_t> sub_mag(const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) {  // a >= b
+    std::vector<uint32_t> r; int64_t br = 0;
+    for (size_t i = 0; i < a.size(); i++) { int64_t d = (int64_t)a[i] - (i < b.size() ? b[i] : 0) - br; br = d < 0; if (d < 0) d += ((int64_t)1 << 32); r.push_back((uint32_t)d); }
+    while (!r.empty() && r.back() == 0) r.pop_back();
+    return r;
+  }
+  Big operator-() const { Big r = *this; if (!r.is_zero()) r.neg = !neg; return r; }
+  Big operator+(const Big& o) const {
+    Big r;
+    if (neg == o.neg) { r.mag = add_mag(mag, o.mag); r.neg = neg; }
+    else { int c = cmp_mag(mag, o.mag); if (c == 0) return Big(); if (c > 0) { r.mag = sub_mag(mag, o.mag); r.neg = neg; } else { r.mag = sub_mag(o.mag, mag); r.neg = o.neg; } }
+    r.trim(); return r;
+  }
+  Big operator-(const Big& o) const { return *this + (-o); }
+  Big abs() const { Big r = *this; r.neg = false; return r; }
+  Big mul_small(uint32_t m) const { Big r; r.neg = neg; uint64_t c = 0; for (uint32_t d : mag) { uint64_t p = (uint64_t)d * m + c; r.mag.push_back((uint32_t)p); c = p >> 32; } if (c) r.mag.push_back((uint32_t)c); r.trim(); return r; }
+  Big mul(const Big& o) const {
+    Big r; if (is_zero() || o.is_zero()) return r;
+    r.mag.assign(mag.size() + o.mag.size(), 0);
+    for (size_t i = 0; i < mag.size(); i++) { uint64_t c = 0; for (size_t j = 0; j < o.mag.size(); j++) { uint64_t p = (uint64_t)mag[i] * o.mag[j] + r.mag[i + j] + c; r.mag[i + j] = (uint32_t)p; c = p >> 32; } r.mag[i + o.mag.size()] += (uint32_t)c; }
+    r.neg = neg != o.neg; r.trim(); return r;
+  }
+  static Big pow2(unsigned k) { Big r; r.mag.assign(k / 32 + 1, 0); r.mag[k / 32] = 1u << (k % 32); return r; }
+  Big bor(const Big& o) const {  // both non-negative
+    Big r; size_t n = std::max(mag.size(), o.mag.size()); r.mag.assign(n, 0);
+    for (size_t i = 0; i < n; i++) r.mag[i] = (i < mag.size() ? mag[i] : 0) | (i < o.mag.size() ? o.mag[i] : 0);
+    r.trim(); return r;
+  }
+  // N*10 + d accumulation (get_num, erlamsa_mutations.erl:119-120)
+  void mul10_add(uint32_t d) { uint64_t c = d; for (auto& l : mag) { uint64_t p = (uint64_t)l * 10 + c; l = (uint32_t)p; c = p >> 32; } if (c) mag.push_back((uint32_t)c); }
+  std::string to_dec() const {  // integer_to_list/1
+    if (is_zero()) return "0";
+    std::vector<uint32_t> m = mag; std::string out;
+    while (!m.empty()) {
+      uint64_t rem = 0;
+      for (size_t i = m.size(); i-- > 0;) { uint64_t cur = (rem << 32) | m[i]; m[i] = (uint32_t)(cur / 1000000000u); rem = cur % 1000000000u; }
+      while (!m.empty() && m.back() == 0) m.pop_back();
+      for (int k = 0; k < 9; k++) { out.push_back((char)('0' + rem % 10)); rem /= 10; if (m.empty() && rem == 0) break; }
+    }
+    while (out.size() > 1 && out.back() == '0') out.pop_back();
+    if (neg) out.push_back('-');
+    return std::string(out.rbegin(), out.rend());
+  }
+  // erts big_to_double (64-bit ErtsDigit): d = d*2^64 + digit, most significant first.
+  // Returns false on overflow (-> badarith in the caller).
+  bool to_double(double* out) const {
+    volatile double d = 0.0;
+    size_t nd = (mag.size() + 1) / 2;
+    for (size_t k = nd; k-- > 0;) {
+      uint64_t lo = mag[2 * k], hi = (2 * k + 1 < mag.size()) ? mag[2 * k + 1] : 0;
+      uint64_t dig = (hi << 32) | lo;
+      d = d * 18446744073709551616.0 + (double)dig;
+      if (!std::isfinite((double)d)) return false;
+    }
+    *out = neg ? -(double)d : (double)d;
+    return true;
+  }
+  // trunc(F) for a finite non-negative double -> exact integer
+  static Big from_double_trunc(double f) {
+    Big r; bool ng = f < 0; if (ng) f = -f; f = std::trunc(f);
+    if (f == 0) return r;
+    int e; double m = std::frexp(f, &e);           // f = m * 2^e, m in [0.5,1)
+    uint64_t mant = (uint64_t)std::ldexp(m, 53);   // 53-bit integer mantissa
+    int sh = e - 53;
+    if (sh <= 0) { r = from_u64(mant >> (-sh)); }
+    else { r = from_u64(mant); r = r.mul(pow2((unsigned)sh)); }
+    r.neg = ng && !r.is_zero(); return r;
+  }
+  bool fits_i64(int64_t* v) const {
+    if (mag.size() > 2) return false;
+    uint64_t u = 0; for (size_t i = mag.size(); i-- > 0;) u = (u << 32) | mag[i];
+    if (!neg && u <= (uint64_t)INT64_MAX) { *v = (int64_t)u; return true; }
+    if (neg && u <= (uint64_t)INT64_MAX + 1) { *v = (int64_t)(0 - u); return true; }
+    return false;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// base64 (stdlib base64.erl): decode/1 skips whitespace (\t \n \r space), '='
+// padding terminates; any other byte -> error (function_clause/badarg).
+// ---------------------------------------------------------------------------
+inline bool base64_decode(const std::vector<uint8_t>& in, std::vector<uint8_t>* out) {
+  auto val = [](int c) -> int {
+    if (c >= 'A' && c <= 'Z') return c - 'A';
+    if (c >= 'a' && c <= 'z') return c - 'a' + 26;
+    if (c >= '0' && c <= '9') return c - '0' + 52;
+    if (c == '+') return 62;
+    if (c == '/') return 63;
+    return -1;
+  };
+  auto ws = [](int c) { return c == '\t' || c == '\n' || c == '\r' || c == ' '; };
+  // Restatement of base64:decode_list/2 .. (stdlib >= R13): groups of 4 sextets,
+  // "xx==" and "xxx=" tails; whitespace is skipped between any characters;
+  // after the '=' tail only whitespace may follow.
+  out->clear();
+  std::vector<int> q; size_t i = 0, n = in.size();
+  while (true) {
+    // collect up to 4 symbols
+    q.clear();
+    while (i < n && q.size() < 4) {
+      int c = in[i];
+      if (ws(c)) { i++; continue; }
+      if (c == '=') break;
+      int v = val(c); if (v < 0) return false;
+      q.push_back(v); i++;
+    }
+    if (q.size() == 4) {
+      out->push_back((uint8_t)((q[0] << 2) | (q[1] >> 4)));
+      out->push_back((uint8_t)((q[1] << 4) | (q[2] >> 2)));
+      out->push_back((uint8_t)((q[2] << 6) | q[3]));
+      continue;
+    }
+    if (i >= n) { return q.empty(); }  // input exhausted mid-quantum -> error unless clean
+    // in[i] == '='
+    if (q.size() == 2) {
+      i++;  // first '='
+      while (i < n && ws(in[i])) i++;
+      if (i >= n || in[i] != '=') return false;
+      i++;
+      out->push_back((uint8_t)((q[0] << 2) | (q[1] >> 4)));
+    } else if (q.size() == 3) {
+      i++;
+      out->push_back((uint8_t)((q[0] << 2) | (q[1] >> 4)));
+      out->push_back((uint8_t)((q[1] << 4) | (q[2] >> 2)));
+    } else return false;
+    while (i < n) { if (!ws(in[i])) return false; i++; }
+    return true;
+  }
+}
+inline std::vector<uint8_t> base64_encode(const std::vector<uint8_t>& in) {
+  static const char* T = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+  std::vector<uint8_t> o; size_t i = 0;
+  for (; i + 3 <= in.size(); i += 3) {
+    uint32_t v = (in[i] << 16) | (in[i + 1] << 8) | in[i + 2];
+    o.push_back(T[v >> 18]); o.push_back(T[(v >> 12) & 63]); o.push_back(T[(v >> 6) & 63]); o.push_back(T[v & 63]);
+  }
+  if (in.size() - i == 1) { uint32_t v = in[i] << 16; o.push_back(T[v >> 18]); o.push_back(T[(v >> 12) & 63]); o.push_back('='); o.push_back('='); }
+  else if (in.size() - i == 2) { uint32_t v = (in[i] << 16) | (in[i + 1] << 8); o.push_back(T[v >> 18]); o.push_back(T[(v >> 12) & 63]); o.push_back(T[(v >> 6) & 63]); o.push_back('='); }
+  return o;
+}
+
+}  // namespace otp

@@ -1,0 +1,92 @@
+"""Shared helpers for the parity tests: synthetic corpora (BASELINE/SURVEY §8d) and comparison."""
+import numpy as np
+
+SEED_C = 0xE71A
+
+
+def corpus_uniform(n, size, seed=SEED_C):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    data = rng.integers(0, 256, size=n * size, dtype=np.uint8)
+    return [data[i * size:(i + 1) * size].tobytes() for i in range(n)]
+
+
+def _ascii_lines(rng, size):
+    out = bytearray()
+    while len(out) < size:
+        ll = int(rng.integers(16, 81))
+        line = bytearray(rng.integers(32, 127, size=ll, dtype=np.uint8).tobytes())
+        if rng.random() < 0.5:
+            num = str(int(rng.integers(0, 10 ** int(rng.integers(1, 12))))).encode()
+            pos = int(rng.integers(0, max(1, len(line) - len(num))))
+            line[pos:pos + len(num)] = num
+        out += line + b"\n"
+    return bytes(out[:size])
+
+
+def _bracketed(rng, size):
+    out = bytearray()
+    opens, closes = b"([<{\"'", b")]>}\"'"
+    stack = []
+    while len(out) < size:
+        r = rng.random()
+        if r < 0.12 and len(stack) < 8:
+            k = int(rng.integers(0, 6)); out.append(opens[k]); stack.append(closes[k])
+        elif r < 0.24 and stack:
+            out.append(stack.pop())
+        elif r < 0.30:
+            out += b"\n"
+        else:
+            out += rng.integers(97, 123, size=int(rng.integers(1, 9)), dtype=np.uint8).tobytes() + b" "
+    return bytes(out[:size])
+
+
+def _framed(rng, size):
+    import zlib
+    hdr = int(rng.integers(0, 16))
+    width = int(rng.choice([1, 2, 4]))
+    big = bool(rng.integers(0, 2))
+    trailer = int(rng.choice([0, 1, 4]))
+    body_len = size - hdr - width - trailer
+    if width == 1:
+        body_len = min(body_len, 255)
+    head = rng.integers(0, 256, size=hdr, dtype=np.uint8).tobytes()
+    body = rng.integers(0, 256, size=body_len, dtype=np.uint8).tobytes()
+    lenf = body_len.to_bytes(width, "big" if big else "little")
+    blob = head + lenf + body
+    pad = size - len(blob) - trailer
+    blob += rng.integers(0, 256, size=max(pad, 0), dtype=np.uint8).tobytes()
+    if trailer == 1:
+        x = 0
+        for b in blob:
+            x ^= b
+        blob += bytes([x])
+    elif trailer == 4:
+        blob += zlib.crc32(blob).to_bytes(4, "big")
+    return blob[:size]
+
+
+def corpus_mixed(n, size, seed=SEED_C):
+    """C3 'mixed-binary': 50% uniform bytes, 25% ASCII lines with numbers, 15% bracket/quote
+    structured text, 10% binary with a length field and xor8/crc32 trailer."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    kinds = rng.random(n)
+    out = []
+    for i in range(n):
+        k = kinds[i]
+        if k < 0.5:
+            out.append(rng.integers(0, 256, size=size, dtype=np.uint8).tobytes())
+        elif k < 0.75:
+            out.append(_ascii_lines(rng, size))
+        elif k < 0.90:
+            out.append(_bracketed(rng, size))
+        else:
+            out.append(_framed(rng, size))
+    return out
+
+
+def first_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return i
+    return n if len(a) != len(b) else -1
