@@ -306,7 +306,7 @@ static const MutaInfo MUTAS[M_COUNT] = {
     {"ld", 1, 0},   {"lds", 1, 0}, {"lr2", 1, 0},  {"lri", 1, 0}, {"lr", 1, 0},  {"ls", 1, 0},  {"lp", 1, 0},  {"lis", 1, 0},
     {"lrs", 1, 0},  {"ft", 2, 0},  {"fn", 1, 0},   {"fo", 2, 0},  {"len", 2, 0}, {"b64", 7, 0}, {"uri", 1, 0}, {"zip", 1, 0},
     {"nil", 0, 1}};
-static const PatInfo PATS[P_COUNT] = {{"od", 1, 1}, {"nd", 2, 1}, {"bu", 1, 1}, {"sk", 2, 1}, {"sz", 2, 0},
+static const PatInfo PATS[P_COUNT] = {{"od", 1, 1}, {"nd", 2, 1}, {"bu", 1, 1}, {"sk", 2, 0}, {"sz", 2, 0},
                                       {"cs", 1, 0}, {"ar", 1, 0}, {"cp", 1, 0}, {"co", 0, 1}, {"nu", 0, 1}};
 
 }  // namespace eh
