@@ -178,6 +178,7 @@ struct Ctx {
   int nb, cur;
   Blk* em;
   int nem;
+  uint8_t* aux;        // per-slot mutator state (lis/lrs lines, fo block)
   // linear work allocator
   uint8_t* ws;
   uint64_t ws_used, ws_cap;
@@ -406,6 +407,7 @@ EH_DEV uint32_t em_name(uint32_t m) { return (m >> 16) & 0xFF; }
 EH_DEV uint32_t em_mask(uint32_t m) { return (m >> 24) & 0xFF; }
 EH_DEV uint32_t em_pack(uint32_t score, uint32_t fn, uint32_t name, uint32_t mask) { return score | (fn << 8) | (name << 16) | (mask << 24); }
 
+EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask);   // eh_engine.hip: text/tree/... mutators
 EH_DEV int run_mutator(Ctx& c, uint32_t fn, uint32_t mask) {
   switch (fn) {
     case M_BD: case M_BEI: case M_BED: case M_BF: case M_BI: case M_BER: case M_BR: case M_UW: case M_UI:
@@ -413,7 +415,7 @@ EH_DEV int run_mutator(Ctx& c, uint32_t fn, uint32_t mask) {
     case M_SP: case M_SR: case M_SD: case M_SNAND: case M_SRND:
       return muta_seq(c, (int)fn, (int)mask);
     case M_NIL: c.r_kind = R_SAME; return -1;               // nomutation :1104-1105
-    default: c.status = CASE_UNSUPPORTED; c.r_kind = R_SAME; return 0;
+    default: return run_mutator_ext(c, fn, mask);
   }
 }
 

@@ -21,8 +21,23 @@
 
 #include "../../include/erlamsa_hip.h"
 #include "eh_device.h"
+#include "eh_text.h"
 
 namespace eh {
+
+constexpr uint64_t AUX_BYTES = 2048;
+
+EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
+  (void)mask;
+  StState* st = (StState*)c.aux;
+  switch (fn) {
+    case M_LD: case M_LDS: case M_LR2: case M_LRI: case M_LR: case M_LS: case M_LP: return muta_line(c, (int)fn);
+    case M_LIS: return muta_st_line(c, (int)fn, st);
+    case M_LRS: return muta_st_line(c, (int)fn, st + 1);
+    case M_NUM: return muta_num(c);
+    default: c.status = CASE_UNSUPPORTED; c.r_kind = R_SAME; return 0;
+  }
+}
 
 // =============================================================================================
 // device: per-run setup  (erlamsa_main.erl:134-158)
@@ -220,7 +235,8 @@ __global__ void __launch_bounds__(64) eh_mutate_kernel(KParams p) {
   c.bl = (Blk*)slot;
   c.bl2 = c.bl + MAX_BLOCKS;
   c.em = c.bl2 + MAX_BLOCKS;
-  c.ws = (uint8_t*)(c.em + MAX_EMITS);
+  c.aux = (uint8_t*)(c.em + MAX_EMITS);
+  c.ws = c.aux + AUX_BYTES;
   c.ws_cap = p.work_cap;
 
   // mode 0: the run state is shared by all cases
@@ -244,6 +260,7 @@ __global__ void __launch_bounds__(64) eh_mutate_kernel(KParams p) {
 
     c.status = CASE_OK; c.lastm = -1; c.nb = 0; c.cur = 0; c.nem = 0; c.ws_used = 0;
     c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0;
+    if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; }
     int gen;
     Rng pr;
     if (p.mode == 0) {
@@ -301,10 +318,10 @@ __global__ void __launch_bounds__(64) eh_mutate_kernel(KParams p) {
 // =============================================================================================
 static const MutaInfo MUTAS[M_COUNT] = {
     {"sgm", 10, 0}, {"js", 3, 0},  {"uw", 1, 1},   {"ui", 2, 1},  {"ab", 1, 0},  {"ad", 1, 0},  {"tr2", 1, 0}, {"td", 1, 0},
-    {"num", 3, 0},  {"ts1", 2, 0}, {"tr", 2, 0},   {"ts2", 2, 0}, {"bd", 1, 1},  {"bei", 1, 1}, {"bed", 1, 1}, {"bf", 1, 1},
+    {"num", 3, 1},  {"ts1", 2, 0}, {"tr", 2, 0},   {"ts2", 2, 0}, {"bd", 1, 1},  {"bei", 1, 1}, {"bed", 1, 1}, {"bf", 1, 1},
     {"bi", 1, 1},   {"ber", 1, 1}, {"br", 1, 1},   {"sp", 1, 1},  {"sr", 1, 1},  {"sd", 1, 1},  {"snand", 1, 1}, {"srnd", 1, 1},
-    {"ld", 1, 0},   {"lds", 1, 0}, {"lr2", 1, 0},  {"lri", 1, 0}, {"lr", 1, 0},  {"ls", 1, 0},  {"lp", 1, 0},  {"lis", 1, 0},
-    {"lrs", 1, 0},  {"ft", 2, 0},  {"fn", 1, 0},   {"fo", 2, 0},  {"len", 2, 0}, {"b64", 7, 0}, {"uri", 1, 0}, {"zip", 1, 0},
+    {"ld", 1, 1},   {"lds", 1, 1}, {"lr2", 1, 1},  {"lri", 1, 1}, {"lr", 1, 1},  {"ls", 1, 1},  {"lp", 1, 1},  {"lis", 1, 1},
+    {"lrs", 1, 1},  {"ft", 2, 0},  {"fn", 1, 0},   {"fo", 2, 0},  {"len", 2, 0}, {"b64", 7, 0}, {"uri", 1, 0}, {"zip", 1, 0},
     {"nil", 0, 1}};
 static const PatInfo PATS[P_COUNT] = {{"od", 1, 1}, {"nd", 2, 1}, {"bu", 1, 1}, {"sk", 2, 0}, {"sz", 2, 0},
                                       {"cs", 1, 0}, {"ar", 1, 0}, {"cp", 1, 0}, {"co", 0, 1}, {"nu", 0, 1}};
@@ -498,7 +515,7 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   uint32_t want_slots = ctx->max_slots_opt ? ctx->max_slots_opt : (uint32_t)ctx->cus * 16u;
   if (want_slots > n) want_slots = (uint32_t)(n ? n : 1);
   uint64_t work_cap = ctx->max_case_bytes ? ctx->max_case_bytes : (8ull << 20);
-  uint64_t stride = (uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + work_cap;
+  uint64_t stride = (uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + work_cap;
   stride = (stride + 255) & ~255ull;
   if (!ctx->d_slots || ctx->nslots < want_slots || ctx->work_cap != work_cap) {
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);

@@ -75,3 +75,38 @@ def test_first_case_offset_is_a_pure_function_of_index():
 
 def test_4k_blocks_sequences():
     _compare(util.corpus_uniform(256, 4096), BYTE_ALL + "," + SEQ + ",uw,ui", "od,nd,bu")
+
+
+LINES = "ld,lds,lr2,lri,lr,ls,lp,lis,lrs"
+
+
+def _texty(n, size, seed):
+    from erlamsa_amd import synth
+    m = synth.mixed(n * 2, size, seed=seed)
+    return [bytes(r) for r in m]
+
+
+@pytest.mark.parametrize("seed", [(1, 2, 3), (11, 22, 33)])
+def test_lines_and_num_mixed_corpus(seed):
+    _compare(_texty(300, 1024, seed[0]), LINES + ",num," + BYTE_ALL + ",sd", "od,nd,bu", seed=seed)
+
+
+def test_num_edge_cases():
+    inputs = [b" 100 + 100 + 100 ", b"-1", b"--5 x -0 007", b"9" * 400 + b"\n", b"x" * 2048, b"1\n" * 1100,
+              b"18446744073709551615 340282366920938463463374607431768211455\n", b"abc", b"0", b"1-2-3",
+              b"12345678901234567890123456789012345678901234567890" * 7, b"A\n B\n", b"1\n"] * 40
+    _compare(inputs, "num", "od,nd,bu")
+    _compare(inputs, "num," + LINES, "od,nd,bu", seed=(5, 6, 7))
+
+
+def test_lines_small_texts():
+    rng = np.random.Generator(np.random.PCG64(9))
+    inputs = []
+    for i in range(600):
+        nl = int(rng.integers(0, 12))
+        parts = [bytes(rng.integers(97, 123, size=int(rng.integers(0, 9)), dtype=np.uint8)) for _ in range(nl + 1)]
+        s = b"\n".join(parts)
+        if rng.random() < 0.5:
+            s += b"\n"
+        inputs.append(s)
+    _compare(inputs, LINES, "od,nd,bu")
