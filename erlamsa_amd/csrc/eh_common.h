@@ -97,6 +97,8 @@ struct KParams {
   int32_t* status;
   uint64_t* draws;
   int32_t* lastm;
+  uint64_t* cycles;           // per-case shader-clock ticks (diagnostic)
+  unsigned long long* prof;   // EH_PROF builds: [2*k] cycles, [2*k+1] calls; k < 64 mutator fn, 64.. phases
   unsigned long long* ticket;
   unsigned long long* in_bytes;
 };

@@ -126,7 +126,20 @@ EH_DEV void wave_copy(uint8_t* dst, const uint8_t* src, uint32_t n) {
   if ((uint32_t)l < head) dst[l] = src[l];
   dst += head; src += head; n -= head;
   uint32_t nv = n >> 4;
-  for (uint32_t i = l; i < nv; i += 64) {
+  uint32_t i = l;
+  // 4 independent 16-byte loads in flight per lane (4 KiB per wave per round trip)
+  for (; i + 192 < nv; i += 256) {
+    uint4 v0, v1, v2, v3;
+    __builtin_memcpy(&v0, src + 16 * (size_t)i, 16);
+    __builtin_memcpy(&v1, src + 16 * (size_t)(i + 64), 16);
+    __builtin_memcpy(&v2, src + 16 * (size_t)(i + 128), 16);
+    __builtin_memcpy(&v3, src + 16 * (size_t)(i + 192), 16);
+    *reinterpret_cast<uint4*>(dst + 16 * (size_t)i) = v0;
+    *reinterpret_cast<uint4*>(dst + 16 * (size_t)(i + 64)) = v1;
+    *reinterpret_cast<uint4*>(dst + 16 * (size_t)(i + 128)) = v2;
+    *reinterpret_cast<uint4*>(dst + 16 * (size_t)(i + 192)) = v3;
+  }
+  for (; i < nv; i += 64) {
     uint4 v;
     __builtin_memcpy(&v, src + 16 * (size_t)i, 16);  // unaligned dwordx4 load
     *reinterpret_cast<uint4*>(dst + 16 * (size_t)i) = v;
@@ -134,35 +147,39 @@ EH_DEV void wave_copy(uint8_t* dst, const uint8_t* src, uint32_t n) {
   uint32_t done = nv << 4;
   if (done + l < n) dst[done + l] = src[done + l];
 }
-// dst[i] = pat[i % plen], i < total
+// dst[i] = pat[i % plen], i < total.  The first copy is written directly, the rest by doubling
+// (dst[0,k) -> dst[k,2k)) so that all but the first plen bytes move as 16-byte vectors.
 EH_DEV void wave_fill_periodic(uint8_t* dst, const uint8_t* pat, uint32_t plen, uint64_t total) {
-  const int l = EH_LANE;
-  if (plen == 1) {
-    uint8_t b = pat[0];
-    for (uint64_t i = l; i < total; i += 64) dst[i] = b;
-    return;
+  if (total == 0) return;
+  uint64_t have = plen < total ? plen : total;
+  wave_copy(dst, pat, (uint32_t)have);
+  while (have < total) {
+    wave_sync();
+    uint64_t chunk = have < total - have ? have : total - have;
+    // copy in <= 1 GiB pieces (32-bit length of wave_copy)
+    uint64_t done = 0;
+    while (done < chunk) { uint32_t c = chunk - done > 0x40000000ull ? 0x40000000u : (uint32_t)(chunk - done); wave_copy(dst + have + done, dst + done, c); done += c; }
+    have += chunk;
   }
-  if (plen >= 256) {  // long pattern: copy it repeatedly with the vector mover
-    uint64_t reps = total / plen;
-    for (uint64_t r = 0; r < reps; r++) wave_copy(dst + r * plen, pat, plen);
-    return;
-  }
-  uint32_t ph = (uint32_t)l % plen, step = 64u % plen;
-  for (uint64_t i = l; i < total; i += 64) { dst[i] = pat[ph]; ph += step; if (ph >= plen) ph -= plen; }
 }
 // returns true if the two byte ranges are equal
 EH_DEV bool wave_equal(const uint8_t* a, const uint8_t* b, uint32_t n) {
   const int l = EH_LANE;
-  bool ne = false;
   uint32_t nv = n >> 4;
-  for (uint32_t i = l; i < nv; i += 64) {
-    uint4 x, y;
-    __builtin_memcpy(&x, a + 16 * (size_t)i, 16);
-    __builtin_memcpy(&y, b + 16 * (size_t)i, 16);
-    ne |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+  // uniform trip count (the early exit must be taken by the whole wave)
+  for (uint32_t base = 0; base < nv; base += 128) {
+    uint32_t i0 = base + l, i1 = base + 64 + l;
+    bool ne = false;
+    uint4 x0, y0, x1, y1;
+    if (i0 < nv) { __builtin_memcpy(&x0, a + 16 * (size_t)i0, 16); __builtin_memcpy(&y0, b + 16 * (size_t)i0, 16); }
+    if (i1 < nv) { __builtin_memcpy(&x1, a + 16 * (size_t)i1, 16); __builtin_memcpy(&y1, b + 16 * (size_t)i1, 16); }
+    if (i0 < nv) ne |= (x0.x != y0.x) | (x0.y != y0.y) | (x0.z != y0.z) | (x0.w != y0.w);
+    if (i1 < nv) ne |= (x1.x != y1.x) | (x1.y != y1.y) | (x1.z != y1.z) | (x1.w != y1.w);
+    if (__ballot(ne) != 0) return false;
   }
   uint32_t done = nv << 4;
-  if (done + l < n) ne |= a[done + l] != b[done + l];
+  bool ne = false;
+  if (done + l < n) ne = a[done + l] != b[done + l];
   return __ballot(ne) == 0;
 }
 
@@ -190,6 +207,7 @@ struct Ctx {
   uint32_t r_len;
   int r_flush;         // result goes through flush_bvecs/2
   int r_drop_next;     // fn consumed the following block
+  int r_changed;       // mutator guarantees hd(result) != hd(input): skip the compare
   // per-lane mux_fuzzers entry (lane i = list position i)
   uint32_t e_pri;
   uint32_t e_meta;     // score | fn<<8 | name<<16 | mask<<24
@@ -273,7 +291,7 @@ EH_DEV int muta_byte(Ctx& c, int fn) {
   wave_copy(dst, src, p);
   if (EH_LANE == 0) { if (repl >= 1) dst[p] = (uint8_t)nb0; if (repl == 2) dst[p + 1] = (uint8_t)nb1; }
   wave_copy(dst + p + repl, src + p + 1, L - p - 1);
-  c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = nl;
+  c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = nl; c.r_changed = 1;   // length or the byte value differs
   return d;
 }
 
@@ -282,18 +300,30 @@ EH_DEV int muta_byte(Ctx& c, int fn) {
 // entries carry hi = ~0.
 // ---------------------------------------------------------------------------------------------
 struct Key2 { uint64_t hi, lo; };
+EH_DEV bool key2_gt(const Key2& a, const Key2& b) { return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo); }
 EH_DEV void wave_sort_key2(Key2* k, uint32_t n_pow2) {
   const int l = EH_LANE;
+  const uint32_t half = n_pow2 >> 1;
   for (uint32_t size = 2; size <= n_pow2; size <<= 1) {
     for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
       wave_sync();
-      for (uint32_t t = l; t < (n_pow2 >> 1); t += 64) {
+      uint32_t t = l;
+      for (; t + 192 < half; t += 256) {   // 4 compare-exchanges (8 loads) in flight per lane
+        uint32_t i0 = 2 * t - (t & (stride - 1)), i1 = 2 * (t + 64) - ((t + 64) & (stride - 1));
+        uint32_t i2 = 2 * (t + 128) - ((t + 128) & (stride - 1)), i3 = 2 * (t + 192) - ((t + 192) & (stride - 1));
+        Key2 a0 = k[i0], b0 = k[i0 + stride], a1 = k[i1], b1 = k[i1 + stride];
+        Key2 a2 = k[i2], b2 = k[i2 + stride], a3 = k[i3], b3 = k[i3 + stride];
+        if (key2_gt(a0, b0) == ((i0 & size) == 0)) { k[i0] = b0; k[i0 + stride] = a0; }
+        if (key2_gt(a1, b1) == ((i1 & size) == 0)) { k[i1] = b1; k[i1 + stride] = a1; }
+        if (key2_gt(a2, b2) == ((i2 & size) == 0)) { k[i2] = b2; k[i2 + stride] = a2; }
+        if (key2_gt(a3, b3) == ((i3 & size) == 0)) { k[i3] = b3; k[i3 + stride] = a3; }
+      }
+      for (; t < half; t += 64) {
         uint32_t i = 2 * t - (t & (stride - 1));  // lower index of the pair
         uint32_t j = i + stride;
         bool up = ((i & size) == 0);
         Key2 a = k[i], b = k[j];
-        bool gt = a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo);
-        if (gt == up) { k[i] = b; k[j] = a; }
+        if (key2_gt(a, b) == up) { k[i] = b; k[j] = a; }
       }
     }
   }
@@ -317,7 +347,7 @@ EH_DEV int muta_seq(Ctx& c, int fn, int mask_fun) {
   switch (fn) {
     case M_SD: {                                           // :273-276
       uint8_t* dst = ws_alloc(c, B - Lp);
-      if (dst) { wave_copy(dst, src, S); wave_copy(dst + S, P + Lp, tl); c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = B - Lp; }
+      if (dst) { wave_copy(dst, src, S); wave_copy(dst + S, P + Lp, tl); c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = B - Lp; c.r_changed = 1; }
       break;
     }
     case M_SR: {                                           // :263-270
@@ -328,7 +358,7 @@ EH_DEV int muta_seq(Ctx& c, int fn, int mask_fun) {
         wave_copy(dst, src, S);
         wave_fill_periodic(dst + S, P, Lp, (uint64_t)Lp * n);
         wave_copy(dst + S + (uint64_t)Lp * n, P + Lp, tl);
-        c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)nl;
+        c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)nl; c.r_changed = 1;
       }
       break;
     }
@@ -364,31 +394,81 @@ EH_DEV int muta_seq(Ctx& c, int fn, int mask_fun) {
       break;
     }
     case M_SNAND:
-    case M_SRND: {                                         // randmask :281-307 — sequential draw chain
+    case M_SRND: {
+      // randmask/2 + randmask_loop/5 (:281-293).  Draw stream after MaskProb and the first
+      // rand_occurs: per byte one "occurs" draw (for the NEXT byte; argument order of the
+      // recursive call) and, when the byte's own flag is set, one mask draw.  Over the draw index
+      // this is a 4-state automaton (O0,O1 = occurs-draw with the current flag 0/1; M0,M1 = mask
+      // draw carrying the next flag), so 64 draws are resolved at once: every lane evaluates its
+      // uniform by jump-ahead, the transition maps are composed with a shuffle prefix scan, and
+      // ballots assign draws to bytes.
       uint8_t* dst = ws_alloc(c, B);
       if (!dst) break;
-      wave_copy(dst, src, S);
-      wave_copy(dst + S + Lp, P + Lp, tl);
+      wave_copy(dst, src, B);
       uint32_t prob = rng_erand(c.rng, 100);
       bool occ = rng_occurs(c.rng, prob, 100);
-      for (uint32_t base = 0; base < Lp; base += 64) {
-        uint32_t chunk = Lp - base < 64 ? Lp - base : 64;
-        uint32_t mine = (uint32_t)l < chunk ? P[base + l] : 0;
-        for (uint32_t j = 0; j < chunk; j++) {
-          bool next = rng_occurs(c.rng, prob, 100);        // drawn before MaskFun(H) (argument order)
-          if (occ) {
-            uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)j);
-            uint32_t nbv;
-            if (mask_fun == 3) nbv = rng_rand(c.rng, 256);
-            else {
-              uint32_t m = 1u << rng_rand(c.rng, 8);
-              nbv = mask_fun == 0 ? (b & ~m) : (mask_fun == 1 ? (b | m) : (b ^ m));
-            }
-            if ((uint32_t)l == j) mine = nbv & 255;
+      uint32_t byte0 = 0;                    // first byte whose occurs-draw is still pending
+      uint32_t st = occ ? 1u : 0u;           // automaton state before the next draw: 0=O0 1=O1 2=M0 3=M1
+      wave_sync();
+      while (byte0 < Lp) {
+        double u = rng_peek(c.rng, (uint32_t)l + 1);
+        uint32_t n100 = (uint32_t)(u * 100.0);
+        uint32_t F = prob == 1 ? (n100 != 0 ? 1u : 0u) : (n100 < prob ? 1u : 0u);
+        // transition map of this draw, 2 bits per source state: O0->O_F, O1->M_F, M0->O0, M1->O1
+        uint32_t tm = (F) | ((2u + F) << 2) | (0u << 4) | (1u << 6);
+        // inclusive scan of map composition: comp(a then b)[s] = b[a[s]]
+        uint32_t inc = tm;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          uint32_t prev = (uint32_t)__shfl_up((int)inc, d);
+          if (l >= d) {
+            uint32_t r = 0;
+#pragma unroll
+            for (int sidx = 0; sidx < 4; sidx++) { uint32_t mid = (prev >> (2 * sidx)) & 3u; r |= ((inc >> (2 * mid)) & 3u) << (2 * sidx); }
+            inc = r;
           }
-          occ = next;
         }
-        if ((uint32_t)l < chunk) dst[S + base + l] = (uint8_t)mine;
+        uint32_t excl = (uint32_t)__shfl_up((int)inc, 1);
+        uint32_t my_state = l == 0 ? st : ((excl >> (2 * st)) & 3u);   // state BEFORE my draw
+        bool is_o = my_state < 2;
+        unsigned long long omask = __ballot(is_o);
+        uint32_t o_before = (uint32_t)__popcll(omask & ((1ull << l) - 1));
+        // byte index served by my draw: an O-draw belongs to byte byte0+o_before; an M-draw to the
+        // byte of the preceding O-draw
+        uint32_t bidx = is_o ? byte0 + o_before : byte0 + o_before - 1;
+        // the stream ends after the O-draw of byte Lp-1 and, if that byte's flag is set, its M-draw
+        bool valid = is_o ? (bidx < Lp) : (bidx < Lp);
+        // an M-draw at the very start of a chunk (state M*) belongs to byte0-1 which is < Lp by construction
+        unsigned long long vmask = __ballot(valid);
+        uint32_t nvalid = vmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~vmask);   // valid draws form a prefix
+        if (!is_o && (uint32_t)l < nvalid) {
+          uint32_t old = P[bidx];
+          uint32_t nbv;
+          if (mask_fun == 3) nbv = (uint32_t)(u * 256.0);
+          else { uint32_t m = 1u << (uint32_t)(u * 8.0); nbv = mask_fun == 0 ? (old & ~m) : (mask_fun == 1 ? (old | m) : (old ^ m)); }
+          dst[S + bidx] = (uint8_t)nbv;
+        }
+        // advance: state after the last valid draw, bytes whose O-draw happened
+        uint32_t last = nvalid - 1;
+        uint32_t new_st = (uint32_t)__builtin_amdgcn_readlane((int)((inc >> (2 * st)) & 3u), (int)last);
+        uint32_t o_done = (uint32_t)__popcll(omask & (nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1)));
+        rng_skip(c.rng, nvalid);
+        byte0 += o_done;
+        st = uni(new_st);
+        if (nvalid < 64) break;
+      }
+      // If the loop ended exactly at a chunk boundary with the last byte's M-draw still pending
+      // (state M*), it is consumed here.
+      if (byte0 >= Lp && st >= 2) {
+        double u = rng_uniform(c.rng);
+        if (l == 0) {
+          uint32_t old = P[Lp - 1];
+          uint32_t nbv;
+          if (mask_fun == 3) nbv = (uint32_t)(u * 256.0);
+          else { uint32_t m = 1u << (uint32_t)(u * 8.0); nbv = mask_fun == 0 ? (old & ~m) : (mask_fun == 1 ? (old | m) : (old ^ m)); }
+          dst[S + Lp - 1] = (uint8_t)nbv;
+        }
+        st = 0;
       }
       c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = B;
       break;
@@ -472,9 +552,15 @@ EH_DEV void mux_fuzzers(Ctx& c) {
     int j = (int)__builtin_ctzll(who);
     uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)c.e_meta, j);
     uint32_t fn = em_fn(meta), name = em_name(meta);
-    c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0;
+    c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0;
     uint64_t mark = c.ws_used;
+#ifdef EH_PROF
+    uint64_t pt0 = __builtin_readcyclecounter();
+#endif
     int delta = run_mutator(c, fn, em_mask(meta));
+#ifdef EH_PROF
+    if (l == 0) { atomicAdd(&c.p->prof[2 * fn], (unsigned long long)(__builtin_readcyclecounter() - pt0)); atomicAdd(&c.p->prof[2 * fn + 1], 1ull); }
+#endif
     if (c.status != CASE_OK) return;
     // adjust_priority :1238-1242
     uint32_t sc = em_score(meta);
@@ -485,7 +571,7 @@ EH_DEV void mux_fuzzers(Ctx& c) {
     bool changed = false;
     if (c.r_kind == R_NEW) {
       uint32_t hd_len = c.r_flush && c.r_len >= AVG_BLOCK_SIZE ? AVG_BLOCK_SIZE : c.r_len;
-      changed = hd_len != h0.len || !wave_equal(c.r_ptr, (const uint8_t*)h0.ptr, hd_len);
+      changed = c.r_changed || hd_len != h0.len || !wave_equal(c.r_ptr, (const uint8_t*)h0.ptr, hd_len);
     }
     if (changed) { c.lastm = (int)name; commit_result(c); used = true; break; }
     c.ws_used = mark;                                                             // discard candidate

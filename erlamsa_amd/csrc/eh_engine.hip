@@ -227,7 +227,10 @@ EH_DEV void gen_random(Ctx& c) {                                       // random
 // =============================================================================================
 // the mutate kernel
 // =============================================================================================
-__global__ void __launch_bounds__(64) eh_mutate_kernel(KParams p) {
+#ifndef EH_WAVES_PER_SIMD
+#define EH_WAVES_PER_SIMD 2
+#endif
+__global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(KParams p) {
   const int l = EH_LANE;
   Ctx c;
   c.p = &p;
@@ -258,6 +261,7 @@ __global__ void __launch_bounds__(64) eh_mutate_kernel(KParams p) {
     uint64_t i = uni64(t);
     if (i >= p.n) break;
 
+    uint64_t tick0 = __builtin_readcyclecounter();
     c.status = CASE_OK; c.lastm = -1; c.nb = 0; c.cur = 0; c.nem = 0; c.ws_used = 0;
     c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0;
     if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; }
@@ -272,13 +276,21 @@ __global__ void __launch_bounds__(64) eh_mutate_kernel(KParams p) {
       int mask;
       setup_run(p.cfg, p.seeds[3 * i], p.seeds[3 * i + 1], p.seeds[3 * i + 2], pr, gen, mask, c.e_pri, c.e_meta, c.nfs);
     }
+#ifdef EH_PROF
+#define EH_PH(k) do { uint64_t now_ = __builtin_readcyclecounter(); if (l == 0) { atomicAdd(&p.prof[2 * (64 + (k))], (unsigned long long)(now_ - ph0)); atomicAdd(&p.prof[2 * (64 + (k)) + 1], 1ull); } ph0 = now_; } while (0)
+    uint64_t ph0 = tick0;
+#else
+#define EH_PH(k) do {} while (0)
+#endif
     int64_t t1 = (int64_t)rng_erand(pr, 99999), t2 = (int64_t)rng_erand(pr, 99999), t3 = (int64_t)rng_erand(pr, 99999);
     c.rng.draws = 0;
     rng_seed(c.rng, t1, t2, t3);                                        // worker: erlamsa_rnd:seed(ThreadSeed) :183
 
     uint64_t o0 = p.coff[p.corpus_first + i], o1 = p.coff[p.corpus_first + i + 1];
     o0 = uni64(o0); o1 = uni64(o1);
+    EH_PH(0);
     if (gen == G_DIRECT) gen_direct(c, p.corpus + o0, (uint32_t)(o1 - o0)); else gen_random(c);   // DataGen() :185
+    EH_PH(1);
 
     if (c.status == CASE_OK) {
       // choose_pattern_fun (erlamsa_patterns.erl:431-434) + choose_pri
@@ -291,6 +303,7 @@ __global__ void __launch_bounds__(64) eh_mutate_kernel(KParams p) {
       if (pat < 0) c.status = CASE_CRASHED; else run_patterns(c, pat);  // Pat(Ll, CurMuta, Meta) :189
     }
 
+    EH_PH(2);
     // ---- erlamsa_out:output/4: concatenate the written blocks into the output arena
     uint64_t total = 0;
     if (c.status == CASE_OK) for (int k = 0; k < c.nem; k++) total += blk_load(c.em, k).len;
@@ -305,10 +318,23 @@ __global__ void __launch_bounds__(64) eh_mutate_kernel(KParams p) {
       uint64_t pos = base;
       for (int k = 0; k < c.nem; k++) { Blk b = blk_load(c.em, k); wave_copy(p.out + pos, (const uint8_t*)b.ptr, b.len); pos += b.len; }
     }
+    EH_PH(3);
     if (l == 0) {
       p.out_off[i] = base; p.out_len[i] = total; p.status[i] = c.status;
-      p.draws[i] = c.rng.draws; p.lastm[i] = c.lastm;
+      p.draws[i] = c.rng.draws; p.lastm[i] = c.lastm; p.cycles[i] = __builtin_readcyclecounter() - tick0;
     }
+    wave_sync();
+  }
+}
+
+// kernel-level self tests of the byte movers (driven by tests/test_gpu_primitives.py)
+__global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf, const uint32_t* jobs, uint32_t njobs, uint32_t* eq_out) {
+  // job = {kind, dst_off, src_off, n, plen}: kind 0 copy, 1 periodic fill, 2 equal
+  for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
+    uint32_t kind = jobs[5 * j], d = jobs[5 * j + 1], s = jobs[5 * j + 2], n = jobs[5 * j + 3], pl = jobs[5 * j + 4];
+    if (kind == 0) wave_copy(buf + d, buf + s, n);
+    else if (kind == 1) wave_fill_periodic(buf + d, buf + s, pl, n);
+    else { bool e = wave_equal(buf + d, buf + s, n); if (EH_LANE == 0) eq_out[j] = e ? 1u : 0u; }
     wave_sync();
   }
 }
@@ -346,7 +372,7 @@ struct eh_ctx {
   uint8_t* d_slots = nullptr; uint64_t slot_stride = 0, work_cap = 0; uint32_t nslots = 0;
   // outputs
   uint8_t* d_out = nullptr; uint64_t out_cap = 0;
-  uint64_t* d_off = nullptr; uint64_t* d_len = nullptr; int32_t* d_status = nullptr; uint64_t* d_draws = nullptr; int32_t* d_lastm = nullptr;
+  uint64_t* d_off = nullptr; uint64_t* d_len = nullptr; int32_t* d_status = nullptr; uint64_t* d_draws = nullptr; int32_t* d_lastm = nullptr; uint64_t* d_cycles = nullptr;
   uint64_t res_cap = 0;
   unsigned long long* d_counters = nullptr;  // [0] ticket, [1] out cursor
   RunState* d_run = nullptr;
@@ -495,7 +521,8 @@ static int build_funny(uint8_t (*out)[5]) {
 
 static int ensure_results(eh_ctx* ctx, uint64_t n) {
   if (n <= ctx->res_cap) return EH_OK;
-  if (ctx->d_off) { (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len); (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); }
+  if (ctx->d_off) { (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len); (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); }
+  HIPCHK(ctx, hipMalloc(&ctx->d_cycles, n * 8));
   HIPCHK(ctx, hipMalloc(&ctx->d_off, n * 8));
   HIPCHK(ctx, hipMalloc(&ctx->d_len, n * 8));
   HIPCHK(ctx, hipMalloc(&ctx->d_status, n * 4));
@@ -533,8 +560,8 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
     HIPCHK(ctx, hipMalloc(&ctx->d_out, want_out));
     ctx->out_cap = want_out;
   }
-  if (!ctx->d_counters) { HIPCHK(ctx, hipMalloc(&ctx->d_counters, 64)); HIPCHK(ctx, hipMalloc(&ctx->d_run, sizeof(RunState))); }
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 64, st));
+  if (!ctx->d_counters) { HIPCHK(ctx, hipMalloc(&ctx->d_counters, 4096)); HIPCHK(ctx, hipMalloc(&ctx->d_run, sizeof(RunState))); }
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 4096, st));
 
   KParams p;
   memset(&p, 0, sizeof(p));
@@ -542,8 +569,8 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.mode = mode; p.run = ctx->d_run; p.seeds = ctx->d_seeds; p.cfg = ctx->cfg;
   p.slot_base = ctx->d_slots; p.slot_stride = ctx->slot_stride; p.work_cap = ctx->work_cap;
   p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
-  p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm;
-  p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2;
+  p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles;
+  p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;
 
   if (mode == 0) hipLaunchKernelGGL(eh_setup_kernel, dim3(1), dim3(64), 0, st, ctx->cfg, seed[0], seed[1], seed[2], ctx->d_run);
   HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
@@ -617,7 +644,7 @@ void eh_destroy(eh_ctx* ctx) {
   (void)hipDeviceSynchronize();
   if (ctx->own_corpus) { (void)hipFree(ctx->d_corpus); (void)hipFree(ctx->d_coff); }
   (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
-  (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_counters);
+  (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_run); (void)hipFree(ctx->d_seeds);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -785,6 +812,37 @@ int eh_result_diag(eh_ctx* ctx, uint64_t* draws, int32_t* last_mutator) {
   uint64_t n = ctx->last_n;
   if (draws && n) HIPCHK(ctx, hipMemcpy(draws, ctx->d_draws, n * 8, hipMemcpyDeviceToHost));
   if (last_mutator && n) HIPCHK(ctx, hipMemcpy(last_mutator, ctx->d_lastm, n * 4, hipMemcpyDeviceToHost));
+  return EH_OK;
+}
+int eh_result_cycles(eh_ctx* ctx, uint64_t* cycles) {
+  if (!ctx || !cycles) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  int rc = eh_sync(ctx); if (rc) return rc;
+  if (ctx->last_n) HIPCHK(ctx, hipMemcpy(cycles, ctx->d_cycles, ctx->last_n * 8, hipMemcpyDeviceToHost));
+  return EH_OK;
+}
+int eh_result_prof(eh_ctx* ctx, uint64_t* prof /* 256 values */) {
+  if (!ctx || !prof) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  int rc = eh_sync(ctx); if (rc) return rc;
+  HIPCHK(ctx, hipMemcpy(prof, ctx->d_counters + 8, 256 * 8, hipMemcpyDeviceToHost));
+  return EH_OK;
+}
+// Self test hook: runs `njobs` byte-mover jobs ({kind,dst,src,n,plen} x uint32) on a caller
+// supplied buffer image; jobs must touch disjoint destination ranges.  Returns the buffer.
+int eh_selftest_movers(eh_ctx* ctx, uint8_t* buf, uint64_t buf_len, const uint32_t* jobs, uint32_t njobs, uint32_t* eq_out) {
+  if (!ctx || !buf || !jobs) return EH_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  uint8_t* d = nullptr; uint32_t* dj = nullptr; uint32_t* de = nullptr;
+  HIPCHK(ctx, hipMalloc(&d, buf_len)); HIPCHK(ctx, hipMalloc(&dj, njobs * 20)); HIPCHK(ctx, hipMalloc(&de, njobs * 4));
+  HIPCHK(ctx, hipMemcpy(d, buf, buf_len, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(dj, jobs, njobs * 20, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemset(de, 0, njobs * 4));
+  hipLaunchKernelGGL(eh_test_copy_kernel, dim3(njobs < 256 ? njobs : 256), dim3(64), 0, 0, d, dj, njobs, de);
+  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, hipMemcpy(buf, d, buf_len, hipMemcpyDeviceToHost));
+  if (eq_out) HIPCHK(ctx, hipMemcpy(eq_out, de, njobs * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d); (void)hipFree(dj); (void)hipFree(de);
   return EH_OK;
 }
 int eh_last_kernel_ms(eh_ctx* ctx, float* ms) {

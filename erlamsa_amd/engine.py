@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liberlamsa_hip.so")
+LIB_PATH = os.environ.get("ERLAMSA_HIP_LIB") or os.path.join(_HERE, "liberlamsa_hip.so")
 
 EH_ABI_VERSION = 1
 EH_FLAG_ORDERED_OUTPUT = 1
@@ -20,7 +20,7 @@ CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED = 0, 1, 2, 3
 # every symbol include/erlamsa_hip.h declares
 ABI_SYMBOLS = [
     "eh_create", "eh_destroy", "eh_configure", "eh_corpus_upload", "eh_corpus_attach", "eh_fuzz_batch",
-    "eh_fuzz_calls", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_totals", "eh_result_diag",
+    "eh_fuzz_calls", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_prof", "eh_selftest_movers",
     "eh_last_kernel_ms", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
@@ -65,6 +65,9 @@ def load_library():
     lib.eh_result_download.argtypes = [vp, vp, C.c_uint64, vp, vp]
     lib.eh_result_totals.argtypes = [vp, u64p, u64p, u64p]
     lib.eh_result_diag.argtypes = [vp, vp, vp]
+    lib.eh_result_cycles.argtypes = [vp, vp]
+    lib.eh_result_prof.argtypes = [vp, vp]
+    lib.eh_selftest_movers.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
     lib.eh_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.eh_kernel_name.restype = C.c_char_p
     lib.eh_abi_version.restype = C.c_uint32
@@ -197,6 +200,24 @@ class Engine:
         lastm = np.zeros(max(n, 1), dtype=np.int32)
         self._chk(self.lib.eh_result_diag(self.h, draws.ctypes.data, lastm.ctypes.data))
         return draws[:n], lastm[:n]
+
+    def cycles(self):
+        n = self.last_n
+        cyc = np.zeros(max(n, 1), dtype=np.uint64)
+        self._chk(self.lib.eh_result_cycles(self.h, cyc.ctypes.data))
+        return cyc[:n]
+
+    def prof(self):
+        pr = np.zeros(256, dtype=np.uint64)
+        self._chk(self.lib.eh_result_prof(self.h, pr.ctypes.data))
+        return pr
+
+    def selftest_movers(self, buf, jobs):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8).copy()
+        jobs = np.ascontiguousarray(jobs, dtype=np.uint32)
+        eq = np.zeros(len(jobs), dtype=np.uint32)
+        self._chk(self.lib.eh_selftest_movers(self.h, buf.ctypes.data, buf.size, jobs.ctypes.data, len(jobs), eq.ctypes.data))
+        return buf, eq
 
     def result_device(self):
         d, o, l, s = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()

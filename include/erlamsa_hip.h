@@ -110,6 +110,17 @@ int eh_result_totals(eh_ctx* ctx, uint64_t* in_bytes, uint64_t* out_bytes, uint6
  * the id (index in eh_mutator_name) of the last mutator that fired, -1 if none.  May be NULL. */
 int eh_result_diag(eh_ctx* ctx, uint64_t* draws, int32_t* last_mutator);
 
+/* Per-case shader-clock ticks spent by the wavefront that ran the case (diagnostic). */
+int eh_result_cycles(eh_ctx* ctx, uint64_t* cycles);
+
+/* Profiling builds (-DEH_PROF) only: prof[2k] = ticks, prof[2k+1] = calls; k < 64 is a mutator
+ * id, 64.. are phases (setup, generator, pattern+mutators, output copy).  256 values. */
+int eh_result_prof(eh_ctx* ctx, uint64_t* prof);
+
+/* Kernel self-test hook for the wave-level byte movers (tests only): jobs = njobs x
+ * {kind (0 copy, 1 periodic fill, 2 equal), dst_off, src_off, n, plen} over the buffer image. */
+int eh_selftest_movers(eh_ctx* ctx, uint8_t* buf, uint64_t buf_len, const uint32_t* jobs, uint32_t njobs, uint32_t* eq_out);
+
 /* Elapsed GPU time of the mutate kernel of the last batch in ms (HIP events on the launch
  * stream), and its name for matching against a rocprofv3 kernel trace. */
 int eh_last_kernel_ms(eh_ctx* ctx, float* ms);
