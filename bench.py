@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--patterns", default="od,nd,bu")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="cases timed on the CPU oracle (0 = skip)")
     ap.add_argument("--max-slots", type=int, default=0)
+    ap.add_argument("--out-gib", type=int, default=16, help="output arena capacity per GPU (GiB)")
     args = ap.parse_args()
 
     import numpy as np
@@ -69,7 +70,7 @@ def main():
     torch.cuda.synchronize()
 
     eng = ea.Engine(local)
-    eng.configure(mutations=muts, patterns=pats, max_slots=args.max_slots)
+    eng.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30)
     eng.attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
     stream = torch.cuda.current_stream().cuda_stream
     seed = (1, 2, 3)
@@ -87,6 +88,7 @@ def main():
     t0 = time.perf_counter()
     out_bytes = 0
     kern_ms = []
+    status_counts = np.zeros(5, dtype=np.int64)
     for k in range(args.steps):
         step(args.warmup + k)
         # totals() waits for the batch (the next batch reuses the result buffers); the kernel time
@@ -94,6 +96,7 @@ def main():
         _, ob, _ = eng.totals()
         out_bytes += ob
         kern_ms.append(eng.kernel_ms())
+        status_counts += np.bincount(eng.status(), minlength=5)[:5]
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -129,6 +132,8 @@ def main():
                             % (n, size, pats, muts, len(muts.split(",")), nmut_total),
                 "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world,
             },
+            "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(max_case_bytes)", "unsupported", "arena_full"],
+                                    [int(x) for x in status_counts])),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel": ea.load_library().eh_kernel_name().decode(), "kernel_ms_avg": round(avg_kern_s * 1e3, 3),

@@ -91,18 +91,25 @@ EH_DEV void wave_collect(const uint8_t* p, uint32_t n, uint32_t r0, uint32_t r1,
   wave_sync();
 }
 
-// erlamsa_utils:binarish/1 (erlamsa_utils.erl:238-247)
+// erlamsa_utils:binarish/1 (erlamsa_utils.erl:238-247): one load of the first 11 bytes, the
+// clause order is then replayed on registers.
 EH_DEV bool binarish(const uint8_t* p, uint32_t n) {
-  for (uint32_t pos = 0;; pos++) {
-    uint32_t rem = n - pos;
-    uint32_t b0 = rem > 0 ? uni(p[pos]) : 0, b1 = rem > 1 ? uni(p[pos + 1]) : 0, b2 = rem > 2 ? uni(p[pos + 2]) : 0;
-    if (rem >= 3 && b0 == 0xEF && b1 == 0xBB && b2 == 0xBF) return false;
-    if (rem >= 2 && b0 == 0xFE && b1 == 0x0F) return false;
+  const int l = EH_LANE;
+  uint32_t mine = (uint32_t)l < n && l < 11 ? p[l] : 0;
+  uint32_t b[11];
+#pragma unroll
+  for (int k = 0; k < 11; k++) b[k] = (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
+#pragma unroll
+  for (uint32_t pos = 0; pos <= 8; pos++) {
+    uint32_t rem = n > pos ? n - pos : 0;
+    if (rem >= 3 && b[pos] == 0xEF && b[pos + 1] == 0xBB && b[pos + 2] == 0xBF) return false;
+    if (rem >= 2 && b[pos] == 0xFE && b[pos + 1] == 0x0F) return false;
     if (pos == 8) return false;
     if (rem == 0) return false;
-    if (b0 == 0) return true;
-    if (b0 & 128) return true;
+    if (b[pos] == 0) return true;
+    if (b[pos] & 128) return true;
   }
+  return false;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -445,23 +452,44 @@ EH_DEV int muta_num(Ctx& c) {                                  // sed_num :154-1
     return r == 0 ? -1 : 0;
   }
   uint32_t s = wave_find_kth(H, L, nfound - 1 - which, IsDigitStart());
-  // end of the digit run / start of the dash run: sequential from s (numbers are short in practice)
-  uint32_t e = s, a = s;
+  // end of the digit run / start of the dash run.  Fast path: one 64-byte window each way,
+  // resolved with ballots; runs longer than the window fall back to a lane-0 walk.
+  uint32_t e, a; bool fast_parse = false; uint64_t mag = 0;
   {
-    uint32_t ee = s, aa = s;
-    if (l == 0) {
-      while (ee < L && H[ee] >= 48 && H[ee] <= 57) ee++;
-      while (aa > 0 && H[aa - 1] == 45) aa--;
+    uint32_t idx = s + (uint32_t)l;
+    uint32_t ch = idx < L ? H[idx] : 0;
+    unsigned long long dm = __ballot(ch >= 48 && ch <= 57);
+    uint32_t run = dm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~dm);
+    uint32_t ch2 = (uint32_t)l < s ? H[s - 1 - (uint32_t)l] : 0;
+    unsigned long long mm = __ballot((uint32_t)l < s && ch2 == 45);
+    uint32_t dr = mm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~mm);
+    if (run < 64 && dr < 64) {
+      e = s + run; a = s - dr;
+      if (run <= 18) {
+        fast_parse = true;
+        uint64_t part = 0;
+        if ((uint32_t)l < run) { uint64_t pw = 1; for (uint32_t k = (uint32_t)l + 1; k < run; k++) pw *= 10; part = (uint64_t)(ch - 48) * pw; }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += ((uint64_t)(uint32_t)__shfl_xor((int)(part >> 32), d) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)part, d);
+        mag = uni64(part);
+      }
+    } else {
+      uint32_t ee = s, aa = s;
+      if (l == 0) {
+        while (ee < L && H[ee] >= 48 && H[ee] <= 57) ee++;
+        while (aa > 0 && H[aa - 1] == 45) aa--;
+      }
+      e = uni(ee); a = uni(aa);
     }
-    e = uni(ee); a = uni(aa);
   }
   bool negsign = a < s;
   uint32_t nd = e - s;
-  // ---- mutate_num/2 :93-112 : draws first (uniform), arithmetic on lane 0
+  // ---- mutate_num/2 :93-112 : draws first (uniform), arithmetic afterwards
   uint32_t op = rng_rand(c.rng, 12);
   uint32_t ielem = 0, rl_n = 0, rl_s = 0; double u9 = 0.0; double u_hi = 0.0; uint32_t rl_k = 0;
   bool is_zero_num = false;
-  {  // is the parsed value zero? (needed to know whether case 9 draws)
+  if (fast_parse) is_zero_num = mag == 0;
+  else {  // is the parsed value zero? (needed to know whether case 9 draws)
     uint32_t nz = 0;
     if (l == 0) { for (uint32_t k = s; k < e; k++) if (H[k] != 48) { nz = 1; break; } }
     is_zero_num = uni(nz) == 0;
@@ -473,6 +501,78 @@ EH_DEV int muta_num(Ctx& c) {                                  // sed_num :154-1
     rl_k = rng_rand(c.rng, rl_n);                              // rand_log: rand_nbit(rand(N))
     if (rl_k > 0) u_hi = rng_uniform(c.rng);                   // rand(Hi), Hi = 2^(k-1)
     rl_s = rng_rand(c.rng, 3);
+  }
+  // ---- register fast path: |Num| < 10^18 and an operand below 2^120: signed 128-bit arithmetic,
+  // digits produced one per lane.
+  bool fast_op = fast_parse && !((op == 4 || op == 5 || op == 7 || op == 8) && ielem < 6) && !((op == 6 || op == 11) && rl_k > 120);
+  if (fast_op) {
+    __int128 v = negsign ? -(__int128)mag : (__int128)mag;
+    __int128 r = 0;
+    auto inum = [](uint32_t idx) -> __int128 {                 // interesting_numbers/0, idx >= 6
+      const int is[11] = {128, 127, 64, 63, 32, 31, 16, 15, 8, 7, 1};
+      int ex = 1;
+#pragma unroll
+      for (int k = 2; k < 11; k++) if ((int)(idx / 3) == k) ex = is[k];
+      __int128 x = (__int128)1 << ex; int w = (int)(idx % 3);
+      return w == 0 ? x - 1 : (w == 1 ? x : x + 1);
+    };
+    switch (op) {
+      case 0: r = v + 1; break;
+      case 1: r = v - 1; break;
+      case 2: r = 0; break;
+      case 3: r = 1; break;
+      case 4: case 5: r = inum(ielem); break;
+      case 7: r = v + inum(ielem); break;
+      case 8: r = v - inum(ielem); break;
+      case 9: {
+        if (mag == 0) { r = 0; break; }
+        double f = (double)(mag * 2);
+        double x = u9 * f;
+        uint64_t rr = (uint64_t)x;
+        r = negsign ? v + (__int128)rr : v - (__int128)rr;
+        break;
+      }
+      case 10: r = -v; break;
+      default: {
+        unsigned __int128 lv = 0;
+        if (rl_k > 0) {
+          unsigned __int128 hi = (unsigned __int128)1 << (rl_k - 1), rv = 0;
+          if (u_hi > 0.0) {
+            int ex; double m = frexp(u_hi, &ex); uint64_t mant = (uint64_t)ldexp(m, 53);
+            int sh = ex - 53 + (int)(rl_k - 1);
+            rv = sh >= 0 ? ((unsigned __int128)mant << sh) : (sh > -64 ? (unsigned __int128)(mant >> (-sh)) : 0);
+          }
+          lv = hi | rv;
+        }
+        r = rl_s == 0 ? v - (__int128)lv : v + (__int128)lv;
+        break;
+      }
+    }
+    bool rneg = r < 0;
+    unsigned __int128 m = rneg ? (unsigned __int128)(-r) : (unsigned __int128)r;
+    const unsigned __int128 P19 = (unsigned __int128)10000000000000000000ull;
+    uint64_t hi64 = (uint64_t)(m / P19), lo64 = (uint64_t)(m % P19);
+    hi64 = uni64(hi64); lo64 = uni64(lo64);
+    uint32_t dig = 0;
+    if (l < 39) {
+      uint64_t src = l < 19 ? lo64 : hi64; uint32_t j = l < 19 ? (uint32_t)l : (uint32_t)l - 19;
+      uint64_t pw = 1; for (uint32_t k = 0; k < j; k++) pw *= 10;
+      dig = (uint32_t)((src / pw) % 10);
+    }
+    unsigned long long nzm = __ballot(dig != 0);
+    uint32_t ndig = nzm == 0 ? 1u : 64u - (uint32_t)__builtin_clzll(nzm);
+    uint32_t sg = rneg ? 1u : 0u;
+    uint32_t tlen = sg + ndig;
+    uint32_t nlen = a + tlen + (L - e);
+    uint8_t* dst = ws_alloc(c, nlen);
+    if (!dst) return 0;
+    wave_copy(dst, H, a);
+    if ((uint32_t)l < ndig) dst[a + sg + (ndig - 1 - (uint32_t)l)] = (uint8_t)(48 + dig);
+    if (rneg && l == 63) dst[a] = 45;
+    wave_copy(dst + a + tlen, H + e, L - e);
+    wave_sync();
+    c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = nlen; c.r_flush = 1;
+    return binarish(dst, nlen) ? -1 : 2;
   }
   // work arrays (lane 0): limbs for value, operand, result
   uint32_t nl = (nd + 8) / 9 + 8;

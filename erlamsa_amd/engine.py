@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("ERLAMSA_HIP_LIB") or os.path.join(_HERE, "liberlamsa_
 EH_ABI_VERSION = 1
 EH_FLAG_ORDERED_OUTPUT = 1
 
-CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED = 0, 1, 2, 3
+CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL = 0, 1, 2, 3, 4
 
 # every symbol include/erlamsa_hip.h declares
 ABI_SYMBOLS = [
@@ -193,6 +193,12 @@ class Engine:
         buf = data.tobytes()
         outs = [buf[int(off[i]):int(off[i + 1])] for i in range(n)]
         return outs, status[:n]
+
+    def status(self):
+        n = self.last_n
+        st = np.zeros(max(n, 1), dtype=np.int32)
+        self._chk(self.lib.eh_result_download(self.h, None, 0, None, st.ctypes.data))
+        return st[:n]
 
     def diag(self):
         n = self.last_n

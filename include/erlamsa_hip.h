@@ -55,8 +55,10 @@ enum eh_case_status {
   EH_CASE_CRASHED = 1,     /* the reference worker would have died (badmatch/badarith...):
                               output is <<>> (erlamsa_main.erl:211-220) */
   EH_CASE_OVERFLOW = 2,    /* exceeded max_case_bytes / block-table / arena capacity: output empty */
-  EH_CASE_UNSUPPORTED = 3  /* reached a container success path (zip/zlib re-encode) that is not
+  EH_CASE_UNSUPPORTED = 3, /* reached a container success path (zip/zlib re-encode) that is not
                               implemented; output empty, caller should route the case to BEAM */
+  EH_CASE_ARENA_FULL = 4   /* the output arena (eh_options.out_capacity) was exhausted; re-run the
+                              case with a larger arena */
 };
 
 typedef struct eh_options {
@@ -70,7 +72,7 @@ typedef struct eh_options {
   const char* ssrf_host;     /* NULL => "localhost" */
   int32_t ssrf_port;         /* 0 => 51234 */
   uint64_t max_case_bytes;   /* per-case working-set cap; 0 => default (8 MiB) */
-  uint64_t out_capacity;     /* output arena bytes; 0 => 2 x corpus bytes + 256 MiB */
+  uint64_t out_capacity;     /* output arena bytes; 0 => 8 x batch input bytes + 1 GiB */
   uint32_t max_slots;        /* resident wavefront slots; 0 => auto */
   uint32_t flags;            /* EH_FLAG_* */
 } eh_options;

@@ -13,7 +13,7 @@ pats = sys.argv[3] if len(sys.argv) > 3 else "od,nd,bu"
 mat = synth.mixed(n, 4096)
 data, off = synth.as_arena(mat)
 eng = ea.Engine(0)
-eng.configure(mutations=muts, patterns=pats)
+eng.configure(mutations=muts, patterns=pats, out_capacity=8 << 30)
 eng.upload_corpus(data, off)
 eng.fuzz_batch(seed=(1, 2, 3))
 outs, st = eng.download()
@@ -21,7 +21,7 @@ cyc = eng.cycles().astype(np.float64)
 dr, lm = eng.diag()
 names = [m[0] for m in ea.mutator_table()]
 print("kernel ms", eng.kernel_ms(), "cases", n, "total Mcycles", cyc.sum() / 1e6, "max Mcycles", cyc.max() / 1e6, "median kcycles", np.median(cyc) / 1e3)
-print("status counts", np.bincount(st, minlength=4), "output MB", sum(map(len, outs)) / 1e6)
+print("status counts", np.bincount(st, minlength=5), "output MB", sum(map(len, outs)) / 1e6)
 order = np.argsort(-cyc)
 print("top cases:")
 for i in order[:12]:
