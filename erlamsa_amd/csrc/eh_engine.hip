@@ -22,6 +22,7 @@
 #include "../../include/erlamsa_hip.h"
 #include "eh_device.h"
 #include "eh_text.h"
+#include "eh_lex.h"
 
 namespace eh {
 
@@ -35,6 +36,10 @@ EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
     case M_LIS: return muta_st_line(c, (int)fn, st);
     case M_LRS: return muta_st_line(c, (int)fn, st + 1);
     case M_NUM: return muta_num(c);
+    case M_AB: case M_AD: return muta_ascii(c, *(LexCache*)(c.aux + 1024), (int)fn);
+    case M_URI: return muta_uri(c, *(LexCache*)(c.aux + 1024));
+    case M_B64: return muta_b64(c, *(LexCache*)(c.aux + 1024));
+    case M_ZIP: return muta_zip(c);
     default: c.status = CASE_UNSUPPORTED; c.r_kind = R_SAME; return 0;
   }
 }
@@ -268,7 +273,9 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(KParam
     uint64_t tick0 = __builtin_readcyclecounter();
     c.status = CASE_OK; c.lastm = -1; c.nb = 0; c.cur = 0; c.nem = 0; c.ws_used = 0;
     c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0;
-    if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; }
+    if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; ((LexCache*)(c.aux + 1024))->n = -1; }
+    c.ws_cap = p.work_cap;
+    wave_sync();
     int gen;
     Rng pr;
     if (p.mode == 0) {
@@ -347,11 +354,11 @@ __global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf, const ui
 // host side
 // =============================================================================================
 static const MutaInfo MUTAS[M_COUNT] = {
-    {"sgm", 10, 0}, {"js", 3, 0},  {"uw", 1, 1},   {"ui", 2, 1},  {"ab", 1, 0},  {"ad", 1, 0},  {"tr2", 1, 0}, {"td", 1, 0},
+    {"sgm", 10, 0}, {"js", 3, 0},  {"uw", 1, 1},   {"ui", 2, 1},  {"ab", 1, 1},  {"ad", 1, 1},  {"tr2", 1, 0}, {"td", 1, 0},
     {"num", 3, 1},  {"ts1", 2, 0}, {"tr", 2, 0},   {"ts2", 2, 0}, {"bd", 1, 1},  {"bei", 1, 1}, {"bed", 1, 1}, {"bf", 1, 1},
     {"bi", 1, 1},   {"ber", 1, 1}, {"br", 1, 1},   {"sp", 1, 1},  {"sr", 1, 1},  {"sd", 1, 1},  {"snand", 1, 1}, {"srnd", 1, 1},
     {"ld", 1, 1},   {"lds", 1, 1}, {"lr2", 1, 1},  {"lri", 1, 1}, {"lr", 1, 1},  {"ls", 1, 1},  {"lp", 1, 1},  {"lis", 1, 1},
-    {"lrs", 1, 1},  {"ft", 2, 0},  {"fn", 1, 0},   {"fo", 2, 0},  {"len", 2, 0}, {"b64", 7, 0}, {"uri", 1, 0}, {"zip", 1, 0},
+    {"lrs", 1, 1},  {"ft", 2, 0},  {"fn", 1, 0},   {"fo", 2, 0},  {"len", 2, 0}, {"b64", 7, 1}, {"uri", 1, 1}, {"zip", 1, 1},
     {"nil", 0, 1}};
 static const PatInfo PATS[P_COUNT] = {{"od", 1, 1}, {"nd", 2, 1}, {"bu", 1, 1}, {"sk", 2, 0}, {"sz", 2, 0},
                                       {"cs", 1, 0}, {"ar", 1, 0}, {"cp", 1, 0}, {"co", 0, 1}, {"nu", 0, 1}};
