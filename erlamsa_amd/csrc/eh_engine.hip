@@ -23,6 +23,7 @@
 #include "eh_device.h"
 #include "eh_text.h"
 #include "eh_lex.h"
+#include "eh_tree.h"
 
 namespace eh {
 
@@ -40,6 +41,7 @@ EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
     case M_URI: return muta_uri(c, *(LexCache*)(c.aux + 1024));
     case M_B64: return muta_b64(c, *(LexCache*)(c.aux + 1024));
     case M_ZIP: return muta_zip(c);
+    case M_TR2: case M_TD: case M_TS1: case M_TS2: case M_TR: return muta_tree(c, (int)fn);
     default: c.status = CASE_UNSUPPORTED; c.r_kind = R_SAME; return 0;
   }
 }
@@ -354,8 +356,8 @@ __global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf, const ui
 // host side
 // =============================================================================================
 static const MutaInfo MUTAS[M_COUNT] = {
-    {"sgm", 10, 0}, {"js", 3, 0},  {"uw", 1, 1},   {"ui", 2, 1},  {"ab", 1, 1},  {"ad", 1, 1},  {"tr2", 1, 0}, {"td", 1, 0},
-    {"num", 3, 1},  {"ts1", 2, 0}, {"tr", 2, 0},   {"ts2", 2, 0}, {"bd", 1, 1},  {"bei", 1, 1}, {"bed", 1, 1}, {"bf", 1, 1},
+    {"sgm", 10, 0}, {"js", 3, 0},  {"uw", 1, 1},   {"ui", 2, 1},  {"ab", 1, 1},  {"ad", 1, 1},  {"tr2", 1, 1}, {"td", 1, 1},
+    {"num", 3, 1},  {"ts1", 2, 1}, {"tr", 2, 1},   {"ts2", 2, 1}, {"bd", 1, 1},  {"bei", 1, 1}, {"bed", 1, 1}, {"bf", 1, 1},
     {"bi", 1, 1},   {"ber", 1, 1}, {"br", 1, 1},   {"sp", 1, 1},  {"sr", 1, 1},  {"sd", 1, 1},  {"snand", 1, 1}, {"srnd", 1, 1},
     {"ld", 1, 1},   {"lds", 1, 1}, {"lr2", 1, 1},  {"lri", 1, 1}, {"lr", 1, 1},  {"ls", 1, 1},  {"lp", 1, 1},  {"lis", 1, 1},
     {"lrs", 1, 1},  {"ft", 2, 0},  {"fn", 1, 0},   {"fo", 2, 0},  {"len", 2, 0}, {"b64", 7, 1}, {"uri", 1, 1}, {"zip", 1, 1},

@@ -1,0 +1,296 @@
+// eh_tree.h — device code for the guessed-parse-tree mutators tr2, td, ts1, ts2, tr
+// (erlamsa_mutations.erl:787-1023).
+//
+// partial_parse/1 + grow/3 build nested lists out of matched delimiter pairs ()[]<>{}""''.  Every
+// list node is a contiguous byte range [open, close] of the block, unclosed openers stay plain
+// bytes, and completed nodes are properly nested.  So the "tree" is kept as a table of matched
+// pairs sorted by opening position (= pre-order); node equality (Erlang =:= on the nested lists)
+// is byte equality of the ranges; sublists/1 (reverse pre-order) is that table read backwards; and
+// edit_sublist/3 ("first equal node per level, the rest of that level is left alone") is a single
+// pre-order sweep with a skip pointer.
+#pragma once
+#include "eh_lex.h"
+
+namespace eh {
+
+struct TNode { uint32_t open, close; };
+
+EH_DEV uint32_t usual_delim_close(uint32_t c) {                 // usual_delims/1 :791-798
+  switch (c) { case 40: return 41; case 91: return 93; case 60: return 62; case 123: return 125; case 34: return 34; case 39: return 39; }
+  return 0;
+}
+struct IsOpener { EH_DEV bool operator()(uint32_t b, uint32_t) const { return b == 40 || b == 91 || b == 60 || b == 123 || b == 34 || b == 39; } };
+
+// Parses the block; returns the number of completed nodes (table sorted by open), or -1 on
+// allocation failure.  Tables live in the work area (caller resets the allocator mark).
+EH_DEV int tree_parse(Ctx& c, const uint8_t* H, uint32_t L, TNode** out) {
+  const int l = EH_LANE;
+  uint32_t nopen = wave_count(H, L, IsOpener());
+  TNode* tab = (TNode*)ws_alloc(c, (uint64_t)(nopen + 1) * sizeof(TNode));
+  uint32_t* stack = (uint32_t*)ws_alloc(c, (uint64_t)(nopen + 1) * 4);
+  if (!tab || !stack) return -1;
+  ByteReader r; br_init(r, H, L);
+  uint32_t nslots = 0, sp = 0, top_close = 0, top_slot = 0;
+  for (uint32_t pos = 0; pos < L; pos++) {
+    uint32_t b = br_get(r, pos, pos);
+    if (sp > 0 && b == top_close) {                              // grow: H =:= Close  (:806-807)
+      if (l == 0) tab[top_slot].close = pos;
+      sp--;
+      if (sp > 0) { uint32_t e = uni(stack[sp - 1]); top_slot = e >> 8; top_close = e & 255u; }
+      continue;
+    }
+    uint32_t cl = usual_delim_close(b);
+    if (cl) {
+      if (nslots >= (1u << 24)) { c.status = CASE_OVERFLOW; return -1; }
+      if (l == 0) { tab[nslots].open = pos; tab[nslots].close = 0xFFFFFFFFu; stack[sp] = (nslots << 8) | cl; }
+      wave_sync();
+      top_slot = nslots; top_close = cl; nslots++; sp++;
+    }
+  }
+  wave_sync();
+  // compact completed nodes (keep pre-order)
+  uint32_t n = 0;
+  for (uint32_t base = 0; base < nslots; base += 64) {
+    uint32_t i = base + (uint32_t)l;
+    TNode t{0, 0xFFFFFFFFu};
+    if (i < nslots) t = tab[i];
+    bool ok = i < nslots && t.close != 0xFFFFFFFFu;
+    unsigned long long m = __ballot(ok);
+    uint32_t before = (uint32_t)__popcll(m & ((1ull << l) - 1));
+    wave_sync();
+    if (ok) tab[n + before] = t;      // n + before <= i: never overwrites an unread slot of a later chunk
+    n += (uint32_t)__popcll(m);
+    wave_sync();
+  }
+  *out = tab;
+  return (int)n;
+}
+
+EH_DEV bool node_eq(const uint8_t* H, TNode a, TNode b) {
+  uint32_t la = a.close - a.open + 1, lb = b.close - b.open + 1;
+  if (la != lb) return false;
+  if (a.open == b.open) return true;
+  return wave_equal(H + a.open, H + b.open, la);
+}
+EH_DEV TNode node_load(const TNode* t, uint32_t i) { TNode x = t[i]; x.open = uni(x.open); x.close = uni(x.close); return x; }
+
+// edit_sublist/3 sweep (:858-869) over nodes[lo..hi) (a subtree in pre-order; the level that
+// contains nodes[lo] ends at `level_end`).  Calls f(match, idx) for each matched node in order.
+// `anc` is scratch for the ancestor stack (capacity = node count).
+template <class F>
+EH_DEV void tree_matches(const uint8_t* H, const TNode* nodes, uint32_t lo, uint32_t hi, uint32_t level_end, TNode sub, uint32_t* anc, F f) {
+  uint32_t skip_until = 0, sp = 0;
+  for (uint32_t i = lo; i < hi; i++) {
+    TNode q = node_load(nodes, i);
+    if (q.open < skip_until) continue;
+    while (sp > 0 && uni(anc[sp - 1]) < q.open) sp--;           // anc holds close positions of open ancestors
+    if (node_eq(H, q, sub)) {
+      f(q, i);
+      skip_until = sp > 0 ? uni(anc[sp - 1]) + 1 : level_end;    // rest of the parent's level is left alone
+      continue;
+    }
+    if (EH_LANE == 0) anc[sp] = q.close;
+    wave_sync();
+    sp++;
+  }
+}
+
+// sed_tree_op (tr2/td :917-936), construct_sed_tree_swap (ts1/ts2 :940-971), sed_tree_stutter (tr :975-1023)
+EH_DEV int muta_tree(Ctx& c, int fn) {
+  Blk hb = blk_load(c.bl, c.cur);
+  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  const int l = EH_LANE;
+  c.r_kind = R_SAME;
+  if (binarish(H, L)) return -1;
+  uint64_t mark = c.ws_used;
+  TNode* nodes;
+  int n_ = tree_parse(c, H, L, &nodes);
+  if (n_ < 0) return 0;
+  uint32_t N = (uint32_t)n_;
+  uint32_t* anc = (uint32_t*)ws_alloc(c, (uint64_t)(N + 1) * 4);
+  if (!anc) return 0;
+  // Subs = sublists(Lst): list position j (0-based) <-> nodes[N-1-j]
+
+  if (fn == M_TR2 || fn == M_TD) {
+    if (N == 0) { c.ws_used = mark; return 1; }                  // pick_sublist -> false: nothing is edited
+    uint32_t idx = rng_rand(c.rng, N);
+    TNode sub = node_load(nodes, N - 1 - idx);
+    // two sweeps: size, then emit
+    uint32_t slen = sub.close - sub.open + 1;
+    uint32_t nm = 0;
+    tree_matches(H, nodes, 0, N, L, sub, anc, [&](TNode, uint32_t) { nm++; });
+    uint64_t nl = fn == M_TR2 ? (uint64_t)L + (uint64_t)nm * slen : (uint64_t)L - (uint64_t)nm * slen;
+    uint8_t* dst = ws_alloc(c, nl);
+    if (!dst) return 1;
+    uint32_t cur = 0; uint64_t out = 0;
+    tree_matches(H, nodes, 0, N, L, sub, anc, [&](TNode q, uint32_t) {
+      wave_copy(dst + out, H + cur, q.open - cur); out += q.open - cur;
+      if (fn == M_TR2) { wave_copy(dst + out, H + q.open, slen); out += slen; cur = q.open; }   // [H | Node]
+      else cur = q.close + 1;                                                                  // T
+    });
+    wave_copy(dst + out, H + cur, L - cur); out += L - cur;
+    wave_sync();
+    c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)out;
+    return 1;
+  }
+
+  if (fn == M_TS1 || fn == M_TS2) {
+    if (N < 2) { c.ws_used = mark; return -1; }
+    // reservoir_sample(Subs, 2) (erlamsa_rnd.erl:201-214) over list positions
+    uint32_t r0 = 0, r1 = 1;
+    for (uint32_t i = 3; i <= N; i++) { uint32_t j = rng_erand(c.rng, i); if (j == 1) r0 = i - 1; else if (j == 2) r1 = i - 1; }
+    TNode A = node_load(nodes, N - 1 - r0), B = node_load(nodes, N - 1 - r1);
+    if (fn == M_TS1) {                                           // sed_tree_swap_one
+      if (rng_rand(c.rng, 2) == 1) { TNode t = A; A = B; B = t; } // random_permutation([A,B])
+      uint32_t al = A.close - A.open + 1, bl = B.close - B.open + 1;
+      uint32_t nm = 0;
+      tree_matches(H, nodes, 0, N, L, A, anc, [&](TNode, uint32_t) { nm++; });
+      uint64_t nl = (uint64_t)L + (uint64_t)nm * bl - (uint64_t)nm * al;
+      uint8_t* dst = ws_alloc(c, nl);
+      if (!dst) return 1;
+      uint32_t cur = 0; uint64_t out = 0;
+      tree_matches(H, nodes, 0, N, L, A, anc, [&](TNode q, uint32_t) {
+        wave_copy(dst + out, H + cur, q.open - cur); out += q.open - cur;
+        wave_copy(dst + out, H + B.open, bl); out += bl; cur = q.close + 1;                    // [B | Tl]
+      });
+      wave_copy(dst + out, H + cur, L - cur); out += L - cur;
+      wave_sync();
+      c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)out;
+      return 1;
+    }
+    // sed_tree_swap_two: edit_sublists/2 with {A -> B, B -> A}; every occurrence, no descent into a replaced node
+    uint32_t al = A.close - A.open + 1, bl = B.close - B.open + 1;
+    bool same = node_eq(H, A, B);
+    int64_t delta = 0;
+    for (int pass = 0; pass < 2; pass++) {
+      uint8_t* dst = nullptr; uint32_t cur = 0; uint64_t out = 0;
+      if (pass == 1) { dst = ws_alloc(c, (uint64_t)((int64_t)L + delta)); if (!dst) return 1; }
+      uint32_t skip_until = 0; delta = pass == 0 ? 0 : delta;
+      int64_t d2 = 0;
+      for (uint32_t i = 0; i < N; i++) {
+        TNode q = node_load(nodes, i);
+        if (q.open < skip_until) continue;
+        bool isB = node_eq(H, q, B), isA = !isB && node_eq(H, q, A);
+        if (!isA && !isB) continue;
+        // gb_trees: enter(A,->B) then enter(B,->A); equal keys: A -> A
+        TNode rep = isB ? A : B; uint32_t rl = isB ? al : bl; uint32_t ql = q.close - q.open + 1;
+        if (same) { rep = A; rl = al; }
+        if (pass == 0) d2 += (int64_t)rl - (int64_t)ql;
+        else { wave_copy(dst + out, H + cur, q.open - cur); out += q.open - cur; wave_copy(dst + out, H + rep.open, rl); out += rl; cur = q.close + 1; }
+        skip_until = q.close + 1;
+      }
+      if (pass == 0) delta = d2;
+      else { wave_copy(dst + out, H + cur, L - cur); out += L - cur; wave_sync(); c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)out; }
+    }
+    return 1;
+  }
+
+  // ---- tree stutter
+  // RandSubs = random_permutation(Subs): only its first element WITH descendants matters.
+  uint32_t pidx = 0xFFFFFFFFu;                                    // index into nodes[]
+  auto has_desc = [&](uint32_t k) -> bool { return k + 1 < N && uni(nodes[k + 1].open) < uni(nodes[k].close); };
+  if (N == 2) {
+    uint32_t sw = rng_rand(c.rng, 2);                             // [A,B] = Subs[0],Subs[1] = nodes[1],nodes[0]
+    uint32_t first = sw == 1 ? 0u : 1u, second = sw == 1 ? 1u : 0u;
+    if (has_desc(first)) pidx = first; else if (has_desc(second)) pidx = second;
+  } else if (N > 0) {
+    // keys in list order: list position j <-> nodes[N-1-j]; the minimum {U, node} among nodes with descendants
+    uint64_t best = ~(uint64_t)0; uint32_t bestk = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base < N; base += 64) {
+      uint32_t j = base + (uint32_t)l;
+      if (j < N) {
+        uint32_t k = N - 1 - j;
+        double u = rng_peek(c.rng, (uint32_t)l + 1);
+        bool hd = k + 1 < N && nodes[k + 1].open < nodes[k].close;
+        uint64_t key = (uint64_t)__double_as_longlong(u);
+        if (hd && key < best) { best = key; bestk = k; }          // (ties on the float key would fall back to term order)
+      }
+      rng_skip(c.rng, N - base < 64 ? N - base : 64);
+    }
+    // wave arg-min
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      uint64_t ob = ((uint64_t)(uint32_t)__shfl_xor((int)(best >> 32), d) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)best, d);
+      uint32_t ok = (uint32_t)__shfl_xor((int)bestk, d);
+      if (ob < best) { best = ob; bestk = ok; }
+    }
+    pidx = uni(bestk);
+  }
+  TNode P{0, 0}, C{0, 0}; uint32_t ndesc = 0;
+  if (pidx != 0xFFFFFFFFu) {
+    P = node_load(nodes, pidx);
+    // descendants of P are contiguous in pre-order: nodes[pidx+1 .. pidx+ndesc]
+    uint32_t cnt = 0;
+    for (uint32_t base = pidx + 1; base < N; base += 64) {
+      uint32_t k = base + (uint32_t)l;
+      bool in = k < N && nodes[k].open < P.close;
+      unsigned long long m = __ballot(in);
+      cnt += (uint32_t)__popcll(m);
+      if (m != ~0ull) break;
+    }
+    ndesc = cnt;
+    uint32_t ci = rng_rand(c.rng, ndesc);                          // choose_child: rand_elem(sublists(H))
+    C = node_load(nodes, pidx + ndesc - ci);                      // reverse pre-order
+  }
+  uint32_t nreps = rng_log(c.rng, 10);
+  if (pidx == 0xFFFFFFFFu) { c.ws_used = mark; return -1; }
+  // R_n = repeat_path(Parent, Child, n): matches of Child inside Parent
+  uint32_t plen = P.close - P.open + 1, clen = C.close - C.open + 1;
+  uint32_t k_in = 0; uint64_t matched_bytes = 0;
+  tree_matches(H, nodes, pidx + 1, pidx + 1 + ndesc, P.close + 1, C, anc, [&](TNode q, uint32_t) { k_in++; matched_bytes += q.close - q.open + 1; });
+  (void)clen;
+  uint64_t fixed = plen - matched_bytes;                          // bytes of P outside the matched children
+  // size of R_n
+  uint64_t rsz = plen;
+  for (uint32_t t = 2; t <= nreps; t++) { rsz = (uint64_t)k_in * rsz + fixed; if (rsz > c.ws_cap) { c.status = CASE_OVERFLOW; return 1; } }
+  uint8_t* R = nullptr;
+  if (nreps < 2) R = (uint8_t*)(H + P.open);
+  else if (k_in == 1) {
+    // R_n = pre^(n-1) ++ P ++ suf^(n-1)
+    TNode m{0, 0};
+    tree_matches(H, nodes, pidx + 1, pidx + 1 + ndesc, P.close + 1, C, anc, [&](TNode q, uint32_t) { m = q; });
+    uint32_t pre = m.open - P.open, suf = P.close - m.close;
+    R = ws_alloc(c, rsz);
+    if (!R) return 1;
+    wave_fill_periodic(R, H + P.open, pre, (uint64_t)pre * (nreps - 1));
+    wave_copy(R + (uint64_t)pre * (nreps - 1), H + P.open, plen);
+    wave_fill_periodic(R + (uint64_t)pre * (nreps - 1) + plen, H + m.close + 1, suf, (uint64_t)suf * (nreps - 1));
+    wave_sync();
+  } else {
+    const uint8_t* prev = H + P.open; uint64_t prevsz = plen;
+    for (uint32_t t = 2; t <= nreps; t++) {
+      uint64_t sz = (uint64_t)k_in * prevsz + fixed;
+      uint8_t* cur = ws_alloc(c, sz);
+      if (!cur) return 1;
+      uint32_t from = P.open; uint64_t out = 0;
+      tree_matches(H, nodes, pidx + 1, pidx + 1 + ndesc, P.close + 1, C, anc, [&](TNode q, uint32_t) {
+        wave_copy(cur + out, H + from, q.open - from); out += q.open - from;
+        uint64_t done = 0; while (done < prevsz) { uint32_t cc = prevsz - done > 0x40000000ull ? 0x40000000u : (uint32_t)(prevsz - done); wave_copy(cur + out + done, prev + done, cc); done += cc; }
+        out += prevsz; from = q.close + 1;
+      });
+      wave_copy(cur + out, H + from, P.close + 1 - from);
+      wave_sync();
+      prev = cur; prevsz = sz;
+    }
+    R = (uint8_t*)prev;
+  }
+  // top level: edit_sublist(Lst, Child, [R_N | Tl])
+  uint32_t nm = 0; uint64_t mb = 0;
+  tree_matches(H, nodes, 0, N, L, C, anc, [&](TNode q, uint32_t) { nm++; mb += q.close - q.open + 1; });
+  uint64_t nl = (uint64_t)L - mb + (uint64_t)nm * rsz;
+  if (nl > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; return 1; }
+  uint8_t* dst = ws_alloc(c, nl);
+  if (!dst) return 1;
+  uint32_t cur = 0; uint64_t out = 0;
+  tree_matches(H, nodes, 0, N, L, C, anc, [&](TNode q, uint32_t) {
+    wave_copy(dst + out, H + cur, q.open - cur); out += q.open - cur;
+    uint64_t done = 0; while (done < rsz) { uint32_t cc = rsz - done > 0x40000000ull ? 0x40000000u : (uint32_t)(rsz - done); wave_copy(dst + out + done, R + done, cc); done += cc; }
+    out += rsz; cur = q.close + 1;
+  });
+  wave_copy(dst + out, H + cur, L - cur); out += L - cur;
+  wave_sync();
+  c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)out;
+  return 1;
+}
+
+}  // namespace eh

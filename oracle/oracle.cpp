@@ -10,6 +10,8 @@
 // code, plus hand-derived AS183 known answers.
 #include "oracle.h"
 
+#include <pthread.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -585,14 +587,22 @@ int sed_fuse_old(Ctx& c, BList& ll, Muta& m) {                                //
 // ---------------------------------------------------------------------------
 struct Term;  // byte | list
 typedef std::shared_ptr<const Term> TermP;
-struct Term { bool is_list; uint8_t b; std::vector<TermP> kids; };
-TermP mk_byte(uint8_t b) { auto t = std::make_shared<Term>(); t->is_list = false; t->b = b; return t; }
-TermP mk_list(std::vector<TermP> k) { auto t = std::make_shared<Term>(); t->is_list = true; t->b = 0; t->kids = std::move(k); return t; }
+struct Term { bool is_list; uint8_t b; std::vector<TermP> kids; size_t flat; uint64_t hash; };
+TermP mk_byte(uint8_t b) { auto t = std::make_shared<Term>(); t->is_list = false; t->b = b; t->flat = 1; t->hash = 0x9E3779B97F4A7C15ull * (b + 1); return t; }
+TermP mk_list(std::vector<TermP> k) {
+  auto t = std::make_shared<Term>(); t->is_list = true; t->b = 0; t->kids = std::move(k);
+  size_t f = 0; uint64_t h = 0xCBF29CE484222325ull;
+  for (auto& x : t->kids) { f += x->flat; h = (h ^ x->hash) * 0x100000001B3ull; h ^= h >> 29; }
+  t->flat = f; t->hash = h ^ 0x5555555555555555ull;
+  return t;
+}
+// structural equality (=:=); flattened size and a structural hash are cached per node so that
+// unequal subtrees are rejected without walking them
 bool term_eq(const TermP& a, const TermP& b) {
   if (a.get() == b.get()) return true;
   if (a->is_list != b->is_list) return false;
   if (!a->is_list) return a->b == b->b;
-  if (a->kids.size() != b->kids.size()) return false;
+  if (a->flat != b->flat || a->hash != b->hash || a->kids.size() != b->kids.size()) return false;
   for (size_t i = 0; i < a->kids.size(); i++) if (!term_eq(a->kids[i], b->kids[i])) return false;
   return true;
 }
@@ -612,7 +622,9 @@ int usual_delims(uint8_t c) {                                                 //
   switch (c) { case 40: return 41; case 91: return 93; case 60: return 62; case 123: return 125; case 34: return 34; case 39: return 39; }
   return -1;
 }
-// grow/3 :800-823.  Returns true if closed; `out` = node contents (without the opener); pos advanced.
+// grow/3 :800-823.  Returns true if closed; `out` already holds the opener and receives the node
+// contents; pos advanced.  (Vectors are appended to, which is what the reference's
+// reverse-accumulators amount to; no O(n^2) front insertion.)
 bool grow(const Bytes& in, size_t& pos, uint8_t close, std::vector<TermP>& out) {
   while (true) {
     if (pos >= in.size()) return false;
@@ -621,11 +633,10 @@ bool grow(const Bytes& in, size_t& pos, uint8_t close, std::vector<TermP>& out) 
     int nc = usual_delims(h);
     if (nc < 0) { out.push_back(mk_byte(h)); pos++; continue; }
     pos++;
-    std::vector<TermP> inner;
+    std::vector<TermP> inner; inner.push_back(mk_byte(h));
     bool ok = grow(in, pos, (uint8_t)nc, inner);
-    if (!ok) { out.push_back(mk_byte(h)); out.insert(out.end(), inner.begin(), inner.end()); return false; }  // :817
-    inner.insert(inner.begin(), mk_byte(h));
-    out.push_back(mk_list(inner));
+    if (!ok) { out.insert(out.end(), inner.begin(), inner.end()); return false; }  // :817 partial parse is spliced in flat
+    out.push_back(mk_list(std::move(inner)));
   }
 }
 std::vector<TermP> partial_parse(const Bytes& in) {                           // :883-905
@@ -635,19 +646,19 @@ std::vector<TermP> partial_parse(const Bytes& in) {                           //
     int cp = usual_delims(h);
     if (cp < 0) { out.push_back(mk_byte(h)); pos++; continue; }
     pos++;
-    std::vector<TermP> inner;
+    std::vector<TermP> inner; inner.push_back(mk_byte(h));
     bool ok = grow(in, pos, (uint8_t)cp, inner);
-    if (!ok) { out.push_back(mk_byte(h)); out.insert(out.end(), inner.begin(), inner.end()); return out; }
-    inner.insert(inner.begin(), mk_byte(h));
-    out.push_back(mk_list(inner));
+    if (!ok) { out.insert(out.end(), inner.begin(), inner.end()); return out; }
+    out.push_back(mk_list(std::move(inner)));
   }
   return out;
 }
-// sublists/2 :838-845 — result is a cons-list built by prepending; we return it in LIST order.
-void sublists_acc(const std::vector<TermP>& l, std::vector<TermP>& found_front) {
-  for (auto& h : l) if (h->is_list) { found_front.insert(found_front.begin(), h); sublists_acc(h->kids, found_front); }
+// sublists/2 :838-845 — the reference conses each node in front while walking in pre-order, i.e.
+// the result is the pre-order list reversed.
+void sublists_pre(const std::vector<TermP>& l, std::vector<TermP>& pre) {
+  for (auto& h : l) if (h->is_list) { pre.push_back(h); sublists_pre(h->kids, pre); }
 }
-std::vector<TermP> sublists(const std::vector<TermP>& l) { std::vector<TermP> f; sublists_acc(l, f); return f; }
+std::vector<TermP> sublists(const std::vector<TermP>& l) { std::vector<TermP> f; sublists_pre(l, f); std::reverse(f.begin(), f.end()); return f; }
 
 // edit_sublist/3 :858-869, flattened on the fly.  `op(list, idx, out)` emits the
 // flattening of Op([H|T]) where [H|T] = l[idx..].
@@ -1513,7 +1524,7 @@ const char* eo_last_error(void) { return g_err.c_str(); }
 void eo_free(void* p) { free(p); }
 void eo_free_result(eo_result* r) { free(r->data); free(r->off); free(r->status); free(r->draws); free(r->trace); memset(r, 0, sizeof(*r)); }
 
-int eo_fuzz_batch(const eo_config* ec, const uint8_t* data, const uint64_t* off, uint64_t n, int want_trace, eo_result* res) {
+static int eo_fuzz_batch_impl(const eo_config* ec, const uint8_t* data, const uint64_t* off, uint64_t n, int want_trace, eo_result* res) {
   try {
     Config cfg;
     if (!build_config(ec, &cfg)) return 1;
@@ -1543,6 +1554,19 @@ int eo_fuzz_batch(const eo_config* ec, const uint8_t* data, const uint64_t* off,
     if (want_trace) { res->trace = (char*)malloc(trace.size() + 1); memcpy(res->trace, trace.c_str(), trace.size() + 1); res->trace_len = trace.size(); }
     return 0;
   } catch (std::exception& e) { g_err = e.what(); return 2; }
+}
+
+// The restated algorithms recurse as deeply as the reference's list code does (grow/3,
+// edit_sublist/4 on deeply nested input), so the batch runs on a thread with a 2 GiB stack.
+struct BatchArgs { const eo_config* ec; const uint8_t* data; const uint64_t* off; uint64_t n; int want_trace; eo_result* res; int rc; };
+static void* batch_thread(void* p) { BatchArgs* a = (BatchArgs*)p; a->rc = eo_fuzz_batch_impl(a->ec, a->data, a->off, a->n, a->want_trace, a->res); return nullptr; }
+int eo_fuzz_batch(const eo_config* ec, const uint8_t* data, const uint64_t* off, uint64_t n, int want_trace, eo_result* res) {
+  BatchArgs a{ec, data, off, n, want_trace, res, 0};
+  pthread_attr_t at; pthread_attr_init(&at); pthread_attr_setstacksize(&at, (size_t)2 << 30);
+  pthread_t th;
+  if (pthread_create(&th, &at, batch_thread, &a) != 0) return eo_fuzz_batch_impl(ec, data, off, n, want_trace, res);
+  pthread_join(th, nullptr); pthread_attr_destroy(&at);
+  return a.rc;
 }
 
 void eo_rand_uniforms(int64_t a, int64_t b, int64_t c, uint64_t n, double* out) {
