@@ -24,6 +24,7 @@
 #include "eh_text.h"
 #include "eh_lex.h"
 #include "eh_tree.h"
+#include "eh_field.h"
 
 namespace eh {
 
@@ -41,6 +42,7 @@ EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
     case M_URI: return muta_uri(c, *(LexCache*)(c.aux + 1024));
     case M_B64: return muta_b64(c, *(LexCache*)(c.aux + 1024));
     case M_ZIP: return muta_zip(c);
+    case M_LEN: return muta_len(c);
     case M_TR2: case M_TD: case M_TS1: case M_TS2: case M_TR: return muta_tree(c, (int)fn);
     default: c.status = CASE_UNSUPPORTED; c.r_kind = R_SAME; return 0;
   }
@@ -127,9 +129,135 @@ EH_DEV void split_head(Ctx& c) {
 enum Act { A_RUN_PAT, A_MUTATE_ONCE, A_LOOP, A_CONT, A_TERMINAL, A_DONE };
 enum ContKind { C_EMIT, C_ND, C_BU, C_PAT };
 
+// CRC-32 (zlib polynomial, reflected) helpers for the csum pattern
+__constant__ uint32_t c_crc_table[256];
+EH_DEV uint32_t gf2_multmodp(uint32_t a, uint32_t b) {            // a(x)*b(x) mod p(x), reflected representation (x^0 = bit 31)
+  uint32_t m = 1u << 31, p = 0;
+  for (;;) {
+    if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+    m >>= 1;
+    b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+  }
+  return p;
+}
+EH_DEV uint32_t gf2_xpow8n(uint64_t nbytes) {                      // x^(8*nbytes) mod p
+  uint32_t r = 1u << 31, sq = 1u << 23;                            // sq = x^8
+  while (nbytes) { if (nbytes & 1) r = gf2_multmodp(r, sq); sq = gf2_multmodp(sq, sq); nbytes >>= 1; }
+  return r;
+}
+// erlang:crc32/1 of a contiguous buffer: 64 lane-local chunk CRCs combined with x^(8*len) shifts
+EH_DEV uint32_t wave_crc32(const uint8_t* p, uint32_t n) {
+  const int l = EH_LANE;
+  uint32_t chunk = (n + 63) / 64;
+  uint32_t a = (uint32_t)l * chunk, b = a + chunk; if (a > n) a = n; if (b > n) b = n;
+  uint32_t crc = 0xFFFFFFFFu;
+  for (uint32_t i = a; i < b; i++) crc = c_crc_table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+  crc ^= 0xFFFFFFFFu;                                              // crc32 of my chunk (0 for an empty chunk)
+  uint32_t total = 0; uint32_t done = 0;
+  for (int k = 0; k < 64; k++) {                                   // crc32_combine left to right
+    uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)crc, k);
+    uint32_t ak = (uint32_t)k * chunk, bk = ak + chunk; if (ak > n) ak = n; if (bk > n) bk = n;
+    uint32_t lk = bk - ak;
+    if (lk == 0) continue;
+    total = done == 0 ? ck : (gf2_multmodp(gf2_xpow8n(lk), total) ^ ck);
+    done += lk;
+  }
+  return total;
+}
+EH_DEV uint32_t wave_xor8(const uint8_t* p, uint32_t n) {
+  uint32_t x = 0;
+  for (uint32_t i = EH_LANE; i < n; i += 64) x ^= p[i];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) x ^= (uint32_t)__shfl_xor((int)x, d);
+  return uni(x) & 255u;
+}
+
+struct PatFrame {           // a sizer/csum wrapper waiting for its inner evaluation (prepare4sizer)
+  int kind;                 // P_SZ or P_CS
+  int em_field;             // sz: index of the length-field piece in the emit list; cs: first inner piece
+  uint8_t* field;           // sz: the Size/8 bytes to fill in
+  uint32_t size_bits, big;  // sz
+  uint64_t tail_ptr; uint32_t tail_len;   // sz: TailBin
+  uint32_t crc;             // cs: 1 crc32, 0 xor8
+};
+
+// get_possible_csum_locations/1 + rand_elem (erlamsa_field_predict.erl:131-161).
+// Returns 1 with (*crc,*plen,*blen), 0 for no candidate, -1 on failure.
+EH_DEV int pick_csum(Ctx& c, const uint8_t* H, uint32_t L, uint32_t* crc, uint32_t* plen, uint32_t* blen) {
+  const int l = EH_LANE;
+  if (L == 0) return 0;
+  uint32_t maxp = (uint32_t)(2.0 * (double)L / 3.0);
+  if (maxp > 30 * PREAMBLE_MAX_BYTES) maxp = 30 * PREAMBLE_MAX_BYTES;
+  uint32_t np = maxp + 1;                                          // preambles 0..maxp
+  // xor8: xor(bytes[A .. L-1)) == byte[L-1]  <=>  prefix_xor(A) == total_xor ^ last
+  uint32_t last = uni(H[L - 1]);
+  uint32_t tot = wave_xor8(H, L - 1);
+  uint32_t target = tot ^ last;
+  uint64_t mark = c.ws_used;
+  uint8_t* flags = ws_alloc(c, (uint64_t)np * 2);                  // [0,np): xor8 hit, [np,2np): crc32 hit
+  if (!flags) return -1;
+  uint32_t carry = 0, nx = 0;
+  for (uint32_t base = 0; base < np; base += 64) {
+    uint32_t A = base + (uint32_t)l;
+    uint32_t v = (A < np && A < L - 1 + 1 && A > 0) ? H[A - 1] : 0;   // prefix_xor(A) = xor of bytes [0,A)
+    if (A == 0 || A > L - 1) v = 0;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)inc, d); if (l >= d) inc ^= t; }
+    uint32_t px = inc ^ carry;
+    bool hit = A < np && A <= L - 1 && px == target;               // has_xor8_checksum: needs Len - A - 1 >= 0
+    if (A < np) flags[A] = hit ? 1 : 0;
+    nx += hit ? 1u : 0u;
+    carry = uni((uint32_t)__shfl((int)px, 63));
+  }
+  nx = wave_sum(nx);
+  // crc32: crc(bytes[A .. L-4)) == BE32(last 4), for A with L - A >= 4
+  uint32_t nc = 0;
+  if (L >= 4) {
+    uint32_t stored = (uni(H[L - 4]) << 24) | (uni(H[L - 3]) << 16) | (uni(H[L - 2]) << 8) | uni(H[L - 1]);
+    uint32_t E = L - 4;
+    uint32_t whole = wave_crc32(H, E);                             // crc(0..E)
+    // prefix CRCs crc(0..A) for A <= maxp: one sequential table walk shared by the wave ...
+    uint32_t* pre = (uint32_t*)ws_alloc(c, (uint64_t)np * 4);
+    if (!pre) return -1;
+    uint32_t run = 0xFFFFFFFFu;
+    ByteReader r; br_init(r, H, L);
+    for (uint32_t A = 0; A < np; A++) {
+      if (l == 0) pre[A] = run ^ 0xFFFFFFFFu;                       // crc32(bytes[0..A))
+      if (A < L) run = c_crc_table[(run ^ br_get(r, A, A)) & 0xFF] ^ (run >> 8);
+    }
+    wave_sync();
+    // ... then every lane tests its own preamble:
+    // crc(A..E) = crc(0..E) ^ shift(crc(0..A), E-A)   (crc32_combine solved for the suffix)
+    for (uint32_t base = 0; base < np; base += 64) {
+      uint32_t A = base + (uint32_t)l;
+      bool hit = false;
+      if (A < np && A <= E) {
+        uint32_t suf = A == 0 ? whole : (whole ^ gf2_multmodp(gf2_xpow8n(E - A), pre[A]));
+        hit = suf == stored;
+      }
+      if (A < np) flags[np + A] = hit ? 1 : 0;
+      nc += hit ? 1u : 0u;
+    }
+    nc = wave_sum(nc);
+  } else { for (uint32_t A = l; A < np; A += 64) flags[np + A] = 0; }
+  wave_sync();
+  uint32_t total = nx + nc;
+  if (total == 0) { c.ws_used = mark; return 0; }
+  uint32_t idx = rng_rand(c.rng, total);
+  uint32_t want = idx, off = 0, iscrc = 0;
+  if (idx >= nx) { want = idx - nx; off = np; iscrc = 1; }
+  uint32_t Asel = 0, seen = 0;
+  for (uint32_t A = 0; A < np; A++) { if (uni(flags[off + A])) { if (seen == want) { Asel = A; break; } seen++; } }
+  c.ws_used = mark;
+  *crc = iscrc; *plen = Asel; *blen = iscrc ? L - Asel - 4 : L - Asel - 1;
+  return 1;
+}
+
 EH_DEV void run_patterns(Ctx& c, int pat) {
   int act = A_RUN_PAT, cont = C_EMIT, contpat = 0; uint32_t ip = 0;
   int guard = 0;
+  PatFrame* frames = (PatFrame*)(c.aux + 1152); int nfr = 0;     // wrapper stack lives in slot memory
   while (act != A_DONE && c.status == CASE_OK) {
     if (++guard > 1000000) { c.status = CASE_OVERFLOW; break; }
     switch (act) {
@@ -140,21 +268,83 @@ EH_DEV void run_patterns(Ctx& c, int pat) {
           case P_BU: cont = C_BU; act = A_MUTATE_ONCE; break;                         // :346-349
           case P_CO: pat = rng_erand(c.rng, 2) == 1 ? P_NU : P_OD; break;             // :378-384
           case P_NU: split_head(c); emit_all(c); act = A_TERMINAL; break;             // :386-390
-          case P_SK: {                                                                // make_complex_pat :351-357 + skipper :146-161
+          default: {
+            // make_complex_pat :351-357: the continuation pattern is drawn first, then Ip
             contpat = (int)rng_rand(c.rng, P_COUNT);                                  // rand_elem(patterns())
             cont = C_PAT;
             ip = rng_rand(c.rng, INITIAL_IP);
-            if (c.cur >= c.nb) { c.status = CASE_CRASHED; break; }                    // size(false)
+            if (c.cur >= c.nb) { c.status = CASE_CRASHED; break; }                    // uncons(Ll, false) -> false -> badarg
             Blk b = blk_load(c.bl, c.cur);
-            uint32_t len = rng_rand(c.rng, b.len / 2);
-            emit_ref(c, b.ptr, len);
-            blk_store(c.bl, c.cur, b.ptr + len, b.len - len);
-            wave_sync();
+            const uint8_t* H = (const uint8_t*)b.ptr;
+            if (pat == P_SK) {                                                        // mutate_once_skipper :146-161
+              uint32_t len = rng_rand(c.rng, b.len / 2);
+              emit_ref(c, b.ptr, len);
+              blk_store(c.bl, c.cur, b.ptr + len, b.len - len);
+              wave_sync();
+            } else if (pat == P_SZ) {                                                 // mutate_once_sizer :81-111
+              SizerElem e;
+              int r = pick_simple_len(c, H, b.len, &e);
+              if (r < 0) break;
+              if (r == 1) {
+                uint32_t nbytes = e.size_bits / 8;
+                if ((uint64_t)e.a + nbytes + e.len > b.len) { c.status = CASE_CRASHED; break; }
+                if (nfr >= MAX_FRAMES) { c.status = CASE_OVERFLOW; break; }
+                uint8_t* fld = ws_alloc(c, 16);
+                if (!fld) break;
+                emit_ref(c, b.ptr, e.a);                                              // H
+                if (EH_LANE == 0) {
+                  PatFrame& f = frames[nfr];
+                  f.kind = P_SZ; f.em_field = c.nem; f.field = fld; f.size_bits = e.size_bits; f.big = e.big;
+                  f.tail_ptr = b.ptr + e.a + nbytes + e.len; f.tail_len = b.len - (e.a + nbytes + e.len); f.crc = 0;
+                }
+                nfr++;
+                emit_ref(c, (uint64_t)fld, nbytes);                                   // length field, filled when the inner evaluation ends
+                blk_store(c.bl, c.cur, b.ptr + e.a + nbytes, e.len);                  // Blob
+                wave_sync();
+              }
+            } else if (pat == P_CS) {                                                 // mutate_once_csum :115-144
+              uint32_t iscrc, plen, blen;
+              int r = pick_csum(c, H, b.len, &iscrc, &plen, &blen);
+              if (r < 0) break;
+              if (r == 1) {
+                if (nfr >= MAX_FRAMES) { c.status = CASE_OVERFLOW; break; }
+                emit_ref(c, b.ptr, plen);                                             // P
+                if (EH_LANE == 0) {
+                  PatFrame& f = frames[nfr];
+                  f.kind = P_CS; f.em_field = c.nem; f.crc = iscrc; f.field = nullptr; f.size_bits = 0; f.big = 0; f.tail_ptr = 0; f.tail_len = 0;
+                }
+                nfr++;
+                blk_store(c.bl, c.cur, b.ptr + plen, blen);
+                wave_sync();
+              }
+            } else if (pat == P_AR) {                                                 // mutate_once_archiver :165-214
+              // list_to_binary([Bin|Rest]) -> one block; zip:foldl fails unless an EOCD record exists
+              uint64_t tot = 0; for (int i = c.cur; i < c.nb; i++) tot += blk_load(c.bl, i).len;
+              if (tot > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; break; }
+              if (c.nb - c.cur > 1) {
+                uint8_t* all = ws_alloc(c, tot);
+                if (!all) break;
+                uint64_t o = 0;
+                for (int i = c.cur; i < c.nb; i++) { Blk x = blk_load(c.bl, i); wave_copy(all + o, (const uint8_t*)x.ptr, x.len); o += x.len; }
+                wave_sync();
+                blk_store(c.bl, c.cur, (uint64_t)all, (uint32_t)tot); c.nb = c.cur + 1;
+                wave_sync();
+                b = blk_load(c.bl, c.cur);
+              }
+              if (has_zip_eocd((const uint8_t*)b.ptr, b.len)) { c.status = CASE_UNSUPPORTED; break; }
+            } else if (pat == P_CP) {                                                 // mutate_once_compressed :216-260
+              // zlib:gunzip needs the 1f 8b magic, zlib:inflate a valid 2-byte zlib header; data
+              // that passes those checks would need OTP's zlib bit for bit
+              bool small = b.len < 2;
+              uint32_t b0 = small ? 0 : uni(H[0]), b1 = small ? 0 : uni(H[1]);
+              bool gz = b0 == 0x1f && b1 == 0x8b;
+              bool zl = (b0 & 0x0f) == 8 && (b0 >> 4) <= 7 && ((b0 << 8) | b1) % 31 == 0 && !(b1 & 0x20);
+              if (small || gz || zl) { c.status = CASE_UNSUPPORTED; break; }
+            }
             split_head(c);
             act = A_LOOP;
             break;
           }
-          default: c.status = CASE_UNSUPPORTED; break;
         }
         break;
       case A_MUTATE_ONCE:                                                             // mutate_once/4 :265-278
@@ -188,7 +378,38 @@ EH_DEV void run_patterns(Ctx& c, int pat) {
           case C_PAT: pat = contpat; act = A_RUN_PAT; break;
         }
         break;
-      case A_TERMINAL: act = A_DONE; break;
+      case A_TERMINAL: {
+        // the innermost evaluation finished: unwind the sizer/csum wrappers inside out
+        if (nfr == 0) { act = A_DONE; break; }
+        wave_sync();
+        PatFrame f = frames[--nfr];
+        f.kind = (int)uni((uint32_t)f.kind); f.em_field = (int)uni((uint32_t)f.em_field); f.field = (uint8_t*)uni64((uint64_t)f.field);
+        f.size_bits = uni(f.size_bits); f.big = uni(f.big); f.tail_ptr = uni64(f.tail_ptr); f.tail_len = uni(f.tail_len); f.crc = uni(f.crc);
+        if (f.kind == P_SZ) {
+          // NewLen = size(NewBlob) = everything written after the length field  (:105-110)
+          uint64_t tot = 0; for (int k = f.em_field + 1; k < c.nem; k++) tot += blk_load(c.em, k).len;
+          // (the field piece itself is at em_field unless Size/8 was 0, which cannot happen)
+          if (EH_LANE == 0) put_field(f.field, tot, f.size_bits, f.big != 0);
+          wave_sync();
+          emit_ref(c, f.tail_ptr, f.tail_len);                                        // TailBin
+        } else {
+          // NewC = recalc_csum(Type, NewBlob): gather the inner pieces, checksum, append  (:139-143)
+          uint64_t tot = 0; for (int k = f.em_field; k < c.nem; k++) tot += blk_load(c.em, k).len;
+          if (tot > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; break; }
+          uint8_t* blob = ws_alloc(c, tot + 16);
+          if (!blob) break;
+          uint64_t o = 0;
+          for (int k = f.em_field; k < c.nem; k++) { Blk x = blk_load(c.em, k); wave_copy(blob + o, (const uint8_t*)x.ptr, x.len); o += x.len; }
+          wave_sync();
+          uint32_t cs = f.crc ? wave_crc32(blob, (uint32_t)tot) : wave_xor8(blob, (uint32_t)tot);
+          uint32_t cb = f.crc ? 4u : 1u;
+          if (EH_LANE == 0) put_field(blob + tot, cs, cb * 8, true);
+          wave_sync();
+          c.nem = f.em_field;
+          emit_ref(c, (uint64_t)blob, (uint32_t)tot + cb);
+        }
+        break;
+      }
     }
   }
 }
@@ -360,10 +581,10 @@ static const MutaInfo MUTAS[M_COUNT] = {
     {"num", 3, 1},  {"ts1", 2, 1}, {"tr", 2, 1},   {"ts2", 2, 1}, {"bd", 1, 1},  {"bei", 1, 1}, {"bed", 1, 1}, {"bf", 1, 1},
     {"bi", 1, 1},   {"ber", 1, 1}, {"br", 1, 1},   {"sp", 1, 1},  {"sr", 1, 1},  {"sd", 1, 1},  {"snand", 1, 1}, {"srnd", 1, 1},
     {"ld", 1, 1},   {"lds", 1, 1}, {"lr2", 1, 1},  {"lri", 1, 1}, {"lr", 1, 1},  {"ls", 1, 1},  {"lp", 1, 1},  {"lis", 1, 1},
-    {"lrs", 1, 1},  {"ft", 2, 0},  {"fn", 1, 0},   {"fo", 2, 0},  {"len", 2, 0}, {"b64", 7, 1}, {"uri", 1, 1}, {"zip", 1, 1},
+    {"lrs", 1, 1},  {"ft", 2, 0},  {"fn", 1, 0},   {"fo", 2, 0},  {"len", 2, 1}, {"b64", 7, 1}, {"uri", 1, 1}, {"zip", 1, 1},
     {"nil", 0, 1}};
-static const PatInfo PATS[P_COUNT] = {{"od", 1, 1}, {"nd", 2, 1}, {"bu", 1, 1}, {"sk", 2, 0}, {"sz", 2, 0},
-                                      {"cs", 1, 0}, {"ar", 1, 0}, {"cp", 1, 0}, {"co", 0, 1}, {"nu", 0, 1}};
+static const PatInfo PATS[P_COUNT] = {{"od", 1, 1}, {"nd", 2, 1}, {"bu", 1, 1}, {"sk", 2, 1}, {"sz", 2, 1},
+                                      {"cs", 1, 1}, {"ar", 1, 1}, {"cp", 1, 1}, {"co", 0, 1}, {"nu", 0, 1}};
 
 }  // namespace eh
 
@@ -637,6 +858,9 @@ int eh_create(int device, eh_ctx** out) {
   ctx->cus = prop.multiProcessorCount;
   uint16_t t1[65], t2[65], t3[65];
   init_tables(t1, t2, t3);
+  uint32_t crct[256];
+  for (uint32_t i = 0; i < 256; i++) { uint32_t cc = i; for (int k = 0; k < 8; k++) cc = (cc & 1) ? 0xEDB88320u ^ (cc >> 1) : cc >> 1; crct[i] = cc; }
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_crc_table), crct, sizeof(crct)) != hipSuccess) { delete ctx; return EH_E_HIP; }
   static uint8_t funny[192][5];
   memset(funny, 0, sizeof(funny));
   int nf = build_funny(funny);

@@ -171,3 +171,22 @@ def test_tree_mutators(seed):
 
 def test_tree_mutators_mixed_corpus():
     _compare(_texty(150, 2048, 31), TREES + ",bd", "od,nd,bu", max_skipped=0.15, oracle_cap=256 << 10, engine_cap=2 << 20)
+
+
+def _framed_inputs(n, size, seed):
+    from erlamsa_amd import synth
+    rng = np.random.Generator(np.random.PCG64(seed))
+    m = synth._framed(rng, n, size)
+    return [bytes(r) for r in m]
+
+
+def test_len_mutator():
+    ins = _framed_inputs(200, 300, 1) + _framed_inputs(100, 64, 2) + [b"\x00\x05hello", b"\x03abc", b"abc", b"\x00\x00\x00\x04abcd\x00"] * 10
+    _compare(ins, "len", "od,nd,bu", max_skipped=0.2, oracle_cap=1 << 20, engine_cap=4 << 20)
+    _compare(ins + util.corpus_uniform(100, 700), "len,bd,bf,sd", "od,nd,bu", seed=(4, 4, 4), max_skipped=0.2, oracle_cap=1 << 20, engine_cap=4 << 20)
+
+
+@pytest.mark.parametrize("pats", ["sk", "sz", "cs", "ar", "cp", "od,nd,bu,sk,sz,cs,ar,cp,co,nu"])
+def test_complex_patterns(pats):
+    ins = _framed_inputs(150, 400, 3) + util.corpus_uniform(100, 300, seed=8) + _texty(60, 512, 9)
+    _compare(ins, BYTE_ALL + ",sd,sr,num,ld", pats, max_skipped=0.2, oracle_cap=1 << 20, engine_cap=4 << 20)
