@@ -39,7 +39,7 @@ def main():
     import numpy as np
     import torch
     import erlamsa_amd as ea
-    from erlamsa_amd import synth
+    from erlamsa_amd import shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -66,7 +66,7 @@ def main():
         mat = synth.mixed(n, size)
         arena.copy_(torch.from_numpy(mat.reshape(-1)))
     if dist is not None:
-        dist.broadcast(arena, src=0)
+        shard.broadcast_corpus(arena, offs, src=0)
     torch.cuda.synchronize()
 
     eng = ea.Engine(local)
@@ -77,7 +77,7 @@ def main():
 
     def step(k):
         # rank r, step k -> case numbers ((k*world + r) * n) + 1 ...
-        eng.fuzz_batch(seed=seed, first_case=(k * world + rank) * n + 1, corpus_first=0, n=n, stream=stream)
+        eng.fuzz_batch(seed=seed, first_case=shard.weak_first_case(k, rank, world, n), corpus_first=0, n=n, stream=stream)
 
     for k in range(args.warmup):
         step(k)

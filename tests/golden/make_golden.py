@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/vectors.json.
+
+IMPORTANT: the reference (Erlang) cannot run on this image, so these vectors are produced by the
+CPU oracle (oracle/), not by erlamsa itself.  They pin the oracle against regressions and give the
+GPU tests a fixture that does not need the oracle at run time.  Format per vector:
+  {seed, first_case, mutations, patterns, inputs_hex[], outputs_hex[], status[]}
+When an Erlang host is available, the same format can be filled from
+  erlamsa_main:fuzzer(#{paths=>[direct], input=>Bin, output=>return, seed=>S, mutations=>M, patterns=>P, n=>N})
+and dropped in here to pin oracle-vs-BEAM parity ("Oracle").
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pyoracle as po  # noqa: E402
+from erlamsa_amd import synth  # noqa: E402
+
+SETS = [
+    ("c2_bytes", (1, 2, 3), "bd,bf,bi", "od", 24, 256, "uniform"),
+    ("bytes_seq", (4, 5, 6), "bd,bei,bed,bf,bi,ber,br,sp,sr,sd,snand,srnd,uw,ui,nil", "od,nd,bu", 24, 200, "uniform"),
+    ("text", (7, 8, 9), "num,ld,lds,lr2,lri,lr,ls,lp,lis,lrs,ab,ad,uri,b64,zip", "od,nd,bu", 24, 300, "mixed"),
+    ("trees_len", (10, 11, 12), "tr2,td,ts1,ts2,tr,len", "od,nd,bu,sk,sz,cs", 24, 300, "mixed"),
+    ("hello", (1, 2, 3), None, "od,nd,bu", 1, 0, "hello"),
+]
+
+
+def main():
+    vecs = []
+    for name, seed, muts, pats, n, size, kind in SETS:
+        if kind == "uniform":
+            inputs = [bytes(r) for r in synth.uniform(n, size, seed=seed[0])]
+        elif kind == "mixed":
+            inputs = [bytes(r) for r in synth.mixed(n, size, seed=seed[0])]
+        else:
+            inputs = [b"Hello erlamsa!\n"]
+            muts = "bd,bei,bed,bf,bi,ber,br,sp,sr,sd,snand,srnd,uw,ui,num,ld,lds,lr2,lri,lr,ls,lp,lis,lrs,ab,ad,tr2,td,ts1,ts2,tr,len,uri,zip,nil"
+        data, off = po.pack(inputs)
+        outs, st, _, _ = po.fuzz_batch(data, off, seed=seed, mutations=muts, patterns=pats, max_case_bytes=256 << 10)
+        vecs.append({"name": name, "seed": list(seed), "first_case": 1, "mutations": muts, "patterns": pats,
+                     "inputs_hex": [b.hex() for b in inputs], "outputs_hex": [o.hex() for o in outs], "status": [int(x) for x in st]})
+    with open(os.path.join(HERE, "vectors.json"), "w") as f:
+        json.dump({"generator": "oracle (C++ restatement) — NOT a BEAM run", "vectors": vecs}, f, indent=0)
+    print("wrote", len(vecs), "vector sets")
+
+
+if __name__ == "__main__":
+    main()

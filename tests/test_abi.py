@@ -1,0 +1,82 @@
+"""The C-ABI shared library loads and exports every symbol include/erlamsa_hip.h declares.
+No compute calls here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    h = open(os.path.join(ROOT, "include", "erlamsa_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(eh_[a-z0-9_]+)\s*\(", h)))
+
+
+def test_library_exports_every_declared_symbol():
+    import erlamsa_amd.engine as eng
+    lib = eng.load_library()
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "missing export " + n
+    assert sorted(eng.ABI_SYMBOLS) == names, "engine.ABI_SYMBOLS out of date with the header"
+    assert lib.eh_abi_version() == 1
+
+
+def test_tables_mirror_the_reference():
+    import erlamsa_amd as ea
+    mt = ea.mutator_table()
+    # table order and default priorities of erlamsa_mutations:mutations/1 (erlamsa_mutations.erl:1291-1331)
+    assert [m[0] for m in mt] == ("sgm js uw ui ab ad tr2 td num ts1 tr ts2 bd bei bed bf bi ber br sp sr sd snand srnd "
+                                  "ld lds lr2 lri lr ls lp lis lrs ft fn fo len b64 uri zip nil").split()
+    assert dict((m[0], m[1]) for m in mt)["sgm"] == 10 and dict((m[0], m[1]) for m in mt)["b64"] == 7
+    assert sum(m[1] for m in mt) == 66
+    pt = ea.pattern_table()
+    assert [(p[0], p[1]) for p in pt] == [("od", 1), ("nd", 2), ("bu", 1), ("sk", 2), ("sz", 2), ("cs", 1), ("ar", 1), ("cp", 1), ("co", 0), ("nu", 0)]
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    """Creating a context must fail loudly when no HIP device is present."""
+    import erlamsa_amd.engine as eng
+    lib = eng.load_library()
+    h = ctypes.c_void_p()
+    rc = lib.eh_create(0, ctypes.byref(h))
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        assert rc != 0 and not h.value
+        with pytest.raises(eng.EngineError):
+            eng.Engine(0)
+    else:
+        assert rc == 0
+        lib.eh_destroy(h)
+
+
+def test_strerror_and_names():
+    import erlamsa_amd.engine as eng
+    lib = eng.load_library()
+    assert lib.eh_strerror(0) == b"ok"
+    assert lib.eh_strerror(-2) == b"no usable HIP device"
+    assert lib.eh_kernel_name() == b"eh_mutate_kernel"
+    assert lib.eh_mutator_name(999) is None
+
+
+def test_host_helpers():
+    import numpy as np
+    import erlamsa_amd as ea
+    data, off = ea.pack_corpus([b"ab", b"", b"cde"])
+    assert off.tolist() == [0, 2, 2, 5] and bytes(data) == b"abcde"
+    assert ea.actions_to_string([("bd", 1), ("num", 3)]) == "bd=1,num=3"
+    assert ea.actions_to_string("bd,bf") == "bd,bf"
+    from erlamsa_amd import shard
+    for n, w in [(10, 3), (65536, 8), (7, 8), (0, 2)]:
+        got = [shard.case_range(n, r, w) for r in range(w)]
+        assert sum(c for _, c in got) == n
+        assert all(got[i][0] + got[i][1] == got[i + 1][0] for i in range(w - 1))
+    assert shard.weak_first_case(0, 0, 8, 100) == 1 and shard.weak_first_case(1, 2, 8, 100) == 1001

@@ -1,0 +1,123 @@
+"""Oracle pinning, part 3: the reference's own eunit properties
+(/root/reference/src/erlamsa_mutations_test.erl) re-expressed against the oracle.  The reference
+seeds from now(); here every run loops over explicit seeds."""
+import re
+
+import numpy as np
+
+import pyoracle as po
+
+
+def _tries(name, data, pred, n, base=0):
+    for k in range(n):
+        d, out, _ = po.run_mutator(name, (base + k, 2 * k + 1, 3 * k + 7), data)
+        if d is not None and pred(out):
+            return True
+    return False
+
+
+def test_sed_num():                       # erlamsa_mutations_test.erl:74-77
+    assert _tries("num", b" 100 + 100 + 100 ", lambda o: b"101" in o, 1500)
+
+
+def test_string_lexer_roundtrip():        # :84-93 (unlex(lex(X)) =:= X)
+    rng = np.random.Generator(np.random.PCG64(4))
+    assert po.lex_roundtrip(bytes([233, 39, 39, 97, 97, 97, 0]))[1] == bytes([233, 39, 39, 97, 97, 97, 0])
+    for _ in range(10000):
+        n = int(rng.integers(0, 42))
+        t = rng.integers(0, 8, size=n)
+        s = bytes([92 if x == 0 else 34 if x == 1 else 39 if x == 2 else 0 if x == 3 else int(rng.integers(0, 256)) if x == 4 else 97 for x in t])
+        cnt, out = po.lex_roundtrip(s)
+        assert cnt >= 0 and out == s
+
+
+DASHES = b"-" * 40 + b'""' + b"-" * 50
+
+
+def test_ascii_bad():                     # :96-100
+    rx = re.compile(rb'^-*".*[%|a].*"-*$', re.S)
+    assert _tries("ab", DASHES, lambda o: rx.match(o) is not None, 50)
+
+
+def test_ascii_delimeter():               # :102-109
+    rx = re.compile(rb'^-*"-*$', re.S)
+    assert _tries("ad", DASHES, lambda o: rx.match(o) is not None, 50)
+
+
+def test_sed_fuse_this():                 # :115-119
+    src = b"kittenslartibartfasterthaneelslartibartfastenyourseatbelts"
+    assert _tries("ft", src, lambda o: o == b"kittenslartibartfastenyourseatbelts", 500)
+
+
+def test_sed_tree_stutter():              # :126-130
+    assert _tries("tr", b"(x (Y x))", lambda o: o == b"(x (x (x (x (Y x)))))", 500)
+
+
+def _distinct(name, data, n):
+    outs = set()
+    for k in range(n):
+        d, out, _ = po.run_mutator(name, (k + 1, k * k + 3, 17 * k + 5), data)
+        outs.add(out)
+    return outs
+
+
+def test_sed_tree_dup_swap_counts():      # :145-152: number of DISTINCT outputs
+    assert len(_distinct("tr2", b"(a)", 20)) == 1          # "(a)(a)" only
+    assert len(_distinct("tr2", b"(a) (b)", 200)) == 2
+    assert len(_distinct("ts1", b"(a) (b) (c)", 400)) == 6
+    assert len(_distinct("ts2", b"(a) (b) (c)", 400)) == 3
+
+
+def test_line_mutators():                 # :167-217
+    d, out, _ = po.run_mutator("lr2", (1, 2, 3), b"1\n")
+    assert out == b"1\n1\n"
+    d, out, _ = po.run_mutator("ls", (1, 2, 3), b"A\n B\n")
+    assert out == b" B\nA\n"
+    outs = _distinct("lri", b"A\nB\n", 200)
+    assert outs == {b"A\nA\n", b"A\nB\n", b"B\nB\n"}
+    src = b"1\n 2\n  3\n   4\n"
+    for k in range(100):
+        d, out, _ = po.run_mutator("ld", (k, 1, 1), src)
+        assert out.count(b"\n") == 3
+        d, out, _ = po.run_mutator("lds", (k, 1, 1), src)
+        assert out.count(b"\n") < 4
+        d, out, _ = po.run_mutator("lp", (k, 1, 1), src)
+        assert sorted(out.split(b"\n")) == sorted(src.split(b"\n"))
+        d, out, _ = po.run_mutator("lr", (k, 1, 1), src)
+        assert out.count(b"\n") > 4
+
+
+def test_st_line_ins_single_line():       # :223-228, the only fixed seed {1,2,3} of the reference
+    d, out, _ = po.run_mutator("lis", (1, 2, 3), b"Hello\n")
+    assert out == b"Hello\nHello\n"
+    h = len(out) // 2
+    assert out[:h] == out[h:]
+
+
+def test_byte_mutators_size_and_sum():    # :247-310
+    rng = np.random.Generator(np.random.PCG64(6))
+    for k in range(300):
+        blk = rng.integers(0, 256, size=int(rng.integers(1, 4097)), dtype=np.uint8).tobytes()
+        seed = (k, k + 1, k + 2)
+        assert len(po.run_mutator("bd", seed, blk)[1]) == len(blk) - 1
+        assert len(po.run_mutator("bi", seed, blk)[1]) == len(blk) + 1
+        assert len(po.run_mutator("br", seed, blk)[1]) == len(blk) + 1
+        for nm, delta in (("bei", 1), ("bed", -1)):
+            out = po.run_mutator(nm, seed, blk)[1]
+            assert len(out) == len(blk)
+            assert (sum(out) - sum(blk)) % 256 == delta % 256
+        out = po.run_mutator("bf", seed, blk)[1]
+        diff = [a ^ b for a, b in zip(out, blk) if a != b]
+        assert len(diff) == 1 and bin(diff[0]).count("1") == 1
+        assert len(po.run_mutator("sd", seed, blk)[1]) < len(blk)
+        assert len(po.run_mutator("sr", seed, blk)[1]) > len(blk)
+        out = po.run_mutator("sp", seed, blk)[1]
+        assert sorted(out) == sorted(blk)
+
+
+def test_utf8_mutators():                 # untested in the reference (:7-11); structural properties
+    assert po.run_mutator("uw", (1, 1, 1), b"\x20")[1] == b"\xc0\xa0"
+    assert po.run_mutator("uw", (1, 1, 1), b"\x7f")[1] == b"\x7f"
+    for k in range(50):
+        out = po.run_mutator("ui", (k, 2, 3), b"abc")[1]
+        assert len(out) > 3 and out[0:1] == b"a"

@@ -1,0 +1,62 @@
+"""Oracle pinning, part 1: AS183 / erlamsa_rnd known answers.
+
+No Erlang runtime exists on this image and the reference's own tests seed from now(), so these
+known answers are HAND-DERIVED from the published algorithm (Wichmann & Hill 1982, AS183) and
+the OTP `random` seeding rule Ai = (|x| rem (Pi-1)) + 1."""
+import numpy as np
+
+import pyoracle as po
+
+P = (30269, 30307, 30323)
+M = (171, 172, 170)
+
+
+def as183(seed, n):
+    a = [(abs(s) % (p - 1)) + 1 for s, p in zip(seed, P)]
+    out = []
+    for _ in range(n):
+        a = [(x * m) % p for x, m, p in zip(a, M, P)]
+        r = a[0] / 30269.0 + a[1] / 30307.0 + a[2] / 30323.0   # left-assoc, IEEE double
+        out.append(r - int(r))
+    return out
+
+
+def test_first_uniform_known_answer():
+    # seed({1,2,3}) -> state {2,3,4}; one step -> {342,516,680}
+    u = po.uniforms((1, 2, 3), 1)[0]
+    assert u == 342 / 30269 + 516 / 30307 + 680 / 30323
+    assert repr(float(u)) == "0.05074967983013061"
+
+
+def test_stream_matches_independent_python_model():
+    for seed in [(1, 2, 3), (0, 0, 0), (30268, 30306, 30322), (-5, 99999, 123456789), (42, 4242, 424242)]:
+        got = po.uniforms(seed, 5000)
+        want = np.array(as183(seed, 5000))
+        assert (got == want).all(), seed
+
+
+def test_seed_wraps_like_otp_random():
+    # (|x| rem (P-1)) + 1: 30268 -> 1, -1 -> 2
+    assert (po.uniforms((30268, 30306, 30322), 10) == po.uniforms((0, 0, 0), 10)).all()
+    assert (po.uniforms((-1, -2, -3), 10) == po.uniforms((1, 2, 3), 10)).all()
+
+
+def test_jump_ahead_identity():
+    """state after k draws = A * mult^k mod P — what the GPU uses for lane-parallel draws."""
+    seed = (7, 11, 13)
+    a = [(abs(s) % (p - 1)) + 1 for s, p in zip(seed, P)]
+    us = as183(seed, 300)
+    for k in (1, 2, 63, 64, 65, 299):
+        b = [(x * pow(m, k + 1, p)) % p for x, m, p in zip(a, M, P)]
+        r = b[0] / 30269.0 + b[1] / 30307.0 + b[2] / 30323.0
+        assert r - int(r) == us[k]
+
+
+def test_period_components_are_full():
+    # 171, 172, 170 are primitive roots of their primes (period 6.95e12)
+    for m, p in zip(M, P):
+        x, n = m, 1
+        while x != 1:
+            x = x * m % p
+            n += 1
+        assert n == p - 1
