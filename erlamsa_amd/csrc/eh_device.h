@@ -248,7 +248,7 @@ EH_DEV void random_block_rev(Ctx& c, uint8_t* dst, uint32_t n) {
 // ---------------------------------------------------------------------------------------------
 // Single-byte mutators  (erlamsa_mutations.erl:56-61,176-223) and UTF-8 (:1081-1099)
 // ---------------------------------------------------------------------------------------------
-EH_DEV int muta_byte(Ctx& c, int fn) {
+__device__ __noinline__ int muta_byte(Ctx& c, int fn) {
   Blk h = blk_load(c.bl, c.cur);
   const uint8_t* src = (const uint8_t*)h.ptr;
   uint32_t L = h.len;
@@ -333,7 +333,7 @@ EH_DEV void wave_sort_key2(Key2* k, uint32_t n_pow2) {
 // ---------------------------------------------------------------------------------------------
 // Multi-byte mutators (erlamsa_mutations.erl:232-318)
 // ---------------------------------------------------------------------------------------------
-EH_DEV int muta_seq(Ctx& c, int fn, int mask_fun) {
+__device__ __noinline__ int muta_seq(Ctx& c, int fn, int mask_fun) {
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* src = (const uint8_t*)hb.ptr;
   uint32_t B = hb.len;

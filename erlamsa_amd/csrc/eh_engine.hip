@@ -183,7 +183,7 @@ struct PatFrame {           // a sizer/csum wrapper waiting for its inner evalua
 
 // get_possible_csum_locations/1 + rand_elem (erlamsa_field_predict.erl:131-161).
 // Returns 1 with (*crc,*plen,*blen), 0 for no candidate, -1 on failure.
-EH_DEV int pick_csum(Ctx& c, const uint8_t* H, uint32_t L, uint32_t* crc, uint32_t* plen, uint32_t* blen) {
+__device__ __noinline__ int pick_csum(Ctx& c, const uint8_t* H, uint32_t L, uint32_t* crc, uint32_t* plen, uint32_t* blen) {
   const int l = EH_LANE;
   if (L == 0) return 0;
   uint32_t maxp = (uint32_t)(2.0 * (double)L / 3.0);

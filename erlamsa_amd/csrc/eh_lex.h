@@ -46,7 +46,7 @@ EH_DEV bool texty(uint32_t b) {                                 // erlamsa_strle
 struct LexChunk { uint32_t type, a, b; };
 
 // Lexes H[0,L) into tab (capacity cap); returns the number of chunks or -1 on table overflow.
-EH_DEV int lex_block(const uint8_t* H, uint32_t L, LexChunk* tab, uint32_t cap) {
+__device__ __noinline__ int lex_block(const uint8_t* H, uint32_t L, LexChunk* tab, uint32_t cap) {
   const int l = EH_LANE;
   ByteReader r; br_init(r, H, L);
   uint32_t pos = 0, n = 0; uint32_t raw_start = 0xFFFFFFFFu;
@@ -248,7 +248,7 @@ EH_DEV void mutate_text_emit(Ctx& c, int tm, const uint8_t* H, uint32_t L, uint3
 
 // construct_ascii_mutator (:585-602) with string_generic_mutate (ab, :571-583) or
 // string_delimeter_mutate (ad, :626-644)
-EH_DEV int muta_ascii(Ctx& c, LexCache& lc, int fn) {
+__device__ __noinline__ int muta_ascii(Ctx& c, LexCache& lc, int fn) {
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
@@ -326,7 +326,7 @@ EH_DEV bool has_zip_eocd(const uint8_t* H, uint32_t L) {
   }
   return __ballot(found != 0) != 0;
 }
-EH_DEV int muta_zip(Ctx& c) {                                   // zip_path_traversal :1149-1163
+__device__ __noinline__ int muta_zip(Ctx& c) {                                   // zip_path_traversal :1149-1163
   Blk hb = blk_load(c.bl, c.cur);
   c.r_kind = R_SAME;
   if (has_zip_eocd((const uint8_t*)hb.ptr, hb.len)) { c.status = CASE_UNSUPPORTED; return 0; }
@@ -365,7 +365,7 @@ EH_DEV bool b64_decodes(const uint8_t* t, uint32_t n) {        // stdlib base64:
   }
   return uni((uint32_t)__shfl((int)ok, 0)) != 0;
 }
-EH_DEV int muta_b64(Ctx& c, LexCache& lc) {
+__device__ __noinline__ int muta_b64(Ctx& c, LexCache& lc) {
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
@@ -383,7 +383,7 @@ EH_DEV int muta_b64(Ctx& c, LexCache& lc) {
 }
 
 // uri_mutator :770-784 (+ try_uri_mutate :760-768, rand_uri_mutate :737-758)
-EH_DEV int muta_uri(Ctx& c, LexCache& lc) {
+__device__ __noinline__ int muta_uri(Ctx& c, LexCache& lc) {
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;

@@ -96,7 +96,7 @@ EH_DEV void tree_matches(const uint8_t* H, const TNode* nodes, uint32_t lo, uint
 }
 
 // sed_tree_op (tr2/td :917-936), construct_sed_tree_swap (ts1/ts2 :940-971), sed_tree_stutter (tr :975-1023)
-EH_DEV int muta_tree(Ctx& c, int fn) {
+__device__ __noinline__ int muta_tree(Ctx& c, int fn) {
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   const int l = EH_LANE;
