@@ -33,7 +33,9 @@ def main():
     ap.add_argument("--patterns", default="od,nd,bu")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="cases timed on the CPU oracle (0 = skip)")
     ap.add_argument("--max-slots", type=int, default=0)
-    ap.add_argument("--out-gib", type=int, default=16, help="output arena capacity per GPU (GiB)")
+    ap.add_argument("--out-gib", type=int, default=8, help="output arena capacity per context (GiB)")
+    ap.add_argument("--case-mib", type=int, default=8, help="per-case work area (MiB), eh_options.max_case_bytes")
+    ap.add_argument("--inflight", type=int, default=3, help="passes in flight (engine contexts / HIP streams)")
     args = ap.parse_args()
 
     import numpy as np
@@ -69,18 +71,29 @@ def main():
         shard.broadcast_corpus(arena, offs, src=0)
     torch.cuda.synchronize()
 
-    eng = ea.Engine(local)
-    eng.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30)
-    eng.attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
-    stream = torch.cuda.current_stream().cuda_stream
+    # `--inflight` engine contexts, each on its own HIP stream: step k runs on context k % inflight, so
+    # the long tail of one pass (a few MB-sized cases handled by single wavefronts) overlaps with
+    # the next pass instead of idling the GPU.  Every step is still a complete, separate pass.
+    nctx = max(1, min(args.inflight, args.steps))
+    engines, streams = [], []
+    for _ in range(nctx):
+        e = ea.Engine(local)
+        e.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
+                    max_case_bytes=args.case_mib << 20)
+        e.attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
+        engines.append(e)
+        streams.append(torch.cuda.Stream(device=dev))
     seed = (1, 2, 3)
 
-    def step(k):
+    def launch(k):
         # rank r, step k -> case numbers ((k*world + r) * n) + 1 ...
-        eng.fuzz_batch(seed=seed, first_case=shard.weak_first_case(k, rank, world, n), corpus_first=0, n=n, stream=stream)
+        engines[k % nctx].fuzz_batch(seed=seed, first_case=shard.weak_first_case(k, rank, world, n), corpus_first=0, n=n,
+                                     stream=streams[k % nctx].cuda_stream)
 
     for k in range(args.warmup):
-        step(k)
+        launch(k)
+    for e in engines:
+        e.sync() if getattr(e, "last_n", None) is not None else None
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -89,14 +102,23 @@ def main():
     out_bytes = 0
     kern_ms = []
     status_counts = np.zeros(5, dtype=np.int64)
-    for k in range(args.steps):
-        step(args.warmup + k)
-        # totals() waits for the batch (the next batch reuses the result buffers); the kernel time
-        # itself comes from HIP events recorded on the launch stream inside the library
-        _, ob, _ = eng.totals()
+
+    def collect(e):
+        nonlocal out_bytes, status_counts
+        # totals() waits for that context's batch; the kernel time itself comes from HIP events
+        # recorded on the launch stream inside the library
+        _, ob, _ = e.totals()
         out_bytes += ob
-        kern_ms.append(eng.kernel_ms())
-        status_counts += np.bincount(eng.status(), minlength=5)[:5]
+        kern_ms.append(e.kernel_ms())
+        status_counts += np.bincount(e.status(), minlength=5)[:5]
+
+    for k in range(args.steps):
+        kk = args.warmup + k
+        if k >= nctx:
+            collect(engines[kk % nctx])          # the result buffers of this context are reused below
+        launch(kk)
+    for k in range(max(0, args.steps - nctx), args.steps):
+        collect(engines[(args.warmup + k) % nctx])
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -130,7 +152,7 @@ def main():
                             "15%% bracketed text, 10%% length/CRC-framed), generator direct=500/random=1, patterns %s, "
                             "mutators %s (%d of the %d in the default table run on the GPU in this build)"
                             % (n, size, pats, muts, len(muts.split(",")), nmut_total),
-                "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world,
+                "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx,
             },
             "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(max_case_bytes)", "unsupported", "arena_full"],
                                     [int(x) for x in status_counts])),

@@ -208,6 +208,7 @@ struct Ctx {
   int r_flush;         // result goes through flush_bvecs/2
   int r_drop_next;     // fn consumed the following block
   int r_changed;       // mutator guarantees hd(result) != hd(input): skip the compare
+  int r2; uint8_t* r2_ptr; uint32_t r2_len;   // optional second flushed region (fo: flush_bvecs(A, flush_bvecs(B, T)))
   // per-lane mux_fuzzers entry (lane i = list position i)
   uint32_t e_pri;
   uint32_t e_meta;     // score | fn<<8 | name<<16 | mask<<24
@@ -502,8 +503,10 @@ EH_DEV int run_mutator(Ctx& c, uint32_t fn, uint32_t mask) {
 // Applies the candidate to the block list: bl[cur] is replaced (possibly by several flush_bvecs
 // chunks) and, for fn, bl[cur+1] is dropped.
 EH_DEV void commit_result(Ctx& c) {
-  uint32_t chunks = 1;
-  if (c.r_flush) chunks = c.r_len / AVG_BLOCK_SIZE + 1;     // flush_bvecs: k full blocks + remainder (may be <<>>)
+  uint32_t chunks1 = 1;
+  if (c.r_flush) chunks1 = c.r_len / AVG_BLOCK_SIZE + 1;    // flush_bvecs: k full blocks + remainder (may be <<>>)
+  uint32_t chunks2 = c.r2 ? c.r2_len / AVG_BLOCK_SIZE + 1 : 0;
+  uint32_t chunks = chunks1 + chunks2;
   int drop = 1 + (c.r_drop_next && c.cur + 1 < c.nb ? 1 : 0);
   int tail = c.nb - c.cur - drop;
   int newnb = c.cur + (int)chunks + tail;
@@ -515,9 +518,13 @@ EH_DEV void commit_result(Ctx& c) {
     for (int i = l; i < tail; i += 64) c.bl[c.cur + (int)chunks + i] = c.bl2[i];
   }
   for (uint32_t k = EH_LANE; k < chunks; k += 64) {
-    uint64_t off = (uint64_t)k * AVG_BLOCK_SIZE;
-    uint32_t len = c.r_flush ? (k + 1 < chunks ? AVG_BLOCK_SIZE : c.r_len - (uint32_t)off) : c.r_len;
-    c.bl[c.cur + k].ptr = (uint64_t)(c.r_ptr + off); c.bl[c.cur + k].len = len; c.bl[c.cur + k].aux = 0;
+    bool second = k >= chunks1;
+    uint32_t kk = second ? k - chunks1 : k, nchk = second ? chunks2 : chunks1;
+    uint8_t* base = second ? c.r2_ptr : c.r_ptr; uint32_t blen = second ? c.r2_len : c.r_len;
+    bool fl = second || c.r_flush;
+    uint64_t off = (uint64_t)kk * AVG_BLOCK_SIZE;
+    uint32_t len = fl ? (kk + 1 < nchk ? AVG_BLOCK_SIZE : blen - (uint32_t)off) : blen;
+    c.bl[c.cur + k].ptr = (uint64_t)(base + off); c.bl[c.cur + k].len = len; c.bl[c.cur + k].aux = 0;
   }
   c.nb = newnb;
   wave_sync();
@@ -552,7 +559,7 @@ EH_DEV void mux_fuzzers(Ctx& c) {
     int j = (int)__builtin_ctzll(who);
     uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)c.e_meta, j);
     uint32_t fn = em_fn(meta), name = em_name(meta);
-    c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0;
+    c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
     uint64_t mark = c.ws_used;
 #ifdef EH_PROF
     uint64_t pt0 = __builtin_readcyclecounter();

@@ -25,6 +25,7 @@
 #include "eh_lex.h"
 #include "eh_tree.h"
 #include "eh_field.h"
+#include "eh_fuse.h"
 
 namespace eh {
 
@@ -43,6 +44,7 @@ EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
     case M_B64: return muta_b64(c, *(LexCache*)(c.aux + 1024));
     case M_ZIP: return muta_zip(c);
     case M_LEN: return muta_len(c);
+    case M_FT: case M_FN: case M_FO: return muta_fuse(c, (int)fn, (FoState*)(c.aux + 704));
     case M_TR2: case M_TD: case M_TS1: case M_TS2: case M_TR: return muta_tree(c, (int)fn);
     default: c.status = CASE_UNSUPPORTED; c.r_kind = R_SAME; return 0;
   }
@@ -495,8 +497,8 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(KParam
     if (i >= p.n) break;
     uint64_t tick0 = __builtin_readcyclecounter();
     c.status = CASE_OK; c.lastm = -1; c.nb = 0; c.cur = 0; c.nem = 0; c.ws_used = 0;
-    c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0;
-    if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; ((LexCache*)(c.aux + 1024))->n = -1; }
+    c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r2 = 0;
+    if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; ((LexCache*)(c.aux + 1024))->n = -1; ((FoState*)(c.aux + 704))->has = 0; }
     c.ws_cap = p.work_cap;
     wave_sync();
     int gen;
@@ -568,7 +570,19 @@ __global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf, const ui
     uint32_t kind = jobs[5 * j], d = jobs[5 * j + 1], s = jobs[5 * j + 2], n = jobs[5 * j + 3], pl = jobs[5 * j + 4];
     if (kind == 0) wave_copy(buf + d, buf + s, n);
     else if (kind == 1) wave_fill_periodic(buf + d, buf + s, pl, n);
-    else { bool e = wave_equal(buf + d, buf + s, n); if (EH_LANE == 0) eq_out[j] = e ? 1u : 0u; }
+    else if (kind == 2) { bool e = wave_equal(buf + d, buf + s, n); if (EH_LANE == 0) eq_out[j] = e ? 1u : 0u; }
+    else {  // kind 3: mask window self check over buf[s, s+n) with window base d (multiple of 64)
+      MaskWin<4> a, b; a.p = buf + s; a.L = n; b.p = buf + s; b.L = n;
+      mw_load(a, d, LexCls()); mw_load_ref(b, d, LexCls());
+      uint32_t bad = 0;
+      for (int k = 0; k < 4; k++) bad += a.m[k] != b.m[k] ? 1u : 0u;
+      bad += a.inrange != b.inrange ? 1u : 0u;
+      MaskWin<4> c2, d2; c2.p = buf + s; c2.L = n; d2.p = buf + s; d2.L = n;
+      mw_load(c2, d, DelimCls()); mw_load_ref(d2, d, DelimCls());
+      for (int k = 0; k < 4; k++) bad += c2.m[k] != d2.m[k] ? 1u : 0u;
+      bad = wave_sum(bad);
+      if (EH_LANE == 0) eq_out[j] = bad;
+    }
     wave_sync();
   }
 }
@@ -581,7 +595,7 @@ static const MutaInfo MUTAS[M_COUNT] = {
     {"num", 3, 1},  {"ts1", 2, 1}, {"tr", 2, 1},   {"ts2", 2, 1}, {"bd", 1, 1},  {"bei", 1, 1}, {"bed", 1, 1}, {"bf", 1, 1},
     {"bi", 1, 1},   {"ber", 1, 1}, {"br", 1, 1},   {"sp", 1, 1},  {"sr", 1, 1},  {"sd", 1, 1},  {"snand", 1, 1}, {"srnd", 1, 1},
     {"ld", 1, 1},   {"lds", 1, 1}, {"lr2", 1, 1},  {"lri", 1, 1}, {"lr", 1, 1},  {"ls", 1, 1},  {"lp", 1, 1},  {"lis", 1, 1},
-    {"lrs", 1, 1},  {"ft", 2, 0},  {"fn", 1, 0},   {"fo", 2, 0},  {"len", 2, 1}, {"b64", 7, 1}, {"uri", 1, 1}, {"zip", 1, 1},
+    {"lrs", 1, 1},  {"ft", 2, 1},  {"fn", 1, 1},   {"fo", 2, 1},  {"len", 2, 1}, {"b64", 7, 1}, {"uri", 1, 1}, {"zip", 1, 1},
     {"nil", 0, 1}};
 static const PatInfo PATS[P_COUNT] = {{"od", 1, 1}, {"nd", 2, 1}, {"bu", 1, 1}, {"sk", 2, 1}, {"sz", 2, 1},
                                       {"cs", 1, 1}, {"ar", 1, 1}, {"cp", 1, 1}, {"co", 0, 1}, {"nu", 0, 1}};

@@ -8,6 +8,7 @@
 // lexing mutators are usually tried on the same block within one mux_fuzzers call.
 #pragma once
 #include "eh_text.h"
+#include "eh_mask.h"
 
 namespace eh {
 
@@ -45,48 +46,88 @@ EH_DEV bool texty(uint32_t b) {                                 // erlamsa_strle
 // (for delimited: a = opening quote, b = one past the closing quote)
 struct LexChunk { uint32_t type, a, b; };
 
+// Event-driven lexer.  Classes: 0 texty, 1 '"', 2 "'", 3 backslash.  The automaton of
+// erlamsa_strlex (string_lex_step / step_text / step_delimited) only changes state at quotes,
+// backslashes, non-texty bytes and at positions where texty_enough/1 flips, so it hops between
+// those with mask lookups.
+struct LexCls { EH_DEV uint32_t operator()(uint32_t b) const { return (texty(b) ? 1u : 0u) | (b == 34 ? 2u : 0u) | (b == 39 ? 4u : 0u) | (b == 92 ? 8u : 0u); } };
+struct LexWin { MaskWin<4> w; uint64_t nt, te; };
+EH_DEV void lw_load(LexWin& x, uint32_t base) {
+#ifdef EH_MW_REF
+  mw_load_ref(x.w, base, LexCls());
+#else
+  mw_load(x.w, base, LexCls());
+#endif
+  uint64_t T = x.w.m[0];
+  x.nt = ~T & x.w.inrange;
+  // texty_enough (:54-64): the next 6 bytes are texty, running off the end counts as texty
+  uint64_t Tp = T | ~x.w.inrange;
+  uint64_t nx = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(Tp >> 32), 1) << 32) | (uint32_t)__shfl_down((int)(uint32_t)Tp, 1);
+  if (EH_LANE == 63) nx = ~0ull;
+  uint64_t te = Tp;
+#pragma unroll
+  for (int d = 1; d <= 5; d++) te &= (Tp >> d) | (nx << (64 - d));
+  x.te = te & x.w.inrange;
+}
+enum { EV_TE, EV_TEXT, EV_D1, EV_D2 };
+// absolute position of the next event of kind `ev` at or after pos (L if none)
+EH_DEV uint32_t lw_find(LexWin& x, int ev, uint32_t pos) {
+  const uint32_t L = x.w.L;
+  while (pos < L) {
+    if (!x.w.valid || pos < x.w.base || pos >= x.w.base + MW_STEP) lw_load(x, pos & ~63u);
+    uint64_t word = ev == EV_TE ? x.te : (ev == EV_TEXT ? (x.w.m[1] | x.w.m[2] | x.nt) : (ev == EV_D1 ? (x.w.m[1] | x.w.m[3] | x.nt) : (x.w.m[2] | x.w.m[3] | x.nt)));
+    uint32_t r = mw_next(word, pos - x.w.base);
+    if (r < MW_STEP) return x.w.base + r;
+    pos = x.w.base + MW_STEP;
+  }
+  return L;
+}
+EH_DEV bool lw_is(LexWin& x, int cls, uint32_t pos) {           // cls: 0 texty 1 dq 2 sq 3 bs 4 texty_enough; pos < L
+  // texty_enough bits of the lookahead word are not valid
+  if (!x.w.valid || pos < x.w.base || pos >= x.w.base + (cls == 4 ? MW_STEP : MW_STEP + 64)) lw_load(x, pos & ~63u);
+  return mw_test(cls == 4 ? x.te : x.w.m[cls], pos - x.w.base);
+}
+
 // Lexes H[0,L) into tab (capacity cap); returns the number of chunks or -1 on table overflow.
 __device__ __noinline__ int lex_block(const uint8_t* H, uint32_t L, LexChunk* tab, uint32_t cap) {
   const int l = EH_LANE;
-  ByteReader r; br_init(r, H, L);
+  LexWin x; x.w.p = H; x.w.L = L; x.w.valid = false; x.w.base = 0;
   uint32_t pos = 0, n = 0; uint32_t raw_start = 0xFFFFFFFFu;
   auto emit = [&](uint32_t type, uint32_t a, uint32_t b) {
     if (n < cap && l == 0) { tab[n].type = type; tab[n].a = a; tab[n].b = b; }
     n++;
   };
   while (pos < L) {
-    // string_lex_step: texty_enough(Lst) with MIN_TEXTY = 6   (:54-64,79-97)
-    bool te = true;
-    for (uint32_t k = 0; k < 6; k++) {
-      if (pos + k >= L) break;
-      if (!texty(br_get(r, pos + k, pos))) { te = false; break; }
+    // string_lex_step (:79-97): raw bytes until texty_enough holds
+    if (!lw_is(x, 4, pos)) {
+      if (raw_start == 0xFFFFFFFFu) raw_start = pos;
+      pos = lw_find(x, EV_TE, pos + 1);
+      continue;
     }
-    if (!te) { if (raw_start == 0xFFFFFFFFu) raw_start = pos; pos++; continue; }
     if (raw_start != 0xFFFFFFFFu) { emit(1, raw_start, pos); raw_start = 0xFFFFFFFFu; }
-    // step_text (:99-112)
     uint32_t seen = pos; bool resume = false;
-    while (!resume) {
-      if (pos >= L) { emit(0, seen, L); resume = true; break; }
-      uint32_t h = br_get(r, pos, seen < pos ? pos : seen);
-      if (h == 34 || h == 39) {
-        // step_delimited (:114-142)
-        uint32_t q = pos, p2 = pos + 1;
-        while (true) {
-          if (p2 >= L) { emit(0, seen, L); pos = L; resume = true; break; }
-          uint32_t x = br_get(r, p2, p2);
-          if (x == h) {
-            if (q > seen) emit(0, seen, q);
-            emit(2, q, p2 + 1);
-            pos = p2 + 1; resume = true; break;
-          } else if (x == 92) {
-            if (p2 + 1 >= L) p2 += 1;
-            else if (texty(br_get(r, p2 + 1, p2))) p2 += 2;
-            else p2 += 1;
-          } else if (texty(x)) p2 += 1;
-          else { emit(0, seen, p2); pos = p2; resume = true; break; }
+    while (!resume) {                                           // step_text (:99-112)
+      pos = lw_find(x, EV_TEXT, pos);
+      if (pos >= L) { emit(0, seen, L); pos = L; break; }
+      if (!lw_is(x, 0, pos)) { emit(0, seen, pos); break; }     // non-texty byte ends the text chunk
+      uint32_t qcls = lw_is(x, 1, pos) ? 1 : 2;                 // step_delimited (:114-142)
+      uint32_t q = pos, p2 = pos + 1;
+      while (true) {
+        p2 = lw_find(x, qcls == 1 ? EV_D1 : EV_D2, p2);
+        if (p2 >= L) { emit(0, seen, L); pos = L; resume = true; break; }
+        if (lw_is(x, (int)qcls, p2)) {                          // closing quote
+          if (q > seen) emit(0, seen, q);
+          emit(2, q, p2 + 1);
+          pos = p2 + 1; resume = true; break;
         }
-      } else if (texty(h)) pos++;
-      else { emit(0, seen, pos); resume = true; }
+        if (lw_is(x, 3, p2)) {                                  // backslash: skips the next byte when that is texty
+          if (p2 + 1 >= L) p2 += 1;
+          else if (lw_is(x, 0, p2 + 1)) p2 += 2;
+          else p2 += 1;
+          continue;
+        }
+        emit(0, seen, p2); pos = p2; resume = true; break;      // non-texty byte: the whole thing was text
+      }
     }
   }
   if (raw_start != 0xFFFFFFFFu) emit(1, raw_start, L);

@@ -13,52 +13,100 @@
 
 namespace eh {
 
-struct TNode { uint32_t open, close; };
+struct TNode { uint32_t open, close, pend, pad; };      // pend = one past the close of the nearest enclosing NODE (level end)
 
 EH_DEV uint32_t usual_delim_close(uint32_t c) {                 // usual_delims/1 :791-798
   switch (c) { case 40: return 41; case 91: return 93; case 60: return 62; case 123: return 125; case 34: return 34; case 39: return 39; }
   return 0;
 }
+// delimiter code planes: 1 ( 2 ) 3 [ 4 ] 5 < 6 > 7 { 8 } 9 " 10 '  (0 = plain byte)
+struct DelimCls {
+  EH_DEV uint32_t operator()(uint32_t b) const {
+    switch (b) { case 40: return 1; case 41: return 2; case 91: return 3; case 93: return 4; case 60: return 5; case 62: return 6;
+                 case 123: return 7; case 125: return 8; case 34: return 9; case 39: return 10; }
+    return 0;
+  }
+};
+EH_DEV uint32_t delim_close_code(uint32_t code) { return code == 9 ? 9u : (code == 10 ? 10u : code + 1); }   // opener code -> closer code
+EH_DEV bool delim_is_opener(uint32_t code) { return code == 1 || code == 3 || code == 5 || code == 7 || code == 9 || code == 10; }
 struct IsOpener { EH_DEV bool operator()(uint32_t b, uint32_t) const { return b == 40 || b == 91 || b == 60 || b == 123 || b == 34 || b == 39; } };
 
-// Parses the block; returns the number of completed nodes (table sorted by open), or -1 on
-// allocation failure.  Tables live in the work area (caller resets the allocator mark).
-EH_DEV int tree_parse(Ctx& c, const uint8_t* H, uint32_t L, TNode** out) {
+// Parses the block (partial_parse/1 + grow/3, :800-905) and returns the completed nodes sorted by
+// open position (pre-order), or -1 on allocation failure.  The matcher only looks at delimiter
+// bytes (mask events); its stack lives in lane registers (entry d in lane d - base), spilling 32
+// entries at a time to the work area for nesting deeper than 64.
+struct IsDelim { EH_DEV bool operator()(uint32_t b, uint32_t) const { return b == 40 || b == 41 || b == 91 || b == 93 || b == 60 || b == 62 || b == 123 || b == 125 || b == 34 || b == 39; } };
+__device__ __noinline__ int tree_parse(Ctx& c, const uint8_t* H, uint32_t L, TNode** out) {
   const int l = EH_LANE;
+  // 1. positions of all delimiter bytes, in order (parallel scan + compaction)
+  uint32_t nev = wave_count(H, L, IsDelim());
   uint32_t nopen = wave_count(H, L, IsOpener());
   TNode* tab = (TNode*)ws_alloc(c, (uint64_t)(nopen + 1) * sizeof(TNode));
-  uint32_t* stack = (uint32_t*)ws_alloc(c, (uint64_t)(nopen + 1) * 4);
-  if (!tab || !stack) return -1;
-  ByteReader r; br_init(r, H, L);
-  uint32_t nslots = 0, sp = 0, top_close = 0, top_slot = 0;
-  for (uint32_t pos = 0; pos < L; pos++) {
-    uint32_t b = br_get(r, pos, pos);
-    if (sp > 0 && b == top_close) {                              // grow: H =:= Close  (:806-807)
-      if (l == 0) tab[top_slot].close = pos;
-      sp--;
-      if (sp > 0) { uint32_t e = uni(stack[sp - 1]); top_slot = e >> 8; top_close = e & 255u; }
-      continue;
-    }
-    uint32_t cl = usual_delim_close(b);
-    if (cl) {
-      if (nslots >= (1u << 24)) { c.status = CASE_OVERFLOW; return -1; }
-      if (l == 0) { tab[nslots].open = pos; tab[nslots].close = 0xFFFFFFFFu; stack[sp] = (nslots << 8) | cl; }
-      wave_sync();
-      top_slot = nslots; top_close = cl; nslots++; sp++;
+  uint32_t* spill = (uint32_t*)ws_alloc(c, (uint64_t)(nopen + 64) * 4);
+  uint32_t* evp = (uint32_t*)ws_alloc(c, (uint64_t)(nev + 64) * 4);
+  if (!tab || !spill || !evp) return -1;
+  if (nopen >= (1u << 24)) { c.status = CASE_OVERFLOW; return -1; }
+  wave_collect(H, L, 0, nev, evp, IsDelim());
+  // 2. the matcher walks the event list 64 events at a time; positions and delimiter codes sit in
+  //    registers (lane i = event i of the batch), the stack in lane registers too.
+  uint32_t stk = 0;                      // my stack entry: slot << 8 | expected closer code
+  uint32_t sp = 0, sbase = 0;            // depth, depth held by lane 0
+  uint32_t nslots = 0, top = 0;          // top = copy of the top entry
+  for (uint32_t eb = 0; eb < nev; eb += 64) {
+    uint32_t mypos = eb + (uint32_t)l < nev ? evp[eb + l] : 0;
+    uint32_t mycode = eb + (uint32_t)l < nev ? DelimCls()((uint32_t)H[mypos]) : 0;
+    uint32_t cnt = nev - eb < 64 ? nev - eb : 64;
+    for (uint32_t e = 0; e < cnt; e++) {
+      uint32_t code = (uint32_t)__builtin_amdgcn_readlane((int)mycode, (int)e);
+      if (sp > 0 && code == (top & 255u)) {                       // grow: H =:= Close (:806-807)
+        uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)mypos, (int)e);
+        if (l == 0) tab[top >> 8].close = pos;
+        sp--;
+        if (sp > 0) {
+          if (sp == sbase) {                                      // refill the lower 32 entries from the spill area
+            uint32_t up = (uint32_t)__shfl_up((int)stk, 32);
+            sbase -= 32;
+            stk = l < 32 ? spill[sbase + l] : up;
+          }
+          top = (uint32_t)__builtin_amdgcn_readlane((int)stk, (int)(sp - 1 - sbase));
+        }
+      } else if (delim_is_opener(code)) {
+        uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)mypos, (int)e);
+        if (sp - sbase == 64) {                                   // spill the lower half
+          if (l < 32) spill[sbase + l] = stk;
+          stk = (uint32_t)__shfl_down((int)stk, 32);
+          sbase += 32;
+        }
+        uint32_t parent = sp > 0 ? (top >> 8) : 0xFFFFFFFFu;
+        uint32_t ent = (nslots << 8) | delim_close_code(code);
+        if ((uint32_t)l == sp - sbase) stk = ent;
+        if (l == 0) { tab[nslots].open = pos; tab[nslots].close = 0xFFFFFFFFu; tab[nslots].pend = parent; }
+        top = ent; nslots++; sp++;
+      }
     }
   }
   wave_sync();
-  // compact completed nodes (keep pre-order)
+  // level end of every slot: one past the close of the nearest ancestor that did close (L at top level)
+  for (uint32_t base = 0; base < nslots; base += 64) {
+    uint32_t i = base + (uint32_t)l;
+    if (i < nslots) {
+      uint32_t pidx = tab[i].pend, pe = L;
+      while (pidx != 0xFFFFFFFFu) { uint32_t pc = tab[pidx].close; if (pc != 0xFFFFFFFFu) { pe = pc + 1; break; } pidx = tab[pidx].pend; }
+      tab[i].pad = pe;
+    }
+  }
+  wave_sync();
+  // compact completed nodes (keep pre-order); pend <- level end
   uint32_t n = 0;
   for (uint32_t base = 0; base < nslots; base += 64) {
     uint32_t i = base + (uint32_t)l;
-    TNode t{0, 0xFFFFFFFFu};
+    TNode t{0, 0xFFFFFFFFu, 0, 0};
     if (i < nslots) t = tab[i];
     bool ok = i < nslots && t.close != 0xFFFFFFFFu;
     unsigned long long m = __ballot(ok);
     uint32_t before = (uint32_t)__popcll(m & ((1ull << l) - 1));
     wave_sync();
-    if (ok) tab[n + before] = t;      // n + before <= i: never overwrites an unread slot of a later chunk
+    if (ok) { t.pend = t.pad; tab[n + before] = t; }   // n + before <= i: never overwrites an unread slot of a later chunk
     n += (uint32_t)__popcll(m);
     wave_sync();
   }
@@ -72,26 +120,33 @@ EH_DEV bool node_eq(const uint8_t* H, TNode a, TNode b) {
   if (a.open == b.open) return true;
   return wave_equal(H + a.open, H + b.open, la);
 }
-EH_DEV TNode node_load(const TNode* t, uint32_t i) { TNode x = t[i]; x.open = uni(x.open); x.close = uni(x.close); return x; }
+EH_DEV TNode node_load(const TNode* t, uint32_t i) { TNode x = t[i]; x.open = uni(x.open); x.close = uni(x.close); x.pend = uni(x.pend); return x; }
 
-// edit_sublist/3 sweep (:858-869) over nodes[lo..hi) (a subtree in pre-order; the level that
-// contains nodes[lo] ends at `level_end`).  Calls f(match, idx) for each matched node in order.
-// `anc` is scratch for the ancestor stack (capacity = node count).
+// edit_sublist/3 sweep (:858-869) over nodes[lo..hi) in pre-order: the first node of a level that
+// equals `sub` is reported and the rest of that level (up to its pend) is skipped.  64 nodes are
+// loaded per step; only nodes of the right length are compared.  `level_end` replaces pend for
+// nodes whose level is the sweep's own top level (sweeps restricted to a subtree pass its end).
 template <class F>
 EH_DEV void tree_matches(const uint8_t* H, const TNode* nodes, uint32_t lo, uint32_t hi, uint32_t level_end, TNode sub, uint32_t* anc, F f) {
-  uint32_t skip_until = 0, sp = 0;
-  for (uint32_t i = lo; i < hi; i++) {
-    TNode q = node_load(nodes, i);
-    if (q.open < skip_until) continue;
-    while (sp > 0 && uni(anc[sp - 1]) < q.open) sp--;           // anc holds close positions of open ancestors
-    if (node_eq(H, q, sub)) {
-      f(q, i);
-      skip_until = sp > 0 ? uni(anc[sp - 1]) + 1 : level_end;    // rest of the parent's level is left alone
-      continue;
+  (void)anc;
+  const int l = EH_LANE;
+  uint32_t skip_until = 0;
+  uint32_t slen = sub.close - sub.open;
+  for (uint32_t base = lo; base < hi; base += 64) {
+    uint32_t i = base + (uint32_t)l;
+    TNode q{0, 0, 0, 0};
+    if (i < hi) q = nodes[i];
+    bool cand = i < hi && q.close - q.open == slen;
+    unsigned long long cm = __ballot(cand);
+    while (cm) {
+      int j = (int)__builtin_ctzll(cm); cm &= cm - 1;
+      TNode x; x.open = (uint32_t)__builtin_amdgcn_readlane((int)q.open, j); x.close = (uint32_t)__builtin_amdgcn_readlane((int)q.close, j);
+      x.pend = (uint32_t)__builtin_amdgcn_readlane((int)q.pend, j); x.pad = 0;
+      if (x.open < skip_until) continue;
+      if (!node_eq(H, x, sub)) continue;
+      f(x, base + (uint32_t)j);
+      skip_until = x.pend < level_end ? x.pend : level_end;     // rest of the parent's level is left alone
     }
-    if (EH_LANE == 0) anc[sp] = q.close;
-    wave_sync();
-    sp++;
   }
 }
 
@@ -216,7 +271,7 @@ __device__ __noinline__ int muta_tree(Ctx& c, int fn) {
     }
     pidx = uni(bestk);
   }
-  TNode P{0, 0}, C{0, 0}; uint32_t ndesc = 0;
+  TNode P{0, 0, 0, 0}, C{0, 0, 0, 0}; uint32_t ndesc = 0;
   if (pidx != 0xFFFFFFFFu) {
     P = node_load(nodes, pidx);
     // descendants of P are contiguous in pre-order: nodes[pidx+1 .. pidx+ndesc]
@@ -247,7 +302,7 @@ __device__ __noinline__ int muta_tree(Ctx& c, int fn) {
   if (nreps < 2) R = (uint8_t*)(H + P.open);
   else if (k_in == 1) {
     // R_n = pre^(n-1) ++ P ++ suf^(n-1)
-    TNode m{0, 0};
+    TNode m{0, 0, 0, 0};
     tree_matches(H, nodes, pidx + 1, pidx + 1 + ndesc, P.close + 1, C, anc, [&](TNode q, uint32_t) { m = q; });
     uint32_t pre = m.open - P.open, suf = P.close - m.close;
     R = ws_alloc(c, rsz);

@@ -190,3 +190,18 @@ def test_len_mutator():
 def test_complex_patterns(pats):
     ins = _framed_inputs(150, 400, 3) + util.corpus_uniform(100, 300, seed=8) + _texty(60, 512, 9)
     _compare(ins, BYTE_ALL + ",sd,sr,num,ld", pats, max_skipped=0.2, oracle_cap=1 << 20, engine_cap=4 << 20)
+
+
+FUSE = "ft,fn,fo"
+
+
+@pytest.mark.parametrize("seed", [(1, 2, 3), (6, 6, 6)])
+def test_fuse_mutators(seed):
+    ins = [b"kittenslartibartfasterthaneelslartibartfastenyourseatbelts", b"a", b"ab", b"aaaaaaaa", b"abcabcabc", b""] * 10
+    ins += util.corpus_uniform(80, 200, seed=seed[0]) + _texty(60, 300, seed[1]) + [b"xy" * 300, b"\x00" * 500]
+    _compare(ins, FUSE, "od,nd,bu", seed=seed, max_skipped=0.1, oracle_cap=1 << 20, engine_cap=8 << 20)
+
+
+def test_fuse_with_other_mutators_and_blocks():
+    ins = util.corpus_uniform(60, 3000, seed=3) + _texty(60, 2500, 4)
+    _compare(ins, FUSE + ",num,bd,sd,ld", "od,nd,bu", max_skipped=0.1, oracle_cap=1 << 20, engine_cap=8 << 20)

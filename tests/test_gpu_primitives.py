@@ -52,3 +52,20 @@ def test_wave_copy_fill_equal_random_offsets():
     assert bad.size == 0, "first mismatch at %d (job %d: %s)" % (bad[0], bad[0] // (2 * region), jobs[bad[0] // (2 * region)])
     for j, e in eq_expect.items():
         assert bool(eq[j]) == e, "wave_equal wrong for job %s" % jobs[j]
+
+
+def test_mask_window_matches_reference():
+    import erlamsa_amd as ea
+    rng = np.random.Generator(np.random.PCG64(11))
+    buf = rng.integers(0, 256, size=1 << 16, dtype=np.uint8)
+    text = np.frombuffer(b"hello \"quoted\" it's (a [b] <c> {d}) back\\slash\n" * 400, dtype=np.uint8)
+    buf[20000:20000 + len(text)] = text
+    jobs = []
+    for (s0, n) in [(0, 4096), (0, 100), (3, 5000), (20000, 9000), (20001, 4095), (7, 64), (9, 63), (11, 1), (13, 0), (20000, 4097), (5, 1024 + 17)]:
+        for base in (0, 64, 4032):
+            if base <= n:
+                jobs.append([3, base, s0, n, 0])
+    eng = ea.Engine(0)
+    _, bad = eng.selftest_movers(buf, np.array(jobs, dtype=np.uint32))
+    eng.close()
+    assert bad.tolist() == [0] * len(jobs), list(zip(jobs, bad.tolist()))
