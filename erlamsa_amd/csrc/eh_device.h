@@ -147,6 +147,25 @@ EH_DEV void wave_copy(uint8_t* dst, const uint8_t* src, uint32_t n) {
   uint32_t done = nv << 4;
   if (done + l < n) dst[done + l] = src[done + l];
 }
+// memmove towards lower addresses (dst < src, ranges may overlap): every iteration is executed by
+// the whole wave — all loads of a 4 KiB stripe are issued before its stores — so no lane can read
+// bytes that a lane running ahead has already overwritten (wave_copy's per-lane loop trip counts
+// differ, which is only safe for disjoint ranges).
+EH_DEV void wave_move_down(uint8_t* dst, const uint8_t* src, uint32_t n) {
+  const int l = EH_LANE;
+  uint32_t nv = n >> 4;
+  for (uint32_t base = 0; base < nv; base += 256) {
+    uint4 v[4]; bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { uint32_t i = base + 64u * u + (uint32_t)l; ok[u] = i < nv; if (ok[u]) __builtin_memcpy(&v[u], src + 16 * (size_t)i, 16); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { uint32_t i = base + 64u * u + (uint32_t)l; if (ok[u]) __builtin_memcpy(dst + 16 * (size_t)i, &v[u], 16); }
+  }
+  uint32_t done = nv << 4;
+  uint8_t t = 0; bool tk = done + (uint32_t)l < n;
+  if (tk) t = src[done + l];
+  if (tk) dst[done + l] = t;
+}
 // dst[i] = pat[i % plen], i < total.  The first copy is written directly, the rest by doubling
 // (dst[0,k) -> dst[k,2k)) so that all but the first plen bytes move as 16-byte vectors.
 EH_DEV void wave_fill_periodic(uint8_t* dst, const uint8_t* pat, uint32_t plen, uint64_t total) {
@@ -577,10 +596,29 @@ EH_DEV void mux_fuzzers(Ctx& c) {
     tried++;
     bool changed = false;
     if (c.r_kind == R_NEW) {
+      wave_sync();                                                                  // candidate bytes were written by other lanes
       uint32_t hd_len = c.r_flush && c.r_len >= AVG_BLOCK_SIZE ? AVG_BLOCK_SIZE : c.r_len;
       changed = c.r_changed || hd_len != h0.len || !wave_equal(c.r_ptr, (const uint8_t*)h0.ptr, hd_len);
     }
-    if (changed) { c.lastm = (int)name; commit_result(c); used = true; break; }
+    if (changed) {
+      c.lastm = (int)name;
+      // Reclaim work memory before committing: everything between `mark` and the candidate is a
+      // dead temporary, and the block being replaced is dead too when it is the newest committed
+      // allocation and no mutator state (lis/lrs lines, fo block) can point into it.  The
+      // candidate slides down (ascending copy, dst < src) so that chains of mutations on one block
+      // keep a ~1x footprint instead of growing linearly with the number of rounds.
+      uint8_t* lo = c.ws + mark;
+      if (!c.r2 && c.r_ptr >= lo && c.r_ptr + c.r_len <= c.ws + c.ws_used) {
+        uint8_t* dst = lo;
+        uint8_t* hp = (uint8_t*)h0.ptr;
+        bool state_refs = uni(((const uint32_t*)c.aux)[0]) != 0 || uni(((const uint32_t*)(c.aux + 336))[0]) != 0 || uni(((const uint32_t*)(c.aux + 704))[3]) != 0;
+        if (!state_refs && hp >= c.ws && hp + ((h0.len + 15u) & ~15u) == lo && ((uintptr_t)hp & 15) == 0) dst = hp;
+        if (dst == hp && EH_LANE == 0) ((int32_t*)(c.aux + 1024))[3] = -1;       // the lex cache is keyed by (ptr, len): H's memory is being reused
+        if (dst != c.r_ptr) { wave_sync(); wave_move_down(dst, c.r_ptr, c.r_len); wave_sync(); c.r_ptr = dst; }   // candidate stores must have landed
+        c.ws_used = (uint64_t)(dst - c.ws) + (((uint64_t)c.r_len + 15) & ~(uint64_t)15);
+      }
+      commit_result(c); used = true; break;
+    }
     c.ws_used = mark;                                                             // discard candidate
   }
   // --- new list: reverse(tried) ++ untried (sorted order)   :1268,1270,1279

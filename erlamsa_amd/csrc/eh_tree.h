@@ -126,6 +126,22 @@ EH_DEV TNode node_load(const TNode* t, uint32_t i) { TNode x = t[i]; x.open = un
 // equals `sub` is reported and the rest of that level (up to its pend) is skipped.  64 nodes are
 // loaded per step; only nodes of the right length are compared.  `level_end` replaces pend for
 // nodes whose level is the sweep's own top level (sweeps restricted to a subtree pass its end).
+// Lane-parallel equality of up to 64 candidate nodes against `sub` (all slen+1 bytes long): every
+// candidate lane walks its own node 8 bytes at a time.  Returns the mask of equal candidates.
+EH_DEV unsigned long long nodes_equal_mask(const uint8_t* H, uint32_t my_open, bool cand, TNode sub) {
+  uint32_t n = sub.close - sub.open + 1;
+  bool ne = !cand;
+  uint32_t k = 0;
+  for (; k + 8 <= n; k += 8) {
+    uint64_t a = 0, b;
+    __builtin_memcpy(&b, H + sub.open + k, 8);
+    if (!ne) __builtin_memcpy(&a, H + my_open + k, 8);
+    ne = ne || a != b;
+    if (__ballot(!ne) == 0) return 0;
+  }
+  for (; k < n; k++) { uint32_t b = H[sub.open + k]; if (!ne && H[my_open + k] != b) ne = true; }
+  return __ballot(!ne);
+}
 template <class F>
 EH_DEV void tree_matches(const uint8_t* H, const TNode* nodes, uint32_t lo, uint32_t hi, uint32_t level_end, TNode sub, uint32_t* anc, F f) {
   (void)anc;
@@ -136,14 +152,14 @@ EH_DEV void tree_matches(const uint8_t* H, const TNode* nodes, uint32_t lo, uint
     uint32_t i = base + (uint32_t)l;
     TNode q{0, 0, 0, 0};
     if (i < hi) q = nodes[i];
-    bool cand = i < hi && q.close - q.open == slen;
-    unsigned long long cm = __ballot(cand);
+    bool cand = i < hi && q.close - q.open == slen && q.open >= skip_until;
+    if (__ballot(cand) == 0) continue;
+    unsigned long long cm = nodes_equal_mask(H, q.open, cand, sub);
     while (cm) {
       int j = (int)__builtin_ctzll(cm); cm &= cm - 1;
       TNode x; x.open = (uint32_t)__builtin_amdgcn_readlane((int)q.open, j); x.close = (uint32_t)__builtin_amdgcn_readlane((int)q.close, j);
       x.pend = (uint32_t)__builtin_amdgcn_readlane((int)q.pend, j); x.pad = 0;
       if (x.open < skip_until) continue;
-      if (!node_eq(H, x, sub)) continue;
       f(x, base + (uint32_t)j);
       skip_until = x.pend < level_end ? x.pend : level_end;     // rest of the parent's level is left alone
     }
@@ -222,17 +238,29 @@ __device__ __noinline__ int muta_tree(Ctx& c, int fn) {
       if (pass == 1) { dst = ws_alloc(c, (uint64_t)((int64_t)L + delta)); if (!dst) return 1; }
       uint32_t skip_until = 0; delta = pass == 0 ? 0 : delta;
       int64_t d2 = 0;
-      for (uint32_t i = 0; i < N; i++) {
-        TNode q = node_load(nodes, i);
-        if (q.open < skip_until) continue;
-        bool isB = node_eq(H, q, B), isA = !isB && node_eq(H, q, A);
-        if (!isA && !isB) continue;
-        // gb_trees: enter(A,->B) then enter(B,->A); equal keys: A -> A
-        TNode rep = isB ? A : B; uint32_t rl = isB ? al : bl; uint32_t ql = q.close - q.open + 1;
-        if (same) { rep = A; rl = al; }
-        if (pass == 0) d2 += (int64_t)rl - (int64_t)ql;
-        else { wave_copy(dst + out, H + cur, q.open - cur); out += q.open - cur; wave_copy(dst + out, H + rep.open, rl); out += rl; cur = q.close + 1; }
-        skip_until = q.close + 1;
+      for (uint32_t base = 0; base < N; base += 64) {
+        uint32_t i = base + (uint32_t)l;
+        TNode q{0, 0, 0, 0};
+        if (i < N) q = nodes[i];
+        uint32_t qlen = q.close - q.open + 1;
+        bool candB = i < N && qlen == bl && q.open >= skip_until, candA = i < N && qlen == al && q.open >= skip_until;
+        if (__ballot(candA || candB) == 0) continue;
+        unsigned long long mB = __ballot(candB) ? nodes_equal_mask(H, q.open, candB, B) : 0ull;
+        unsigned long long mA = __ballot(candA) ? nodes_equal_mask(H, q.open, candA, A) : 0ull;
+        mA &= ~mB;                                              // a node equal to both is looked up as B first
+        unsigned long long cm = mA | mB;
+        while (cm) {
+          int j = (int)__builtin_ctzll(cm); cm &= cm - 1;
+          uint32_t qo = (uint32_t)__builtin_amdgcn_readlane((int)q.open, j), qc = (uint32_t)__builtin_amdgcn_readlane((int)q.close, j);
+          if (qo < skip_until) continue;
+          bool isB = (mB >> j) & 1ull;
+          // gb_trees: enter(A,->B) then enter(B,->A); equal keys: A -> A
+          TNode rep = isB ? A : B; uint32_t rl = isB ? al : bl; uint32_t ql = qc - qo + 1;
+          if (same) { rep = A; rl = al; }
+          if (pass == 0) d2 += (int64_t)rl - (int64_t)ql;
+          else { wave_copy(dst + out, H + cur, qo - cur); out += qo - cur; wave_copy(dst + out, H + rep.open, rl); out += rl; cur = qc + 1; }
+          skip_until = qc + 1;
+        }
       }
       if (pass == 0) delta = d2;
       else { wave_copy(dst + out, H + cur, L - cur); out += L - cur; wave_sync(); c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)out; }
