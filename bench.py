@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--max-slots", type=int, default=0)
     ap.add_argument("--out-gib", type=int, default=8, help="output arena capacity per context (GiB)")
     ap.add_argument("--case-mib", type=int, default=8, help="per-case work area (MiB), eh_options.max_case_bytes")
+    ap.add_argument("--work-mib", type=int, default=4, help="per-case work budget (MiB), eh_options.max_case_work: the "
+                    "deterministic stand-in for the reference's maxrunningtime watchdog")
     ap.add_argument("--inflight", type=int, default=3, help="passes in flight (engine contexts / HIP streams)")
     args = ap.parse_args()
 
@@ -84,7 +86,7 @@ def main():
     for _ in range(nctx):
         e = ea.Engine(local)
         e.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
-                    max_case_bytes=args.case_mib << 20)
+                    max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20)
         e.attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
         engines.append(e)
         streams.append(torch.cuda.Stream(device=dev))
@@ -106,7 +108,7 @@ def main():
     t0 = time.perf_counter()
     out_bytes = 0
     kern_ms = []
-    status_counts = np.zeros(5, dtype=np.int64)
+    status_counts = np.zeros(6, dtype=np.int64)
 
     def collect(e):
         nonlocal out_bytes, status_counts
@@ -115,7 +117,7 @@ def main():
         _, ob, _ = e.totals()
         out_bytes += ob
         kern_ms.append(e.kernel_ms())
-        status_counts += np.bincount(e.status(), minlength=5)[:5]
+        status_counts += np.bincount(e.status(), minlength=6)[:6]
 
     for k in range(args.steps):
         kk = args.warmup + k
@@ -159,8 +161,10 @@ def main():
                             % (n, size, pats, muts, len(muts.split(",")), nmut_total,
                                ",".join(m for m, _, _ in ea.mutator_table() if m not in muts.split(","))),
                 "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx,
+                "max_case_bytes": args.case_mib << 20, "max_case_work": args.work_mib << 20,
             },
-            "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(max_case_bytes)", "unsupported", "arena_full"],
+            "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(max_case_bytes)", "unsupported", "arena_full",
+                                     "budget(max_case_work; reference analogue: maxrunningtime -> <<>>)"],
                                     [int(x) for x in status_counts])),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
@@ -174,7 +178,8 @@ def main():
             ns = min(args.cpu_sample, n)
             d, o = synth.as_arena(mat[:ns])
             t1 = time.perf_counter()
-            outs, _, _, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, first_case=1, max_case_bytes=8 << 20)
+            outs, _, _, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, first_case=1, max_case_bytes=args.case_mib << 20,
+                                          max_case_work=args.work_mib << 20)
             ct = time.perf_counter() - t1
             cb = sum(len(x) for x in outs)
             res["cpu_baseline"] = {"value": round(cb / ct / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",

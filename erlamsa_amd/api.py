@@ -66,7 +66,7 @@ def _configure(eng, opts):
                   generators=actions_to_string(opts.get("generators")), blockscale=float(opts.get("blockscale", 1.0)),
                   ssrf_host=opts.get("ssrf_host"), ssrf_port=int(opts.get("ssrf_port", 0)),
                   max_case_bytes=int(opts.get("max_case_bytes", 0)), out_capacity=int(opts.get("out_capacity", 0)),
-                  max_slots=int(opts.get("max_slots", 0)))
+                  max_slots=int(opts.get("max_slots", 0)), max_case_work=int(opts.get("max_case_work", 0)))
 
 
 def fuzz_batch(inputs, opts=None, return_status=False, device=0):

@@ -16,7 +16,7 @@ enum MutaId : int {
 enum PatId : int { P_OD, P_ND, P_BU, P_SK, P_SZ, P_CS, P_AR, P_CP, P_CO, P_NU, P_COUNT };
 enum GenId : int { G_DIRECT = 0, G_RANDOM = 1 };
 
-enum CaseStatus : int { CASE_OK = 0, CASE_CRASHED = 1, CASE_OVERFLOW = 2, CASE_UNSUPPORTED = 3, CASE_ARENA_FULL = 4 };
+enum CaseStatus : int { CASE_OK = 0, CASE_CRASHED = 1, CASE_OVERFLOW = 2, CASE_UNSUPPORTED = 3, CASE_ARENA_FULL = 4, CASE_BUDGET = 5 };
 
 constexpr int MAX_FS = 64;          // mux_fuzzers list entries (one per lane of the wavefront)
 constexpr int MAX_BLOCKS = 2048;    // block-list entries per case
@@ -88,6 +88,7 @@ struct KParams {
   uint8_t* slot_base;
   uint64_t slot_stride;
   uint64_t work_cap;          // bytes of the linear work area
+  uint64_t work_budget;       // per-case byte budget (sum of block sizes handed to mutators)
   // outputs
   uint8_t* out;
   uint64_t out_cap;

@@ -220,6 +220,7 @@ struct Ctx {
   uint64_t ws_used, ws_cap;
   int status;
   int lastm;
+  uint64_t work;       // bytes handed to mutators so far (deterministic stand-in for maxrunningtime)
   // mutator result (candidate new head of the list)
   int r_kind;          // R_SAME: list unchanged ; R_NEW: r_ptr/r_len replace bl[cur]
   uint8_t* r_ptr;
@@ -580,6 +581,10 @@ EH_DEV void mux_fuzzers(Ctx& c) {
     uint32_t fn = em_fn(meta), name = em_name(meta);
     c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
     uint64_t mark = c.ws_used;
+    // work budget: the reference kills a worker after maxrunningtime and records <<>>
+    // (erlamsa_main.erl:211-220); the engine's deterministic analogue counts bytes
+    c.work += h0.len;
+    if (c.work > c.p->work_budget) { c.status = CASE_BUDGET; return; }
 #ifdef EH_PROF
     uint64_t pt0 = __builtin_readcyclecounter();
 #endif

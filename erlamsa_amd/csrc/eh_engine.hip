@@ -496,6 +496,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(KParam
     uint64_t i = tk_next++;
     if (i >= p.n) break;
     uint64_t tick0 = __builtin_readcyclecounter();
+    c.work = 0;
     c.status = CASE_OK; c.lastm = -1; c.nb = 0; c.cur = 0; c.nem = 0; c.ws_used = 0;
     c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r2 = 0;
     if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; ((LexCache*)(c.aux + 1024))->n = -1; ((FoState*)(c.aux + 704))->has = 0; }
@@ -610,7 +611,7 @@ struct eh_ctx {
   std::string err;
   bool configured = false;
   DevConfig cfg;
-  uint64_t max_case_bytes = 0, out_capacity_opt = 0;
+  uint64_t max_case_bytes = 0, out_capacity_opt = 0, work_budget = 0;
   uint32_t max_slots_opt = 0, flags = 0;
   // corpus
   uint8_t* d_corpus = nullptr; uint64_t* d_coff = nullptr; bool own_corpus = false;
@@ -816,6 +817,7 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.corpus = ctx->d_corpus; p.coff = ctx->d_coff; p.corpus_first = corpus_first; p.n = n; p.first_case = first_case;
   p.mode = mode; p.run = ctx->d_run; p.seeds = ctx->d_seeds; p.cfg = ctx->cfg;
   p.slot_base = ctx->d_slots; p.slot_stride = ctx->slot_stride; p.work_cap = ctx->work_cap;
+  p.work_budget = ctx->work_budget ? ctx->work_budget : (4ull << 20);
   p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
   p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles;
   p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;
@@ -953,6 +955,7 @@ int eh_configure(eh_ctx* ctx, const eh_options* o) {
   snprintf(cfg.ssrf_host, sizeof(cfg.ssrf_host), "%s", o->ssrf_host ? o->ssrf_host : "localhost");
   snprintf(cfg.ssrf_port, sizeof(cfg.ssrf_port), "%d", o->ssrf_port ? o->ssrf_port : 51234);
   ctx->cfg = cfg;
+  ctx->work_budget = o->max_case_work;
   ctx->max_case_bytes = o->max_case_bytes; ctx->out_capacity_opt = o->out_capacity; ctx->max_slots_opt = o->max_slots; ctx->flags = o->flags;
   ctx->configured = true;
   return EH_OK;

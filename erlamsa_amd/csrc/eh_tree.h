@@ -86,16 +86,30 @@ __device__ __noinline__ int tree_parse(Ctx& c, const uint8_t* H, uint32_t L, TNo
     }
   }
   wave_sync();
-  // level end of every slot: one past the close of the nearest ancestor that did close (L at top level)
+  // level end of every slot: one past the close of the nearest ancestor that did close (L at top level).
+  // pe[i] = closed(parent) ? close[parent] + 1 : pe[parent] and parents precede their children, so the
+  // slots are resolved chunk by chunk in index order; inside a chunk a lane whose parent sits in the same
+  // chunk waits (shuffle rounds, no memory traffic) until that lane is resolved.  Walking the ancestor
+  // chain per slot instead is quadratic on text full of unclosed openers.
   for (uint32_t base = 0; base < nslots; base += 64) {
     uint32_t i = base + (uint32_t)l;
-    if (i < nslots) {
-      uint32_t pidx = tab[i].pend, pe = L;
-      while (pidx != 0xFFFFFFFFu) { uint32_t pc = tab[pidx].close; if (pc != 0xFFFFFFFFu) { pe = pc + 1; break; } pidx = tab[pidx].pend; }
-      tab[i].pad = pe;
+    bool act = i < nslots;
+    uint32_t par = 0xFFFFFFFFu, myclose = 0xFFFFFFFFu, pe = L;
+    if (act) { par = tab[i].pend; myclose = tab[i].close; }
+    bool res = true;
+    bool inchunk = act && par != 0xFFFFFFFFu && par >= base;
+    if (act && par != 0xFFFFFFFFu && par < base) { uint32_t pc = tab[par].close; pe = pc != 0xFFFFFFFFu ? pc + 1 : tab[par].pad; }
+    uint32_t pl = inchunk ? par - base : 0;
+    uint32_t pclose = (uint32_t)__shfl((int)myclose, (int)pl);
+    if (inchunk) { if (pclose != 0xFFFFFFFFu) pe = pclose + 1; else res = false; }
+    while (__ballot(!res)) {
+      uint32_t ppe = (uint32_t)__shfl((int)pe, (int)pl);
+      bool pres = __shfl((int)res, (int)pl) != 0;
+      if (!res && pres) { pe = ppe; res = true; }
     }
+    if (act) tab[i].pad = pe;
+    wave_sync();
   }
-  wave_sync();
   // compact completed nodes (keep pre-order); pend <- level end
   uint32_t n = 0;
   for (uint32_t base = 0; base < nslots; base += 64) {
@@ -130,22 +144,35 @@ EH_DEV TNode node_load(const TNode* t, uint32_t i) { TNode x = t[i]; x.open = un
 // candidate lane walks its own node 8 bytes at a time.  Returns the mask of equal candidates.
 EH_DEV unsigned long long nodes_equal_mask(const uint8_t* H, uint32_t my_open, bool cand, TNode sub) {
   uint32_t n = sub.close - sub.open + 1;
+  if (n > 256) {
+    // long nodes: one wave-wide compare per candidate (1 KiB per step); the node itself is trivially equal
+    unsigned long long cm = __ballot(cand), res = 0;
+    while (cm) {
+      int j = (int)__builtin_ctzll(cm); cm &= cm - 1;
+      uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)my_open, j);
+      if (o == sub.open || wave_equal(H + o, H + sub.open, n)) res |= 1ull << j;
+    }
+    return res;
+  }
   bool ne = !cand;
+  bool self = cand && my_open == sub.open;
   uint32_t k = 0;
   for (; k + 8 <= n; k += 8) {
     uint64_t a = 0, b;
     __builtin_memcpy(&b, H + sub.open + k, 8);
-    if (!ne) __builtin_memcpy(&a, H + my_open + k, 8);
-    ne = ne || a != b;
-    if (__ballot(!ne) == 0) return 0;
+    if (!ne && !self) __builtin_memcpy(&a, H + my_open + k, 8);
+    ne = ne || (!self && a != b);
+    if (__ballot(!ne && !self) == 0) break;
   }
-  for (; k < n; k++) { uint32_t b = H[sub.open + k]; if (!ne && H[my_open + k] != b) ne = true; }
+  if (k + 8 <= n) return __ballot(!ne);                        // left the loop early: only `self` lanes (or none) remain
+  for (; k < n; k++) { uint32_t b = H[sub.open + k]; if (!ne && !self && H[my_open + k] != b) ne = true; }
   return __ballot(!ne);
 }
 template <class F>
 EH_DEV void tree_matches(const uint8_t* H, const TNode* nodes, uint32_t lo, uint32_t hi, uint32_t level_end, TNode sub, uint32_t* anc, F f) {
   (void)anc;
   const int l = EH_LANE;
+  (void)l;
   uint32_t skip_until = 0;
   uint32_t slen = sub.close - sub.open;
   for (uint32_t base = lo; base < hi; base += 64) {
@@ -166,17 +193,90 @@ EH_DEV void tree_matches(const uint8_t* H, const TNode* nodes, uint32_t lo, uint
   }
 }
 
+// Assembles the edited block from a recorded match list without a serial copy per match (blocks with
+// tens of thousands of equal small nodes are common after the line/sequence repeaters).  Match k
+// (node index mlist[k] & 0x7fffffff, flag = top bit) contributes the segment
+//   gap  = H[start_k, open_k)      start_k = end of the previous match (or its open when keep_node)
+//   rep  = flag ? R1[0,r1len) : R0[0,r0len)
+// 64 matches are handled per step: lane k owns a segment, a shuffle scan gives every segment its output
+// offset, short segments are then written byte-per-lane (each output byte finds its segment by a 6-step
+// shuffle search), long ones by a wave-wide copy each.
+EH_DEV uint64_t tree_emit(uint8_t* dst, const uint8_t* H, uint32_t L, const TNode* nodes, const uint32_t* mlist, uint32_t nm,
+                          const uint8_t* R0, uint32_t r0len, const uint8_t* R1, uint32_t r1len, bool keep_node) {
+  const int l = EH_LANE;
+  uint64_t out = 0; uint32_t cur = 0;
+  for (uint32_t base = 0; base < nm; base += 64) {
+    uint32_t k = base + (uint32_t)l; bool act = k < nm;
+    uint32_t qo = 0, qc = 0, flag = 0;
+    if (act) { uint32_t e = mlist[k]; flag = e >> 31; TNode q = nodes[e & 0x7fffffffu]; qo = q.open; qc = q.close; }
+    uint32_t nxt = keep_node ? qo : qc + 1;
+    uint32_t start = (uint32_t)__shfl_up((int)nxt, 1); if (l == 0) start = cur;
+    uint32_t g = act ? qo - start : 0;
+    uint32_t rl = act ? (flag ? r1len : r0len) : 0;
+    uint32_t seg = g + rl;
+    bool big = seg > 512;
+    uint32_t sseg = big ? 0 : seg;
+    uint32_t inc = seg, sinc = sseg;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t t = (uint32_t)__shfl_up((int)inc, d), t2 = (uint32_t)__shfl_up((int)sinc, d);
+      if (l >= d) { inc += t; sinc += t2; }
+    }
+    uint32_t excl = inc - seg, sexcl = sinc - sseg;
+    uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), stotal = (uint32_t)__builtin_amdgcn_readlane((int)sinc, 63);
+    for (uint32_t b0 = 0; b0 < stotal; b0 += 64) {
+      uint32_t b = b0 + (uint32_t)l;
+      uint32_t j = 0;
+#pragma unroll
+      for (uint32_t step = 32; step; step >>= 1) { uint32_t cand = j + step; uint32_t v = (uint32_t)__shfl((int)sexcl, (int)(cand & 63)); if (v <= b) j = cand; }
+      uint32_t within = b - (uint32_t)__shfl((int)sexcl, (int)j);
+      uint32_t gj = (uint32_t)__shfl((int)g, (int)j), sj = (uint32_t)__shfl((int)start, (int)j), fj = (uint32_t)__shfl((int)flag, (int)j);
+      uint32_t ej = (uint32_t)__shfl((int)excl, (int)j);
+      if (b < stotal) {
+        uint8_t v = within < gj ? H[sj + within] : (fj ? R1 : R0)[within - gj];
+        dst[out + ej + within] = v;
+      }
+    }
+    unsigned long long bm = __ballot(big);
+    while (bm) {
+      int j = (int)__builtin_ctzll(bm); bm &= bm - 1;
+      uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)g, j), sj = (uint32_t)__builtin_amdgcn_readlane((int)start, j);
+      uint32_t fj = (uint32_t)__builtin_amdgcn_readlane((int)flag, j), ej = (uint32_t)__builtin_amdgcn_readlane((int)excl, j);
+      wave_copy(dst + out + ej, H + sj, gj);
+      wave_copy(dst + out + ej + gj, fj ? R1 : R0, fj ? r1len : r0len);
+    }
+    out += total;
+    uint32_t lastl = nm - base < 64 ? nm - base - 1 : 63;
+    cur = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)lastl);
+  }
+  wave_copy(dst + out, H + cur, L - cur); out += L - cur;
+  return out;
+}
+
 // sed_tree_op (tr2/td :917-936), construct_sed_tree_swap (ts1/ts2 :940-971), sed_tree_stutter (tr :975-1023)
+#ifdef EH_PROF
+#define TR_PH(k) do { uint64_t now_ = __builtin_readcyclecounter(); if (EH_LANE == 0) { atomicAdd(&c.p->prof[2 * (70 + (k))], (unsigned long long)(now_ - tph)); atomicAdd(&c.p->prof[2 * (70 + (k)) + 1], 1ull); } tph = now_; } while (0)
+#define TR_ST(k, v) do { if (EH_LANE == 0) { atomicAdd(&c.p->prof[2 * (70 + (k))], (unsigned long long)(v)); atomicAdd(&c.p->prof[2 * (70 + (k)) + 1], 1ull); } } while (0)
+#else
+#define TR_PH(k) do { } while (0)
+#define TR_ST(k, v) do { } while (0)
+#endif
 __device__ __noinline__ int muta_tree(Ctx& c, int fn) {
+#ifdef EH_PROF
+  uint64_t tph = __builtin_readcyclecounter();
+#endif
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   const int l = EH_LANE;
   c.r_kind = R_SAME;
-  if (binarish(H, L)) return -1;
+  if (binarish(H, L)) { TR_PH(0); return -1; }
+  TR_PH(0);
   uint64_t mark = c.ws_used;
   TNode* nodes;
   int n_ = tree_parse(c, H, L, &nodes);
+  TR_PH(1);
   if (n_ < 0) return 0;
+  TR_ST(5, L); TR_ST(6, n_);
   uint32_t N = (uint32_t)n_;
   uint32_t* anc = (uint32_t*)ws_alloc(c, (uint64_t)(N + 1) * 4);
   if (!anc) return 0;
@@ -186,20 +286,16 @@ __device__ __noinline__ int muta_tree(Ctx& c, int fn) {
     if (N == 0) { c.ws_used = mark; return 1; }                  // pick_sublist -> false: nothing is edited
     uint32_t idx = rng_rand(c.rng, N);
     TNode sub = node_load(nodes, N - 1 - idx);
-    // two sweeps: size, then emit
+    // one sweep records the matches, the edited block is then assembled in parallel
     uint32_t slen = sub.close - sub.open + 1;
     uint32_t nm = 0;
-    tree_matches(H, nodes, 0, N, L, sub, anc, [&](TNode, uint32_t) { nm++; });
+    tree_matches(H, nodes, 0, N, L, sub, anc, [&](TNode, uint32_t idx) { if (l == 0) anc[nm] = idx; nm++; });
     uint64_t nl = fn == M_TR2 ? (uint64_t)L + (uint64_t)nm * slen : (uint64_t)L - (uint64_t)nm * slen;
     uint8_t* dst = ws_alloc(c, nl);
     if (!dst) return 1;
-    uint32_t cur = 0; uint64_t out = 0;
-    tree_matches(H, nodes, 0, N, L, sub, anc, [&](TNode q, uint32_t) {
-      wave_copy(dst + out, H + cur, q.open - cur); out += q.open - cur;
-      if (fn == M_TR2) { wave_copy(dst + out, H + q.open, slen); out += slen; cur = q.open; }   // [H | Node]
-      else cur = q.close + 1;                                                                  // T
-    });
-    wave_copy(dst + out, H + cur, L - cur); out += L - cur;
+    wave_sync();
+    // tr2: [H | Node] -> the node is written once more in front of itself; td: T -> the node is dropped
+    uint64_t out = tree_emit(dst, H, L, nodes, anc, nm, H + sub.open, fn == M_TR2 ? slen : 0, nullptr, 0, fn == M_TR2);
     wave_sync();
     c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)out;
     return 1;
@@ -208,24 +304,40 @@ __device__ __noinline__ int muta_tree(Ctx& c, int fn) {
   if (fn == M_TS1 || fn == M_TS2) {
     if (N < 2) { c.ws_used = mark; return -1; }
     // reservoir_sample(Subs, 2) (erlamsa_rnd.erl:201-214) over list positions
+    // J_i = erand(i) for i = 3..N are independent draws: lane-parallel by jump-ahead; slot 1 / slot 2 end
+    // up holding the LAST i that drew 1 / 2
     uint32_t r0 = 0, r1 = 1;
-    for (uint32_t i = 3; i <= N; i++) { uint32_t j = rng_erand(c.rng, i); if (j == 1) r0 = i - 1; else if (j == 2) r1 = i - 1; }
+    {
+      uint32_t m0 = 0, m1 = 0;
+      for (uint32_t base = 3; base <= N; base += 64) {
+        uint32_t i = base + (uint32_t)l;
+        if (i <= N) {
+          uint32_t j = (uint32_t)(rng_peek(c.rng, (uint32_t)l + 1) * (double)i) + 1;
+          if (j == 1) m0 = i; else if (j == 2) m1 = i;
+        }
+        rng_skip(c.rng, N - base + 1 < 64 ? N - base + 1 : 64);
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) { uint32_t a = (uint32_t)__shfl_xor((int)m0, d), b = (uint32_t)__shfl_xor((int)m1, d); m0 = a > m0 ? a : m0; m1 = b > m1 ? b : m1; }
+      m0 = uni(m0); m1 = uni(m1);
+      if (m0) r0 = m0 - 1;
+      if (m1) r1 = m1 - 1;
+    }
     TNode A = node_load(nodes, N - 1 - r0), B = node_load(nodes, N - 1 - r1);
+    TR_PH(2);
     if (fn == M_TS1) {                                           // sed_tree_swap_one
       if (rng_rand(c.rng, 2) == 1) { TNode t = A; A = B; B = t; } // random_permutation([A,B])
       uint32_t al = A.close - A.open + 1, bl = B.close - B.open + 1;
       uint32_t nm = 0;
-      tree_matches(H, nodes, 0, N, L, A, anc, [&](TNode, uint32_t) { nm++; });
+      tree_matches(H, nodes, 0, N, L, A, anc, [&](TNode, uint32_t idx) { if (l == 0) anc[nm] = idx; nm++; });
+      TR_PH(3); TR_ST(7, nm);
       uint64_t nl = (uint64_t)L + (uint64_t)nm * bl - (uint64_t)nm * al;
       uint8_t* dst = ws_alloc(c, nl);
       if (!dst) return 1;
-      uint32_t cur = 0; uint64_t out = 0;
-      tree_matches(H, nodes, 0, N, L, A, anc, [&](TNode q, uint32_t) {
-        wave_copy(dst + out, H + cur, q.open - cur); out += q.open - cur;
-        wave_copy(dst + out, H + B.open, bl); out += bl; cur = q.close + 1;                    // [B | Tl]
-      });
-      wave_copy(dst + out, H + cur, L - cur); out += L - cur;
       wave_sync();
+      uint64_t out = tree_emit(dst, H, L, nodes, anc, nm, H + B.open, bl, nullptr, 0, false);      // [B | Tl]
+      wave_sync();
+      TR_PH(4);
       c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)out;
       return 1;
     }
@@ -233,11 +345,9 @@ __device__ __noinline__ int muta_tree(Ctx& c, int fn) {
     uint32_t al = A.close - A.open + 1, bl = B.close - B.open + 1;
     bool same = node_eq(H, A, B);
     int64_t delta = 0;
-    for (int pass = 0; pass < 2; pass++) {
-      uint8_t* dst = nullptr; uint32_t cur = 0; uint64_t out = 0;
-      if (pass == 1) { dst = ws_alloc(c, (uint64_t)((int64_t)L + delta)); if (!dst) return 1; }
-      uint32_t skip_until = 0; delta = pass == 0 ? 0 : delta;
-      int64_t d2 = 0;
+    uint32_t nm = 0;
+    {
+      uint32_t skip_until = 0;
       for (uint32_t base = 0; base < N; base += 64) {
         uint32_t i = base + (uint32_t)l;
         TNode q{0, 0, 0, 0};
@@ -255,16 +365,20 @@ __device__ __noinline__ int muta_tree(Ctx& c, int fn) {
           if (qo < skip_until) continue;
           bool isB = (mB >> j) & 1ull;
           // gb_trees: enter(A,->B) then enter(B,->A); equal keys: A -> A
-          TNode rep = isB ? A : B; uint32_t rl = isB ? al : bl; uint32_t ql = qc - qo + 1;
-          if (same) { rep = A; rl = al; }
-          if (pass == 0) d2 += (int64_t)rl - (int64_t)ql;
-          else { wave_copy(dst + out, H + cur, qo - cur); out += qo - cur; wave_copy(dst + out, H + rep.open, rl); out += rl; cur = qc + 1; }
+          uint32_t rl = (isB || same) ? al : bl; uint32_t ql = qc - qo + 1;
+          delta += (int64_t)rl - (int64_t)ql;
+          if (l == 0) anc[nm] = (base + (uint32_t)j) | ((isB || same) ? 0x80000000u : 0u);
+          nm++;
           skip_until = qc + 1;
         }
       }
-      if (pass == 0) delta = d2;
-      else { wave_copy(dst + out, H + cur, L - cur); out += L - cur; wave_sync(); c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)out; }
     }
+    uint8_t* dst = ws_alloc(c, (uint64_t)((int64_t)L + delta));
+    if (!dst) return 1;
+    wave_sync();
+    uint64_t out = tree_emit(dst, H, L, nodes, anc, nm, H + B.open, bl, H + A.open, al, false);
+    wave_sync();
+    c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)out;
     return 1;
   }
 

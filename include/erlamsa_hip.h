@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EH_ABI_VERSION 1
+#define EH_ABI_VERSION 2
 
 typedef struct eh_ctx eh_ctx;
 
@@ -57,8 +57,11 @@ enum eh_case_status {
   EH_CASE_OVERFLOW = 2,    /* exceeded max_case_bytes / block-table / arena capacity: output empty */
   EH_CASE_UNSUPPORTED = 3, /* reached a container success path (zip/zlib re-encode) that is not
                               implemented; output empty, caller should route the case to BEAM */
-  EH_CASE_ARENA_FULL = 4   /* the output arena (eh_options.out_capacity) was exhausted; re-run the
+  EH_CASE_ARENA_FULL = 4,  /* the output arena (eh_options.out_capacity) was exhausted; re-run the
                               case with a larger arena */
+  EH_CASE_BUDGET = 5       /* exceeded max_case_work: the engine's deterministic stand-in for the
+                              reference's maxrunningtime watchdog (erlamsa_main.erl:211-220), which
+                              also yields <<>> */
 };
 
 typedef struct eh_options {
@@ -73,6 +76,8 @@ typedef struct eh_options {
   int32_t ssrf_port;         /* 0 => 51234 */
   uint64_t max_case_bytes;   /* per-case working-set cap; 0 => default (8 MiB) */
   uint64_t out_capacity;     /* output arena bytes; 0 => 8 x batch input bytes + 1 GiB */
+  uint64_t max_case_work;    /* per-case work budget in bytes (sum of the sizes of the blocks handed to
+                                mutators, failed attempts included); 0 => default (4 MiB) */
   uint32_t max_slots;        /* resident wavefront slots; 0 => auto */
   uint32_t flags;            /* EH_FLAG_* */
 } eh_options;

@@ -39,6 +39,7 @@ const size_t SIZER_MAX_FIRST_BYTES = 512;
 const size_t PREAMBLE_MAX_BYTES = 32;
 
 struct Overflow {};     // engine cap exceeded (not a reference behaviour)
+struct Budget {};       // engine work budget exceeded (deterministic stand-in for maxrunningtime)
 struct Unsupported {};  // container success paths (zip/zlib re-encode) not restated
 
 // ===========================================================================
@@ -200,6 +201,7 @@ struct Config {
   double blockscale = 1.0;
   std::string ssrf_host = "localhost"; int ssrf_port = 51234;
   uint64_t max_case_bytes = 0;
+  uint64_t max_case_work = 0;
 };
 
 struct Case;  // fwd
@@ -213,6 +215,7 @@ struct Ctx {
   std::vector<Muta> fs;  // the mux_fuzzers list, in list order
   std::string* trace = nullptr;
   Bytes out;             // blocks already written by blocks_port
+  uint64_t work = 0;     // engine work budget accounting (see Config::max_case_work)
   void t(const char* tag, const char* name) { if (trace) { trace->append(tag); trace->push_back(':'); trace->append(name); trace->push_back(' '); } }
   void check_cap(size_t n) { if (cfg->max_case_bytes && n > cfg->max_case_bytes) throw Overflow(); }
 };
@@ -1146,6 +1149,8 @@ void mux_fuzzers(Ctx& c, std::vector<Muta>& fs, BList& ll) {
       std::vector<Muta> nf = out; nf.insert(nf.end(), sorted.begin() + i + 1, sorted.end()); fs.swap(nf); return;
     }
     Muta node = sorted[i];
+    c.work += ll[0].size();
+    if (c.cfg->max_case_work && c.work > c.cfg->max_case_work) throw Budget();
     BList mll = ll;
     int delta = run_muta_fn(c, mll, node);
     node.score = adjust_priority(node.score, delta);
@@ -1464,6 +1469,7 @@ void run_case(Run& run, const Config& cfg, const Bytes& input, Bytes* out, int* 
   } catch (ErlCrash& e) { out->clear(); *status = EO_CRASHED; if (trace) { trace->append("crash:"); trace->append(e.what()); } }
   catch (Overflow&) { out->clear(); *status = EO_OVERFLOW; }
   catch (Unsupported&) { out->clear(); *status = EO_UNSUPPORTED; }
+  catch (Budget&) { out->clear(); *status = 5; }
   *draws = c.rnd.r.draws;
 }
 
@@ -1510,6 +1516,7 @@ bool build_config(const eo_config* ec, Config* cfg) {
   if (ec->ssrf_host) cfg->ssrf_host = ec->ssrf_host;
   if (ec->ssrf_port) cfg->ssrf_port = ec->ssrf_port;
   cfg->max_case_bytes = ec->max_case_bytes;
+  cfg->max_case_work = ec->max_case_work;
   return true;
 }
 

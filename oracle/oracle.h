@@ -31,6 +31,7 @@ typedef struct eo_config {
   uint64_t first_case;     // 1-based index of the first case of this batch (mode 0)
   const int64_t* seeds;    // mode 1
   uint64_t max_case_bytes; // engine cap mirrored here; 0 = unlimited
+  uint64_t max_case_work;  // engine work budget mirrored here; 0 = unlimited
 } eo_config;
 
 enum { EO_OK = 0, EO_CRASHED = 1, EO_OVERFLOW = 2, EO_UNSUPPORTED = 3 };

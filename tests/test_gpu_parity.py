@@ -12,14 +12,14 @@ SEQ = "sp,sr,sd,snand,srnd"
 
 
 def _compare(inputs, mutations, patterns, seed=(1, 2, 3), generators=None, first_case=1, max_report=5, max_skipped=0.03,
-             oracle_cap=8 << 20, engine_cap=0):
+             oracle_cap=8 << 20, engine_cap=0, work=4 << 20):
     import pyoracle as po
     import erlamsa_amd as ea
     data, off = po.pack(inputs)
     want, wst, wdr, trace = po.fuzz_batch(data, off, seed=seed, mutations=mutations, patterns=patterns, generators=generators,
-                                          first_case=first_case, max_case_bytes=oracle_cap, trace=True)
+                                          first_case=first_case, max_case_bytes=oracle_cap, max_case_work=work, trace=True)
     eng = ea.Engine(0)
-    eng.configure(mutations=mutations, patterns=patterns, generators=generators, max_case_bytes=engine_cap)
+    eng.configure(mutations=mutations, patterns=patterns, generators=generators, max_case_bytes=engine_cap, max_case_work=work)
     eng.upload_corpus(data, off)
     eng.fuzz_batch(seed=seed, first_case=first_case)
     got, gst = eng.download()

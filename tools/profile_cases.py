@@ -13,7 +13,8 @@ pats = sys.argv[3] if len(sys.argv) > 3 else "od,nd,bu"
 mat = synth.mixed(n, 4096)
 data, off = synth.as_arena(mat)
 eng = ea.Engine(0)
-eng.configure(mutations=muts, patterns=pats, out_capacity=8 << 30)
+import os
+eng.configure(mutations=muts, patterns=pats, out_capacity=8 << 30, max_case_work=int(os.environ.get('WORK_MIB', '4')) << 20)
 eng.upload_corpus(data, off)
 eng.fuzz_batch(seed=(1, 2, 3))
 outs, st = eng.download()
@@ -21,7 +22,7 @@ cyc = eng.cycles().astype(np.float64)
 dr, lm = eng.diag()
 names = [m[0] for m in ea.mutator_table()]
 print("kernel ms", eng.kernel_ms(), "cases", n, "total Mcycles", cyc.sum() / 1e6, "max Mcycles", cyc.max() / 1e6, "median kcycles", np.median(cyc) / 1e3)
-print("status counts", np.bincount(st, minlength=5), "output MB", sum(map(len, outs)) / 1e6)
+print("status counts", np.bincount(st, minlength=6), "output MB", sum(map(len, outs)) / 1e6)
 order = np.argsort(-cyc)
 print("top cases:")
 for i in order[:12]:
@@ -39,6 +40,10 @@ if pr.sum() > 0:
     for m in range(len(names)):
         if pr[2 * m + 1] > 0:
             print("  %-6s %8d %10.1f %10.1f" % (names[m], pr[2 * m + 1], pr[2 * m] / pr[2 * m + 1] / 1e3, pr[2 * m] / 1e6))
+    for k, nm in enumerate(["tree:binarish", "tree:parse", "ts:sample", "ts1:match", "ts1:emit", "tree:sum L", "tree:sum N", "ts1:sum nm"]):
+        i = 70 + k
+        if pr[2 * i + 1] > 0:
+            print("  %-14s %8d %10.1f %10.1f" % (nm, pr[2 * i + 1], pr[2 * i] / pr[2 * i + 1] / 1e3, pr[2 * i] / 1e6))
     for k, nm in enumerate(["setup", "generator", "pattern+mux", "output"]):
         i = 64 + k
         if pr[2 * i + 1] > 0:
