@@ -29,15 +29,27 @@ struct DelimCls {
 };
 EH_DEV uint32_t delim_close_code(uint32_t code) { return code == 9 ? 9u : (code == 10 ? 10u : code + 1); }   // opener code -> closer code
 EH_DEV bool delim_is_opener(uint32_t code) { return code == 1 || code == 3 || code == 5 || code == 7 || code == 9 || code == 10; }
-struct IsOpener { EH_DEV bool operator()(uint32_t b, uint32_t) const { return b == 40 || b == 91 || b == 60 || b == 123 || b == 34 || b == 39; } };
+// byte-class tests as bit tables (word = byte >> 5), a handful of ALU ops per byte instead of a compare chain
+EH_DEV bool delim_bit(uint32_t b, uint32_t w1, uint32_t w23) { uint32_t m = b < 32 ? 0u : (b < 64 ? w1 : (b < 128 ? w23 : 0u)); return (m >> (b & 31u)) & 1u; }
+struct IsOpener { EH_DEV bool operator()(uint32_t b, uint32_t) const { return delim_bit(b, (1u << 2) | (1u << 7) | (1u << 8) | (1u << 28), 1u << 27); } };
 
 // Parses the block (partial_parse/1 + grow/3, :800-905) and returns the completed nodes sorted by
 // open position (pre-order), or -1 on allocation failure.  The matcher only looks at delimiter
 // bytes (mask events); its stack lives in lane registers (entry d in lane d - base), spilling 32
 // entries at a time to the work area for nesting deeper than 64.
-struct IsDelim { EH_DEV bool operator()(uint32_t b, uint32_t) const { return b == 40 || b == 41 || b == 91 || b == 93 || b == 60 || b == 62 || b == 123 || b == 125 || b == 34 || b == 39; } };
+#ifdef EH_PROF
+#define TR_PH(k) do { uint64_t now_ = __builtin_readcyclecounter(); if (EH_LANE == 0) { atomicAdd(&c.p->prof[2 * (70 + (k))], (unsigned long long)(now_ - tph)); atomicAdd(&c.p->prof[2 * (70 + (k)) + 1], 1ull); } tph = now_; } while (0)
+#define TR_ST(k, v) do { if (EH_LANE == 0) { atomicAdd(&c.p->prof[2 * (70 + (k))], (unsigned long long)(v)); atomicAdd(&c.p->prof[2 * (70 + (k)) + 1], 1ull); } } while (0)
+#else
+#define TR_PH(k) do { } while (0)
+#define TR_ST(k, v) do { } while (0)
+#endif
+struct IsDelim { EH_DEV bool operator()(uint32_t b, uint32_t) const { return delim_bit(b, (1u << 2) | (1u << 7) | (1u << 8) | (1u << 9) | (1u << 28) | (1u << 30), (1u << 27) | (1u << 29)); } };
 __device__ __noinline__ int tree_parse(Ctx& c, const uint8_t* H, uint32_t L, TNode** out) {
   const int l = EH_LANE;
+#ifdef EH_PROF
+  uint64_t tph = __builtin_readcyclecounter();
+#endif
   // 1. positions of all delimiter bytes, in order (parallel scan + compaction)
   uint32_t nev = wave_count(H, L, IsDelim());
   uint32_t nopen = wave_count(H, L, IsOpener());
@@ -46,21 +58,34 @@ __device__ __noinline__ int tree_parse(Ctx& c, const uint8_t* H, uint32_t L, TNo
   uint32_t* evp = (uint32_t*)ws_alloc(c, (uint64_t)(nev + 64) * 4);
   if (!tab || !spill || !evp) return -1;
   if (nopen >= (1u << 24)) { c.status = CASE_OVERFLOW; return -1; }
+  TR_PH(10);
   wave_collect(H, L, 0, nev, evp, IsDelim());
+  TR_PH(11); TR_ST(15, nev);
   // 2. the matcher walks the event list 64 events at a time; positions and delimiter codes sit in
-  //    registers (lane i = event i of the batch), the stack in lane registers too.
+  //    registers (lane i = event i of the batch), the stack in lane registers too.  The inner loop
+  //    touches no memory: on this ISA stores count in vmcnt, so a store per event makes every
+  //    iteration wait for the previous one's write (~600 cycles).  Pushes and closes of a batch are
+  //    buffered in lane registers (k-th push / k-th close of the batch in lane k) and written with one
+  //    coalesced store / one scatter per batch.
+  for (uint32_t i = (uint32_t)l; i < nopen + 1; i += 64) tab[i].close = 0xFFFFFFFFu;
+  wave_sync();
   uint32_t stk = 0;                      // my stack entry: slot << 8 | expected closer code
   uint32_t sp = 0, sbase = 0;            // depth, depth held by lane 0
   uint32_t nslots = 0, top = 0;          // top = copy of the top entry
   for (uint32_t eb = 0; eb < nev; eb += 64) {
     uint32_t mypos = eb + (uint32_t)l < nev ? evp[eb + l] : 0;
     uint32_t mycode = eb + (uint32_t)l < nev ? DelimCls()((uint32_t)H[mypos]) : 0;
+    // bit 8: opener; bits 16..23: the closer code an opener waits for
+    mycode |= delim_is_opener(mycode) ? (0x100u | (delim_close_code(mycode) << 16)) : 0u;
     uint32_t cnt = nev - eb < 64 ? nev - eb : 64;
+    uint32_t first = nslots, npush = 0, nclose = 0;
+    uint32_t po = 0, pp = 0, cs = 0, cp = 0;
     for (uint32_t e = 0; e < cnt; e++) {
       uint32_t code = (uint32_t)__builtin_amdgcn_readlane((int)mycode, (int)e);
-      if (sp > 0 && code == (top & 255u)) {                       // grow: H =:= Close (:806-807)
-        uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)mypos, (int)e);
-        if (l == 0) tab[top >> 8].close = pos;
+      uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)mypos, (int)e);
+      if (sp > 0 && (code & 255u) == (top & 255u)) {              // grow: H =:= Close (:806-807)
+        if ((uint32_t)l == nclose) { cs = top >> 8; cp = pos; }
+        nclose++;
         sp--;
         if (sp > 0) {
           if (sp == sbase) {                                      // refill the lower 32 entries from the spill area
@@ -70,22 +95,25 @@ __device__ __noinline__ int tree_parse(Ctx& c, const uint8_t* H, uint32_t L, TNo
           }
           top = (uint32_t)__builtin_amdgcn_readlane((int)stk, (int)(sp - 1 - sbase));
         }
-      } else if (delim_is_opener(code)) {
-        uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)mypos, (int)e);
+      } else if (code & 0x100u) {
         if (sp - sbase == 64) {                                   // spill the lower half
           if (l < 32) spill[sbase + l] = stk;
           stk = (uint32_t)__shfl_down((int)stk, 32);
           sbase += 32;
         }
         uint32_t parent = sp > 0 ? (top >> 8) : 0xFFFFFFFFu;
-        uint32_t ent = (nslots << 8) | delim_close_code(code);
+        uint32_t ent = (nslots << 8) | (code >> 16);
         if ((uint32_t)l == sp - sbase) stk = ent;
-        if (l == 0) { tab[nslots].open = pos; tab[nslots].close = 0xFFFFFFFFu; tab[nslots].pend = parent; }
+        if ((uint32_t)l == npush) { po = pos; pp = parent; }
+        npush++;
         top = ent; nslots++; sp++;
       }
     }
+    if ((uint32_t)l < npush) { tab[first + l].open = po; tab[first + l].pend = pp; }
+    if ((uint32_t)l < nclose) tab[cs].close = cp;
   }
   wave_sync();
+  TR_PH(12); TR_ST(16, nslots);
   // level end of every slot: one past the close of the nearest ancestor that did close (L at top level).
   // pe[i] = closed(parent) ? close[parent] + 1 : pe[parent] and parents precede their children, so the
   // slots are resolved chunk by chunk in index order; inside a chunk a lane whose parent sits in the same
@@ -110,6 +138,7 @@ __device__ __noinline__ int tree_parse(Ctx& c, const uint8_t* H, uint32_t L, TNo
     if (act) tab[i].pad = pe;
     wave_sync();
   }
+  TR_PH(13);
   // compact completed nodes (keep pre-order); pend <- level end
   uint32_t n = 0;
   for (uint32_t base = 0; base < nslots; base += 64) {
@@ -124,6 +153,7 @@ __device__ __noinline__ int tree_parse(Ctx& c, const uint8_t* H, uint32_t L, TNo
     n += (uint32_t)__popcll(m);
     wave_sync();
   }
+  TR_PH(14);
   *out = tab;
   return (int)n;
 }
@@ -254,13 +284,6 @@ EH_DEV uint64_t tree_emit(uint8_t* dst, const uint8_t* H, uint32_t L, const TNod
 }
 
 // sed_tree_op (tr2/td :917-936), construct_sed_tree_swap (ts1/ts2 :940-971), sed_tree_stutter (tr :975-1023)
-#ifdef EH_PROF
-#define TR_PH(k) do { uint64_t now_ = __builtin_readcyclecounter(); if (EH_LANE == 0) { atomicAdd(&c.p->prof[2 * (70 + (k))], (unsigned long long)(now_ - tph)); atomicAdd(&c.p->prof[2 * (70 + (k)) + 1], 1ull); } tph = now_; } while (0)
-#define TR_ST(k, v) do { if (EH_LANE == 0) { atomicAdd(&c.p->prof[2 * (70 + (k))], (unsigned long long)(v)); atomicAdd(&c.p->prof[2 * (70 + (k)) + 1], 1ull); } } while (0)
-#else
-#define TR_PH(k) do { } while (0)
-#define TR_ST(k, v) do { } while (0)
-#endif
 __device__ __noinline__ int muta_tree(Ctx& c, int fn) {
 #ifdef EH_PROF
   uint64_t tph = __builtin_readcyclecounter();

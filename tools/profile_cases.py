@@ -40,7 +40,7 @@ if pr.sum() > 0:
     for m in range(len(names)):
         if pr[2 * m + 1] > 0:
             print("  %-6s %8d %10.1f %10.1f" % (names[m], pr[2 * m + 1], pr[2 * m] / pr[2 * m + 1] / 1e3, pr[2 * m] / 1e6))
-    for k, nm in enumerate(["tree:binarish", "tree:parse", "ts:sample", "ts1:match", "ts1:emit", "tree:sum L", "tree:sum N", "ts1:sum nm"]):
+    for k, nm in enumerate(["tree:binarish", "tree:parse", "ts:sample", "ts1:match", "ts1:emit", "tree:sum L", "tree:sum N", "ts1:sum nm", "-", "-", "parse:counts", "parse:collect", "parse:match loop", "parse:level end", "parse:compact", "parse:sum events", "parse:sum slots"]):
         i = 70 + k
         if pr[2 * i + 1] > 0:
             print("  %-14s %8d %10.1f %10.1f" % (nm, pr[2 * i + 1], pr[2 * i] / pr[2 * i + 1] / 1e3, pr[2 * i] / 1e6))
