@@ -49,10 +49,21 @@ struct Rng {
 };
 
 // U from a POST-STEP state: R = B1/30269 + B2/30307 + B3/30323 ; U = R - trunc(R)
+// The three quotients must be the correctly rounded IEEE quotients (that is what the BEAM computes).
+// A full f64 division expands to ~12 dependent instructions; for these divisors and integer numerators
+// below 2^15 one Newton-style correction of the reciprocal product is already correctly rounded:
+//   q0 = b * RN(1/P);  e = fma(-P, q0, b);  q = fma(e, RN(1/P), q0)
+// which tests/test_oracle_rng.py checks exhaustively (all 90 899 numerators) against real division.
+EH_DEV double as183_div(uint32_t b, double P, double rP) {
+  double a = (double)b;
+  double q0 = a * rP;
+  double e = fma(-P, q0, a);
+  return fma(e, rP, q0);
+}
 EH_DEV double u_of(uint32_t b1, uint32_t b2, uint32_t b3) {
-  double q1 = (double)b1 / 30269.0;
-  double q2 = (double)b2 / 30307.0;
-  double q3 = (double)b3 / 30323.0;
+  double q1 = as183_div(b1, 30269.0, 1.0 / 30269.0);
+  double q2 = as183_div(b2, 30307.0, 1.0 / 30307.0);
+  double q3 = as183_div(b3, 30323.0, 1.0 / 30323.0);
   double r = (q1 + q2) + q3;
   return r - trunc(r);
 }
@@ -508,6 +519,19 @@ EH_DEV uint32_t em_name(uint32_t m) { return (m >> 16) & 0xFF; }
 EH_DEV uint32_t em_mask(uint32_t m) { return (m >> 24) & 0xFF; }
 EH_DEV uint32_t em_pack(uint32_t score, uint32_t fn, uint32_t name, uint32_t mask) { return score | (fn << 8) | (name << 16) | (mask << 24); }
 
+// Cost weight of one byte handed to mutator `fn` in the work budget (measured cycles per byte, rounded
+// to powers of two): parsers and per-byte-draw mutators are an order of magnitude dearer than byte
+// movers, and the budget stands in for a time limit.  oracle/oracle.cpp mirrors this table.
+EH_DEV uint32_t work_weight(uint32_t fn) {
+  switch (fn) {
+    case M_SGM: case M_JS: case M_AB: case M_AD: case M_TR2: case M_TD: case M_TS1: case M_TR: case M_TS2:
+    case M_SNAND: case M_SRND: case M_B64: case M_URI: return 8;
+    case M_NUM: return 4;
+    case M_FT: case M_FN: case M_FO: return 64;
+    default: return 1;
+  }
+}
+
 EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask);   // eh_engine.hip: text/tree/... mutators
 EH_DEV int run_mutator(Ctx& c, uint32_t fn, uint32_t mask) {
   switch (fn) {
@@ -583,7 +607,7 @@ EH_DEV void mux_fuzzers(Ctx& c) {
     uint64_t mark = c.ws_used;
     // work budget: the reference kills a worker after maxrunningtime and records <<>>
     // (erlamsa_main.erl:211-220); the engine's deterministic analogue counts bytes
-    c.work += h0.len;
+    c.work += (uint64_t)h0.len * work_weight(fn);
     if (c.work > c.p->work_budget) { c.status = CASE_BUDGET; return; }
 #ifdef EH_PROF
     uint64_t pt0 = __builtin_readcyclecounter();

@@ -817,7 +817,7 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.corpus = ctx->d_corpus; p.coff = ctx->d_coff; p.corpus_first = corpus_first; p.n = n; p.first_case = first_case;
   p.mode = mode; p.run = ctx->d_run; p.seeds = ctx->d_seeds; p.cfg = ctx->cfg;
   p.slot_base = ctx->d_slots; p.slot_stride = ctx->slot_stride; p.work_cap = ctx->work_cap;
-  p.work_budget = ctx->work_budget ? ctx->work_budget : (4ull << 20);
+  p.work_budget = ctx->work_budget ? ctx->work_budget : (8ull << 20);
   p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
   p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles;
   p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;

@@ -69,68 +69,67 @@ EH_DEV void lw_load(LexWin& x, uint32_t base) {
   for (int d = 1; d <= 5; d++) te &= (Tp >> d) | (nx << (64 - d));
   x.te = te & x.w.inrange;
 }
-enum { EV_TE, EV_TEXT, EV_D1, EV_D2 };
-// absolute position of the next event of kind `ev` at or after pos (L if none)
-EH_DEV uint32_t lw_find(LexWin& x, int ev, uint32_t pos) {
-  const uint32_t L = x.w.L;
-  while (pos < L) {
-    if (!x.w.valid || pos < x.w.base || pos >= x.w.base + MW_STEP) lw_load(x, pos & ~63u);
-    uint64_t word = ev == EV_TE ? x.te : (ev == EV_TEXT ? (x.w.m[1] | x.w.m[2] | x.nt) : (ev == EV_D1 ? (x.w.m[1] | x.w.m[3] | x.nt) : (x.w.m[2] | x.w.m[3] | x.nt)));
-    uint32_t r = mw_next(word, pos - x.w.base);
-    if (r < MW_STEP) return x.w.base + r;
-    pos = x.w.base + MW_STEP;
-  }
-  return L;
-}
-EH_DEV bool lw_is(LexWin& x, int cls, uint32_t pos) {           // cls: 0 texty 1 dq 2 sq 3 bs 4 texty_enough; pos < L
-  // texty_enough bits of the lookahead word are not valid
-  if (!x.w.valid || pos < x.w.base || pos >= x.w.base + (cls == 4 ? MW_STEP : MW_STEP + 64)) lw_load(x, pos & ~63u);
-  return mw_test(cls == 4 ? x.te : x.w.m[cls], pos - x.w.base);
-}
-
 // Lexes H[0,L) into tab (capacity cap); returns the number of chunks or -1 on table overflow.
+// One explicit state machine with a SINGLE window-load site, so that the event loop stays a few
+// hundred bytes of code (an earlier version inlined the window load at every lookup: 60 KB of code,
+// instruction-cache misses on every hop).
+//   ST_STEP   string_lex_step (:79-97): is texty_enough at pos?
+//   ST_RAW    raw bytes: hop to the next position where texty_enough holds
+//   ST_TEXT   step_text (:99-112): hop to the next quote or non-texty byte
+//   ST_DELIM  step_delimited (:114-142): hop to the next closing quote, backslash or non-texty byte
 __device__ __noinline__ int lex_block(const uint8_t* H, uint32_t L, LexChunk* tab, uint32_t cap) {
   const int l = EH_LANE;
   LexWin x; x.w.p = H; x.w.L = L; x.w.valid = false; x.w.base = 0;
   uint32_t pos = 0, n = 0; uint32_t raw_start = 0xFFFFFFFFu;
-  auto emit = [&](uint32_t type, uint32_t a, uint32_t b) {
-    if (n < cap && l == 0) { tab[n].type = type; tab[n].a = a; tab[n].b = b; }
-    n++;
+  // chunk records are staged in lane registers (record k of the batch in lane k) and written 64 at a
+  // time: a store per chunk would make the next window load wait for it
+  uint32_t bt = 0, ba = 0, bb = 0, nb = 0;
+  auto flush = [&]() {
+    uint32_t first = n - nb;
+    if ((uint32_t)l < nb && first + (uint32_t)l < cap) { tab[first + l].type = bt; tab[first + l].a = ba; tab[first + l].b = bb; }
+    nb = 0;
   };
+  auto emit = [&](uint32_t type, uint32_t a, uint32_t b) {
+    if ((uint32_t)l == nb) { bt = type; ba = a; bb = b; }
+    nb++; n++;
+    if (nb == 64) flush();
+  };
+  enum { ST_STEP, ST_RAW, ST_TEXT, ST_DELIM };
+  int state = ST_STEP; uint32_t seen = 0, q = 0, qcls = 1;
   while (pos < L) {
-    // string_lex_step (:79-97): raw bytes until texty_enough holds
-    if (!lw_is(x, 4, pos)) {
-      if (raw_start == 0xFFFFFFFFu) raw_start = pos;
-      pos = lw_find(x, EV_TE, pos + 1);
-      continue;
-    }
-    if (raw_start != 0xFFFFFFFFu) { emit(1, raw_start, pos); raw_start = 0xFFFFFFFFu; }
-    uint32_t seen = pos; bool resume = false;
-    while (!resume) {                                           // step_text (:99-112)
-      pos = lw_find(x, EV_TEXT, pos);
-      if (pos >= L) { emit(0, seen, L); pos = L; break; }
-      if (!lw_is(x, 0, pos)) { emit(0, seen, pos); break; }     // non-texty byte ends the text chunk
-      uint32_t qcls = lw_is(x, 1, pos) ? 1 : 2;                 // step_delimited (:114-142)
-      uint32_t q = pos, p2 = pos + 1;
-      while (true) {
-        p2 = lw_find(x, qcls == 1 ? EV_D1 : EV_D2, p2);
-        if (p2 >= L) { emit(0, seen, L); pos = L; resume = true; break; }
-        if (lw_is(x, (int)qcls, p2)) {                          // closing quote
-          if (q > seen) emit(0, seen, q);
-          emit(2, q, p2 + 1);
-          pos = p2 + 1; resume = true; break;
-        }
-        if (lw_is(x, 3, p2)) {                                  // backslash: skips the next byte when that is texty
-          if (p2 + 1 >= L) p2 += 1;
-          else if (lw_is(x, 0, p2 + 1)) p2 += 2;
-          else p2 += 1;
-          continue;
-        }
-        emit(0, seen, p2); pos = p2; resume = true; break;      // non-texty byte: the whole thing was text
-      }
+    if (!x.w.valid || pos < x.w.base || pos >= x.w.base + MW_STEP) lw_load(x, pos & ~63u);
+    const uint32_t rel = pos - x.w.base;
+    if (state == ST_STEP) {
+      if (!mw_test(x.te, rel)) { if (raw_start == 0xFFFFFFFFu) raw_start = pos; pos++; state = ST_RAW; }
+      else { if (raw_start != 0xFFFFFFFFu) { emit(1, raw_start, pos); raw_start = 0xFFFFFFFFu; } seen = pos; state = ST_TEXT; }
+    } else if (state == ST_RAW) {
+      uint32_t r = mw_next(x.te, rel);
+      if (r >= MW_STEP) pos = x.w.base + MW_STEP; else { pos = x.w.base + r; state = ST_STEP; }
+    } else if (state == ST_TEXT) {
+      uint32_t r = mw_next(x.w.m[1] | x.w.m[2] | x.nt, rel);
+      if (r >= MW_STEP) { pos = x.w.base + MW_STEP; continue; }
+      pos = x.w.base + r;
+      if (!mw_test(x.w.m[0], r)) { emit(0, seen, pos); state = ST_STEP; }     // non-texty byte ends the text chunk
+      else { qcls = mw_test(x.w.m[1], r) ? 1u : 2u; q = pos; pos++; state = ST_DELIM; }
+    } else {
+      uint64_t quote = qcls == 1 ? x.w.m[1] : x.w.m[2];
+      uint32_t r = mw_next(quote | x.w.m[3] | x.nt, rel);
+      if (r >= MW_STEP) { pos = x.w.base + MW_STEP; continue; }
+      uint32_t p2 = x.w.base + r;
+      if (mw_test(quote, r)) {                                   // closing quote
+        if (q > seen) emit(0, seen, q);
+        emit(2, q, p2 + 1);
+        pos = p2 + 1; state = ST_STEP;
+      } else if (mw_test(x.w.m[3], r)) {                         // backslash: skips the next byte when that is texty
+        if (p2 + 1 >= L) pos = p2 + 1;                           // (r + 1 is inside the lookahead word)
+        else pos = mw_test(x.w.m[0], r + 1) ? p2 + 2 : p2 + 1;
+      } else { emit(0, seen, p2); pos = p2; state = ST_STEP; }   // non-texty byte: the whole thing was text
     }
   }
+  // the block ended inside a chunk
+  if (state == ST_TEXT || state == ST_DELIM) emit(0, seen, L);
   if (raw_start != 0xFFFFFFFFu) emit(1, raw_start, L);
+  flush();
   wave_sync();
   return n <= cap ? (int)n : -1;
 }

@@ -76,8 +76,10 @@ typedef struct eh_options {
   int32_t ssrf_port;         /* 0 => 51234 */
   uint64_t max_case_bytes;   /* per-case working-set cap; 0 => default (8 MiB) */
   uint64_t out_capacity;     /* output arena bytes; 0 => 8 x batch input bytes + 1 GiB */
-  uint64_t max_case_work;    /* per-case work budget in bytes (sum of the sizes of the blocks handed to
-                                mutators, failed attempts included); 0 => default (4 MiB) */
+  uint64_t max_case_work;    /* per-case work budget in bytes (sum over mutator attempts, failed ones
+                                included, of block size x cost weight of the mutator: 8 for parsers and
+                                per-byte-draw mutators, 64 for the fuse family, 4 for num, 1 otherwise);
+                                0 => default (8 MiB) */
   uint32_t max_slots;        /* resident wavefront slots; 0 => auto */
   uint32_t flags;            /* EH_FLAG_* */
 } eh_options;

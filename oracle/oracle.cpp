@@ -1133,6 +1133,17 @@ int run_muta_fn(Ctx& c, BList& ll, Muta& m) {
 
 // mux_fuzzers/1 + mux_fuzzers_loop/4 :1256-1280.  Mutates `fs` (the closure's
 // list) and `ll` in place.
+// engine work budget (Config::max_case_work): cost weight per byte by mutator, mirrors
+// erlamsa_amd/csrc/eh_device.h work_weight()
+static uint32_t work_weight(int fn) {
+  switch (fn) {
+    case M_SGM: case M_JS: case M_AB: case M_AD: case M_TR2: case M_TD: case M_TS1: case M_TR: case M_TS2:
+    case M_SNAND: case M_SRND: case M_B64: case M_URI: return 8;
+    case M_NUM: return 4;
+    case M_FT: case M_FN: case M_FO: return 64;
+    default: return 1;
+  }
+}
 void mux_fuzzers(Ctx& c, std::vector<Muta>& fs, BList& ll) {
   if (ll.size() == 1 && ll[0].empty()) return;                                // L([<<>>], Meta)
   if (ll.empty()) throw ErlCrash("mux_fuzzers([]) -> <<>> (non-list result)");
@@ -1149,7 +1160,7 @@ void mux_fuzzers(Ctx& c, std::vector<Muta>& fs, BList& ll) {
       std::vector<Muta> nf = out; nf.insert(nf.end(), sorted.begin() + i + 1, sorted.end()); fs.swap(nf); return;
     }
     Muta node = sorted[i];
-    c.work += ll[0].size();
+    c.work += (uint64_t)ll[0].size() * work_weight(node.fn);
     if (c.cfg->max_case_work && c.work > c.cfg->max_case_work) throw Budget();
     BList mll = ll;
     int delta = run_muta_fn(c, mll, node);
@@ -1606,6 +1617,23 @@ void eo_sort_by_priority(const int32_t* pri, uint32_t n, uint32_t* perm) {
   std::vector<PriItem> l; for (uint32_t i = 0; i < n; i++) l.push_back({pri[i], (int)i});
   int tot; std::vector<PriItem> s = sort_by_priority(l, &tot);
   for (uint32_t i = 0; i < n; i++) perm[i] = (uint32_t)s[i].id;
+}
+
+// Exhaustive check used by tests/test_oracle_rng.py: the reciprocal + one FMA correction that the
+// HIP engine uses for B/30269.0, B/30307.0, B/30323.0 equals real IEEE division for every numerator.
+uint64_t eo_check_recip_div(void) {
+  const double P[3] = {30269.0, 30307.0, 30323.0};
+  uint64_t bad = 0;
+  for (int k = 0; k < 3; k++) {
+    volatile double pr = 1.0 / P[k];
+    double r = pr;
+    for (int b = 0; b < (int)P[k]; b++) {
+      double a = (double)b, qe = a / P[k];
+      double q0 = a * r, e = std::fma(-P[k], q0, a), q1 = std::fma(e, r, q0);
+      if (std::memcmp(&qe, &q1, 8) != 0) bad++;
+    }
+  }
+  return bad;
 }
 
 }  // extern "C"

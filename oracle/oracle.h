@@ -67,6 +67,8 @@ int32_t eo_lex_roundtrip(const uint8_t* in, uint64_t len, uint8_t* out);
 // over `n` integer priorities; writes the permutation of input indices.
 void eo_sort_by_priority(const int32_t* pri, uint32_t n, uint32_t* perm);
 void eo_free(void* p);
+// number of numerators for which reciprocal+FMA division differs from IEEE division (must be 0)
+uint64_t eo_check_recip_div(void);
 
 #ifdef __cplusplus
 }

@@ -14,33 +14,44 @@ SEQ = "sp,sr,sd,snand,srnd"
 def _compare(inputs, mutations, patterns, seed=(1, 2, 3), generators=None, first_case=1, max_report=5, max_skipped=0.03,
              oracle_cap=8 << 20, engine_cap=0, work=4 << 20):
     import pyoracle as po
-    import erlamsa_amd as ea
     data, off = po.pack(inputs)
-    want, wst, wdr, trace = po.fuzz_batch(data, off, seed=seed, mutations=mutations, patterns=patterns, generators=generators,
-                                          first_case=first_case, max_case_bytes=oracle_cap, max_case_work=work, trace=True)
+    okw = dict(seed=seed, mutations=mutations, patterns=patterns, generators=generators, first_case=first_case,
+               max_case_bytes=oracle_cap, max_case_work=work)
+    ora = util.oracle_batch(data, off, **okw)
+    if util.priming():
+        pytest.skip("oracle cache primed")
+    import erlamsa_amd as ea
     eng = ea.Engine(0)
     eng.configure(mutations=mutations, patterns=patterns, generators=generators, max_case_bytes=engine_cap, max_case_work=work)
     eng.upload_corpus(data, off)
     eng.fuzz_batch(seed=seed, first_case=first_case)
     got, gst = eng.download()
     gdr, glm = eng.diag()
-    tr = trace.split("\n")
-    bad = []
-    skipped = 0
-    for i in range(len(inputs)):
-        # engine-only statuses (work-area cap, paths the GPU build reports as UNSUPPORTED) have no
-        # counterpart in the reference semantics; they are tolerated in small numbers and counted
-        if gst[i] in (2, 3) or wst[i] in (2, 3):
-            skipped += 1
-            continue
-        if got[i] != want[i] or gst[i] != wst[i]:
-            bad.append((i, util.first_diff(got[i], want[i]), len(got[i]), len(want[i]), int(gst[i]), int(wst[i]), int(gdr[i]), int(wdr[i]), tr[i]))
-    msg = "\n".join("case %d: first diff at %d, len gpu %d vs oracle %d, status %d vs %d, draws %d vs %d, trace: %s" % b for b in bad[:max_report])
+    eng.close()
+    wst, wdr = ora.status, ora.draws
+
+    def diff():
+        bad, skipped = [], 0
+        for i in range(len(inputs)):
+            # engine-only statuses (work-area cap, paths the GPU build reports as UNSUPPORTED) have no
+            # counterpart in the reference semantics; they are tolerated in small numbers and counted
+            if gst[i] in (2, 3) or wst[i] in (2, 3):
+                skipped += 1
+                continue
+            if gst[i] != wst[i] or not ora.same(i, got[i]):
+                bad.append(i)
+        return bad, skipped
+
+    bad, skipped = diff()
+    if bad and ora.outs is None:
+        ora = util.oracle_batch(data, off, live=True, **okw)      # digests only: recompute for the report
+    msg = "\n".join("case %d: first diff at %d, len gpu %d vs oracle %d, status %d vs %d, draws %d vs %d, trace: %s"
+                    % (i, util.first_diff(got[i], ora.outs[i]), len(got[i]), len(ora.outs[i]), int(gst[i]), int(wst[i]), int(gdr[i]), int(wdr[i]),
+                       ora.trace[i] if i < len(ora.trace) else "") for i in bad[:max_report])
     assert not bad, "%d/%d cases differ\n%s" % (len(bad), len(inputs), msg)
     assert skipped <= max_skipped * len(inputs), "%d cases skipped as overflow/unsupported" % skipped
     ok = (wst == 0) & (gst == 0)
     assert (gdr[ok] == wdr[ok]).all(), "draw counts differ"
-    eng.close()
 
 
 def test_c2_byte_mutators_od():

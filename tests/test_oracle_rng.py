@@ -60,3 +60,13 @@ def test_period_components_are_full():
             x = x * m % p
             n += 1
         assert n == p - 1
+
+
+def test_reciprocal_fma_division_is_exact_for_as183_divisors():
+    """The HIP engine replaces B/30269.0 etc. by a reciprocal product plus one FMA correction
+    (erlamsa_amd/csrc/eh_device.h as183_div); exhaustive over every possible numerator."""
+    import ctypes
+    import pyoracle as po
+    f = po.lib().eo_check_recip_div
+    f.restype = ctypes.c_uint64
+    assert f() == 0
