@@ -115,29 +115,15 @@ __device__ __noinline__ int tree_parse(Ctx& c, const uint8_t* H, uint32_t L, TNo
   wave_sync();
   TR_PH(12); TR_ST(16, nslots);
   // level end of every slot: one past the close of the nearest ancestor that did close (L at top level).
-  // pe[i] = closed(parent) ? close[parent] + 1 : pe[parent] and parents precede their children, so the
-  // slots are resolved chunk by chunk in index order; inside a chunk a lane whose parent sits in the same
-  // chunk waits (shuffle rounds, no memory traffic) until that lane is resolved.  Walking the ancestor
-  // chain per slot instead is quadratic on text full of unclosed openers.
-  for (uint32_t base = 0; base < nslots; base += 64) {
-    uint32_t i = base + (uint32_t)l;
-    bool act = i < nslots;
-    uint32_t par = 0xFFFFFFFFu, myclose = 0xFFFFFFFFu, pe = L;
-    if (act) { par = tab[i].pend; myclose = tab[i].close; }
-    bool res = true;
-    bool inchunk = act && par != 0xFFFFFFFFu && par >= base;
-    if (act && par != 0xFFFFFFFFu && par < base) { uint32_t pc = tab[par].close; pe = pc != 0xFFFFFFFFu ? pc + 1 : tab[par].pad; }
-    uint32_t pl = inchunk ? par - base : 0;
-    uint32_t pclose = (uint32_t)__shfl((int)myclose, (int)pl);
-    if (inchunk) { if (pclose != 0xFFFFFFFFu) pe = pclose + 1; else res = false; }
-    while (__ballot(!res)) {
-      uint32_t ppe = (uint32_t)__shfl((int)pe, (int)pl);
-      bool pres = __shfl((int)res, (int)pl) != 0;
-      if (!res && pres) { pe = ppe; res = true; }
-    }
-    if (act) tab[i].pad = pe;
-    wave_sync();
+  // An opener that never closes stays on the matcher's stack for good, and so does everything below
+  // it: the ancestors of an unclosed slot are all unclosed.  So the level end is close[parent] + 1 if
+  // the parent closed and L otherwise — one gather (before the in-place compaction moves slots).
+  for (uint32_t i = (uint32_t)l; i < nslots; i += 64) {
+    uint32_t par = tab[i].pend, pe = L;
+    if (par != 0xFFFFFFFFu) { uint32_t pc = tab[par].close; if (pc != 0xFFFFFFFFu) pe = pc + 1; }
+    tab[i].pad = pe;
   }
+  wave_sync();
   TR_PH(13);
   // compact completed nodes (keep pre-order); pend <- level end
   uint32_t n = 0;
