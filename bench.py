@@ -31,11 +31,13 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--mutations", default=None, help="-m syntax; default: every mutator this build runs on the GPU")
     ap.add_argument("--patterns", default="od,nd,bu")
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="cases timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="upper bound of cases timed on the CPU oracle (0 = skip); "
+                    "the leg stops after --cpu-seconds")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time bound of the CPU oracle leg")
     ap.add_argument("--max-slots", type=int, default=0)
     ap.add_argument("--out-gib", type=int, default=8, help="output arena capacity per context (GiB)")
     ap.add_argument("--case-mib", type=int, default=8, help="per-case work area (MiB), eh_options.max_case_bytes")
-    ap.add_argument("--work-mib", type=int, default=4, help="per-case work budget (MiB), eh_options.max_case_work: the "
+    ap.add_argument("--work-mib", type=int, default=8, help="per-case work budget (MiB), eh_options.max_case_work: the "
                     "deterministic stand-in for the reference's maxrunningtime watchdog")
     ap.add_argument("--inflight", type=int, default=3, help="passes in flight (engine contexts / HIP streams)")
     args = ap.parse_args()
@@ -175,16 +177,20 @@ def main():
         if args.cpu_sample > 0:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle as po
-            ns = min(args.cpu_sample, n)
-            d, o = synth.as_arena(mat[:ns])
-            t1 = time.perf_counter()
-            outs, _, _, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, first_case=1, max_case_bytes=args.case_mib << 20,
-                                          max_case_work=args.work_mib << 20)
-            ct = time.perf_counter() - t1
-            cb = sum(len(x) for x in outs)
-            res["cpu_baseline"] = {"value": round(cb / ct / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
-                                   "cases_per_s": round(ns / ct, 1),
-                                   "sample": "first %d cases of the same corpus/config, single thread, %.1f s" % (ns, ct)}
+            # chunks of 512 cases (case numbers 1.., same corpus rows) until the time bound is reached
+            ns, ct, cb = 0, 0.0, 0
+            while ns < min(args.cpu_sample, n) and ct < args.cpu_seconds:
+                d, o = synth.as_arena(mat[ns:ns + 512])
+                t1 = time.perf_counter()
+                outs, _, _, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, first_case=ns + 1,
+                                              max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20)
+                ct += time.perf_counter() - t1
+                cb += sum(len(x) for x in outs)
+                ns += len(outs)
+            res["cpu_baseline"] = {"value": round(cb / ct / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+                                   "cases_per_s": round(ns / ct, 2),
+                                   "sample": "cases 1..%d of the same run (same corpus rows, seed, mutators, patterns, limits), "
+                                             "oracle/ C++ restatement, single thread, %.1f s" % (ns, ct)}
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -458,7 +458,7 @@ EH_DEV void gen_random(Ctx& c) {                                       // random
 // the mutate kernel
 // =============================================================================================
 #ifndef EH_WAVES_PER_SIMD
-#define EH_WAVES_PER_SIMD 2
+#define EH_WAVES_PER_SIMD 4
 #endif
 __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(KParams p) {
   const int l = EH_LANE;

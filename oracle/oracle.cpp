@@ -625,35 +625,31 @@ int usual_delims(uint8_t c) {                                                 //
   switch (c) { case 40: return 41; case 91: return 93; case 60: return 62; case 123: return 125; case 34: return 34; case 39: return 39; }
   return -1;
 }
-// grow/3 :800-823.  Returns true if closed; `out` already holds the opener and receives the node
-// contents; pos advanced.  (Vectors are appended to, which is what the reference's
-// reverse-accumulators amount to; no O(n^2) front insertion.)
-bool grow(const Bytes& in, size_t& pos, uint8_t close, std::vector<TermP>& out) {
-  while (true) {
-    if (pos >= in.size()) return false;
+// grow/3 :800-823 + partial_parse/1 :883-905, restated with an explicit stack instead of the
+// reference's recursion.  Semantics kept: a closer only matches the innermost open node; when the
+// input ends inside open nodes, their partial contents are spliced flat into the parent (:817), which
+// for the whole chain of open frames is simply their concatenation bottom-up (each frame was being
+// appended at the end of its parent) — done once here, the level-by-level splice of a literal
+// translation is quadratic on text full of unclosed openers.
+std::vector<TermP> partial_parse(const Bytes& in) {
+  struct Frame { std::vector<TermP> v; int close; };
+  std::vector<Frame> st; st.push_back(Frame{{}, -1});
+  for (size_t pos = 0; pos < in.size(); pos++) {
     uint8_t h = in[pos];
-    if (h == close) { out.push_back(mk_byte(close)); pos++; return true; }
+    if (st.size() > 1 && (int)h == st.back().close) {
+      st.back().v.push_back(mk_byte(h));
+      TermP node = mk_list(std::move(st.back().v));
+      st.pop_back();
+      st.back().v.push_back(std::move(node));
+      continue;
+    }
     int nc = usual_delims(h);
-    if (nc < 0) { out.push_back(mk_byte(h)); pos++; continue; }
-    pos++;
-    std::vector<TermP> inner; inner.push_back(mk_byte(h));
-    bool ok = grow(in, pos, (uint8_t)nc, inner);
-    if (!ok) { out.insert(out.end(), inner.begin(), inner.end()); return false; }  // :817 partial parse is spliced in flat
-    out.push_back(mk_list(std::move(inner)));
+    if (nc < 0) { st.back().v.push_back(mk_byte(h)); continue; }
+    st.push_back(Frame{{}, nc});
+    st.back().v.push_back(mk_byte(h));
   }
-}
-std::vector<TermP> partial_parse(const Bytes& in) {                           // :883-905
-  std::vector<TermP> out; size_t pos = 0;
-  while (pos < in.size()) {
-    uint8_t h = in[pos];
-    int cp = usual_delims(h);
-    if (cp < 0) { out.push_back(mk_byte(h)); pos++; continue; }
-    pos++;
-    std::vector<TermP> inner; inner.push_back(mk_byte(h));
-    bool ok = grow(in, pos, (uint8_t)cp, inner);
-    if (!ok) { out.insert(out.end(), inner.begin(), inner.end()); return out; }
-    out.push_back(mk_list(std::move(inner)));
-  }
+  std::vector<TermP> out = std::move(st[0].v);
+  for (size_t i = 1; i < st.size(); i++) out.insert(out.end(), st[i].v.begin(), st[i].v.end());
   return out;
 }
 // sublists/2 :838-845 — the reference conses each node in front while walking in pre-order, i.e.
