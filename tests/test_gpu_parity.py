@@ -216,3 +216,48 @@ def test_fuse_mutators(seed):
 def test_fuse_with_other_mutators_and_blocks():
     ins = util.corpus_uniform(60, 3000, seed=3) + _texty(60, 2500, 4)
     _compare(ins, FUSE + ",num,bd,sd,ld", "od,nd,bu", max_skipped=0.1, oracle_cap=1 << 20, engine_cap=8 << 20)
+
+
+PROD = "uw,ui,ab,ad,tr2,td,num,ts1,tr,ts2,bd,bei,bed,bf,bi,ber,br,sp,sr,sd,snand,srnd,ld,lds,lr2,lri,lr,ls,lp,lis,lrs,len,uri,zip,nil"
+
+
+def test_bench_workload_sample_with_bench_limits():
+    """The first 8192 rows of the bench corpus generator (BASELINE configs[2], mixed-binary 4 KiB seeds) with
+    the bench's mutator set, patterns and limits: this is where blocks grow to megabytes (sr/lr/tr chains)
+    and the tree/lexer paths see large inputs."""
+    from erlamsa_amd import synth
+    mat = synth.mixed(8192, 4096)
+    _compare([mat[i].tobytes() for i in range(mat.shape[0])], PROD, "od,nd,bu", max_skipped=0.02,
+             oracle_cap=8 << 20, engine_cap=8 << 20, work=8 << 20)
+
+
+def test_results_do_not_depend_on_slot_count_or_batch_cut():
+    """Full-size property (no oracle): the same 16384 cases through 4096 slots in one call, and through 256
+    slots in three calls, give identical bytes and statuses — results are a pure function of
+    (seed, case number, input, options), never of scheduling."""
+    if util.priming():
+        pytest.skip("no oracle involved")
+    import erlamsa_amd as ea
+    from erlamsa_amd import synth
+    import hashlib
+    n = 16384
+    mat = synth.mixed(n, 4096)
+    data, off = synth.as_arena(mat)
+
+    def run(max_slots, cuts):
+        eng = ea.Engine(0)
+        eng.configure(mutations=PROD, patterns="od,nd,bu", max_slots=max_slots)
+        eng.upload_corpus(data, off)
+        dig, sts = [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            eng.fuzz_batch(seed=(7, 8, 9), first_case=a + 1, corpus_first=a, n=b - a)
+            outs, st = eng.download()
+            dig += [hashlib.sha1(o).digest() for o in outs]
+            sts += [int(x) for x in st]
+        eng.close()
+        return dig, sts
+
+    d1, s1 = run(0, [0, n])
+    d2, s2 = run(256, [0, 5000, 5001, n])
+    assert s1 == s2
+    assert d1 == d2
