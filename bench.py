@@ -149,6 +149,20 @@ def main():
         avg_kern_s = float(np.mean(kern_ms)) / 1e3
         alg_bytes = in_bytes + out_bytes / args.steps + DESC_BYTES * n       # per launch (this rank)
         achieved = alg_bytes / avg_kern_s / 1e9
+        # HBM-side bytes per launch cannot be measured from inside this process (PMC counters need
+        # rocprofv3 around it); the figure of the committed counter run of this same workload is attached
+        # when the configuration matches, else null.
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_summary.json")) as fh:
+                ps = json.load(fh)
+            wk = ps["workload_key"]
+            if (wk["cases"], wk["size"], wk["max_case_work"], wk["max_case_bytes"], wk["mutators"], wk["patterns"]) == \
+                    (n, size, args.work_mib << 20, args.case_mib << 20, muts, pats):
+                traffic = int(ps["traffic_bytes_per_launch"]["total_fetch_x2_plus_write"])
+                traffic_src = "profiles/r01_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch)"
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "mutated_MB_per_s", "value": round(mbps, 1), "unit": "MB/s",
             "cases_per_s": round(cases_all / dt_all, 1),
@@ -169,7 +183,7 @@ def main():
                                      "budget(max_case_work; reference analogue: maxrunningtime -> <<>>)"],
                                     [int(x) for x in status_counts])),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ea.load_library().eh_kernel_name().decode(), "kernel_ms_avg": round(avg_kern_s * 1e3, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
