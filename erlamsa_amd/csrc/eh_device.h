@@ -636,8 +636,11 @@ EH_DEV void mux_fuzzers(Ctx& c) {
       // allocation and no mutator state (lis/lrs lines, fo block) can point into it.  The
       // candidate slides down (ascending copy, dst < src) so that chains of mutations on one block
       // keep a ~1x footprint instead of growing linearly with the number of rounds.
+      // The slide is a second full copy of the block plus two memory round trips, so it is only done
+      // once the work area is more than 1/8 full: the typical case (a 4 KiB block, ~10 rounds) never
+      // gets there and simply leaves its dead candidates behind.
       uint8_t* lo = c.ws + mark;
-      if (!c.r2 && c.r_ptr >= lo && c.r_ptr + c.r_len <= c.ws + c.ws_used) {
+      if (c.ws_used > c.ws_cap / 8 && !c.r2 && c.r_ptr >= lo && c.r_ptr + c.r_len <= c.ws + c.ws_used) {
         uint8_t* dst = lo;
         uint8_t* hp = (uint8_t*)h0.ptr;
         bool state_refs = uni(((const uint32_t*)c.aux)[0]) != 0 || uni(((const uint32_t*)(c.aux + 336))[0]) != 0 || uni(((const uint32_t*)(c.aux + 704))[3]) != 0;
