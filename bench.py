@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--mutations", default=None, help="-m syntax; default: every mutator this build runs on the GPU")
     ap.add_argument("--patterns", default="od,nd,bu")
+    ap.add_argument("--corpus", default="mixed", choices=["mixed", "uniform"],
+                    help="mixed = BASELINE configs[2] (default); uniform = random bytes (configs[1] with --cases 1024 --size 256)")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="upper bound of cases timed on the CPU oracle (0 = skip); "
                     "the leg stops after --cpu-seconds")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time bound of the CPU oracle leg")
@@ -74,7 +76,7 @@ def main():
     offs = torch.arange(n + 1, dtype=torch.int64, device=dev) * size
     mat = None
     if rank == 0:
-        mat = synth.mixed(n, size)
+        mat = synth.mixed(n, size) if args.corpus == "mixed" else synth.uniform(n, size)
         arena.copy_(torch.from_numpy(mat.reshape(-1)))
     if dist is not None:
         shard.broadcast_corpus(arena, offs, src=0)
@@ -171,10 +173,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (byte edits) + f64 (AS183 draws)", "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: %d seeds x %d B mixed-binary corpus (50%% random, 25%% ASCII lines+numbers, "
-                            "15%% bracketed text, 10%% length/CRC-framed), generator direct=500/random=1, patterns %s, "
+                "workload": "%s: %d seeds x %d B %s, generator direct=500/random=1, patterns %s, "
                             "mutators %s (%d of the %d of the default table; not measured: %s)"
-                            % (n, size, pats, muts, len(muts.split(",")), nmut_total,
+                            % ("BASELINE configs[2]" if (args.corpus, n, size) == ("mixed", 65536, 4096) else "custom",
+                               n, size, "mixed-binary corpus (50% random, 25% ASCII lines+numbers, 15% bracketed text, "
+                               "10% length/CRC-framed)" if args.corpus == "mixed" else "uniform random bytes",
+                               pats, muts, len(muts.split(",")), nmut_total,
                                ",".join(m for m, _, _ in ea.mutator_table() if m not in muts.split(","))),
                 "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx,
                 "max_case_bytes": args.case_mib << 20, "max_case_work": args.work_mib << 20,
