@@ -95,6 +95,14 @@ def main():
         engines.append(e)
         streams.append(torch.cuda.Stream(device=dev))
     seed = (1, 2, 3)
+    # Context set-up, not a step: the first dispatch on a new HIP stream makes the runtime allocate that
+    # queue's scratch (~1.3 KB per lane for every wave slot of the device).  A 256-case launch per context
+    # pays for that here, so that the W warm-up steps and the K timed steps see the same steady state no
+    # matter how W compares with the number of contexts.
+    for e, st in zip(engines, streams):
+        e.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=min(256, n), stream=st.cuda_stream)
+    for e in engines:
+        e.sync()
 
     def launch(k):
         # rank r, step k -> case numbers ((k*world + r) * n) + 1 ...
@@ -180,7 +188,7 @@ def main():
                                "10% length/CRC-framed)" if args.corpus == "mixed" else "uniform random bytes",
                                pats, muts, len(muts.split(",")), nmut_total,
                                ",".join(m for m, _, _ in ea.mutator_table() if m not in muts.split(","))),
-                "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx,
+                "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "one 256-case launch per context/stream before warm-up (scratch allocation)",
                 "max_case_bytes": args.case_mib << 20, "max_case_work": args.work_mib << 20,
             },
             "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(max_case_bytes)", "unsupported", "arena_full",

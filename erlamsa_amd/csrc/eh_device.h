@@ -240,10 +240,21 @@ struct Ctx {
   int r_drop_next;     // fn consumed the following block
   int r_changed;       // mutator guarantees hd(result) != hd(input): skip the compare
   int r2; uint8_t* r2_ptr; uint32_t r2_len;   // optional second flushed region (fo: flush_bvecs(A, flush_bvecs(B, T)))
-  // per-lane mux_fuzzers entry (lane i = list position i)
+  int nfs;             // entries of the mux_fuzzers list (the entries themselves: LaneTab)
+  uint64_t work_budget;
+};
+// The per-case context lives in LDS.  One workgroup is one wavefront, so there is exactly one Ctx per
+// workgroup and no synchronisation is needed.  As a stack object it was reached through generic
+// pointers from every non-inlined mutator function: each field access was a flat scratch access with
+// a full memory round trip behind it (72 % of all wave cycles were s_waitcnt).  Non-inlined functions
+// therefore ignore their Ctx& argument and bind `c` to the LDS object directly (EH_CTX), which lets the
+// compiler emit ds_read/ds_write.
+__shared__ Ctx g_ctx;
+#define EH_CTX Ctx& c = g_ctx
+// per-lane mux_fuzzers entry (lane i = list position i); private registers, never in LDS
+struct LaneTab {
   uint32_t e_pri;
   uint32_t e_meta;     // score | fn<<8 | name<<16 | mask<<24
-  int nfs;
 };
 enum { R_SAME = 0, R_NEW = 1 };
 
@@ -280,7 +291,8 @@ EH_DEV void random_block_rev(Ctx& c, uint8_t* dst, uint32_t n) {
 // ---------------------------------------------------------------------------------------------
 // Single-byte mutators  (erlamsa_mutations.erl:56-61,176-223) and UTF-8 (:1081-1099)
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ int muta_byte(Ctx& c, int fn) {
+__device__ __noinline__ int muta_byte(Ctx&, int fn) {
+  EH_CTX;
   Blk h = blk_load(c.bl, c.cur);
   const uint8_t* src = (const uint8_t*)h.ptr;
   uint32_t L = h.len;
@@ -365,7 +377,8 @@ EH_DEV void wave_sort_key2(Key2* k, uint32_t n_pow2) {
 // ---------------------------------------------------------------------------------------------
 // Multi-byte mutators (erlamsa_mutations.erl:232-318)
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ int muta_seq(Ctx& c, int fn, int mask_fun) {
+__device__ __noinline__ int muta_seq(Ctx&, int fn, int mask_fun) {
+  EH_CTX;
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* src = (const uint8_t*)hb.ptr;
   uint32_t B = hb.len;
@@ -575,13 +588,13 @@ EH_DEV void commit_result(Ctx& c) {
 }
 
 // One call of the mux_fuzzers closure on the list bl[cur..nb).
-EH_DEV void mux_fuzzers(Ctx& c) {
+EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
   const int l = EH_LANE;
   if (c.nb - c.cur == 1 && blk_load(c.bl, c.cur).len == 0) return;   // L([<<>>], Meta)
   if (c.nb - c.cur <= 0) { c.status = CASE_CRASHED; return; }
   const int nfs = c.nfs;
   // --- weighted_permutations: key_i = rand(trunc(Score*Pri)) in list order, lane-parallel jump-ahead
-  uint32_t nkey = (l < nfs) ? em_score(c.e_meta) * c.e_pri : 0;
+  uint32_t nkey = (l < nfs) ? em_score(lt.e_meta) * lt.e_pri : 0;
   unsigned long long drawing = __ballot(nkey > 0);
   uint32_t my_idx = (uint32_t)__popcll(drawing & ((1ull << l) - 1));
   uint32_t ndraw = (uint32_t)__popcll(drawing);
@@ -601,14 +614,14 @@ EH_DEV void mux_fuzzers(Ctx& c) {
     if (h0.len > ABSMAX_BINARY_BLOCK) { dropped = true; break; }                 // :1269-1270
     unsigned long long who = __ballot(l < nfs && rank == (uint32_t)r);
     int j = (int)__builtin_ctzll(who);
-    uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)c.e_meta, j);
+    uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)lt.e_meta, j);
     uint32_t fn = em_fn(meta), name = em_name(meta);
     c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
     uint64_t mark = c.ws_used;
     // work budget: the reference kills a worker after maxrunningtime and records <<>>
     // (erlamsa_main.erl:211-220); the engine's deterministic analogue counts bytes
     c.work += (uint64_t)h0.len * work_weight(fn);
-    if (c.work > c.p->work_budget) { c.status = CASE_BUDGET; return; }
+    if (c.work > c.work_budget) { c.status = CASE_BUDGET; return; }
 #ifdef EH_PROF
     uint64_t pt0 = __builtin_readcyclecounter();
 #endif
@@ -621,7 +634,7 @@ EH_DEV void mux_fuzzers(Ctx& c) {
     uint32_t sc = em_score(meta);
     if (delta != 0) { int ns = (int)sc + delta; ns = ns < 2 ? 2 : (ns > 10 ? 10 : ns); sc = (uint32_t)ns; }
     uint32_t nfn = (fn == M_URI) ? (uint32_t)M_B64 : fn;                          // :784 (sic)
-    if (l == j) c.e_meta = em_pack(sc, nfn, name, em_mask(meta));
+    if (l == j) lt.e_meta = em_pack(sc, nfn, name, em_mask(meta));
     tried++;
     bool changed = false;
     if (c.r_kind == R_NEW) {
@@ -664,8 +677,8 @@ EH_DEV void mux_fuzzers(Ctx& c) {
     else newpos = rk == tried ? nfs - 1 : rk - 1;
   }
   // ds_permute (forward): lane i sends its value to lane newpos (a bijection)
-  c.e_meta = (uint32_t)__builtin_amdgcn_ds_permute(newpos << 2, (int)c.e_meta);
-  c.e_pri = (uint32_t)__builtin_amdgcn_ds_permute(newpos << 2, (int)c.e_pri);
+  lt.e_meta = (uint32_t)__builtin_amdgcn_ds_permute(newpos << 2, (int)lt.e_meta);
+  lt.e_pri = (uint32_t)__builtin_amdgcn_ds_permute(newpos << 2, (int)lt.e_pri);
   if (dropped) c.nfs = nfs - 1;
 }
 

@@ -185,7 +185,8 @@ struct PatFrame {           // a sizer/csum wrapper waiting for its inner evalua
 
 // get_possible_csum_locations/1 + rand_elem (erlamsa_field_predict.erl:131-161).
 // Returns 1 with (*crc,*plen,*blen), 0 for no candidate, -1 on failure.
-__device__ __noinline__ int pick_csum(Ctx& c, const uint8_t* H, uint32_t L, uint32_t* crc, uint32_t* plen, uint32_t* blen) {
+__device__ __noinline__ int pick_csum(Ctx&, const uint8_t* H, uint32_t L, uint32_t* crc, uint32_t* plen, uint32_t* blen) {
+  EH_CTX;
   const int l = EH_LANE;
   if (L == 0) return 0;
   uint32_t maxp = (uint32_t)(2.0 * (double)L / 3.0);
@@ -256,7 +257,7 @@ __device__ __noinline__ int pick_csum(Ctx& c, const uint8_t* H, uint32_t L, uint
   return 1;
 }
 
-EH_DEV void run_patterns(Ctx& c, int pat) {
+EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
   int act = A_RUN_PAT, cont = C_EMIT, contpat = 0; uint32_t ip = 0;
   int guard = 0;
   PatFrame* frames = (PatFrame*)(c.aux + 1152); int nfr = 0;     // wrapper stack lives in slot memory
@@ -358,7 +359,7 @@ EH_DEV void run_patterns(Ctx& c, int pat) {
         break;
       case A_LOOP: {                                                                  // mutate_once_loop/6 :281-296
         uint32_t n = rng_rand(c.rng, ip);
-        if (n == 0 || c.nb - c.cur == 1) { mux_fuzzers(c); act = A_CONT; }
+        if (n == 0 || c.nb - c.cur == 1) { mux_fuzzers(c, lt); act = A_CONT; }
         else { Blk b = blk_load(c.bl, c.cur); emit_ref(c, b.ptr, b.len); c.cur++; }
         break;
       }
@@ -372,7 +373,7 @@ EH_DEV void run_patterns(Ctx& c, int pat) {
             int n = 1;
             while (c.status == CASE_OK) {
               bool p = rng_occurs(c.rng, 4, 5);
-              if (p || n < 2) { mux_fuzzers(c); n++; } else { emit_all(c); act = A_TERMINAL; break; }
+              if (p || n < 2) { mux_fuzzers(c, lt); n++; } else { emit_all(c); act = A_TERMINAL; break; }
               if (++guard > 1000000) { c.status = CASE_OVERFLOW; break; }
             }
             break;
@@ -462,8 +463,10 @@ EH_DEV void gen_random(Ctx& c) {                                       // random
 #endif
 __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(KParams p) {
   const int l = EH_LANE;
-  Ctx c;
+  Ctx& c = g_ctx;
+  LaneTab lt;
   c.p = &p;
+  c.work_budget = p.work_budget;
   uint8_t* slot = p.slot_base + (uint64_t)blockIdx.x * p.slot_stride;
   c.bl = (Blk*)slot;
   c.bl2 = c.bl + MAX_BLOCKS;
@@ -508,10 +511,10 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(KParam
       // ThreadSeed of case I = parent draws 3(I-1)+1..3(I-1)+3   (erlamsa_main.erl:179, erlamsa_rnd.erl:65)
       pr = parent;
       rng_skip(pr, 3 * (p.first_case + i - 1));
-      gen = gen0; c.e_pri = pri0; c.e_meta = meta0; c.nfs = nfs0;
+      gen = gen0; lt.e_pri = pri0; lt.e_meta = meta0; c.nfs = nfs0;
     } else {
       int mask;
-      setup_run(p.cfg, p.seeds[3 * i], p.seeds[3 * i + 1], p.seeds[3 * i + 2], pr, gen, mask, c.e_pri, c.e_meta, c.nfs);
+      setup_run(p.cfg, p.seeds[3 * i], p.seeds[3 * i + 1], p.seeds[3 * i + 2], pr, gen, mask, lt.e_pri, lt.e_meta, c.nfs);
     }
 #ifdef EH_PROF
 #define EH_PH(k) do { uint64_t now_ = __builtin_readcyclecounter(); if (l == 0) { atomicAdd(&p.prof[2 * (64 + (k))], (unsigned long long)(now_ - ph0)); atomicAdd(&p.prof[2 * (64 + (k)) + 1], 1ull); } ph0 = now_; } while (0)
@@ -537,7 +540,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(KParam
         if (r == 0 || r < p.cfg.pat_pri[k]) { pat = p.cfg.pat_id[k]; break; }
         r -= p.cfg.pat_pri[k];
       }
-      if (pat < 0) c.status = CASE_CRASHED; else run_patterns(c, pat);  // Pat(Ll, CurMuta, Meta) :189
+      if (pat < 0) c.status = CASE_CRASHED; else run_patterns(c, lt, pat);  // Pat(Ll, CurMuta, Meta) :189
     }
 
     EH_PH(2);

@@ -40,7 +40,8 @@ EH_DEV int basic_len_clause(const uint64_t fv[6], uint32_t fmask, uint32_t L, ui
 
 // Picks rand_elem(get_possible_simple_lens(Bin)).  Returns 1 and fills *e, 0 when the list is
 // empty (no draw for rand_elem), -1 on allocation failure.  Consumes SubLen+1 draws when L > 10.
-__device__ __noinline__ int pick_simple_len(Ctx& c, const uint8_t* H, uint32_t L, SizerElem* e) {
+__device__ __noinline__ int pick_simple_len(Ctx&, const uint8_t* H, uint32_t L, SizerElem* e) {
+  EH_CTX;
   const int l = EH_LANE;
   const int64_t adjs[5] = {0, 1, 2, 4, 8};
   if (L <= 10) {                                                 // :102-105: offsets 0..3, [simple_len, simple_u8len] per offset
@@ -168,7 +169,8 @@ __device__ inline void put_field(uint8_t* o, uint64_t v, uint32_t bits, bool big
 }
 
 // length_predict/2 + mutate_length/2 (erlamsa_mutations.erl:1107-1143)
-__device__ __noinline__ int muta_len(Ctx& c) {
+__device__ __noinline__ int muta_len(Ctx&) {
+  EH_CTX;
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   const int l = EH_LANE;

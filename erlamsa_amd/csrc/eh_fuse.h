@@ -182,7 +182,8 @@ EH_DEV bool fuse_lists(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, 
 
 struct FoState { uint64_t ptr; uint32_t len; uint32_t has; };
 
-__device__ __noinline__ int muta_fuse(Ctx& c, int fn, FoState* fo) {
+__device__ __noinline__ int muta_fuse(Ctx&, int fn, FoState* fo) {
+  EH_CTX;
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;

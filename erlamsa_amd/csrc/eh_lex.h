@@ -288,7 +288,8 @@ EH_DEV void mutate_text_emit(Ctx& c, int tm, const uint8_t* H, uint32_t L, uint3
 
 // construct_ascii_mutator (:585-602) with string_generic_mutate (ab, :571-583) or
 // string_delimeter_mutate (ad, :626-644)
-__device__ __noinline__ int muta_ascii(Ctx& c, LexCache& lc, int fn) {
+__device__ __noinline__ int muta_ascii(Ctx&, LexCache& lc, int fn) {
+  EH_CTX;
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
@@ -366,7 +367,8 @@ EH_DEV bool has_zip_eocd(const uint8_t* H, uint32_t L) {
   }
   return __ballot(found != 0) != 0;
 }
-__device__ __noinline__ int muta_zip(Ctx& c) {                                   // zip_path_traversal :1149-1163
+__device__ __noinline__ int muta_zip(Ctx&) {
+  EH_CTX;                                   // zip_path_traversal :1149-1163
   Blk hb = blk_load(c.bl, c.cur);
   c.r_kind = R_SAME;
   if (has_zip_eocd((const uint8_t*)hb.ptr, hb.len)) { c.status = CASE_UNSUPPORTED; return 0; }
@@ -405,7 +407,8 @@ EH_DEV bool b64_decodes(const uint8_t* t, uint32_t n) {        // stdlib base64:
   }
   return uni((uint32_t)__shfl((int)ok, 0)) != 0;
 }
-__device__ __noinline__ int muta_b64(Ctx& c, LexCache& lc) {
+__device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
+  EH_CTX;
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
@@ -423,7 +426,8 @@ __device__ __noinline__ int muta_b64(Ctx& c, LexCache& lc) {
 }
 
 // uri_mutator :770-784 (+ try_uri_mutate :760-768, rand_uri_mutate :737-758)
-__device__ __noinline__ int muta_uri(Ctx& c, LexCache& lc) {
+__device__ __noinline__ int muta_uri(Ctx&, LexCache& lc) {
+  EH_CTX;
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;

@@ -163,7 +163,8 @@ EH_DEV uint32_t li_start(const LineIdx& li, uint32_t j) {
 struct StLineRef { uint64_t nptr; uint64_t pptr; uint32_t nlen; uint32_t plen; uint32_t has_nested; uint32_t pad; };
 struct StState { int32_t count; int32_t pad[3]; StLineRef ln[10]; };
 
-__device__ __noinline__ int muta_line(Ctx& c, int fn) {                       // construct_line_muta :351-362
+__device__ __noinline__ int muta_line(Ctx&, int fn) {
+  EH_CTX;                       // construct_line_muta :351-362
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
@@ -282,7 +283,8 @@ __device__ __noinline__ int muta_line(Ctx& c, int fn) {                       //
   return 1;
 }
 
-__device__ __noinline__ int muta_st_line(Ctx& c, int fn, StState* st) {        // construct_st_line_muta :366-378
+__device__ __noinline__ int muta_st_line(Ctx&, int fn, StState* st) {
+  EH_CTX;        // construct_st_line_muta :366-378
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
@@ -436,7 +438,8 @@ __device__ inline void bd_interesting(BD& r, uint32_t idx, uint32_t* t1) {
   bd_add_abs(r, m, one); r.neg = false;
 }
 
-__device__ __noinline__ int muta_num(Ctx& c) {                                  // sed_num :154-169
+__device__ __noinline__ int muta_num(Ctx&) {
+  EH_CTX;                                  // sed_num :154-169
   Blk hb = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   const int l = EH_LANE;

@@ -45,7 +45,8 @@ struct IsOpener { EH_DEV bool operator()(uint32_t b, uint32_t) const { return de
 #define TR_ST(k, v) do { } while (0)
 #endif
 struct IsDelim { EH_DEV bool operator()(uint32_t b, uint32_t) const { return delim_bit(b, (1u << 2) | (1u << 7) | (1u << 8) | (1u << 9) | (1u << 28) | (1u << 30), (1u << 27) | (1u << 29)); } };
-__device__ __noinline__ int tree_parse(Ctx& c, const uint8_t* H, uint32_t L, TNode** out) {
+__device__ __noinline__ int tree_parse(Ctx&, const uint8_t* H, uint32_t L, TNode** out) {
+  EH_CTX;
   const int l = EH_LANE;
 #ifdef EH_PROF
   uint64_t tph = __builtin_readcyclecounter();
@@ -270,7 +271,8 @@ EH_DEV uint64_t tree_emit(uint8_t* dst, const uint8_t* H, uint32_t L, const TNod
 }
 
 // sed_tree_op (tr2/td :917-936), construct_sed_tree_swap (ts1/ts2 :940-971), sed_tree_stutter (tr :975-1023)
-__device__ __noinline__ int muta_tree(Ctx& c, int fn) {
+__device__ __noinline__ int muta_tree(Ctx&, int fn) {
+  EH_CTX;
 #ifdef EH_PROF
   uint64_t tph = __builtin_readcyclecounter();
 #endif
