@@ -95,12 +95,14 @@ def main():
         engines.append(e)
         streams.append(torch.cuda.Stream(device=dev))
     seed = (1, 2, 3)
-    # Context set-up, not a step: the first dispatch on a new HIP stream makes the runtime allocate that
-    # queue's scratch (~1.3 KB per lane for every wave slot of the device).  A 256-case launch per context
-    # pays for that here, so that the W warm-up steps and the K timed steps see the same steady state no
-    # matter how W compares with the number of contexts.
+    # Context set-up, not a step: every context reserves its device memory for a full batch (eh_reserve) and
+    # runs one untimed full-size pass on its own HIP stream, which makes the runtime allocate that queue's
+    # scratch for the full grid.  Otherwise the first pass of a context (32 GiB of hipMalloc plus the
+    # queue's scratch) would land inside the timed region whenever W is smaller than the number of contexts.
+    for e in engines:
+        e.reserve(n)
     for e, st in zip(engines, streams):
-        e.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=min(256, n), stream=st.cuda_stream)
+        e.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=n, stream=st.cuda_stream)
     for e in engines:
         e.sync()
 
@@ -188,7 +190,7 @@ def main():
                                "10% length/CRC-framed)" if args.corpus == "mixed" else "uniform random bytes",
                                pats, muts, len(muts.split(",")), nmut_total,
                                ",".join(m for m, _, _ in ea.mutator_table() if m not in muts.split(","))),
-                "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "one 256-case launch per context/stream before warm-up (scratch allocation)",
+                "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream before the W warm-up steps",
                 "max_case_bytes": args.case_mib << 20, "max_case_work": args.work_mib << 20,
             },
             "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(max_case_bytes)", "unsupported", "arena_full",

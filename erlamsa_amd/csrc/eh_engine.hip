@@ -784,13 +784,13 @@ static int ensure_results(eh_ctx* ctx, uint64_t n) {
   return EH_OK;
 }
 
-static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_case, uint64_t corpus_first, uint64_t n, hipStream_t st) {
-  if (!ctx->configured || !ctx->d_corpus) { ctx->err = "configure and load a corpus first"; return EH_E_STATE; }
-  if (corpus_first + n > ctx->n_corpus || (mode == 0 && first_case < 1)) { ctx->err = "case range outside the corpus"; return EH_E_INVALID; }
+// Device memory for batches of up to `n` cases over `in_bytes` input bytes: result arrays, per-slot work
+// areas, output arena.  Buffers only ever grow, so after eh_reserve (or a first batch of the largest
+// size) no launch allocates or frees — hipFree synchronises the whole device.
+static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc = ensure_results(ctx, n ? n : 1);
   if (rc) return rc;
-  // slots
   uint32_t want_slots = ctx->max_slots_opt ? ctx->max_slots_opt : (uint32_t)ctx->cus * 16u;
   if (want_slots > n) want_slots = (uint32_t)(n ? n : 1);
   uint64_t work_cap = ctx->max_case_bytes ? ctx->max_case_bytes : (8ull << 20);
@@ -802,9 +802,6 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
     HIPCHK(ctx, hipMalloc(&ctx->d_slots, stride * want_slots));
     ctx->nslots = want_slots; ctx->work_cap = work_cap; ctx->slot_stride = stride;
   }
-  // output arena
-  uint64_t in_bytes = 0;
-  if (!ctx->h_coff.empty()) in_bytes = ctx->h_coff[corpus_first + n] - ctx->h_coff[corpus_first];
   uint64_t want_out = ctx->out_capacity_opt ? ctx->out_capacity_opt : (8 * (in_bytes ? in_bytes : ctx->corpus_bytes) + (1024ull << 20));
   if (!ctx->d_out || ctx->out_cap < want_out) {
     if (ctx->d_out) (void)hipFree(ctx->d_out);
@@ -812,6 +809,17 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
     HIPCHK(ctx, hipMalloc(&ctx->d_out, want_out));
     ctx->out_cap = want_out;
   }
+  return EH_OK;
+}
+
+static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_case, uint64_t corpus_first, uint64_t n, hipStream_t st) {
+  if (!ctx->configured || !ctx->d_corpus) { ctx->err = "configure and load a corpus first"; return EH_E_STATE; }
+  if (corpus_first + n > ctx->n_corpus || (mode == 0 && first_case < 1)) { ctx->err = "case range outside the corpus"; return EH_E_INVALID; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  uint64_t in_bytes = 0;
+  if (!ctx->h_coff.empty()) in_bytes = ctx->h_coff[corpus_first + n] - ctx->h_coff[corpus_first];
+  int rc = reserve(ctx, n, in_bytes);
+  if (rc) return rc;
   if (!ctx->d_counters) { HIPCHK(ctx, hipMalloc(&ctx->d_counters, 4096)); HIPCHK(ctx, hipMalloc(&ctx->d_run, sizeof(RunState))); }
   HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 4096, st));
 
@@ -988,6 +996,12 @@ int eh_corpus_attach(eh_ctx* ctx, const void* d_data, const void* d_off, uint64_
   HIPCHK(ctx, hipMemcpy(ctx->h_coff.data(), d_off, (n + 1) * 8, hipMemcpyDeviceToHost));
   if (ctx->h_coff[n] != nbytes) { ctx->err = "off[n] != nbytes"; return EH_E_INVALID; }
   return set_corpus(ctx, (uint8_t*)d_data, (uint64_t*)d_off, false, n, nbytes);
+}
+
+int eh_reserve(eh_ctx* ctx, uint64_t max_cases) {
+  if (!ctx) return EH_E_INVALID;
+  if (!ctx->configured || !ctx->d_corpus) { ctx->err = "configure and load a corpus first"; return EH_E_STATE; }
+  return reserve(ctx, max_cases, 0);
 }
 
 int eh_fuzz_batch(eh_ctx* ctx, const int64_t seed[3], uint64_t first_case, uint64_t corpus_first, uint64_t n, void* stream) {

@@ -20,7 +20,7 @@ CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BU
 # every symbol include/erlamsa_hip.h declares
 ABI_SYMBOLS = [
     "eh_create", "eh_destroy", "eh_configure", "eh_corpus_upload", "eh_corpus_attach", "eh_fuzz_batch",
-    "eh_fuzz_calls", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_prof", "eh_selftest_movers",
+    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_prof", "eh_selftest_movers",
     "eh_last_kernel_ms", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
@@ -61,6 +61,7 @@ def load_library():
     lib.eh_fuzz_batch.argtypes = [vp, i64p, C.c_uint64, C.c_uint64, C.c_uint64, vp]
     lib.eh_fuzz_calls.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp]
     lib.eh_sync.argtypes = [vp]
+    lib.eh_reserve.argtypes = [vp, C.c_uint64]
     lib.eh_result_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u64p]
     lib.eh_result_download.argtypes = [vp, vp, C.c_uint64, vp, vp]
     lib.eh_result_totals.argtypes = [vp, u64p, u64p, u64p]
@@ -169,6 +170,9 @@ class Engine:
         n = seeds.size // 3
         self._chk(self.lib.eh_fuzz_calls(self.h, seeds.ctypes.data, corpus_first, n, C.c_void_p(stream)))
         self.last_n = n
+
+    def reserve(self, max_cases):
+        self._chk(self.lib.eh_reserve(self.h, max_cases))
 
     def sync(self):
         self._chk(self.lib.eh_sync(self.h))

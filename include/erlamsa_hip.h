@@ -96,6 +96,13 @@ int eh_corpus_upload(eh_ctx* ctx, const uint8_t* data, const uint64_t* off, uint
  * broadcast); the engine does not take ownership. */
 int eh_corpus_attach(eh_ctx* ctx, const void* d_data, const void* d_off, uint64_t n, uint64_t nbytes);
 
+/* Allocates all device memory batches of up to `max_cases` cases will need (result arrays, per-slot work
+ * areas, output arena sized from eh_options.out_capacity or 8 x corpus bytes + 1 GiB), so that later
+ * eh_fuzz_batch / eh_fuzz_calls launches never allocate or free.  Optional: the first batch does the same
+ * on demand.  Reference counterpart: none (BEAM allocates per worker process); it exists because
+ * erlamsa_fsupervisor-style services want a flat first-request latency. */
+int eh_reserve(eh_ctx* ctx, uint64_t max_cases);
+
 /* Case i of this call (0 <= i < n) mutates corpus entry corpus_first + i and is case number
  * first_case + i (1-based) of a fuzzer/1 run seeded with `seed`.  Results do not depend on how
  * a run is cut into calls, GPUs or streams.  `stream` is a hipStream_t (NULL = default
