@@ -202,7 +202,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
         # ---- CPU baseline: the oracle (C++ restatement of the reference) on a bounded sample, 1 thread
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle as po
             # chunks of 512 cases (case numbers 1.., same corpus rows) until the time bound is reached
