@@ -5,7 +5,7 @@
  *      -L../../erlamsa_amd -lerlamsa_hip -o ../priv/erlamsa_hip_nif.so
  *
  * Exposes erlamsa_hip:fuzz_batch_nif(Opts :: map(), Seed :: {A,B,C}, FirstCase, [binary()])
- *   -> {ok, [{Status :: 0..4, binary()}]} | {error, Reason}
+ *   -> {ok, [{Status :: 0..5, binary()}]} | {error, Reason}   (status: enum eh_case_status)
  * It runs on a dirty I/O scheduler: one call = one GPU batch.
  */
 #include <erl_nif.h>
@@ -66,6 +66,9 @@ static ERL_NIF_TERM nif_fuzz_batch(ErlNifEnv* env, int argc, const ERL_NIF_TERM 
   if (get_str(env, argv[1], "ssrf_host", host, sizeof(host))) o.ssrf_host = host;
   if (enif_get_map_value(env, argv[1], enif_make_atom(env, "ssrf_port"), &v)) enif_get_int(env, v, &port);
   if (enif_get_map_value(env, argv[1], enif_make_atom(env, "blockscale"), &v)) enif_get_double(env, v, &bs);
+  ErlNifUInt64 u64;
+  if (enif_get_map_value(env, argv[1], enif_make_atom(env, "max_case_bytes"), &v) && enif_get_uint64(env, v, &u64)) o.max_case_bytes = u64;
+  if (enif_get_map_value(env, argv[1], enif_make_atom(env, "max_case_work"), &v) && enif_get_uint64(env, v, &u64)) o.max_case_work = u64;
   o.ssrf_port = port; o.blockscale = bs;
   int rc = eh_configure(r->ctx, &o);
   if (rc) return mk_error(env, r->ctx, rc);

@@ -80,3 +80,16 @@ def test_host_helpers():
         assert sum(c for _, c in got) == n
         assert all(got[i][0] + got[i][1] == got[i + 1][0] for i in range(w - 1))
     assert shard.weak_first_case(0, 0, 8, 100) == 1 and shard.weak_first_case(1, 2, 8, 100) == 1001
+
+
+def test_erlang_nif_shim_compiles_against_the_header():
+    """erlang/c_src/erlamsa_hip_nif.c is the reference-side binding INTEGRATION.md describes.  There is no
+    OTP in this image, so it is compile-checked (syntax + types against include/erlamsa_hip.h) with a
+    stand-in erl_nif.h that declares only the documented NIF API functions the shim uses."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
+                        "-I", os.path.join(root, "tests", "stubs"), "-I", os.path.join(root, "include"),
+                        os.path.join(root, "erlang", "c_src", "erlamsa_hip_nif.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
