@@ -169,12 +169,14 @@ EH_DEV void wave_move_down(uint8_t* dst, const uint8_t* src, uint32_t n) {
     uint4 v[4]; bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) { uint32_t i = base + 64u * u + (uint32_t)l; ok[u] = i < nv; if (ok[u]) __builtin_memcpy(&v[u], src + 16 * (size_t)i, 16); }
+    wave_sync();                                     // every lane has loaded its 4 chunks before any lane stores
 #pragma unroll
     for (int u = 0; u < 4; u++) { uint32_t i = base + 64u * u + (uint32_t)l; if (ok[u]) __builtin_memcpy(dst + 16 * (size_t)i, &v[u], 16); }
   }
   uint32_t done = nv << 4;
   uint8_t t = 0; bool tk = done + (uint32_t)l < n;
   if (tk) t = src[done + l];
+  wave_sync();
   if (tk) dst[done + l] = t;
 }
 // dst[i] = pat[i % plen], i < total.  The first copy is written directly, the rest by doubling

@@ -19,48 +19,123 @@ struct FuseSide {
   uint32_t* pos;                      // suffix start positions (len == empty suffix), grouped by node
   uint32_t* node;                     // node index of every entry
   uint32_t n;                         // live entries
-  Key2* keys;                         // sort buffer (capacity cap2)
+  Key2* keys;                         // entries in group order: hi = group key << 32 | ..., lo = next position
+  uint32_t* gid;                      // group index of every sorted entry
   uint32_t* bstart;                   // group starts in sorted order (+1 sentinel)
   uint64_t* bkey;                     // group key = (nn-1-node) << 8 | (255-byte)
   uint32_t* bcnt;                     // group size after fix_empty_list
+  uint32_t* child;                    // child node built from this group (or NONE)
   uint32_t nb;
 };
+constexpr uint32_t FUSE_NONE = 0xFFFFFFFFu, FUSE_SPECIAL = 0xFFFFFFFEu;
 
-// keys + sort + grouping for one side.  Returns false on allocation problems.
-EH_DEV void fuse_group(FuseSide& x, uint32_t nn) {
-  const int l = EH_LANE;
-  uint32_t np2 = 64; while (np2 < x.n) np2 <<= 1;
-  for (uint32_t i = l; i < np2; i += 64) {
-    Key2 k; k.hi = ~(uint64_t)0; k.lo = 0;
-    if (i < x.n) {
-      uint32_t p = x.pos[i];
-      if (p < x.len) {                                           // ([], Subs) -> Subs : the empty suffix drops out
-        k.hi = ((uint64_t)(nn - 1 - x.node[i]) << 40) | ((uint64_t)(255u - x.s[p]) << 32) | (uint64_t)(x.n - 1 - i);
-        k.lo = p + 1;
-      }
+// ascending bitonic sort of one 32-bit key per lane
+EH_DEV uint32_t wave_sort64(uint32_t key) {
+  const uint32_t l = (uint32_t)EH_LANE;
+#pragma unroll
+  for (uint32_t k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+    for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+      uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j);
+      bool up = (l & k2) == 0 || k2 == 64, lower = (l & j) == 0;
+      bool take_min = lower == up;
+      uint32_t mn = key < other ? key : other, mx = key < other ? other : key;
+      key = take_min ? mn : mx;
     }
-    x.keys[i] = k;
   }
-  wave_sort_key2(x.keys, np2);
-  // group boundaries: (hi >> 32) changes; invalid keys (hi == ~0) sort last
-  uint32_t nb = 0;
-  for (uint32_t base = 0; base < np2; base += 64) {
+  return key;
+}
+
+// Orders the live suffixes of one side the way the reference's prepending builds its groups and node
+// list — descending (node, next byte, list index), the empty suffix dropped (`([], Subs) -> Subs`) —
+// and cuts them into groups.  The entries arrive grouped by node (seg[k]..seg[k+1]), so this is a stable
+// counting sort by the next byte inside every segment, mirrored: segments of more than 64 entries use
+// a 256-bin histogram in the work area (ballot match for the stable ranks), smaller ones are packed up
+// to 64 segments per step and ordered by a register bitonic network.  (A full comparison sort of
+// 128-bit keys per round cost ~10 ms per fuse call.)
+EH_DEV void fuse_group(FuseSide& x, uint32_t nn, const uint32_t* seg, uint32_t* hist) {
+  const int l = EH_LANE;
+  uint32_t nvalid = 0;
+  for (uint32_t base = 0; base < x.n; base += 64) {
     uint32_t i = base + (uint32_t)l;
-    uint64_t h = x.keys[i].hi;
-    bool valid = h != ~(uint64_t)0;
+    nvalid += (uint32_t)__popcll(__ballot(i < x.n && x.pos[i] < x.len));
+  }
+  auto put = [&](uint32_t asc, uint32_t nd, uint32_t b, uint32_t idx, uint32_t p) {
+    uint32_t d = nvalid - 1 - asc;
+    x.keys[d].hi = ((uint64_t)(nn - 1 - nd) << 40) | ((uint64_t)(255u - b) << 32) | (uint64_t)(x.n - 1 - idx);
+    x.keys[d].lo = p + 1;
+  };
+  uint32_t vbase = 0, k = 0;
+  while (k < nn) {
+    uint32_t s0 = uni(seg[k]);
+    uint32_t kk = k + (uint32_t)l + 1;
+    uint32_t myend = kk <= nn ? seg[kk] : 0xFFFFFFFFu;
+    bool fits = kk <= nn && myend - s0 <= 64;
+    unsigned long long fm = __ballot(fits);
+    uint32_t nfit = fm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fm);       // offsets ascend: `fits` is a prefix
+    if (nfit > 0) {
+      uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)myend, (int)(nfit - 1)) - s0;
+      uint32_t i = s0 + (uint32_t)l; bool in = (uint32_t)l < cnt;
+      uint32_t p = in ? x.pos[i] : 0u; bool v = in && p < x.len;
+      uint32_t nd = in ? x.node[i] : 0u;
+      uint32_t b = v ? (uint32_t)x.s[p] : 0u;
+      uint32_t key = v ? (((nd - k) << 14) | (b << 6) | (uint32_t)l) : 0xFFFFFFFFu;
+      uint32_t sk = wave_sort64(key);
+      bool sv = sk != 0xFFFFFFFFu;
+      uint32_t ol = sk & 63u;
+      uint32_t sp = (uint32_t)__shfl((int)p, (int)ol), snd = (uint32_t)__shfl((int)nd, (int)ol);
+      if (sv) put(vbase + (uint32_t)l, snd, (sk >> 6) & 255u, s0 + ol, sp);
+      vbase += (uint32_t)__popcll(__ballot(sv));
+      k += nfit;
+      continue;
+    }
+    // one big segment
+    uint32_t e0 = uni(seg[k + 1]);
+    for (uint32_t b = (uint32_t)l; b < 256; b += 64) hist[b] = 0;
+    wave_sync();
+    for (uint32_t base = s0; base < e0; base += 64) {
+      uint32_t i = base + (uint32_t)l;
+      if (i < e0) { uint32_t p = x.pos[i]; if (p < x.len) atomicAdd(&hist[x.s[p]], 1u); }
+    }
+    wave_sync();
+    uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+    uint32_t sum = h0 + h1 + h2 + h3, inc = wave_incl_scan(sum), exc = inc - sum;
+    uint32_t segvalid = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    wave_sync();
+    hist[4 * l] = exc; hist[4 * l + 1] = exc + h0; hist[4 * l + 2] = exc + h0 + h1; hist[4 * l + 3] = exc + h0 + h1 + h2;
+    wave_sync();
+    for (uint32_t base = s0; base < e0; base += 64) {
+      uint32_t i = base + (uint32_t)l; bool in = i < e0;
+      uint32_t p = in ? x.pos[i] : 0u; bool v = in && p < x.len;
+      uint32_t b = v ? (uint32_t)x.s[p] : 0u;
+      unsigned long long eq = __ballot(v);                        // lanes holding the same byte as me
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) { unsigned long long m = __ballot(v && ((b >> bit) & 1u)); eq &= ((b >> bit) & 1u) ? m : ~m; }
+      uint32_t rank = (uint32_t)__popcll(eq & ((1ull << l) - 1)), cntg = (uint32_t)__popcll(eq);
+      uint32_t off = v ? hist[b] : 0u;
+      wave_sync();                                                // every lane has read its bin before the group leaders bump them
+      if (v && rank == 0) hist[b] = off + cntg;
+      wave_sync();
+      if (v) put(vbase + off + rank, k, b, i, p);
+    }
+    vbase += segvalid;
+    k += 1;
+  }
+  wave_sync();
+  // group boundaries: (hi >> 32) changes
+  uint32_t nb = 0;
+  for (uint32_t base = 0; base < nvalid; base += 64) {
+    uint32_t i = base + (uint32_t)l;
+    bool valid = i < nvalid;
+    uint64_t h = valid ? x.keys[i].hi : 0;
     bool start = valid && (i == 0 || (x.keys[i - 1].hi >> 32) != (h >> 32));
     unsigned long long m = __ballot(start);
-    uint32_t before = (uint32_t)__popcll(m & ((1ull << l) - 1));
-    if (start) { x.bstart[nb + before] = i; x.bkey[nb + before] = h >> 32; }
+    uint32_t upto = (uint32_t)__popcll(m & ((2ull << l) - 1));    // group starts at or before me
+    if (start) { x.bstart[nb + upto - 1] = i; x.bkey[nb + upto - 1] = h >> 32; }
+    if (valid) x.gid[i] = nb + upto - 1;
     nb += (uint32_t)__popcll(m);
-    unsigned long long vm = __ballot(valid);
-    if (vm != ~0ull) {                                            // end of the valid prefix
-      uint32_t nvalid = base + (uint32_t)__popcll(vm);
-      if (l == 0) x.bstart[nb] = nvalid;
-      break;
-    }
-    if (base + 64 >= np2 && l == 0) x.bstart[nb] = np2;
   }
+  if (l == 0) x.bstart[nb] = nvalid;
   wave_sync();
   x.nb = nb;
   // fix_empty_list (:58-60): a group whose LAST element (first one inserted) is the empty tail loses it
@@ -69,6 +144,7 @@ EH_DEV void fuse_group(FuseSide& x, uint32_t nn) {
     uint32_t cnt = b - a;
     if (cnt > 0 && (uint32_t)x.keys[b - 1].lo == x.len) cnt--;
     x.bcnt[j] = cnt;
+    x.child[j] = FUSE_NONE;
   }
   wave_sync();
 }
@@ -81,24 +157,21 @@ EH_DEV bool fuse_lists(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, 
   uint64_t mark = c.ws_used;
   FuseSide f, t;
   uint32_t capf = la + 2, capt = lb + 2;
-  uint32_t np2f = 64; while (np2f < capf) np2f <<= 1;
-  uint32_t np2t = 64; while (np2t < capt) np2t <<= 1;
   f.s = A; f.len = la; t.s = B; t.len = lb;
-  f.pos = (uint32_t*)ws_alloc(c, (uint64_t)capf * 4); f.node = (uint32_t*)ws_alloc(c, (uint64_t)capf * 4);
-  t.pos = (uint32_t*)ws_alloc(c, (uint64_t)capt * 4); t.node = (uint32_t*)ws_alloc(c, (uint64_t)capt * 4);
-  uint32_t* f2 = (uint32_t*)ws_alloc(c, (uint64_t)capf * 4); uint32_t* fn2 = (uint32_t*)ws_alloc(c, (uint64_t)capf * 4);
-  uint32_t* t2 = (uint32_t*)ws_alloc(c, (uint64_t)capt * 4); uint32_t* tn2 = (uint32_t*)ws_alloc(c, (uint64_t)capt * 4);
-  f.keys = (Key2*)ws_alloc(c, (uint64_t)np2f * sizeof(Key2)); t.keys = (Key2*)ws_alloc(c, (uint64_t)np2t * sizeof(Key2));
-  f.bstart = (uint32_t*)ws_alloc(c, (uint64_t)(capf + 1) * 4); t.bstart = (uint32_t*)ws_alloc(c, (uint64_t)(capt + 1) * 4);
+  auto u32 = [&](uint64_t n) { return (uint32_t*)ws_alloc(c, n * 4); };
+  f.pos = u32(capf); f.node = u32(capf); t.pos = u32(capt); t.node = u32(capt);
+  uint32_t* f2 = u32(capf); uint32_t* fn2 = u32(capf); uint32_t* t2 = u32(capt); uint32_t* tn2 = u32(capt);
+  f.keys = (Key2*)ws_alloc(c, (uint64_t)capf * sizeof(Key2)); t.keys = (Key2*)ws_alloc(c, (uint64_t)capt * sizeof(Key2));
+  f.gid = u32(capf); t.gid = u32(capt);
+  f.bstart = u32(capf + 1); t.bstart = u32(capt + 1);
   f.bkey = (uint64_t*)ws_alloc(c, (uint64_t)capf * 8); t.bkey = (uint64_t*)ws_alloc(c, (uint64_t)capt * 8);
-  f.bcnt = (uint32_t*)ws_alloc(c, (uint64_t)capf * 4); t.bcnt = (uint32_t*)ws_alloc(c, (uint64_t)capt * 4);
+  f.bcnt = u32(capf); t.bcnt = u32(capt); f.child = u32(capf); t.child = u32(capt);
   // node table: per node start/count in pos arrays (current and next)
   uint32_t capn = capf;                                            // every node owns >= 1 source entry
-  uint32_t* nfs = (uint32_t*)ws_alloc(c, (uint64_t)(capn + 1) * 4); uint32_t* nts = (uint32_t*)ws_alloc(c, (uint64_t)(capn + 1) * 4);
-  uint32_t* nfs2 = (uint32_t*)ws_alloc(c, (uint64_t)(capn + 1) * 4); uint32_t* nts2 = (uint32_t*)ws_alloc(c, (uint64_t)(capn + 1) * 4);
-  uint32_t* cflag = (uint32_t*)ws_alloc(c, (uint64_t)capn * 4); uint32_t* cmatch = (uint32_t*)ws_alloc(c, (uint64_t)capn * 4);
-  if (!f.pos || !f.node || !t.pos || !t.node || !f2 || !fn2 || !t2 || !tn2 || !f.keys || !t.keys || !f.bstart || !t.bstart || !f.bkey ||
-      !t.bkey || !f.bcnt || !t.bcnt || !nfs || !nts || !nfs2 || !nts2 || !cflag || !cmatch) return false;
+  uint32_t* nfs = u32(capn + 1); uint32_t* nts = u32(capn + 1); uint32_t* nfs2 = u32(capn + 1); uint32_t* nts2 = u32(capn + 1);
+  uint32_t* cmatch = u32(capn); uint32_t* hist = u32(256);
+  if (!f.pos || !f.node || !t.pos || !t.node || !f2 || !fn2 || !t2 || !tn2 || !f.keys || !t.keys || !f.gid || !t.gid || !f.bstart ||
+      !t.bstart || !f.bkey || !t.bkey || !f.bcnt || !t.bcnt || !f.child || !t.child || !nfs || !nts || !nfs2 || !nts2 || !cmatch || !hist) return false;
   // find_jump_points (:103-107): one node with all non-empty suffixes of both lists
   for (uint32_t i = l; i < la; i += 64) { f.pos[i] = i; f.node[i] = 0; }
   for (uint32_t i = l; i < lb; i += 64) { t.pos[i] = i; t.node[i] = 0; }
@@ -110,17 +183,17 @@ EH_DEV bool fuse_lists(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, 
   while (true) {                                                   // find_jump_points_loop (:115-128)
     if (fuel < 0) break;
     if (rng_rand(c.rng, 8) == 0) break;                            // ?SEARCH_STOP_IP
-    fuse_group(f, nn);
-    fuse_group(t, nn);
-    // children, in the order of the sorted source groups: a group with no elements left is the
-    // special node {[[]], [[]]}; otherwise it needs a target group with the same (node, byte)
+    fuse_group(f, nn, nfs, hist);
+    fuse_group(t, nn, nts, hist);
+    // children, in the order of the source groups: a group with no elements left is the special node
+    // {[[]], [[]]}; otherwise it needs a target group with the same (node, byte)
     uint32_t nchild = 0, newf = 0, newt = 0;
     for (uint32_t base = 0; base < f.nb; base += 64) {
       uint32_t j = base + (uint32_t)l;
-      bool child = false; uint32_t fc = 0, tc = 0, tj = 0xFFFFFFFFu;
+      bool child = false; uint32_t fc = 0, tc = 0, tj = FUSE_NONE;
       if (j < f.nb) {
         fc = f.bcnt[j];
-        if (fc == 0) { child = true; fc = 1; tc = 1; tj = 0xFFFFFFFEu; }        // [[[[]], []] | Tl]
+        if (fc == 0) { child = true; fc = 1; tc = 1; tj = FUSE_SPECIAL; }           // [[[[]], []] | Tl]
         else {
           uint64_t key = f.bkey[j];
           uint32_t lo = 0, hi = t.nb;                              // binary search (ascending keys)
@@ -132,29 +205,26 @@ EH_DEV bool fuse_lists(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, 
       uint32_t ci = child ? 1u : 0u, fi = child ? fc : 0u, ti = child ? tc : 0u;
       uint32_t cs = wave_incl_scan(ci), fs = wave_incl_scan(fi), ts = wave_incl_scan(ti);
       if (child) {
-        uint32_t k = nchild + cs - 1, fo = newf + fs - fi, to = newt + ts - ti;
-        nfs2[k] = fo; nts2[k] = to; cflag[k] = j; cmatch[k] = tj;
+        uint32_t kc = nchild + cs - 1;
+        nfs2[kc] = newf + fs - fi; nts2[kc] = newt + ts - ti; cmatch[kc] = tj;
+        if (tj != FUSE_SPECIAL) { f.child[j] = kc; t.child[tj] = kc; }
       }
       nchild += uni((uint32_t)__shfl((int)cs, 63)); newf += uni((uint32_t)__shfl((int)fs, 63)); newt += uni((uint32_t)__shfl((int)ts, 63));
     }
     if (l == 0) { nfs2[nchild] = newf; nts2[nchild] = newt; }
     wave_sync();
     if (nchild == 0) break;                                        // NoDesp =:= [] -> any_position_pair(Nodes)
-    // materialise the children's suffix lists (one lane per child)
-    for (uint32_t base = 0; base < nchild; base += 64) {
-      uint32_t k = base + (uint32_t)l;
-      if (k < nchild) {
-        uint32_t j = cflag[k], tj = cmatch[k];
-        uint32_t fo = nfs2[k], fcnt = nfs2[k + 1] - fo, to = nts2[k], tcnt = nts2[k + 1] - to;
-        if (tj == 0xFFFFFFFEu) { f2[fo] = la; fn2[fo] = k; t2[to] = lb; tn2[to] = k; }
-        else {
-          uint32_t fa = f.bstart[j];
-          for (uint32_t i = 0; i < fcnt; i++) { f2[fo + i] = (uint32_t)f.keys[fa + i].lo; fn2[fo + i] = k; }
-          uint32_t ta = t.bstart[tj];
-          for (uint32_t i = 0; i < tcnt; i++) { t2[to + i] = (uint32_t)t.keys[ta + i].lo; tn2[to + i] = k; }
-        }
-      }
+    // the children's suffix lists are the surviving groups in the same order: a compaction
+    for (uint32_t i = (uint32_t)l; i < f.bstart[f.nb]; i += 64) {
+      uint32_t g = f.gid[i], kc = f.child[g];
+      if (kc != FUSE_NONE) { uint32_t o = i - f.bstart[g]; if (o < f.bcnt[g]) { f2[nfs2[kc] + o] = (uint32_t)f.keys[i].lo; fn2[nfs2[kc] + o] = kc; } }
     }
+    for (uint32_t i = (uint32_t)l; i < t.bstart[t.nb]; i += 64) {
+      uint32_t g = t.gid[i], kc = t.child[g];
+      if (kc != FUSE_NONE) { uint32_t o = i - t.bstart[g]; if (o < t.bcnt[g]) { t2[nts2[kc] + o] = (uint32_t)t.keys[i].lo; tn2[nts2[kc] + o] = kc; } }
+    }
+    for (uint32_t kc = (uint32_t)l; kc < nchild; kc += 64)
+      if (cmatch[kc] == FUSE_SPECIAL) { f2[nfs2[kc]] = la; fn2[nfs2[kc]] = kc; t2[nts2[kc]] = lb; tn2[nts2[kc]] = kc; }
     wave_sync();
     // swap generations
     { uint32_t* tmp; tmp = f.pos; f.pos = f2; f2 = tmp; tmp = f.node; f.node = fn2; fn2 = tmp; tmp = t.pos; t.pos = t2; t2 = tmp; tmp = t.node; t.node = tn2; tn2 = tmp;
