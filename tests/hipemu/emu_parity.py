@@ -25,13 +25,20 @@ def main():
     assert "emu" in os.environ.get("ERLAMSA_HIP_LIB", ""), "point ERLAMSA_HIP_LIB at the emulator build"
     inputs = util.corpus_uniform(n, size) if kind == "uniform" else util.corpus_mixed(n, size)
     data, off = po.pack(inputs)
-    want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=muts, patterns=pats, max_case_bytes=1 << 20,
+    per_call = os.environ.get("EMU_PER_CALL") == "1"                 # eh_fuzz_calls: one seed per case
+    seeds = None
+    if per_call:
+        seeds = np.random.Generator(np.random.PCG64(seed[0])).integers(0, 99999, size=(n, 3)).astype(np.int64) + 1
+    want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, seeds=seeds, mutations=muts, patterns=pats, max_case_bytes=4 << 20,
                                        max_case_work=8 << 20, trace=True)
     t = time.time()
     eng = ea.Engine(0)
     eng.configure(mutations=muts, patterns=pats, max_case_bytes=4 << 20, max_case_work=8 << 20)
     eng.upload_corpus(data, off)
-    eng.fuzz_batch(seed=seed)
+    if per_call:
+        eng.fuzz_calls(seeds)
+    else:
+        eng.fuzz_batch(seed=seed)
     got, gst = eng.download()
     gdr, _ = eng.diag()
     dt = time.time() - t

@@ -22,8 +22,8 @@ def emu_lib():
     return build_emu.build()
 
 
-def _run(lib, *args):
-    env = dict(os.environ, ERLAMSA_HIP_LIB=lib)
+def _run(lib, *args, per_call=False):
+    env = dict(os.environ, ERLAMSA_HIP_LIB=lib, EMU_PER_CALL="1" if per_call else "0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_parity.py")] + [str(a) for a in args],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -39,3 +39,7 @@ def test_emulated_production_set_on_mixed_corpus(emu_lib):
 
 def test_emulated_all_patterns_and_fuse(emu_lib):
     _run(emu_lib, PROD + ",ft,fn,fo", "od,nd,bu,sk,sz,cs,ar,cp,co,nu", 32, 512, "mixed", "5,6,7")
+
+
+def test_emulated_per_call_seeds(emu_lib):
+    _run(emu_lib, "bd,bf,bi,sr,sd,num,ld,lr,tr2,ab,uw,len", "od,nd,bu", 48, 512, "mixed", per_call=True)

@@ -261,3 +261,31 @@ def test_results_do_not_depend_on_slot_count_or_batch_cut():
     d2, s2 = run(256, [0, 5000, 5001, n])
     assert s1 == s2
     assert d1 == d2
+
+
+def test_per_call_seeds_mode():
+    """eh_fuzz_calls: every case is its own fuzzer/1 run with its own seed — what erlamsa_esi:call_fuzzer/3
+    does per HTTP request (erlamsa_app:fuzz(Bin, #{seed => S}))."""
+    import pyoracle as po
+    n = 600
+    inputs = util.corpus_mixed(n, 512, seed=21)
+    data, off = po.pack(inputs)
+    rng = np.random.Generator(np.random.PCG64(9))
+    seeds = rng.integers(0, 99999, size=(n, 3)).astype(np.int64) + 1
+    seeds[0] = (0, 0, 0); seeds[1] = (30268, 30306, 30322); seeds[2] = (-5, 7, -9)
+    muts = "bd,bf,bi,sr,sd,num,ld,lr,tr2,ab,uw,len"
+    ora = util.oracle_batch(data, off, seeds=seeds, mutations=muts, patterns="od,nd,bu", max_case_bytes=8 << 20, max_case_work=8 << 20)
+    if util.priming():
+        pytest.skip("oracle cache primed")
+    import erlamsa_amd as ea
+    eng = ea.Engine(0)
+    eng.configure(mutations=muts, patterns="od,nd,bu", max_case_bytes=8 << 20, max_case_work=8 << 20)
+    eng.upload_corpus(data, off)
+    eng.fuzz_calls(seeds)
+    got, gst = eng.download()
+    gdr, _ = eng.diag()
+    eng.close()
+    cmp = [i for i in range(n) if gst[i] not in (2, 3) and ora.status[i] not in (2, 3)]
+    assert len(cmp) >= 0.97 * n
+    bad = [i for i in cmp if gst[i] != ora.status[i] or not ora.same(i, got[i]) or (gst[i] == 0 and gdr[i] != ora.draws[i])]
+    assert not bad, "cases differ: %s" % bad[:10]

@@ -136,7 +136,8 @@ def oracle_batch(data, off, live=False, **kw):
     h = hashlib.sha1()
     h.update(_oracle_hash().encode())
     h.update(np.ascontiguousarray(data).tobytes()); h.update(np.ascontiguousarray(off).tobytes())
-    h.update(repr(sorted((k, str(v)) for k, v in kw.items())).encode())
+    h.update(repr(sorted((k, hashlib.sha1(np.ascontiguousarray(v).tobytes()).hexdigest() if isinstance(v, np.ndarray) else str(v))
+                         for k, v in kw.items())).encode())
     path = os.path.join(_CACHE_DIR, h.hexdigest() + ".npz")
     if not live and os.path.exists(path):
         z = np.load(path, allow_pickle=False)
