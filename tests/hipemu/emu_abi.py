@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Host-side behaviour of the C ABI (call order, error codes, option parsing, buffer growth, result
+accessors) exercised on the CPU emulator build.  Run by tests/test_emulated_kernel.py in a subprocess."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import pyoracle as po
+import util
+import erlamsa_amd as ea
+from erlamsa_amd.engine import EngineError
+
+assert "emu" in os.environ.get("ERLAMSA_HIP_LIB", "")
+
+
+def code(f, *a, **k):
+    try:
+        f(*a, **k)
+    except EngineError as e:
+        return e.code
+    return 0
+
+
+eng = ea.Engine(0)
+# call order: nothing configured / no corpus yet
+assert code(eng.fuzz_batch, seed=(1, 2, 3), n=1) == -5                       # EH_E_STATE
+eng.configure(mutations="bd,bf", patterns="od")
+assert code(eng.fuzz_batch, seed=(1, 2, 3), n=1) == -5                       # still no corpus
+# option parsing follows erlamsa_cmdparse: unknown names, bad priorities, names the build cannot run
+assert code(eng.configure, mutations="bd,nosuch") == -1                      # EH_E_INVALID
+assert code(eng.configure, patterns="xx") == -1
+assert code(eng.configure, mutations="sgm") == -6                            # EH_E_UNSUPPORTED (not on the GPU yet)
+assert code(eng.configure, mutations="js,bd") == -6
+eng.configure(mutations="bd=3,bf,bi=7", patterns="od,nd=2", generators="direct=500,random=1")
+inputs = util.corpus_uniform(40, 200)
+data, off = po.pack(inputs)
+eng.upload_corpus(data, off)
+# ranges
+assert code(eng.fuzz_batch, seed=(1, 2, 3), corpus_first=30, n=20) == -1     # outside the corpus
+assert code(eng.fuzz_batch, seed=(1, 2, 3), first_case=0) == -1              # case numbers are 1-based
+# a batch, then a smaller one, then a bigger one after reserve: buffers only grow, results stay right
+want, wst, _, _ = po.fuzz_batch(data, off, seed=(1, 2, 3), mutations="bd=3,bf,bi=7", patterns="od,nd=2", generators="direct=500,random=1")
+eng.fuzz_batch(seed=(1, 2, 3), n=8)
+g8, s8 = eng.download()
+assert g8 == want[:8] and list(s8) == list(wst[:8])
+eng.reserve(40)
+eng.fuzz_batch(seed=(1, 2, 3))
+g, s = eng.download()
+assert g == want and list(s) == list(wst)
+inb, outb, nc = eng.totals()
+assert nc == 40 and inb == 40 * 200 and outb == sum(map(len, want))
+# a sub-range with the matching first_case reproduces the same cases
+eng.fuzz_batch(seed=(1, 2, 3), first_case=11, corpus_first=10, n=5)
+g5, _ = eng.download()
+assert g5 == want[10:15]
+# empty corpus entries and an empty batch
+e2 = ea.Engine(0)
+e2.configure(mutations="bd,sr,ld", patterns="od,nd,bu")
+d2, o2 = po.pack([b"", b"", b"x"])
+e2.upload_corpus(d2, o2)
+e2.fuzz_batch(seed=(4, 5, 6))
+w2, ws2, _, _ = po.fuzz_batch(d2, o2, seed=(4, 5, 6), mutations="bd,sr,ld", patterns="od,nd,bu")
+g2, s2 = e2.download()
+assert g2 == w2 and list(s2) == list(ws2)
+e2.close(); eng.close()
+# introspection tables mirror the reference's tables
+names = [m[0] for m in ea.mutator_table()]
+assert names[0] == "sgm" and names[-1] == "nil" and len(names) == 41
+assert [p[0] for p in ea.pattern_table()] == ["od", "nd", "bu", "sk", "sz", "cs", "ar", "cp", "co", "nu"]
+print("abi behaviour ok")

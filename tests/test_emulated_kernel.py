@@ -43,3 +43,10 @@ def test_emulated_all_patterns_and_fuse(emu_lib):
 
 def test_emulated_per_call_seeds(emu_lib):
     _run(emu_lib, "bd,bf,bi,sr,sd,num,ld,lr,tr2,ab,uw,len", "od,nd,bu", 48, 512, "mixed", per_call=True)
+
+
+def test_emulated_abi_behaviour(emu_lib):
+    """call order, error codes, option parsing, buffer growth, sub-range reproducibility, empty inputs"""
+    env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_abi.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "abi behaviour ok" in r.stdout, r.stdout + r.stderr
