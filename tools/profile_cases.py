@@ -2,7 +2,7 @@
 """Per-case cost breakdown on the GPU: which mutators dominate the wavefront time."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
 import numpy as np
 import erlamsa_amd as ea
 from erlamsa_amd import synth
