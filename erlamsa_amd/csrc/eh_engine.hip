@@ -568,6 +568,37 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(KParam
 }
 
 // kernel-level self tests of the byte movers (driven by tests/test_gpu_primitives.py)
+// =============================================================================================
+// EH_FLAG_ORDERED_OUTPUT: compaction of the completion-ordered arena into case order
+// =============================================================================================
+// ord_off[i] = sum of out_len[0..i): one wavefront, 64 cases per step (n / 64 shuffle scans)
+__global__ void __launch_bounds__(64) eh_order_scan_kernel(const uint64_t* out_len, uint64_t* ord_off, uint64_t n) {
+  const int l = EH_LANE;
+  uint64_t run = 0;
+  for (uint64_t base = 0; base < n; base += 64) {
+    uint64_t i = base + (uint64_t)l;
+    uint64_t v = i < n ? out_len[i] : 0;
+    uint64_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint64_t t = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)inc, d);
+      if (l >= d) inc += t;
+    }
+    if (i < n) ord_off[i] = run + inc - v;
+    run += uni64(((uint64_t)(uint32_t)__shfl((int)(uint32_t)(inc >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)inc, 63));
+  }
+  if (l == 0) ord_off[n] = run;
+}
+// one wavefront per case (grid-stride): dst[ord_off[i] ..) = src[out_off[i] ..)
+__global__ void __launch_bounds__(64) eh_order_gather_kernel(const uint8_t* src, uint8_t* dst, const uint64_t* out_off, const uint64_t* out_len,
+                                                             const uint64_t* ord_off, uint64_t n) {
+  for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    uint64_t len = uni64(out_len[i]), so = uni64(out_off[i]), d0 = uni64(ord_off[i]);
+    uint64_t done = 0;
+    while (done < len) { uint32_t c = len - done > 0x40000000ull ? 0x40000000u : (uint32_t)(len - done); wave_copy(dst + d0 + done, src + so + done, c); done += c; }
+  }
+}
+
 __global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf, const uint32_t* jobs, uint32_t njobs, uint32_t* eq_out) {
   // job = {kind, dst_off, src_off, n, plen}: kind 0 copy, 1 periodic fill, 2 equal
   for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
@@ -616,6 +647,9 @@ struct eh_ctx {
   DevConfig cfg;
   uint64_t max_case_bytes = 0, out_capacity_opt = 0, work_budget = 0;
   uint32_t max_slots_opt = 0, flags = 0;
+  uint8_t* d_out2 = nullptr; uint64_t out2_cap = 0;   // EH_FLAG_ORDERED_OUTPUT: second arena (case order)
+  uint64_t* d_ord = nullptr; uint64_t ord_cap = 0;      // ordered offsets (n + 1)
+  bool ordered = false;                                 // the last batch's results are in case order
   // corpus
   uint8_t* d_corpus = nullptr; uint64_t* d_coff = nullptr; bool own_corpus = false;
   uint64_t n_corpus = 0, corpus_bytes = 0;
@@ -838,6 +872,31 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   if (n > 0) hipLaunchKernelGGL(eh_mutate_kernel, dim3(ctx->nslots < n ? ctx->nslots : (uint32_t)n), dim3(64), 0, st, p);
   HIPCHK(ctx, hipEventRecord(ctx->ev1, st));
   HIPCHK(ctx, hipGetLastError());
+  ctx->ordered = false;
+  if ((ctx->flags & EH_FLAG_ORDERED_OUTPUT) && n > 0) {
+    // second arena + ordered offsets, then scan + gather on the same stream; the arenas swap roles so that
+    // eh_result_device / eh_result_download see one contiguous case-ordered buffer
+    if (!ctx->d_out2 || ctx->out2_cap < ctx->out_cap) {
+      if (ctx->d_out2) (void)hipFree(ctx->d_out2);
+      ctx->d_out2 = nullptr;
+      HIPCHK(ctx, hipMalloc(&ctx->d_out2, ctx->out_cap));
+      ctx->out2_cap = ctx->out_cap;
+    }
+    if (!ctx->d_ord || ctx->ord_cap < n + 1) {
+      if (ctx->d_ord) (void)hipFree(ctx->d_ord);
+      ctx->d_ord = nullptr;
+      HIPCHK(ctx, hipMalloc(&ctx->d_ord, (n + 1) * 8));
+      ctx->ord_cap = n + 1;
+    }
+    hipLaunchKernelGGL(eh_order_scan_kernel, dim3(1), dim3(64), 0, st, ctx->d_len, ctx->d_ord, n);
+    uint32_t g = (uint32_t)ctx->cus * 32u; if (g > n) g = (uint32_t)n;
+    hipLaunchKernelGGL(eh_order_gather_kernel, dim3(g), dim3(64), 0, st, ctx->d_out, ctx->d_out2, ctx->d_off, ctx->d_len, ctx->d_ord, n);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_off, ctx->d_ord, n * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHK(ctx, hipGetLastError());
+    uint8_t* t = ctx->d_out; ctx->d_out = ctx->d_out2; ctx->d_out2 = t;
+    uint64_t tc = ctx->out_cap; ctx->out_cap = ctx->out2_cap; ctx->out2_cap = tc;
+    ctx->ordered = true;
+  }
   ctx->last_stream = st; ctx->last_n = n; ctx->last_in_bytes = in_bytes; ctx->have_result = true;
   return EH_OK;
 }
@@ -910,6 +969,8 @@ void eh_destroy(eh_ctx* ctx) {
   (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
   (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_run); (void)hipFree(ctx->d_seeds);
+  if (ctx->d_out2) (void)hipFree(ctx->d_out2);
+  if (ctx->d_ord) (void)hipFree(ctx->d_ord);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   delete ctx;
@@ -1036,7 +1097,12 @@ int eh_result_device(eh_ctx* ctx, const uint8_t** d_data, const uint64_t** d_off
   if (d_off) *d_off = ctx->d_off;
   if (d_len) *d_len = ctx->d_len;
   if (d_status) *d_status = ctx->d_status;
-  if (total) { unsigned long long cur = 0; HIPCHK(ctx, hipMemcpy(&cur, ctx->d_counters + 1, 8, hipMemcpyDeviceToHost)); *total = cur; }
+  if (total) {
+    unsigned long long cur = 0;
+    if (ctx->ordered) HIPCHK(ctx, hipMemcpy(&cur, ctx->d_ord + ctx->last_n, 8, hipMemcpyDeviceToHost));   // bytes of the compact, case-ordered buffer
+    else HIPCHK(ctx, hipMemcpy(&cur, ctx->d_counters + 1, 8, hipMemcpyDeviceToHost));                     // bump cursor of the completion-ordered arena (16-byte granules)
+    *total = cur;
+  }
   return EH_OK;
 }
 int eh_result_totals(eh_ctx* ctx, uint64_t* in_bytes, uint64_t* out_bytes, uint64_t* n_cases) {
@@ -1066,6 +1132,10 @@ int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, 
   if (off) { uint64_t p = 0; for (uint64_t i = 0; i < n; i++) { off[i] = p; p += len[i]; } off[n] = p; }
   if (data) {
     if (total > cap) { ctx->err = "download buffer too small"; return EH_E_INVALID; }
+    if (ctx->ordered) {                                          // already in case order and contiguous: one copy
+      if (total) HIPCHK(ctx, hipMemcpy(data, ctx->d_out, total, hipMemcpyDeviceToHost));
+      return EH_OK;
+    }
     unsigned long long cur = 0;
     HIPCHK(ctx, hipMemcpy(&cur, ctx->d_counters + 1, 8, hipMemcpyDeviceToHost));
     if (cur > ctx->out_cap) cur = ctx->out_cap;

@@ -66,6 +66,27 @@ w2, ws2, _, _ = po.fuzz_batch(d2, o2, seed=(4, 5, 6), mutations="bd,sr,ld", patt
 g2, s2 = e2.download()
 assert g2 == w2 and list(s2) == list(ws2)
 e2.close(); eng.close()
+# EH_FLAG_ORDERED_OUTPUT: results compacted into case order on the device; download is one contiguous
+# copy and eh_result_device hands out the compact buffer with prefix-sum offsets
+e3 = ea.Engine(0)
+e3.configure(mutations="bd=3,bf,bi=7,sr,ld", patterns="od,nd,bu", flags=ea.engine.EH_FLAG_ORDERED_OUTPUT)
+ins3 = util.corpus_mixed(150, 700, seed=3) + [b"", b"q"]
+d3, o3 = po.pack(ins3)
+e3.upload_corpus(d3, o3)
+w3, ws3, _, _ = po.fuzz_batch(d3, o3, seed=(9, 9, 9), mutations="bd=3,bf,bi=7,sr,ld", patterns="od,nd,bu", max_case_bytes=8 << 20, max_case_work=8 << 20)
+for rep in range(2):                                              # twice: the arenas swap roles every batch
+    e3.fuzz_batch(seed=(9, 9, 9))
+    g3, s3 = e3.download()
+    assert g3 == w3 and list(s3) == list(ws3)
+    dptr, optr, lptr, sptr, tot = e3.result_device()
+    n3 = len(ins3)
+    offs = np.ctypeslib.as_array(C.cast(optr, C.POINTER(C.c_uint64)), shape=(n3,)).copy()      # emulator: device memory is host memory
+    lens = np.ctypeslib.as_array(C.cast(lptr, C.POINTER(C.c_uint64)), shape=(n3,)).copy()
+    assert tot == sum(map(len, w3)) and list(lens) == [len(x) for x in w3]
+    assert list(offs) == list(np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.uint64))
+    flat = bytes(np.ctypeslib.as_array(C.cast(dptr, C.POINTER(C.c_uint8)), shape=(max(tot, 1),))[:tot])
+    assert flat == b"".join(w3)
+e3.close()
 # introspection tables mirror the reference's tables
 names = [m[0] for m in ea.mutator_table()]
 assert names[0] == "sgm" and names[-1] == "nil" and len(names) == 41

@@ -289,3 +289,37 @@ def test_per_call_seeds_mode():
     assert len(cmp) >= 0.97 * n
     bad = [i for i in cmp if gst[i] != ora.status[i] or not ora.same(i, got[i]) or (gst[i] == 0 and gdr[i] != ora.draws[i])]
     assert not bad, "cases differ: %s" % bad[:10]
+
+
+def test_ordered_output_flag():
+    """EH_FLAG_ORDERED_OUTPUT: the completion-ordered arena is compacted into case order on the device
+    (prefix sum of out_len + gather); download becomes one contiguous copy and eh_result_device hands
+    out the compact buffer.  Two batches in a row, because the two arenas swap roles every batch."""
+    import pyoracle as po
+    import torch
+    inputs = util.corpus_mixed(3000, 700, seed=3) + [b"", b"q"]
+    data, off = po.pack(inputs)
+    muts = "bd=3,bf,bi=7,sr,ld,num,tr2"
+    ora = util.oracle_batch(data, off, seed=(9, 9, 9), mutations=muts, patterns="od,nd,bu", max_case_bytes=8 << 20, max_case_work=8 << 20)
+    if util.priming():
+        pytest.skip("oracle cache primed")
+    import erlamsa_amd as ea
+    eng = ea.Engine(0)
+    eng.configure(mutations=muts, patterns="od,nd,bu", max_case_bytes=8 << 20, max_case_work=8 << 20, flags=ea.engine.EH_FLAG_ORDERED_OUTPUT)
+    eng.upload_corpus(data, off)
+    n = len(inputs)
+    for _ in range(2):
+        eng.fuzz_batch(seed=(9, 9, 9))
+        got, gst = eng.download()
+        assert all(gst[i] == ora.status[i] and ora.same(i, got[i]) for i in range(n) if gst[i] not in (2, 3) and ora.status[i] not in (2, 3))
+        dptr, optr, lptr, sptr, tot = eng.result_device()
+        lens = np.array([len(g) for g in got], dtype=np.uint64)
+        assert tot == int(lens.sum())
+        # the device-side offsets are the prefix sums of the lengths (compact, case order)
+        offs = torch.empty(n, dtype=torch.int64, device="cuda")
+        import ctypes
+        assert ea.load_library() is not None
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(ctypes.c_void_p(offs.data_ptr()), ctypes.c_void_p(optr), ctypes.c_size_t(n * 8), 3) == 0     # device to device
+        assert offs.cpu().numpy().astype(np.uint64).tolist() == np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.uint64).tolist()
+    eng.close()
