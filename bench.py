@@ -22,6 +22,51 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DESC_BYTES = 24        # per-case descriptor: out_off, out_len, status/draws
 
 
+def cpu_baseline_leg(mat, seed, muts, pats, args):
+    """oracle/ timed on the host: chunks of 512 cases (case numbers 1.., the same corpus rows, options and
+    limits as the GPU run) are handed to `--cpu-threads` worker threads (the ctypes call releases the GIL)
+    until `--cpu-seconds` have passed or `--cpu-sample` cases are done.  Reported: the aggregate rate over
+    all threads and the threads actually used."""
+    import threading
+    from erlamsa_amd import synth
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    po.lib()
+    n = mat.shape[0]
+    limit = min(args.cpu_sample, n)
+    threads = max(1, args.cpu_threads or (os.cpu_count() or 1))
+    CH = 512
+    lock = threading.Lock()
+    state = {"next": 0, "cases": 0, "bytes": 0}
+    t0 = time.perf_counter()
+
+    def worker():
+        while True:
+            with lock:
+                a = state["next"]
+                if a >= limit or time.perf_counter() - t0 >= args.cpu_seconds:
+                    return
+                state["next"] = a + CH
+            b = min(a + CH, limit)
+            d, o = synth.as_arena(mat[a:b])
+            outs, _, _, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, first_case=a + 1,
+                                          max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20)
+            with lock:
+                state["cases"] += b - a
+                state["bytes"] += sum(len(x) for x in outs)
+
+    ts = [threading.Thread(target=worker) for _ in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    ct = time.perf_counter() - t0
+    return {"value": round(state["bytes"] / ct / 1e6, 3), "unit": "MB/s", "cores": threads, "kind": "port",
+            "cases_per_s": round(state["cases"] / ct, 2),
+            "sample": "cases 1..%d of the same run (same corpus rows, seed, mutators, patterns, limits), oracle/ C++ restatement, "
+                      "%d threads, %.1f s wall" % (state["cases"], threads, ct)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -33,9 +78,10 @@ def main():
     ap.add_argument("--patterns", default="od,nd,bu")
     ap.add_argument("--corpus", default="mixed", choices=["mixed", "uniform"],
                     help="mixed = BASELINE configs[2] (default); uniform = random bytes (configs[1] with --cases 1024 --size 256)")
-    ap.add_argument("--cpu-sample", type=int, default=16384, help="upper bound of cases timed on the CPU oracle (0 = skip); "
+    ap.add_argument("--cpu-sample", type=int, default=65536, help="upper bound of cases timed on the CPU oracle (0 = skip); "
                     "the leg stops after --cpu-seconds")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time bound of the CPU oracle leg")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle leg (0 = all host cores)")
     ap.add_argument("--max-slots", type=int, default=0)
     ap.add_argument("--out-gib", type=int, default=8, help="output arena capacity per context (GiB)")
     ap.add_argument("--case-mib", type=int, default=8, help="per-case work area (MiB), eh_options.max_case_bytes")
@@ -201,24 +247,9 @@ def main():
                          "kernel": ea.load_library().eh_kernel_name().decode(), "kernel_ms_avg": round(avg_kern_s * 1e3, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
-        # ---- CPU baseline: the oracle (C++ restatement of the reference) on a bounded sample, 1 thread
+        # ---- CPU baseline: the oracle (C++ restatement of the reference) on the host cores, N=1 only
         if args.cpu_sample > 0 and world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import pyoracle as po
-            # chunks of 512 cases (case numbers 1.., same corpus rows) until the time bound is reached
-            ns, ct, cb = 0, 0.0, 0
-            while ns < min(args.cpu_sample, n) and ct < args.cpu_seconds:
-                d, o = synth.as_arena(mat[ns:ns + 512])
-                t1 = time.perf_counter()
-                outs, _, _, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, first_case=ns + 1,
-                                              max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20)
-                ct += time.perf_counter() - t1
-                cb += sum(len(x) for x in outs)
-                ns += len(outs)
-            res["cpu_baseline"] = {"value": round(cb / ct / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
-                                   "cases_per_s": round(ns / ct, 2),
-                                   "sample": "cases 1..%d of the same run (same corpus rows, seed, mutators, patterns, limits), "
-                                             "oracle/ C++ restatement, single thread, %.1f s" % (ns, ct)}
+            res["cpu_baseline"] = cpu_baseline_leg(mat, seed, muts, pats, args)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
