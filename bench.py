@@ -34,7 +34,7 @@ def cpu_baseline_leg(mat, seed, muts, pats, args):
     po.lib()
     n = mat.shape[0]
     limit = min(args.cpu_sample, n)
-    threads = max(1, args.cpu_threads or (os.cpu_count() or 1))
+    threads = max(1, args.cpu_threads or min(os.cpu_count() or 1, 64))
     CH = 512
     lock = threading.Lock()
     state = {"next": 0, "cases": 0, "bytes": 0}
@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=65536, help="upper bound of cases timed on the CPU oracle (0 = skip); "
                     "the leg stops after --cpu-seconds")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time bound of the CPU oracle leg")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle leg (0 = all host cores)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle leg (0 = all host cores, at most 64)")
     ap.add_argument("--max-slots", type=int, default=0)
     ap.add_argument("--out-gib", type=int, default=8, help="output arena capacity per context (GiB)")
     ap.add_argument("--case-mib", type=int, default=8, help="per-case work area (MiB), eh_options.max_case_bytes")
