@@ -25,6 +25,8 @@ struct FuseSide {
   uint64_t* bkey;                     // group key = (nn-1-node) << 8 | (255-byte)
   uint32_t* bcnt;                     // group size after fix_empty_list
   uint32_t* child;                    // child node built from this group (or NONE)
+  uint32_t* nfirst;                   // per (reversed) node: first group and one past its last group
+  uint32_t* nend;
   uint32_t nb;
 };
 constexpr uint32_t FUSE_NONE = 0xFFFFFFFFu, FUSE_SPECIAL = 0xFFFFFFFEu;
@@ -80,7 +82,10 @@ EH_DEV void fuse_group(FuseSide& x, uint32_t nn, const uint32_t* seg, uint32_t* 
       uint32_t nd = in ? x.node[i] : 0u;
       uint32_t b = v ? (uint32_t)x.s[p] : 0u;
       uint32_t key = v ? (((nd - k) << 14) | (b << 6) | (uint32_t)l) : 0xFFFFFFFFu;
-      uint32_t sk = wave_sort64(key);
+      // entries arrive ordered by segment; when the bytes happen to ascend inside every segment too (always
+      // the case once segments have shrunk to single entries) the 21-step network is skipped
+      uint32_t nxt = (uint32_t)__shfl_down((int)key, 1);
+      uint32_t sk = __ballot(l < 63 && key > nxt) == 0 ? key : wave_sort64(key);
       bool sv = sk != 0xFFFFFFFFu;
       uint32_t ol = sk & 63u;
       uint32_t sp = (uint32_t)__shfl((int)p, (int)ol), snd = (uint32_t)__shfl((int)nd, (int)ol);
@@ -138,6 +143,15 @@ EH_DEV void fuse_group(FuseSide& x, uint32_t nn, const uint32_t* seg, uint32_t* 
   if (l == 0) x.bstart[nb] = nvalid;
   wave_sync();
   x.nb = nb;
+  // group range of every node (keys ascend, so a node's groups are contiguous): lookups then search at most
+  // 256 groups, usually one, instead of all of them
+  for (uint32_t k2 = (uint32_t)l; k2 < nn; k2 += 64) { x.nfirst[k2] = 0; x.nend[k2] = 0; }
+  wave_sync();
+  for (uint32_t j = (uint32_t)l; j < nb; j += 64) {
+    uint32_t np = (uint32_t)(x.bkey[j] >> 8);
+    if (j == 0 || (uint32_t)(x.bkey[j - 1] >> 8) != np) x.nfirst[np] = j;
+    if (j + 1 == nb || (uint32_t)(x.bkey[j + 1] >> 8) != np) x.nend[np] = j + 1;
+  }
   // fix_empty_list (:58-60): a group whose LAST element (first one inserted) is the empty tail loses it
   for (uint32_t j = l; j < nb; j += 64) {
     uint32_t a = x.bstart[j], b = x.bstart[j + 1];
@@ -166,12 +180,13 @@ EH_DEV bool fuse_lists(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, 
   f.bstart = u32(capf + 1); t.bstart = u32(capt + 1);
   f.bkey = (uint64_t*)ws_alloc(c, (uint64_t)capf * 8); t.bkey = (uint64_t*)ws_alloc(c, (uint64_t)capt * 8);
   f.bcnt = u32(capf); t.bcnt = u32(capt); f.child = u32(capf); t.child = u32(capt);
+  f.nfirst = u32(capf); f.nend = u32(capf); t.nfirst = u32(capf); t.nend = u32(capf);      // indexed by node: nn <= capf
   // node table: per node start/count in pos arrays (current and next)
   uint32_t capn = capf;                                            // every node owns >= 1 source entry
   uint32_t* nfs = u32(capn + 1); uint32_t* nts = u32(capn + 1); uint32_t* nfs2 = u32(capn + 1); uint32_t* nts2 = u32(capn + 1);
   uint32_t* cmatch = u32(capn); uint32_t* hist = u32(256);
   if (!f.pos || !f.node || !t.pos || !t.node || !f2 || !fn2 || !t2 || !tn2 || !f.keys || !t.keys || !f.gid || !t.gid || !f.bstart ||
-      !t.bstart || !f.bkey || !t.bkey || !f.bcnt || !t.bcnt || !f.child || !t.child || !nfs || !nts || !nfs2 || !nts2 || !cmatch || !hist) return false;
+      !t.bstart || !f.bkey || !t.bkey || !f.bcnt || !t.bcnt || !f.child || !t.child || !f.nfirst || !f.nend || !t.nfirst || !t.nend || !nfs || !nts || !nfs2 || !nts2 || !cmatch || !hist) return false;
   // find_jump_points (:103-107): one node with all non-empty suffixes of both lists
   for (uint32_t i = l; i < la; i += 64) { f.pos[i] = i; f.node[i] = 0; }
   for (uint32_t i = l; i < lb; i += 64) { t.pos[i] = i; t.node[i] = 0; }
@@ -196,9 +211,11 @@ EH_DEV bool fuse_lists(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, 
         if (fc == 0) { child = true; fc = 1; tc = 1; tj = FUSE_SPECIAL; }           // [[[[]], []] | Tl]
         else {
           uint64_t key = f.bkey[j];
-          uint32_t lo = 0, hi = t.nb;                              // binary search (ascending keys)
+          uint32_t np = (uint32_t)(key >> 8);
+          uint32_t lo = t.nfirst[np], hi = t.nend[np];             // binary search inside the node's groups (ascending keys)
+          uint32_t tend = hi;
           while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (t.bkey[mid] < key) lo = mid + 1; else hi = mid; }
-          if (lo < t.nb && t.bkey[lo] == key) { child = true; tj = lo; tc = t.bcnt[lo]; }
+          if (lo < tend && t.bkey[lo] == key) { child = true; tj = lo; tc = t.bcnt[lo]; }
         }
       }
       // exclusive prefix sums of (child, fc, tc) across the wave
