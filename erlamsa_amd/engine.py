@@ -48,6 +48,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime: when both live in one process torch must initialise first (the
+    # engine then shares that runtime; the other order leaves torch without devices — INTEGRATION.md §4)
+    import sys
+    if "torch" in sys.modules:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
