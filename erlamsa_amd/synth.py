@@ -72,6 +72,67 @@ def mixed(n, size, seed=DEFAULT_SEED):
     return out
 
 
+def _json_value(rng, depth):
+    r = rng.random()
+    if depth > 3 or r < 0.45:
+        k = int(rng.integers(0, 6))
+        if k == 0:
+            return str(int(rng.integers(-10 ** 6, 10 ** 9)))
+        if k == 1:
+            return "%.3f" % float(rng.random() * 1000)
+        if k == 2:
+            return ["true", "false", "null"][int(rng.integers(0, 3))]
+        words = ["alpha", "beta gamma", "http://example.com/a/b?c=d", "dGhpcyBpcyBiYXNlNjQgdGV4dA==", "12 + 34", "x", ""]
+        return '"%s"' % words[int(rng.integers(0, len(words)))]
+    n = int(rng.integers(0, 5))
+    if r < 0.75:
+        return "{" + ",".join('"k%d":%s' % (int(rng.integers(0, 100)), _json_value(rng, depth + 1)) for _ in range(n)) + "}"
+    return "[" + ",".join(_json_value(rng, depth + 1) for _ in range(n)) + "]"
+
+
+def json_docs(n, seed=DEFAULT_SEED):
+    """Compact JSON documents (what erlamsa_json:fold_ast/1 prints back unchanged), list[bytes]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return [_json_value(rng, 0 if rng.random() < 0.9 else 9).encode() for _ in range(n)]
+
+
+def _sgml_elem(rng, depth):
+    names = ["a", "div", "P", "xmlns:x", "item", "Br"]
+    r = rng.random()
+    if depth > 3 or r < 0.3:
+        words = [b"text ", b"12 apples", b"http://h/p/q", b"line\n", b"c29tZSBiYXNlNjQgZGF0YQ==", b"x"]
+        return words[int(rng.integers(0, len(words)))]
+    nm = names[int(rng.integers(0, len(names)))].encode()
+    attrs = b""
+    for _ in range(int(rng.integers(0, 3))):
+        k = int(rng.integers(0, 4))
+        an = [b"id", b"xmlns", b"class", b"href"][k]
+        q = [b"'", b'"', b""][int(rng.integers(0, 3))]
+        val = [b"v1", b"http://e.org/ns", b"7"][int(rng.integers(0, 3))]
+        attrs += b" " + an + b"=" + q + val + q
+    if r < 0.4:
+        return b"<" + nm + attrs + b" />"
+    if r < 0.45:
+        return b"<!-- note -->"
+    kids = b"".join(_sgml_elem(rng, depth + 1) for _ in range(int(rng.integers(0, 4))))
+    return b"<" + nm + attrs + b">" + kids + b"</" + nm + b">"
+
+
+def sgml_docs(n, seed=DEFAULT_SEED):
+    """Canonical SGML/XML-ish documents (erlamsa_sgml:fold_ast(parse(X)) == X for them), list[bytes]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    for _ in range(n):
+        head = b"<?xml version='1.0'?>" if rng.random() < 0.5 else b""
+        body = b""
+        while not body.startswith(b"<") and not head:
+            body = _sgml_elem(rng, 0)
+        if head:
+            body = _sgml_elem(rng, 0)
+        out.append(head + body + b"".join(_sgml_elem(rng, 1) for _ in range(int(rng.integers(0, 3)))))
+    return out
+
+
 def as_arena(mat):
     """uint8[n, size] -> (flat data, uint64 off[n+1])"""
     n, size = mat.shape

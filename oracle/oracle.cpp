@@ -206,6 +206,17 @@ struct Config {
 
 struct Case;  // fwd
 
+// ENGINE GUARD — NOT reference behaviour.  The HIP engine has per-case caps (work-area bytes, optional work
+// budget); when a test wants to compare the *status* of capped cases too, the C API hands the worker one of
+// these.  With guard == nullptr (max_case_bytes = max_case_work = 0) the restated functions below are the
+// pure reference semantics: the reference's only limit is the wall-clock maxrunningtime watchdog
+// (erlamsa_main.erl:211-220), which is outside parity.
+struct EngineGuard {
+  uint64_t max_bytes = 0, max_work = 0, work = 0;
+  void attempt(int fn, size_t len);          // called once per mutator attempt of mux_fuzzers_loop
+  void size(size_t n) const { if (max_bytes && n > max_bytes) throw Overflow(); }
+};
+
 // ===========================================================================
 // Worker context for one case: PRNG + mutator list + trace
 // ===========================================================================
@@ -215,9 +226,9 @@ struct Ctx {
   std::vector<Muta> fs;  // the mux_fuzzers list, in list order
   std::string* trace = nullptr;
   Bytes out;             // blocks already written by blocks_port
-  uint64_t work = 0;     // engine work budget accounting (see Config::max_case_work)
+  EngineGuard* guard = nullptr;   // engine caps (not reference behaviour); nullptr = pure reference semantics
   void t(const char* tag, const char* name) { if (trace) { trace->append(tag); trace->push_back(':'); trace->append(name); trace->push_back(' '); } }
-  void check_cap(size_t n) { if (cfg->max_case_bytes && n > cfg->max_case_bytes) throw Overflow(); }
+  void check_cap(size_t n) { if (guard) guard->size(n); }
 };
 
 // ---------------------------------------------------------------------------
@@ -1129,16 +1140,19 @@ int run_muta_fn(Ctx& c, BList& ll, Muta& m) {
 
 // mux_fuzzers/1 + mux_fuzzers_loop/4 :1256-1280.  Mutates `fs` (the closure's
 // list) and `ll` in place.
-// engine work budget (Config::max_case_work): cost weight per byte by mutator, mirrors
-// erlamsa_amd/csrc/eh_device.h work_weight()
-static uint32_t work_weight(int fn) {
+// cost weights of the engine's optional work budget (erlamsa_amd/csrc/eh_device.h work_weight()); see EngineGuard
+void EngineGuard::attempt(int fn, size_t len) {
+  if (!max_work) return;
+  uint32_t w = 1;
   switch (fn) {
     case M_SGM: case M_JS: case M_AB: case M_AD: case M_TR2: case M_TD: case M_TS1: case M_TR: case M_TS2:
-    case M_SNAND: case M_SRND: case M_B64: case M_URI: return 8;
-    case M_NUM: return 4;
-    case M_FT: case M_FN: case M_FO: return 64;
-    default: return 1;
+    case M_SNAND: case M_SRND: case M_B64: case M_URI: w = 8; break;
+    case M_NUM: w = 4; break;
+    case M_FT: case M_FN: case M_FO: w = 64; break;
+    default: break;
   }
+  work += (uint64_t)len * w;
+  if (work > max_work) throw Budget();
 }
 void mux_fuzzers(Ctx& c, std::vector<Muta>& fs, BList& ll) {
   if (ll.size() == 1 && ll[0].empty()) return;                                // L([<<>>], Meta)
@@ -1156,8 +1170,7 @@ void mux_fuzzers(Ctx& c, std::vector<Muta>& fs, BList& ll) {
       std::vector<Muta> nf = out; nf.insert(nf.end(), sorted.begin() + i + 1, sorted.end()); fs.swap(nf); return;
     }
     Muta node = sorted[i];
-    c.work += (uint64_t)ll[0].size() * work_weight(node.fn);
-    if (c.cfg->max_case_work && c.work > c.cfg->max_case_work) throw Budget();
+    if (c.guard) c.guard->attempt(node.fn, ll[0].size());
     BList mll = ll;
     int delta = run_muta_fn(c, mll, node);
     node.score = adjust_priority(node.score, delta);
@@ -1254,17 +1267,6 @@ int uri_mutator(Ctx& c, BList& ll, Muta& m) {                                 //
   ll[0] = unlex(cs);
   m.fn = M_B64;                                                               // :784 returns fun base64_mutator/2 (sic)
   return dacc;
-}
-
-// sgm / js: staged last; until restated they are not selectable.
-// erlamsa_sgml:sgml_mutate/2 :739-757 — only the failure paths that need no tokenizer are restated so far:
-// parse/1 throws incorrect_sgml for binarish blocks (:191-199) and tz(nil, _) throws it when the block
-// holds no '<' at all (:102-104); both leave the block alone with delta -1 and draw nothing.
-int sgml_mutate(Ctx&, BList& ll) {
-  const Bytes& h = ll[0];
-  if (binarish(h)) return -1;
-  if (std::find(h.begin(), h.end(), (uint8_t)'<') == h.end()) return -1;
-  throw Unsupported();
 }
 
 // ===========================================================================
@@ -1636,6 +1638,444 @@ int json_mutate(Ctx& c, BList& ll) {                                          //
 }
 
 // ===========================================================================
+// erlamsa_sgml.erl — tokenizer (:66-177), AST builder (:187-279), folder (:290-331), walk/select
+// (:341-477), mutations (:488-737), sgml_mutate/2 (:739-757).
+// ===========================================================================
+struct SParam { Bytes name, value; int delim; };   // delim: 0 = [] (unquoted), 1 = "'", 2 = "\""
+enum SKind { S_OPEN, S_CLOSE, S_SC, S_TEXT, S_BANG, S_COMMENT, S_QUE, S_EOF, S_TAG, S_TAGCLOSE };
+struct STok { SKind k; Bytes name; std::vector<SParam> params; Bytes text; };   // close: name = Tag (raw)
+struct SNode;
+typedef std::shared_ptr<const SNode> SN;
+struct SNode {
+  SKind k;                       // S_TAG {tag,Open,Close,Params,Internals}; S_TEXT; S_SC; S_QUE; S_BANG; S_COMMENT; S_OPEN; S_CLOSE; S_TAGCLOSE
+  Bytes name, close_name; std::vector<SParam> params; Bytes text; std::vector<SN> kids;
+};
+struct IncorrectSgml {};
+struct SgmlOtherError {};        // function_clause etc.: caught by `catch _:_` inside tokenize/1, fatal outside of it
+
+// string:to_lower/1 (ISO 8859-1 rule of the old string module)
+uint8_t latin1_lower(uint8_t ch) {
+  if ((ch >= 'A' && ch <= 'Z') || (ch >= 0xC0 && ch <= 0xD6) || (ch >= 0xD8 && ch <= 0xDE)) return (uint8_t)(ch + 32);
+  return ch;
+}
+Bytes to_lower(const Bytes& b) { Bytes o(b); for (auto& x : o) x = latin1_lower(x); return o; }
+bool sg_ws(uint8_t x) { return x == ' ' || x == '\r' || x == '\n' || x == '\t'; }            // ?ws :58
+bool sg_ev(uint8_t x) { return sg_ws(x) || x == '>' || x == '='; }                            // ?ev :64
+// NB ?ok(X) (:57) is a disjunction of inequalities, i.e. always true: every byte is a name character.
+size_t sg_skip_ws(const Bytes& s, size_t p) { while (p < s.size() && sg_ws(s[p])) p++; return p; }   // ws/1 :176-177
+bool sg_starts(const Bytes& s, size_t p, const char* w) { size_t l = strlen(w); return p + l <= s.size() && memcmp(s.data() + p, w, l) == 0; }
+
+// tz/2 :100-164 driven from state {tag,""} at position p (p is already past the '<' and the ws/1 skip) until a
+// token is complete.  Returns the token and the position where the text state resumes.
+STok sgml_tag(const Bytes& s, size_t p, size_t* next) {
+  const size_t n = s.size();
+  STok t;
+  if (sg_starts(s, p, "!--")) {                                               // :104, :117-118
+    size_t q = p + 3;
+    for (;; q++) {
+      if (sg_starts(s, q, "-->")) { t.k = S_COMMENT; t.text.assign(s.begin() + p + 3, s.begin() + q); *next = q + 3; return t; }
+      if (q >= n) throw SgmlOtherError();                                     // no clause of tz/2 matches {'!--',_}, <<>>
+    }
+  }
+  if (sg_starts(s, p, "!")) {                                                 // :105, :113-115
+    size_t q0 = sg_skip_ws(s, p + 1);
+    for (size_t q = q0;; q++) {
+      if (q >= n) throw IncorrectSgml();
+      if (s[q] == '>') { t.k = S_BANG; t.text.assign(s.begin() + q0, s.begin() + q); *next = q + 1; return t; }
+    }
+  }
+  if (sg_starts(s, p, "?")) {                                                 // :106, :120-122
+    size_t q0 = sg_skip_ws(s, p + 1);
+    for (size_t q = q0;; q++) {
+      if (sg_starts(s, q, "?>")) { t.k = S_QUE; t.text.assign(s.begin() + q0, s.begin() + q); *next = q + 2; return t; }
+      if (q >= n) throw IncorrectSgml();
+    }
+  }
+  if (sg_starts(s, p, "/")) {                                                 // :107, :128-132
+    size_t q0 = sg_skip_ws(s, p + 1), q = q0;
+    for (;; q++) {
+      if (q >= n) throw IncorrectSgml();
+      if (sg_ev(s[q])) break;
+    }
+    size_t r = sg_skip_ws(s, q);
+    if (r < n && s[r] == '>') { t.k = S_CLOSE; t.name.assign(s.begin() + q0, s.begin() + q); *next = r + 1; return t; }
+    throw IncorrectSgml();
+  }
+  // {tag,Tag} :108-111
+  size_t q = p;
+  for (;; q++) {
+    if (sg_starts(s, q, "/>")) { t.k = S_SC; t.name.assign(s.begin() + p, s.begin() + q); *next = q + 2; return t; }
+    if (q >= n) throw IncorrectSgml();
+    if (sg_ev(s[q])) break;
+  }
+  t.name.assign(s.begin() + p, s.begin() + q);
+  size_t r = sg_skip_ws(s, q);                                                // {attr,"",{Tag,[]}}, ws(S)
+  for (;;) {
+    // {attr,"",{Tag,As}} :134-135,138-139
+    if (r >= n) throw IncorrectSgml();
+    if (sg_ev(s[r]) || sg_starts(s, r, "/>")) {                               // {etag,Tag,As} :124-126
+      if (sg_starts(s, r, "/>")) { t.k = S_SC; *next = r + 2; return t; }
+      if (s[r] == '>') { t.k = S_OPEN; *next = r + 1; return t; }
+      throw IncorrectSgml();
+    }
+    size_t a0 = r;                                                            // {attr,A,..} with A /= "" :136-139
+    for (r++;; r++) {
+      if (r >= n) throw IncorrectSgml();
+      if (sg_ev(s[r]) || sg_starts(s, r, "/>")) break;
+    }
+    SParam pa; pa.name.assign(s.begin() + a0, s.begin() + r); pa.delim = 0;
+    r = sg_skip_ws(s, r);                                                     // {eatt,..}, ws(S)
+    if (r < n && s[r] == '=') {                                               // :141 -> {val,..}, ws(Str)
+      r = sg_skip_ws(s, r + 1);
+      if (r < n && (s[r] == '\'' || s[r] == '"')) {                           // :144-145, :148-154
+        uint8_t qc = s[r]; size_t v0 = r + 1, e = v0;
+        while (e < n && s[e] != qc) e++;
+        if (e >= n) throw IncorrectSgml();
+        pa.value.assign(s.begin() + v0, s.begin() + e); pa.delim = qc == '\'' ? 1 : 2;
+        r = sg_skip_ws(s, e + 1);
+      } else {                                                                // :146, :157-160
+        size_t v0 = r;
+        for (;; r++) {
+          if (r >= n) throw IncorrectSgml();
+          if (sg_ev(s[r]) || sg_starts(s, r, "/>")) break;
+        }
+        pa.value.assign(s.begin() + v0, s.begin() + r);
+        r = sg_skip_ws(s, r);
+      }
+    } else {
+      r = sg_skip_ws(s, r);                                                   // :142 {A,"",[]}
+    }
+    t.params.push_back(pa);
+  }
+}
+
+// tokenize/1 :66-98.  The first tag is parsed outside any try (errors propagate); every later '<' is tried
+// inside `try ... catch _:_`, a failure turns the '<' (minus the white space that followed it) into text.
+std::vector<STok> sgml_tokenize(const Bytes& s) {
+  const size_t n = s.size();
+  size_t p = 0;
+  while (p < n && s[p] != '<') p++;                                           // tz(nil, ..) :100-102
+  if (p >= n) throw IncorrectSgml();
+  size_t pos;
+  STok cur = sgml_tag(s, sg_skip_ws(s, p + 1), &pos);
+  std::vector<STok> out;
+  for (;;) {
+    Bytes text; size_t from = pos; bool bad = false;
+    for (;;) {
+      size_t lt = from; while (lt < n && s[lt] != '<') lt++;                  // ff/4 :166-174
+      if (bad) text.push_back('<');
+      text.insert(text.end(), s.begin() + from, s.begin() + lt);
+      if (lt >= n) {
+        out.push_back(cur); STok e; e.k = S_EOF; e.text = text; out.push_back(e);
+        return out;
+      }
+      size_t estr = sg_skip_ws(s, lt + 1);
+      STok nt; size_t np; bool ok = true;
+      try { nt = sgml_tag(s, estr, &np); } catch (IncorrectSgml&) { ok = false; } catch (SgmlOtherError&) { ok = false; }
+      if (ok) { out.push_back(cur); STok tx; tx.k = S_TEXT; tx.text = text; out.push_back(tx); cur = nt; pos = np; break; }
+      bad = true; from = estr;                                                // {bad_text, Part1, "<", Part2, Token}
+    }
+  }
+}
+
+
+SN sg_from_tok(const STok& t, SKind k) { auto x = std::make_shared<SNode>(); x->k = k; x->name = t.name; x->params = t.params; x->text = t.text; return x; }
+
+// build_ast2/4 :204-279.  `ast` is kept in document order (the reference conses and reverses), `tags` with
+// the innermost open tag last.  st: 0 ok, 1 no_pair_tag, 2 closed_earlier.
+struct SBuild { int st = 0; std::vector<SN> ast; size_t tpos = 0; std::vector<Bytes> tags; long n = 0, nt = 0; Bytes ce_name, ce_close; };
+SBuild sgml_build(const std::vector<STok>& toks, size_t i, std::vector<Bytes> tags) {
+  SBuild b; b.tags = std::move(tags);
+  for (;;) {
+    const STok& t = toks[i];
+    switch (t.k) {
+      case S_OPEN: {
+        Bytes low = to_lower(t.name);
+        std::vector<Bytes> tg = b.tags; tg.push_back(low);
+        SBuild r = sgml_build(toks, i + 1, tg);
+        if (r.st == 0) {                                                      // {ok, [{tagclose,TagClose}|TagInternals], TagOuters, {K,KT}}
+          if (r.ast.empty() || r.ast[0]->k != S_TAGCLOSE) throw ErlCrash("case_clause: build_ast2 open");
+          auto x = std::make_shared<SNode>(); x->k = S_TAG; x->name = t.name; x->close_name = r.ast[0]->name; x->params = t.params;
+          x->kids.assign(r.ast.begin() + 1, r.ast.end());
+          b.ast.push_back(x); i = r.tpos; b.n += r.n + 1; b.nt += r.nt + 1;
+        } else if (r.st == 1) {                                               // no_pair_tag :220-225
+          b.ast.push_back(sg_from_tok(t, S_OPEN)); b.ast.insert(b.ast.end(), r.ast.begin(), r.ast.end());
+          i = r.tpos; b.tags = r.tags; b.n += r.n + 1; b.nt += r.nt;
+        } else if (r.ce_name == low) {                                        // closed_earlier, our tag :226-229
+          auto x = std::make_shared<SNode>(); x->k = S_TAG; x->name = t.name; x->close_name = r.ce_close; x->params = t.params; x->kids = r.ast;
+          b.ast.push_back(x); i = r.tpos; b.tags = r.tags; b.n += r.n + 1; b.nt += r.nt + 1;
+        } else {                                                              // closed_earlier, pass upwards :230-235
+          b.ast.push_back(sg_from_tok(t, S_OPEN)); b.ast.insert(b.ast.end(), r.ast.begin(), r.ast.end());
+          b.st = 2; b.ce_name = r.ce_name; b.ce_close = r.ce_close; b.tpos = r.tpos; b.tags = r.tags; b.n += r.n + 1; b.nt += r.nt;
+          return b;
+        }
+        break;
+      }
+      case S_CLOSE: {
+        Bytes low = to_lower(t.name);                                         // {close, Tag, string:to_lower(Tag)} :129
+        if (!b.tags.empty() && b.tags.back() == low) {                        // :237-239
+          auto tc = std::make_shared<SNode>(); tc->k = S_TAGCLOSE; tc->name = t.name;
+          b.ast.insert(b.ast.begin(), tc); b.tpos = i + 1; b.st = 0; return b;
+        }
+        bool member = false; size_t at = 0;
+        if (!b.tags.empty()) for (size_t k = b.tags.size() - 1; k-- > 0;) if (b.tags[k] == low) { member = true; at = k; break; }
+        if (member) {                                                         // :246-248
+          b.st = 2; b.ce_name = low; b.ce_close = t.name; b.tpos = i + 1; b.tags.resize(at);   // push_till/2
+          return b;
+        }
+        b.ast.push_back(sg_from_tok(t, S_CLOSE)); b.n++; i++;                  // :243-245, :250-252
+        break;
+      }
+      case S_TEXT:
+        if (!t.text.empty()) { b.ast.push_back(sg_from_tok(t, S_TEXT)); b.n++; }   // :253-258
+        i++; break;
+      case S_BANG: case S_COMMENT: case S_QUE: case S_SC:
+        b.ast.push_back(sg_from_tok(t, t.k)); b.n++; i++; break;              // :259-270
+      case S_EOF:
+        if (b.tags.empty()) {                                                 // :271-276
+          if (!t.text.empty()) { b.ast.push_back(sg_from_tok(t, S_TEXT)); b.n++; }
+          b.st = 0; b.tpos = i; return b;
+        }
+        b.st = 1; b.tpos = i; b.tags.pop_back(); return b;                    // :277-279
+      default: throw ErlCrash("function_clause: build_ast2");
+    }
+  }
+}
+
+// fold_params/2 + enclose_param_value/2 :290-303, fold_ast/2 :305-331
+void sgml_fold_params(const std::vector<SParam>& ps, Bytes& o) {
+  for (auto& p : ps) {
+    o.push_back(' '); o.insert(o.end(), p.name.begin(), p.name.end());
+    if (p.value.empty()) continue;                                            // {ParamName, [], _Type}
+    o.push_back('=');
+    if (p.delim == 1) o.push_back('\''); else if (p.delim == 2) o.push_back('"');
+    o.insert(o.end(), p.value.begin(), p.value.end());
+    if (p.delim == 1) o.push_back('\''); else if (p.delim == 2) o.push_back('"');
+  }
+}
+void sgml_fold(const std::vector<SN>& l, Bytes& o) {
+  auto app = [&](const char* w) { o.insert(o.end(), w, w + strlen(w)); };
+  auto appb = [&](const Bytes& b) { o.insert(o.end(), b.begin(), b.end()); };
+  for (auto& e : l) {
+    switch (e->k) {
+      case S_TAG: app("<"); appb(e->name); sgml_fold_params(e->params, o); app(">"); sgml_fold(e->kids, o); app("</"); appb(e->close_name); app(">"); break;
+      case S_TEXT: appb(e->text); break;
+      case S_SC: app("<"); appb(e->name); sgml_fold_params(e->params, o); app(" />"); break;
+      case S_QUE: app("<?"); appb(e->text); app("?>"); break;
+      case S_BANG: app("<!"); appb(e->text); app(">"); break;
+      case S_COMMENT: app("<!--"); appb(e->text); app("-->"); break;
+      case S_OPEN: app("<"); appb(e->name); sgml_fold_params(e->params, o); app(">"); break;
+      case S_CLOSE: app("</"); appb(e->name); app(">"); break;
+      case S_TAGCLOSE: break;
+      default: throw ErlCrash("function_clause: fold_ast");
+    }
+  }
+}
+
+// walk/3 :344-361 with a list accumulator.  fun(elem, tree, TagCnt, I): tree.push_back(X) is the reference's
+// [X | Tree]; for a tag, `elem` carries the already walked children.
+struct SCnt { long t = 0, c = 0; };
+typedef std::function<void(const SN&, std::vector<SN>&, long, long)> SWalkFun;
+void sgml_walk(const std::vector<SN>& l, std::vector<SN>& acc, SCnt& c, const SWalkFun& fun) {
+  for (auto& e : l) {
+    if (e->k == S_TAG) {
+      c.t++; c.c++; long t = c.t, i = c.c;
+      auto x = std::make_shared<SNode>(*e); x->kids.clear();
+      sgml_walk(e->kids, x->kids, c, fun);
+      fun(x, acc, t, i);
+    } else { c.c++; fun(e, acc, c.t, c.c); }
+  }
+}
+std::vector<SN> sgml_walk_top(const std::vector<SN>& ast, const SWalkFun& fun) { std::vector<SN> acc; SCnt c; sgml_walk(ast, acc, c, fun); return acc; }
+void sgml_count(const std::vector<SN>& l, SCnt& c) { for (auto& e : l) { c.c++; if (e->k == S_TAG) { c.t++; sgml_count(e->kids, c); } } }
+// select/2 :381-404
+struct SSel { SN elem; long t = 0, c = 0; bool found = false; };
+void sgml_select(const std::vector<SN>& l, SCnt& c, bool want_tag, long n, SSel& r) {
+  for (auto& e : l) {
+    if (r.found) return;
+    if (e->k == S_TAG) {
+      c.t++; c.c++;
+      if (want_tag ? c.t == n : c.c == n) { r.elem = e; r.t = c.t; r.c = c.c; r.found = true; return; }
+      sgml_select(e->kids, c, want_tag, n, r);
+    } else {
+      c.c++;
+      if (!want_tag && c.c == n) { r.elem = e; r.t = c.t; r.c = c.c; r.found = true; return; }
+    }
+  }
+}
+SSel sgml_select_elem(const std::vector<SN>& ast, long n) { SSel r; SCnt c; sgml_select(ast, c, false, n, r); if (!r.found) throw ErlCrash("badmatch: select_elem"); return r; }
+SSel sgml_select_tag(const std::vector<SN>& ast, long n) { SSel r; SCnt c; sgml_select(ast, c, true, n, r); if (!r.found) throw ErlCrash("badmatch: select_tag"); return r; }
+
+std::vector<SN> sgml_replace_elem(const std::vector<SN>& ast, long r, const SN& el) {       // :445-454
+  return sgml_walk_top(ast, [&](const SN& e, std::vector<SN>& tree, long, long i) { tree.push_back(i == r ? el : e); });
+}
+std::vector<SN> sgml_repeat_elem(const std::vector<SN>& ast, long r, long times) {          // :456-468
+  return sgml_walk_top(ast, [&](const SN& e, std::vector<SN>& tree, long, long i) { tree.push_back(e); if (i == r) for (long k = 0; k < times; k++) tree.push_back(e); });
+}
+std::vector<SN> sgml_insert_elem(const std::vector<SN>& ast, long r, const SN& ne) {        // :470-477
+  return sgml_walk_top(ast, [&](const SN& e, std::vector<SN>& tree, long, long i) { tree.push_back(e); if (i == r) tree.push_back(ne); });
+}
+SN sgml_pump_path(SN start, long end, long n) {                                             // :488-499
+  for (; n > 0; n--) {
+    std::vector<SN> one{start};
+    std::vector<SN> res = sgml_walk_top(one, [&](const SN& e, std::vector<SN>& tree, long, long i) { tree.push_back(i == end ? start : e); });
+    if (res.empty()) throw ErlCrash("badarg: hd([])");
+    start = res[0]; end = end * 2 - 1;
+  }
+  return start;
+}
+std::string ssrf_uri(Ctx& c) { return "://" + c.cfg->ssrf_host + ":" + std::to_string(c.cfg->ssrf_port) + "/"; }   // get_ssrf_uri :727-731
+bool sparams_eq(const std::vector<SParam>& a, const std::vector<SParam>& b) {
+  if (a.size() != b.size()) return false;
+  for (size_t i = 0; i < a.size(); i++) if (a[i].name != b[i].name || a[i].value != b[i].value || a[i].delim != b[i].delim) return false;
+  return true;
+}
+// Erlang term order on {Name, Value, Delim} tuples of strings (ties of random_permutation/1's sort keys)
+int bytes_cmp(const Bytes& a, const Bytes& b) { size_t m = std::min(a.size(), b.size()); int r = m ? memcmp(a.data(), b.data(), m) : 0; if (r) return r; return a.size() < b.size() ? -1 : (a.size() > b.size() ? 1 : 0); }
+bool sparam_less(const SParam& a, const SParam& b) {
+  int r = bytes_cmp(a.name, b.name); if (r) return r < 0;
+  r = bytes_cmp(a.value, b.value); if (r) return r < 0;
+  auto ds = [](int d) { return d == 0 ? Bytes{} : (d == 1 ? Bytes{'\''} : Bytes{'"'}); };
+  return bytes_cmp(ds(a.delim), ds(b.delim)) < 0;
+}
+std::vector<Muta> inner_muta(Ctx& c, const std::vector<int>& names) {                       // inner_mutations/1 :1346-1356 + mutators_mutator/1
+  std::vector<Muta> table = mutations_table(c.rnd), sel;
+  for (auto& m : table) for (int nm : names) if (m.name == nm) { sel.insert(sel.begin(), m); break; }
+  return mutators_mutator(c.rnd, sel);
+}
+
+// sgml_mutation/2,3 :696-737
+std::vector<SN> sgml_mutation(Ctx& c, const std::vector<SN>& ast, long n, long nt, int* d) {
+  uint64_t r = c.rnd.rand(12);
+  *d = 1;
+  switch (r) {
+    case 0: {                                                                 // sgml_swap :530-543
+      long r1 = (long)c.rnd.erand(n), r2 = (long)c.rnd.erand(n);
+      SN e1 = sgml_select_elem(ast, r1).elem, e2 = sgml_select_elem(ast, r2).elem;
+      return sgml_walk_top(ast, [&](const SN& e, std::vector<SN>& tree, long, long i) { tree.push_back(i == r1 ? e2 : (i == r2 ? e1 : e)); });
+    }
+    case 1: { long rr = (long)c.rnd.erand(n); return sgml_repeat_elem(ast, rr, 1); }          // sgml_dup :522-524
+    case 2: {                                                                 // sgml_pump :502-520
+      *d = -2;
+      if (nt == 0) return ast;
+      long rr = (long)c.rnd.erand(nt);
+      SSel st = sgml_select_tag(ast, rr);
+      SCnt cc; std::vector<SN> one{st.elem}; sgml_count(one, cc);
+      long e = (long)c.rnd.erand((uint64_t)(cc.c - 1)) + 1;                   // not the tag itself
+      long pc = (long)c.rnd.erand((uint64_t)std::trunc(1000.0 / (100.0 + (double)cc.c)));
+      SN pumped = sgml_pump_path(st.elem, e, pc);
+      return sgml_replace_elem(ast, st.c, pumped);
+    }
+    case 3: { long rr = (long)c.rnd.erand(n); long times = (long)c.rnd.erand(100); return sgml_repeat_elem(ast, rr, times); }   // sgml_repeat :526-528
+    case 4: {                                                                 // sgml_insert2 :565-569
+      long r1 = (long)c.rnd.erand(n), r2 = (long)c.rnd.erand(n);
+      SN ne = sgml_select_elem(ast, r1).elem;
+      return sgml_insert_elem(ast, r2, ne);
+    }
+    case 5: {                                                                 // sgml_permparams :571-579
+      long rr = (long)c.rnd.erand(nt);
+      return sgml_walk_top(ast, [&](const SN& e, std::vector<SN>& tree, long t, long) {
+        if (e->k == S_TAG && t == rr) { auto x = std::make_shared<SNode>(*e); x->params = c.rnd.random_permutation(e->params, sparam_less); tree.push_back(x); }
+        else tree.push_back(e);
+      });
+    }
+    case 6: {                                                                 // sgml_breaktag :581-592
+      long rr = (long)c.rnd.erand(nt);
+      return sgml_walk_top(ast, [&](const SN& e, std::vector<SN>& tree, long t, long) {
+        if (e->k == S_TAG && t == rr) {
+          // Internals ++ [{open,..} | Tree] on the reversed accumulator: the open tag, then the children in
+          // REVERSE order once the accumulator is reversed back
+          bool open = c.rnd.rand(1) == 0;
+          auto x = std::make_shared<SNode>(); x->k = open ? S_OPEN : S_CLOSE; x->name = open ? e->name : e->close_name; if (open) x->params = e->params;
+          tree.push_back(x);
+          for (size_t k = e->kids.size(); k-- > 0;) tree.push_back(e->kids[k]);
+        } else tree.push_back(e);
+      });
+    }
+    case 7: {                                                                 // sgml_insert :547-562
+      long r1 = (long)c.rnd.erand(n), r2 = (long)c.rnd.erand(n);
+      SN ne = sgml_select_elem(ast, r1).elem;
+      if (ne->k != S_TAG) return sgml_insert_elem(ast, r2, ne);
+      return sgml_walk_top(ast, [&](const SN& e, std::vector<SN>& tree, long, long i) {
+        if (i == r2) { auto x = std::make_shared<SNode>(*ne); x->kids.clear(); x->kids.push_back(e); tree.push_back(x); }
+        else tree.push_back(e);
+      });
+    }
+    case 8: {                                                                 // sgml_xmlfeatures(Ast, NT, 1) :651-665
+      if (nt <= 0) { *d = -1; return ast; }
+      std::string uri = "http" + ssrf_uri(c);
+      bool changed = false;
+      std::vector<SN> res = sgml_walk_top(ast, [&](const SN& e, std::vector<SN>& tree, long t, long) {
+        if (e->k != S_TAG) { tree.push_back(e); return; }
+        if (c.rnd.erand((uint64_t)std::trunc((double)t * 1.5)) != 1) { tree.push_back(e); return; }     // xmlns_modify/2 :618-625
+        std::vector<SParam> np;                                               // xmlns_modify_params/1,2 :594-616
+        for (auto& p : e->params) {
+          if (p.name.size() >= 5 && memcmp(p.name.data(), "xmlns", 5) == 0) {
+            SParam q = p;
+            if (c.rnd.erand(2) == 1) { const char* sp = " "; q.value.insert(q.value.end(), sp, sp + 1); q.value.insert(q.value.end(), uri.begin(), uri.end()); }
+            else q.value.assign(uri.begin(), uri.end());
+            np.push_back(q);
+          } else np.push_back(p);
+        }
+        if (sparams_eq(np, e->params)) {
+          std::vector<SParam> pre;
+          for (const char* nm : {"xmlns", "xmlns:xsi", "xsi:schemaLocation"}) { SParam q; q.name.assign(nm, nm + strlen(nm)); q.value.assign(uri.begin(), uri.end()); q.delim = 2; pre.push_back(q); }
+          pre.insert(pre.end(), e->params.begin(), e->params.end());
+          np = pre;
+        }
+        auto x = std::make_shared<SNode>(*e); x->params = np; tree.push_back(x); changed = true;
+      });
+      if (!changed) { *d = -1; return ast; }                                  // Ast =:= NewAst
+      return res;
+    }
+    default: break;
+  }
+  // inner text :727-737: walk2acc/3 :363-379 visits children before the tag itself
+  static const std::vector<int> names = {M_AB, M_AD, M_BD, M_B64, M_LD, M_LP, M_LRI, M_LR, M_NUM, M_SD, M_URI};   // `json` names nothing (:1343)
+  std::vector<Muta> muta = inner_muta(c, names);
+  auto mutate_innertext = [&](const Bytes& bin, long nt2) -> Bytes {          // :667-681
+    long nw = 0; for (uint8_t x : bin) if (x != 0 && x != 10 && x != 13 && x != 32) nw++;
+    if (!(nw > 0 && nt2 > 0)) return bin;
+    double rnd = c.rnd.rand_float();
+    if (rnd > 3.0 / (double)nt2) return bin;
+    std::vector<Muta> m = muta; BList one{bin};
+    mux_fuzzers(c, m, one);
+    if (one.empty()) throw ErlCrash("badarg: hd([])");
+    return one[0];
+  };
+  std::function<void(const std::vector<SN>&, std::vector<SN>&)> w2 = [&](const std::vector<SN>& l, std::vector<SN>& acc) {
+    for (auto& e : l) {
+      if (e->k == S_TAG) {
+        auto x = std::make_shared<SNode>(*e); x->kids.clear();
+        w2(e->kids, x->kids);
+        long np = (long)e->params.size();
+        for (auto& p : x->params) p.value = mutate_innertext(p.value, nt + np);             // try_mutate_innertext :683-690
+        acc.push_back(x);
+      } else if (e->k == S_TEXT) {
+        auto x = std::make_shared<SNode>(*e); x->text = mutate_innertext(e->text, nt); acc.push_back(x);
+      } else acc.push_back(e);
+    }
+  };
+  std::vector<SN> out; w2(ast, out);
+  return out;
+}
+
+int sgml_mutate(Ctx& c, BList& ll) {                                          // sgml_mutate/2 :739-757
+  const Bytes h = ll[0];
+  if (binarish(h)) return -1;                                                 // parse/2 :198-199
+  std::vector<STok> toks;
+  try { toks = sgml_tokenize(h); } catch (IncorrectSgml&) { return -1; } catch (SgmlOtherError&) { throw ErlCrash("function_clause in erlamsa_sgml:tz/2"); }
+  SBuild b = sgml_build(toks, 0, {});
+  if (b.st != 0) throw ErlCrash("try_clause: parse/1");
+  int d = 1;
+  std::vector<SN> res = sgml_mutation(c, b.ast, b.n, b.nt, &d);
+  Bytes nb; sgml_fold(res, nb);
+  if (nb == h) return -1;
+  ll[0] = nb;
+  return d + (int)(nb.size() / (AVG_BLOCK_SIZE * 10));
+}
+
+// ===========================================================================
 // erlamsa_patterns.erl
 // ===========================================================================
 enum PatId { P_OD, P_ND, P_BU, P_SK, P_SZ, P_CS, P_AR, P_CP, P_CO, P_NU, P_COUNT };
@@ -1838,6 +2278,8 @@ void setup_run(Run& run, const Config& cfg, int64_t s1, int64_t s2, int64_t s3) 
 void run_case(Run& run, const Config& cfg, const Bytes& input, Bytes* out, int* status, uint64_t* draws, std::string* trace) {
   int64_t t1 = (int64_t)run.parent.erand(99999), t2 = (int64_t)run.parent.erand(99999), t3 = (int64_t)run.parent.erand(99999);   // gen_predictable_seed :179
   Ctx c; c.cfg = &cfg; c.trace = trace;
+  EngineGuard guard; guard.max_bytes = cfg.max_case_bytes; guard.max_work = cfg.max_case_work;
+  if (guard.max_bytes || guard.max_work) c.guard = &guard;                    // engine caps requested by the test (not reference behaviour)
   c.rnd.seed(t1, t2, t3);                                                     // :183
   c.fs = run.muta;                                                            // CurMuta (not advanced between cases, :229-230)
   *status = EO_OK;
@@ -1982,6 +2424,28 @@ int32_t eo_lex_roundtrip(const uint8_t* in, uint64_t len, uint8_t* out) {
   if (u.size() != len) return -1;
   if (len) memcpy(out, u.data(), len);
   return (int32_t)cs.size();
+}
+
+// erlamsa_sgml:verify/1 (:768-773): fold_ast(parse(Str)); counts = {N, NT} of build_ast2.  kind 1: erlamsa_json
+// fold_ast(tokenize(Bin)) with counts {N, NT, NV}.  Returns 0, -1 for incorrect_sgml / incorrect_json, -2 for a crash.
+int32_t eo_parse_fold(int32_t kind, const uint8_t* in, uint64_t len, uint8_t** out, uint64_t* out_len, int64_t* counts) {
+  Bytes h(in, in + len), o;
+  try {
+    if (kind == 0) {
+      if (binarish(h)) return -1;
+      std::vector<STok> toks = sgml_tokenize(h);
+      SBuild b = sgml_build(toks, 0, {});
+      if (b.st != 0) return -2;
+      sgml_fold(b.ast, o); counts[0] = b.n; counts[1] = b.nt; counts[2] = 0;
+    } else {
+      std::vector<JTP> toks = json_tokenize(h);
+      JCnt cc; long nv = json_count_walk(j_list(toks), 0, cc);
+      json_fold(j_list(toks), o); counts[0] = cc.cnt; counts[1] = cc.ct; counts[2] = nv;
+    }
+  } catch (IncorrectSgml&) { return -1; } catch (IncorrectJson&) { return -1; } catch (SgmlOtherError&) { return -2; } catch (ErlCrash&) { return -2; }
+  *out = (uint8_t*)malloc(o.size() ? o.size() : 1); if (!o.empty()) memcpy(*out, o.data(), o.size());
+  *out_len = o.size();
+  return 0;
 }
 
 void eo_sort_by_priority(const int32_t* pri, uint32_t n, uint32_t* perm) {

@@ -63,6 +63,9 @@ int32_t eo_run_mutator(const char* name, int64_t a, int64_t b, int64_t c,
                        uint32_t* nblocks);
 // erlamsa_strlex:lex + unlex round trip; returns number of chunks, writes unlexed bytes.
 int32_t eo_lex_roundtrip(const uint8_t* in, uint64_t len, uint8_t* out);
+// kind 0: erlamsa_sgml fold_ast(parse(Bin)), counts = {N, NT, 0}; kind 1: erlamsa_json fold_ast(tokenize(Bin)),
+// counts = {N, NT, NV}.  0 ok, -1 incorrect_sgml/incorrect_json, -2 crash.
+int32_t eo_parse_fold(int32_t kind, const uint8_t* in, uint64_t len, uint8_t** out, uint64_t* out_len, int64_t* counts);
 // order of lists:sort/2 with the strict '>' comparator of erlamsa_utils:sort_by_priority
 // over `n` integer priorities; writes the permutation of input indices.
 void eo_sort_by_priority(const int32_t* pri, uint32_t n, uint32_t* perm);

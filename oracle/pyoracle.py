@@ -49,6 +49,8 @@ def lib():
         _lib.eo_run_mutator.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_uint64,
                                         C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         _lib.eo_lex_roundtrip.restype = C.c_int32
+        _lib.eo_parse_fold.restype = C.c_int32
+        _lib.eo_parse_fold.argtypes = [C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]
         _lib.eo_lex_roundtrip.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         _lib.eo_sort_by_priority.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         _lib.eo_free.argtypes = [C.c_void_p]
@@ -129,6 +131,20 @@ def lex_roundtrip(data):
     out = np.zeros(max(len(data), 1), dtype=np.uint8)
     n = lib().eo_lex_roundtrip(buf.ctypes.data, len(data), out.ctypes.data)
     return n, bytes(out[:len(data)])
+
+
+def parse_fold(kind, data):
+    """kind 'sgml' | 'json': (rc, folded bytes, counts) of the restated parser + serializer."""
+    buf = np.frombuffer(data, dtype=np.uint8).copy() if len(data) else np.zeros(1, dtype=np.uint8)
+    out = C.POINTER(C.c_uint8)()
+    olen = C.c_uint64()
+    cnt = (C.c_int64 * 3)()
+    rc = lib().eo_parse_fold(0 if kind == "sgml" else 1, buf.ctypes.data, len(data), C.byref(out), C.byref(olen), cnt)
+    if rc != 0:
+        return rc, b"", (0, 0, 0)
+    b = bytes(np.ctypeslib.as_array(out, shape=(max(olen.value, 1),))[:olen.value])
+    lib().eo_free(out)
+    return 0, b, tuple(int(x) for x in cnt)
 
 
 def sort_by_priority(pris):

@@ -27,7 +27,12 @@ SETS = [
     ("bytes_seq", (4, 5, 6), "bd,bei,bed,bf,bi,ber,br,sp,sr,sd,snand,srnd,uw,ui,nil", "od,nd,bu", 24, 200, "uniform"),
     ("text", (7, 8, 9), "num,ld,lds,lr2,lri,lr,ls,lp,lis,lrs,ab,ad,uri,b64,zip", "od,nd,bu", 24, 300, "mixed"),
     ("trees_len", (10, 11, 12), "tr2,td,ts1,ts2,tr,len", "od,nd,bu,sk,sz,cs", 24, 300, "mixed"),
-    ("hello", (1, 2, 3), None, "od,nd,bu", 1, 0, "hello"),
+    ("hello", (1, 2, 3), None, None, 1, 0, "hello"),
+    # the full default tables (41 mutators incl. sgm/js/b64/fuse, all 10 patterns)
+    ("default_mixed", (13, 14, 15), None, None, 48, 400, "mixed"),
+    ("default_json", (16, 17, 18), None, None, 32, 0, "json"),
+    ("default_sgml", (19, 20, 21), None, None, 32, 0, "sgml"),
+    ("sgm_js_only", (22, 23, 24), "sgm,js", "od,nd,bu", 48, 0, "docs"),
 ]
 
 
@@ -38,9 +43,14 @@ def main():
             inputs = [bytes(r) for r in synth.uniform(n, size, seed=seed[0])]
         elif kind == "mixed":
             inputs = [bytes(r) for r in synth.mixed(n, size, seed=seed[0])]
+        elif kind == "json":
+            inputs = synth.json_docs(n, seed=seed[0])
+        elif kind == "sgml":
+            inputs = synth.sgml_docs(n, seed=seed[0])
+        elif kind == "docs":
+            inputs = synth.json_docs(n // 2, seed=seed[0]) + synth.sgml_docs(n - n // 2, seed=seed[1])
         else:
-            inputs = [b"Hello erlamsa!\n"]
-            muts = "bd,bei,bed,bf,bi,ber,br,sp,sr,sd,snand,srnd,uw,ui,num,ld,lds,lr2,lri,lr,ls,lp,lis,lrs,ab,ad,tr2,td,ts1,ts2,tr,len,uri,zip,nil"
+            inputs = [b"Hello erlamsa!\n"]          # BASELINE configs[0] input; default mutators and patterns
         data, off = po.pack(inputs)
         outs, st, _, _ = po.fuzz_batch(data, off, seed=seed, mutations=muts, patterns=pats, max_case_bytes=256 << 10)
         vecs.append({"name": name, "seed": list(seed), "first_case": 1, "mutations": muts, "patterns": pats,

@@ -150,3 +150,58 @@ def test_json_mutator_properties():
     for bad in (b"not json at all", b'{"a" "b"}', b"]", b'"str"', b"42"):
         d, out, _ = po.run_mutator("js", (1, 2, 3), bad)
         assert d == -1 and out == bad
+
+
+def test_sgml_verify_roundtrip():
+    """erlamsa_sgml:verify/1 (:768-773): fold_ast(parse(Str)) =:= Str for canonically written documents;
+    same for erlamsa_json fold_ast(tokenize(Bin)) on compact JSON."""
+    from erlamsa_amd import synth
+    for d in synth.sgml_docs(400, seed=11):
+        rc, out, (n, nt, _) = po.parse_fold("sgml", d)
+        assert rc == 0 and out == d and n >= 1 and nt <= n
+    for d in synth.json_docs(400, seed=11):
+        rc, out, (n, nt, nv) = po.parse_fold("json", d)
+        assert rc == 0 and out == d and nv <= n and nt <= n
+
+
+def test_sgml_tokenizer_quirks():
+    """Behaviour that follows from the reference's clauses and is easy to get wrong."""
+    # leading text before the first '<' is dropped (tz(nil, ..) :100-101); ws after '<' and inside tags is dropped
+    assert po.parse_fold("sgml", b"junk < a  b = 'c'  d >t</a >")[1] == b"<a b='c' d>t</a>"
+    # a '<' whose tag does not parse becomes text, minus the white space that followed it (:79-96)
+    assert po.parse_fold("sgml", b"<a>1 <  2 = 3</a>")[1] == b"<a>1 <2 = 3</a>"
+    # ?ok(X) is always true: quotes, '<' and '/' are name characters
+    assert po.parse_fold("sgml", b"<a/b c\"d>x")[1] == b"<a/b c\"d>x"
+    # empty attribute values lose their quotes (fold_params :297-298)
+    assert po.parse_fold("sgml", b"<a b=\"\" c=''>")[1] == b"<a b c>"
+    # close of an outer tag closes it early; the inner open tag is kept as a bare {open,..} (:226-235)
+    rc, out, (n, nt, _) = po.parse_fold("sgml", b"<a><b>x</a>y</b>")
+    assert (rc, out, n, nt) == (0, b"<a><b>x</a>y</b>", 5, 1)
+    # unterminated comment as the FIRST tag: function_clause outside any try -> the worker dies
+    assert po.parse_fold("sgml", b"<!-- never closed")[0] == -2
+    assert po.run_mutator("sgm", (1, 2, 3), b"<!-- never closed")[0] is None
+    # ... but inside the text state it is caught and the '<' becomes text
+    assert po.parse_fold("sgml", b"<a><!-- never closed")[1] == b"<a><!-- never closed"
+    # binarish blocks and blocks without '<' fail with delta -1 and no draw
+    assert po.run_mutator("sgm", (1, 2, 3), b"\x00<a>")[0] == -1
+    assert po.run_mutator("sgm", (1, 2, 3), b"plain")[:2] == (-1, b"plain")
+    # case-insensitive pairing, the close tag keeps its spelling
+    assert po.parse_fold("sgml", b"<DIV>x</div>") == (0, b"<DIV>x</div>", (2, 1, 0))
+
+
+def test_sgml_mutator_properties():
+    """sgml_mutate/2 :739-757 restated: pure function of the seed, every output parses again, and the
+    twelve mutation kinds are all reachable on a small document."""
+    doc = b"<?xml v='1'?><r xmlns='u' a=b><i>one</i><i k=\"v\">two 22</i><e /><!-- c --></r>tail"
+    outs = set()
+    for s in range(1, 400):
+        seed = (s, 3 * s + 1, 5 * s + 2)
+        d1, o1, _ = po.run_mutator("sgm", seed, doc)
+        assert (d1, o1) == po.run_mutator("sgm", seed, doc)[:2]
+        assert d1 is not None
+        outs.add(o1)
+        if o1 != doc and b"<" in o1 and not o1.startswith(b"\x00"):
+            assert po.parse_fold("sgml", o1)[0] in (0, -1)
+    assert len(outs) > 100
+    assert any(o.count(b"<r ") > 1 for o in outs)            # pump / dup / repeat
+    assert any(b"xmlns:xsi" in o or b"u http://" in o or b"'http://localhost:51234/'" in o for o in outs)   # xmlns features
