@@ -244,6 +244,7 @@ struct Ctx {
   int r2; uint8_t* r2_ptr; uint32_t r2_len;   // optional second flushed region (fo: flush_bvecs(A, flush_bvecs(B, T)))
   int nfs;             // entries of the mux_fuzzers list (the entries themselves: LaneTab)
   uint64_t work_budget;
+  int depth;           // nesting depth of mux_fuzzers (b64 / sgm / js inner mutations re-enter the scheduler)
 };
 // The per-case context lives in LDS.  One workgroup is one wavefront, so there is exactly one Ctx per
 // workgroup and no synchronisation is needed.  As a stack object it was reached through generic
@@ -622,8 +623,10 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
     uint64_t mark = c.ws_used;
     // work budget: the reference kills a worker after maxrunningtime and records <<>>
     // (erlamsa_main.erl:211-220); the engine's deterministic analogue counts bytes
-    c.work += (uint64_t)h0.len * work_weight(fn);
-    if (c.work > c.work_budget) { c.status = CASE_BUDGET; return; }
+    if (c.work_budget) {                                                          // optional (eh_options.max_case_work, 0 = off)
+      c.work += (uint64_t)h0.len * work_weight(fn);
+      if (c.work > c.work_budget) { c.status = CASE_BUDGET; return; }
+    }
 #ifdef EH_PROF
     uint64_t pt0 = __builtin_readcyclecounter();
 #endif

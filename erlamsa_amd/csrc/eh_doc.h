@@ -1,0 +1,128 @@
+// eh_doc.h — piece lists: the common output form of the document mutators (sgm, js, b64).
+//
+// A document mutator never edits bytes in place.  Its tokenizer records, for every token, the
+// pieces of the token's canonical rendering (erlamsa_sgml:fold_ast/2, erlamsa_json:fold_ast/2) as
+// (pointer, length, repeat) triples that reference the input block, a small literal pool or a
+// temporary in the work area.  Every AST element of those modules is a contiguous token range, so a
+// structural mutation (swap, dup, repeat, insert, pump ...) is an edit script over piece ranges, and
+// the new block is produced by ONE gather at the end — the input is read once, the output written
+// once.
+//
+// wave_gather: pieces of <= 48 bytes are copied lane-per-piece (8 byte loads in flight per lane, no
+// cross-lane traffic), longer or repeated pieces wave-per-piece with the 16-byte movers.
+#pragma once
+#include "eh_lex.h"
+
+namespace eh {
+
+struct Piece { uint64_t ptr; uint32_t len; uint32_t rep; };
+
+EH_DEV void piece_put(Piece* t, uint32_t i, const void* p, uint32_t len, uint32_t rep = 1) {
+  if (EH_LANE == 0) { t[i].ptr = (uint64_t)p; t[i].len = len; t[i].rep = rep; }
+}
+EH_DEV uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, d);
+  return uni64(v);
+}
+EH_DEV uint32_t wave_max(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { uint32_t t = (uint32_t)__shfl_xor((int)v, d); v = t > v ? t : v; }
+  return uni(v);
+}
+EH_DEV uint64_t pieces_total(const Piece* t, uint32_t n) {
+  uint64_t s = 0;
+  for (uint32_t i = EH_LANE; i < n; i += 64) s += (uint64_t)t[i].len * t[i].rep;
+  return wave_sum64(s);
+}
+// dst[0, total) = concatenation of the pieces; the caller allocated `total` = pieces_total() bytes
+EH_DEV void wave_gather(uint8_t* dst, const Piece* t, uint32_t n) {
+  const int l = EH_LANE;
+  uint64_t pos = 0;
+  for (uint32_t base = 0; base < n; base += 64) {
+    uint32_t idx = base + (uint32_t)l;
+    uint64_t ptr = 0; uint32_t len = 0, rep = 1;
+    if (idx < n) { Piece p = t[idx]; ptr = p.ptr; len = p.len; rep = p.rep; }
+    uint64_t tl = (uint64_t)len * rep;
+    // exclusive offsets inside the batch (64-bit: a repeated piece can be large)
+    uint64_t inc = tl;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint64_t up = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)inc, d);
+      if (l >= d) inc += up;
+    }
+    uint64_t off = pos + inc - tl;
+    bool big = len > 48 || rep > 1;
+    uint32_t maxs = wave_max(big ? 0u : len);
+    const uint8_t* sp = (const uint8_t*)ptr;
+    uint8_t* dp = dst + off;
+    for (uint32_t i0 = 0; i0 < maxs; i0 += 8) {
+      uint8_t b[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) if (!big && i0 + k < len) b[k] = sp[i0 + k];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) if (!big && i0 + k < len) dp[i0 + k] = b[k];
+    }
+    unsigned long long bm = __ballot(big && tl > 0);
+    while (bm) {
+      int j = (int)__builtin_ctzll(bm); bm &= bm - 1;
+      uint64_t pj = readlane64(ptr, (uint32_t)j), oj = readlane64(off, (uint32_t)j);
+      uint32_t lj = (uint32_t)__builtin_amdgcn_readlane((int)len, j), rj = (uint32_t)__builtin_amdgcn_readlane((int)rep, j);
+      if (rj == 1) wave_copy(dst + oj, (const uint8_t*)pj, lj);
+      else wave_fill_periodic(dst + oj, (const uint8_t*)pj, lj, (uint64_t)lj * rj);
+    }
+    pos += readlane64(inc, 63);
+  }
+}
+// entries [a, b) of src appended to dst[*n ..)
+EH_DEV void pieces_append(Piece* dst, uint32_t* n, const Piece* src, uint32_t a, uint32_t b) {
+  if (b <= a) return;
+  uint32_t cnt = b - a, at = *n;
+  for (uint32_t i = EH_LANE; i < cnt; i += 64) dst[at + i] = src[a + i];
+  *n = at + cnt;
+}
+// gathers pieces [a, b) into a fresh temporary of the work area; returns it as one piece (ptr, len)
+EH_DEV bool pieces_materialize(Ctx& c, const Piece* t, uint32_t a, uint32_t b, uint8_t** out, uint32_t* outlen) {
+  wave_sync();
+  uint64_t tot = pieces_total(t + a, b - a);
+  if (tot > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; return false; }
+  uint8_t* d = ws_alloc(c, tot ? tot : 16);
+  if (!d) return false;
+  wave_gather(d, t + a, b - a);
+  wave_sync();
+  *out = d; *outlen = (uint32_t)tot;
+  return true;
+}
+// number of bytes of [p, p+n) that are not 0, 10, 13 or 32 (mutate_innertext, erlamsa_sgml.erl:675)
+struct IsInk { EH_DEV bool operator()(uint32_t b, uint32_t) const { return b != 0 && b != 10 && b != 13 && b != 32; } };
+
+// Muta([Bin], []) of a freshly scored mutator list: the nested scheduler call of base64_mutator
+// (erlamsa_mutations.erl:669-670), erlamsa_sgml:mutate_innertext_prob/4 (:669-672) and
+// erlamsa_json:mutate_innertext_prob/4 (:633-639).  Lane i holds entry i of the list.  Returns the number
+// of blocks of the resulting list, which sit at c.bl[c.nb .. c.nb + n) until the next nested call, or -1
+// with c.status set.  Defined in eh_engine.hip (it re-enters mux_fuzzers; real device recursion).
+__device__ int nested_fuzz(Ctx&, uint32_t e_pri, uint32_t e_meta, int nfs, const uint8_t* bin, uint32_t len);
+
+__constant__ uint8_t c_def_pri[M_COUNT] = {10, 3, 1, 2, 1, 1, 1, 1, 3, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 2, 2, 7, 1, 1, 0};
+
+// inner_mutations(sgml | json) (erlamsa_mutations.erl:1342-1356) + mutators_mutator/1 (:1387-1395):
+// mutations([]) is evaluated first (2 draws, :1313-1314), the filtered table is folded into reverse
+// table order, mutators_mutator draws rand(10) along that list and prepends => list in table order.
+EH_DEV void inner_table(Ctx& c, bool json, uint32_t* e_pri, uint32_t* e_meta, int* nfs) {
+  const int l = EH_LANE;
+  (void)rng_rand(c.rng, 3); (void)rng_rand(c.rng, 1);
+  const uint8_t sg[11] = {M_AB, M_AD, M_NUM, M_BD, M_SD, M_LD, M_LRI, M_LR, M_LP, M_B64, M_URI};
+  const uint8_t js[9] = {M_SGM, M_AB, M_AD, M_NUM, M_SP, M_SR, M_SD, M_B64, M_URI};
+  int n = json ? 9 : 11;
+  uint32_t name = 0;
+#pragma unroll
+  for (int k = 0; k < 11; k++) if (k == l) name = json ? (k < 9 ? js[k] : 0) : sg[k];
+  uint32_t score = 0;
+  if (l < n) { uint32_t v = (uint32_t)(rng_peek(c.rng, (uint32_t)(n - 1 - l) + 1) * 10.0); score = v < 2 ? 2 : v; }
+  rng_skip(c.rng, (uint64_t)n);
+  *e_pri = l < n ? (uint32_t)c_def_pri[name] : 0;
+  *e_meta = em_pack(score, name, name, 3u);
+  *nfs = n;
+}
+
+}  // namespace eh

@@ -26,6 +26,8 @@
 #include "eh_tree.h"
 #include "eh_field.h"
 #include "eh_fuse.h"
+#include "eh_doc.h"
+#include "eh_sgml.h"
 
 namespace eh {
 
@@ -46,8 +48,40 @@ EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
     case M_LEN: return muta_len(c);
     case M_FT: case M_FN: case M_FO: return muta_fuse(c, (int)fn, (FoState*)(c.aux + 704));
     case M_TR2: case M_TD: case M_TS1: case M_TS2: case M_TR: return muta_tree(c, (int)fn);
+    case M_SGM: return muta_sgml(c);
     default: c.status = CASE_UNSUPPORTED; c.r_kind = R_SAME; return 0;
   }
+}
+
+// Nested scheduler call (see eh_doc.h).  The inner list [Bin] lives above the outer block list; the stateful
+// mutators of the inner table (lis, lrs, fo) start from their initial state, as the closures of a fresh
+// mutators_mutator/1 do, so the outer states are parked in the work area for the duration of the call.
+constexpr int MAX_NEST = 6;
+__device__ __noinline__ int nested_fuzz(Ctx&, uint32_t e_pri, uint32_t e_meta, int nfs, const uint8_t* bin, uint32_t len) {
+  EH_CTX;
+  const int l = EH_LANE;
+  if (c.depth >= MAX_NEST || c.nb + 2 > MAX_BLOCKS) { c.status = CASE_OVERFLOW; return -1; }
+  constexpr uint32_t SAVE = 720;                                            // StState x 2 + FoState (aux + 0 .. 720)
+  uint32_t* save = (uint32_t*)ws_alloc(c, SAVE);
+  if (!save) return -1;
+  uint32_t* ax = (uint32_t*)c.aux;
+  for (uint32_t i = l; i < SAVE / 4; i += 64) save[i] = ax[i];
+  wave_sync();
+  if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; ((FoState*)(c.aux + 704))->has = 0; }
+  const int cur0 = c.cur, nb0 = c.nb, nfs0 = c.nfs, lastm0 = c.lastm;
+  blk_store(c.bl, nb0, (uint64_t)bin, len);
+  wave_sync();
+  c.cur = nb0; c.nb = nb0 + 1; c.nfs = nfs; c.depth++;
+  LaneTab lt; lt.e_pri = e_pri; lt.e_meta = e_meta;
+  mux_fuzzers(c, lt);
+  c.depth--;
+  int nres = c.nb - c.cur;
+  wave_sync();
+  for (uint32_t i = l; i < SAVE / 4; i += 64) ax[i] = save[i];
+  wave_sync();
+  c.cur = cur0; c.nb = nb0; c.nfs = nfs0; c.lastm = lastm0;
+  c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
+  return c.status == CASE_OK ? nres : -1;
 }
 
 // =============================================================================================
@@ -502,7 +536,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     uint64_t i = tk_next++;
     if (i >= p.n) break;
     uint64_t tick0 = __builtin_readcyclecounter();
-    c.work = 0;
+    c.work = 0; c.depth = 0;
     c.status = CASE_OK; c.lastm = -1; c.nb = 0; c.cur = 0; c.nem = 0; c.ws_used = 0;
     c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r2 = 0;
     if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; ((LexCache*)(c.aux + 1024))->n = -1; ((FoState*)(c.aux + 704))->has = 0; }
@@ -629,7 +663,7 @@ __global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf, const ui
 // host side
 // =============================================================================================
 static const MutaInfo MUTAS[M_COUNT] = {
-    {"sgm", 10, 0}, {"js", 3, 0},  {"uw", 1, 1},   {"ui", 2, 1},  {"ab", 1, 1},  {"ad", 1, 1},  {"tr2", 1, 1}, {"td", 1, 1},
+    {"sgm", 10, 1}, {"js", 3, 0},  {"uw", 1, 1},   {"ui", 2, 1},  {"ab", 1, 1},  {"ad", 1, 1},  {"tr2", 1, 1}, {"td", 1, 1},
     {"num", 3, 1},  {"ts1", 2, 1}, {"tr", 2, 1},   {"ts2", 2, 1}, {"bd", 1, 1},  {"bei", 1, 1}, {"bed", 1, 1}, {"bf", 1, 1},
     {"bi", 1, 1},   {"ber", 1, 1}, {"br", 1, 1},   {"sp", 1, 1},  {"sr", 1, 1},  {"sd", 1, 1},  {"snand", 1, 1}, {"srnd", 1, 1},
     {"ld", 1, 1},   {"lds", 1, 1}, {"lr2", 1, 1},  {"lri", 1, 1}, {"lr", 1, 1},  {"ls", 1, 1},  {"lp", 1, 1},  {"lis", 1, 1},
@@ -867,7 +901,7 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.corpus = ctx->d_corpus; p.coff = ctx->d_coff; p.corpus_first = corpus_first; p.n = n; p.first_case = first_case;
   p.mode = mode; p.run = ctx->d_run; p.seeds = ctx->d_seeds; p.cfg = ctx->cfg;
   p.slot_base = ctx->d_slots; p.slot_stride = ctx->slot_stride; p.work_cap = ctx->work_cap;
-  p.work_budget = ctx->work_budget ? ctx->work_budget : (8ull << 20);
+  p.work_budget = ctx->work_budget;                                            // 0 = no budget (the default)
   p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
   p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles;
   p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;
