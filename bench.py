@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cases", type=int, default=65536)
     ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--mutations", default=None, help="-m syntax; default: every mutator this build runs on the GPU")
+    ap.add_argument("--mutations", default=None, help="-m syntax; default: the reference's full default table (erlamsa_mutations.erl:1291-1331)")
     ap.add_argument("--patterns", default="od,nd,bu")
     ap.add_argument("--corpus", default="mixed", choices=["mixed", "uniform"],
                     help="mixed = BASELINE configs[2] (default); uniform = random bytes (configs[1] with --cases 1024 --size 256)")
@@ -85,8 +85,8 @@ def main():
     ap.add_argument("--max-slots", type=int, default=0)
     ap.add_argument("--out-gib", type=int, default=8, help="output arena capacity per context (GiB)")
     ap.add_argument("--case-mib", type=int, default=8, help="per-case work area (MiB), eh_options.max_case_bytes")
-    ap.add_argument("--work-mib", type=int, default=8, help="per-case work budget (MiB), eh_options.max_case_work: the "
-                    "deterministic stand-in for the reference's maxrunningtime watchdog")
+    ap.add_argument("--work-mib", type=int, default=0, help="optional per-case work budget (MiB), eh_options.max_case_work; "
+                    "0 = off (default): every case runs to completion like under the reference's 30 s CLI watchdog")
     ap.add_argument("--inflight", type=int, default=3, help="passes in flight (engine contexts / HIP streams)")
     args = ap.parse_args()
 
@@ -108,12 +108,8 @@ def main():
     torch.cuda.set_device(dev)
 
     n, size = args.cases, args.size
-    # Measured set = every mutator the GPU build runs end to end at production speed.  Left out and
-    # named in config.workload: b64 (GPU side is a probe: a chunk that really decodes is reported
-    # UNSUPPORTED), ft/fn/fo (bit-exact on the GPU but their sort-based refinement is not optimised
-    # yet: ~10 ms per call), sgm/js (not implemented).  `--mutations` overrides.
-    EXCLUDE = {"b64", "ft", "fn", "fo"}
-    muts = args.mutations or ",".join(m for m in ea.gpu_mutators() if m not in EXCLUDE)
+    # Measured set = the reference's full default mutator table (41 entries, default priorities) unless overridden.
+    muts = args.mutations or ",".join("%s=%d" % (m, p) for m, p, _ in ea.mutator_table())
     pats = args.patterns
     nmut_total = len(ea.mutator_table())
 
@@ -212,13 +208,13 @@ def main():
         # when the configuration matches, else null.
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_summary.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r02_summary.json")) as fh:
                 ps = json.load(fh)
             wk = ps["workload_key"]
             if (wk["cases"], wk["size"], wk["max_case_work"], wk["max_case_bytes"], wk["mutators"], wk["patterns"]) == \
                     (n, size, args.work_mib << 20, args.case_mib << 20, muts, pats):
                 traffic = int(ps["traffic_bytes_per_launch"]["total_fetch_x2_plus_write"])
-                traffic_src = "profiles/r01_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch)"
+                traffic_src = "profiles/r02_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch)"
         except (OSError, KeyError, ValueError):
             pass
         res = {
@@ -235,7 +231,7 @@ def main():
                                n, size, "mixed-binary corpus (50% random, 25% ASCII lines+numbers, 15% bracketed text, "
                                "10% length/CRC-framed)" if args.corpus == "mixed" else "uniform random bytes",
                                pats, muts, len(muts.split(",")), nmut_total,
-                               ",".join(m for m, _, _ in ea.mutator_table() if m not in muts.split(","))),
+                               ",".join(m for m, _, _ in ea.mutator_table() if m not in [x.split("=")[0] for x in muts.split(",")]) or "none"),
                 "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream before the W warm-up steps",
                 "max_case_bytes": args.case_mib << 20, "max_case_work": args.work_mib << 20,
             },

@@ -125,4 +125,74 @@ EH_DEV void inner_table(Ctx& c, bool json, uint32_t* e_pri, uint32_t* e_meta, in
   *nfs = n;
 }
 
+// base64_mutator/2 (erlamsa_mutations.erl:658-690): every text chunk longer than 6 that base64:decode/1 accepts
+// is decoded, mutated once by a FRESH mutators_mutator over the whole default table (mutas_list(mutations([])):
+// 2 draws for the table itself, then 41 score draws per chunk, list in REVERSE table order) and encoded again.
+__device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
+  EH_CTX;
+  const int l = EH_LANE;
+  Blk hb = blk_load(c.bl, c.cur);
+  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  c.r_kind = R_SAME;
+  LexChunk* tab;
+  int n = lex_cached(c, lc, H, L, &tab);
+  if (n < 0) return 0;
+  uint32_t snand_mask = rng_rand(c.rng, 3); (void)rng_rand(c.rng, 1);   // mutations([]) :661 -> :1313-1314
+  Piece* out = nullptr; uint32_t nout = 0, cap = 0, done_to = 0;
+  int dacc = -1;
+  for (int i = 0; i < n; i++) {
+    LexChunk e = tab[i];
+    uint32_t ty = uni(e.type), a = uni(e.a), b = uni(e.b);
+    if (ty != 0 || b - a <= 6) continue;
+    int dl = b64_decode(H + a, b - a, nullptr);
+    if (dl < 0) continue;                                        // error:badarg / function_clause :677-684
+    if (!out) {                                                  // first hit: the piece list of unlex(Ms)
+      cap = 2 * (uint32_t)(n - i) + 4;
+      out = (Piece*)ws_alloc(c, (uint64_t)cap * sizeof(Piece));
+      if (!out) return 0;
+    }
+    uint8_t* dec = ws_alloc(c, (uint64_t)dl + 16);
+    if (!dec) return 0;
+    (void)b64_decode(H + a, b - a, dec);
+    wave_sync();
+    int d = rng_delta(c.rng);                                    // :666
+    // mutators_mutator(MutasList, []) :667: rand(10) per table entry in table order, each prepended
+    uint32_t name = l < (int)M_COUNT ? (uint32_t)((int)M_COUNT - 1 - l) : 0;
+    uint32_t score = 0;
+    if (l < (int)M_COUNT) { uint32_t v = (uint32_t)(rng_peek(c.rng, name + 1) * 10.0); score = v < 2 ? 2 : v; }
+    rng_skip(c.rng, (uint64_t)M_COUNT);
+    uint32_t e_pri = l < (int)M_COUNT ? (uint32_t)c_def_pri[name] : 0;
+    uint32_t e_meta = em_pack(score, name, name, name == M_SNAND ? snand_mask : 3u);
+    int nres = nested_fuzz(c, e_pri, e_meta, (int)M_COUNT, dec, (uint32_t)dl);   // Muta([Bin], []) :668
+    if (nres < 0) return 0;
+    // NewBin = iolist_to_binary(NewLl) :669
+    uint64_t tot = 0;
+    for (int k = 0; k < nres; k++) tot += blk_load(c.bl, c.nb + k).len;
+    if (tot > 0xBFFFFFF0ull) { c.status = CASE_OVERFLOW; return 0; }
+    uint8_t* nb = ws_alloc(c, tot + 16);
+    uint8_t* enc = ws_alloc(c, (tot + 2) / 3 * 4 + 16);
+    if (!nb || !enc) return 0;
+    uint64_t o = 0;
+    for (int k = 0; k < nres; k++) { Blk x = blk_load(c.bl, c.nb + k); wave_copy(nb + o, (const uint8_t*)x.ptr, x.len); o += x.len; }
+    wave_sync();
+    b64_encode(nb, (uint32_t)tot, enc);
+    wave_sync();
+    piece_put(out, nout, H + done_to, a - done_to); nout++;
+    piece_put(out, nout, enc, (uint32_t)((tot + 2) / 3 * 4)); nout++;
+    done_to = b;
+    dacc += d;
+  }
+  if (!out) return -1;                                           // nothing decoded: unlex(lex(H)) =:= H
+  piece_put(out, nout, H + done_to, L - done_to); nout++;
+  wave_sync();
+  uint64_t total = pieces_total(out, nout);
+  if (total > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; return 0; }
+  uint8_t* dst = ws_alloc(c, total ? total : 16);
+  if (!dst) return 0;
+  wave_gather(dst, out, nout);
+  wave_sync();
+  c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)total;
+  return dacc;
+}
+
 }  // namespace eh

@@ -28,6 +28,7 @@
 #include "eh_fuse.h"
 #include "eh_doc.h"
 #include "eh_sgml.h"
+#include "eh_json.h"
 
 namespace eh {
 
@@ -49,6 +50,7 @@ EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
     case M_FT: case M_FN: case M_FO: return muta_fuse(c, (int)fn, (FoState*)(c.aux + 704));
     case M_TR2: case M_TD: case M_TS1: case M_TS2: case M_TR: return muta_tree(c, (int)fn);
     case M_SGM: return muta_sgml(c);
+    case M_JS: return muta_json(c);
     default: c.status = CASE_UNSUPPORTED; c.r_kind = R_SAME; return 0;
   }
 }
@@ -663,7 +665,7 @@ __global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf, const ui
 // host side
 // =============================================================================================
 static const MutaInfo MUTAS[M_COUNT] = {
-    {"sgm", 10, 1}, {"js", 3, 0},  {"uw", 1, 1},   {"ui", 2, 1},  {"ab", 1, 1},  {"ad", 1, 1},  {"tr2", 1, 1}, {"td", 1, 1},
+    {"sgm", 10, 1}, {"js", 3, 1},  {"uw", 1, 1},   {"ui", 2, 1},  {"ab", 1, 1},  {"ad", 1, 1},  {"tr2", 1, 1}, {"td", 1, 1},
     {"num", 3, 1},  {"ts1", 2, 1}, {"tr", 2, 1},   {"ts2", 2, 1}, {"bd", 1, 1},  {"bei", 1, 1}, {"bed", 1, 1}, {"bf", 1, 1},
     {"bi", 1, 1},   {"ber", 1, 1}, {"br", 1, 1},   {"sp", 1, 1},  {"sr", 1, 1},  {"sd", 1, 1},  {"snand", 1, 1}, {"srnd", 1, 1},
     {"ld", 1, 1},   {"lds", 1, 1}, {"lr2", 1, 1},  {"lri", 1, 1}, {"lr", 1, 1},  {"ls", 1, 1},  {"lp", 1, 1},  {"lis", 1, 1},
@@ -982,6 +984,9 @@ int eh_create(int device, eh_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return EH_E_NODEVICE; }
   ctx->cus = prop.multiProcessorCount;
+  // eh_mutate_kernel recurses (nested scheduler calls of b64 / sgm / js, depth <= MAX_NEST): ~1 KiB of private stack
+  // per level on top of the kernel's fixed 1.2 KiB
+  if (hipDeviceSetLimit(hipLimitStackSize, 8192) != hipSuccess) { delete ctx; return EH_E_HIP; }
   uint16_t t1[65], t2[65], t3[65];
   init_tables(t1, t2, t3);
   uint32_t crct[256];

@@ -375,56 +375,55 @@ __device__ __noinline__ int muta_zip(Ctx&) {
   return -1;
 }
 
-// base64_mutator :658-690 — decode probe.  A chunk that really decodes needs the nested
-// mutators_mutator (fresh default table); until that path exists it is reported as UNSUPPORTED.
-EH_DEV bool b64_decodes(const uint8_t* t, uint32_t n) {        // stdlib base64:decode/1 acceptance (otp_compat.h)
-  uint32_t ok = 0;
+// base64:decode/1 acceptance (stdlib, restated in oracle/otp_compat.h): groups of four sextets, "xx==" / "xxx="
+// tails, white space skipped anywhere, only white space after the padding.  Returns the decoded length or -1;
+// with dst != nullptr lane 0 also writes the bytes.
+EH_DEV int b64_decode(const uint8_t* t, uint32_t n, uint8_t* dst) {
+  int res = -1;
   if (EH_LANE == 0) {
-    uint32_t i = 0; bool good = true, done = false;
+    uint32_t i = 0, o = 0; bool good = true, done = false;
     while (!done) {
-      uint32_t q = 0; bool eq = false;
+      uint32_t q = 0, acc = 0; bool eq = false;
       while (i < n && q < 4) {
         uint32_t ch = t[i];
         if (ch == 9 || ch == 10 || ch == 13 || ch == 32) { i++; continue; }
         if (ch == '=') { eq = true; break; }
-        bool v = (ch >= 'A' && ch <= 'Z') || (ch >= 'a' && ch <= 'z') || (ch >= '0' && ch <= '9') || ch == '+' || ch == '/';
-        if (!v) { good = false; break; }
-        q++; i++;
+        uint32_t v;
+        if (ch >= 'A' && ch <= 'Z') v = ch - 'A'; else if (ch >= 'a' && ch <= 'z') v = ch - 'a' + 26; else if (ch >= '0' && ch <= '9') v = ch - '0' + 52;
+        else if (ch == '+') v = 62; else if (ch == '/') v = 63; else { good = false; break; }
+        acc = (acc << 6) | v; q++; i++;
       }
       if (!good) break;
-      if (q == 4) continue;
+      if (q == 4) { if (dst) { dst[o] = (uint8_t)(acc >> 16); dst[o + 1] = (uint8_t)(acc >> 8); dst[o + 2] = (uint8_t)acc; } o += 3; continue; }
       if (!eq) { good = (q == 0); break; }                       // input exhausted
       if (q == 2) {
         i++; while (i < n && (t[i] == 9 || t[i] == 10 || t[i] == 13 || t[i] == 32)) i++;
         if (i >= n || t[i] != '=') { good = false; break; }
         i++;
-      } else if (q == 3) i++;
+        if (dst) dst[o] = (uint8_t)(acc >> 4);
+        o += 1;
+      } else if (q == 3) { i++; if (dst) { dst[o] = (uint8_t)(acc >> 10); dst[o + 1] = (uint8_t)(acc >> 2); } o += 2; }
       else { good = false; break; }
       while (i < n) { uint32_t ch = t[i]; if (!(ch == 9 || ch == 10 || ch == 13 || ch == 32)) { good = false; break; } i++; }
       done = true;
     }
-    ok = good ? 1u : 0u;
+    res = good ? (int)o : -1;
   }
-  return uni((uint32_t)__shfl((int)ok, 0)) != 0;
+  return (int)uni((uint32_t)__shfl(res, 0));
 }
-__device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
-  EH_CTX;
-  Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
-  c.r_kind = R_SAME;
-  LexChunk* tab;
-  int n = lex_cached(c, lc, H, L, &tab);
-  if (n < 0) return 0;
-  (void)rng_rand(c.rng, 3); (void)rng_rand(c.rng, 1);           // mutas_list(mutations([])) :661 re-evaluates the table
-  for (int i = 0; i < n; i++) {
-    LexChunk e = tab[i];
-    uint32_t ty = uni(e.type), a = uni(e.a), b = uni(e.b);
-    if (ty != 0 || b - a <= 6) continue;
-    if (b64_decodes(H + a, b - a)) { c.status = CASE_UNSUPPORTED; return 0; }
+// base64:encode_to_string/1: lane g encodes the g-th 3-byte group
+EH_DEV void b64_encode(const uint8_t* src, uint32_t n, uint8_t* dst) {
+  uint32_t ng = (n + 2) / 3;
+  for (uint32_t g = EH_LANE; g < ng; g += 64) {
+    uint32_t i = 3 * g, rem = n - i;
+    uint32_t b0 = src[i], b1 = rem > 1 ? src[i + 1] : 0, b2 = rem > 2 ? src[i + 2] : 0;
+    uint32_t v = (b0 << 16) | (b1 << 8) | b2;
+    auto ch = [](uint32_t x) -> uint8_t { return (uint8_t)(x < 26 ? 'A' + x : (x < 52 ? 'a' + (x - 26) : (x < 62 ? '0' + (x - 52) : (x == 62 ? '+' : '/')))); };
+    dst[4 * g] = ch((v >> 18) & 63); dst[4 * g + 1] = ch((v >> 12) & 63);
+    dst[4 * g + 2] = rem > 1 ? ch((v >> 6) & 63) : (uint8_t)'=';
+    dst[4 * g + 3] = rem > 2 ? ch(v & 63) : (uint8_t)'=';
   }
-  return -1;
 }
-
 // uri_mutator :770-784 (+ try_uri_mutate :760-768, rand_uri_mutate :737-758)
 __device__ __noinline__ int muta_uri(Ctx&, LexCache& lc) {
   EH_CTX;

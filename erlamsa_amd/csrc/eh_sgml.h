@@ -74,8 +74,8 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   }
   nlt = wave_sum(nlt); nstop = wave_sum(nstop);
   if (nlt == 0) return -1;                                                 // tz(nil, <<>>) :102
-  uint32_t cap_tok = 2 * nlt + 2, cap_par = nstop + 2;
-  uint64_t cap_pc = 4ull * cap_tok + (uint64_t)SG_PARPCS * cap_par + nlt + 4;
+  uint32_t cap_tok = 2 * nlt + 8, cap_par = nstop + 8;
+  uint64_t cap_pc = 4ull * cap_tok + (uint64_t)SG_PARPCS * cap_par + nlt + 32;
   SgTok* tok = (SgTok*)ws_alloc(c, (uint64_t)cap_tok * sizeof(SgTok));
   SgParam* par = (SgParam*)ws_alloc(c, (uint64_t)cap_par * sizeof(SgParam));
   Piece* pc = (Piece*)ws_alloc(c, cap_pc * sizeof(Piece));

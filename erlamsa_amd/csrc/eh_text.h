@@ -438,55 +438,24 @@ __device__ inline void bd_interesting(BD& r, uint32_t idx, uint32_t* t1) {
   bd_add_abs(r, m, one); r.neg = false;
 }
 
-__device__ __noinline__ int muta_num(Ctx&) {
-  EH_CTX;                                  // sed_num :154-169
-  Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+// mutate_num/1,2 (erlamsa_mutations.erl:93-112) on the decimal number whose digits are H[s, e) (sign given
+// separately): draws first, then the arithmetic; the decimal text of the result (integer_to_list/1) is left
+// in *txt / *tlen (work-area memory).  Returns false after setting c.status (crash: float overflow in rand/1).
+__device__ __noinline__ bool num_core(Ctx&, const uint8_t* H, uint32_t L, uint32_t s, uint32_t e, bool negsign, uint8_t** txt_out, uint32_t* tlen_out) {
+  EH_CTX;
   const int l = EH_LANE;
-  c.r_kind = R_SAME;
-  // mutate_a_num/2: numbers = maximal digit runs, each extended left over the dashes before it
-  uint32_t nfound = wave_count(H, L, IsDigitStart());
-  uint32_t which = rng_rand(c.rng, nfound);
-  if (nfound == 0) {
-    // nothing to change; the data still goes through flush_bvecs (re-chunking counts as a change
-    // for blocks >= 2048 bytes, erlamsa_mutations.erl:157 + mux_fuzzers_loop :1278)
-    c.r_kind = R_NEW; c.r_ptr = (uint8_t*)H; c.r_len = L; c.r_flush = 1;
-    uint32_t r = rng_rand(c.rng, 10);
-    return r == 0 ? -1 : 0;
-  }
-  uint32_t s = wave_find_kth(H, L, nfound - 1 - which, IsDigitStart());
-  // end of the digit run / start of the dash run.  Fast path: one 64-byte window each way,
-  // resolved with ballots; runs longer than the window fall back to a lane-0 walk.
-  uint32_t e, a; bool fast_parse = false; uint64_t mag = 0;
-  {
-    uint32_t idx = s + (uint32_t)l;
-    uint32_t ch = idx < L ? H[idx] : 0;
-    unsigned long long dm = __ballot(ch >= 48 && ch <= 57);
-    uint32_t run = dm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~dm);
-    uint32_t ch2 = (uint32_t)l < s ? H[s - 1 - (uint32_t)l] : 0;
-    unsigned long long mm = __ballot((uint32_t)l < s && ch2 == 45);
-    uint32_t dr = mm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~mm);
-    if (run < 64 && dr < 64) {
-      e = s + run; a = s - dr;
-      if (run <= 18) {
-        fast_parse = true;
-        uint64_t part = 0;
-        if ((uint32_t)l < run) { uint64_t pw = 1; for (uint32_t k = (uint32_t)l + 1; k < run; k++) pw *= 10; part = (uint64_t)(ch - 48) * pw; }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) part += ((uint64_t)(uint32_t)__shfl_xor((int)(part >> 32), d) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)part, d);
-        mag = uni64(part);
-      }
-    } else {
-      uint32_t ee = s, aa = s;
-      if (l == 0) {
-        while (ee < L && H[ee] >= 48 && H[ee] <= 57) ee++;
-        while (aa > 0 && H[aa - 1] == 45) aa--;
-      }
-      e = uni(ee); a = uni(aa);
-    }
-  }
-  bool negsign = a < s;
   uint32_t nd = e - s;
+  bool fast_parse = false; uint64_t mag = 0;
+  if (nd <= 18) {
+    fast_parse = true;
+    uint32_t idx = s + (uint32_t)l;
+    uint32_t ch = (uint32_t)l < nd && idx < L ? H[idx] : 48;
+    uint64_t part = 0;
+    if ((uint32_t)l < nd) { uint64_t pw = 1; for (uint32_t k = (uint32_t)l + 1; k < nd; k++) pw *= 10; part = (uint64_t)(ch - 48) * pw; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += ((uint64_t)(uint32_t)__shfl_xor((int)(part >> 32), d) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)part, d);
+    mag = uni64(part);
+  }
   // ---- mutate_num/2 :93-112 : draws first (uniform), arithmetic afterwards
   uint32_t op = rng_rand(c.rng, 12);
   uint32_t ielem = 0, rl_n = 0, rl_s = 0; double u9 = 0.0; double u_hi = 0.0; uint32_t rl_k = 0;
@@ -566,26 +535,22 @@ __device__ __noinline__ int muta_num(Ctx&) {
     uint32_t ndig = nzm == 0 ? 1u : 64u - (uint32_t)__builtin_clzll(nzm);
     uint32_t sg = rneg ? 1u : 0u;
     uint32_t tlen = sg + ndig;
-    uint32_t nlen = a + tlen + (L - e);
-    uint8_t* dst = ws_alloc(c, nlen);
-    if (!dst) return 0;
-    wave_copy(dst, H, a);
-    if ((uint32_t)l < ndig) dst[a + sg + (ndig - 1 - (uint32_t)l)] = (uint8_t)(48 + dig);
-    if (rneg && l == 63) dst[a] = 45;
-    wave_copy(dst + a + tlen, H + e, L - e);
+    uint8_t* t = ws_alloc(c, 48);
+    if (!t) return false;
+    if ((uint32_t)l < ndig) t[sg + (ndig - 1 - (uint32_t)l)] = (uint8_t)(48 + dig);
+    if (rneg && l == 63) t[0] = 45;
     wave_sync();
-    c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = nlen; c.r_flush = 1;
-    return binarish(dst, nlen) ? -1 : 2;
+    *txt_out = t; *tlen_out = tlen;
+    return true;
   }
   // work arrays (lane 0): limbs for value, operand, result
   uint32_t nl = (nd + 8) / 9 + 8;
-  uint64_t mark = c.ws_used;
   uint32_t* va = (uint32_t*)ws_alloc(c, (uint64_t)nl * 4 + 64);
   uint32_t* vb = (uint32_t*)ws_alloc(c, (uint64_t)nl * 4 + 256);
   uint32_t* vr = (uint32_t*)ws_alloc(c, (uint64_t)nl * 4 + 256);
   uint64_t* wb = (uint64_t*)ws_alloc(c, 20 * 8);
   uint8_t* txt = ws_alloc(c, (uint64_t)nl * 9 + 64);
-  if (!va || !vb || !vr || !wb || !txt) return 0;
+  if (!va || !vb || !vr || !wb || !txt) return false;
   uint32_t tlen = 0, crashed = 0;
   if (l == 0) {
     BD num{va, 0, false}, opd{vb, 0, false}, res{vr, 0, false};
@@ -649,16 +614,58 @@ __device__ __noinline__ int muta_num(Ctx&) {
     if (!crashed) tlen = bd_to_text(res, txt);
   }
   wave_sync();
-  if (uni(crashed)) { c.status = CASE_CRASHED; return 0; }
-  tlen = uni(tlen);
-  uint8_t* dst = ws_alloc(c, (uint64_t)a + tlen + (L - e));
+  if (uni(crashed)) { c.status = CASE_CRASHED; return false; }
+  *txt_out = txt; *tlen_out = uni(tlen);
+  return true;
+}
+
+__device__ __noinline__ int muta_num(Ctx&) {
+  EH_CTX;                                  // sed_num :154-169
+  Blk hb = blk_load(c.bl, c.cur);
+  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  const int l = EH_LANE;
+  c.r_kind = R_SAME;
+  // mutate_a_num/2: numbers = maximal digit runs, each extended left over the dashes before it
+  uint32_t nfound = wave_count(H, L, IsDigitStart());
+  uint32_t which = rng_rand(c.rng, nfound);
+  if (nfound == 0) {
+    // nothing to change; the data still goes through flush_bvecs (re-chunking counts as a change
+    // for blocks >= 2048 bytes, erlamsa_mutations.erl:157 + mux_fuzzers_loop :1278)
+    c.r_kind = R_NEW; c.r_ptr = (uint8_t*)H; c.r_len = L; c.r_flush = 1;
+    uint32_t r = rng_rand(c.rng, 10);
+    return r == 0 ? -1 : 0;
+  }
+  uint32_t s = wave_find_kth(H, L, nfound - 1 - which, IsDigitStart());
+  // end of the digit run / start of the dash run: one 64-byte window each way resolved with ballots;
+  // runs longer than the window fall back to a lane-0 walk.
+  uint32_t e, a;
+  {
+    uint32_t idx = s + (uint32_t)l;
+    uint32_t ch = idx < L ? H[idx] : 0;
+    unsigned long long dm = __ballot(ch >= 48 && ch <= 57);
+    uint32_t run = dm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~dm);
+    uint32_t ch2 = (uint32_t)l < s ? H[s - 1 - (uint32_t)l] : 0;
+    unsigned long long mm = __ballot((uint32_t)l < s && ch2 == 45);
+    uint32_t dr = mm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~mm);
+    if (run < 64 && dr < 64) { e = s + run; a = s - dr; }
+    else {
+      uint32_t ee = s, aa = s;
+      if (l == 0) {
+        while (ee < L && H[ee] >= 48 && H[ee] <= 57) ee++;
+        while (aa > 0 && H[aa - 1] == 45) aa--;
+      }
+      e = uni(ee); a = uni(aa);
+    }
+  }
+  uint8_t* txt; uint32_t tlen;
+  if (!num_core(c, H, L, s, e, a < s, &txt, &tlen)) return 0;
+  uint32_t nlen = a + tlen + (L - e);
+  uint8_t* dst = ws_alloc(c, nlen);
   if (!dst) return 0;
   wave_copy(dst, H, a);
   wave_copy(dst + a, txt, tlen);
   wave_copy(dst + a + tlen, H + e, L - e);
   wave_sync();
-  (void)mark;
-  uint32_t nlen = a + tlen + (L - e);
   c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = nlen; c.r_flush = 1;
   return binarish(dst, nlen) ? -1 : 2;
 }

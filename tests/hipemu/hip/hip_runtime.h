@@ -214,6 +214,8 @@ inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "n
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+enum hipLimit_t { hipLimitStackSize = 0 };
+inline hipError_t hipDeviceSetLimit(hipLimit_t, size_t) { return hipSuccess; }   // fibers have 1 MiB stacks
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu (CPU wavefront emulator)"); strcpy(p->gcnArchName, "hipemu");
   p->multiProcessorCount = 1; p->totalGlobalMem = (size_t)8 << 30;

@@ -12,7 +12,7 @@ SEQ = "sp,sr,sd,snand,srnd"
 
 
 def _compare(inputs, mutations, patterns, seed=(1, 2, 3), generators=None, first_case=1, max_report=5, max_skipped=0.03,
-             oracle_cap=8 << 20, engine_cap=0, work=4 << 20):
+             oracle_cap=8 << 20, engine_cap=0, work=0):
     import pyoracle as po
     data, off = po.pack(inputs)
     okw = dict(seed=seed, mutations=mutations, patterns=patterns, generators=generators, first_case=first_case,
@@ -151,15 +151,62 @@ def _lexy_inputs(n, seed):
 
 @pytest.mark.parametrize("seed", [(1, 2, 3), (9, 8, 7)])
 def test_lexer_mutators(seed):
-    _compare(_lexy_inputs(500, seed[0]), LEXERS, "od,nd,bu", seed=seed, max_skipped=0.25)
+    _compare(_lexy_inputs(500, seed[0]), LEXERS, "od,nd,bu", seed=seed, max_skipped=0.05)
 
 
 def test_lexer_mutators_on_mixed_corpus():
-    _compare(_texty(200, 2048, 77), LEXERS + ",bd,bf", "od,nd,bu", max_skipped=0.25)
+    _compare(_texty(200, 2048, 77), LEXERS + ",bd,bf", "od,nd,bu", max_skipped=0.05)
 
 
 def test_lexer_with_everything_else():
-    _compare(_lexy_inputs(300, 5) + _texty(100, 1024, 5), LEXERS + "," + LINES + ",num," + BYTE_ALL + "," + SEQ + ",uw,ui,nil", "od,nd,bu", max_skipped=0.25)
+    _compare(_lexy_inputs(300, 5) + _texty(100, 1024, 5), LEXERS + "," + LINES + ",num," + BYTE_ALL + "," + SEQ + ",uw,ui,nil", "od,nd,bu", max_skipped=0.05)
+
+
+def _docs(n, seed):
+    from erlamsa_amd import synth
+    return synth.sgml_docs(n // 2, seed=seed) + synth.json_docs(n - n // 2, seed=seed + 1)
+
+
+ADVERSARIAL_DOCS = [
+    b'{"a" "b"', b'{"a" "b":1}', b'[1, 2', b'[1,2]x', b'{"a":1}', b'{1:2,[3]:{"x":null}}', b'"junk', b'true', b'truex', b'tru', b'nul',
+    b'[true,false,null]', b'  [ ]  ', b'{}', b'{ }', b'[[[[]]]]', b'{"k":[1,{"z":"dGhpcyBpcyBiYXNlNjQ="},"<a>x</a>"],"n":-0012,"m":+5,"e":1e5}',
+    b'[', b'{', b'{"a":', b'{"a"', b'{"a":1,', b'[1,,2]', b'[1 2]', b'"a":1', b'x', b'12 ', b' 12', b'"s"', b'[null]',
+    b'{"a":{"b":{"c":[1,2,3,{"d":"e"}]}}}', b'{"a":1}{"b":2}', b'[1]]', b':', b',', b']', b'{"a":1 "b":2}', b'{"a"::1}',
+    b'[{"a":1},{"a":1},{"a":1}]', b'{"long":"' + b'x' * 300 + b'"}', b'[' + b','.join(b'%d' % i for i in range(200)) + b']',
+    b'<a', b'<a>', b'< a >', b'<>', b'</>', b'<a/>', b'<a b/>', b'<a b=/>', b'<a b= c>', b'<a =b>', b'<a b="c>', b"<a b='c'd>", b'<!-->',
+    b'<!---->', b'<!-- x --', b'<a><!-- x --', b'<?x?>', b'<?x', b'<!x', b'<a></b></a>', b'<a><b><a></a></b></a>', b'<A></a><a></A>',
+    b'x<a>y<  z<b>w</b>', b'<a\n b\t=\r"v"\n>t</a\n>', b'<a b=c/>', b'<a b=c />', b'<a/b>', b'<a b="">', b'<a>1<b>2<c>3</a>4</c>5</b>6',
+    b'<p>' * 70 + b'x', b'<p>' * 70 + b'</p>' * 70, b'<a x=1 y=2 z=3 xmlns=u xmlns:q="v">t</a>', b'text only < not a tag',
+    b'<a>' + b'w' * 5000 + b'</a>', b'<a ' + b'k=v ' * 100 + b'>x</a>', b''.join(b'<i n="%d">v%d</i>' % (i, i) for i in range(150)),
+    b'<\xc9L>x</\xe9l>', b'<a>\x00</a>', b'<r><![CDATA[ <x> ]]></r>',
+    # base64 of base64 of base64 of "<a>hello world</a>": nested scheduler calls three deep
+    b'UEVFK2FHVnNiRzhnZDI5eWJHUThMMkUr', b'say "PGE+aGVsbG8gd29ybGQ8L2E+" and eyJrIjoiYUdWc2JHOD0ifQ== twice',
+]
+
+
+@pytest.mark.parametrize("seed", [(1, 2, 3), (4, 5, 6)])
+def test_sgml_json_documents(seed):
+    """sgm (erlamsa_sgml) and js (erlamsa_json) on well-formed documents: every mutation kind incl. the inner text
+    mutations that re-enter the scheduler with inner_mutations(sgml | json)."""
+    _compare(_docs(400, seed[0]), "sgm,js", "od,nd,bu", seed=seed, oracle_cap=4 << 20, engine_cap=4 << 20)
+
+
+def test_sgml_json_adversarial():
+    """Corner cases of the two tokenizers (tz/2 clause order, `catch _:_` in tokenize/1, contexts that never produce a
+    token, crashes outside any try), 12 runs each."""
+    _compare([d for d in ADVERSARIAL_DOCS for _ in range(12)], "sgm,js,b64", "od", seed=(2, 7, 1), oracle_cap=4 << 20, engine_cap=4 << 20)
+
+
+def test_b64_nested_default_table():
+    """base64_mutator success path: decoded chunks are mutated by a fresh mutators_mutator over the whole default table."""
+    _compare(_docs(300, 9) + [d for d in ADVERSARIAL_DOCS[-2:] for _ in range(50)], "b64", "od,nd,bu", oracle_cap=4 << 20, engine_cap=4 << 20)
+
+
+@pytest.mark.parametrize("kind", ["docs", "mixed"])
+def test_default_tables(kind):
+    """eh_options.mutations = patterns = NULL: the reference's full default tables (41 mutators, 10 patterns)."""
+    inputs = _docs(240, 3) if kind == "docs" else _texty(150, 1200, 6)
+    _compare(inputs, None, None, seed=(3, 4, 5), max_skipped=0.06, oracle_cap=4 << 20, engine_cap=4 << 20)
 
 
 TREES = "tr2,td,ts1,ts2,tr"

@@ -8,7 +8,7 @@ import erlamsa_amd as ea
 from erlamsa_amd import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-muts = sys.argv[2] if len(sys.argv) > 2 else ",".join(ea.gpu_mutators())
+muts = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "default" else None   # None = the full default table
 pats = sys.argv[3] if len(sys.argv) > 3 else "od,nd,bu"
 mat = synth.mixed(n, 4096)
 data, off = synth.as_arena(mat)
