@@ -261,6 +261,15 @@ struct LaneTab {
 };
 enum { R_SAME = 0, R_NEW = 1 };
 
+// EH_PROF builds: cycle counters per code region (eh_result_prof slots; 0..63 mutators, 64.. phases)
+#ifdef EH_PROF
+#define EH_PT0 uint64_t pt_ = __builtin_readcyclecounter()
+#define EH_PT(c, k) do { uint64_t n_ = __builtin_readcyclecounter(); if (EH_LANE == 0) { atomicAdd(&(c).p->prof[2 * (k)], (unsigned long long)(n_ - pt_)); atomicAdd(&(c).p->prof[2 * (k) + 1], 1ull); } pt_ = n_; } while (0)
+#else
+#define EH_PT0 do {} while (0)
+#define EH_PT(c, k) do {} while (0)
+#endif
+
 EH_DEV uint8_t* ws_alloc(Ctx& c, uint64_t n) {
   uint64_t need = (n + 15) & ~(uint64_t)15;
   if (c.ws_used + need > c.ws_cap) { c.status = CASE_OVERFLOW; return nullptr; }

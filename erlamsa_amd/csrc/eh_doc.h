@@ -35,6 +35,56 @@ EH_DEV uint64_t pieces_total(const Piece* t, uint32_t n) {
   for (uint32_t i = EH_LANE; i < n; i += 64) s += (uint64_t)t[i].len * t[i].rep;
   return wave_sum64(s);
 }
+// Merges neighbours that are adjacent in memory (ptr + len == next ptr, no repeats) IN PLACE and returns the new
+// count.  Tokenizers point their "literal" pieces at the input bytes whenever the input spells the canonical form,
+// so an unedited stretch of a document collapses into one long piece and the gather below moves it with 16-byte
+// vectors instead of a lane per 1-byte piece.
+EH_DEV uint32_t pieces_coalesce(Piece* t, uint32_t n) {
+  const int l = EH_LANE;
+  uint32_t nout = 0;
+  uint64_t carry_end = 0; bool have_carry = false;                  // end address of the last written piece (if mergeable)
+  for (uint32_t base = 0; base < n; base += 64) {
+    uint32_t idx = base + (uint32_t)l;
+    Piece p = {0, 0, 1};
+    if (idx < n) p = t[idx];
+    bool valid = idx < n && p.len > 0;                             // empty pieces vanish
+    bool plain = p.rep == 1;
+    // does my piece continue its valid predecessor?  (predecessor = nearest lower valid lane, or the carry)
+    unsigned long long vm = __ballot(valid);
+    unsigned long long below = vm & ((1ull << l) - 1);
+    int pl = below ? 63 - (int)__builtin_clzll(below) : -1;
+    uint64_t pend = readlane64(p.ptr + p.len, (uint32_t)(pl < 0 ? 0 : pl));
+    bool pplain = __shfl((int)(plain ? 1 : 0), pl < 0 ? 0 : pl) != 0;
+    if (pl < 0) { pend = carry_end; pplain = have_carry; }
+    bool cont = valid && plain && pplain && pend == p.ptr;
+    bool head = valid && !cont;
+    unsigned long long hm = __ballot(head);
+    // run = head .. next head: total length by a segmented sum
+    uint32_t hi = (uint32_t)__popcll(hm & ((2ull << l) - 1));       // 1-based index of my run among this batch's heads (0: continues the carry)
+    // lengths: sum over the lanes of my run
+    uint32_t len = valid ? p.len : 0u;
+    uint32_t inc = wave_incl_scan(len);
+    // run end lane = (next head lane) - 1 or 63
+    unsigned long long after = hm & ~((2ull << l) - 1);
+    int endl = after ? (int)__builtin_ctzll(after) - 1 : 63;
+    uint32_t run_total = (uint32_t)__shfl((int)inc, endl) - (inc - len);
+    wave_sync();                                                    // all lanes have loaded their piece before the table is overwritten
+    if (head) { Piece q; q.ptr = p.ptr; q.len = run_total; q.rep = p.rep; t[nout + hi - 1] = q; }
+    // pieces before the first head continue the carried piece
+    uint32_t first_head = hm ? (uint32_t)__builtin_ctzll(hm) : 64u;
+    uint32_t carry_add = first_head > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(first_head - 1)) : 0u;
+    if (carry_add > 0 && l == 0 && nout > 0) t[nout - 1].len += carry_add;
+    nout += (uint32_t)__popcll(hm);
+    // new carry: the last valid piece of the batch
+    if (vm) {
+      int last = 63 - (int)__builtin_clzll(vm);
+      carry_end = readlane64(p.ptr + p.len, (uint32_t)last);
+      have_carry = __shfl((int)(plain ? 1 : 0), last) != 0;
+    }
+    wave_sync();
+  }
+  return nout;
+}
 // dst[0, total) = concatenation of the pieces; the caller allocated `total` = pieces_total() bytes
 EH_DEV void wave_gather(uint8_t* dst, const Piece* t, uint32_t n) {
   const int l = EH_LANE;
@@ -140,12 +190,18 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
   uint32_t snand_mask = rng_rand(c.rng, 3); (void)rng_rand(c.rng, 1);   // mutations([]) :661 -> :1313-1314
   Piece* out = nullptr; uint32_t nout = 0, cap = 0, done_to = 0;
   int dacc = -1;
-  for (int i = 0; i < n; i++) {
-    LexChunk e = tab[i];
-    uint32_t ty = uni(e.type), a = uni(e.a), b = uni(e.b);
-    if (ty != 0 || b - a <= 6) continue;
+  // candidate chunks ({text, A} when length(A) > 6, :664) are picked 64 table entries at a time
+  for (int base = 0; base < n; base += 64) {
+   int ti = base + l;
+   uint32_t cty = 1, ca = 0, cb = 0;
+   if (ti < n) { LexChunk e = tab[ti]; cty = e.type; ca = e.a; cb = e.b; }
+   unsigned long long cand = __ballot(cty == 0 && cb - ca > 6);
+   while (cand) {
+    int cj = (int)__builtin_ctzll(cand); cand &= cand - 1;
+    int i = base + cj;
+    uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)ca, cj), b = (uint32_t)__builtin_amdgcn_readlane((int)cb, cj);
+    if (!b64_accepts(H + a, b - a)) continue;                    // error:badarg / function_clause :677-684
     int dl = b64_decode(H + a, b - a, nullptr);
-    if (dl < 0) continue;                                        // error:badarg / function_clause :677-684
     if (!out) {                                                  // first hit: the piece list of unlex(Ms)
       cap = 2 * (uint32_t)(n - i) + 4;
       out = (Piece*)ws_alloc(c, (uint64_t)cap * sizeof(Piece));
@@ -181,6 +237,7 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
     piece_put(out, nout, enc, (uint32_t)((tot + 2) / 3 * 4)); nout++;
     done_to = b;
     dacc += d;
+   }
   }
   if (!out) return -1;                                           // nothing decoded: unlex(lex(H)) =:= H
   piece_put(out, nout, H + done_to, L - done_to); nout++;

@@ -1,35 +1,31 @@
 // eh_fuse.h — device code for erlamsa_fuse:fuse/2 (erlamsa_fuse.erl:47-134) and the mutators
 // ft, fn, fo (erlamsa_mutations.erl:380-427).
 //
-// find_jump_points/2 refines a list of nodes {source suffixes, target suffixes} one character per
-// round: suffixes are grouped by their next byte and a source group survives if the target side
-// has the same byte.  Suffixes are positions, so a round is: key every live suffix with
-// (node, next byte, list index), SORT (the reference builds every group by prepending and the node
-// list by prepending, i.e. everything comes out in descending order of (node, byte, index)), cut
-// the sorted sequence into groups with ballot/prefix scans, and join source groups with target
-// groups by binary search.  The PRNG draws (one rand(8) per round, rand_elem x3 at the end) are
-// the reference's.
+// See fuse_round() below for how find_jump_points/2 is run on one wavefront.
 #pragma once
 #include "eh_field.h"
 
 namespace eh {
 
-struct FuseSide {
-  const uint8_t* s; uint32_t len;     // the byte list
-  uint32_t* pos;                      // suffix start positions (len == empty suffix), grouped by node
-  uint32_t* node;                     // node index of every entry
-  uint32_t n;                         // live entries
-  Key2* keys;                         // entries in group order: hi = group key << 32 | ..., lo = next position
-  uint32_t* gid;                      // group index of every sorted entry
-  uint32_t* bstart;                   // group starts in sorted order (+1 sentinel)
-  uint64_t* bkey;                     // group key = (nn-1-node) << 8 | (255-byte)
-  uint32_t* bcnt;                     // group size after fix_empty_list
-  uint32_t* child;                    // child node built from this group (or NONE)
-  uint32_t* nfirst;                   // per (reversed) node: first group and one past its last group
-  uint32_t* nend;
-  uint32_t nb;
-};
-constexpr uint32_t FUSE_NONE = 0xFFFFFFFFu, FUSE_SPECIAL = 0xFFFFFFFEu;
+// ---------------------------------------------------------------------------------------------
+// find_jump_points/2 as an MSD radix refinement, one byte per round, in ONE ordered pass per round.
+//
+// A node is {fo, fc, to, tc}: its source suffixes F[fo, fo+fc) and target suffixes T[to, to+tc) (start positions;
+// len = the empty suffix).  The reference builds every child list and the new node list by prepending, so its
+// lists come out reversed every round; here the arrays are kept in REFERENCE order on even generations and in
+// REVERSED reference order on odd ones, which turns every round into the same stable operation:
+//   for the nodes in array order, for the next bytes in ascending (even -> odd) or descending (odd -> even)
+//   order: child = {source entries with that byte, target entries with that byte}, in array order.
+// (fix_empty_list/1 :58-60 drops the entry whose rest is [] when it is inserted FIRST into its group, i.e. when it
+// is the group's first member in reference order: first in array order on even generations, last on odd ones.)
+// Three paths, chosen per run of nodes, all writing children in node order behind running counters:
+//   * a run of {1,1} nodes — the steady state on most data: one node per lane, two byte loads and a compare;
+//   * whole nodes packed into <= 64 source and <= 64 target entries: one entry per lane, register bitonic sort by
+//     (node, byte), groups from neighbour compares, source/target groups joined by shuffle binary search;
+//   * a node with more than 64 entries on a side: 256-bin LDS histograms + ballot-matched stable scatter.
+// The PRNG draws (one rand(8) per round, rand_elem x3 at the end) are the reference's.
+// ---------------------------------------------------------------------------------------------
+struct FNode { uint32_t fo, fc, to, tc; };
 
 // ascending bitonic sort of one 32-bit key per lane
 EH_DEV uint32_t wave_sort64(uint32_t key) {
@@ -47,120 +43,235 @@ EH_DEV uint32_t wave_sort64(uint32_t key) {
   }
   return key;
 }
+// number of leading lanes (of the first cnt) whose ascending value v is <= x  (v held one per lane)
+EH_DEV uint32_t lanes_le(uint32_t v, uint32_t cnt, uint32_t x) {
+  uint32_t lo = 0;
+#pragma unroll
+  for (uint32_t s = 32; s > 0; s >>= 1) { uint32_t t = (uint32_t)__shfl((int)v, (int)((lo + s - 1) & 63)); if (lo + s <= cnt && t <= x) lo += s; }
+  { uint32_t t = (uint32_t)__shfl((int)v, (int)(lo & 63)); if (lo < cnt && t <= x) lo++; }   // (the shuffle itself must not diverge)
+  return lo;
+}
+EH_DEV uint32_t lanes_lt(uint32_t v, uint32_t cnt, uint32_t x) { uint32_t r = lanes_le(v, cnt, x ? x - 1 : 0u); return x == 0 ? 0u : r; }
 
-// Orders the live suffixes of one side the way the reference's prepending builds its groups and node
-// list — descending (node, next byte, list index), the empty suffix dropped (`([], Subs) -> Subs`) —
-// and cuts them into groups.  The entries arrive grouped by node (seg[k]..seg[k+1]), so this is a stable
-// counting sort by the next byte inside every segment, mirrored: segments of more than 64 entries use
-// a 256-bin histogram in the work area (ballot match for the stable ranks), smaller ones are packed up
-// to 64 segments per step and ordered by a register bitonic network.  (A full comparison sort of
-// 128-bit keys per round cost ~10 ms per fuse call.)
-EH_DEV void fuse_group(FuseSide& x, uint32_t nn, const uint32_t* seg, uint32_t* hist) {
+struct FuseGen { FNode* nd; uint32_t* F; uint32_t* T; };
+
+// one refinement round over all nodes of `g` (generation parity par) into `o`; returns the number of children
+EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, const FuseGen& g, uint32_t nn, const FuseGen& o, uint32_t par, uint32_t* hist) {
   const int l = EH_LANE;
-  uint32_t nvalid = 0;
-  for (uint32_t base = 0; base < x.n; base += 64) {
-    uint32_t i = base + (uint32_t)l;
-    nvalid += (uint32_t)__popcll(__ballot(i < x.n && x.pos[i] < x.len));
-  }
-  auto put = [&](uint32_t asc, uint32_t nd, uint32_t b, uint32_t idx, uint32_t p) {
-    uint32_t d = nvalid - 1 - asc;
-    x.keys[d].hi = ((uint64_t)(nn - 1 - nd) << 40) | ((uint64_t)(255u - b) << 32) | (uint64_t)(x.n - 1 - idx);
-    x.keys[d].lo = p + 1;
-  };
-  uint32_t vbase = 0, k = 0;
-  while (k < nn) {
-    uint32_t s0 = uni(seg[k]);
-    uint32_t kk = k + (uint32_t)l + 1;
-    uint32_t myend = kk <= nn ? seg[kk] : 0xFFFFFFFFu;
-    bool fits = kk <= nn && myend - s0 <= 64;
-    unsigned long long fm = __ballot(fits);
-    uint32_t nfit = fm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fm);       // offsets ascend: `fits` is a prefix
-    if (nfit > 0) {
-      uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)myend, (int)(nfit - 1)) - s0;
-      uint32_t i = s0 + (uint32_t)l; bool in = (uint32_t)l < cnt;
-      uint32_t p = in ? x.pos[i] : 0u; bool v = in && p < x.len;
-      uint32_t nd = in ? x.node[i] : 0u;
-      uint32_t b = v ? (uint32_t)x.s[p] : 0u;
-      uint32_t key = v ? (((nd - k) << 14) | (b << 6) | (uint32_t)l) : 0xFFFFFFFFu;
-      // entries arrive ordered by segment; when the bytes happen to ascend inside every segment too (always
-      // the case once segments have shrunk to single entries) the 21-step network is skipped
-      uint32_t nxt = (uint32_t)__shfl_down((int)key, 1);
-      uint32_t sk = __ballot(l < 63 && key > nxt) == 0 ? key : wave_sort64(key);
-      bool sv = sk != 0xFFFFFFFFu;
-      uint32_t ol = sk & 63u;
-      uint32_t sp = (uint32_t)__shfl((int)p, (int)ol), snd = (uint32_t)__shfl((int)nd, (int)ol);
-      if (sv) put(vbase + (uint32_t)l, snd, (sk >> 6) & 255u, s0 + ol, sp);
-      vbase += (uint32_t)__popcll(__ballot(sv));
-      k += nfit;
+  const bool asc = par == 0;
+  uint32_t cn = 0, cf = 0, ct = 0;                               // children, source entries, target entries written so far
+  uint32_t k0 = 0;
+  while (k0 < nn) {
+    uint32_t k = k0 + (uint32_t)l;
+    FNode nd = {0, 0, 0, 0};
+    if (k < nn) nd = g.nd[k];
+    bool valid = k < nn;
+    bool big = valid && (nd.fc > 64 || nd.tc > 64);
+    bool one = valid && nd.fc == 1 && nd.tc == 1;
+    unsigned long long vm = __ballot(valid), bm = __ballot(big), om = __ballot(one);
+    uint32_t nvalid = (uint32_t)__popcll(vm);
+    uint32_t nones = ~om == 0ull ? 64u : (uint32_t)__builtin_ctzll(~om);
+    if (nones > nvalid) nones = nvalid;
+    EH_PT0;
+    if (nones >= 16 || (nones > 0 && nones == nvalid)) {
+      // ---- run of {1,1} nodes
+      bool in = (uint32_t)l < nones;
+      uint32_t p = in ? g.F[nd.fo] : la, q = in ? g.T[nd.to] : lb;
+      uint32_t ba = (in && p < la) ? A[p] : 256u, bb = (in && q < lb) ? B[q] : 257u;
+      bool special = in && p == la - 1;                          // its only member is dropped: {[[]], [[]]}
+      bool child = special || (in && p < la && ba == bb);
+      bool tkeep = child && !special && q != lb - 1;             // a target whose rest is [] is dropped as well
+      unsigned long long cm = __ballot(child), tm = __ballot(child && (special || tkeep));
+      uint32_t ci = (uint32_t)__popcll(cm & ((1ull << l) - 1)), ti = (uint32_t)__popcll(tm & ((1ull << l) - 1));
+      if (child) {
+        FNode c2; c2.fo = cf + ci; c2.fc = 1; c2.to = ct + ti; c2.tc = (special || tkeep) ? 1u : 0u;
+        o.nd[cn + ci] = c2;
+        o.F[cf + ci] = special ? la : p + 1;
+        if (special || tkeep) o.T[ct + ti] = special ? lb : q + 1;
+      }
+      uint32_t nc = (uint32_t)__popcll(cm);
+      cn += nc; cf += nc; ct += (uint32_t)__popcll(tm);
+      k0 += nones;
+      EH_PT(g_ctx, 100);
       continue;
     }
-    // one big segment
-    uint32_t e0 = uni(seg[k + 1]);
-    for (uint32_t b = (uint32_t)l; b < 256; b += 64) hist[b] = 0;
-    wave_sync();
-    for (uint32_t base = s0; base < e0; base += 64) {
-      uint32_t i = base + (uint32_t)l;
-      if (i < e0) { uint32_t p = x.pos[i]; if (p < x.len) atomicAdd(&hist[x.s[p]], 1u); }
-    }
-    wave_sync();
-    uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
-    uint32_t sum = h0 + h1 + h2 + h3, inc = wave_incl_scan(sum), exc = inc - sum;
-    uint32_t segvalid = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-    wave_sync();
-    hist[4 * l] = exc; hist[4 * l + 1] = exc + h0; hist[4 * l + 2] = exc + h0 + h1; hist[4 * l + 3] = exc + h0 + h1 + h2;
-    wave_sync();
-    for (uint32_t base = s0; base < e0; base += 64) {
-      uint32_t i = base + (uint32_t)l; bool in = i < e0;
-      uint32_t p = in ? x.pos[i] : 0u; bool v = in && p < x.len;
-      uint32_t b = v ? (uint32_t)x.s[p] : 0u;
-      unsigned long long eq = __ballot(v);                        // lanes holding the same byte as me
-#pragma unroll
-      for (int bit = 0; bit < 8; bit++) { unsigned long long m = __ballot(v && ((b >> bit) & 1u)); eq &= ((b >> bit) & 1u) ? m : ~m; }
-      uint32_t rank = (uint32_t)__popcll(eq & ((1ull << l) - 1)), cntg = (uint32_t)__popcll(eq);
-      uint32_t off = v ? hist[b] : 0u;
-      wave_sync();                                                // every lane has read its bin before the group leaders bump them
-      if (v && rank == 0) hist[b] = off + cntg;
+    if (bm & 1ull) {
+      // ---- one big node, the whole wave: histograms of the next byte on both sides
+      FNode b0; b0.fo = uni(nd.fo); b0.fc = uni(nd.fc); b0.to = uni(nd.to); b0.tc = uni(nd.tc);
+      uint32_t* hf = hist; uint32_t* ht = hist + 256;                // source bins [0,256), target bins [256,512) (work area)
+      for (uint32_t i = l; i < 512; i += 64) hist[i] = 0;
       wave_sync();
-      if (v) put(vbase + off + rank, k, b, i, p);
+      // the entry whose rest is []: its byte' and how many members of its group precede it (array order)
+      uint32_t fdb = 0xFFFFFFFFu, fdbefore = 0, tdb = 0xFFFFFFFFu, tdbefore = 0;
+      for (int side = 0; side < 2; side++) {
+        const uint8_t* S = side ? B : A; uint32_t slen = side ? lb : la;
+        const uint32_t* P = side ? g.T + b0.to : g.F + b0.fo; uint32_t cnt = side ? b0.tc : b0.fc;
+        uint32_t* h = side ? ht : hf;
+        for (uint32_t base = 0; base < cnt; base += 64) {
+          uint32_t i = base + (uint32_t)l; bool in = i < cnt;
+          uint32_t pp = in ? P[i] : slen; bool v = in && pp < slen;
+          uint32_t bt = v ? (uint32_t)S[pp] : 0u; if (!asc) bt = 255u - bt;
+          unsigned long long lastm = __ballot(v && pp == slen - 1);
+          if (lastm) {                                           // rare: at most once per side and round
+            int j = (int)__builtin_ctzll(lastm);
+            uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)bt, j);
+            uint32_t before = h[bj] + (uint32_t)__popcll(__ballot(v && bt == bj) & ((1ull << j) - 1));
+            if (side) { tdb = bj; tdbefore = before; } else { fdb = bj; fdbefore = before; }
+            wave_sync();
+          }
+          if (v) atomicAdd(&h[bt], 1u);
+          wave_sync();
+        }
+      }
+      wave_sync();
+      // bins in output order: lane l owns byte' 4l .. 4l+3
+      uint32_t rf[4], rt[4], ef[4], et[4]; bool ch[4], sp[4];
+      uint32_t lc = 0, lf = 0, lt2 = 0;
+      bool anyfd = false, anytd = false;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint32_t bt = 4u * (uint32_t)l + (uint32_t)j;
+        rf[j] = hf[bt]; rt[j] = ht[bt];
+        bool fdrop = bt == fdb && (asc ? fdbefore == 0 : fdbefore + 1 == rf[j]);
+        bool tdrop = bt == tdb && (asc ? tdbefore == 0 : tdbefore + 1 == rt[j]);
+        anyfd |= fdrop; anytd |= tdrop;
+        ef[j] = rf[j] - (fdrop ? 1u : 0u); et[j] = rt[j] - (tdrop ? 1u : 0u);
+        sp[j] = rf[j] > 0 && ef[j] == 0;
+        ch[j] = rf[j] > 0 && (sp[j] || rt[j] > 0);
+        if (sp[j]) { ef[j] = 1; et[j] = 1; }
+        if (!ch[j]) { ef[j] = 0; et[j] = 0; }
+        lc += ch[j] ? 1u : 0u; lf += ef[j]; lt2 += et[j];
+      }
+      const bool fdropped = __ballot(anyfd) != 0, tdropped = __ballot(anytd) != 0;   // the entry with rest [] leaves its group
+      uint32_t ic = wave_incl_scan(lc), iff = wave_incl_scan(lf), it = wave_incl_scan(lt2);
+      uint32_t oc = cn + ic - lc, of = cf + iff - lf, ot = ct + it - lt2;
+      wave_sync();
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint32_t bt = 4u * (uint32_t)l + (uint32_t)j;
+        // cursors for the scatter; 0xFFFFFFFF = no child for this byte (or nothing to scatter: special)
+        hf[bt] = (ch[j] && !sp[j]) ? of : 0xFFFFFFFFu; ht[bt] = (ch[j] && !sp[j]) ? ot : 0xFFFFFFFFu;
+        if (ch[j]) {
+          FNode c2; c2.fo = of; c2.fc = ef[j]; c2.to = ot; c2.tc = et[j];
+          o.nd[oc] = c2;
+          if (sp[j]) { o.F[of] = la; o.T[ot] = lb; }
+          oc++; of += ef[j]; ot += et[j];
+        }
+      }
+      cn += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63); cf += (uint32_t)__builtin_amdgcn_readlane((int)iff, 63); ct += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
+      wave_sync();
+      // stable scatter: rank among the lanes of this chunk with the same byte', behind the bin's cursor
+      for (int side = 0; side < 2; side++) {
+        const uint8_t* S = side ? B : A; uint32_t slen = side ? lb : la;
+        const uint32_t* P = side ? g.T + b0.to : g.F + b0.fo; uint32_t cnt = side ? b0.tc : b0.fc;
+        uint32_t* h = side ? ht : hf; uint32_t* O = side ? o.T : o.F;
+        const bool dropped = side ? tdropped : fdropped;
+        for (uint32_t base = 0; base < cnt; base += 64) {
+          uint32_t i = base + (uint32_t)l; bool in = i < cnt;
+          uint32_t pp = in ? P[i] : slen; bool v = in && pp < slen;
+          uint32_t bt = v ? (uint32_t)S[pp] : 0u; if (!asc) bt = 255u - bt;
+          bool isdrop = dropped && v && pp == slen - 1;            // positions are distinct: at most one such entry
+          bool vv = v && !isdrop;
+          unsigned long long eq = __ballot(vv);
+#pragma unroll
+          for (int bit = 0; bit < 8; bit++) { unsigned long long m = __ballot(vv && ((bt >> bit) & 1u)); eq &= ((bt >> bit) & 1u) ? m : ~m; }
+          uint32_t rank = (uint32_t)__popcll(eq & ((1ull << l) - 1)), cntg = (uint32_t)__popcll(eq);
+          uint32_t off = vv ? h[bt] : 0xFFFFFFFFu;
+          wave_sync();
+          if (vv && off != 0xFFFFFFFFu) { O[off + rank] = pp + 1; if (rank == 0) h[bt] = off + cntg; }
+          wave_sync();
+        }
+      }
+      k0 += 1;
+      EH_PT(g_ctx, 101);
+      continue;
     }
-    vbase += segvalid;
-    k += 1;
+    // ---- whole nodes packed into <= 64 + 64 entries, one entry per lane
+    uint32_t cumf = wave_incl_scan(valid && !big ? nd.fc : 0u), cumt = wave_incl_scan(valid && !big ? nd.tc : 0u);
+    uint32_t firstbig = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
+    unsigned long long fitm = __ballot(valid && (uint32_t)l < firstbig && cumf <= 64 && cumt <= 64);
+    uint32_t nfit = ~fitm == 0ull ? 64u : (uint32_t)__builtin_ctzll(~fitm);     // cumulative sums ascend: a prefix
+    uint32_t totf = (uint32_t)__builtin_amdgcn_readlane((int)cumf, (int)(nfit - 1)), tott = (uint32_t)__builtin_amdgcn_readlane((int)cumt, (int)(nfit - 1));
+    uint32_t key[2], pos[2], tot[2] = {totf, tott};
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      const uint8_t* S = side ? B : A; uint32_t slen = side ? lb : la;
+      uint32_t cum = side ? cumt : cumf, cntn = side ? nd.tc : nd.fc, offn = side ? nd.to : nd.fo;
+      bool in = (uint32_t)l < tot[side];
+      uint32_t nj = lanes_le(cum, nfit, (uint32_t)l);                          // node (of this batch) of entry l
+      uint32_t ex = (uint32_t)__shfl((int)(cum - cntn), (int)(nj & 63)), ob = (uint32_t)__shfl((int)offn, (int)(nj & 63));
+      uint32_t pp = in ? (side ? g.T : g.F)[ob + ((uint32_t)l - ex)] : slen;
+      bool v = in && pp < slen;
+      uint32_t bt = v ? (uint32_t)S[pp] : 0u; if (!asc) bt = 255u - bt;
+      uint32_t kk = in ? (((nj << 9) | (v ? bt : 511u)) << 6) | (uint32_t)l : 0xFFFFFFFFu;
+      uint32_t nxt = (uint32_t)__shfl_down((int)kk, 1);
+      uint32_t sk = __ballot(l < 63 && kk > nxt) == 0 ? kk : wave_sort64(kk);
+      key[side] = sk; pos[side] = (uint32_t)__shfl((int)pp, (int)(sk & 63u));
+    }
+    // groups = runs of equal (node, byte')
+    uint32_t gk[2], lead[2], len[2], drops[2]; bool alive[2], isdrop[2];
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      uint32_t slen = side ? lb : la;
+      gk[side] = key[side] >> 6;
+      alive[side] = (uint32_t)l < tot[side] && (gk[side] & 511u) != 511u;
+      uint32_t prevk = (uint32_t)__shfl_up((int)gk[side], 1), nextk = (uint32_t)__shfl_down((int)gk[side], 1);
+      bool leader = alive[side] && (l == 0 || prevk != gk[side]);
+      bool last = alive[side] && (l == 63 || (uint32_t)l + 1 >= tot[side] || nextk != gk[side]);
+      unsigned long long lm = __ballot(leader);
+      uint32_t ll = alive[side] ? 63u - (uint32_t)__builtin_clzll(lm & ((2ull << l) - 1)) : 0u;
+      unsigned long long after = lm & ~((2ull << ll) - 1);                     // next leader
+      unsigned long long am = __ballot(alive[side]);
+      uint32_t endl = after ? (uint32_t)__builtin_ctzll(after) : 64u;          // runs are contiguous among alive lanes of a node...
+      // ...but dead entries (key byte 511) sit between nodes: the run ends at the next leader or at the first non-alive lane
+      unsigned long long dead_after = ~am & ~((2ull << ll) - 1);
+      uint32_t endd = dead_after ? (uint32_t)__builtin_ctzll(dead_after) : 64u;
+      uint32_t e = endl < endd ? endl : endd;
+      lead[side] = ll; len[side] = alive[side] ? e - ll : 0u;
+      isdrop[side] = alive[side] && pos[side] == slen - 1 && (asc ? leader : last);
+      unsigned long long dm = __ballot(isdrop[side]);
+      unsigned long long runm = (e >= 64 ? ~0ull : ((1ull << e) - 1)) & ~((1ull << ll) - 1);
+      drops[side] = alive[side] ? (uint32_t)__popcll(dm & runm) : 0u;
+    }
+    // join: the target run with my (node, byte'), if any
+    uint32_t tl = lanes_lt(gk[1], tott, gk[0]);                                 // first target lane with key >= mine
+    uint32_t tk_at = (uint32_t)__shfl((int)gk[1], (int)(tl & 63)), tlen_at = (uint32_t)__shfl((int)len[1], (int)(tl & 63)), tdr_at = (uint32_t)__shfl((int)drops[1], (int)(tl & 63));
+    bool texists = alive[0] && tl < tott && tk_at == gk[0];
+    bool fleader = alive[0] && lead[0] == (uint32_t)l;
+    uint32_t fcnt = len[0] - drops[0];
+    bool special = fleader && fcnt == 0;
+    bool child = fleader && (special || texists);
+    uint32_t nf = child ? (special ? 1u : fcnt) : 0u, nt = child ? (special ? 1u : (tlen_at - tdr_at)) : 0u;
+    uint32_t ic = wave_incl_scan(child ? 1u : 0u), iff = wave_incl_scan(nf), it = wave_incl_scan(nt);
+    uint32_t oc = cn + ic - (child ? 1u : 0u), of = cf + iff - nf, ot = ct + it - nt;
+    if (child) {
+      FNode c2; c2.fo = of; c2.fc = nf; c2.to = ot; c2.tc = nt;
+      o.nd[oc] = c2;
+      if (special) { o.F[of] = la; o.T[ot] = lb; }
+    }
+    // source entries: behind their leader's offset
+    {
+      bool lchild = (__shfl((int)(child && !special ? 1 : 0), (int)lead[0]) != 0);
+      uint32_t lof = (uint32_t)__shfl((int)of, (int)lead[0]);
+      bool ldrop = __shfl((int)(isdrop[0] ? 1 : 0), (int)lead[0]) != 0;        // asc: the leader itself was dropped
+      if (alive[0] && lchild && !isdrop[0]) o.F[lof + ((uint32_t)l - lead[0]) - (ldrop ? 1u : 0u)] = pos[0] + 1;
+    }
+    // target entries: find the source leader with my key
+    {
+      uint32_t sl = lanes_lt(gk[0], totf, gk[1]);
+      uint32_t sk_at = (uint32_t)__shfl((int)gk[0], (int)(sl & 63));
+      bool has = alive[1] && sl < totf && sk_at == gk[1];
+      bool schild = __shfl((int)(child && !special ? 1 : 0), (int)(sl & 63)) != 0;
+      uint32_t sot = (uint32_t)__shfl((int)ot, (int)(sl & 63));
+      bool ldrop = __shfl((int)(isdrop[1] ? 1 : 0), (int)lead[1]) != 0;
+      if (has && schild && !isdrop[1]) o.T[sot + ((uint32_t)l - lead[1]) - (ldrop ? 1u : 0u)] = pos[1] + 1;
+    }
+    cn += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63); cf += (uint32_t)__builtin_amdgcn_readlane((int)iff, 63); ct += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
+    k0 += nfit;
+    EH_PT(g_ctx, 102);
   }
   wave_sync();
-  // group boundaries: (hi >> 32) changes
-  uint32_t nb = 0;
-  for (uint32_t base = 0; base < nvalid; base += 64) {
-    uint32_t i = base + (uint32_t)l;
-    bool valid = i < nvalid;
-    uint64_t h = valid ? x.keys[i].hi : 0;
-    bool start = valid && (i == 0 || (x.keys[i - 1].hi >> 32) != (h >> 32));
-    unsigned long long m = __ballot(start);
-    uint32_t upto = (uint32_t)__popcll(m & ((2ull << l) - 1));    // group starts at or before me
-    if (start) { x.bstart[nb + upto - 1] = i; x.bkey[nb + upto - 1] = h >> 32; }
-    if (valid) x.gid[i] = nb + upto - 1;
-    nb += (uint32_t)__popcll(m);
-  }
-  if (l == 0) x.bstart[nb] = nvalid;
-  wave_sync();
-  x.nb = nb;
-  // group range of every node (keys ascend, so a node's groups are contiguous): lookups then search at most
-  // 256 groups, usually one, instead of all of them
-  for (uint32_t k2 = (uint32_t)l; k2 < nn; k2 += 64) { x.nfirst[k2] = 0; x.nend[k2] = 0; }
-  wave_sync();
-  for (uint32_t j = (uint32_t)l; j < nb; j += 64) {
-    uint32_t np = (uint32_t)(x.bkey[j] >> 8);
-    if (j == 0 || (uint32_t)(x.bkey[j - 1] >> 8) != np) x.nfirst[np] = j;
-    if (j + 1 == nb || (uint32_t)(x.bkey[j + 1] >> 8) != np) x.nend[np] = j + 1;
-  }
-  // fix_empty_list (:58-60): a group whose LAST element (first one inserted) is the empty tail loses it
-  for (uint32_t j = l; j < nb; j += 64) {
-    uint32_t a = x.bstart[j], b = x.bstart[j + 1];
-    uint32_t cnt = b - a;
-    if (cnt > 0 && (uint32_t)x.keys[b - 1].lo == x.len) cnt--;
-    x.bcnt[j] = cnt;
-    x.child[j] = FUSE_NONE;
-  }
-  wave_sync();
+  return cn;
 }
 
 // fuse(Al, Bl) -> new byte list in the work area
@@ -169,92 +280,37 @@ EH_DEV bool fuse_lists(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, 
   if (la == 0) { *out = (uint8_t*)B; *outlen = lb; return true; }   // fuse([], Bl) -> Bl
   if (lb == 0) { *out = (uint8_t*)A; *outlen = la; return true; }
   uint64_t mark = c.ws_used;
-  FuseSide f, t;
-  uint32_t capf = la + 2, capt = lb + 2;
-  f.s = A; f.len = la; t.s = B; t.len = lb;
-  auto u32 = [&](uint64_t n) { return (uint32_t*)ws_alloc(c, n * 4); };
-  f.pos = u32(capf); f.node = u32(capf); t.pos = u32(capt); t.node = u32(capt);
-  uint32_t* f2 = u32(capf); uint32_t* fn2 = u32(capf); uint32_t* t2 = u32(capt); uint32_t* tn2 = u32(capt);
-  f.keys = (Key2*)ws_alloc(c, (uint64_t)capf * sizeof(Key2)); t.keys = (Key2*)ws_alloc(c, (uint64_t)capt * sizeof(Key2));
-  f.gid = u32(capf); t.gid = u32(capt);
-  f.bstart = u32(capf + 1); t.bstart = u32(capt + 1);
-  f.bkey = (uint64_t*)ws_alloc(c, (uint64_t)capf * 8); t.bkey = (uint64_t*)ws_alloc(c, (uint64_t)capt * 8);
-  f.bcnt = u32(capf); t.bcnt = u32(capt); f.child = u32(capf); t.child = u32(capt);
-  f.nfirst = u32(capf); f.nend = u32(capf); t.nfirst = u32(capf); t.nend = u32(capf);      // indexed by node: nn <= capf
-  // node table: per node start/count in pos arrays (current and next)
-  uint32_t capn = capf;                                            // every node owns >= 1 source entry
-  uint32_t* nfs = u32(capn + 1); uint32_t* nts = u32(capn + 1); uint32_t* nfs2 = u32(capn + 1); uint32_t* nts2 = u32(capn + 1);
-  uint32_t* cmatch = u32(capn); uint32_t* hist = u32(256);
-  if (!f.pos || !f.node || !t.pos || !t.node || !f2 || !fn2 || !t2 || !tn2 || !f.keys || !t.keys || !f.gid || !t.gid || !f.bstart ||
-      !t.bstart || !f.bkey || !t.bkey || !f.bcnt || !t.bcnt || !f.child || !t.child || !f.nfirst || !f.nend || !t.nfirst || !t.nend || !nfs || !nts || !nfs2 || !nts2 || !cmatch || !hist) return false;
+  FuseGen g[2];
+  for (int k = 0; k < 2; k++) {
+    g[k].nd = (FNode*)ws_alloc(c, ((uint64_t)la + 4) * sizeof(FNode));     // every node owns >= 1 source entry
+    g[k].F = (uint32_t*)ws_alloc(c, ((uint64_t)la + 4) * 4);
+    g[k].T = (uint32_t*)ws_alloc(c, ((uint64_t)lb + 4) * 4);
+    if (!g[k].nd || !g[k].F || !g[k].T) return false;
+  }
+  uint32_t* hist = (uint32_t*)ws_alloc(c, 512 * 4);
+  if (!hist) return false;
   // find_jump_points (:103-107): one node with all non-empty suffixes of both lists
-  for (uint32_t i = l; i < la; i += 64) { f.pos[i] = i; f.node[i] = 0; }
-  for (uint32_t i = l; i < lb; i += 64) { t.pos[i] = i; t.node[i] = 0; }
-  if (l == 0) { nfs[0] = 0; nfs[1] = la; nts[0] = 0; nts[1] = lb; }
-  f.n = la; t.n = lb;
-  uint32_t nn = 1;
+  for (uint32_t i = l; i < la; i += 64) g[0].F[i] = i;
+  for (uint32_t i = l; i < lb; i += 64) g[0].T[i] = i;
+  if (l == 0) { FNode n0; n0.fo = 0; n0.fc = la; n0.to = 0; n0.tc = lb; g[0].nd[0] = n0; }
+  uint32_t nn = 1, par = 0;
   int64_t fuel = 100000;                                           // ?SEARCH_FUEL
   wave_sync();
   while (true) {                                                   // find_jump_points_loop (:115-128)
     if (fuel < 0) break;
     if (rng_rand(c.rng, 8) == 0) break;                            // ?SEARCH_STOP_IP
-    fuse_group(f, nn, nfs, hist);
-    fuse_group(t, nn, nts, hist);
-    // children, in the order of the source groups: a group with no elements left is the special node
-    // {[[]], [[]]}; otherwise it needs a target group with the same (node, byte)
-    uint32_t nchild = 0, newf = 0, newt = 0;
-    for (uint32_t base = 0; base < f.nb; base += 64) {
-      uint32_t j = base + (uint32_t)l;
-      bool child = false; uint32_t fc = 0, tc = 0, tj = FUSE_NONE;
-      if (j < f.nb) {
-        fc = f.bcnt[j];
-        if (fc == 0) { child = true; fc = 1; tc = 1; tj = FUSE_SPECIAL; }           // [[[[]], []] | Tl]
-        else {
-          uint64_t key = f.bkey[j];
-          uint32_t np = (uint32_t)(key >> 8);
-          uint32_t lo = t.nfirst[np], hi = t.nend[np];             // binary search inside the node's groups (ascending keys)
-          uint32_t tend = hi;
-          while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (t.bkey[mid] < key) lo = mid + 1; else hi = mid; }
-          if (lo < tend && t.bkey[lo] == key) { child = true; tj = lo; tc = t.bcnt[lo]; }
-        }
-      }
-      // exclusive prefix sums of (child, fc, tc) across the wave
-      uint32_t ci = child ? 1u : 0u, fi = child ? fc : 0u, ti = child ? tc : 0u;
-      uint32_t cs = wave_incl_scan(ci), fs = wave_incl_scan(fi), ts = wave_incl_scan(ti);
-      if (child) {
-        uint32_t kc = nchild + cs - 1;
-        nfs2[kc] = newf + fs - fi; nts2[kc] = newt + ts - ti; cmatch[kc] = tj;
-        if (tj != FUSE_SPECIAL) { f.child[j] = kc; t.child[tj] = kc; }
-      }
-      nchild += uni((uint32_t)__shfl((int)cs, 63)); newf += uni((uint32_t)__shfl((int)fs, 63)); newt += uni((uint32_t)__shfl((int)ts, 63));
-    }
-    if (l == 0) { nfs2[nchild] = newf; nts2[nchild] = newt; }
-    wave_sync();
+    uint32_t nchild = fuse_round(A, la, B, lb, g[par], nn, g[par ^ 1], par, hist);
     if (nchild == 0) break;                                        // NoDesp =:= [] -> any_position_pair(Nodes)
-    // the children's suffix lists are the surviving groups in the same order: a compaction
-    for (uint32_t i = (uint32_t)l; i < f.bstart[f.nb]; i += 64) {
-      uint32_t g = f.gid[i], kc = f.child[g];
-      if (kc != FUSE_NONE) { uint32_t o = i - f.bstart[g]; if (o < f.bcnt[g]) { f2[nfs2[kc] + o] = (uint32_t)f.keys[i].lo; fn2[nfs2[kc] + o] = kc; } }
-    }
-    for (uint32_t i = (uint32_t)l; i < t.bstart[t.nb]; i += 64) {
-      uint32_t g = t.gid[i], kc = t.child[g];
-      if (kc != FUSE_NONE) { uint32_t o = i - t.bstart[g]; if (o < t.bcnt[g]) { t2[nts2[kc] + o] = (uint32_t)t.keys[i].lo; tn2[nts2[kc] + o] = kc; } }
-    }
-    for (uint32_t kc = (uint32_t)l; kc < nchild; kc += 64)
-      if (cmatch[kc] == FUSE_SPECIAL) { f2[nfs2[kc]] = la; fn2[nfs2[kc]] = kc; t2[nts2[kc]] = lb; tn2[nts2[kc]] = kc; }
-    wave_sync();
-    // swap generations
-    { uint32_t* tmp; tmp = f.pos; f.pos = f2; f2 = tmp; tmp = f.node; f.node = fn2; fn2 = tmp; tmp = t.pos; t.pos = t2; t2 = tmp; tmp = t.node; t.node = tn2; tn2 = tmp;
-      tmp = nfs; nfs = nfs2; nfs2 = tmp; tmp = nts; nts = nts2; nts2 = tmp; }
-    f.n = newf; t.n = newt; nn = nchild;
+    par ^= 1; nn = nchild;
     fuel -= (int64_t)nchild;
   }
-  // any_position_pair/1 (:73-77)
+  // any_position_pair/1 (:73-77); odd generations are stored reversed
   uint32_t ni = rng_rand(c.rng, nn);
-  uint32_t fo = uni(nfs[ni]), fcnt = uni(nfs[ni + 1]) - fo, to = uni(nts[ni]), tcnt = uni(nts[ni + 1]) - to;
+  FNode nd = g[par].nd[par ? nn - 1 - ni : ni];
+  uint32_t fo = uni(nd.fo), fc = uni(nd.fc), to = uni(nd.to), tc = uni(nd.tc);
   uint32_t from = la, tpos = lb;
-  if (fcnt > 0) from = uni(f.pos[fo + rng_rand(c.rng, fcnt)]);
-  if (tcnt > 0) tpos = uni(t.pos[to + rng_rand(c.rng, tcnt)]);
+  if (fc > 0) { uint32_t j = rng_rand(c.rng, fc); from = uni(g[par].F[fo + (par ? fc - 1 - j : j)]); }
+  if (tc > 0) { uint32_t j = rng_rand(c.rng, tc); tpos = uni(g[par].T[to + (par ? tc - 1 - j : j)]); }
   c.ws_used = mark;                                                // release all tables
   // jump/3 (:47-50): Al up to From, then To
   uint32_t nl = from + (lb - tpos);

@@ -53,24 +53,32 @@ __constant__ char c_js_pay5[] = "{\"@class\":\" com.atomikos.icatch.jta.RemoteCl
 struct JsDoc { JNode* nd; Piece* pc; uint32_t nn, npc, have_top; };
 
 // tokenize/1 :83-188.  0 ok (out->have_top says whether a token was produced); -1 incorrect_json; -2 a
-// case_clause in ws/3 (the worker dies); -3 engine capacity.
-__device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, JsDoc* out) {
+// case_clause in ws/3 (the worker dies); -3 engine capacity.  build = false only runs the machine (no node or piece is
+// recorded): on most blocks js fails within a token or two, and that verdict then costs one window load.
+__device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, JsDoc* out, bool build) {
   EH_CTX;
   const int l = EH_LANE;
   // capacity: every node and every structure piece needs one of these bytes, or starts the block
-  uint32_t nsig = 0;
-  for (uint32_t i0 = 16u * (uint32_t)l; i0 < L; i0 += 1024) {
-    uint32_t cnt = L - i0 < 16 ? L - i0 : 16;
-    for (uint32_t k = 0; k < cnt; k++) { uint32_t x = H[i0 + k]; nsig += (x == '[' || x == ']' || x == '{' || x == '}' || x == ',' || x == ':' || x == '"' || x == ' ' || x == '\n' || x == '\r' || x == '\t'); }
+  uint32_t nsig = L;
+  if (build) {
+    nsig = 0;
+    for (uint32_t i0 = 16u * (uint32_t)l; i0 < L; i0 += 1024) {
+      uint32_t cnt = L - i0 < 16 ? L - i0 : 16;
+      for (uint32_t k = 0; k < cnt; k++) { uint32_t x = H[i0 + k]; nsig += (x == '[' || x == ']' || x == '{' || x == '}' || x == ',' || x == ':' || x == '"' || x == ' ' || x == '\n' || x == '\r' || x == '\t'); }
+    }
+    nsig = wave_sum(nsig);
   }
-  nsig = wave_sum(nsig);
-  uint32_t cap_n = 2 * nsig + 16;
-  uint64_t cap_pc = 4ull * cap_n + 16;
-  JNode* nd = (JNode*)ws_alloc(c, (uint64_t)cap_n * sizeof(JNode));
-  Piece* pc = (Piece*)ws_alloc(c, cap_pc * sizeof(Piece));
-  uint32_t* nstk = (uint32_t*)ws_alloc(c, (uint64_t)cap_n * 4 + 16);     // open container / pair nodes
-  uint32_t* cold = (uint32_t*)ws_alloc(c, (uint64_t)(cap_n / 4 + 8) * 4);  // spilled context atoms, 8 per word
-  if (!nd || !pc || !nstk || !cold) return -3;
+  uint32_t cap_n = build ? 2 * nsig + 16 : 0xFFFFFFF0u;
+  uint64_t cap_pc = build ? 4ull * cap_n + 16 : ~0ull;
+  JNode* nd = nullptr; Piece* pc = nullptr; uint32_t* nstk = nullptr;
+  if (build) {
+    nd = (JNode*)ws_alloc(c, (uint64_t)cap_n * sizeof(JNode));
+    pc = (Piece*)ws_alloc(c, cap_pc * sizeof(Piece));
+    nstk = (uint32_t*)ws_alloc(c, (uint64_t)cap_n * 4 + 16);              // open container / pair nodes
+    if (!nd || !pc || !nstk) return -3;
+  }
+  uint32_t* cold = (uint32_t*)ws_alloc(c, ((uint64_t)nsig / 2 + 16) * 4);  // spilled context atoms, 8 per word (<= 3 atoms per byte)
+  if (!cold) return -3;
   uint32_t nn = 0, npc = 0, nns = 0, ncold = 0;
 
   enum { C_ARRAY = 1, C_ELEMENTS, C_OBJECT, C_MEMBERS, C_PAIR, C_PAIR_DELIM, C_VALUE, C_ARRAY_END, C_OBJECT_END, C_PAIR_END, C_PAIR_START };
@@ -87,7 +95,7 @@ __device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, Js
 
   JsWin x; x.w.p = H; x.w.L = L; x.w.valid = false; x.w.base = 0;
   uint32_t pos = 0;
-  bool pushing = false, weird = false, have_top = false;
+  bool pushing = false, weird = false, have_top = false, mk = build;   // mk: nodes and pieces are being recorded
   uint32_t pv = 0, inkey_node = 0xFFFFFFFFu;
   int rc = 0;
   auto put = [&](const uint8_t* p, uint32_t len) { piece_put(pc, npc, p, len); npc++; };
@@ -108,7 +116,7 @@ __device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, Js
       if (t == C_PAIR_DELIM) { cpop(); cpush(C_PAIR_START); cpush(C_PAIR_DELIM); pushing = false; continue; }
       if (t == C_PAIR_END && csecond() == C_PAIR_START) {                  // {pair, Key, Value} is pushed in turn
         cpop(); cpop();
-        if (!weird && nns > 0) { wave_sync(); uint32_t pi = uni(nstk[--nns]); close_node(pi); pv = pi; }
+        if (mk && nns > 0) { wave_sync(); uint32_t pi = uni(nstk[--nns]); close_node(pi); pv = pi; }
         continue;
       }
       rc = -1; break;                                                      // push(_, _, _, _) -> throw(incorrect_json)
@@ -130,49 +138,49 @@ __device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, Js
     switch (term) {
       case C_ARRAY:                                                        // array/3 :120-124
         cpop(); cpush(C_ARRAY_END);
-        if (is(JC_RB)) { pos++; cpop(); if (!weird) { put(jslit(JL_RB), 1); wave_sync(); uint32_t ni = uni(nstk[--nns]); close_node(ni); pv = ni; } pushing = true; }
+        if (is(JC_RB)) { pos++; cpop(); if (mk) { put(H + pos - 1, 1); wave_sync(); uint32_t ni = uni(nstk[--nns]); close_node(ni); pv = ni; } pushing = true; }
         else { cpush(C_ELEMENTS); cpush(C_VALUE); }
         break;
       case C_ELEMENTS:                                                     // elements/4 :126-132
         cpop();
-        if (is(JC_RB) && ctop() == C_ARRAY_END) { pos++; cpop(); if (!weird) { put(jslit(JL_RB), 1); wave_sync(); uint32_t ni = uni(nstk[--nns]); close_node(ni); pv = ni; } pushing = true; }
-        else if (is(JC_COMMA)) { pos++; if (!weird) put(jslit(JL_COMMA), 1); cpush(C_ELEMENTS); cpush(C_VALUE); }
+        if (is(JC_RB) && ctop() == C_ARRAY_END) { pos++; cpop(); if (mk) { put(H + pos - 1, 1); wave_sync(); uint32_t ni = uni(nstk[--nns]); close_node(ni); pv = ni; } pushing = true; }
+        else if (is(JC_COMMA)) { pos++; if (mk) put(H + pos - 1, 1); cpush(C_ELEMENTS); cpush(C_VALUE); }
         else rc = -1;
         break;
       case C_OBJECT:                                                       // object/3 :135-139
         cpop(); cpush(C_OBJECT_END);
-        if (is(JC_RC)) { pos++; cpop(); if (!weird) { put(jslit(JL_RC), 1); wave_sync(); uint32_t ni = uni(nstk[--nns]); close_node(ni); pv = ni; } pushing = true; }
+        if (is(JC_RC)) { pos++; cpop(); if (mk) { put(H + pos - 1, 1); wave_sync(); uint32_t ni = uni(nstk[--nns]); close_node(ni); pv = ni; } pushing = true; }
         else { cpush(C_MEMBERS); cpush(C_PAIR); }
         break;
       case C_MEMBERS:                                                      // members/4 :141-147
         cpop();
-        if (is(JC_RC) && ctop() == C_OBJECT_END) { pos++; cpop(); if (!weird) { put(jslit(JL_RC), 1); wave_sync(); uint32_t ni = uni(nstk[--nns]); close_node(ni); pv = ni; } pushing = true; }
-        else if (is(JC_COMMA)) { pos++; if (!weird) put(jslit(JL_COMMA), 1); cpush(C_MEMBERS); cpush(C_PAIR); }
+        if (is(JC_RC) && ctop() == C_OBJECT_END) { pos++; cpop(); if (mk) { put(H + pos - 1, 1); wave_sync(); uint32_t ni = uni(nstk[--nns]); close_node(ni); pv = ni; } pushing = true; }
+        else if (is(JC_COMMA)) { pos++; if (mk) put(H + pos - 1, 1); cpush(C_MEMBERS); cpush(C_PAIR); }
         else rc = -1;
         break;
       case C_PAIR:                                                         // pair/3 :149-154 called with RestContext
         cpop();
-        if (is(JC_COLON) && ctop() == C_PAIR_DELIM) { pos++; cpop(); cpush(C_PAIR_END); cpush(C_VALUE); weird = true; }
+        if (is(JC_COLON) && ctop() == C_PAIR_DELIM) { pos++; cpop(); cpush(C_PAIR_END); cpush(C_VALUE); weird = true; mk = false; }
         else {
-          if (!weird) { uint32_t pi = new_node(J_PAIR, JX_MEMBER, 0, 0); if (l == 0) nstk[nns] = pi; nns++; }
+          if (mk) { uint32_t pi = new_node(J_PAIR, JX_MEMBER, 0, 0); if (l == 0) nstk[nns] = pi; nns++; }
           cpush(C_PAIR_DELIM); cpush(C_VALUE);
         }
         break;
       case C_PAIR_DELIM:                                                   // pair/3 called with the whole Context
-        if (is(JC_COLON)) { pos++; cpop(); cpush(C_PAIR_END); cpush(C_VALUE); if (!weird) put(jslit(JL_COLON), 1); }
-        else { cpush(C_PAIR_DELIM); cpush(C_VALUE); weird = true; }        // ends in a throw or at the end of the block, never in a token
+        if (is(JC_COLON)) { pos++; cpop(); cpush(C_PAIR_END); cpush(C_VALUE); if (mk) put(H + pos - 1, 1); }
+        else { cpush(C_PAIR_DELIM); cpush(C_VALUE); weird = true; mk = false; }        // ends in a throw or at the end of the block, never in a token
         break;
       case C_VALUE: {                                                      // value/3 :104-117
         cpop();
         uint32_t ctx = value_ctx();
         if (is(JC_LB) || is(JC_LC)) {
           bool arr = is(JC_LB);
-          if (!weird) {
+          if (mk) {
             uint32_t ni = new_node(arr ? J_ARR : J_OBJ, ctx, 0, 0);
             if (ctx == JX_KEY && inkey_node == 0xFFFFFFFFu) inkey_node = ni;
             if (l == 0) nstk[nns] = ni;
             nns++;
-            put(jslit(arr ? JL_LB : JL_LC), 1);
+            put(H + pos, 1);
           }
           pos++; cpush(arr ? C_ARRAY : C_OBJECT);
           break;
@@ -189,7 +197,7 @@ __device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, Js
         }
         if (cst < 3) {
           uint32_t wl = cst == 1 ? 5u : 4u;
-          if (!weird) { pv = new_node(J_CONST, ctx, cst, 0); put(jslit(cst == 0 ? JL_TRUE : (cst == 1 ? JL_FALSE : JL_NULL)), wl); close_node(pv); }
+          if (mk) { pv = new_node(J_CONST, ctx, cst, 0); put(H + pos, wl); close_node(pv); }
           pos += wl; pushing = true;
           break;
         }
@@ -203,10 +211,10 @@ __device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, Js
             q = x.w.base + r; found = true; break;
           }
           if (found) {
-            if (!weird) { pv = new_node(J_STR, ctx, pos + 1, q); put(jslit(JL_QUOTE), 1); put(H + pos + 1, q - pos - 1); put(jslit(JL_QUOTE), 1); close_node(pv); }
+            if (mk) { pv = new_node(J_STR, ctx, pos + 1, q); put(H + pos, 1); put(H + pos + 1, q - pos - 1); put(H + q, 1); close_node(pv); }
             pos = q + 1;
           } else {                                                         // {junkstring, Str ++ "\""} printed between quotes
-            if (!weird) { pv = new_node(J_JUNK, ctx, pos + 1, L); put(jslit(JL_QUOTE), 1); put(H + pos + 1, L - pos - 1); put(jslit(JL_QUOTE), 1); put(jslit(JL_QUOTE), 1); close_node(pv); }
+            if (mk) { pv = new_node(J_JUNK, ctx, pos + 1, L); put(H + pos, 1); put(H + pos + 1, L - pos - 1); put(jslit(JL_QUOTE), 1); put(jslit(JL_QUOTE), 1); close_node(pv); }
             pos = L;
           }
           pushing = true;
@@ -222,7 +230,7 @@ __device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, Js
           if (r >= MW_STEP) { q = x.w.base + MW_STEP; continue; }
           q = x.w.base + r; break;
         }
-        if (!weird) { pv = new_node(J_NUM, ctx, pos, q); put(H + pos, q - pos); close_node(pv); }
+        if (mk) { pv = new_node(J_NUM, ctx, pos, q); put(H + pos, q - pos); close_node(pv); }
         pos = q; pushing = true;
         break;
       }
@@ -233,7 +241,7 @@ __device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, Js
   wave_sync();
   if (rc != 0) return rc;
   if (weird && have_top) { c.status = CASE_UNSUPPORTED; return -3; }       // cannot happen (see C_PAIR_DELIM); never guess
-  if (l == 0) { out->nd = nd; out->pc = pc; out->nn = have_top ? nn : 0; out->npc = have_top ? npc : 0; out->have_top = have_top ? 1u : 0u; }
+  if (l == 0) { out->nd = nd; out->pc = pc; out->nn = have_top && build ? nn : 0; out->npc = have_top && build ? npc : 0; out->have_top = have_top ? 1u : 0u; }
   wave_sync();
   return 0;
 }
@@ -264,7 +272,35 @@ __device__ __noinline__ int muta_json(Ctx&) {
   c.r_kind = R_SAME;
   JsDoc* dh = (JsDoc*)ws_alloc(c, sizeof(JsDoc));
   if (!dh) return 0;
-  int rc = json_tokenize(c, H, L, dh);
+  // Quick verdict for the common non-JSON block: a first token that is a "number" (any run of non-separators, :181-188),
+  // something else after it -> ws/3 throws incorrect_json with the empty context (:86-102).  Two 64-byte probes.
+  {
+    uint32_t p0 = L, q0 = L;
+    for (uint32_t base = 0; base < L && p0 == L; base += 64) {            // first non-blank byte
+      uint32_t i = base + (uint32_t)l; uint32_t ch = i < L ? H[i] : 32u;
+      unsigned long long m = __ballot(i < L && !(ch == ' ' || ch == '\n' || ch == '\r' || ch == '\t'));
+      if (m) p0 = base + (uint32_t)__builtin_ctzll(m);
+    }
+    if (p0 < L) {
+      uint32_t c0 = uni(H[p0]);
+      if (c0 != '[' && c0 != '{' && c0 != '"' && c0 != 't' && c0 != 'f' && c0 != 'n') {
+        if (c0 == ',' || c0 == ']' || c0 == '}' || c0 == ':') return -1;  // number/3 throws at once
+        bool more = false;
+        for (uint32_t base = p0; base < L && !more; base += 64) {         // end of the number, then anything but blanks?
+          uint32_t i = base + (uint32_t)l; uint32_t ch = i < L ? H[i] : 0u;
+          bool sep = ch == ' ' || ch == '\n' || ch == '\r' || ch == '\t' || ch == ',' || ch == ']' || ch == '}' || ch == ':';
+          bool blank = ch == ' ' || ch == '\n' || ch == '\r' || ch == '\t';
+          if (q0 == L) { unsigned long long sm = __ballot(i < L && sep); if (sm) q0 = base + (uint32_t)__builtin_ctzll(sm); }
+          unsigned long long nb = __ballot(i < L && i >= q0 && !blank);
+          if (q0 != L && nb) more = true;
+        }
+        if (more) return -1;
+      }
+    }
+  }
+  uint64_t mark0 = c.ws_used;
+  int rc = json_tokenize(c, H, L, dh, false);                              // verdict first, tables only for real documents
+  if (rc == 0 && uni(dh->have_top)) { c.ws_used = mark0; rc = json_tokenize(c, H, L, dh, true); }
   if (rc == -1) return -1;                                                 // catch incorrect_json :729-730
   if (rc == -2) { c.status = CASE_CRASHED; return 0; }
   if (rc != 0) return 0;
@@ -454,6 +490,7 @@ __device__ __noinline__ int muta_json(Ctx&) {
   uint8_t* dst; uint64_t total;
   if (raw) { dst = rawp; total = rawl; }
   else {
+    nout = pieces_coalesce(out, nout);
     total = pieces_total(out, nout);
     if (total > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; return 0; }
     dst = ws_alloc(c, total ? total : 16);

@@ -411,6 +411,42 @@ EH_DEV int b64_decode(const uint8_t* t, uint32_t n, uint8_t* dst) {
   }
   return (int)uni((uint32_t)__shfl(res, 0));
 }
+// The same acceptance test, wave-parallel and without decoding: 64 bytes per step are classified (alphabet, white
+// space, '=', other) with ballots; everything before the first '=' must be alphabet or white space, the number of
+// alphabet characters there decides which padding is legal.  Almost every text chunk fails within its first step,
+// which is what keeps b64 cheap as a failing probe.
+EH_DEV bool b64_accepts(const uint8_t* t, uint32_t n) {
+  const int l = EH_LANE;
+  uint32_t nalpha = 0, eqpos = 0xFFFFFFFFu;
+  for (uint32_t base = 0; base < n && eqpos == 0xFFFFFFFFu; base += 64) {
+    uint32_t i = base + (uint32_t)l; bool in = i < n;
+    uint32_t ch = in ? t[i] : 32u;
+    bool ws = ch == 9 || ch == 10 || ch == 13 || ch == 32;
+    bool al = (ch >= 'A' && ch <= 'Z') || (ch >= 'a' && ch <= 'z') || (ch >= '0' && ch <= '9') || ch == '+' || ch == '/';
+    unsigned long long em = __ballot(in && ch == '='), om = __ballot(in && !ws && !al && ch != '='), am = __ballot(in && al);
+    unsigned long long upto = em ? ((1ull << __builtin_ctzll(em)) - 1) : ~0ull;   // lanes before the first '='
+    if (om & upto) return false;
+    nalpha += (uint32_t)__popcll(am & upto);
+    if (em) eqpos = base + (uint32_t)__builtin_ctzll(em);
+  }
+  uint32_t q = nalpha & 3u;
+  if (eqpos == 0xFFFFFFFFu) return q == 0;
+  if (q != 2 && q != 3) return false;
+  // after the first '=': q == 2 needs one more '=' (white space may sit in between), then only white space
+  uint32_t need = q == 2 ? 1u : 0u; bool ok = true;
+  for (uint32_t base = eqpos + 1; base < n && ok; base += 64) {
+    uint32_t i = base + (uint32_t)l; bool in = i < n;
+    uint32_t ch = in ? t[i] : 32u;
+    bool ws = ch == 9 || ch == 10 || ch == 13 || ch == 32;
+    unsigned long long nm = __ballot(in && !ws);                 // non white space
+    while (nm && ok) {
+      int j = (int)__builtin_ctzll(nm); nm &= nm - 1;
+      uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)ch, j);
+      if (need && cj == '=') need = 0; else ok = false;
+    }
+  }
+  return ok && need == 0;
+}
 // base64:encode_to_string/1: lane g encodes the g-th 3-byte group
 EH_DEV void b64_encode(const uint8_t* src, uint32_t n, uint8_t* dst) {
   uint32_t ng = (n + 2) / 3;

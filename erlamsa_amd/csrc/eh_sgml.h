@@ -18,29 +18,21 @@
 
 namespace eh {
 
-enum { SC_LT, SC_GT, SC_WS, SC_EQ, SC_SL, SC_SQ, SC_DQ, SC_DASH, SC_QM, SC_BANG, SC_K };
-struct SgCls {
-  EH_DEV uint32_t operator()(uint32_t b) const {
-    return (b == '<' ? 1u : 0u) | (b == '>' ? 2u : 0u) | ((b == ' ' || b == '\r' || b == '\n' || b == '\t') ? 4u : 0u) | (b == '=' ? 8u : 0u) |
-           (b == '/' ? 16u : 0u) | (b == '\'' ? 32u : 0u) | (b == '"' ? 64u : 0u) | (b == '-' ? 128u : 0u) | (b == '?' ? 256u : 0u) | (b == '!' ? 512u : 0u);
-  }
-};
-// bit r of the result = bit r+d of the window (crossing into the next lane's word)
-EH_DEV uint64_t word_ahead(uint64_t w, int d) {
-  uint64_t nx = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(w >> 32), 1) << 32) | (uint32_t)__shfl_down((int)(uint32_t)w, 1);
-  if (EH_LANE == 63) nx = 0;
-  return (w >> d) | (nx << (64 - d));
-}
-struct SgWin { MaskWin<SC_K> w; uint64_t ev, stop, slgt, cmt, qgt, nws; };
-EH_DEV void sg_load(SgWin& x, uint32_t base) {
-  mw_load(x.w, base, SgCls());
-  uint64_t gt1 = word_ahead(x.w.m[SC_GT], 1);
-  x.slgt = x.w.m[SC_SL] & gt1;                                             // "/>"
-  x.qgt = x.w.m[SC_QM] & gt1;                                              // "?>"
-  x.cmt = x.w.m[SC_DASH] & word_ahead(x.w.m[SC_DASH], 1) & word_ahead(x.w.m[SC_GT], 2);   // "-->"
-  x.ev = x.w.m[SC_WS] | x.w.m[SC_GT] | x.w.m[SC_EQ];                       // ?ev :64
-  x.stop = x.ev | x.slgt;
-  x.nws = ~x.w.m[SC_WS] & x.w.inrange;
+// byte classes of the tokenizer; 0 = ordinary byte (no event).  The three two/three byte terminators are resolved
+// when the events are extracted: '/' of "/>" is E_SLGT, '?' of "?>" is E_QGT, the first '-' of "-->" is E_CMTEND.
+enum { E_LT = 1, E_GT, E_WS, E_EQ, E_SL, E_SQ, E_DQ, E_DASH, E_QM, E_BANG, E_SLGT, E_QGT, E_CMTEND, E_SPACE };   // E_SPACE: the blank itself; E_WS: \t \n \r
+constexpr uint32_t ES_WS = (1u << E_WS) | (1u << E_SPACE);                                // ?ws :58
+constexpr uint32_t ES_EV = ES_WS | (1u << E_GT) | (1u << E_EQ);                           // ?ev :64
+constexpr uint32_t ES_STOP = ES_EV | (1u << E_SLGT);
+constexpr uint32_t ES_DASH = (1u << E_DASH) | (1u << E_CMTEND);
+// class of a byte below 64, 4 bits each (every special byte is below 64)
+EH_DEV uint32_t sg_class(uint32_t b) {
+  // 9 \t, 10 \n, 13 \r, 32 ' ' -> WS; 33 '!'; 34 '"'; 39 '\''; 45 '-'; 47 '/'; 60 '<'; 61 '='; 62 '>'; 63 '?'
+  const uint64_t t0 = ((uint64_t)E_WS << 36) | ((uint64_t)E_WS << 40) | ((uint64_t)E_WS << 52);                  // bytes 0..15
+  const uint64_t t2 = ((uint64_t)E_SPACE << 0) | ((uint64_t)E_BANG << 4) | ((uint64_t)E_DQ << 8) | ((uint64_t)E_SQ << 28) | ((uint64_t)E_DASH << 52) | ((uint64_t)E_SL << 60);   // 32..47
+  const uint64_t t3 = ((uint64_t)E_LT << 48) | ((uint64_t)E_EQ << 52) | ((uint64_t)E_GT << 56) | ((uint64_t)E_QM << 60);   // 48..63
+  uint64_t t = b < 16 ? t0 : (b < 32 ? 0ull : (b < 48 ? t2 : t3));
+  return b < 64 ? (uint32_t)((t >> (4 * (b & 15))) & 15) : 0u;
 }
 
 // literal pool of fold_ast/2 (:290-331)
@@ -59,172 +51,252 @@ struct SgDoc { SgTok* tok; SgParam* par; Piece* pc; uint32_t ntok, npar, npc; };
 
 // tokenize/1 :66-98 + tz/2 :100-164.  0 ok; -1 incorrect_sgml; -2 an error other than incorrect_sgml in the
 // first tag (outside any try: the worker dies); -3 engine capacity (c.status set).
+//
+// Phase 1 turns the block into an EVENT list — (position, class) of every special byte, extracted 1 KiB per step by
+// the whole wave.  Phase 2 is tz/2 written as plain loops over that list: every tz state is "the next event whose
+// class is in set X", answered for 64 events at a time with one ballot; ordinary bytes are never looked at.
+// A failed tag is retried from its next '<' by the reference (catch _:_ :79-96), which re-scans the same attribute
+// list again and again on text like "<a <b <c ... " without a '>' — quadratic, minutes on BEAM.  The attribute
+// loop entered at byte p always ends the same way, whatever tag led there, so the positions at which a FAILED
+// attempt entered it are remembered (after its 16th attribute) and a later attempt arriving at one of them fails
+// at once: same tokens, linear time.
 __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, SgDoc* out) {
   EH_CTX;
   const int l = EH_LANE;
-  // capacity: tokens <= 2 x '<' + 2; a parameter needs a byte of the stop set after its name
-  uint32_t nlt = 0, nstop = 0;
-  for (uint32_t i0 = 16u * (uint32_t)l; i0 < L; i0 += 1024) {
-    uint32_t cnt = L - i0 < 16 ? L - i0 : 16;
-    uint8_t b[16];
-    if (cnt == 16) { uint4 v; __builtin_memcpy(&v, H + i0, 16); __builtin_memcpy(b, &v, 16); }
-    else { for (uint32_t k = 0; k < 16; k++) b[k] = k < cnt ? H[i0 + k] : 0; }
+  // ---- phase 1: events
+  uint32_t* ev = (uint32_t*)ws_alloc(c, ((uint64_t)L + 80) * 4);
+  if (!ev) return -3;
+  uint32_t nev = 0, nlt = 0, nstop = 0;
+  for (uint32_t tb = 0; tb < L; tb += 1024) {
+    uint32_t i0 = tb + 16u * (uint32_t)l;
+    uint8_t b[18];
+    if (i0 + 18 <= L) { uint4 v; __builtin_memcpy(&v, H + i0, 16); __builtin_memcpy(b, &v, 16); b[16] = H[i0 + 16]; b[17] = H[i0 + 17]; }
+    else { for (uint32_t k = 0; k < 18; k++) b[k] = i0 + k < L ? H[i0 + k] : 0; }
+    uint32_t cls[16]; uint32_t cnt = 0, lts = 0, stops = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 16; k++) { uint32_t x = b[k]; if (k < cnt) { nlt += x == '<'; nstop += (x == ' ' || x == '\r' || x == '\n' || x == '\t' || x == '>' || x == '=' || x == '/'); } }
+    for (uint32_t k = 0; k < 16; k++) {
+      uint32_t x = b[k];
+      uint32_t cl = i0 + k < L ? sg_class(x) : 0u;
+      if (cl == E_SL && b[k + 1] == '>') cl = E_SLGT;
+      if (cl == E_QM && b[k + 1] == '>') cl = E_QGT;
+      if (cl == E_DASH && b[k + 1] == '-' && b[k + 2] == '>') cl = E_CMTEND;
+      cls[k] = cl; cnt += cl ? 1u : 0u; lts += cl == E_LT ? 1u : 0u; stops += (cl == E_WS || cl == E_SPACE || cl == E_GT || cl == E_EQ || cl == E_SL || cl == E_SLGT) ? 1u : 0u;
+    }
+    uint32_t inc = wave_incl_scan(cnt);
+    uint32_t o = nev + inc - cnt;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) if (cls[k]) ev[o++] = ((i0 + k) << 4) | cls[k];
+    nev += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    nlt += lts; nstop += stops;
   }
   nlt = wave_sum(nlt); nstop = wave_sum(nstop);
   if (nlt == 0) return -1;                                                 // tz(nil, <<>>) :102
+  // capacity: tokens <= 2 x '<' + 2; a parameter needs a byte of the stop set after its name
   uint32_t cap_tok = 2 * nlt + 8, cap_par = nstop + 8;
   uint64_t cap_pc = 4ull * cap_tok + (uint64_t)SG_PARPCS * cap_par + nlt + 32;
   SgTok* tok = (SgTok*)ws_alloc(c, (uint64_t)cap_tok * sizeof(SgTok));
   SgParam* par = (SgParam*)ws_alloc(c, (uint64_t)cap_par * sizeof(SgParam));
   Piece* pc = (Piece*)ws_alloc(c, cap_pc * sizeof(Piece));
   if (!tok || !par || !pc) return -3;
+  wave_sync();
   uint32_t ntok = 0, npar = 0, npc = 0;
 
-  enum { Z_NIL, Z_TEXT, Z_SKIPWS, Z_TAG0, Z_NAME, Z_ATTR0, Z_ATTRN, Z_EATT, Z_VAL, Z_SQ, Z_DQ, Z_UQ, Z_BANG, Z_COMMENT, Z_QUE, Z_ENDNAME, Z_END2 };
-  SgWin x; x.w.p = H; x.w.L = L; x.w.valid = false; x.w.base = 0;
-  int state = Z_NIL, after = Z_NIL;
-  bool first = true, done = false;
-  uint32_t pos = 0, lt = 0, tag0 = 0, seg_start = 0, text_p0 = 0, text_len = 0, seg_slot = 0, tag_p0 = 0, par0 = 0;
-  uint32_t na = 0, nb = 0, an = 0, ae = 0, va = 0, dta = 0;
+  // ---- phase 2
+  uint32_t bev = 0, bbase = 0xFFFFFFFFu;                                   // lane k holds event bbase + k
+  auto need = [&](uint32_t i) { if (bbase == 0xFFFFFFFFu || i < bbase || i >= bbase + 64) { bbase = i & ~63u; uint32_t j = bbase + (uint32_t)l; bev = j < nev ? ev[j] : 0u; } };
+  // index of the first event >= from whose class is in `set`; nev if there is none
+  auto find = [&](uint32_t from, uint32_t set) -> uint32_t {
+    while (from < nev) {
+      need(from);
+      unsigned long long m = __ballot(((set >> (bev & 15u)) & 1u) != 0 && bbase + (uint32_t)l >= from && bbase + (uint32_t)l < nev);
+      if (m) return bbase + (uint32_t)__builtin_ctzll(m);
+      from = bbase + 64;
+    }
+    return nev;
+  };
+  auto evget = [&](uint32_t i) -> uint32_t { need(i); return (uint32_t)__builtin_amdgcn_readlane((int)bev, (int)(i - bbase)); };
+  uint32_t pos = 0, ei = 0;                                                // ei = first event at or after byte pos
+  auto cls_here = [&]() -> uint32_t { if (ei >= nev) return 0u; uint32_t e = evget(ei); return (e >> 4) == pos ? (e & 15u) : 0u; };
+  auto step1 = [&]() { if (ei < nev && (evget(ei) >> 4) == pos) ei++; pos++; };        // consume one byte
+  bool ws_sp = false;                                                      // the last skipws() ended on a blank (0x20)
+  auto skipws = [&]() {                                                    // ws/1 :176-177
+    ws_sp = false;
+    while (ei < nev) {
+      need(ei);
+      uint32_t off = ei - bbase;
+      bool ok = (uint32_t)l >= off && bbase + (uint32_t)l < nev && ((ES_WS >> (bev & 15u)) & 1u) && (bev >> 4) == pos + ((uint32_t)l - off);
+      unsigned long long notok = ~__ballot(ok) & ~((1ull << off) - 1);
+      uint32_t run = notok ? (uint32_t)__builtin_ctzll(notok) - off : 64u - off;
+      if (run > 0) ws_sp = ((uint32_t)__builtin_amdgcn_readlane((int)bev, (int)(off + run - 1)) & 15u) == E_SPACE;
+      pos += run; ei += run;
+      if (off + run < 64) break;
+    }
+  };
+  auto put = [&](const uint8_t* p, uint32_t len) { if (l == 0) { Piece q; q.ptr = (uint64_t)p; q.len = len; q.rep = 1; pc[npc] = q; } npc++; };
+
+  // memo of attribute-loop entries of failed attempts (see above)
+  uint8_t* bad = nullptr; uint32_t* chain = nullptr; uint32_t nchain = 0;
   int rc = 0;
-
-  auto put = [&](const uint8_t* p, uint32_t len) { piece_put(pc, npc, p, len); npc++; };
-  auto param = [&](uint32_t vb, uint32_t delim) {                          // As ++ [{A, V, Delim}]
-    if (l == 0) { SgParam q; q.na = an; q.nb = ae; q.va = va; q.vb = vb; q.delim = delim; q.pad = 0; par[npar] = q; }
-    npar++;
-    bool has = vb > va;
-    const uint8_t* qp = sglit(delim == 1 ? SL_SQ : SL_DQ);
-    put(sglit(SL_SP), 1); put(H + an, ae - an);
-    put(sglit(SL_EQ), has ? 1u : 0u); put(qp, has && delim ? 1u : 0u); put(H + va, has ? vb - va : 0u); put(qp, has && delim ? 1u : 0u);
-  };
-  auto tag_head = [&]() { put(sglit(SL_LT), 1); put(H + na, nb - na); put(sglit(SL_SP), 0); };
-  // a token is complete: the text before it (if any) and the token itself are recorded
-  auto success = [&](uint32_t kind, uint32_t next) {
-    if (!first) {
-      if (l == 0) { pc[seg_slot].ptr = (uint64_t)(H + seg_start); pc[seg_slot].len = lt - seg_start; pc[seg_slot].rep = 1; }
-      text_len += lt - seg_start;
-      if (l == 0) { SgTok t; t.kind = TK_TEXT | (text_len == 0 ? (uint32_t)TF_EMPTY : 0u); t.p0 = text_p0; t.np = seg_slot + 1 - text_p0; t.na = 0; t.nb = 0; t.par0 = 0; t.npar = 0; t.match = -1; tok[ntok] = t; }
-      ntok++;
-    }
-    if (l == 0) { SgTok t; t.kind = kind; t.p0 = tag_p0; t.np = npc - tag_p0; t.na = na; t.nb = nb; t.par0 = par0; t.npar = npar - par0; t.match = -1; tok[ntok] = t; }
-    ntok++;
-    first = false;
-    pos = next; seg_start = next; text_p0 = npc; text_len = 0; state = Z_TEXT;
-  };
-  // the tag does not parse.  other = an error that is not throw(incorrect_sgml)
-  auto fail = [&](bool other) {
-    if (first) { rc = other ? -2 : -1; done = true; return; }
-    npc = seg_slot; npar = par0;                                           // forget the pieces of the attempt
-    if (tag0 > lt + 1) {                                                   // ws/1 ate white space after the '<': it is gone from the text (:80,:92)
-      piece_put(pc, npc, H + seg_start, lt + 1 - seg_start); npc++;
-      text_len += lt + 1 - seg_start; seg_start = tag0;
-    }
-    pos = tag0; state = Z_TEXT;                                            // ff/4 goes on from EStr
-  };
-
-  while (!done) {
-    if (npc + 16 > cap_pc || ntok + 2 > cap_tok || npar + 1 > cap_par) { c.status = CASE_OVERFLOW; return -3; }
-    if (pos >= L) {                                                        // end of the block
-      if (state == Z_SKIPWS) { state = after; continue; }
-      if (state == Z_NIL) { rc = -1; break; }
-      if (state == Z_TAG0) tag0 = L;                                       // ws/1 ran into the end: EStr = <<>>
-      if (state == Z_TEXT) {                                               // {{text,Str},"",eof} :82-83,:94-95
-        uint32_t n = L - seg_start;
-        put(H + seg_start, n); text_len += n;
-        if (l == 0) { SgTok t; t.kind = TK_TEXT | (text_len == 0 ? (uint32_t)TF_EMPTY : 0u); t.p0 = text_p0; t.np = npc - text_p0; t.na = 0; t.nb = 0; t.par0 = 0; t.npar = 0; t.match = -1; tok[ntok] = t; }
-        ntok++;
-        break;
+  bool first = true;
+  uint32_t lt = 0, seg_start = 0, text_p0 = 0, text_len = 0, seg_slot = 0;
+  // tz(nil, ..) :100-101: bytes before the first '<' are dropped
+  {
+    uint32_t j = find(0, 1u << E_LT);
+    lt = evget(j) >> 4; pos = lt + 1; ei = j + 1;
+  }
+  for (;;) {
+    if (npc + 16 > cap_pc || ntok + 2 > cap_tok) { c.status = CASE_OVERFLOW; return -3; }
+    // ---- one tag attempt: '<' at lt, pos/ei just behind it
+    skipws();
+    const uint32_t tag0 = pos, ei0 = ei, tag_p0 = npc, par0 = npar;
+    const bool tight = tag0 == lt + 1;                                     // no white space behind the '<': "<!", "</" ... are in the input as such
+    uint32_t kind = 0, na = pos, nb = pos, next = 0, nexte = 0;
+    bool ok = false, other = false;
+    nchain = 0;
+    do {
+      if (pos >= L) break;
+      uint32_t c0 = cls_here();
+      if (c0 == E_BANG) {                                                  // :104-105
+        bool d1 = false, d2 = false;
+        if (ei + 2 < nev + 0u) { uint32_t e1 = evget(ei + 1), e2 = evget(ei + 2); d1 = (e1 >> 4) == pos + 1 && ((ES_DASH >> (e1 & 15u)) & 1u); d2 = (e2 >> 4) == pos + 2 && ((ES_DASH >> (e2 & 15u)) & 1u); }
+        if (d1 && d2) {                                                    // {'!--',DT} :117-118
+          uint32_t dta = pos + 3;
+          uint32_t j = find(ei + 3, 1u << E_CMTEND);
+          if (j >= nev) { other = true; break; }                           // no clause of tz/2 matches {'!--',_}, <<>>
+          uint32_t e = evget(j) >> 4;
+          put(tight ? H + lt : sglit(SL_CMT), 4); put(H + dta, e - dta); put(H + e, 3);
+          kind = TK_COMMENT; next = e + 3; nexte = j + 3; ok = true; break;
+        }
+        step1(); skipws();                                                 // {'!',DT} :113-115
+        uint32_t dta = pos;
+        uint32_t j = find(ei, 1u << E_GT);
+        if (j >= nev) break;
+        uint32_t e = evget(j) >> 4;
+        put(tight ? H + lt : sglit(SL_LTBANG), 2); put(H + dta, e - dta); put(H + e, 1);
+        kind = TK_BANG; next = e + 1; nexte = j + 1; ok = true; break;
       }
-      fail(state == Z_COMMENT);                                            // no clause of tz/2 matches {'!--',_}, <<>>
-      continue;
+      if (c0 == E_QM || c0 == E_QGT) {                                     // {que,DT} :106,:120-122
+        step1(); skipws();
+        uint32_t dta = pos;
+        uint32_t j = find(ei, 1u << E_QGT);
+        if (j >= nev) break;
+        uint32_t e = evget(j) >> 4;
+        put(tight ? H + lt : sglit(SL_LTQ), 2); put(H + dta, e - dta); put(H + e, 2);
+        kind = TK_QUE; next = e + 2; nexte = j + 2; ok = true; break;
+      }
+      if (c0 == E_SL || c0 == E_SLGT) {                                    // {end_tag,Tag} :107,:128-132
+        step1(); skipws();
+        na = pos;
+        uint32_t j = find(ei, ES_EV);
+        if (j >= nev) break;
+        nb = evget(j) >> 4; pos = nb; ei = j;
+        skipws();
+        if (cls_here() != E_GT) break;
+        put(tight ? H + lt : sglit(SL_LTSL), 2); put(H + na, nb - na); put(H + pos, 1);
+        kind = TK_CLOSE; next = pos + 1; nexte = ei + 1; ok = true; break;
+      }
+      // {tag,Tag} :108-111
+      uint32_t j = find(ei, ES_STOP);
+      if (j >= nev) break;
+      uint32_t ej = evget(j);
+      nb = ej >> 4;
+      put(H + lt, 1); put(H + na, nb - na); put(sglit(SL_SP), 0);           // "<", name, slot for extra params
+      if ((ej & 15u) == E_SLGT) { put(sglit(SL_SPSLGT), 3); kind = TK_SC; next = nb + 2; nexte = j + 2; ok = true; break; }
+      pos = nb; ei = j;
+      skipws();
+      // attribute loop: {attr,..} {eatt,..} {val,..} {sqval|dqval|uqval,..} :134-160
+      uint32_t nattr = 0;
+      for (;;) {
+        if (npc + 16 > cap_pc || npar + 1 > cap_par) { c.status = CASE_OVERFLOW; return -3; }
+        if (pos >= L) break;
+        if (nattr >= 16) {                                                 // quadratic-rescan guard
+          if (bad && uni(bad[pos])) break;
+          if (!chain) { chain = (uint32_t*)ws_alloc(c, ((uint64_t)nstop + 8) * 4); if (!chain) return -3; }
+          if (l == 0) chain[nchain] = pos;
+          nchain++;
+        }
+        uint32_t ca = cls_here();
+        if (ca == E_SLGT) { put(ws_sp ? H + pos - 1 : sglit(SL_SPSLGT), 3); kind = TK_SC; next = pos + 2; nexte = ei + 2; ok = true; break; }   // {etag,..} :124-125
+        if (ca == E_GT) { put(H + pos, 1); kind = TK_OPEN; next = pos + 1; nexte = ei + 1; ok = true; break; }
+        const bool sp_before = ws_sp;                                      // the blank in front of the name is in the input
+        if (ca == E_EQ) break;                                             // tz({etag,..}, _) throws
+        uint32_t an = pos;
+        step1();
+        uint32_t ja = find(ei, ES_STOP);
+        if (ja >= nev) break;
+        uint32_t ae = evget(ja) >> 4; pos = ae; ei = ja;
+        skipws();
+        uint32_t va = pos, vb = pos, delim = 0, eqpos = 0xFFFFFFFFu;
+        if (pos < L && cls_here() == E_EQ) {                               // {eatt,..} "=" -> {val,..} :141,:144-146
+          eqpos = pos;
+          step1(); skipws();
+          if (pos >= L) break;
+          uint32_t cv = cls_here();
+          if (cv == E_SQ || cv == E_DQ) {
+            uint32_t jq = find(ei + 1, 1u << cv);
+            if (jq >= nev) break;                                          // unterminated quote
+            va = pos + 1; vb = evget(jq) >> 4; delim = cv == E_SQ ? 1u : 2u;
+            pos = vb + 1; ei = jq + 1;
+          } else {
+            uint32_t ju = find(ei, ES_STOP);
+            if (ju >= nev) break;
+            va = pos; vb = evget(ju) >> 4; pos = vb; ei = ju;
+          }
+          skipws();
+        }
+        // As ++ [{A, V, Delim}]
+        if (l == 0) { SgParam q; q.na = an; q.nb = ae; q.va = va; q.vb = vb; q.delim = delim; q.pad = 0; par[npar] = q; }
+        npar++; nattr++;
+        bool has = vb > va;
+        const uint8_t* qp = sglit(delim == 1 ? SL_SQ : SL_DQ);
+        put(sp_before ? H + an - 1 : sglit(SL_SP), 1); put(H + an, ae - an);
+        put(has ? H + eqpos : sglit(SL_EQ), has ? 1u : 0u); put(has && delim ? H + va - 1 : qp, has && delim ? 1u : 0u);
+        put(H + va, has ? vb - va : 0u); put(has && delim ? H + vb : qp, has && delim ? 1u : 0u);
+      }
+    } while (false);
+    if (c.status != CASE_OK) return -3;
+    if (ok) {
+      // the text before the tag (if any) and the tag itself
+      if (!first) {
+        if (l == 0) { Piece q; q.ptr = (uint64_t)(H + seg_start); q.len = lt - seg_start; q.rep = 1; pc[seg_slot] = q; }
+        text_len += lt - seg_start;
+        if (l == 0) { SgTok t; t.kind = TK_TEXT | (text_len == 0 ? (uint32_t)TF_EMPTY : 0u); t.p0 = text_p0; t.np = seg_slot + 1 - text_p0; t.na = 0; t.nb = 0; t.par0 = 0; t.npar = 0; t.match = -1; tok[ntok] = t; }
+        ntok++;
+      }
+      if (l == 0) { SgTok t; t.kind = kind; t.p0 = tag_p0; t.np = npc - tag_p0; t.na = na; t.nb = nb; t.par0 = par0; t.npar = npar - par0; t.match = -1; tok[ntok] = t; }
+      ntok++;
+      first = false;
+      pos = next; ei = nexte; seg_start = next; text_p0 = npc; text_len = 0;
+    } else {
+      if (first) { rc = other ? -2 : -1; break; }
+      if (nchain > 0) {                                                    // remember where this attempt entered the attribute loop
+        if (!bad) {
+          bad = ws_alloc(c, (uint64_t)L + 16);
+          if (!bad) return -3;
+          for (uint32_t i = 16u * (uint32_t)l; i < L + 16; i += 1024) { uint4 z = {0, 0, 0, 0}; __builtin_memcpy(bad + i, &z, 16); }
+        }
+        wave_sync();
+        for (uint32_t i = l; i < nchain; i += 64) bad[chain[i]] = 1;
+        wave_sync();
+      }
+      npc = seg_slot; npar = par0;                                         // forget the pieces of the attempt
+      if (tag0 > lt + 1) {                                                 // ws/1 ate white space after the '<': it is gone from the text (:80,:92)
+        put(H + seg_start, lt + 1 - seg_start);
+        text_len += lt + 1 - seg_start; seg_start = tag0;
+      }
+      pos = tag0; ei = ei0;                                                // ff/4 goes on from EStr
     }
-    if (!x.w.valid || pos < x.w.base || pos >= x.w.base + MW_STEP) sg_load(x, pos & ~63u);
-    const uint32_t rel = pos - x.w.base;
-    // "hop": next position of `word` at or after pos; false = not in this window (pos moved to its end)
-    auto hop = [&](uint64_t word, uint32_t* at) -> bool {
-      uint32_t r = mw_next(word, rel);
-      if (r >= MW_STEP) { pos = x.w.base + MW_STEP; return false; }
-      *at = x.w.base + r; return true;
-    };
-    uint32_t p;
-    switch (state) {
-      case Z_NIL:                                                          // tz(nil, ..) :100-101: bytes before the first '<' are dropped
-        if (!hop(x.w.m[SC_LT], &p)) break;
-        lt = p; pos = p + 1; after = Z_TAG0; state = Z_SKIPWS; break;
-      case Z_TEXT:                                                         // ff/4 :166-174
-        if (!hop(x.w.m[SC_LT], &p)) break;
-        lt = p; seg_slot = npc; npc++; par0 = npar;                        // slot for the text segment that ends here
-        pos = p + 1; after = Z_TAG0; state = Z_SKIPWS; break;
-      case Z_SKIPWS:                                                       // ws/1 :176-177
-        if (!hop(x.nws, &p)) break;
-        pos = p; state = after; break;
-      case Z_TAG0:                                                         // {tag,""} :104-107
-        tag0 = pos; tag_p0 = npc; par0 = npar; na = pos; nb = pos;
-        if (mw_test(x.w.m[SC_BANG], rel)) {
-          if (mw_test(x.w.m[SC_DASH], rel + 1) && mw_test(x.w.m[SC_DASH], rel + 2)) { dta = pos + 3; pos += 3; state = Z_COMMENT; }
-          else { pos += 1; after = Z_BANG; state = Z_SKIPWS; dta = 0xFFFFFFFFu; }
-        } else if (mw_test(x.w.m[SC_QM], rel)) { pos += 1; after = Z_QUE; state = Z_SKIPWS; dta = 0xFFFFFFFFu; }
-        else if (mw_test(x.w.m[SC_SL], rel)) { pos += 1; after = Z_ENDNAME; state = Z_SKIPWS; na = 0xFFFFFFFFu; }
-        else state = Z_NAME;
-        break;
-      case Z_NAME:                                                         // {tag,Tag} :108-111
-        if (!hop(x.stop, &p)) break;
-        nb = p;
-        tag_head();
-        if (mw_test(x.slgt, p - x.w.base)) { put(sglit(SL_SPSLGT), 3); success(TK_SC, p + 2); }
-        else { pos = p; after = Z_ATTR0; state = Z_SKIPWS; }
-        break;
-      case Z_ATTR0:                                                        // {attr,"",..} :134-135,138 -> {etag,..} :124-126
-        if (mw_test(x.slgt, rel)) { put(sglit(SL_SPSLGT), 3); success(TK_SC, pos + 2); }
-        else if (mw_test(x.w.m[SC_GT], rel)) { put(sglit(SL_GT), 1); success(TK_OPEN, pos + 1); }
-        else if (mw_test(x.ev, rel)) fail(false);                          // '=' : tz({etag,..}, _) throws
-        else { an = pos; pos += 1; state = Z_ATTRN; }
-        break;
-      case Z_ATTRN:                                                        // {attr,A,..} :136-139
-        if (!hop(x.stop, &p)) break;
-        ae = p; pos = p; after = Z_EATT; state = Z_SKIPWS; break;
-      case Z_EATT:                                                         // {eatt,..} :141-142
-        if (mw_test(x.w.m[SC_EQ], rel)) { pos += 1; after = Z_VAL; state = Z_SKIPWS; }
-        else { va = pos; param(pos, 0); state = Z_ATTR0; }
-        break;
-      case Z_VAL:                                                          // {val,..} :144-146
-        if (mw_test(x.w.m[SC_SQ], rel)) { va = pos + 1; pos += 1; state = Z_SQ; }
-        else if (mw_test(x.w.m[SC_DQ], rel)) { va = pos + 1; pos += 1; state = Z_DQ; }
-        else { va = pos; state = Z_UQ; }
-        break;
-      case Z_SQ: case Z_DQ:                                                // :148-154
-        if (!hop(state == Z_SQ ? x.w.m[SC_SQ] : x.w.m[SC_DQ], &p)) break;
-        param(p, state == Z_SQ ? 1u : 2u);
-        pos = p + 1; after = Z_ATTR0; state = Z_SKIPWS; break;
-      case Z_UQ:                                                           // :157-160
-        if (!hop(x.stop, &p)) break;
-        param(p, 0);
-        pos = p; after = Z_ATTR0; state = Z_SKIPWS; break;
-      case Z_BANG:                                                         // {'!',DT} :113-115
-        if (dta == 0xFFFFFFFFu) dta = pos;
-        if (!hop(x.w.m[SC_GT], &p)) break;
-        put(sglit(SL_LTBANG), 2); put(H + dta, p - dta); put(sglit(SL_GT), 1);
-        success(TK_BANG, p + 1); break;
-      case Z_COMMENT:                                                      // {'!--',DT} :117-118
-        if (!hop(x.cmt, &p)) break;
-        put(sglit(SL_CMT), 4); put(H + dta, p - dta); put(sglit(SL_CMTEND), 3);
-        success(TK_COMMENT, p + 3); break;
-      case Z_QUE:                                                          // {que,DT} :120-122
-        if (dta == 0xFFFFFFFFu) dta = pos;
-        if (!hop(x.qgt, &p)) break;
-        put(sglit(SL_LTQ), 2); put(H + dta, p - dta); put(sglit(SL_QGT), 2);
-        success(TK_QUE, p + 2); break;
-      case Z_ENDNAME:                                                      // {end_tag,Tag} :128,:130
-        if (na == 0xFFFFFFFFu) na = pos;
-        if (!hop(x.ev, &p)) break;
-        nb = p; pos = p; after = Z_END2; state = Z_SKIPWS; break;
-      case Z_END2:                                                         // {end_tag,Tag,'>'} :129,:131
-        if (mw_test(x.w.m[SC_GT], rel)) { put(sglit(SL_LTSL), 2); put(H + na, nb - na); put(sglit(SL_GT), 1); success(TK_CLOSE, pos + 1); }
-        else fail(false);
-        break;
+    // ---- text state: ff/4 :166-174
+    uint32_t j = find(ei, 1u << E_LT);
+    if (j >= nev) {                                                        // {{text,Str},"",eof} :82-83,:94-95
+      uint32_t n = L - seg_start;
+      put(H + seg_start, n); text_len += n;
+      if (l == 0) { SgTok t; t.kind = TK_TEXT | (text_len == 0 ? (uint32_t)TF_EMPTY : 0u); t.p0 = text_p0; t.np = npc - text_p0; t.na = 0; t.nb = 0; t.par0 = 0; t.npar = 0; t.match = -1; tok[ntok] = t; }
+      ntok++;
+      break;
     }
+    lt = evget(j) >> 4; seg_slot = npc; npc++;                             // slot for the text segment that ends here
+    pos = lt + 1; ei = j + 1;
   }
   wave_sync();
   if (rc != 0) return rc;
@@ -359,7 +431,9 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
   if (binarish(H, L)) return -1;                                           // parse/2 :198-199
   SgDoc* dh = (SgDoc*)ws_alloc(c, sizeof(SgDoc));
   if (!dh) return 0;
+  EH_PT0;
   int rc = sgml_tokenize(c, H, L, dh);
+  EH_PT(c, 90);
   if (rc == -1) return -1;                                                 // catch incorrect_sgml :755-756
   if (rc == -2) { c.status = CASE_CRASHED; return 0; }
   if (rc != 0) return 0;
@@ -371,6 +445,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
   sgml_pair(H, tok, ntok, stk);
   uint32_t N, NT;
   sgml_flags(tok, ntok, ef, &N, &NT);
+  EH_PT(c, 91);
   // output piece list: worst case every doc piece twice plus a few literals
   uint32_t cap_out = 2 * npc + 64;
   Piece* out = (Piece*)ws_alloc(c, (uint64_t)cap_out * sizeof(Piece));
@@ -621,12 +696,15 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
   if (nout > cap_out) { c.status = CASE_OVERFLOW; return 0; }
   // NewBinStr = fold_ast(Res, []) :746
   wave_sync();
+  EH_PT(c, 92);
+  nout = pieces_coalesce(out, nout);
   uint64_t total = pieces_total(out, nout);
   if (total > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; return 0; }
   uint8_t* dst = ws_alloc(c, total ? total : 16);
   if (!dst) return 0;
   wave_gather(dst, out, nout);
   wave_sync();
+  EH_PT(c, 93);
   if ((uint32_t)total == L && wave_equal(dst, H, L)) return -1;            // NewBinStr =:= H :748-749
   c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)total; c.r_changed = 1;
   return D + (int)(total / (AVG_BLOCK_SIZE * 10));
