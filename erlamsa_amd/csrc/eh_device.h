@@ -253,6 +253,16 @@ struct Ctx {
 // therefore ignore their Ctx& argument and bind `c` to the LDS object directly (EH_CTX), which lets the
 // compiler emit ds_read/ds_write.
 __shared__ Ctx g_ctx;
+// LDS scratch that lanes write individually (histograms).  The CPU wavefront emulator of tests/hipemu models
+// __shared__ as wave-uniform state, so there the array is plain memory (one wavefront runs at a time).
+#ifdef HIPEMU
+#define EH_LDS_ARRAY(type, name, n) static type name[n]
+#else
+#define EH_LDS_ARRAY(type, name, n) __shared__ type name[n]
+#endif
+// orders LDS accesses of different lanes of the wavefront.  The hardware runs a wavefront's LDS instructions in
+// program order, so nothing is emitted; on the emulator the ballot is a rendezvous of the lane fibers.
+EH_DEV void lanes_sync() { (void)__ballot(1); }
 #define EH_CTX Ctx& c = g_ctx
 // per-lane mux_fuzzers entry (lane i = list position i); private registers, never in LDS
 struct LaneTab {

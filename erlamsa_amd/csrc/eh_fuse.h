@@ -25,7 +25,11 @@ namespace eh {
 //   * a node with more than 64 entries on a side: 256-bin LDS histograms + ballot-matched stable scatter.
 // The PRNG draws (one rand(8) per round, rand_elem x3 at the end) are the reference's.
 // ---------------------------------------------------------------------------------------------
+// fc == 1: fo IS the suffix position (nothing is stored in F for it); fc > 1: fo = offset of the fc positions in F.
+// Likewise to / tc / T.  Most nodes are {1,1} after a round or two and then cost one 16-byte load and store per round.
 struct FNode { uint32_t fo, fc, to, tc; };
+// big-node path: [0,256) source count -> cursor, [256,512) target, [512,768) child index of the bin, [768,1024) flags
+EH_LDS_ARRAY(uint32_t, g_fuse_lds, 1024);
 
 // ascending bitonic sort of one 32-bit key per lane
 EH_DEV uint32_t wave_sort64(uint32_t key) {
@@ -55,16 +59,18 @@ EH_DEV uint32_t lanes_lt(uint32_t v, uint32_t cnt, uint32_t x) { uint32_t r = la
 
 struct FuseGen { FNode* nd; uint32_t* F; uint32_t* T; };
 
-// one refinement round over all nodes of `g` (generation parity par) into `o`; returns the number of children
-EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, const FuseGen& g, uint32_t nn, const FuseGen& o, uint32_t par, uint32_t* hist) {
+// One refinement round over all nodes of `g` (generation parity par) into `o`; returns the number of children.
+// sym: fuse(H, H) — the target lists are the source lists at every level, only one side is computed.
+EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, const FuseGen& g, uint32_t nn, const FuseGen& o, uint32_t par, bool sym) {
   const int l = EH_LANE;
   const bool asc = par == 0;
-  uint32_t cn = 0, cf = 0, ct = 0;                               // children, source entries, target entries written so far
+  uint32_t cn = 0, cf = 0, ct = 0;                               // children / F entries / T entries written so far
   uint32_t k0 = 0;
   while (k0 < nn) {
     uint32_t k = k0 + (uint32_t)l;
     FNode nd = {0, 0, 0, 0};
     if (k < nn) nd = g.nd[k];
+    if (sym) { nd.to = nd.fo; nd.tc = nd.fc; }
     bool valid = k < nn;
     bool big = valid && (nd.fc > 64 || nd.tc > 64);
     bool one = valid && nd.fc == 1 && nd.tc == 1;
@@ -72,58 +78,59 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
     uint32_t nvalid = (uint32_t)__popcll(vm);
     uint32_t nones = ~om == 0ull ? 64u : (uint32_t)__builtin_ctzll(~om);
     if (nones > nvalid) nones = nvalid;
-    EH_PT0;
     if (nones >= 16 || (nones > 0 && nones == nvalid)) {
-      // ---- run of {1,1} nodes
+      // ---- run of {1,1} nodes: positions are in the descriptor
       bool in = (uint32_t)l < nones;
-      uint32_t p = in ? g.F[nd.fo] : la, q = in ? g.T[nd.to] : lb;
-      uint32_t ba = (in && p < la) ? A[p] : 256u, bb = (in && q < lb) ? B[q] : 257u;
+      uint32_t p = in ? nd.fo : la, q = in ? nd.to : lb;
       bool special = in && p == la - 1;                          // its only member is dropped: {[[]], [[]]}
-      bool child = special || (in && p < la && ba == bb);
+      bool same;
+      if (sym) same = in && p < la;                              // q == p: the bytes are the same byte
+      else { uint32_t ba = (in && p < la) ? A[p] : 256u, bb = (in && q < lb) ? B[q] : 257u; same = ba == bb; }
+      bool child = special || same;
       bool tkeep = child && !special && q != lb - 1;             // a target whose rest is [] is dropped as well
-      unsigned long long cm = __ballot(child), tm = __ballot(child && (special || tkeep));
-      uint32_t ci = (uint32_t)__popcll(cm & ((1ull << l) - 1)), ti = (uint32_t)__popcll(tm & ((1ull << l) - 1));
+      unsigned long long cm = __ballot(child);
+      uint32_t ci = (uint32_t)__popcll(cm & ((1ull << l) - 1));
       if (child) {
-        FNode c2; c2.fo = cf + ci; c2.fc = 1; c2.to = ct + ti; c2.tc = (special || tkeep) ? 1u : 0u;
+        FNode c2; c2.fo = special ? la : p + 1; c2.fc = 1; c2.to = special ? lb : q + 1; c2.tc = (special || tkeep) ? 1u : 0u;
         o.nd[cn + ci] = c2;
-        o.F[cf + ci] = special ? la : p + 1;
-        if (special || tkeep) o.T[ct + ti] = special ? lb : q + 1;
       }
-      uint32_t nc = (uint32_t)__popcll(cm);
-      cn += nc; cf += nc; ct += (uint32_t)__popcll(tm);
+      cn += (uint32_t)__popcll(cm);
       k0 += nones;
-      EH_PT(g_ctx, 100);
       continue;
     }
     if (bm & 1ull) {
-      // ---- one big node, the whole wave: histograms of the next byte on both sides
+      // ---- one big node, the whole wave: LDS histograms of the next byte on both sides
       FNode b0; b0.fo = uni(nd.fo); b0.fc = uni(nd.fc); b0.to = uni(nd.to); b0.tc = uni(nd.tc);
-      uint32_t* hf = hist; uint32_t* ht = hist + 256;                // source bins [0,256), target bins [256,512) (work area)
-      for (uint32_t i = l; i < 512; i += 64) hist[i] = 0;
-      wave_sync();
+      uint32_t* hf = g_fuse_lds; uint32_t* ht = sym ? g_fuse_lds : g_fuse_lds + 256;
+      uint32_t* hc = g_fuse_lds + 512; uint32_t* hk = g_fuse_lds + 768;
+      for (uint32_t i = l; i < 512; i += 64) g_fuse_lds[i] = 0;
+      lanes_sync();
       // the entry whose rest is []: its byte' and how many members of its group precede it (array order)
       uint32_t fdb = 0xFFFFFFFFu, fdbefore = 0, tdb = 0xFFFFFFFFu, tdbefore = 0;
-      for (int side = 0; side < 2; side++) {
+      for (int side = 0; side < (sym ? 1 : 2); side++) {
         const uint8_t* S = side ? B : A; uint32_t slen = side ? lb : la;
-        const uint32_t* P = side ? g.T + b0.to : g.F + b0.fo; uint32_t cnt = side ? b0.tc : b0.fc;
+        uint32_t cnt = side ? b0.tc : b0.fc;
+        const uint32_t* P = side ? g.T + b0.to : g.F + b0.fo;
+        uint32_t single = side ? b0.to : b0.fo;                  // cnt == 1: the position itself
         uint32_t* h = side ? ht : hf;
         for (uint32_t base = 0; base < cnt; base += 64) {
           uint32_t i = base + (uint32_t)l; bool in = i < cnt;
-          uint32_t pp = in ? P[i] : slen; bool v = in && pp < slen;
+          uint32_t pp = in ? (cnt == 1 ? single : P[i]) : slen; bool v = in && pp < slen;
           uint32_t bt = v ? (uint32_t)S[pp] : 0u; if (!asc) bt = 255u - bt;
           unsigned long long lastm = __ballot(v && pp == slen - 1);
           if (lastm) {                                           // rare: at most once per side and round
             int j = (int)__builtin_ctzll(lastm);
             uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)bt, j);
+            lanes_sync();
             uint32_t before = h[bj] + (uint32_t)__popcll(__ballot(v && bt == bj) & ((1ull << j) - 1));
             if (side) { tdb = bj; tdbefore = before; } else { fdb = bj; fdbefore = before; }
-            wave_sync();
+            lanes_sync();
           }
           if (v) atomicAdd(&h[bt], 1u);
-          wave_sync();
         }
       }
-      wave_sync();
+      if (sym) { tdb = fdb; tdbefore = fdbefore; }
+      lanes_sync();
       // bins in output order: lane l owns byte' 4l .. 4l+3
       uint32_t rf[4], rt[4], ef[4], et[4]; bool ch[4], sp[4];
       uint32_t lc = 0, lf = 0, lt2 = 0;
@@ -140,35 +147,37 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
         ch[j] = rf[j] > 0 && (sp[j] || rt[j] > 0);
         if (sp[j]) { ef[j] = 1; et[j] = 1; }
         if (!ch[j]) { ef[j] = 0; et[j] = 0; }
-        lc += ch[j] ? 1u : 0u; lf += ef[j]; lt2 += et[j];
+        lc += ch[j] ? 1u : 0u; lf += ef[j] > 1 ? ef[j] : 0u; lt2 += et[j] > 1 ? et[j] : 0u;   // only lists of > 1 go to F / T
       }
       const bool fdropped = __ballot(anyfd) != 0, tdropped = __ballot(anytd) != 0;   // the entry with rest [] leaves its group
       uint32_t ic = wave_incl_scan(lc), iff = wave_incl_scan(lf), it = wave_incl_scan(lt2);
-      uint32_t oc = cn + ic - lc, of = cf + iff - lf, ot = ct + it - lt2;
-      wave_sync();
+      uint32_t oc = cn + ic - lc, of = cf + iff - lf, ot = sym ? of : ct + it - lt2;
+      lanes_sync();
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         uint32_t bt = 4u * (uint32_t)l + (uint32_t)j;
-        // cursors for the scatter; 0xFFFFFFFF = no child for this byte (or nothing to scatter: special)
-        hf[bt] = (ch[j] && !sp[j]) ? of : 0xFFFFFFFFu; ht[bt] = (ch[j] && !sp[j]) ? ot : 0xFFFFFFFFu;
+        bool scat = ch[j] && !sp[j];
+        hf[bt] = scat ? of : 0xFFFFFFFFu; if (!sym) ht[bt] = scat ? ot : 0xFFFFFFFFu;
+        hc[bt] = scat ? oc : 0xFFFFFFFFu; hk[bt] = (ef[j] == 1 ? 1u : 0u) | (et[j] == 1 ? 2u : 0u);
         if (ch[j]) {
-          FNode c2; c2.fo = of; c2.fc = ef[j]; c2.to = ot; c2.tc = et[j];
-          o.nd[oc] = c2;
-          if (sp[j]) { o.F[of] = la; o.T[ot] = lb; }
-          oc++; of += ef[j]; ot += et[j];
+          FNode c2; c2.fo = sp[j] ? la : of; c2.fc = ef[j]; c2.to = sp[j] ? lb : ot; c2.tc = et[j];
+          o.nd[oc] = c2;                                         // a single member's position is filled in by the scatter below
+          oc++; if (ef[j] > 1) of += ef[j]; if (sym) ot = of; else if (et[j] > 1) ot += et[j];
         }
       }
       cn += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63); cf += (uint32_t)__builtin_amdgcn_readlane((int)iff, 63); ct += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
-      wave_sync();
+      wave_sync();                                               // the child descriptors are patched below
       // stable scatter: rank among the lanes of this chunk with the same byte', behind the bin's cursor
-      for (int side = 0; side < 2; side++) {
+      for (int side = 0; side < (sym ? 1 : 2); side++) {
         const uint8_t* S = side ? B : A; uint32_t slen = side ? lb : la;
-        const uint32_t* P = side ? g.T + b0.to : g.F + b0.fo; uint32_t cnt = side ? b0.tc : b0.fc;
+        uint32_t cnt = side ? b0.tc : b0.fc;
+        const uint32_t* P = side ? g.T + b0.to : g.F + b0.fo;
+        uint32_t single = side ? b0.to : b0.fo;
         uint32_t* h = side ? ht : hf; uint32_t* O = side ? o.T : o.F;
         const bool dropped = side ? tdropped : fdropped;
         for (uint32_t base = 0; base < cnt; base += 64) {
           uint32_t i = base + (uint32_t)l; bool in = i < cnt;
-          uint32_t pp = in ? P[i] : slen; bool v = in && pp < slen;
+          uint32_t pp = in ? (cnt == 1 ? single : P[i]) : slen; bool v = in && pp < slen;
           uint32_t bt = v ? (uint32_t)S[pp] : 0u; if (!asc) bt = 255u - bt;
           bool isdrop = dropped && v && pp == slen - 1;            // positions are distinct: at most one such entry
           bool vv = v && !isdrop;
@@ -176,14 +185,17 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
 #pragma unroll
           for (int bit = 0; bit < 8; bit++) { unsigned long long m = __ballot(vv && ((bt >> bit) & 1u)); eq &= ((bt >> bit) & 1u) ? m : ~m; }
           uint32_t rank = (uint32_t)__popcll(eq & ((1ull << l) - 1)), cntg = (uint32_t)__popcll(eq);
-          uint32_t off = vv ? h[bt] : 0xFFFFFFFFu;
-          wave_sync();
-          if (vv && off != 0xFFFFFFFFu) { O[off + rank] = pp + 1; if (rank == 0) h[bt] = off + cntg; }
-          wave_sync();
+          uint32_t off = vv ? h[bt] : 0xFFFFFFFFu, cidx = vv ? hc[bt] : 0xFFFFFFFFu, kf = vv ? hk[bt] : 0u;
+          lanes_sync();
+          if (vv && cidx != 0xFFFFFFFFu) {
+            bool isone = (kf >> side) & 1u;
+            if (isone) { if (side) o.nd[cidx].to = pp + 1; else { o.nd[cidx].fo = pp + 1; if (sym) o.nd[cidx].to = pp + 1; } }
+            else { O[off + rank] = pp + 1; if (rank == 0) h[bt] = off + cntg; }
+          }
+          lanes_sync();
         }
       }
       k0 += 1;
-      EH_PT(g_ctx, 101);
       continue;
     }
     // ---- whole nodes packed into <= 64 + 64 entries, one entry per lane
@@ -195,12 +207,14 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
     uint32_t key[2], pos[2], tot[2] = {totf, tott};
 #pragma unroll
     for (int side = 0; side < 2; side++) {
+      if (side == 1 && sym) { key[1] = key[0]; pos[1] = pos[0]; break; }
       const uint8_t* S = side ? B : A; uint32_t slen = side ? lb : la;
       uint32_t cum = side ? cumt : cumf, cntn = side ? nd.tc : nd.fc, offn = side ? nd.to : nd.fo;
       bool in = (uint32_t)l < tot[side];
       uint32_t nj = lanes_le(cum, nfit, (uint32_t)l);                          // node (of this batch) of entry l
-      uint32_t ex = (uint32_t)__shfl((int)(cum - cntn), (int)(nj & 63)), ob = (uint32_t)__shfl((int)offn, (int)(nj & 63));
-      uint32_t pp = in ? (side ? g.T : g.F)[ob + ((uint32_t)l - ex)] : slen;
+      uint32_t ex = (uint32_t)__shfl((int)(cum - cntn), (int)(nj & 63)), ob = (uint32_t)__shfl((int)offn, (int)(nj & 63)), cj = (uint32_t)__shfl((int)cntn, (int)(nj & 63));
+      uint32_t pp = slen;
+      if (in) pp = cj == 1 ? ob : (side ? g.T : g.F)[ob + ((uint32_t)l - ex)];
       bool v = in && pp < slen;
       uint32_t bt = v ? (uint32_t)S[pp] : 0u; if (!asc) bt = 255u - bt;
       uint32_t kk = in ? (((nj << 9) | (v ? bt : 511u)) << 6) | (uint32_t)l : 0xFFFFFFFFu;
@@ -212,6 +226,7 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
     uint32_t gk[2], lead[2], len[2], drops[2]; bool alive[2], isdrop[2];
 #pragma unroll
     for (int side = 0; side < 2; side++) {
+      if (side == 1 && sym) { gk[1] = gk[0]; lead[1] = lead[0]; len[1] = len[0]; drops[1] = drops[0]; alive[1] = alive[0]; isdrop[1] = isdrop[0]; break; }
       uint32_t slen = side ? lb : la;
       gk[side] = key[side] >> 6;
       alive[side] = (uint32_t)l < tot[side] && (gk[side] & 511u) != 511u;
@@ -222,8 +237,8 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
       uint32_t ll = alive[side] ? 63u - (uint32_t)__builtin_clzll(lm & ((2ull << l) - 1)) : 0u;
       unsigned long long after = lm & ~((2ull << ll) - 1);                     // next leader
       unsigned long long am = __ballot(alive[side]);
-      uint32_t endl = after ? (uint32_t)__builtin_ctzll(after) : 64u;          // runs are contiguous among alive lanes of a node...
-      // ...but dead entries (key byte 511) sit between nodes: the run ends at the next leader or at the first non-alive lane
+      uint32_t endl = after ? (uint32_t)__builtin_ctzll(after) : 64u;
+      // dead entries (key byte 511) sit between nodes: the run ends at the next leader or at the first non-alive lane
       unsigned long long dead_after = ~am & ~((2ull << ll) - 1);
       uint32_t endd = dead_after ? (uint32_t)__builtin_ctzll(dead_after) : 64u;
       uint32_t e = endl < endd ? endl : endd;
@@ -234,41 +249,47 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
       drops[side] = alive[side] ? (uint32_t)__popcll(dm & runm) : 0u;
     }
     // join: the target run with my (node, byte'), if any
-    uint32_t tl = lanes_lt(gk[1], tott, gk[0]);                                 // first target lane with key >= mine
+    uint32_t tl = sym ? lead[0] : lanes_lt(gk[1], tott, gk[0]);                 // first target lane with key >= mine
     uint32_t tk_at = (uint32_t)__shfl((int)gk[1], (int)(tl & 63)), tlen_at = (uint32_t)__shfl((int)len[1], (int)(tl & 63)), tdr_at = (uint32_t)__shfl((int)drops[1], (int)(tl & 63));
+    bool tldrop = __shfl((int)(isdrop[1] ? 1 : 0), (int)(tl & 63)) != 0;       // the target run's leader is the dropped entry
     bool texists = alive[0] && tl < tott && tk_at == gk[0];
     bool fleader = alive[0] && lead[0] == (uint32_t)l;
     uint32_t fcnt = len[0] - drops[0];
     bool special = fleader && fcnt == 0;
     bool child = fleader && (special || texists);
     uint32_t nf = child ? (special ? 1u : fcnt) : 0u, nt = child ? (special ? 1u : (tlen_at - tdr_at)) : 0u;
-    uint32_t ic = wave_incl_scan(child ? 1u : 0u), iff = wave_incl_scan(nf), it = wave_incl_scan(nt);
-    uint32_t oc = cn + ic - (child ? 1u : 0u), of = cf + iff - nf, ot = ct + it - nt;
+    uint32_t af = nf > 1 ? nf : 0u, at = nt > 1 ? nt : 0u;                      // entries that go to the arrays
+    uint32_t ic = wave_incl_scan(child ? 1u : 0u), iff = wave_incl_scan(af), it = wave_incl_scan(at);
+    uint32_t oc = cn + ic - (child ? 1u : 0u), of = cf + iff - af, ot = sym ? of : ct + it - at;
+    // a single surviving member goes into the descriptor: the run's first member that is not dropped
+    uint32_t fsurv = (uint32_t)__shfl((int)pos[0], (int)(((uint32_t)l + (isdrop[0] ? 1u : 0u)) & 63));
+    uint32_t tsurv = (uint32_t)__shfl((int)pos[1], (int)((tl + (tldrop ? 1u : 0u)) & 63));
     if (child) {
-      FNode c2; c2.fo = of; c2.fc = nf; c2.to = ot; c2.tc = nt;
+      FNode c2;
+      c2.fc = nf; c2.tc = nt;
+      c2.fo = special ? la : (nf == 1 ? fsurv + 1 : of);
+      c2.to = special ? lb : (nt == 1 ? tsurv + 1 : (nt == 0 ? 0u : ot));
       o.nd[oc] = c2;
-      if (special) { o.F[of] = la; o.T[ot] = lb; }
     }
-    // source entries: behind their leader's offset
+    // source entries of multi-member children: behind their leader's offset
     {
-      bool lchild = (__shfl((int)(child && !special ? 1 : 0), (int)lead[0]) != 0);
+      bool lmulti = __shfl((int)(child && !special && nf > 1 ? 1 : 0), (int)lead[0]) != 0;
       uint32_t lof = (uint32_t)__shfl((int)of, (int)lead[0]);
       bool ldrop = __shfl((int)(isdrop[0] ? 1 : 0), (int)lead[0]) != 0;        // asc: the leader itself was dropped
-      if (alive[0] && lchild && !isdrop[0]) o.F[lof + ((uint32_t)l - lead[0]) - (ldrop ? 1u : 0u)] = pos[0] + 1;
+      if (alive[0] && lmulti && !isdrop[0]) o.F[lof + ((uint32_t)l - lead[0]) - (ldrop ? 1u : 0u)] = pos[0] + 1;
     }
     // target entries: find the source leader with my key
-    {
+    if (!sym) {
       uint32_t sl = lanes_lt(gk[0], totf, gk[1]);
       uint32_t sk_at = (uint32_t)__shfl((int)gk[0], (int)(sl & 63));
       bool has = alive[1] && sl < totf && sk_at == gk[1];
-      bool schild = __shfl((int)(child && !special ? 1 : 0), (int)(sl & 63)) != 0;
+      bool smulti = __shfl((int)(child && !special && nt > 1 ? 1 : 0), (int)(sl & 63)) != 0;
       uint32_t sot = (uint32_t)__shfl((int)ot, (int)(sl & 63));
       bool ldrop = __shfl((int)(isdrop[1] ? 1 : 0), (int)lead[1]) != 0;
-      if (has && schild && !isdrop[1]) o.T[sot + ((uint32_t)l - lead[1]) - (ldrop ? 1u : 0u)] = pos[1] + 1;
+      if (has && smulti && !isdrop[1]) o.T[sot + ((uint32_t)l - lead[1]) - (ldrop ? 1u : 0u)] = pos[1] + 1;
     }
     cn += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63); cf += (uint32_t)__builtin_amdgcn_readlane((int)iff, 63); ct += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
     k0 += nfit;
-    EH_PT(g_ctx, 102);
   }
   wave_sync();
   return cn;
@@ -280,26 +301,25 @@ EH_DEV bool fuse_lists(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, 
   if (la == 0) { *out = (uint8_t*)B; *outlen = lb; return true; }   // fuse([], Bl) -> Bl
   if (lb == 0) { *out = (uint8_t*)A; *outlen = la; return true; }
   uint64_t mark = c.ws_used;
+  const bool sym = A == B && la == lb;                             // sed_fuse_this: fuse(Lst, Lst)
   FuseGen g[2];
   for (int k = 0; k < 2; k++) {
     g[k].nd = (FNode*)ws_alloc(c, ((uint64_t)la + 4) * sizeof(FNode));     // every node owns >= 1 source entry
     g[k].F = (uint32_t*)ws_alloc(c, ((uint64_t)la + 4) * 4);
-    g[k].T = (uint32_t*)ws_alloc(c, ((uint64_t)lb + 4) * 4);
+    g[k].T = sym ? g[k].F : (uint32_t*)ws_alloc(c, ((uint64_t)lb + 4) * 4);
     if (!g[k].nd || !g[k].F || !g[k].T) return false;
   }
-  uint32_t* hist = (uint32_t*)ws_alloc(c, 512 * 4);
-  if (!hist) return false;
   // find_jump_points (:103-107): one node with all non-empty suffixes of both lists
-  for (uint32_t i = l; i < la; i += 64) g[0].F[i] = i;
-  for (uint32_t i = l; i < lb; i += 64) g[0].T[i] = i;
-  if (l == 0) { FNode n0; n0.fo = 0; n0.fc = la; n0.to = 0; n0.tc = lb; g[0].nd[0] = n0; }
+  if (la > 1) for (uint32_t i = l; i < la; i += 64) g[0].F[i] = i;
+  if (lb > 1 && !sym) for (uint32_t i = l; i < lb; i += 64) g[0].T[i] = i;
+  if (l == 0) { FNode n0; n0.fo = 0; n0.fc = la; n0.to = 0; n0.tc = lb; g[0].nd[0] = n0; }   // (a single suffix: position 0 = offset 0)
   uint32_t nn = 1, par = 0;
   int64_t fuel = 100000;                                           // ?SEARCH_FUEL
   wave_sync();
   while (true) {                                                   // find_jump_points_loop (:115-128)
     if (fuel < 0) break;
     if (rng_rand(c.rng, 8) == 0) break;                            // ?SEARCH_STOP_IP
-    uint32_t nchild = fuse_round(A, la, B, lb, g[par], nn, g[par ^ 1], par, hist);
+    uint32_t nchild = fuse_round(A, la, B, lb, g[par], nn, g[par ^ 1], par, sym);
     if (nchild == 0) break;                                        // NoDesp =:= [] -> any_position_pair(Nodes)
     par ^= 1; nn = nchild;
     fuel -= (int64_t)nchild;
@@ -307,10 +327,10 @@ EH_DEV bool fuse_lists(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, 
   // any_position_pair/1 (:73-77); odd generations are stored reversed
   uint32_t ni = rng_rand(c.rng, nn);
   FNode nd = g[par].nd[par ? nn - 1 - ni : ni];
-  uint32_t fo = uni(nd.fo), fc = uni(nd.fc), to = uni(nd.to), tc = uni(nd.tc);
+  uint32_t fo = uni(nd.fo), fc = uni(nd.fc), to = sym ? fo : uni(nd.to), tc = sym ? fc : uni(nd.tc);
   uint32_t from = la, tpos = lb;
-  if (fc > 0) { uint32_t j = rng_rand(c.rng, fc); from = uni(g[par].F[fo + (par ? fc - 1 - j : j)]); }
-  if (tc > 0) { uint32_t j = rng_rand(c.rng, tc); tpos = uni(g[par].T[to + (par ? tc - 1 - j : j)]); }
+  if (fc > 0) { uint32_t j = rng_rand(c.rng, fc); from = fc == 1 ? fo : uni(g[par].F[fo + (par ? fc - 1 - j : j)]); }
+  if (tc > 0) { uint32_t j = rng_rand(c.rng, tc); tpos = tc == 1 ? to : uni(g[par].T[to + (par ? tc - 1 - j : j)]); }
   c.ws_used = mark;                                                // release all tables
   // jump/3 (:47-50): Al up to From, then To
   uint32_t nl = from + (lb - tpos);

@@ -36,6 +36,7 @@
 #define __shared__ __attribute__((section("hipemu_shared"), used))
 extern "C" char __start_hipemu_shared[], __stop_hipemu_shared[];
 #define __constant__
+#define HIPEMU 1        // lets the engine place lane-written LDS scratch (EH_LDS_ARRAY) in plain memory: the LDS model here is per lane
 #define __forceinline__ inline __attribute__((always_inline))
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
