@@ -25,6 +25,8 @@ EH_DEV uint64_t wave_sum64(uint64_t v) {
   for (int d = 32; d > 0; d >>= 1) v += ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, d);
   return uni64(v);
 }
+// per-lane source lane (ds_bpermute); readlane64 needs a wave-uniform lane
+EH_DEV uint64_t shfl64(uint64_t v, int src) { return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src); }
 EH_DEV uint32_t wave_max(uint32_t v) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { uint32_t t = (uint32_t)__shfl_xor((int)v, d); v = t > v ? t : v; }
@@ -40,6 +42,9 @@ EH_DEV uint64_t pieces_total(const Piece* t, uint32_t n) {
 // so an unedited stretch of a document collapses into one long piece and the gather below moves it with 16-byte
 // vectors instead of a lane per 1-byte piece.
 EH_DEV uint32_t pieces_coalesce(Piece* t, uint32_t n) {
+#ifdef EH_DBG_NOCOAL
+  return n;
+#endif
   const int l = EH_LANE;
   uint32_t nout = 0;
   uint64_t carry_end = 0; bool have_carry = false;                  // end address of the last written piece (if mergeable)
@@ -53,7 +58,7 @@ EH_DEV uint32_t pieces_coalesce(Piece* t, uint32_t n) {
     unsigned long long vm = __ballot(valid);
     unsigned long long below = vm & ((1ull << l) - 1);
     int pl = below ? 63 - (int)__builtin_clzll(below) : -1;
-    uint64_t pend = readlane64(p.ptr + p.len, (uint32_t)(pl < 0 ? 0 : pl));
+    uint64_t pend = shfl64(p.ptr + p.len, pl < 0 ? 0 : pl);
     bool pplain = __shfl((int)(plain ? 1 : 0), pl < 0 ? 0 : pl) != 0;
     if (pl < 0) { pend = carry_end; pplain = have_carry; }
     bool cont = valid && plain && pplain && pend == p.ptr;
@@ -200,7 +205,9 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
     int cj = (int)__builtin_ctzll(cand); cand &= cand - 1;
     int i = base + cj;
     uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)ca, cj), b = (uint32_t)__builtin_amdgcn_readlane((int)cb, cj);
+#ifndef EH_DBG_NOACCEPT
     if (!b64_accepts(H + a, b - a)) continue;                    // error:badarg / function_clause :677-684
+#endif
     int dl = b64_decode(H + a, b - a, nullptr);
     if (!out) {                                                  // first hit: the piece list of unlex(Ms)
       cap = 2 * (uint32_t)(n - i) + 4;

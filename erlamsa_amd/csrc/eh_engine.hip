@@ -986,7 +986,9 @@ int eh_create(int device, eh_ctx** out) {
   ctx->cus = prop.multiProcessorCount;
   // eh_mutate_kernel recurses (nested scheduler calls of b64 / sgm / js, depth <= MAX_NEST): ~0.6 KiB of private stack
   // per level on top of the kernel's fixed 1.2 KiB
-  if (hipDeviceSetLimit(hipLimitStackSize, 16384) != hipSuccess) { delete ctx; return EH_E_HIP; }
+  size_t stack_bytes = 16384;
+  if (const char* e = getenv("EH_STACK_BYTES")) stack_bytes = (size_t)strtoul(e, nullptr, 10);   // diagnostic override
+  if (hipDeviceSetLimit(hipLimitStackSize, stack_bytes) != hipSuccess) { delete ctx; return EH_E_HIP; }
   uint16_t t1[65], t2[65], t3[65];
   init_tables(t1, t2, t3);
   uint32_t crct[256];

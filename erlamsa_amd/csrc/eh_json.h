@@ -281,6 +281,9 @@ __device__ __noinline__ int muta_json(Ctx&) {
       unsigned long long m = __ballot(i < L && !(ch == ' ' || ch == '\n' || ch == '\r' || ch == '\t'));
       if (m) p0 = base + (uint32_t)__builtin_ctzll(m);
     }
+#ifdef EH_DBG_NOQR
+    p0 = L;
+#endif
     if (p0 < L) {
       uint32_t c0 = uni(H[p0]);
       if (c0 != '[' && c0 != '{' && c0 != '"' && c0 != 't' && c0 != 'f' && c0 != 'n') {
@@ -417,6 +420,7 @@ __device__ __noinline__ int muta_json(Ctx&) {
     }
     default: {                                                             // inner text / basic types :671-706
       all(0, npc);
+      wave_sync();
       uint32_t e_pri, e_meta; int nfs;
       inner_table(c, true, &e_pri, &e_meta, &nfs);
       const double dN = (double)N;

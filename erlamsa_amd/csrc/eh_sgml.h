@@ -582,6 +582,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
     case 8: {                                                              // sgml_xmlfeatures(Ast, NT, 1) :651-665
       if (NT == 0) { D = -1; all(0, npc); break; }
       all(0, npc);
+      wave_sync();
       const DevConfig& cfg = c.p->cfg;
       // "http" ++ get_ssrf_uri() (erlamsa_mutations.erl:727-731)
       uint8_t* uri = ws_alloc(c, 128);
@@ -645,6 +646,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
     }
     default: {                                                             // inner text :727-737 (walk2acc/3 :363-379)
       all(0, npc);
+      wave_sync();                                                         // the list is read back below (other lanes wrote it)
       uint32_t e_pri, e_meta; int nfs;
       inner_table(c, false, &e_pri, &e_meta, &nfs);
       // mutate_innertext/3 :674-681 on [vp, vp+vl); returns false to stop (status set)

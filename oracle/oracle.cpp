@@ -1201,8 +1201,14 @@ int base64_mutator(Ctx& c, BList& ll) {
     int d = c.rnd.rand_delta();
     std::vector<Muta> muta = mutators_mutator(c.rnd, table);                  // :669 (table order => draws in table order)
     BList one{dec};
+    size_t tr0 = c.trace ? c.trace->size() : 0;
     mux_fuzzers(c, muta, one);
     Bytes nb; for (auto& b : one) nb.insert(nb.end(), b.begin(), b.end());
+    if (getenv("EO_DUMP_B64")) {                                              // debugging aid (stderr): every nested call of base64_mutator
+      fprintf(stderr, "B64 in=");  for (uint8_t x : dec) fprintf(stderr, "%02x", x);
+      fprintf(stderr, " out="); for (uint8_t x : nb) fprintf(stderr, "%02x", x);
+      fprintf(stderr, " trace=%s\n", c.trace ? c.trace->substr(tr0).c_str() : "");
+    }
     ch.bs = otp::base64_encode(nb);
     dacc += d;
   }

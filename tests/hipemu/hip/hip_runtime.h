@@ -15,6 +15,7 @@
 #pragma once
 #include <math.h>
 #include <ucontext.h>
+#include <execinfo.h>
 
 #include <chrono>
 #include <cmath>
@@ -173,7 +174,14 @@ inline int __shfl(int v, int src) { unsigned p = hipemu::rendezvous(hipemu::OP_S
 inline int __shfl_up(int v, unsigned d) { unsigned p = hipemu::rendezvous(hipemu::OP_SHFL_UP, (uint32_t)v, d); int s = (int)threadIdx.x - (int)d; return s < 0 ? v : hipemu_fetch(p, s, v); }
 inline int __shfl_down(int v, unsigned d) { unsigned p = hipemu::rendezvous(hipemu::OP_SHFL_DOWN, (uint32_t)v, d); int s = (int)threadIdx.x + (int)d; return s >= hipemu::W ? v : hipemu_fetch(p, s, v); }
 inline int __shfl_xor(int v, int m) { unsigned p = hipemu::rendezvous(hipemu::OP_SHFL_XOR, (uint32_t)v, m); int s = (int)threadIdx.x ^ m; return (s < 0 || s >= hipemu::W) ? v : hipemu_fetch(p, s, v); }
-inline int __builtin_amdgcn_readlane(int v, int lane) { unsigned p = hipemu::rendezvous(hipemu::OP_READLANE, (uint32_t)v, lane); return hipemu_fetch(p, lane & 63, v); }
+// v_readlane_b32 takes its lane select from a scalar register: the index must be the same on every lane (use __shfl
+// for a per-lane source).  A non-uniform index "works" lane by lane on a CPU, so it is checked here.
+inline int __builtin_amdgcn_readlane(int v, int lane) {
+  unsigned p = hipemu::rendezvous(hipemu::OP_READLANE, (uint32_t)v, lane);
+  for (int l = 0; l < hipemu::W; l++)
+    if (hipemu::g_wave.present[p][l] && (int)hipemu::g_wave.arg[p][l] != lane) { fprintf(stderr, "hipemu: v_readlane with a non-uniform lane index (block %u, lanes %d and %d: %d vs %d)\n", blockIdx.x, (int)threadIdx.x, l, lane, (int)hipemu::g_wave.arg[p][l]); void* bt[16]; int nb = backtrace(bt, 16); backtrace_symbols_fd(bt, nb, 2); abort(); }
+  return hipemu_fetch(p, lane & 63, v);
+}
 inline int __builtin_amdgcn_readfirstlane(int v) {
   unsigned p = hipemu::rendezvous(hipemu::OP_READFIRST, (uint32_t)v, 0);
   for (int l = 0; l < hipemu::W; l++) if (hipemu::g_wave.present[p][l]) return (int)(uint32_t)hipemu::g_wave.val[p][l];
