@@ -35,7 +35,7 @@ def cpu_baseline_leg(mat, seed, muts, pats, args):
     n = mat.shape[0]
     limit = min(args.cpu_sample, n)
     threads = max(1, args.cpu_threads or min(os.cpu_count() or 1, 64))
-    CH = 512
+    CH = 64
     lock = threading.Lock()
     state = {"next": 0, "cases": 0, "bytes": 0}
     t0 = time.perf_counter()
@@ -80,14 +80,18 @@ def main():
                     help="mixed = BASELINE configs[2] (default); uniform = random bytes (configs[1] with --cases 1024 --size 256)")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="upper bound of cases timed on the CPU oracle (0 = skip); "
                     "the leg stops after --cpu-seconds")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time bound of the CPU oracle leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time bound of the CPU oracle leg")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle leg (0 = all host cores, at most 64)")
-    ap.add_argument("--max-slots", type=int, default=0)
-    ap.add_argument("--out-gib", type=int, default=8, help="output arena capacity per context (GiB)")
-    ap.add_argument("--case-mib", type=int, default=8, help="per-case work area (MiB), eh_options.max_case_bytes")
+    ap.add_argument("--max-slots", type=int, default=2048, help="resident wavefront slots per context (x --inflight contexts share the GPU)")
+    ap.add_argument("--out-gib", type=int, default=32, help="output arena capacity per context (GiB)")
+    ap.add_argument("--case-mib", type=int, default=16, help="per-case work area of every resident wavefront (MiB), eh_options.max_case_bytes")
+    ap.add_argument("--big-mib", type=int, default=1024, help="largest work area (MiB), eh_options.big_case_bytes: a case that outgrows its area "
+                    "is run again by the next tier (4x the area, a quarter of the wavefronts)")
+    ap.add_argument("--budget-mib", type=int, default=8, help="after the headline run (no budget), repeat 3 steps with this per-case work "
+                    "budget (eh_options.max_case_work) and report them under 'with_work_budget'; 0 = skip")
     ap.add_argument("--work-mib", type=int, default=0, help="optional per-case work budget (MiB), eh_options.max_case_work; "
                     "0 = off (default): every case runs to completion like under the reference's 30 s CLI watchdog")
-    ap.add_argument("--inflight", type=int, default=3, help="passes in flight (engine contexts / HIP streams)")
+    ap.add_argument("--inflight", type=int, default=2, help="passes in flight (engine contexts / HIP streams)")
     args = ap.parse_args()
 
     import numpy as np
@@ -132,7 +136,7 @@ def main():
     for _ in range(nctx):
         e = ea.Engine(local)
         e.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
-                    max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20)
+                    max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20, big_case_bytes=args.big_mib << 20)
         e.attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
         engines.append(e)
         streams.append(torch.cuda.Stream(device=dev))
@@ -188,6 +192,29 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
+    # ---- second, labelled figure: the same steps under a per-case work budget (the round-1 configuration)
+    budgeted = None
+    if args.budget_mib > 0 and args.work_mib == 0 and world == 1:
+        for e in engines:
+            e.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
+                        max_case_bytes=args.case_mib << 20, max_case_work=args.budget_mib << 20, big_case_bytes=args.big_mib << 20)
+        bsteps = min(3, args.steps)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for k in range(bsteps):
+            launch(args.warmup + args.steps + k)
+        bbytes, bstat = 0, np.zeros(6, dtype=np.int64)
+        for k in range(bsteps):
+            e = engines[(args.warmup + args.steps + k) % nctx]
+            _, ob, _ = e.totals()
+            bbytes += ob
+            bstat += np.bincount(e.status(), minlength=6)[:6]
+        torch.cuda.synchronize()
+        bdt = time.perf_counter() - tb
+        budgeted = {"max_case_work": args.budget_mib << 20, "steps": bsteps, "value": round(bbytes / bdt / 1e6, 1), "unit": "MB/s",
+                    "cases_per_s": round(n * bsteps / bdt, 1), "ms_per_step": round(bdt / bsteps * 1e3, 3),
+                    "case_status_budget": int(bstat[5]), "case_status_overflow": int(bstat[2])}
+
     tot = torch.tensor([dt, float(out_bytes), float(n * args.steps)], dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = tot.clone()
@@ -212,7 +239,7 @@ def main():
                 ps = json.load(fh)
             wk = ps["workload_key"]
             if (wk["cases"], wk["size"], wk["max_case_work"], wk["max_case_bytes"], wk["mutators"], wk["patterns"]) == \
-                    (n, size, args.work_mib << 20, args.case_mib << 20, muts, pats):
+                    (n, size, args.work_mib << 20, args.case_mib << 20, muts, pats) and nctx == wk.get("inflight", nctx):
                 traffic = int(ps["traffic_bytes_per_launch"]["total_fetch_x2_plus_write"])
                 traffic_src = "profiles/r02_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch)"
         except (OSError, KeyError, ValueError):
@@ -233,7 +260,7 @@ def main():
                                pats, muts, len(muts.split(",")), nmut_total,
                                ",".join(m for m, _, _ in ea.mutator_table() if m not in [x.split("=")[0] for x in muts.split(",")]) or "none"),
                 "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream before the W warm-up steps",
-                "max_case_bytes": args.case_mib << 20, "max_case_work": args.work_mib << 20,
+                "max_case_bytes": args.case_mib << 20, "big_case_bytes": args.big_mib << 20, "max_case_work": args.work_mib << 20,
             },
             "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(max_case_bytes)", "unsupported", "arena_full",
                                      "budget(max_case_work; reference analogue: maxrunningtime -> <<>>)"],
@@ -243,6 +270,8 @@ def main():
                          "kernel": ea.load_library().eh_kernel_name().decode(), "kernel_ms_avg": round(avg_kern_s * 1e3, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
+        if budgeted is not None:
+            res["with_work_budget"] = budgeted
         # ---- CPU baseline: the oracle (C++ restatement of the reference) on the host cores, N=1 only
         if args.cpu_sample > 0 and world == 1:
             res["cpu_baseline"] = cpu_baseline_leg(mat, seed, muts, pats, args)

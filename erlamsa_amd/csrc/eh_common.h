@@ -102,6 +102,14 @@ struct KParams {
   unsigned long long* prof;   // EH_PROF builds: [2*k] cycles, [2*k+1] calls; k < 64 mutator fn, 64.. phases
   unsigned long long* ticket;
   unsigned long long* in_bytes;
+  // Tiered work areas.  Tier 0: every resident wavefront has a small area (max_case_bytes).  A case that outgrows its
+  // area is queued and run again from scratch (same result: a case is a pure function of its number) by the next
+  // tier: 4x larger areas, 4x fewer wavefronts, up to big_case_bytes.
+  int32_t tier;
+  const uint32_t* in_q;          // tier > 0: case indices (of this batch) to run
+  const unsigned long long* in_n;
+  uint32_t* out_q;               // cases that overflowed in this tier (nullptr: last tier)
+  unsigned long long* out_n;
 };
 
 struct MutaInfo { const char* name; int pri; int on_gpu; };

@@ -527,7 +527,8 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     }
   }
 
-  constexpr uint64_t TICKET_BATCH = 4;   // cases claimed per atomic (one counter saturates at ~88 dequeues/us)
+  const uint64_t TICKET_BATCH = p.tier ? 1 : 4;   // cases claimed per atomic (one counter saturates at ~88 dequeues/us)
+  const uint64_t ncases = p.tier ? uni64(*p.in_n) : p.n;      // tier > 0: the queue the previous tier left behind
   uint64_t tk_next = 0, tk_end = 0;
   while (true) {
     if (tk_next == tk_end) {
@@ -536,7 +537,8 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
       tk_next = uni64(t); tk_end = tk_next + TICKET_BATCH;
     }
     uint64_t i = tk_next++;
-    if (i >= p.n) break;
+    if (i >= ncases) break;
+    if (p.tier) i = uni(p.in_q[i]);
     uint64_t tick0 = __builtin_readcyclecounter();
     c.work = 0; c.depth = 0;
     c.status = CASE_OK; c.lastm = -1; c.nb = 0; c.cur = 0; c.nem = 0; c.ws_used = 0;
@@ -599,6 +601,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     }
     EH_PH(3);
     if (l == 0) {
+      if (c.status == CASE_OVERFLOW && p.out_q) p.out_q[atomicAdd(p.out_n, 1ull)] = (uint32_t)i;
       p.out_off[i] = base; p.out_len[i] = total; p.status[i] = c.status;
       p.draws[i] = c.rng.draws; p.lastm[i] = c.lastm; p.cycles[i] = __builtin_readcyclecounter() - tick0;
     }
@@ -697,6 +700,11 @@ struct eh_ctx {
   std::vector<uint64_t> h_coff;  // host copy of offsets (for totals)
   // slots
   uint8_t* d_slots = nullptr; uint64_t slot_stride = 0, work_cap = 0; uint32_t nslots = 0;
+  // tiers 1.. (see KParams): areas of 4x, 16x, ... max_case_bytes up to big_case_bytes, ~16 GiB per tier
+  static constexpr int MAX_TIERS = 5;
+  int ntiers = 0;                                      // tiers above tier 0
+  uint8_t* d_tslots[MAX_TIERS] = {}; uint64_t tstride[MAX_TIERS] = {}, tcap[MAX_TIERS] = {}; uint32_t tnslots[MAX_TIERS] = {};
+  uint32_t* d_retry = nullptr; uint64_t retry_cap = 0; uint64_t big_case_bytes = 0; uint64_t tier_base = 0, tier_big = 0;
   // outputs
   uint8_t* d_out = nullptr; uint64_t out_cap = 0;
   uint64_t* d_off = nullptr; uint64_t* d_len = nullptr; int32_t* d_status = nullptr; uint64_t* d_draws = nullptr; int32_t* d_lastm = nullptr; uint64_t* d_cycles = nullptr;
@@ -877,7 +885,31 @@ static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
     HIPCHK(ctx, hipMalloc(&ctx->d_slots, stride * want_slots));
     ctx->nslots = want_slots; ctx->work_cap = work_cap; ctx->slot_stride = stride;
   }
-  uint64_t want_out = ctx->out_capacity_opt ? ctx->out_capacity_opt : (8 * (in_bytes ? in_bytes : ctx->corpus_bytes) + (1024ull << 20));
+  // tiers above 0: 4x the area and a quarter of the wavefronts each, up to big_case_bytes (default 32 x max_case_bytes,
+  // at most 1 GiB); every tier gets about 16 GiB (the emulator: two slots)
+  uint64_t big = ctx->big_case_bytes ? ctx->big_case_bytes : (32 * work_cap < (1024ull << 20) ? 32 * work_cap : (1024ull << 20));
+  if (ctx->tier_base != work_cap || ctx->tier_big != big) {
+    for (int t = 0; t < ctx->ntiers; t++) { (void)hipFree(ctx->d_tslots[t]); ctx->d_tslots[t] = nullptr; }
+    ctx->ntiers = 0;
+    uint64_t cap = work_cap;
+    while (cap < big && ctx->ntiers < eh_ctx::MAX_TIERS) {
+      cap = cap * 4 < big ? cap * 4 : big;
+      uint64_t stride_t = ((uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + cap + 255) & ~255ull;
+      uint64_t cnt = (16ull << 30) / stride_t; if (cnt < 8) cnt = 8; if (cnt > 1024) cnt = 1024;
+      if (ctx->cus < 64) cnt = 2;
+      int t = ctx->ntiers;
+      HIPCHK(ctx, hipMalloc(&ctx->d_tslots[t], stride_t * cnt));
+      ctx->tstride[t] = stride_t; ctx->tcap[t] = cap; ctx->tnslots[t] = (uint32_t)cnt; ctx->ntiers++;
+    }
+    ctx->tier_base = work_cap; ctx->tier_big = big;
+  }
+  if (ctx->ntiers > 0 && (!ctx->d_retry || ctx->retry_cap < n)) {
+    if (ctx->d_retry) (void)hipFree(ctx->d_retry);
+    ctx->d_retry = nullptr;
+    HIPCHK(ctx, hipMalloc(&ctx->d_retry, (n ? n : 1) * 4 * (uint64_t)eh_ctx::MAX_TIERS));
+    ctx->retry_cap = n ? n : 1;
+  }
+  uint64_t want_out = ctx->out_capacity_opt ? ctx->out_capacity_opt : (8 * (in_bytes ? in_bytes : ctx->corpus_bytes) + (2048ull << 20));
   if (!ctx->d_out || ctx->out_cap < want_out) {
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     ctx->d_out = nullptr;
@@ -895,7 +927,7 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   if (!ctx->h_coff.empty()) in_bytes = ctx->h_coff[corpus_first + n] - ctx->h_coff[corpus_first];
   int rc = reserve(ctx, n, in_bytes);
   if (rc) return rc;
-  if (!ctx->d_counters) { HIPCHK(ctx, hipMalloc(&ctx->d_counters, 4096)); HIPCHK(ctx, hipMalloc(&ctx->d_run, sizeof(RunState))); HIPCHK(ctx, hipMalloc(&ctx->d_params, sizeof(KParams))); }
+  if (!ctx->d_counters) { HIPCHK(ctx, hipMalloc(&ctx->d_counters, 4096)); HIPCHK(ctx, hipMalloc(&ctx->d_run, sizeof(RunState))); HIPCHK(ctx, hipMalloc(&ctx->d_params, (eh_ctx::MAX_TIERS + 1) * sizeof(KParams))); }
   HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 4096, st));
 
   KParams p;
@@ -907,11 +939,24 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
   p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles;
   p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;
+  // counters: [300 + 2t] ticket of tier t, [301 + 2t] length of the queue tier t consumes (t >= 1); [8, 264) = prof
+  const int ntiers = ctx->ntiers;
+  p.tier = 0; p.in_q = nullptr; p.in_n = nullptr;
+  p.out_q = ntiers > 0 ? ctx->d_retry : nullptr; p.out_n = ctx->d_counters + 301 + 2;
 
   if (mode == 0) hipLaunchKernelGGL(eh_setup_kernel, dim3(1), dim3(64), 0, st, ctx->cfg, seed[0], seed[1], seed[2], ctx->d_run);
   HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, &p, sizeof(p), hipMemcpyHostToDevice, st));      // pageable source: staged before the call returns
   if (n > 0) hipLaunchKernelGGL(eh_mutate_kernel, dim3(ctx->nslots < n ? ctx->nslots : (uint32_t)n), dim3(64), 0, st, (const KParams*)ctx->d_params);
+  for (int t = 1; n > 0 && t <= ntiers; t++) {                                  // tier t over the queue tier t-1 left behind
+    KParams q = p;
+    q.tier = t; q.slot_base = ctx->d_tslots[t - 1]; q.slot_stride = ctx->tstride[t - 1]; q.work_cap = ctx->tcap[t - 1];
+    q.ticket = ctx->d_counters + 300 + 2 * t;
+    q.in_q = ctx->d_retry + (uint64_t)(t - 1) * ctx->retry_cap; q.in_n = ctx->d_counters + 301 + 2 * t;
+    q.out_q = t < ntiers ? ctx->d_retry + (uint64_t)t * ctx->retry_cap : nullptr; q.out_n = ctx->d_counters + 301 + 2 * (t + 1);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_params + t, &q, sizeof(q), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(eh_mutate_kernel, dim3(ctx->tnslots[t - 1]), dim3(64), 0, st, (const KParams*)(ctx->d_params + t));
+  }
   HIPCHK(ctx, hipEventRecord(ctx->ev1, st));
   HIPCHK(ctx, hipGetLastError());
   ctx->ordered = false;
@@ -1018,6 +1063,8 @@ void eh_destroy(eh_ctx* ctx) {
   (void)hipFree(ctx->d_run); (void)hipFree(ctx->d_seeds);
   free(ctx->h_stage);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
+  for (int t = 0; t < ctx->ntiers; t++) (void)hipFree(ctx->d_tslots[t]);
+  if (ctx->d_retry) (void)hipFree(ctx->d_retry);
   if (ctx->d_out2) (void)hipFree(ctx->d_out2);
   if (ctx->d_ord) (void)hipFree(ctx->d_ord);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1077,7 +1124,7 @@ int eh_configure(eh_ctx* ctx, const eh_options* o) {
   snprintf(cfg.ssrf_port, sizeof(cfg.ssrf_port), "%d", o->ssrf_port ? o->ssrf_port : 51234);
   ctx->cfg = cfg;
   ctx->work_budget = o->max_case_work;
-  ctx->max_case_bytes = o->max_case_bytes; ctx->out_capacity_opt = o->out_capacity; ctx->max_slots_opt = o->max_slots; ctx->flags = o->flags;
+  ctx->big_case_bytes = o->big_case_bytes; ctx->max_case_bytes = o->max_case_bytes; ctx->out_capacity_opt = o->out_capacity; ctx->max_slots_opt = o->max_slots; ctx->flags = o->flags;
   ctx->configured = true;
   return EH_OK;
 }

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ERLAMSA_HIP_LIB") or os.path.join(_HERE, "liberlamsa_hip.so")
 
-EH_ABI_VERSION = 2
+EH_ABI_VERSION = 3
 EH_FLAG_ORDERED_OUTPUT = 1
 
 CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BUDGET = 0, 1, 2, 3, 4, 5
@@ -31,7 +31,7 @@ class EhOptions(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("mutations", C.c_char_p), ("patterns", C.c_char_p),
                 ("generators", C.c_char_p), ("blockscale", C.c_double), ("ssrf_host", C.c_char_p),
                 ("ssrf_port", C.c_int32), ("max_case_bytes", C.c_uint64), ("out_capacity", C.c_uint64),
-                ("max_case_work", C.c_uint64), ("max_slots", C.c_uint32), ("flags", C.c_uint32)]
+                ("max_case_work", C.c_uint64), ("max_slots", C.c_uint32), ("flags", C.c_uint32), ("big_case_bytes", C.c_uint64)]
 
 
 class EngineError(RuntimeError):
@@ -137,7 +137,7 @@ class Engine:
             raise EngineError(rc, self.lib.eh_last_error(self.h).decode() or self.lib.eh_strerror(rc).decode())
 
     def configure(self, mutations=None, patterns=None, generators=None, blockscale=1.0, ssrf_host=None, ssrf_port=0,
-                  max_case_bytes=0, out_capacity=0, max_slots=0, flags=0, max_case_work=0):
+                  max_case_bytes=0, out_capacity=0, max_slots=0, flags=0, max_case_work=0, big_case_bytes=0):
         o = EhOptions()
         o.abi_version = EH_ABI_VERSION
         o.mutations = mutations.encode() if mutations is not None else None
@@ -147,6 +147,7 @@ class Engine:
         o.ssrf_host = ssrf_host.encode() if ssrf_host else None
         o.ssrf_port = ssrf_port
         o.max_case_bytes = max_case_bytes
+        o.big_case_bytes = big_case_bytes
         o.out_capacity = out_capacity
         o.max_slots = max_slots
         o.max_case_work = max_case_work

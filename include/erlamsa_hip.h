@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EH_ABI_VERSION 2
+#define EH_ABI_VERSION 3
 
 typedef struct eh_ctx eh_ctx;
 
@@ -74,14 +74,18 @@ typedef struct eh_options {
   double blockscale;         /* 0 => 1.0 (erlamsa_gen.erl:206) */
   const char* ssrf_host;     /* NULL => "localhost" */
   int32_t ssrf_port;         /* 0 => 51234 */
-  uint64_t max_case_bytes;   /* per-case working-set cap; 0 => default (8 MiB) */
-  uint64_t out_capacity;     /* output arena bytes; 0 => 8 x batch input bytes + 1 GiB */
-  uint64_t max_case_work;    /* per-case work budget in bytes (sum over mutator attempts, failed ones
+  uint64_t max_case_bytes;   /* per-case work area of every resident wavefront (tier 0); 0 => default (8 MiB) */
+  uint64_t out_capacity;     /* output arena bytes; 0 => 8 x batch input bytes + 2 GiB */
+  uint64_t max_case_work;    /* OPTIONAL per-case work budget in bytes (sum over mutator attempts, failed ones
                                 included, of block size x cost weight of the mutator: 8 for parsers and
                                 per-byte-draw mutators, 64 for the fuse family, 4 for num, 1 otherwise);
-                                0 => default (8 MiB) */
+                                0 => no budget (default): every case runs to completion */
   uint32_t max_slots;        /* resident wavefront slots; 0 => auto */
   uint32_t flags;            /* EH_FLAG_* */
+  uint64_t big_case_bytes;   /* largest work area.  A case that outgrows its area is run again from scratch (same
+                                result) by the next tier of wavefronts: 4x the area, a quarter as many of them, up to
+                                this size; only a case that outgrows this too ends as EH_CASE_OVERFLOW.
+                                0 => 32 x max_case_bytes, at most 1 GiB; <= max_case_bytes => a single tier */
 } eh_options;
 
 #define EH_FLAG_ORDERED_OUTPUT 1u /* compact the output arena into case order after the batch */
@@ -97,7 +101,7 @@ int eh_corpus_upload(eh_ctx* ctx, const uint8_t* data, const uint64_t* off, uint
 int eh_corpus_attach(eh_ctx* ctx, const void* d_data, const void* d_off, uint64_t n, uint64_t nbytes);
 
 /* Allocates all device memory batches of up to `max_cases` cases will need (result arrays, per-slot work
- * areas, output arena sized from eh_options.out_capacity or 8 x corpus bytes + 1 GiB), so that later
+ * areas, output arena sized from eh_options.out_capacity or 8 x corpus bytes + 2 GiB), so that later
  * eh_fuzz_batch / eh_fuzz_calls launches never allocate or free.  Optional: the first batch does the same
  * on demand.  Reference counterpart: none (BEAM allocates per worker process); it exists because
  * erlamsa_fsupervisor-style services want a flat first-request latency. */

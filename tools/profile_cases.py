@@ -14,7 +14,7 @@ mat = synth.mixed(n, 4096)
 data, off = synth.as_arena(mat)
 eng = ea.Engine(0)
 import os
-eng.configure(mutations=muts, patterns=pats, out_capacity=8 << 30, max_case_work=int(os.environ.get('WORK_MIB', '4')) << 20)
+eng.configure(mutations=muts, patterns=pats, out_capacity=16 << 30, max_case_work=int(os.environ.get("WORK_MIB", "4")) << 20, max_case_bytes=int(os.environ.get("CASE_MIB", "8")) << 20, big_case_bytes=int(os.environ.get("BIG_MIB", "0")) << 20)
 eng.upload_corpus(data, off)
 eng.fuzz_batch(seed=(1, 2, 3))
 outs, st = eng.download()
