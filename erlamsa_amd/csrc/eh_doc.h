@@ -20,11 +20,6 @@ struct Piece { uint64_t ptr; uint32_t len; uint32_t rep; };
 EH_DEV void piece_put(Piece* t, uint32_t i, const void* p, uint32_t len, uint32_t rep = 1) {
   if (EH_LANE == 0) { t[i].ptr = (uint64_t)p; t[i].len = len; t[i].rep = rep; }
 }
-EH_DEV uint64_t wave_sum64(uint64_t v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v += ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, d);
-  return uni64(v);
-}
 // per-lane source lane (ds_bpermute); readlane64 needs a wave-uniform lane
 EH_DEV uint64_t shfl64(uint64_t v, int src) { return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src); }
 EH_DEV uint32_t wave_max(uint32_t v) {

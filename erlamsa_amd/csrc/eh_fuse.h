@@ -57,13 +57,20 @@ EH_DEV uint32_t lanes_le(uint32_t v, uint32_t cnt, uint32_t x) {
 }
 EH_DEV uint32_t lanes_lt(uint32_t v, uint32_t cnt, uint32_t x) { uint32_t r = lanes_le(v, cnt, x ? x - 1 : 0u); return x == 0 ? 0u : r; }
 
+EH_DEV uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, d);
+  return uni64(v);
+}
+#define FUSE_UNROLL 4
 struct FuseGen { FNode* nd; uint32_t* F; uint32_t* T; };
 
 // One refinement round over all nodes of `g` (generation parity par) into `o`; returns the number of children.
 // sym: fuse(H, H) — the target lists are the source lists at every level, only one side is computed.
-EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, const FuseGen& g, uint32_t nn, const FuseGen& o, uint32_t par, bool sym) {
+EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, const FuseGen& g, uint32_t nn, const FuseGen& o, uint32_t par, bool sym, uint64_t* entries) {
   const int l = EH_LANE;
   const bool asc = par == 0;
+  uint64_t le = 0;                                               // list members of the children made by this lane (work accounting)
   uint32_t cn = 0, cf = 0, ct = 0;                               // children / F entries / T entries written so far
   uint32_t k0 = 0;
   while (k0 < nn) {
@@ -93,6 +100,7 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
       if (child) {
         FNode c2; c2.fo = special ? la : p + 1; c2.fc = 1; c2.to = special ? lb : q + 1; c2.tc = (special || tkeep) ? 1u : 0u;
         o.nd[cn + ci] = c2;
+        le += 1u + c2.tc;
       }
       cn += (uint32_t)__popcll(cm);
       k0 += nones;
@@ -113,20 +121,28 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
         const uint32_t* P = side ? g.T + b0.to : g.F + b0.fo;
         uint32_t single = side ? b0.to : b0.fo;                  // cnt == 1: the position itself
         uint32_t* h = side ? ht : hf;
-        for (uint32_t base = 0; base < cnt; base += 64) {
-          uint32_t i = base + (uint32_t)l; bool in = i < cnt;
-          uint32_t pp = in ? (cnt == 1 ? single : P[i]) : slen; bool v = in && pp < slen;
-          uint32_t bt = v ? (uint32_t)S[pp] : 0u; if (!asc) bt = 255u - bt;
-          unsigned long long lastm = __ballot(v && pp == slen - 1);
-          if (lastm) {                                           // rare: at most once per side and round
-            int j = (int)__builtin_ctzll(lastm);
-            uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)bt, j);
-            lanes_sync();
-            uint32_t before = h[bj] + (uint32_t)__popcll(__ballot(v && bt == bj) & ((1ull << j) - 1));
-            if (side) { tdb = bj; tdbefore = before; } else { fdb = bj; fdbefore = before; }
-            lanes_sync();
+        for (uint32_t base = 0; base < cnt; base += 64 * FUSE_UNROLL) {      // FUSE_UNROLL chunks in flight: the loads are the cost
+          uint32_t pp[FUSE_UNROLL], bt[FUSE_UNROLL]; bool v[FUSE_UNROLL];
+#pragma unroll
+          for (int u = 0; u < FUSE_UNROLL; u++) {
+            uint32_t i = base + 64u * (uint32_t)u + (uint32_t)l; bool in = i < cnt;
+            pp[u] = in ? (cnt == 1 ? single : P[i]) : slen; v[u] = in && pp[u] < slen;
           }
-          if (v) atomicAdd(&h[bt], 1u);
+#pragma unroll
+          for (int u = 0; u < FUSE_UNROLL; u++) { bt[u] = v[u] ? (uint32_t)S[pp[u]] : 0u; if (!asc) bt[u] = 255u - bt[u]; }
+#pragma unroll
+          for (int u = 0; u < FUSE_UNROLL; u++) {
+            unsigned long long lastm = __ballot(v[u] && pp[u] == slen - 1);
+            if (lastm) {                                         // rare: at most once per side and round
+              int j = (int)__builtin_ctzll(lastm);
+              uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)bt[u], j);
+              lanes_sync();
+              uint32_t before = h[bj] + (uint32_t)__popcll(__ballot(v[u] && bt[u] == bj) & ((1ull << j) - 1));
+              if (side) { tdb = bj; tdbefore = before; } else { fdb = bj; fdbefore = before; }
+              lanes_sync();
+            }
+            if (v[u]) atomicAdd(&h[bt[u]], 1u);
+          }
         }
       }
       if (sym) { tdb = fdb; tdbefore = fdbefore; }
@@ -147,6 +163,7 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
         ch[j] = rf[j] > 0 && (sp[j] || rt[j] > 0);
         if (sp[j]) { ef[j] = 1; et[j] = 1; }
         if (!ch[j]) { ef[j] = 0; et[j] = 0; }
+        le += ef[j] + et[j];
         lc += ch[j] ? 1u : 0u; lf += ef[j] > 1 ? ef[j] : 0u; lt2 += et[j] > 1 ? et[j] : 0u;   // only lists of > 1 go to F / T
       }
       const bool fdropped = __ballot(anyfd) != 0, tdropped = __ballot(anytd) != 0;   // the entry with rest [] leaves its group
@@ -175,24 +192,34 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
         uint32_t single = side ? b0.to : b0.fo;
         uint32_t* h = side ? ht : hf; uint32_t* O = side ? o.T : o.F;
         const bool dropped = side ? tdropped : fdropped;
-        for (uint32_t base = 0; base < cnt; base += 64) {
-          uint32_t i = base + (uint32_t)l; bool in = i < cnt;
-          uint32_t pp = in ? (cnt == 1 ? single : P[i]) : slen; bool v = in && pp < slen;
-          uint32_t bt = v ? (uint32_t)S[pp] : 0u; if (!asc) bt = 255u - bt;
-          bool isdrop = dropped && v && pp == slen - 1;            // positions are distinct: at most one such entry
-          bool vv = v && !isdrop;
-          unsigned long long eq = __ballot(vv);
+        for (uint32_t base = 0; base < cnt; base += 64 * FUSE_UNROLL) {
+          uint32_t ppu[FUSE_UNROLL], btu[FUSE_UNROLL]; bool vu[FUSE_UNROLL];
 #pragma unroll
-          for (int bit = 0; bit < 8; bit++) { unsigned long long m = __ballot(vv && ((bt >> bit) & 1u)); eq &= ((bt >> bit) & 1u) ? m : ~m; }
-          uint32_t rank = (uint32_t)__popcll(eq & ((1ull << l) - 1)), cntg = (uint32_t)__popcll(eq);
-          uint32_t off = vv ? h[bt] : 0xFFFFFFFFu, cidx = vv ? hc[bt] : 0xFFFFFFFFu, kf = vv ? hk[bt] : 0u;
-          lanes_sync();
-          if (vv && cidx != 0xFFFFFFFFu) {
-            bool isone = (kf >> side) & 1u;
-            if (isone) { if (side) o.nd[cidx].to = pp + 1; else { o.nd[cidx].fo = pp + 1; if (sym) o.nd[cidx].to = pp + 1; } }
-            else { O[off + rank] = pp + 1; if (rank == 0) h[bt] = off + cntg; }
+          for (int u = 0; u < FUSE_UNROLL; u++) {
+            uint32_t i = base + 64u * (uint32_t)u + (uint32_t)l; bool in = i < cnt;
+            ppu[u] = in ? (cnt == 1 ? single : P[i]) : slen; vu[u] = in && ppu[u] < slen;
           }
-          lanes_sync();
+#pragma unroll
+          for (int u = 0; u < FUSE_UNROLL; u++) { btu[u] = vu[u] ? (uint32_t)S[ppu[u]] : 0u; if (!asc) btu[u] = 255u - btu[u]; }
+#pragma unroll
+          for (int u = 0; u < FUSE_UNROLL; u++) {
+            const uint32_t pp = ppu[u], bt = btu[u]; const bool v = vu[u];
+            if (base + 64u * (uint32_t)u >= cnt) break;
+            bool isdrop = dropped && v && pp == slen - 1;          // positions are distinct: at most one such entry
+            bool vv = v && !isdrop;
+            unsigned long long eq = __ballot(vv);
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++) { unsigned long long m = __ballot(vv && ((bt >> bit) & 1u)); eq &= ((bt >> bit) & 1u) ? m : ~m; }
+            uint32_t rank = (uint32_t)__popcll(eq & ((1ull << l) - 1)), cntg = (uint32_t)__popcll(eq);
+            uint32_t off = vv ? h[bt] : 0xFFFFFFFFu, cidx = vv ? hc[bt] : 0xFFFFFFFFu, kf = vv ? hk[bt] : 0u;
+            lanes_sync();
+            if (vv && cidx != 0xFFFFFFFFu) {
+              bool isone = (kf >> side) & 1u;
+              if (isone) { if (side) o.nd[cidx].to = pp + 1; else { o.nd[cidx].fo = pp + 1; if (sym) o.nd[cidx].to = pp + 1; } }
+              else { O[off + rank] = pp + 1; if (rank == 0) h[bt] = off + cntg; }
+            }
+            lanes_sync();
+          }
         }
       }
       k0 += 1;
@@ -270,6 +297,7 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
       c2.fo = special ? la : (nf == 1 ? fsurv + 1 : of);
       c2.to = special ? lb : (nt == 1 ? tsurv + 1 : (nt == 0 ? 0u : ot));
       o.nd[oc] = c2;
+      le += nf + nt;
     }
     // source entries of multi-member children: behind their leader's offset
     {
@@ -291,6 +319,7 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
     cn += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63); cf += (uint32_t)__builtin_amdgcn_readlane((int)iff, 63); ct += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
     k0 += nfit;
   }
+  *entries = wave_sum64(le);
   wave_sync();
   return cn;
 }
@@ -315,11 +344,16 @@ EH_DEV bool fuse_lists(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, 
   if (l == 0) { FNode n0; n0.fo = 0; n0.fc = la; n0.to = 0; n0.tc = lb; g[0].nd[0] = n0; }   // (a single suffix: position 0 = offset 0)
   uint32_t nn = 1, par = 0;
   int64_t fuel = 100000;                                           // ?SEARCH_FUEL
+  uint64_t gen_entries = (uint64_t)la + lb;
   wave_sync();
   while (true) {                                                   // find_jump_points_loop (:115-128)
     if (fuel < 0) break;
     if (rng_rand(c.rng, 8) == 0) break;                            // ?SEARCH_STOP_IP
-    uint32_t nchild = fuse_round(A, la, B, lb, g[par], nn, g[par ^ 1], par, sym);
+    if (c.work_budget) {                                           // optional engine guard: a round costs its list members
+      c.work += 16ull * gen_entries;
+      if (c.work > c.work_budget) { c.status = CASE_BUDGET; c.ws_used = mark; return false; }
+    }
+    uint32_t nchild = fuse_round(A, la, B, lb, g[par], nn, g[par ^ 1], par, sym, &gen_entries);
     if (nchild == 0) break;                                        // NoDesp =:= [] -> any_position_pair(Nodes)
     par ^= 1; nn = nchild;
     fuel -= (int64_t)nchild;

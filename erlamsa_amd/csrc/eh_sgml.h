@@ -115,6 +115,46 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
     return nev;
   };
   auto evget = [&](uint32_t i) -> uint32_t { need(i); return (uint32_t)__builtin_amdgcn_readlane((int)bev, (int)(i - bbase)); };
+  // The same two guards against quadratic rescans by retried tags (see below):
+  // a search for ONE class that found nothing from event f finds nothing from any later event either ...
+  uint32_t ff_gt = nev, ff_qgt = nev, ff_cmt = nev, ff_sq = nev, ff_dq = nev;
+  auto find1 = [&](uint32_t from, uint32_t cls, uint32_t& ff) -> uint32_t {
+    if (from >= ff) return nev;
+    uint32_t j = find(from, 1u << cls);
+    if (j >= nev) ff = from;
+    return j;
+  };
+  // ... and a name that runs over many events ("<<<<<< ... ") is skipped through a next-stop table, built on first need
+  uint32_t* nstop_tab = nullptr;
+  auto find_stop = [&](uint32_t from, uint32_t set) -> uint32_t {          // set: ES_STOP or ES_EV
+    if (from >= nev) return nev;
+    need(from);
+    unsigned long long m = __ballot(((set >> (bev & 15u)) & 1u) != 0 && bbase + (uint32_t)l >= from && bbase + (uint32_t)l < nev);
+    if (m) return bbase + (uint32_t)__builtin_ctzll(m);
+    from = bbase + 64;
+    if (from >= nev) return nev;
+    if (!nstop_tab) {
+      nstop_tab = (uint32_t*)ws_alloc(c, ((uint64_t)nev + 64) * 4);
+      if (!nstop_tab) return 0xFFFFFFFFu;
+      uint32_t carry = nev;
+      for (uint32_t base = (nev - 1) & ~63u;; base -= 64) {
+        uint32_t j = base + (uint32_t)l; uint32_t e = j < nev ? ev[j] : 0u;
+        unsigned long long ms = __ballot(j < nev && ((ES_STOP >> (e & 15u)) & 1u));
+        unsigned long long mm = ms & ~((1ull << l) - 1);
+        if (j < nev) nstop_tab[j] = mm ? base + (uint32_t)__builtin_ctzll(mm) : carry;
+        if (ms) carry = base + (uint32_t)__builtin_ctzll(ms);
+        if (base == 0) break;
+      }
+      wave_sync();
+    }
+    for (;;) {
+      uint32_t j = uni(nstop_tab[from]);
+      if (j >= nev) return nev;
+      if (set == ES_STOP || ((set >> (evget(j) & 15u)) & 1u)) return j;    // ES_EV: a "/>" does not end the name
+      from = j + 1;
+      if (from >= nev) return nev;
+    }
+  };
   uint32_t pos = 0, ei = 0;                                                // ei = first event at or after byte pos
   auto cls_here = [&]() -> uint32_t { if (ei >= nev) return 0u; uint32_t e = evget(ei); return (e >> 4) == pos ? (e & 15u) : 0u; };
   auto step1 = [&]() { if (ei < nev && (evget(ei) >> 4) == pos) ei++; pos++; };        // consume one byte
@@ -161,7 +201,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
         if (ei + 2 < nev + 0u) { uint32_t e1 = evget(ei + 1), e2 = evget(ei + 2); d1 = (e1 >> 4) == pos + 1 && ((ES_DASH >> (e1 & 15u)) & 1u); d2 = (e2 >> 4) == pos + 2 && ((ES_DASH >> (e2 & 15u)) & 1u); }
         if (d1 && d2) {                                                    // {'!--',DT} :117-118
           uint32_t dta = pos + 3;
-          uint32_t j = find(ei + 3, 1u << E_CMTEND);
+          uint32_t j = find1(ei + 3, E_CMTEND, ff_cmt);
           if (j >= nev) { other = true; break; }                           // no clause of tz/2 matches {'!--',_}, <<>>
           uint32_t e = evget(j) >> 4;
           put(tight ? H + lt : sglit(SL_CMT), 4); put(H + dta, e - dta); put(H + e, 3);
@@ -169,7 +209,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
         }
         step1(); skipws();                                                 // {'!',DT} :113-115
         uint32_t dta = pos;
-        uint32_t j = find(ei, 1u << E_GT);
+        uint32_t j = find1(ei, E_GT, ff_gt);
         if (j >= nev) break;
         uint32_t e = evget(j) >> 4;
         put(tight ? H + lt : sglit(SL_LTBANG), 2); put(H + dta, e - dta); put(H + e, 1);
@@ -178,7 +218,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
       if (c0 == E_QM || c0 == E_QGT) {                                     // {que,DT} :106,:120-122
         step1(); skipws();
         uint32_t dta = pos;
-        uint32_t j = find(ei, 1u << E_QGT);
+        uint32_t j = find1(ei, E_QGT, ff_qgt);
         if (j >= nev) break;
         uint32_t e = evget(j) >> 4;
         put(tight ? H + lt : sglit(SL_LTQ), 2); put(H + dta, e - dta); put(H + e, 2);
@@ -187,7 +227,8 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
       if (c0 == E_SL || c0 == E_SLGT) {                                    // {end_tag,Tag} :107,:128-132
         step1(); skipws();
         na = pos;
-        uint32_t j = find(ei, ES_EV);
+        uint32_t j = find_stop(ei, ES_EV);
+        if (j == 0xFFFFFFFFu) return -3;
         if (j >= nev) break;
         nb = evget(j) >> 4; pos = nb; ei = j;
         skipws();
@@ -196,7 +237,8 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
         kind = TK_CLOSE; next = pos + 1; nexte = ei + 1; ok = true; break;
       }
       // {tag,Tag} :108-111
-      uint32_t j = find(ei, ES_STOP);
+      uint32_t j = find_stop(ei, ES_STOP);
+      if (j == 0xFFFFFFFFu) return -3;
       if (j >= nev) break;
       uint32_t ej = evget(j);
       nb = ej >> 4;
@@ -222,7 +264,8 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
         if (ca == E_EQ) break;                                             // tz({etag,..}, _) throws
         uint32_t an = pos;
         step1();
-        uint32_t ja = find(ei, ES_STOP);
+        uint32_t ja = find_stop(ei, ES_STOP);
+        if (ja == 0xFFFFFFFFu) return -3;
         if (ja >= nev) break;
         uint32_t ae = evget(ja) >> 4; pos = ae; ei = ja;
         skipws();
@@ -233,12 +276,13 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
           if (pos >= L) break;
           uint32_t cv = cls_here();
           if (cv == E_SQ || cv == E_DQ) {
-            uint32_t jq = find(ei + 1, 1u << cv);
+            uint32_t jq = cv == E_SQ ? find1(ei + 1, E_SQ, ff_sq) : find1(ei + 1, E_DQ, ff_dq);
             if (jq >= nev) break;                                          // unterminated quote
             va = pos + 1; vb = evget(jq) >> 4; delim = cv == E_SQ ? 1u : 2u;
             pos = vb + 1; ei = jq + 1;
           } else {
-            uint32_t ju = find(ei, ES_STOP);
+            uint32_t ju = find_stop(ei, ES_STOP);
+            if (ju == 0xFFFFFFFFu) return -3;
             if (ju >= nev) break;
             va = pos; vb = evget(ju) >> 4; pos = vb; ei = ju;
           }

@@ -214,6 +214,7 @@ struct Case;  // fwd
 struct EngineGuard {
   uint64_t max_bytes = 0, max_work = 0, work = 0;
   void attempt(int fn, size_t len);          // called once per mutator attempt of mux_fuzzers_loop
+  void round(uint64_t members);              // called once per find_jump_points_loop round
   void size(size_t n) const { if (max_bytes && n > max_bytes) throw Overflow(); }
 };
 
@@ -553,6 +554,7 @@ Bytes fuse(Ctx& c, const Bytes& al, const Bytes& bl) {                        //
   while (true) {                                                              // find_jump_points_loop :115-128
     if (fuel < 0) break;
     if (c.rnd.rand(8) == 0) break;
+    if (c.guard) { uint64_t m = 0; for (auto& n : nodes) m += n.froms.size() + n.tos.size(); c.guard->round(m); }
     std::vector<FuseNode> nd;
     for (auto& n : nodes) fuse_split(al, bl, n, nd);
     if (nd.empty()) break;
@@ -1152,6 +1154,11 @@ void EngineGuard::attempt(int fn, size_t len) {
     default: break;
   }
   work += (uint64_t)len * w;
+  if (work > max_work) throw Budget();
+}
+void EngineGuard::round(uint64_t members) {
+  if (!max_work) return;
+  work += 16ull * members;
   if (work > max_work) throw Budget();
 }
 void mux_fuzzers(Ctx& c, std::vector<Muta>& fs, BList& ll) {
@@ -2069,6 +2076,9 @@ std::vector<SN> sgml_mutation(Ctx& c, const std::vector<SN>& ast, long n, long n
 int sgml_mutate(Ctx& c, BList& ll) {                                          // sgml_mutate/2 :739-757
   const Bytes h = ll[0];
   if (binarish(h)) return -1;                                                 // parse/2 :198-199
+  if (const char* dp = getenv("EO_DUMP_SGM")) {                               // debugging aid: every non-binarish sgm input, appended to a file
+    FILE* f = fopen(dp, "ab"); uint32_t n = (uint32_t)h.size(); fwrite(&n, 4, 1, f); fwrite(h.data(), 1, n, f); fclose(f);
+  }
   std::vector<STok> toks;
   try { toks = sgml_tokenize(h); } catch (IncorrectSgml&) { return -1; } catch (SgmlOtherError&) { throw ErlCrash("function_clause in erlamsa_sgml:tz/2"); }
   SBuild b = sgml_build(toks, 0, {});

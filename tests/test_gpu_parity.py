@@ -179,6 +179,10 @@ ADVERSARIAL_DOCS = [
     b'<p>' * 70 + b'x', b'<p>' * 70 + b'</p>' * 70, b'<a x=1 y=2 z=3 xmlns=u xmlns:q="v">t</a>', b'text only < not a tag',
     b'<a>' + b'w' * 5000 + b'</a>', b'<a ' + b'k=v ' * 100 + b'>x</a>', b''.join(b'<i n="%d">v%d</i>' % (i, i) for i in range(150)),
     b'<\xc9L>x</\xe9l>', b'<a>\x00</a>', b'<r><![CDATA[ <x> ]]></r>',
+    # retried tags that scan far: names running over many events, terminators that never come
+    b'<a>' + b'<' * 700 + b' =x>' + b'<' * 300 + b' y=1>t', b'<a>' + b'</' * 400 + b'x >' + b'</' * 200 + b'/>/>/> >', b'<a>' + b'<!--' * 200 + b'x',
+    b'<a>' + b'<!--' * 200 + b'-->y', b'<a>' + b'<!x' * 300, b'<a>' + b'<?x' * 300 + b'?', b'<a>' + b"<a b='" * 150, b'<a>' + b'<a b="' * 151 + b'>',
+    b'<a>' + b'<b c=d/' * 200 + b'>' + b'<' * 200 + b'/>',
     # base64 of base64 of base64 of "<a>hello world</a>": nested scheduler calls three deep
     b'UEVFK2FHVnNiRzhnZDI5eWJHUThMMkUr', b'say "PGE+aGVsbG8gd29ybGQ8L2E+" and eyJrIjoiYUdWc2JHOD0ifQ== twice',
 ]

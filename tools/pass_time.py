@@ -13,7 +13,7 @@ muts = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "default" else None
 mat = synth.mixed(65536, 4096)[:n]
 data, off = synth.as_arena(mat)
 eng = ea.Engine(0)
-eng.configure(mutations=muts, patterns="od,nd,bu", out_capacity=24 << 30, max_case_bytes=case_mib << 20, big_case_bytes=big_mib << 20, max_case_work=work << 20)
+eng.configure(mutations=muts, patterns="od,nd,bu", out_capacity=32 << 30, max_case_bytes=case_mib << 20, big_case_bytes=big_mib << 20, max_case_work=work << 20)
 eng.upload_corpus(data, off)
 for rep in range(2):
     t = time.time()
