@@ -23,10 +23,11 @@ DESC_BYTES = 24        # per-case descriptor: out_off, out_len, status/draws (SU
 
 
 def cpu_baseline_leg(mat, seed, muts, pats, args):
-    """oracle/ timed on the host: chunks of 512 cases (case numbers 1.., the same corpus rows, options and
-    limits as the GPU run) are handed to `--cpu-threads` worker threads (the ctypes call releases the GIL)
-    until `--cpu-seconds` have passed or `--cpu-sample` cases are done.  Reported: the aggregate rate over
-    all threads and the threads actually used."""
+    """oracle/ timed on the host: the first `--cpu-sample` cases of the same run (same corpus rows, options and work-area
+    limit as the GPU run), in chunks of 8, handed to `--cpu-threads` worker threads (the ctypes call releases the GIL).
+    Every case runs under a wall-clock watchdog of `--cpu-case-seconds` — the reference's own maxrunningtime semantics
+    (erlamsa_main.erl:197-204: the worker is killed and the case yields <<>>; its CLI default is 30 s): the time of such a
+    case counts, its output does not.  Reported: the aggregate rate over all threads and the threads actually used."""
     import threading
     from erlamsa_amd import synth
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -35,25 +36,27 @@ def cpu_baseline_leg(mat, seed, muts, pats, args):
     n = mat.shape[0]
     limit = min(args.cpu_sample, n)
     threads = max(1, args.cpu_threads or min(os.cpu_count() or 1, 64))
-    CH = 64
+    CH = 8
     lock = threading.Lock()
-    state = {"next": 0, "cases": 0, "bytes": 0}
+    state = {"next": 0, "cases": 0, "bytes": 0, "timeouts": 0}
     t0 = time.perf_counter()
 
     def worker():
         while True:
             with lock:
                 a = state["next"]
-                if a >= limit or time.perf_counter() - t0 >= args.cpu_seconds:
+                if a >= limit:
                     return
                 state["next"] = a + CH
             b = min(a + CH, limit)
             d, o = synth.as_arena(mat[a:b])
-            outs, _, _, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, first_case=a + 1,
-                                          max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20)
+            outs, st, _, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, first_case=a + 1,
+                                           max_case_bytes=args.big_mib << 20, max_case_work=args.work_mib << 20,
+                                           max_case_seconds=args.cpu_case_seconds)
             with lock:
                 state["cases"] += b - a
                 state["bytes"] += sum(len(x) for x in outs)
+                state["timeouts"] += int((st == 6).sum())
 
     ts = [threading.Thread(target=worker) for _ in range(threads)]
     for t in ts:
@@ -62,9 +65,10 @@ def cpu_baseline_leg(mat, seed, muts, pats, args):
         t.join()
     ct = time.perf_counter() - t0
     return {"value": round(state["bytes"] / ct / 1e6, 3), "unit": "MB/s", "cores": threads, "kind": "port",
-            "cases_per_s": round(state["cases"] / ct, 2),
-            "sample": "cases 1..%d of the same run (same corpus rows, seed, mutators, patterns, limits), oracle/ C++ restatement, "
-                      "%d threads, %.1f s wall" % (state["cases"], threads, ct)}
+            "cases_per_s": round(state["cases"] / ct, 2), "cases_cut_by_watchdog": state["timeouts"],
+            "sample": "cases 1..%d of the same run (same corpus rows, seed, mutators, patterns, work-area limit), oracle/ C++ restatement, "
+                      "%d threads, %.1f s wall; per-case watchdog %.0f s (maxrunningtime semantics: time counted, output <<>>)"
+                      % (state["cases"], threads, ct, args.cpu_case_seconds)}
 
 
 def main():
@@ -78,11 +82,11 @@ def main():
     ap.add_argument("--patterns", default="od,nd,bu")
     ap.add_argument("--corpus", default="mixed", choices=["mixed", "uniform"],
                     help="mixed = BASELINE configs[2] (default); uniform = random bytes (configs[1] with --cases 1024 --size 256)")
-    ap.add_argument("--cpu-sample", type=int, default=65536, help="upper bound of cases timed on the CPU oracle (0 = skip); "
-                    "the leg stops after --cpu-seconds")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time bound of the CPU oracle leg")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="cases timed on the CPU oracle: the first N of the run (0 = skip)")
+    ap.add_argument("--cpu-case-seconds", type=float, default=10.0, help="per-case wall-clock watchdog of the CPU oracle leg "
+                    "(the reference's maxrunningtime; its CLI default is 30 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle leg (0 = all host cores, at most 64)")
-    ap.add_argument("--max-slots", type=int, default=2048, help="resident wavefront slots per context (x --inflight contexts share the GPU)")
+    ap.add_argument("--max-slots", type=int, default=0, help="tier-0 wavefront slots per context (0 = 16 per CU)")
     ap.add_argument("--out-gib", type=int, default=32, help="output arena capacity per context (GiB)")
     ap.add_argument("--case-mib", type=int, default=16, help="per-case work area of every resident wavefront (MiB), eh_options.max_case_bytes")
     ap.add_argument("--big-mib", type=int, default=1024, help="largest work area (MiB), eh_options.big_case_bytes: a case that outgrows its area "
@@ -91,7 +95,8 @@ def main():
                     "budget (eh_options.max_case_work) and report them under 'with_work_budget'; 0 = skip")
     ap.add_argument("--work-mib", type=int, default=0, help="optional per-case work budget (MiB), eh_options.max_case_work; "
                     "0 = off (default): every case runs to completion like under the reference's 30 s CLI watchdog")
-    ap.add_argument("--inflight", type=int, default=2, help="passes in flight (engine contexts / HIP streams)")
+    ap.add_argument("--inflight", type=int, default=1, help="passes in flight (engine contexts / HIP streams); every context owns "
+                    "its work-area tiers and output arena, about 144 GiB at the defaults")
     args = ap.parse_args()
 
     import numpy as np
@@ -225,6 +230,9 @@ def main():
         dt_all, out_all, cases_all = dt, float(out_bytes), float(n * args.steps)
 
     if rank == 0:
+        ntier, cap = 0, args.case_mib
+        while cap < args.big_mib and ntier < 5:
+            cap, ntier = min(cap * 4, args.big_mib), ntier + 1
         mbps = out_all / dt_all / 1e6
         in_bytes = float(n * size)
         avg_kern_s = float(np.mean(kern_ms)) / 1e3
@@ -262,13 +270,15 @@ def main():
                 "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream before the W warm-up steps",
                 "max_case_bytes": args.case_mib << 20, "big_case_bytes": args.big_mib << 20, "max_case_work": args.work_mib << 20,
             },
-            "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(max_case_bytes)", "unsupported", "arena_full",
+            "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(big_case_bytes)", "unsupported", "arena_full",
                                      "budget(max_case_work; reference analogue: maxrunningtime -> <<>>)"],
                                     [int(x) for x in status_counts])),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ea.load_library().eh_kernel_name().decode(), "kernel_ms_avg": round(avg_kern_s * 1e3, 3),
-                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "launch": "one eh_fuzz_batch = %d concurrent dispatches of the kernel (tier 0 + %d overflow tiers on their own "
+                                   "streams); kernel_ms_avg is first start -> last end, HIP events on the launch stream" % (ntier + 1, ntier)},
         }
         if budgeted is not None:
             res["with_work_budget"] = budgeted

@@ -104,12 +104,17 @@ struct KParams {
   unsigned long long* in_bytes;
   // Tiered work areas.  Tier 0: every resident wavefront has a small area (max_case_bytes).  A case that outgrows its
   // area is queued and run again from scratch (same result: a case is a pure function of its number) by the next
-  // tier: 4x larger areas, 4x fewer wavefronts, up to big_case_bytes.
+  // tier: 4x larger areas, fewer wavefronts, up to big_case_bytes.  The tiers of a batch run CONCURRENTLY, each on
+  // its own stream: tier t > 0 consumes its queue while tier t-1 is still filling it (entries start as 0xFFFFFFFF and
+  // are published with a release store; the consumer leaves when the entry it waits for is still empty after every
+  // workgroup of the producer has left).
   int32_t tier;
-  const uint32_t* in_q;          // tier > 0: case indices (of this batch) to run
-  const unsigned long long* in_n;
+  uint32_t* in_q;                // tier > 0: case indices (of this batch) to run
+  unsigned long long* prod_done; // tier > 0: workgroups of tier t-1 that have finished ...
+  uint64_t prod_grid;            // ... out of this many
   uint32_t* out_q;               // cases that overflowed in this tier (nullptr: last tier)
   unsigned long long* out_n;
+  unsigned long long* my_done;   // finished workgroups of this tier (nullptr: last tier)
 };
 
 struct MutaInfo { const char* name; int pri; int on_gpu; };

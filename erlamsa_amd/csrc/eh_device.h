@@ -218,6 +218,8 @@ EH_DEV bool wave_equal(const uint8_t* a, const uint8_t* b, uint32_t n) {
 // ---------------------------------------------------------------------------------------------
 // Per-case context (all wave-uniform)
 // ---------------------------------------------------------------------------------------------
+// site: 1xx eh_device.h, 2xx eh_doc.h, 3xx eh_engine.hip, 4xx eh_json.h, 5xx eh_lex.h, 6xx eh_sgml.h, 7xx eh_text.h, 8xx eh_tree.h
+#define EH_SET_OVERFLOW(c, site) ((c).ovf_line = (site), (c).status = CASE_OVERFLOW)
 struct Ctx {
   Rng rng;
   const KParams* p;
@@ -244,6 +246,7 @@ struct Ctx {
   int r2; uint8_t* r2_ptr; uint32_t r2_len;   // optional second flushed region (fo: flush_bvecs(A, flush_bvecs(B, T)))
   int nfs;             // entries of the mux_fuzzers list (the entries themselves: LaneTab)
   uint64_t work_budget;
+  int ovf_line;        // site id that set CASE_OVERFLOW (diagnostic: reported as -line in the last-mutator array)
   int depth;           // nesting depth of mux_fuzzers (b64 / sgm / js inner mutations re-enter the scheduler)
 };
 // The per-case context lives in LDS.  One workgroup is one wavefront, so there is exactly one Ctx per
@@ -282,7 +285,7 @@ enum { R_SAME = 0, R_NEW = 1 };
 
 EH_DEV uint8_t* ws_alloc(Ctx& c, uint64_t n) {
   uint64_t need = (n + 15) & ~(uint64_t)15;
-  if (c.ws_used + need > c.ws_cap) { c.status = CASE_OVERFLOW; return nullptr; }
+  if (c.ws_used + need > c.ws_cap) { EH_SET_OVERFLOW(c, 102); return nullptr; }
   uint8_t* p = c.ws + c.ws_used;
   c.ws_used += need;
   return p;
@@ -420,7 +423,7 @@ __device__ __noinline__ int muta_seq(Ctx&, int fn, int mask_fun) {
     case M_SR: {                                           // :263-270
       uint32_t n = rng_log(c.rng, 10); if (n < 2) n = 2;
       uint64_t nl = (uint64_t)S + (uint64_t)Lp * n + tl;
-      uint8_t* dst = nl > 0xFFFFFFFFull ? (c.status = CASE_OVERFLOW, nullptr) : ws_alloc(c, nl);
+      uint8_t* dst = nl > 0xFFFFFFFFull ? (EH_SET_OVERFLOW(c, 103), nullptr) : ws_alloc(c, nl);
       if (dst) {
         wave_copy(dst, src, S);
         wave_fill_periodic(dst + S, P, Lp, (uint64_t)Lp * n);
@@ -589,7 +592,7 @@ EH_DEV void commit_result(Ctx& c) {
   int drop = 1 + (c.r_drop_next && c.cur + 1 < c.nb ? 1 : 0);
   int tail = c.nb - c.cur - drop;
   int newnb = c.cur + (int)chunks + tail;
-  if (newnb > MAX_BLOCKS) { c.status = CASE_OVERFLOW; return; }
+  if (newnb > MAX_BLOCKS) { EH_SET_OVERFLOW(c, 104); return; }
   if (chunks != (uint32_t)drop) {                           // move the tail
     const int l = EH_LANE;
     for (int i = l; i < tail; i += 64) c.bl2[i] = c.bl[c.cur + drop + i];

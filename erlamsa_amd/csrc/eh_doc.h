@@ -135,7 +135,7 @@ EH_DEV void pieces_append(Piece* dst, uint32_t* n, const Piece* src, uint32_t a,
 EH_DEV bool pieces_materialize(Ctx& c, const Piece* t, uint32_t a, uint32_t b, uint8_t** out, uint32_t* outlen) {
   wave_sync();
   uint64_t tot = pieces_total(t + a, b - a);
-  if (tot > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; return false; }
+  if (tot > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 201); return false; }
   uint8_t* d = ws_alloc(c, tot ? tot : 16);
   if (!d) return false;
   wave_gather(d, t + a, b - a);
@@ -226,7 +226,7 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
     // NewBin = iolist_to_binary(NewLl) :669
     uint64_t tot = 0;
     for (int k = 0; k < nres; k++) tot += blk_load(c.bl, c.nb + k).len;
-    if (tot > 0xBFFFFFF0ull) { c.status = CASE_OVERFLOW; return 0; }
+    if (tot > 0xBFFFFFF0ull) { EH_SET_OVERFLOW(c, 202); return 0; }
     uint8_t* nb = ws_alloc(c, tot + 16);
     uint8_t* enc = ws_alloc(c, (tot + 2) / 3 * 4 + 16);
     if (!nb || !enc) return 0;
@@ -245,7 +245,7 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
   piece_put(out, nout, H + done_to, L - done_to); nout++;
   wave_sync();
   uint64_t total = pieces_total(out, nout);
-  if (total > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; return 0; }
+  if (total > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 203); return 0; }
   uint8_t* dst = ws_alloc(c, total ? total : 16);
   if (!dst) return 0;
   wave_gather(dst, out, nout);

@@ -62,7 +62,7 @@ constexpr int MAX_NEST = 6;
 __device__ __noinline__ int nested_fuzz(Ctx&, uint32_t e_pri, uint32_t e_meta, int nfs, const uint8_t* bin, uint32_t len) {
   EH_CTX;
   const int l = EH_LANE;
-  if (c.depth >= MAX_NEST || c.nb + 2 > MAX_BLOCKS) { c.status = CASE_OVERFLOW; return -1; }
+  if (c.depth >= MAX_NEST || c.nb + 2 > MAX_BLOCKS) { EH_SET_OVERFLOW(c, 301); return -1; }
   constexpr uint32_t SAVE = 720;                                            // StState x 2 + FoState (aux + 0 .. 720)
   uint32_t* save = (uint32_t*)ws_alloc(c, SAVE);
   if (!save) return -1;
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(64) eh_setup_kernel(DevConfig cfg, int64_t s1,
 // =============================================================================================
 EH_DEV void emit_ref(Ctx& c, uint64_t ptr, uint32_t len) {
   if (len == 0) return;
-  if (c.nem >= MAX_EMITS) { c.status = CASE_OVERFLOW; return; }
+  if (c.nem >= MAX_EMITS) { EH_SET_OVERFLOW(c, 302); return; }
   blk_store(c.em, c.nem, ptr, len);
   c.nem++;
 }
@@ -153,11 +153,11 @@ EH_DEV void split_head(Ctx& c) {
   int k = c.cur; uint64_t ptr = h.ptr; uint32_t rem = h.len;
   while (rem > ABSMAX_BINARY_BLOCK) {
     uint32_t as = ABSMAXHALF_BINARY_BLOCK + rng_rand(c.rng, ABSMAXHALF_BINARY_BLOCK) - 1;
-    if (k + 1 + tail >= MAX_BLOCKS) { c.status = CASE_OVERFLOW; return; }
+    if (k + 1 + tail >= MAX_BLOCKS) { EH_SET_OVERFLOW(c, 303); return; }
     blk_store(c.bl, k++, ptr, as); ptr += as; rem -= as;
   }
   blk_store(c.bl, k++, ptr, rem);
-  if (k + tail > MAX_BLOCKS) { c.status = CASE_OVERFLOW; return; }
+  if (k + tail > MAX_BLOCKS) { EH_SET_OVERFLOW(c, 304); return; }
   wave_sync();
   for (int i = EH_LANE; i < tail; i += 64) c.bl[k + i] = c.bl2[i];
   c.nb = k + tail;
@@ -298,7 +298,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
   int guard = 0;
   PatFrame* frames = (PatFrame*)(c.aux + 1152); int nfr = 0;     // wrapper stack lives in slot memory
   while (act != A_DONE && c.status == CASE_OK) {
-    if (++guard > 1000000) { c.status = CASE_OVERFLOW; break; }
+    if (++guard > 1000000) { EH_SET_OVERFLOW(c, 305); break; }
     switch (act) {
       case A_RUN_PAT:
         switch (pat) {
@@ -327,7 +327,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               if (r == 1) {
                 uint32_t nbytes = e.size_bits / 8;
                 if ((uint64_t)e.a + nbytes + e.len > b.len) { c.status = CASE_CRASHED; break; }
-                if (nfr >= MAX_FRAMES) { c.status = CASE_OVERFLOW; break; }
+                if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 306); break; }
                 uint8_t* fld = ws_alloc(c, 16);
                 if (!fld) break;
                 emit_ref(c, b.ptr, e.a);                                              // H
@@ -346,7 +346,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               int r = pick_csum(c, H, b.len, &iscrc, &plen, &blen);
               if (r < 0) break;
               if (r == 1) {
-                if (nfr >= MAX_FRAMES) { c.status = CASE_OVERFLOW; break; }
+                if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 307); break; }
                 emit_ref(c, b.ptr, plen);                                             // P
                 if (EH_LANE == 0) {
                   PatFrame& f = frames[nfr];
@@ -359,7 +359,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
             } else if (pat == P_AR) {                                                 // mutate_once_archiver :165-214
               // list_to_binary([Bin|Rest]) -> one block; zip:foldl fails unless an EOCD record exists
               uint64_t tot = 0; for (int i = c.cur; i < c.nb; i++) tot += blk_load(c.bl, i).len;
-              if (tot > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; break; }
+              if (tot > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 308); break; }
               if (c.nb - c.cur > 1) {
                 uint8_t* all = ws_alloc(c, tot);
                 if (!all) break;
@@ -410,7 +410,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
             while (c.status == CASE_OK) {
               bool p = rng_occurs(c.rng, 4, 5);
               if (p || n < 2) { mux_fuzzers(c, lt); n++; } else { emit_all(c); act = A_TERMINAL; break; }
-              if (++guard > 1000000) { c.status = CASE_OVERFLOW; break; }
+              if (++guard > 1000000) { EH_SET_OVERFLOW(c, 309); break; }
             }
             break;
           }
@@ -434,7 +434,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
         } else {
           // NewC = recalc_csum(Type, NewBlob): gather the inner pieces, checksum, append  (:139-143)
           uint64_t tot = 0; for (int k = f.em_field; k < c.nem; k++) tot += blk_load(c.em, k).len;
-          if (tot > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; break; }
+          if (tot > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 310); break; }
           uint8_t* blob = ws_alloc(c, tot + 16);
           if (!blob) break;
           uint64_t o = 0;
@@ -483,7 +483,7 @@ EH_DEV void gen_random(Ctx& c) {                                       // random
     uint8_t* dst = ws_alloc(c, n);
     if (!dst) return;
     random_block_rev(c, dst, n);
-    if (c.nb >= MAX_BLOCKS) { c.status = CASE_OVERFLOW; return; }
+    if (c.nb >= MAX_BLOCKS) { EH_SET_OVERFLOW(c, 311); return; }
     blk_store(c.bl, c.nb++, (uint64_t)dst, n);
     uint32_t ip = rng_range(c.rng, 1, 100);
     if (rng_rand(c.rng, ip) == 0) break;
@@ -528,7 +528,6 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
   }
 
   const uint64_t TICKET_BATCH = p.tier ? 1 : 4;   // cases claimed per atomic (one counter saturates at ~88 dequeues/us)
-  const uint64_t ncases = p.tier ? uni64(*p.in_n) : p.n;      // tier > 0: the queue the previous tier left behind
   uint64_t tk_next = 0, tk_end = 0;
   while (true) {
     if (tk_next == tk_end) {
@@ -537,8 +536,25 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
       tk_next = uni64(t); tk_end = tk_next + TICKET_BATCH;
     }
     uint64_t i = tk_next++;
-    if (i >= ncases) break;
-    if (p.tier) i = uni(p.in_q[i]);
+    if (i >= p.n) break;
+    if (p.tier) {
+      // entry i of the queue tier-1 fills while it runs: wait for it, or for the producer to be gone
+      uint32_t ent = 0xFFFFFFFFu;
+      if (l == 0) {
+        for (;;) {
+          ent = atomicAdd(&p.in_q[i], 0u);
+          if (ent != 0xFFFFFFFFu) break;
+          if (atomicAdd(p.prod_done, 0ull) >= p.prod_grid) { __threadfence(); ent = atomicAdd(&p.in_q[i], 0u); break; }
+#ifndef HIPEMU
+          __builtin_amdgcn_s_sleep(127);
+#endif
+        }
+        __threadfence();
+      }
+      ent = uni(ent);
+      if (ent == 0xFFFFFFFFu) break;
+      i = ent;
+    }
     uint64_t tick0 = __builtin_readcyclecounter();
     c.work = 0; c.depth = 0;
     c.status = CASE_OK; c.lastm = -1; c.nb = 0; c.cur = 0; c.nem = 0; c.ws_used = 0;
@@ -601,12 +617,16 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     }
     EH_PH(3);
     if (l == 0) {
-      if (c.status == CASE_OVERFLOW && p.out_q) p.out_q[atomicAdd(p.out_n, 1ull)] = (uint32_t)i;
       p.out_off[i] = base; p.out_len[i] = total; p.status[i] = c.status;
-      p.draws[i] = c.rng.draws; p.lastm[i] = c.lastm; p.cycles[i] = __builtin_readcyclecounter() - tick0;
+      p.draws[i] = c.rng.draws; p.lastm[i] = c.status == CASE_OVERFLOW ? -c.ovf_line : c.lastm; p.cycles[i] = __builtin_readcyclecounter() - tick0;
+      if (c.status == CASE_OVERFLOW && p.out_q) {                        // the next tier's results for i must land after these
+        __threadfence();
+        atomicExch(&p.out_q[atomicAdd(p.out_n, 1ull)], (uint32_t)i);
+      }
     }
     wave_sync();
   }
+  if (l == 0 && p.my_done) { __threadfence(); atomicAdd(p.my_done, 1ull); }
 }
 
 // kernel-level self tests of the byte movers (driven by tests/test_gpu_primitives.py)
@@ -712,7 +732,8 @@ struct eh_ctx {
   unsigned long long* d_counters = nullptr;  // [0] ticket, [1] out cursor
   RunState* d_run = nullptr;
   int64_t* d_seeds = nullptr; uint64_t seeds_cap = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_ready = nullptr;
+  hipStream_t tstream[MAX_TIERS] = {}; hipEvent_t ev_tier[MAX_TIERS] = {};
   hipStream_t last_stream = nullptr;
   uint64_t last_n = 0, last_in_bytes = 0;
   bool have_result = false;
@@ -895,7 +916,9 @@ static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
     while (cap < big && ctx->ntiers < eh_ctx::MAX_TIERS) {
       cap = cap * 4 < big ? cap * 4 : big;
       uint64_t stride_t = ((uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + cap + 255) & ~255ull;
-      uint64_t cnt = (16ull << 30) / stride_t; if (cnt < 8) cnt = 8; if (cnt > 1024) cnt = 1024;
+      uint64_t tier_gib = 16;
+      if (const char* e = getenv("EH_TIER_GIB")) { tier_gib = strtoull(e, nullptr, 10); if (tier_gib < 1) tier_gib = 1; }   // tuning knob
+      uint64_t cnt = (tier_gib << 30) / stride_t; if (cnt < 8) cnt = 8; if (cnt > 1024) cnt = 1024;
       if (ctx->cus < 64) cnt = 2;
       int t = ctx->ntiers;
       HIPCHK(ctx, hipMalloc(&ctx->d_tslots[t], stride_t * cnt));
@@ -939,24 +962,39 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
   p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles;
   p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;
-  // counters: [300 + 2t] ticket of tier t, [301 + 2t] length of the queue tier t consumes (t >= 1); [8, 264) = prof
+  // counters: [300 + 4t] ticket of tier t, [301 + 4t] entries queued FOR tier t, [302 + 4t] finished workgroups of tier t;
+  // [8, 264) = prof
   const int ntiers = ctx->ntiers;
-  p.tier = 0; p.in_q = nullptr; p.in_n = nullptr;
-  p.out_q = ntiers > 0 ? ctx->d_retry : nullptr; p.out_n = ctx->d_counters + 301 + 2;
+  const uint32_t grid0 = ctx->nslots < n ? ctx->nslots : (uint32_t)n;
+  p.tier = 0; p.in_q = nullptr; p.prod_done = nullptr; p.prod_grid = 0;
+  p.out_q = ntiers > 0 ? ctx->d_retry : nullptr; p.out_n = ctx->d_counters + 301 + 4;
+  p.my_done = ntiers > 0 ? ctx->d_counters + 302 : nullptr;
+  std::vector<KParams> all(ntiers + 1, p);
+  for (int t = 1; t <= ntiers; t++) {                                          // tier t over the queue tier t-1 fills
+    KParams& q = all[t];
+    q.tier = t; q.slot_base = ctx->d_tslots[t - 1]; q.slot_stride = ctx->tstride[t - 1]; q.work_cap = ctx->tcap[t - 1];
+    q.ticket = ctx->d_counters + 300 + 4 * t;
+    q.in_q = ctx->d_retry + (uint64_t)(t - 1) * ctx->retry_cap;
+    q.prod_done = ctx->d_counters + 302 + 4 * (t - 1); q.prod_grid = t == 1 ? grid0 : ctx->tnslots[t - 2];
+    q.out_q = t < ntiers ? ctx->d_retry + (uint64_t)t * ctx->retry_cap : nullptr; q.out_n = ctx->d_counters + 301 + 4 * (t + 1);
+    q.my_done = t < ntiers ? ctx->d_counters + 302 + 4 * t : nullptr;
+  }
 
   if (mode == 0) hipLaunchKernelGGL(eh_setup_kernel, dim3(1), dim3(64), 0, st, ctx->cfg, seed[0], seed[1], seed[2], ctx->d_run);
   HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, &p, sizeof(p), hipMemcpyHostToDevice, st));      // pageable source: staged before the call returns
-  if (n > 0) hipLaunchKernelGGL(eh_mutate_kernel, dim3(ctx->nslots < n ? ctx->nslots : (uint32_t)n), dim3(64), 0, st, (const KParams*)ctx->d_params);
-  for (int t = 1; n > 0 && t <= ntiers; t++) {                                  // tier t over the queue tier t-1 left behind
-    KParams q = p;
-    q.tier = t; q.slot_base = ctx->d_tslots[t - 1]; q.slot_stride = ctx->tstride[t - 1]; q.work_cap = ctx->tcap[t - 1];
-    q.ticket = ctx->d_counters + 300 + 2 * t;
-    q.in_q = ctx->d_retry + (uint64_t)(t - 1) * ctx->retry_cap; q.in_n = ctx->d_counters + 301 + 2 * t;
-    q.out_q = t < ntiers ? ctx->d_retry + (uint64_t)t * ctx->retry_cap : nullptr; q.out_n = ctx->d_counters + 301 + 2 * (t + 1);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_params + t, &q, sizeof(q), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(eh_mutate_kernel, dim3(ctx->tnslots[t - 1]), dim3(64), 0, st, (const KParams*)(ctx->d_params + t));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, all.data(), all.size() * sizeof(KParams), hipMemcpyHostToDevice, st));   // pageable source: staged before the call returns
+  if (ntiers > 0 && n > 0) {
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_retry, 0xFF, ctx->retry_cap * 4 * (uint64_t)ntiers, st));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_ready, st));
   }
+  if (n > 0) hipLaunchKernelGGL(eh_mutate_kernel, dim3(grid0), dim3(64), 0, st, (const KParams*)ctx->d_params);
+  for (int t = 1; n > 0 && t <= ntiers; t++) {                                  // always submitted after its producer
+    hipStream_t ts = ctx->tstream[t - 1];
+    HIPCHK(ctx, hipStreamWaitEvent(ts, ctx->ev_ready, 0));
+    hipLaunchKernelGGL(eh_mutate_kernel, dim3(ctx->tnslots[t - 1]), dim3(64), 0, ts, (const KParams*)(ctx->d_params + t));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_tier[t - 1], ts));
+  }
+  for (int t = 1; n > 0 && t <= ntiers; t++) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_tier[t - 1], 0));
   HIPCHK(ctx, hipEventRecord(ctx->ev1, st));
   HIPCHK(ctx, hipGetLastError());
   ctx->ordered = false;
@@ -1045,10 +1083,12 @@ int eh_create(int device, eh_ctx** out) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_T1), t1, sizeof(t1)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_T2), t2, sizeof(t2)) != hipSuccess ||
       hipMemcpyToSymbol(HIP_SYMBOL(c_T3), t3, sizeof(t3)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_funny), funny, sizeof(funny)) != hipSuccess ||
       hipMemcpyToSymbol(HIP_SYMBOL(c_nfunny), &nf, sizeof(nf)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
-      hipEventCreate(&ctx->ev1) != hipSuccess) {
-    delete ctx;
+      hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev_ready) != hipSuccess) {
+    eh_destroy(ctx);
     return EH_E_HIP;
   }
+  for (int t = 0; t < eh_ctx::MAX_TIERS; t++)
+    if (hipStreamCreateWithFlags(&ctx->tstream[t], hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev_tier[t]) != hipSuccess) { eh_destroy(ctx); return EH_E_HIP; }
   *out = ctx;
   return EH_OK;
 }
@@ -1069,6 +1109,8 @@ void eh_destroy(eh_ctx* ctx) {
   if (ctx->d_ord) (void)hipFree(ctx->d_ord);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
+  for (int t = 0; t < eh_ctx::MAX_TIERS; t++) { if (ctx->tstream[t]) (void)hipStreamDestroy(ctx->tstream[t]); if (ctx->ev_tier[t]) (void)hipEventDestroy(ctx->ev_tier[t]); }
   delete ctx;
 }
 

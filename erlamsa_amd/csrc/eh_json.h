@@ -108,7 +108,7 @@ __device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, Js
   auto close_node = [&](uint32_t i) { if (l == 0) { nd[i].p1 = npc; nd[i].nend = nn; } if (inkey_node == i) inkey_node = 0xFFFFFFFFu; };
 
   for (;;) {
-    if (nn + 4 > cap_n || npc + 8 > cap_pc) { c.status = CASE_OVERFLOW; return -3; }
+    if (nn + 4 > cap_n || npc + 8 > cap_pc) { EH_SET_OVERFLOW(c, 401); return -3; }
     if (pushing) {                                                         // push/4 :157-169
       uint32_t t = ctop();
       if (t == 0) { have_top = true; pushing = false; continue; }          // push(Bin, [], Value, Acc)
@@ -496,7 +496,7 @@ __device__ __noinline__ int muta_json(Ctx&) {
   else {
     nout = pieces_coalesce(out, nout);
     total = pieces_total(out, nout);
-    if (total > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; return 0; }
+    if (total > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 402); return 0; }
     dst = ws_alloc(c, total ? total : 16);
     if (!dst) return 0;
     wave_gather(dst, out, nout);

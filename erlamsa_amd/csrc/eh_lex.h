@@ -139,7 +139,7 @@ struct LexCache { uint64_t ptr; uint32_t len; int32_t n; LexChunk* tab; };
 
 EH_DEV uint8_t* ws_alloc_top(Ctx& c, uint64_t n) {
   uint64_t need = (n + 15) & ~(uint64_t)15;
-  if (c.ws_used + need > c.ws_cap) { c.status = CASE_OVERFLOW; return nullptr; }
+  if (c.ws_used + need > c.ws_cap) { EH_SET_OVERFLOW(c, 501); return nullptr; }
   c.ws_cap -= need;
   return c.ws + c.ws_cap;
 }
@@ -150,7 +150,7 @@ EH_DEV int lex_cached(Ctx& c, LexCache& lc, const uint8_t* H, uint32_t L, LexChu
   LexChunk* t = (LexChunk*)ws_alloc_top(c, (uint64_t)cap * sizeof(LexChunk));
   if (!t) return -1;
   int n = lex_block(H, L, t, cap);
-  if (n < 0) { c.status = CASE_OVERFLOW; return -1; }
+  if (n < 0) { EH_SET_OVERFLOW(c, 502); return -1; }
   lc.ptr = (uint64_t)H; lc.len = L; lc.n = n; lc.tab = t; *tab = t;
   return n;
 }

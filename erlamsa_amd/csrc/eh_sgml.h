@@ -185,7 +185,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
     lt = evget(j) >> 4; pos = lt + 1; ei = j + 1;
   }
   for (;;) {
-    if (npc + 16 > cap_pc || ntok + 2 > cap_tok) { c.status = CASE_OVERFLOW; return -3; }
+    if (npc + 16 > cap_pc || ntok + 2 > cap_tok) { EH_SET_OVERFLOW(c, 601); return -3; }
     // ---- one tag attempt: '<' at lt, pos/ei just behind it
     skipws();
     const uint32_t tag0 = pos, ei0 = ei, tag_p0 = npc, par0 = npar;
@@ -249,7 +249,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
       // attribute loop: {attr,..} {eatt,..} {val,..} {sqval|dqval|uqval,..} :134-160
       uint32_t nattr = 0;
       for (;;) {
-        if (npc + 16 > cap_pc || npar + 1 > cap_par) { c.status = CASE_OVERFLOW; return -3; }
+        if (npc + 16 > cap_pc || npar + 1 > cap_par) { EH_SET_OVERFLOW(c, 602); return -3; }
         if (pos >= L) break;
         if (nattr >= 16) {                                                 // quadratic-rescan guard
           if (bad && uni(bad[pos])) break;
@@ -739,13 +739,13 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
     }
   }
   if (c.status != CASE_OK) return 0;
-  if (nout > cap_out) { c.status = CASE_OVERFLOW; return 0; }
+  if (nout > cap_out) { EH_SET_OVERFLOW(c, 603); return 0; }
   // NewBinStr = fold_ast(Res, []) :746
   wave_sync();
   EH_PT(c, 92);
   nout = pieces_coalesce(out, nout);
   uint64_t total = pieces_total(out, nout);
-  if (total > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; return 0; }
+  if (total > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 604); return 0; }
   uint8_t* dst = ws_alloc(c, total ? total : 16);
   if (!dst) return 0;
   wave_gather(dst, out, nout);

@@ -124,7 +124,7 @@ EH_DEV bool pc_emit(Ctx& c, const Pieces& q) {
   uint64_t total = 0;
 #pragma unroll
   for (int i = 0; i < 6; i++) if (i < q.k) total += (uint64_t)q.n[i] * q.rep[i];
-  if (total > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; return false; }
+  if (total > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 701); return false; }
   uint8_t* dst = ws_alloc(c, total);
   if (!dst) return false;
   uint64_t pos = 0;

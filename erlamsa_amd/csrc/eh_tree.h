@@ -58,7 +58,7 @@ __device__ __noinline__ int tree_parse(Ctx&, const uint8_t* H, uint32_t L, TNode
   uint32_t* spill = (uint32_t*)ws_alloc(c, (uint64_t)(nopen + 64) * 4);
   uint32_t* evp = (uint32_t*)ws_alloc(c, (uint64_t)(nev + 64) * 4);
   if (!tab || !spill || !evp) return -1;
-  if (nopen >= (1u << 24)) { c.status = CASE_OVERFLOW; return -1; }
+  if (nopen >= (1u << 24)) { EH_SET_OVERFLOW(c, 801); return -1; }
   TR_PH(10);
   wave_collect(H, L, 0, nev, evp, IsDelim());
   TR_PH(11); TR_ST(15, nev);
@@ -450,7 +450,7 @@ __device__ __noinline__ int muta_tree(Ctx&, int fn) {
   uint64_t fixed = plen - matched_bytes;                          // bytes of P outside the matched children
   // size of R_n
   uint64_t rsz = plen;
-  for (uint32_t t = 2; t <= nreps; t++) { rsz = (uint64_t)k_in * rsz + fixed; if (rsz > c.ws_cap) { c.status = CASE_OVERFLOW; return 1; } }
+  for (uint32_t t = 2; t <= nreps; t++) { rsz = (uint64_t)k_in * rsz + fixed; if (rsz > c.ws_cap) { EH_SET_OVERFLOW(c, 802); return 1; } }
   uint8_t* R = nullptr;
   if (nreps < 2) R = (uint8_t*)(H + P.open);
   else if (k_in == 1) {
@@ -486,7 +486,7 @@ __device__ __noinline__ int muta_tree(Ctx&, int fn) {
   uint32_t nm = 0; uint64_t mb = 0;
   tree_matches(H, nodes, 0, N, L, C, anc, [&](TNode q, uint32_t) { nm++; mb += q.close - q.open + 1; });
   uint64_t nl = (uint64_t)L - mb + (uint64_t)nm * rsz;
-  if (nl > 0xFFFFFFF0ull) { c.status = CASE_OVERFLOW; return 1; }
+  if (nl > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 803); return 1; }
   uint8_t* dst = ws_alloc(c, nl);
   if (!dst) return 1;
   uint32_t cur = 0; uint64_t out = 0;

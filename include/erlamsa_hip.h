@@ -127,7 +127,8 @@ int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, 
 /* Totals of the last batch (sum of input bytes read, output bytes written, cases). */
 int eh_result_totals(eh_ctx* ctx, uint64_t* in_bytes, uint64_t* out_bytes, uint64_t* n_cases);
 /* Per-case diagnostics of the last batch (device->host): PRNG draws consumed by the worker and
- * the id (index in eh_mutator_name) of the last mutator that fired, -1 if none.  May be NULL. */
+ * the id (index in eh_mutator_name) of the last mutator that fired, -1 if none; for an EH_CASE_OVERFLOW case, minus the
+ * id of the capacity check that gave up (EH_SET_OVERFLOW sites in csrc/, a diagnostic).  May be NULL. */
 int eh_result_diag(eh_ctx* ctx, uint64_t* draws, int32_t* last_mutator);
 
 /* Per-case shader-clock ticks spent by the wavefront that ran the case (diagnostic). */

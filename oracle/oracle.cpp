@@ -10,6 +10,7 @@
 // code, plus hand-derived AS183 known answers.
 #include "oracle.h"
 
+#include <chrono>
 #include <pthread.h>
 
 #include <algorithm>
@@ -39,6 +40,7 @@ const size_t SIZER_MAX_FIRST_BYTES = 512;
 const size_t PREAMBLE_MAX_BYTES = 32;
 
 struct Overflow {};     // engine cap exceeded (not a reference behaviour)
+struct Timeout {};      // wall-clock watchdog of the cpu_baseline leg (maxrunningtime)
 struct Budget {};       // engine work budget exceeded (deterministic stand-in for maxrunningtime)
 struct Unsupported {};  // container success paths (zip/zlib re-encode) not restated
 
@@ -202,6 +204,7 @@ struct Config {
   std::string ssrf_host = "localhost"; int ssrf_port = 51234;
   uint64_t max_case_bytes = 0;
   uint64_t max_case_work = 0;
+  double max_case_seconds = 0;
 };
 
 struct Case;  // fwd
@@ -213,6 +216,8 @@ struct Case;  // fwd
 // (erlamsa_main.erl:211-220), which is outside parity.
 struct EngineGuard {
   uint64_t max_bytes = 0, max_work = 0, work = 0;
+  std::chrono::steady_clock::time_point deadline; bool timed = false; uint32_t ticks = 0;
+  void clock() { if (timed && std::chrono::steady_clock::now() > deadline) throw Timeout(); }
   void attempt(int fn, size_t len);          // called once per mutator attempt of mux_fuzzers_loop
   void round(uint64_t members);              // called once per find_jump_points_loop round
   void size(size_t n) const { if (max_bytes && n > max_bytes) throw Overflow(); }
@@ -221,6 +226,8 @@ struct EngineGuard {
 // ===========================================================================
 // Worker context for one case: PRNG + mutator list + trace
 // ===========================================================================
+static thread_local EngineGuard* tl_guard = nullptr;                          // for tick(): long loops of one mutator call
+static inline void tick() { if (tl_guard && (++tl_guard->ticks & 1023u) == 0) tl_guard->clock(); }
 struct Ctx {
   Rnd rnd;
   const Config* cfg;
@@ -530,18 +537,22 @@ CharSufs char_suffixes(const Bytes& s, const std::vector<size_t>& sufs) {     //
   for (size_t p : sufs) {
     if (p >= s.size()) continue;                    // ([], Subs) -> Subs
     std::vector<size_t>& v = m[s[p]];               // get(H, [], Subs)
-    v.insert(v.begin(), p + 1);                     // [T | ...]
+    v.push_back(p + 1);                             // [T | ...]: kept reversed here, turned round below (a cons is O(1))
     if (v.size() == 1 && v[0] == s.size()) v.clear();  // fix_empty_list([[]]) -> []
   }
+  for (auto& kv : m) std::reverse(kv.second.begin(), kv.second.end());
   return m;
 }
+// `acc` is the reference's accumulator list in REVERSE (it prepends, an O(1) cons; appending here and reversing once per
+// round in fuse/2 is the same list without a quadratic vector insert).
 void fuse_split(const Bytes& a, const Bytes& b, const FuseNode& nd, std::vector<FuseNode>& acc) {  // split/2 :85-100
+  tick();
   CharSufs sas = char_suffixes(a, nd.froms), sbs = char_suffixes(b, nd.tos);
   for (auto& kv : sas) {  // gb_trees:to_list ascending
-    if (kv.second.empty()) { acc.insert(acc.begin(), FuseNode{{a.size()}, {b.size()}}); continue; }  // [[[[]], []] | Tl]
+    if (kv.second.empty()) { acc.push_back(FuseNode{{a.size()}, {b.size()}}); continue; }  // [[[[]], []] | Tl]
     auto it = sbs.find(kv.first);
     if (it == sbs.end()) continue;
-    acc.insert(acc.begin(), FuseNode{kv.second, it->second});
+    acc.push_back(FuseNode{kv.second, it->second});
   }
 }
 Bytes fuse(Ctx& c, const Bytes& al, const Bytes& bl) {                        // fuse/2 :131-134
@@ -557,6 +568,7 @@ Bytes fuse(Ctx& c, const Bytes& al, const Bytes& bl) {                        //
     if (c.guard) { uint64_t m = 0; for (auto& n : nodes) m += n.froms.size() + n.tos.size(); c.guard->round(m); }
     std::vector<FuseNode> nd;
     for (auto& n : nodes) fuse_split(al, bl, n, nd);
+    std::reverse(nd.begin(), nd.end());
     if (nd.empty()) break;
     fuel -= (int64_t)nd.size();
     nodes.swap(nd);
@@ -1144,6 +1156,7 @@ int run_muta_fn(Ctx& c, BList& ll, Muta& m) {
 // list) and `ll` in place.
 // cost weights of the engine's optional work budget (erlamsa_amd/csrc/eh_device.h work_weight()); see EngineGuard
 void EngineGuard::attempt(int fn, size_t len) {
+  clock();
   if (!max_work) return;
   uint32_t w = 1;
   switch (fn) {
@@ -1157,6 +1170,7 @@ void EngineGuard::attempt(int fn, size_t len) {
   if (work > max_work) throw Budget();
 }
 void EngineGuard::round(uint64_t members) {
+  clock();
   if (!max_work) return;
   work += 16ull * members;
   if (work > max_work) throw Budget();
@@ -1775,6 +1789,7 @@ std::vector<STok> sgml_tokenize(const Bytes& s) {
   for (;;) {
     Bytes text; size_t from = pos; bool bad = false;
     for (;;) {
+      tick();
       size_t lt = from; while (lt < n && s[lt] != '<') lt++;                  // ff/4 :166-174
       if (bad) text.push_back('<');
       text.insert(text.end(), s.begin() + from, s.begin() + lt);
@@ -2295,7 +2310,9 @@ void run_case(Run& run, const Config& cfg, const Bytes& input, Bytes* out, int* 
   int64_t t1 = (int64_t)run.parent.erand(99999), t2 = (int64_t)run.parent.erand(99999), t3 = (int64_t)run.parent.erand(99999);   // gen_predictable_seed :179
   Ctx c; c.cfg = &cfg; c.trace = trace;
   EngineGuard guard; guard.max_bytes = cfg.max_case_bytes; guard.max_work = cfg.max_case_work;
-  if (guard.max_bytes || guard.max_work) c.guard = &guard;                    // engine caps requested by the test (not reference behaviour)
+  if (cfg.max_case_seconds > 0) { guard.timed = true; guard.deadline = std::chrono::steady_clock::now() + std::chrono::microseconds((int64_t)(cfg.max_case_seconds * 1e6)); }
+  if (guard.max_bytes || guard.max_work || guard.timed) c.guard = &guard;     // engine caps requested by the test (not reference behaviour)
+  tl_guard = c.guard;
   c.rnd.seed(t1, t2, t3);                                                     // :183
   c.fs = run.muta;                                                            // CurMuta (not advanced between cases, :229-230)
   *status = EO_OK;
@@ -2309,7 +2326,9 @@ void run_case(Run& run, const Config& cfg, const Bytes& input, Bytes* out, int* 
   } catch (ErlCrash& e) { out->clear(); *status = EO_CRASHED; if (trace) { trace->append("crash:"); trace->append(e.what()); } }
   catch (Overflow&) { out->clear(); *status = EO_OVERFLOW; }
   catch (Unsupported&) { out->clear(); *status = EO_UNSUPPORTED; }
-  catch (Budget&) { out->clear(); *status = 5; }
+  catch (Budget&) { out->clear(); *status = EO_BUDGET; }
+  catch (Timeout&) { out->clear(); *status = EO_TIMEOUT; }
+  tl_guard = nullptr;
   *draws = c.rnd.r.draws;
 }
 
@@ -2357,6 +2376,7 @@ bool build_config(const eo_config* ec, Config* cfg) {
   if (ec->ssrf_port) cfg->ssrf_port = ec->ssrf_port;
   cfg->max_case_bytes = ec->max_case_bytes;
   cfg->max_case_work = ec->max_case_work;
+  cfg->max_case_seconds = ec->max_case_seconds;
   return true;
 }
 

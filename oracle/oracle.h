@@ -32,9 +32,11 @@ typedef struct eo_config {
   const int64_t* seeds;    // mode 1
   uint64_t max_case_bytes; // engine cap mirrored here; 0 = unlimited
   uint64_t max_case_work;  // engine work budget mirrored here; 0 = unlimited
+  double max_case_seconds; // wall-clock watchdog per case (the reference's maxrunningtime: the case's output is <<>>); 0 = none.
+                           // Only bench.py's cpu_baseline leg sets it: parity tests never depend on time.
 } eo_config;
 
-enum { EO_OK = 0, EO_CRASHED = 1, EO_OVERFLOW = 2, EO_UNSUPPORTED = 3 };
+enum { EO_OK = 0, EO_CRASHED = 1, EO_OVERFLOW = 2, EO_UNSUPPORTED = 3, EO_BUDGET = 5, EO_TIMEOUT = 6 };
 
 typedef struct eo_result {
   uint8_t* data;       // concatenated outputs

@@ -25,7 +25,7 @@ class _Cfg(C.Structure):
     _fields_ = [("mutations", C.c_char_p), ("patterns", C.c_char_p), ("generators", C.c_char_p),
                 ("blockscale", C.c_double), ("ssrf_host", C.c_char_p), ("ssrf_port", C.c_int32),
                 ("mode", C.c_int32), ("seed", C.c_int64 * 3), ("first_case", C.c_uint64),
-                ("seeds", C.POINTER(C.c_int64)), ("max_case_bytes", C.c_uint64), ("max_case_work", C.c_uint64)]
+                ("seeds", C.POINTER(C.c_int64)), ("max_case_bytes", C.c_uint64), ("max_case_work", C.c_uint64), ("max_case_seconds", C.c_double)]
 
 
 class _Res(C.Structure):
@@ -73,7 +73,7 @@ def pack(inputs):
 
 
 def fuzz_batch(data, off, seed=(1, 2, 3), mutations=None, patterns=None, generators=None, blockscale=1.0,
-               first_case=1, seeds=None, max_case_bytes=0, ssrf_host=None, ssrf_port=0, trace=False, max_case_work=0):
+               first_case=1, seeds=None, max_case_bytes=0, ssrf_host=None, ssrf_port=0, trace=False, max_case_work=0, max_case_seconds=0.0):
     """Returns (list[bytes] outputs, status int32[n], draws uint64[n], trace str|None)."""
     n = len(off) - 1
     cfg = _Cfg()
@@ -86,6 +86,7 @@ def fuzz_batch(data, off, seed=(1, 2, 3), mutations=None, patterns=None, generat
     cfg.first_case = first_case
     cfg.max_case_bytes = max_case_bytes
     cfg.max_case_work = max_case_work
+    cfg.max_case_seconds = max_case_seconds
     keep = None
     if seeds is not None:
         keep = np.ascontiguousarray(seeds, dtype=np.int64).reshape(-1)

@@ -13,7 +13,7 @@ muts = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "default" else None
 mat = synth.mixed(65536, 4096)[:n]
 data, off = synth.as_arena(mat)
 eng = ea.Engine(0)
-eng.configure(mutations=muts, patterns="od,nd,bu", out_capacity=32 << 30, max_case_bytes=case_mib << 20, big_case_bytes=big_mib << 20, max_case_work=work << 20)
+eng.configure(mutations=muts, patterns="od,nd,bu", out_capacity=32 << 30, max_case_bytes=case_mib << 20, big_case_bytes=big_mib << 20, max_case_work=work << 20, max_slots=int(os.environ.get("MAX_SLOTS", "0")))
 eng.upload_corpus(data, off)
 for rep in range(2):
     t = time.time()
@@ -25,3 +25,6 @@ for rep in range(2):
     cyc = eng.cycles().astype(np.float64)
     print("pass %d: n %d case %d MiB big %d MiB work %d MiB: wall %.2f s kernel %.1f ms status %s out %.2f GB total Gcyc %.0f max Mcyc %.0f p50 %.1f p99 %.0f Mcyc" % (
         rep, n, case_mib, big_mib, work, dt, eng.kernel_ms(), np.bincount(st, minlength=6).tolist(), ob / 1e9, cyc.sum() / 1e9, cyc.max() / 1e6, np.median(cyc) / 1e6, np.percentile(cyc, 99) / 1e6), flush=True)
+    dr, lm = eng.diag()
+    ov = lm[st == 2]
+    if len(ov): print("    overflow sites:", dict(zip(*[x.tolist() for x in np.unique(-ov, return_counts=True)])), flush=True)
