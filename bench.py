@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--case-mib", type=int, default=16, help="per-case work area of every resident wavefront (MiB), eh_options.max_case_bytes")
     ap.add_argument("--big-mib", type=int, default=1024, help="largest work area (MiB), eh_options.big_case_bytes: a case that outgrows its area "
                     "is run again by the next tier (4x the area, a quarter of the wavefronts)")
-    ap.add_argument("--budget-mib", type=int, default=8, help="after the headline run (no budget), repeat 3 steps with this per-case work "
+    ap.add_argument("--budget-mib", type=int, default=64, help="after the headline run (no budget), repeat 3 steps with this per-case work "
                     "budget (eh_options.max_case_work) and report them under 'with_work_budget'; 0 = skip")
     ap.add_argument("--work-mib", type=int, default=0, help="optional per-case work budget (MiB), eh_options.max_case_work; "
                     "0 = off (default): every case runs to completion like under the reference's 30 s CLI watchdog")
@@ -277,8 +277,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ea.load_library().eh_kernel_name().decode(), "kernel_ms_avg": round(avg_kern_s * 1e3, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "launch": "one eh_fuzz_batch = %d concurrent dispatches of the kernel (tier 0 + %d overflow tiers on their own "
-                                   "streams); kernel_ms_avg is first start -> last end, HIP events on the launch stream" % (ntier + 1, ntier)},
+                         "launch": "one eh_fuzz_batch = 1 dispatch of the kernel (tier 0 + %d overflow tiers as workgroup ranges of one grid); "
+                                   "kernel_ms_avg from HIP events on the launch stream" % ntier},
         }
         if budgeted is not None:
             res["with_work_budget"] = budgeted

@@ -104,16 +104,24 @@ struct KParams {
   unsigned long long* in_bytes;
   // Tiered work areas.  Tier 0: every resident wavefront has a small area (max_case_bytes).  A case that outgrows its
   // area is queued and run again from scratch (same result: a case is a pure function of its number) by the next
-  // tier: 4x larger areas, fewer wavefronts, up to big_case_bytes.  The tiers of a batch run CONCURRENTLY, each on
-  // its own stream: tier t > 0 consumes its queue while tier t-1 is still filling it (entries start as 0xFFFFFFFF and
-  // are published with a release store; the consumer leaves when the entry it waits for is still empty after every
-  // workgroup of the producer has left).
+  // tier: 4x larger areas, fewer wavefronts, up to big_case_bytes.  All tiers of a batch are ONE dispatch: workgroups
+  // [0, tier_wg_end[0]) are tier 0, [tier_wg_end[0], tier_wg_end[1]) tier 1, ... (the argument block is an array, one
+  // entry per tier).  Workgroups are dispatched in index order, so the producers are resident before the consumers;
+  // tier t > 0 consumes its queue while the tiers below are still filling it (entries start as 0xFFFFFFFF and are
+  // published after a fence; a consumer leaves when the entry it waits for is still empty after every workgroup of
+  // tier t-1 has left, which in turn left only after the tiers below it).
   int32_t tier;
   uint32_t* in_q;                // tier > 0: case indices (of this batch) to run
   unsigned long long* prod_done; // tier > 0: workgroups of tier t-1 that have finished ...
   uint64_t prod_grid;            // ... out of this many
-  uint32_t* out_q;               // cases that overflowed in this tier (nullptr: last tier)
-  unsigned long long* out_n;
+  // a case that overflows here goes to the first later tier whose area is at least twice what it had asked for (the
+  // next one if that is unknown), or to none if a single request exceeds the largest area
+  int32_t ntiers;                // tiers above 0
+  uint32_t tier_wg_end[6];       // entry 0 only: workgroup ranges of the tiers (see above)
+  uint64_t tier_cap[5];          // work area of tier 1 .. ntiers
+  uint32_t* q_base;              // queue of tier t: q_base + (t-1) * q_stride, q_stride entries
+  uint64_t q_stride;
+  unsigned long long* q_count;   // entries queued for tier t: q_count[4 * t]
   unsigned long long* my_done;   // finished workgroups of this tier (nullptr: last tier)
 };
 

@@ -219,7 +219,7 @@ EH_DEV bool wave_equal(const uint8_t* a, const uint8_t* b, uint32_t n) {
 // Per-case context (all wave-uniform)
 // ---------------------------------------------------------------------------------------------
 // site: 1xx eh_device.h, 2xx eh_doc.h, 3xx eh_engine.hip, 4xx eh_json.h, 5xx eh_lex.h, 6xx eh_sgml.h, 7xx eh_text.h, 8xx eh_tree.h
-#define EH_SET_OVERFLOW(c, site) ((c).ovf_line = (site), (c).status = CASE_OVERFLOW)
+#define EH_SET_OVERFLOW(c, site) ((c).ovf_line = (site), (c).ovf_need = 0, (c).ovf_req = 0, (c).status = CASE_OVERFLOW)
 struct Ctx {
   Rng rng;
   const KParams* p;
@@ -246,6 +246,7 @@ struct Ctx {
   int r2; uint8_t* r2_ptr; uint32_t r2_len;   // optional second flushed region (fo: flush_bvecs(A, flush_bvecs(B, T)))
   int nfs;             // entries of the mux_fuzzers list (the entries themselves: LaneTab)
   uint64_t work_budget;
+  uint64_t ovf_need, ovf_req;   // work area the case had asked for in total / in the request that failed (0: unknown): picks the tier that runs it again
   int ovf_line;        // site id that set CASE_OVERFLOW (diagnostic: reported as -line in the last-mutator array)
   int depth;           // nesting depth of mux_fuzzers (b64 / sgm / js inner mutations re-enter the scheduler)
 };
@@ -285,7 +286,7 @@ enum { R_SAME = 0, R_NEW = 1 };
 
 EH_DEV uint8_t* ws_alloc(Ctx& c, uint64_t n) {
   uint64_t need = (n + 15) & ~(uint64_t)15;
-  if (c.ws_used + need > c.ws_cap) { EH_SET_OVERFLOW(c, 102); return nullptr; }
+  if (c.ws_used + need > c.ws_cap) { EH_SET_OVERFLOW(c, 102); c.ovf_need = c.ws_used + need; c.ovf_req = need; return nullptr; }
   uint8_t* p = c.ws + c.ws_used;
   c.ws_used += need;
   return p;
@@ -423,7 +424,7 @@ __device__ __noinline__ int muta_seq(Ctx&, int fn, int mask_fun) {
     case M_SR: {                                           // :263-270
       uint32_t n = rng_log(c.rng, 10); if (n < 2) n = 2;
       uint64_t nl = (uint64_t)S + (uint64_t)Lp * n + tl;
-      uint8_t* dst = nl > 0xFFFFFFFFull ? (EH_SET_OVERFLOW(c, 103), nullptr) : ws_alloc(c, nl);
+      uint8_t* dst = nl > 0xFFFFFFFFull ? (EH_SET_OVERFLOW(c, 103), c.ovf_req = ~0ull, nullptr) : ws_alloc(c, nl);
       if (dst) {
         wave_copy(dst, src, S);
         wave_fill_periodic(dst + S, P, Lp, (uint64_t)Lp * n);

@@ -501,12 +501,20 @@ EH_DEV void gen_random(Ctx& c) {                                       // random
 // compiler keep a ~700-byte private copy of it per lane.
 __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const KParams* __restrict__ pp) {
   const int l = EH_LANE;
+  uint32_t wg = blockIdx.x;
+  {                                                                  // which tier this workgroup serves
+    int tier = 0;
+    const int nt = pp->ntiers;
+    while (tier < nt && wg >= pp->tier_wg_end[tier]) tier++;
+    if (tier > 0) wg -= pp->tier_wg_end[tier - 1];
+    pp += tier;
+  }
   const KParams& p = *pp;
   Ctx& c = g_ctx;
   LaneTab lt;
   c.p = pp;
   c.work_budget = p.work_budget;
-  uint8_t* slot = p.slot_base + (uint64_t)blockIdx.x * p.slot_stride;
+  uint8_t* slot = p.slot_base + (uint64_t)wg * p.slot_stride;
   c.bl = (Blk*)slot;
   c.bl2 = c.bl + MAX_BLOCKS;
   c.em = c.bl2 + MAX_BLOCKS;
@@ -619,9 +627,11 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     if (l == 0) {
       p.out_off[i] = base; p.out_len[i] = total; p.status[i] = c.status;
       p.draws[i] = c.rng.draws; p.lastm[i] = c.status == CASE_OVERFLOW ? -c.ovf_line : c.lastm; p.cycles[i] = __builtin_readcyclecounter() - tick0;
-      if (c.status == CASE_OVERFLOW && p.out_q) {                        // the next tier's results for i must land after these
-        __threadfence();
-        atomicExch(&p.out_q[atomicAdd(p.out_n, 1ull)], (uint32_t)i);
+      if (c.status == CASE_OVERFLOW && p.tier < p.ntiers && c.ovf_req <= p.tier_cap[p.ntiers - 1]) {
+        int tt = p.tier + 1;
+        while (tt < p.ntiers && p.tier_cap[tt - 1] < 2 * c.ovf_need) tt++;
+        __threadfence();                                                 // that tier's results for i must land after these
+        atomicExch(&p.q_base[(uint64_t)(tt - 1) * p.q_stride + atomicAdd(&p.q_count[4 * tt], 1ull)], (uint32_t)i);
       }
     }
     wave_sync();
@@ -732,8 +742,7 @@ struct eh_ctx {
   unsigned long long* d_counters = nullptr;  // [0] ticket, [1] out cursor
   RunState* d_run = nullptr;
   int64_t* d_seeds = nullptr; uint64_t seeds_cap = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_ready = nullptr;
-  hipStream_t tstream[MAX_TIERS] = {}; hipEvent_t ev_tier[MAX_TIERS] = {};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
   uint64_t last_n = 0, last_in_bytes = 0;
   bool have_result = false;
@@ -907,7 +916,7 @@ static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
     ctx->nslots = want_slots; ctx->work_cap = work_cap; ctx->slot_stride = stride;
   }
   // tiers above 0: 4x the area and a quarter of the wavefronts each, up to big_case_bytes (default 32 x max_case_bytes,
-  // at most 1 GiB); every tier gets about 16 GiB (the emulator: two slots)
+  // at most 1 GiB); every tier gets an eighth of the free device memory, at most 32 GiB (the emulator: two slots)
   uint64_t big = ctx->big_case_bytes ? ctx->big_case_bytes : (32 * work_cap < (1024ull << 20) ? 32 * work_cap : (1024ull << 20));
   if (ctx->tier_base != work_cap || ctx->tier_big != big) {
     for (int t = 0; t < ctx->ntiers; t++) { (void)hipFree(ctx->d_tslots[t]); ctx->d_tslots[t] = nullptr; }
@@ -916,7 +925,8 @@ static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
     while (cap < big && ctx->ntiers < eh_ctx::MAX_TIERS) {
       cap = cap * 4 < big ? cap * 4 : big;
       uint64_t stride_t = ((uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + cap + 255) & ~255ull;
-      uint64_t tier_gib = 16;
+      uint64_t tier_gib = 16;                                                   // an eighth of the free memory, 1 .. 32 GiB
+      { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) { tier_gib = (uint64_t)fr >> 33; if (tier_gib < 1) tier_gib = 1; if (tier_gib > 32) tier_gib = 32; } }
       if (const char* e = getenv("EH_TIER_GIB")) { tier_gib = strtoull(e, nullptr, 10); if (tier_gib < 1) tier_gib = 1; }   // tuning knob
       uint64_t cnt = (tier_gib << 30) / stride_t; if (cnt < 8) cnt = 8; if (cnt > 1024) cnt = 1024;
       if (ctx->cus < 64) cnt = 2;
@@ -962,39 +972,32 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
   p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles;
   p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;
-  // counters: [300 + 4t] ticket of tier t, [301 + 4t] entries queued FOR tier t, [302 + 4t] finished workgroups of tier t;
+  // counters: [300 + 4t] ticket of tier t, [301 + 4t] entries queued for tier t, [302 + 4t] finished workgroups of tier t;
   // [8, 264) = prof
   const int ntiers = ctx->ntiers;
   const uint32_t grid0 = ctx->nslots < n ? ctx->nslots : (uint32_t)n;
   p.tier = 0; p.in_q = nullptr; p.prod_done = nullptr; p.prod_grid = 0;
-  p.out_q = ntiers > 0 ? ctx->d_retry : nullptr; p.out_n = ctx->d_counters + 301 + 4;
+  p.ntiers = ntiers; p.q_base = ctx->d_retry; p.q_stride = ctx->retry_cap; p.q_count = ctx->d_counters + 301;
+  for (int t = 0; t < ntiers; t++) p.tier_cap[t] = ctx->tcap[t];
   p.my_done = ntiers > 0 ? ctx->d_counters + 302 : nullptr;
   std::vector<KParams> all(ntiers + 1, p);
-  for (int t = 1; t <= ntiers; t++) {                                          // tier t over the queue tier t-1 fills
+  for (int t = 1; t <= ntiers; t++) {                                          // tier t over the queue the tiers below it fill
     KParams& q = all[t];
     q.tier = t; q.slot_base = ctx->d_tslots[t - 1]; q.slot_stride = ctx->tstride[t - 1]; q.work_cap = ctx->tcap[t - 1];
     q.ticket = ctx->d_counters + 300 + 4 * t;
     q.in_q = ctx->d_retry + (uint64_t)(t - 1) * ctx->retry_cap;
-    q.prod_done = ctx->d_counters + 302 + 4 * (t - 1); q.prod_grid = t == 1 ? grid0 : ctx->tnslots[t - 2];
-    q.out_q = t < ntiers ? ctx->d_retry + (uint64_t)t * ctx->retry_cap : nullptr; q.out_n = ctx->d_counters + 301 + 4 * (t + 1);
+    q.prod_done = ctx->d_counters + 302 + 4 * (t - 1); q.prod_grid = t == 1 ? grid0 : ctx->tnslots[t - 2];   // tier t-1 leaves after all below it
     q.my_done = t < ntiers ? ctx->d_counters + 302 + 4 * t : nullptr;
   }
+  uint32_t total_wg = grid0;
+  all[0].tier_wg_end[0] = grid0;
+  for (int t = 1; t <= ntiers; t++) { total_wg += ctx->tnslots[t - 1]; all[0].tier_wg_end[t] = total_wg; }
 
   if (mode == 0) hipLaunchKernelGGL(eh_setup_kernel, dim3(1), dim3(64), 0, st, ctx->cfg, seed[0], seed[1], seed[2], ctx->d_run);
   HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, all.data(), all.size() * sizeof(KParams), hipMemcpyHostToDevice, st));   // pageable source: staged before the call returns
-  if (ntiers > 0 && n > 0) {
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_retry, 0xFF, ctx->retry_cap * 4 * (uint64_t)ntiers, st));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_ready, st));
-  }
-  if (n > 0) hipLaunchKernelGGL(eh_mutate_kernel, dim3(grid0), dim3(64), 0, st, (const KParams*)ctx->d_params);
-  for (int t = 1; n > 0 && t <= ntiers; t++) {                                  // always submitted after its producer
-    hipStream_t ts = ctx->tstream[t - 1];
-    HIPCHK(ctx, hipStreamWaitEvent(ts, ctx->ev_ready, 0));
-    hipLaunchKernelGGL(eh_mutate_kernel, dim3(ctx->tnslots[t - 1]), dim3(64), 0, ts, (const KParams*)(ctx->d_params + t));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_tier[t - 1], ts));
-  }
-  for (int t = 1; n > 0 && t <= ntiers; t++) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_tier[t - 1], 0));
+  if (ntiers > 0 && n > 0) HIPCHK(ctx, hipMemsetAsync(ctx->d_retry, 0xFF, ctx->retry_cap * 4 * (uint64_t)ntiers, st));
+  if (n > 0) hipLaunchKernelGGL(eh_mutate_kernel, dim3(total_wg), dim3(64), 0, st, (const KParams*)ctx->d_params);
   HIPCHK(ctx, hipEventRecord(ctx->ev1, st));
   HIPCHK(ctx, hipGetLastError());
   ctx->ordered = false;
@@ -1083,12 +1086,10 @@ int eh_create(int device, eh_ctx** out) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_T1), t1, sizeof(t1)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_T2), t2, sizeof(t2)) != hipSuccess ||
       hipMemcpyToSymbol(HIP_SYMBOL(c_T3), t3, sizeof(t3)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_funny), funny, sizeof(funny)) != hipSuccess ||
       hipMemcpyToSymbol(HIP_SYMBOL(c_nfunny), &nf, sizeof(nf)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
-      hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev_ready) != hipSuccess) {
+      hipEventCreate(&ctx->ev1) != hipSuccess) {
     eh_destroy(ctx);
     return EH_E_HIP;
   }
-  for (int t = 0; t < eh_ctx::MAX_TIERS; t++)
-    if (hipStreamCreateWithFlags(&ctx->tstream[t], hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev_tier[t]) != hipSuccess) { eh_destroy(ctx); return EH_E_HIP; }
   *out = ctx;
   return EH_OK;
 }
@@ -1109,8 +1110,6 @@ void eh_destroy(eh_ctx* ctx) {
   if (ctx->d_ord) (void)hipFree(ctx->d_ord);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-  if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
-  for (int t = 0; t < eh_ctx::MAX_TIERS; t++) { if (ctx->tstream[t]) (void)hipStreamDestroy(ctx->tstream[t]); if (ctx->ev_tier[t]) (void)hipEventDestroy(ctx->ev_tier[t]); }
   delete ctx;
 }
 

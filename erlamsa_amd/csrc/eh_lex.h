@@ -139,7 +139,7 @@ struct LexCache { uint64_t ptr; uint32_t len; int32_t n; LexChunk* tab; };
 
 EH_DEV uint8_t* ws_alloc_top(Ctx& c, uint64_t n) {
   uint64_t need = (n + 15) & ~(uint64_t)15;
-  if (c.ws_used + need > c.ws_cap) { EH_SET_OVERFLOW(c, 501); return nullptr; }
+  if (c.ws_used + need > c.ws_cap) { EH_SET_OVERFLOW(c, 501); c.ovf_need = c.ws_used + need + (c.p->work_cap - c.ws_cap); c.ovf_req = need; return nullptr; }
   c.ws_cap -= need;
   return c.ws + c.ws_cap;
 }

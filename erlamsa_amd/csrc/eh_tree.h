@@ -450,7 +450,7 @@ __device__ __noinline__ int muta_tree(Ctx&, int fn) {
   uint64_t fixed = plen - matched_bytes;                          // bytes of P outside the matched children
   // size of R_n
   uint64_t rsz = plen;
-  for (uint32_t t = 2; t <= nreps; t++) { rsz = (uint64_t)k_in * rsz + fixed; if (rsz > c.ws_cap) { EH_SET_OVERFLOW(c, 802); return 1; } }
+  for (uint32_t t = 2; t <= nreps; t++) { rsz = (uint64_t)k_in * rsz + fixed; if (rsz > c.ws_cap) { EH_SET_OVERFLOW(c, 802); c.ovf_need = c.ws_used + rsz; c.ovf_req = rsz; return 1; } }
   uint8_t* R = nullptr;
   if (nreps < 2) R = (uint8_t*)(H + P.open);
   else if (k_in == 1) {
@@ -486,7 +486,7 @@ __device__ __noinline__ int muta_tree(Ctx&, int fn) {
   uint32_t nm = 0; uint64_t mb = 0;
   tree_matches(H, nodes, 0, N, L, C, anc, [&](TNode q, uint32_t) { nm++; mb += q.close - q.open + 1; });
   uint64_t nl = (uint64_t)L - mb + (uint64_t)nm * rsz;
-  if (nl > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 803); return 1; }
+  if (nl > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 803); c.ovf_req = ~0ull; return 1; }
   uint8_t* dst = ws_alloc(c, nl);
   if (!dst) return 1;
   uint32_t cur = 0; uint64_t out = 0;

@@ -1,35 +1,26 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 outputs of one profiling call (gpurun_out/prof_r1, pmc_fetch, pmc_write, pmc_sq)
-into the tracked summaries under profiles/.  Usage: tools/collect_profiles.py <round-tag, e.g. r01>"""
+"""Condense the rocprofv3 outputs of one profiling call (gpurun_out/prof_<tag>: --kernel-trace --stats; pmc_fetch,
+pmc_write, pmc_sq: one --pmc pass each) into the tracked summaries under profiles/.
+
+One eh_fuzz_batch ("launch") is one dispatch of eh_mutate_kernel (tier 0 and the overflow tiers are workgroup ranges
+of the same grid).
+
+Usage: tools/collect_profiles.py <round-tag, e.g. r02>"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
+KERNEL = "eh_mutate_kernel"
 
 
 def one(pat):
-    f = sorted(glob.glob(os.path.join(G, pat)))
+    f = sorted(glob.glob(os.path.join(G, pat), recursive=True))
     if not f:
         sys.exit("missing " + pat)
     return f[-1]
-
-
-shutil.copy(one("prof_r1/*/*kernel_stats.csv"), os.path.join(P, tag + "_kernel_stats.csv"))
-rows = []
-hdr = None
-for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    with open(one(d + "/*/*counter_collection.csv")) as fh:
-        rd = csv.reader(fh)
-        h = next(rd)
-        hdr = hdr or h
-        rows += [r for r in rd if "eh_mutate_kernel" in r[h.index("Kernel_Name")]]
-with open(os.path.join(P, tag + "_pmc_eh_mutate_kernel.csv"), "w", newline="") as fh:
-    w = csv.writer(fh)
-    w.writerow(hdr)
-    w.writerows(rows)
 
 
 def jline(path):
@@ -37,24 +28,69 @@ def jline(path):
         return [ln for ln in fh if ln.startswith("{")][-1]
 
 
+bench = json.loads(jline(os.path.join(G, "prof_%s_bench.log" % tag)))
+group = 1                                                                      # dispatches per launch
+
+shutil.copy(one("prof_%s/**/*kernel_stats.csv" % tag), os.path.join(P, tag + "_kernel_stats.csv"))
+# ---- kernel trace: per-dispatch rows of the mutate kernel, grouped into launches
+tr = [r for r in csv.DictReader(open(one("prof_%s/**/*kernel_trace.csv" % tag))) if KERNEL in r["Kernel_Name"]]
+tr.sort(key=lambda r: int(r["Dispatch_Id"]))
+assert len(tr) % group == 0, (len(tr), group)
+launches = [tr[i:i + group] for i in range(0, len(tr), group)]
+by_tier = collections.defaultdict(list)
+spans = []
+for L in launches:
+    for t, r in enumerate(L):
+        by_tier[t].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    spans.append((max(int(r["End_Timestamp"]) for r in L) - min(int(r["Start_Timestamp"]) for r in L)) / 1e6)
+with open(os.path.join(P, tag + "_kernel_trace_mutate.csv"), "w", newline="") as fh:
+    w = csv.writer(fh)
+    w.writerow(["launch", "tier", "grid_workgroups", "start_ns", "end_ns", "duration_ms", "scratch_bytes_per_lane", "vgpr", "sgpr", "lds_bytes"])
+    for li, L in enumerate(launches):
+        for t, r in enumerate(L):
+            w.writerow([li, t, int(r["Grid_Size"]) // 64 if "Grid_Size" in r else int(r["Grid_Size_X"]) // 64, r["Start_Timestamp"], r["End_Timestamp"],
+                        "%.3f" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6),
+                        r.get("Scratch_Size", r.get("Private_Segment_Size", "")), r.get("VGPR_Count", r.get("Arch_VGPR_Count", "")),
+                        r.get("SGPR_Count", ""), r.get("LDS_Block_Size", r.get("LDS_Block_Size_v", ""))])
+
+# ---- counters: sum over the dispatches of a launch, mean over launches
+rows, hdr = [], None
+for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    with open(one(d + "/**/*counter_collection.csv")) as fh:
+        rd = csv.reader(fh)
+        h = next(rd)
+        hdr = hdr or h
+        rows += [[d] + r for r in rd if KERNEL in r[h.index("Kernel_Name")]]
+with open(os.path.join(P, tag + "_pmc_eh_mutate_kernel.csv"), "w", newline="") as fh:
+    w = csv.writer(fh)
+    w.writerow(["pass"] + hdr)
+    w.writerows(rows)
+per = collections.defaultdict(lambda: collections.defaultdict(float))            # counter -> dispatch id -> value
+for r in rows:
+    per[r[1 + hdr.index("Counter_Name")]][int(r[1 + hdr.index("Dispatch_Id")])] += float(r[1 + hdr.index("Counter_Value")])
+mean = {}
+for name, d in per.items():
+    ids = sorted(d)
+    assert len(ids) % group == 0, (name, len(ids), group)
+    sums = [sum(d[i] for i in ids[k:k + group]) for k in range(0, len(ids), group)]
+    mean[name] = sum(sums) / len(sums)
+
 with open(os.path.join(P, tag + "_bench_under_rocprof.json"), "w") as fh:
-    fh.write(jline(os.path.join(G, "prof_r1_bench.log")))
-bl = sorted(glob.glob(os.path.join(G, "bench_[a-z].log")))
+    fh.write(jline(os.path.join(G, "prof_%s_bench.log" % tag)))
+bl = sorted(glob.glob(os.path.join(G, "bench_%s*.log" % tag)))
 if bl:
     with open(os.path.join(P, tag + "_bench.json"), "w") as fh:
         fh.write(jline(bl[-1]))
-acc = collections.defaultdict(list)
-for r in rows:
-    acc[r[hdr.index("Counter_Name")]].append(float(r[hdr.index("Counter_Value")]))
-mean = {k: sum(v) / len(v) for k, v in acc.items()}
-k = [r for r in csv.DictReader(open(os.path.join(P, tag + "_kernel_stats.csv"))) if "eh_mutate_kernel" in r["Name"]][0]
-bench = json.loads(jline(os.path.join(G, "prof_r1_bench.log")))
+k = [r for r in csv.DictReader(open(os.path.join(P, tag + "_kernel_stats.csv"))) if KERNEL in r["Name"]][0]
 out = {
     "round": tag,
-    "command": "rocprofv3 --kernel-trace --stats -f csv -- python bench.py --cpu-sample 0   (defaults: 65536 x 4096 B, 5 steps + 1 warmup, 3 passes in flight)",
-    "pmc_command": "rocprofv3 --pmc <COUNTERS> -f csv -- python bench.py --cpu-sample 0 --steps 2 --warmup 1 --inflight 1   (one pass per launch; separate runs for FETCH_SIZE, WRITE_SIZE and the SQ set)",
-    "kernel": k["Name"], "calls": int(k["Calls"]), "avg_ms_rocprof": float(k["AverageNs"]) / 1e6,
-    "min_ms": float(k["MinNs"]) / 1e6, "max_ms": float(k["MaxNs"]) / 1e6,
+    "command": "rocprofv3 --kernel-trace --stats -f csv -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 --budget-mib 0   (defaults otherwise: 65536 x 4096 B, full default mutator table, no work budget, 1 pass in flight)",
+    "pmc_command": "rocprofv3 --pmc <COUNTERS> -f csv -- python bench.py --steps 2 --warmup 0 --cpu-sample 0 --budget-mib 0   (separate runs for FETCH_SIZE, WRITE_SIZE and the SQ set)",
+    "kernel": k["Name"], "dispatches": int(k["Calls"]), "dispatches_per_launch": group, "launches": len(launches),
+    "avg_ms_per_dispatch_rocprof_stats": float(k["AverageNs"]) / 1e6,
+    "avg_ms_per_dispatch_by_tier": {("tier %d" % t): sum(v) / len(v) for t, v in sorted(by_tier.items())},
+    "launch_span_ms": {"avg": sum(spans) / len(spans), "min": min(spans), "max": max(spans),
+                       "note": "first start -> last end of the %d concurrent dispatches of one eh_fuzz_batch (kernel trace)" % group},
     "avg_ms_bench_hip_events_same_run": bench["roofline"]["kernel_ms_avg"],
     "share_of_gpu_time_pct": float(k["Percentage"]),
     "per_launch_counters_mean": mean,
@@ -69,8 +105,10 @@ out = {
                                     "wait_inst(issue stall)": mean["SQ_WAIT_INST_ANY"] / mean["SQ_WAVE_CYCLES"]},
     "workload_key": {"cases": bench["config"]["cases_per_step_per_gpu"], "size": 4096,
                      "max_case_work": bench["config"]["max_case_work"], "max_case_bytes": bench["config"]["max_case_bytes"],
-                     "mutators": bench["config"]["workload"].split("mutators ")[1].split(" (")[0], "patterns": "od,nd,bu"},
+                     "mutators": bench["config"]["workload"].split("mutators ")[1].split(" (")[0], "patterns": "od,nd,bu",
+                     "inflight": bench["config"]["passes_in_flight"]},
 }
 with open(os.path.join(P, tag + "_summary.json"), "w") as fh:
     json.dump(out, fh, indent=1)
-print(json.dumps({k2: out[k2] for k2 in ("avg_ms_rocprof", "avg_ms_bench_hip_events_same_run", "traffic_bytes_per_launch", "sq_breakdown_of_wave_cycles")}, indent=1))
+print(json.dumps({k2: out[k2] for k2 in ("avg_ms_per_dispatch_by_tier", "launch_span_ms", "avg_ms_bench_hip_events_same_run",
+                                          "traffic_bytes_per_launch", "sq_breakdown_of_wave_cycles")}, indent=1))
