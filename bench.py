@@ -104,9 +104,7 @@ def main():
     import erlamsa_amd as ea
     from erlamsa_amd import shard, synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local = shard.rank_env()
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -157,45 +155,21 @@ def main():
     for e in engines:
         e.sync()
 
-    def launch(k):
-        # rank r, step k -> case numbers ((k*world + r) * n) + 1 ...
-        engines[k % nctx].fuzz_batch(seed=seed, first_case=shard.weak_first_case(k, rank, world, n), corpus_first=0, n=n,
-                                     stream=streams[k % nctx].cuda_stream)
-
-    for k in range(args.warmup):
-        launch(k)
-    for e in engines:
-        e.sync() if getattr(e, "last_n", None) is not None else None
+    raw = [st.cuda_stream for st in streams]
+    # rank r, step k -> case numbers ((k*world + r) * n) + 1 ... (shard.run_steps, the loop tests/test_dist_gloo.py drives too)
+    shard.run_steps(engines, raw, 0, args.warmup, rank, world, n, seed)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out_bytes = 0
-    kern_ms = []
-    status_counts = np.zeros(6, dtype=np.int64)
-
-    def collect(e):
-        nonlocal out_bytes, status_counts
-        # totals() waits for that context's batch; the kernel time itself comes from HIP events
-        # recorded on the launch stream inside the library
-        _, ob, _ = e.totals()
-        out_bytes += ob
-        kern_ms.append(e.kernel_ms())
-        status_counts += np.bincount(e.status(), minlength=6)[:6]
-
-    for k in range(args.steps):
-        kk = args.warmup + k
-        if k >= nctx:
-            collect(engines[kk % nctx])          # the result buffers of this context are reused below
-        launch(kk)
-    for k in range(max(0, args.steps - nctx), args.steps):
-        collect(engines[(args.warmup + k) % nctx])
+    timed = shard.run_steps(engines, raw, args.warmup, args.steps, rank, world, n, seed)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    out_bytes, kern_ms, status_counts = timed["out_bytes"], timed["kernel_ms"], timed["status_counts"]
 
     # ---- second, labelled figure: the same steps under a per-case work budget (the round-1 configuration)
     budgeted = None
@@ -206,28 +180,15 @@ def main():
         bsteps = min(3, args.steps)
         torch.cuda.synchronize()
         tb = time.perf_counter()
-        for k in range(bsteps):
-            launch(args.warmup + args.steps + k)
-        bbytes, bstat = 0, np.zeros(6, dtype=np.int64)
-        for k in range(bsteps):
-            e = engines[(args.warmup + args.steps + k) % nctx]
-            _, ob, _ = e.totals()
-            bbytes += ob
-            bstat += np.bincount(e.status(), minlength=6)[:6]
+        br = shard.run_steps(engines, raw, args.warmup + args.steps, bsteps, rank, world, n, seed)
         torch.cuda.synchronize()
         bdt = time.perf_counter() - tb
+        bbytes, bstat = br["out_bytes"], br["status_counts"]
         budgeted = {"max_case_work": args.budget_mib << 20, "steps": bsteps, "value": round(bbytes / bdt / 1e6, 1), "unit": "MB/s",
                     "cases_per_s": round(n * bsteps / bdt, 1), "ms_per_step": round(bdt / bsteps * 1e3, 3),
                     "case_status_budget": int(bstat[5]), "case_status_overflow": int(bstat[2])}
 
-    tot = torch.tensor([dt, float(out_bytes), float(n * args.steps)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        tmax = tot.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dt_all, out_all, cases_all = float(tmax[0]), float(tot[1]), float(tot[2])
-    else:
-        dt_all, out_all, cases_all = dt, float(out_bytes), float(n * args.steps)
+    dt_all, out_all, cases_all = shard.reduce_over_ranks(dt, out_bytes, n * args.steps, dist, dev)
 
     if rank == 0:
         ntier, cap = 0, args.case_mib

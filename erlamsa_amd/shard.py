@@ -27,3 +27,51 @@ def broadcast_corpus(arena, offsets, src=0):
     dist.broadcast(arena, src=src)
     dist.broadcast(offsets, src=src)
     return arena, offsets
+
+
+def rank_env(env=None):
+    """(rank, world, local_rank) from the torch.distributed.run environment (1 process per GPU)."""
+    import os
+    env = os.environ if env is None else env
+    return int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1")), int(env.get("LOCAL_RANK", "0"))
+
+
+def run_steps(engines, streams, first_step, steps, rank, world, n, seed, on_result=None):
+    """The step loop of bench.py (and of tests/test_dist_gloo.py): step k of this rank is one eh_fuzz_batch over the
+    whole attached corpus with case numbers weak_first_case(k, rank, world, n).., on context k % len(engines) and that
+    context's stream; a context's previous results are collected before it is reused.  `streams` are raw stream handles
+    (0 = the null stream).  Returns {"out_bytes", "kernel_ms": [...], "status_counts": int64[6]}; `on_result(step,
+    engine)` is called at collection time (the engine still holds that step's results)."""
+    import numpy as np
+    nctx = len(engines)
+    res = {"out_bytes": 0, "kernel_ms": [], "status_counts": np.zeros(6, dtype=np.int64)}
+
+    def collect(k):
+        e = engines[k % nctx]
+        _, ob, _ = e.totals()                         # waits for that context's batch
+        res["out_bytes"] += ob
+        res["kernel_ms"].append(e.kernel_ms())        # HIP events recorded on the launch stream inside the library
+        res["status_counts"] += np.bincount(e.status(), minlength=6)[:6]
+        if on_result is not None:
+            on_result(k, e)
+
+    for k in range(first_step, first_step + steps):
+        if k - first_step >= nctx:
+            collect(k - nctx)
+        engines[k % nctx].fuzz_batch(seed=seed, first_case=weak_first_case(k, rank, world, n), corpus_first=0, n=n,
+                                     stream=streams[k % nctx])
+    for k in range(max(first_step, first_step + steps - nctx), first_step + steps):
+        collect(k)
+    return res
+
+
+def reduce_over_ranks(dt, out_bytes, cases, dist=None, device=None):
+    """bench.py's aggregation: MAX of the step-loop time over ranks, SUM of bytes and cases.  Returns floats."""
+    if dist is None:
+        return float(dt), float(out_bytes), float(cases)
+    import torch
+    tot = torch.tensor([dt, float(out_bytes), float(cases)], dtype=torch.float64, device=device)
+    tmax = tot.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    return float(tmax[0]), float(tot[1]), float(tot[2])

@@ -1,7 +1,9 @@
-"""N>1 path on CPU: two gloo ranks broadcast the seed arena, shard the case range, and the union
-of what they compute equals the single-process result.  The per-rank 'engine' here is the oracle
-(the checker) — the property under test is the sharding/broadcast logic that bench.py and the NIF
-shim use, and that results are independent of the number of ranks."""
+"""N>1 path on CPU: gloo ranks broadcast the seed arena and run bench.py's own step loop (shard.run_steps, shard.reduce_
+over_ranks) over it with the ENGINE — the kernel code on the CPU wavefront emulator (tests/hipemu), where device
+pointers are host pointers, so the broadcast torch tensors are attached exactly as bench.py attaches its HBM arena.
+Rank r, step k runs case numbers weak_first_case(k, r, W, n)..; the union over ranks and steps must equal one
+single-process oracle run over the same case numbers, independent of W.  The oracle is only the
+checker here."""
 import os
 import sys
 
@@ -9,56 +11,83 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+MUTS, PATS, SEED = "bd,bf,bi,sr,num,ld,ab", "od,nd,bu", (1, 2, 3)
+N, SIZE, STEPS = 24, 160, 2
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, emu_lib, q):
+    os.environ["ERLAMSA_HIP_LIB"] = emu_lib
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch
     import torch.distributed as dist
-    import pyoracle as po
+    import erlamsa_amd as ea
     from erlamsa_amd import shard, synth
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    n, size = 96, 128
-    arena = torch.zeros(n * size, dtype=torch.uint8)
-    offs = torch.zeros(n + 1, dtype=torch.int64)
-    if rank == 0:
-        arena.copy_(torch.from_numpy(synth.mixed(n, size).reshape(-1)))
-        offs.copy_(torch.arange(n + 1, dtype=torch.int64) * size)
+    r, w, _ = shard.rank_env()
+    dist.init_process_group("gloo", rank=r, world_size=w)
+    arena = torch.zeros(N * SIZE, dtype=torch.uint8)
+    offs = torch.zeros(N + 1, dtype=torch.int64)
+    if r == 0:
+        arena.copy_(torch.from_numpy(synth.mixed(N, SIZE).reshape(-1)))
+        offs.copy_(torch.arange(N + 1, dtype=torch.int64) * SIZE)
     shard.broadcast_corpus(arena, offs, src=0)
-    first, cnt = shard.case_range(n, rank, world)
-    o = offs.numpy().astype(np.uint64)
-    sub_off = o[first:first + cnt + 1] - o[first]
-    sub = arena.numpy()[int(o[first]):int(o[first + cnt])]
-    outs, st, _, _ = po.fuzz_batch(sub if len(sub) else np.zeros(1, np.uint8), sub_off, seed=(1, 2, 3),
-                                   mutations="bd,bf,bi,sr,num,ld", patterns="od,nd,bu", first_case=first + 1)
-    gathered = [None] * world
-    dist.all_gather_object(gathered, (first, outs, st.tolist()))
-    if rank == 0:
-        q.put((arena.numpy().copy(), offs.numpy().copy(), gathered))
+    engines = []
+    for _ in range(2):                                    # two contexts in flight, like bench.py --inflight 2
+        e = ea.Engine(0)
+        e.configure(mutations=MUTS, patterns=PATS, max_case_bytes=1 << 20)
+        e.attach_corpus(arena.data_ptr(), offs.data_ptr(), N, N * SIZE)
+        engines.append(e)
+    got = {}
+
+    def keep(step, e):
+        outs, st = e.download()
+        got[step] = (outs, st.tolist())
+
+    res = shard.run_steps(engines, [0, 0], 0, STEPS, r, w, N, SEED, on_result=keep)
+    dt_all, out_all, cases_all = shard.reduce_over_ranks(1.0 + r, res["out_bytes"], N * STEPS, dist, None)
+    gathered = [None] * w
+    dist.all_gather_object(gathered, (r, got, int(res["out_bytes"]), res["status_counts"].tolist()))
+    if r == 0:
+        q.put((arena.numpy().copy(), gathered, (dt_all, out_all, cases_all)))
+    for e in engines:
+        e.close()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_run_equals_single_process(world):
+def test_sharded_engine_run_equals_single_process_oracle(world):
     import torch.multiprocessing as mp
+    import build_emu
+    emu_lib = build_emu.build()
+    sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
+    from erlamsa_amd import shard
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000 + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, emu_lib, q)) for r in range(world)]
     for p in procs:
         p.start()
-    arena, offs, gathered = q.get(timeout=120)
+    arena, gathered, (dt_all, out_all, cases_all) = q.get(timeout=600)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    whole, st, _, _ = po.fuzz_batch(arena, offs.astype(np.uint64), seed=(1, 2, 3), mutations="bd,bf,bi,sr,num,ld", patterns="od,nd,bu")
-    merged = [None] * len(whole)
-    for first, outs, sts in gathered:
-        for k, o in enumerate(outs):
-            merged[first + k] = o
-    assert merged == whole
+    offs = (np.arange(N + 1, dtype=np.uint64) * SIZE)
+    total = 0
+    for r, got, out_bytes, _ in gathered:
+        assert sorted(got) == list(range(STEPS))
+        for step, (outs, sts) in got.items():
+            first = shard.weak_first_case(step, r, world, N)
+            assert first == (step * world + r) * N + 1
+            want, wst, _, _ = po.fuzz_batch(arena, offs, seed=SEED, mutations=MUTS, patterns=PATS, first_case=first)
+            assert sts == wst.tolist()
+            assert outs == want, "rank %d step %d" % (r, step)
+            total += sum(len(o) for o in outs)
+        assert out_bytes == sum(sum(len(o) for o in got[s][0]) for s in got)
+    # the aggregation bench.py prints: max of the times, sums of bytes and cases
+    assert dt_all == float(world) and out_all == float(total) and cases_all == float(world * N * STEPS)
+    # no two (rank, step) pairs share a case number
+    blocks = sorted(shard.weak_first_case(s, r, world, N) for r in range(world) for s in range(STEPS))
+    assert blocks == [k * N + 1 for k in range(world * STEPS)]
