@@ -95,6 +95,8 @@ def main():
                     "budget (eh_options.max_case_work) and report them under 'with_work_budget'; 0 = skip")
     ap.add_argument("--work-mib", type=int, default=0, help="optional per-case work budget (MiB), eh_options.max_case_work; "
                     "0 = off (default): every case runs to completion like under the reference's 30 s CLI watchdog")
+    ap.add_argument("--pcie", type=int, default=1, help="1: after the timed steps, one extra pass whose outputs are downloaded to pinned host memory "
+                    "(reported as 'pcie'); 0: skip")
     ap.add_argument("--inflight", type=int, default=1, help="passes in flight (engine contexts / HIP streams); every context owns "
                     "its work-area tiers and output arena, about 144 GiB at the defaults")
     args = ap.parse_args()
@@ -188,6 +190,35 @@ def main():
                     "cases_per_s": round(n * bsteps / bdt, 1), "ms_per_step": round(bdt / bsteps * 1e3, 3),
                     "case_status_budget": int(bstat[5]), "case_status_overflow": int(bstat[2])}
 
+    # ---- PCIe-inclusive leg (rank 0, N=1): one more pass whose outputs are also brought to host memory, case-ordered,
+    # through the boundary call a host-side consumer uses (eh_result_download into pinned memory)
+    pcie = None
+    if args.pcie and world == 1 and args.steps > 0:
+        cap = int(out_bytes / args.steps * 1.5) + (1 << 30)
+        try:
+            hbuf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+            kind = "pinned"
+        except RuntimeError:
+            hbuf = torch.empty(cap, dtype=torch.uint8)
+            kind = "pageable"
+        e = engines[0]
+        kx = args.warmup + args.steps + 100
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        e.fuzz_batch(seed=seed, first_case=shard.weak_first_case(kx, rank, world, n), corpus_first=0, n=n, stream=raw[0])
+        e.sync()
+        tk = time.perf_counter()
+        try:
+            off, _ = e.download_into(hbuf.data_ptr(), cap)
+            td = time.perf_counter()
+            ob = int(off[-1])
+            pcie = {"pcie_inclusive_MBps": round(ob / (td - tp) / 1e6, 1), "download_GBps": round(ob / (td - tk) / 1e9, 2), "out_bytes": ob,
+                    "host_buffer": kind, "pass_s": round(tk - tp, 3), "download_s": round(td - tk, 3),
+                    "note": "one pass + eh_result_download (device gather into case order, 2 bounce buffers, D2H overlapped), not overlapped with the next pass"}
+        except ea.EngineError as ex:
+            pcie = {"error": str(ex)}
+        del hbuf
+
     dt_all, out_all, cases_all = shard.reduce_over_ranks(dt, out_bytes, n * args.steps, dist, dev)
 
     if rank == 0:
@@ -243,6 +274,8 @@ def main():
         }
         if budgeted is not None:
             res["with_work_budget"] = budgeted
+        if pcie is not None:
+            res["pcie"] = pcie
         # ---- CPU baseline: the oracle (C++ restatement of the reference) on the host cores, N=1 only
         if args.cpu_sample > 0 and world == 1:
             res["cpu_baseline"] = cpu_baseline_leg(mat, seed, muts, pats, args)

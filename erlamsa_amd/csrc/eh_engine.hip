@@ -663,9 +663,9 @@ __global__ void __launch_bounds__(64) eh_order_scan_kernel(const uint64_t* out_l
 }
 // one wavefront per case (grid-stride): dst[ord_off[i] ..) = src[out_off[i] ..)
 __global__ void __launch_bounds__(64) eh_order_gather_kernel(const uint8_t* src, uint8_t* dst, const uint64_t* out_off, const uint64_t* out_len,
-                                                             const uint64_t* ord_off, uint64_t n) {
+                                                             const uint64_t* ord_off, uint64_t n, uint64_t ord_base) {
   for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
-    uint64_t len = uni64(out_len[i]), so = uni64(out_off[i]), d0 = uni64(ord_off[i]);
+    uint64_t len = uni64(out_len[i]), so = uni64(out_off[i]), d0 = uni64(ord_off[i]) - ord_base;
     uint64_t done = 0;
     while (done < len) { uint32_t c = len - done > 0x40000000ull ? 0x40000000u : (uint32_t)(len - done); wave_copy(dst + d0 + done, src + so + done, c); done += c; }
   }
@@ -720,7 +720,10 @@ struct eh_ctx {
   uint64_t max_case_bytes = 0, out_capacity_opt = 0, work_budget = 0;
   uint32_t max_slots_opt = 0, flags = 0;
   KParams* d_params = nullptr;                          // argument block of eh_mutate_kernel
-  uint8_t* h_stage = nullptr; uint64_t h_stage_cap = 0; // host staging buffer of eh_result_download
+  // eh_result_download: case-ordered chunks are gathered on the device into two bounce buffers; chunk k goes over PCIe
+  // while chunk k+1 is gathered
+  uint8_t* d_bounce[2] = {nullptr, nullptr}; uint64_t bounce_cap = 0; hipStream_t dl_gather = nullptr, dl_copy = nullptr;
+  hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_c[2] = {nullptr, nullptr};
   uint8_t* d_out2 = nullptr; uint64_t out2_cap = 0;   // EH_FLAG_ORDERED_OUTPUT: second arena (case order)
   uint64_t* d_ord = nullptr; uint64_t ord_cap = 0;      // ordered offsets (n + 1)
   bool ordered = false;                                 // the last batch's results are in case order
@@ -1018,7 +1021,7 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
     }
     hipLaunchKernelGGL(eh_order_scan_kernel, dim3(1), dim3(64), 0, st, ctx->d_len, ctx->d_ord, n);
     uint32_t g = (uint32_t)ctx->cus * 32u; if (g > n) g = (uint32_t)n;
-    hipLaunchKernelGGL(eh_order_gather_kernel, dim3(g), dim3(64), 0, st, ctx->d_out, ctx->d_out2, ctx->d_off, ctx->d_len, ctx->d_ord, n);
+    hipLaunchKernelGGL(eh_order_gather_kernel, dim3(g), dim3(64), 0, st, ctx->d_out, ctx->d_out2, ctx->d_off, ctx->d_len, ctx->d_ord, n, 0ull);
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_off, ctx->d_ord, n * 8, hipMemcpyDeviceToDevice, st));
     HIPCHK(ctx, hipGetLastError());
     uint8_t* t = ctx->d_out; ctx->d_out = ctx->d_out2; ctx->d_out2 = t;
@@ -1102,7 +1105,9 @@ void eh_destroy(eh_ctx* ctx) {
   (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
   (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_run); (void)hipFree(ctx->d_seeds);
-  free(ctx->h_stage);
+  for (int k = 0; k < 2; k++) { if (ctx->d_bounce[k]) (void)hipFree(ctx->d_bounce[k]); if (ctx->ev_g[k]) (void)hipEventDestroy(ctx->ev_g[k]); if (ctx->ev_c[k]) (void)hipEventDestroy(ctx->ev_c[k]); }
+  if (ctx->dl_gather) (void)hipStreamDestroy(ctx->dl_gather);
+  if (ctx->dl_copy) (void)hipStreamDestroy(ctx->dl_copy);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
   for (int t = 0; t < ctx->ntiers; t++) (void)hipFree(ctx->d_tslots[t]);
   if (ctx->d_retry) (void)hipFree(ctx->d_retry);
@@ -1273,19 +1278,56 @@ int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, 
       if (total) HIPCHK(ctx, hipMemcpy(data, ctx->d_out, total, hipMemcpyDeviceToHost));
       return EH_OK;
     }
-    unsigned long long cur = 0;
-    HIPCHK(ctx, hipMemcpy(&cur, ctx->d_counters + 1, 8, hipMemcpyDeviceToHost));
-    if (cur > ctx->out_cap) cur = ctx->out_cap;
-    // staging buffer kept across calls (a fresh 2 GB vector costs ~0.3 s of page faults and zero fill)
-    if (ctx->h_stage_cap < cur) {
-      free(ctx->h_stage);
-      ctx->h_stage = (uint8_t*)malloc(cur);
-      ctx->h_stage_cap = ctx->h_stage ? cur : 0;
-      if (!ctx->h_stage) { ctx->err = "out of host memory for the download staging buffer"; return EH_E_NOMEM; }
+    // completion-ordered arena -> case order: gather a chunk of consecutive cases into a bounce buffer on the device,
+    // copy it out (full PCIe rate when `data` is pinned or registered host memory) while the next chunk is gathered
+    if (total == 0) return EH_OK;
+    uint64_t maxlen = 0; for (uint64_t i = 0; i < n; i++) if (len[i] > maxlen) maxlen = len[i];
+    uint64_t chunk = 256ull << 20;
+    if (const char* e = getenv("EH_DL_CHUNK")) { chunk = strtoull(e, nullptr, 10); if (chunk < 64) chunk = 64; }   // tests: many small chunks
+    uint64_t want = maxlen > chunk ? maxlen : chunk;
+    if (want > total) want = total;
+    want = (want + 4095) & ~4095ull;
+    if (!ctx->dl_gather) {
+      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->dl_gather, hipStreamNonBlocking));
+      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->dl_copy, hipStreamNonBlocking));
+      for (int k = 0; k < 2; k++) { HIPCHK(ctx, hipEventCreate(&ctx->ev_g[k])); HIPCHK(ctx, hipEventCreate(&ctx->ev_c[k])); }
     }
-    if (cur) HIPCHK(ctx, hipMemcpy(ctx->h_stage, ctx->d_out, cur, hipMemcpyDeviceToHost));
-    uint64_t p = 0;
-    for (uint64_t i = 0; i < n; i++) { if (len[i]) memcpy(data + p, ctx->h_stage + o[i], len[i]); p += len[i]; }
+    if (ctx->bounce_cap < want || getenv("EH_DL_CHUNK")) {
+      for (int k = 0; k < 2; k++) { if (ctx->d_bounce[k]) (void)hipFree(ctx->d_bounce[k]); ctx->d_bounce[k] = nullptr; }
+      ctx->bounce_cap = 0;
+      for (int k = 0; k < 2; k++) HIPCHK(ctx, hipMalloc(&ctx->d_bounce[k], want));
+      ctx->bounce_cap = want;
+    }
+    if (!ctx->d_ord || ctx->ord_cap < n + 1) {
+      if (ctx->d_ord) (void)hipFree(ctx->d_ord);
+      ctx->d_ord = nullptr;
+      HIPCHK(ctx, hipMalloc(&ctx->d_ord, (n + 1) * 8));
+      ctx->ord_cap = n + 1;
+    }
+    std::vector<uint64_t> ord(n + 1);
+    { uint64_t p = 0; for (uint64_t i = 0; i < n; i++) { ord[i] = p; p += len[i]; } ord[n] = p; }
+    HIPCHK(ctx, hipMemcpy(ctx->d_ord, ord.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    uint64_t a = 0; int k = 0;
+    while (a < n) {
+      uint64_t b = a + 1;
+      while (b < n && ord[b + 1] - ord[a] <= ctx->bounce_cap) b++;
+      const int buf = k & 1;
+      if (k >= 2) HIPCHK(ctx, hipStreamWaitEvent(ctx->dl_gather, ctx->ev_c[buf], 0));     // the copy that last read this buffer
+      uint64_t bytes = ord[b] - ord[a];
+      if (bytes) {
+        uint64_t cnt = b - a;
+        uint32_t g = (uint32_t)ctx->cus * 32u; if (g > cnt) g = (uint32_t)cnt;
+        hipLaunchKernelGGL(eh_order_gather_kernel, dim3(g), dim3(64), 0, ctx->dl_gather, (const uint8_t*)ctx->d_out, ctx->d_bounce[buf],
+                           (const uint64_t*)(ctx->d_off + a), (const uint64_t*)(ctx->d_len + a), (const uint64_t*)(ctx->d_ord + a), cnt, ord[a]);
+      }
+      HIPCHK(ctx, hipEventRecord(ctx->ev_g[buf], ctx->dl_gather));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->dl_copy, ctx->ev_g[buf], 0));
+      if (bytes) HIPCHK(ctx, hipMemcpyAsync(data + ord[a], ctx->d_bounce[buf], bytes, hipMemcpyDeviceToHost, ctx->dl_copy));
+      HIPCHK(ctx, hipEventRecord(ctx->ev_c[buf], ctx->dl_copy));
+      a = b; k++;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->dl_copy));
+    HIPCHK(ctx, hipGetLastError());
   }
   return EH_OK;
 }

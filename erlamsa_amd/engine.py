@@ -207,6 +207,15 @@ class Engine:
         outs = [buf[int(off[i]):int(off[i + 1])] for i in range(n)]
         return outs, status[:n]
 
+    def download_into(self, host_ptr, cap):
+        """Case-ordered outputs of the last batch into caller memory at `host_ptr` (`cap` bytes; pinned or registered
+        host memory gets the full PCIe rate).  -> (off uint64[n+1], status int32[n])"""
+        n = self.last_n
+        off = np.zeros(n + 1, dtype=np.uint64)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        self._chk(self.lib.eh_result_download(self.h, C.c_void_p(host_ptr), cap, off.ctypes.data, status.ctypes.data))
+        return off, status[:n]
+
     def status(self):
         n = self.last_n
         st = np.zeros(max(n, 1), dtype=np.int32)

@@ -53,6 +53,11 @@ g, s = eng.download()
 assert g == want and list(s) == list(wst)
 inb, outb, nc = eng.totals()
 assert nc == 40 and inb == 40 * 200 and outb == sum(map(len, want))
+# the download path in many chunks (device gather into two alternating bounce buffers)
+os.environ["EH_DL_CHUNK"] = "700"
+gc, sc = eng.download()
+del os.environ["EH_DL_CHUNK"]
+assert gc == want and list(sc) == list(wst)
 # a sub-range with the matching first_case reproduces the same cases
 eng.fuzz_batch(seed=(1, 2, 3), first_case=11, corpus_first=10, n=5)
 g5, _ = eng.download()
