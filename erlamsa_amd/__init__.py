@@ -12,8 +12,8 @@ no CPU fallback.
 """
 from .engine import (CASE_CRASHED, CASE_OK, CASE_OVERFLOW, CASE_UNSUPPORTED, Engine, EngineError, gpu_mutators,
                      gpu_patterns, load_library, mutator_table, pattern_table)
-from .api import actions_to_string, default_mutations, default_patterns, fuzz, fuzz_batch, fuzzer, pack_corpus
+from .api import EngineLimit, actions_to_string, default_mutations, default_patterns, fuzz, fuzz_batch, fuzzer, pack_corpus
 
-__all__ = ["Engine", "EngineError", "fuzzer", "fuzz", "fuzz_batch", "pack_corpus", "default_mutations",
+__all__ = ["Engine", "EngineError", "EngineLimit", "fuzzer", "fuzz", "fuzz_batch", "pack_corpus", "default_mutations",
            "default_patterns", "actions_to_string", "mutator_table", "pattern_table", "gpu_mutators", "gpu_patterns",
            "load_library", "CASE_OK", "CASE_CRASHED", "CASE_OVERFLOW", "CASE_UNSUPPORTED"]

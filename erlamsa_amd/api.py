@@ -81,21 +81,36 @@ def fuzz_batch(inputs, opts=None, return_status=False, device=0):
     return (outs, status) if return_status else outs
 
 
+class EngineLimit(RuntimeError):
+    """Cases of a fuzzer() call stopped at an engine limit the reference does not have (statuses 2 overflow,
+    3 unsupported, 4 arena full, 5 work budget): `.cases` = [(index, status)], `.results` = what the other cases gave."""
+
+    def __init__(self, cases, results):
+        super().__init__("%d case(s) stopped at an engine limit: %s" % (len(cases), cases[:8]))
+        self.cases, self.results = cases, results
+
+
 def fuzzer(opts):
     """erlamsa_main:fuzzer/1 for paths=[direct], output=return: the same input N times.
-    Like record_result/2 (erlamsa_main.erl:120-122) empty results are dropped."""
+    Like record_result/2 (erlamsa_main.erl:120-122) empty results are dropped (a crashed worker, status 1, gives <<>>).
+    A case that stopped at an engine-only limit is never dropped silently: EngineLimit is raised unless
+    opts["on_engine_limit"] == "skip" (then the caller reads the statuses through fuzz_batch(return_status=True))."""
     opts = dict(opts)
     if opts.get("paths", ["direct"]) != ["direct"] or opts.get("output", "return") != "return":
         raise ValueError("only paths=[direct], output=return is served by the GPU path")
     n = int(opts.get("n", 1))
     skip = int(opts.get("skip", 0))
     outs, status = fuzz_batch([bytes(opts.get("input", b""))] * n, opts, return_status=True, device=int(opts.get("device", 0)))
-    res = []
+    res, limited = [], []
     for i, (o, s) in enumerate(zip(outs, status)):
         if i < skip:
             continue
         if s == CASE_OK and len(o) > 0:
             res.append(o)
+        elif s >= 2:
+            limited.append((i, int(s)))
+    if limited and opts.get("on_engine_limit", "raise") != "skip":
+        raise EngineLimit(limited, res)
     return res
 
 

@@ -729,6 +729,7 @@ struct eh_ctx {
   bool ordered = false;                                 // the last batch's results are in case order
   // corpus
   uint8_t* d_corpus = nullptr; uint64_t* d_coff = nullptr; bool own_corpus = false;
+  uint64_t own_corpus_cap = 0, own_coff_cap = 0;         // capacity of the owned buffers: eh_corpus_upload reuses them when they fit
   uint64_t n_corpus = 0, corpus_bytes = 0;
   std::vector<uint64_t> h_coff;  // host copy of offsets (for totals)
   // slots
@@ -1184,13 +1185,25 @@ int eh_corpus_upload(eh_ctx* ctx, const uint8_t* data, const uint64_t* off, uint
   if (!ctx || !off || (!data && off[n] > 0)) return EH_E_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   uint64_t nbytes = off[n];
+  HIPCHK(ctx, hipDeviceSynchronize());                       // no launch may still read the previous corpus
+  if (ctx->own_corpus && ctx->own_corpus_cap >= nbytes && ctx->own_coff_cap >= n + 1) {      // steady state of a service: no hipMalloc / hipFree
+    if (nbytes) HIPCHK(ctx, hipMemcpy(ctx->d_corpus, data, nbytes, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_coff, off, (n + 1) * 8, hipMemcpyHostToDevice));
+    ctx->h_coff.assign(off, off + n + 1);
+    ctx->n_corpus = n; ctx->corpus_bytes = nbytes;
+    return EH_OK;
+  }
   uint8_t* d = nullptr; uint64_t* doff = nullptr;
-  HIPCHK(ctx, hipMalloc(&d, nbytes ? nbytes : 16));
-  HIPCHK(ctx, hipMalloc(&doff, (n + 1) * 8));
-  if (nbytes) HIPCHK(ctx, hipMemcpy(d, data, nbytes, hipMemcpyHostToDevice));
-  HIPCHK(ctx, hipMemcpy(doff, off, (n + 1) * 8, hipMemcpyHostToDevice));
+  uint64_t cap_b = nbytes + nbytes / 2 + 4096, cap_o = n + n / 2 + 16;                         // room to grow
+  hipError_t e = hipMalloc(&d, cap_b);
+  if (e == hipSuccess) e = hipMalloc(&doff, cap_o * 8);
+  if (e == hipSuccess && nbytes) e = hipMemcpy(d, data, nbytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(doff, off, (n + 1) * 8, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { if (d) (void)hipFree(d); if (doff) (void)hipFree(doff); HIPCHK(ctx, e); }
   ctx->h_coff.assign(off, off + n + 1);
-  return set_corpus(ctx, d, doff, true, n, nbytes);
+  int rc = set_corpus(ctx, d, doff, true, n, nbytes);
+  ctx->own_corpus_cap = cap_b; ctx->own_coff_cap = cap_o;
+  return rc;
 }
 int eh_corpus_attach(eh_ctx* ctx, const void* d_data, const void* d_off, uint64_t n, uint64_t nbytes) {
   if (!ctx || !d_off) return EH_E_INVALID;
@@ -1220,7 +1233,8 @@ int eh_fuzz_calls(eh_ctx* ctx, const int64_t* seeds, uint64_t corpus_first, uint
     HIPCHK(ctx, hipMalloc(&ctx->d_seeds, n * 24));
     ctx->seeds_cap = n;
   }
-  if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->d_seeds, seeds, n * 24, hipMemcpyHostToDevice, (hipStream_t)stream));
+  // synchronous copy: the caller's `seeds` may be freed or reused as soon as this call returns
+  if (n) { HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream)); HIPCHK(ctx, hipMemcpy(ctx->d_seeds, seeds, n * 24, hipMemcpyHostToDevice)); }
   int64_t dummy[3] = {0, 0, 0};
   return launch(ctx, 1, dummy, 1, corpus_first, n, (hipStream_t)stream);
 }
@@ -1243,7 +1257,7 @@ int eh_result_device(eh_ctx* ctx, const uint8_t** d_data, const uint64_t** d_off
     unsigned long long cur = 0;
     if (ctx->ordered) HIPCHK(ctx, hipMemcpy(&cur, ctx->d_ord + ctx->last_n, 8, hipMemcpyDeviceToHost));   // bytes of the compact, case-ordered buffer
     else HIPCHK(ctx, hipMemcpy(&cur, ctx->d_counters + 1, 8, hipMemcpyDeviceToHost));                     // bump cursor of the completion-ordered arena (16-byte granules)
-    *total = cur;
+    *total = cur > ctx->out_cap ? ctx->out_cap : cur;               // the cursor runs past the arena after EH_CASE_ARENA_FULL
   }
   return EH_OK;
 }
@@ -1360,15 +1374,22 @@ int eh_selftest_movers(eh_ctx* ctx, uint8_t* buf, uint64_t buf_len, const uint32
   if (!ctx || !buf || !jobs) return EH_E_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   uint8_t* d = nullptr; uint32_t* dj = nullptr; uint32_t* de = nullptr;
-  HIPCHK(ctx, hipMalloc(&d, buf_len)); HIPCHK(ctx, hipMalloc(&dj, njobs * 20)); HIPCHK(ctx, hipMalloc(&de, njobs * 4));
-  HIPCHK(ctx, hipMemcpy(d, buf, buf_len, hipMemcpyHostToDevice));
-  HIPCHK(ctx, hipMemcpy(dj, jobs, njobs * 20, hipMemcpyHostToDevice));
-  HIPCHK(ctx, hipMemset(de, 0, njobs * 4));
-  hipLaunchKernelGGL(eh_test_copy_kernel, dim3(njobs < 256 ? njobs : 256), dim3(64), 0, 0, d, dj, njobs, de);
-  HIPCHK(ctx, hipDeviceSynchronize());
-  HIPCHK(ctx, hipMemcpy(buf, d, buf_len, hipMemcpyDeviceToHost));
-  if (eq_out) HIPCHK(ctx, hipMemcpy(eq_out, de, njobs * 4, hipMemcpyDeviceToHost));
-  (void)hipFree(d); (void)hipFree(dj); (void)hipFree(de);
+  hipError_t e = hipMalloc(&d, buf_len);
+  if (e == hipSuccess) e = hipMalloc(&dj, njobs * 20);
+  if (e == hipSuccess) e = hipMalloc(&de, njobs * 4);
+  if (e == hipSuccess) e = hipMemcpy(d, buf, buf_len, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dj, jobs, njobs * 20, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(de, 0, njobs * 4);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(eh_test_copy_kernel, dim3(njobs < 256 ? njobs : 256), dim3(64), 0, 0, d, dj, njobs, de);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(buf, d, buf_len, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && eq_out) e = hipMemcpy(eq_out, de, njobs * 4, hipMemcpyDeviceToHost);
+  if (d) (void)hipFree(d);
+  if (dj) (void)hipFree(dj);
+  if (de) (void)hipFree(de);
+  HIPCHK(ctx, e);
   return EH_OK;
 }
 int eh_last_kernel_ms(eh_ctx* ctx, float* ms) {

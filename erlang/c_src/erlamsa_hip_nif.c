@@ -1,12 +1,17 @@
 /* erlamsa_hip_nif.c — Erlang NIF shim over the C ABI of liberlamsa_hip.so (include/erlamsa_hip.h).
  *
- * NOT compiled in this repository's image (no erl_nif.h here); build on a host with OTP:
+ * Build on a host with OTP (this repository only compile-checks it against tests/stubs/erl_nif.h):
  *   cc -O2 -fPIC -shared -I$ERL_ROOT/usr/include -I../../include erlamsa_hip_nif.c \
  *      -L../../erlamsa_amd -lerlamsa_hip -o ../priv/erlamsa_hip_nif.so
  *
- * Exposes erlamsa_hip:fuzz_batch_nif(Opts :: map(), Seed :: {A,B,C}, FirstCase, [binary()])
- *   -> {ok, [{Status :: 0..5, binary()}]} | {error, Reason}   (status: enum eh_case_status)
- * It runs on a dirty I/O scheduler: one call = one GPU batch.
+ *   open(Device)                                             -> {ok, Ctx} | {error, Reason}
+ *   fuzz_batch_nif(Ctx, Opts, {A,B,C}, FirstCase, [binary()]) -> {ok, [{Status, binary()}]} | {error, Reason}
+ *       one erlamsa_main:fuzzer/1 run, case I of the list = iteration FirstCase+I-1           (eh_fuzz_batch)
+ *   fuzz_calls_nif(Ctx, Opts, [{A,B,C}], [binary()])          -> {ok, [{Status, binary()}]} | {error, Reason}
+ *       case I is its own fuzzer/1 run with n = 1 and the I-th seed: erlamsa_app:fuzz/2      (eh_fuzz_calls)
+ *   Status: enum eh_case_status.  Both run on a dirty I/O scheduler: one call = one GPU batch.
+ *
+ * A context remembers the options it was last configured with: eh_configure runs again only when they change.
  */
 #include <erl_nif.h>
 #include <stdint.h>
@@ -15,9 +20,21 @@
 
 #include "erlamsa_hip.h"
 
+#define OPT_STR 1024
+typedef struct {
+  char muts[OPT_STR], pats[256], host[64];
+  int has_muts, has_pats, has_host, port;
+  double blockscale;
+  uint64_t max_case_bytes, big_case_bytes, max_case_work;
+} opt_key;
+
 static ErlNifResourceType* ctx_type;
-typedef struct { eh_ctx* ctx; } ctx_res;
-static void ctx_dtor(ErlNifEnv* env, void* obj) { (void)env; ctx_res* r = obj; if (r->ctx) eh_destroy(r->ctx); }
+typedef struct { eh_ctx* ctx; ErlNifMutex* lock; int configured; opt_key key; } ctx_res;
+static void ctx_dtor(ErlNifEnv* env, void* obj) {
+  (void)env; ctx_res* r = obj;
+  if (r->ctx) eh_destroy(r->ctx);
+  if (r->lock) enif_mutex_destroy(r->lock);
+}
 
 static int load(ErlNifEnv* env, void** priv, ERL_NIF_TERM info) {
   (void)priv; (void)info;
@@ -25,7 +42,9 @@ static int load(ErlNifEnv* env, void** priv, ERL_NIF_TERM info) {
   return ctx_type ? 0 : 1;
 }
 
+static ERL_NIF_TERM mk_err_atom(ErlNifEnv* env, const char* a) { return enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_atom(env, a)); }
 static ERL_NIF_TERM mk_error(ErlNifEnv* env, eh_ctx* c, int rc) {
+  if (rc == EH_E_NOMEM) return mk_err_atom(env, "enomem");
   const char* msg = c ? eh_last_error(c) : eh_strerror(rc);
   return enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_string(env, msg && *msg ? msg : eh_strerror(rc), ERL_NIF_LATIN1));
 }
@@ -36,74 +55,136 @@ static ERL_NIF_TERM nif_open(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]
   if (!enif_get_int(env, argv[0], &dev)) return enif_make_badarg(env);
   eh_ctx* c = NULL; int rc = eh_create(dev, &c);
   if (rc) return mk_error(env, NULL, rc);
-  ctx_res* r = enif_alloc_resource(ctx_type, sizeof(*r)); r->ctx = c;
+  ctx_res* r = enif_alloc_resource(ctx_type, sizeof(*r));
+  if (!r) { eh_destroy(c); return mk_err_atom(env, "enomem"); }
+  memset(r, 0, sizeof(*r));
+  r->ctx = c; r->lock = enif_mutex_create((char*)"erlamsa_hip_ctx");
+  if (!r->lock) { enif_release_resource(r); return mk_err_atom(env, "enomem"); }
   ERL_NIF_TERM t = enif_make_resource(env, r); enif_release_resource(r);
   return enif_make_tuple2(env, enif_make_atom(env, "ok"), t);
 }
 
+/* 1 = present and read, 0 = key absent, -1 = present but not a string that fits */
 static int get_str(ErlNifEnv* env, ERL_NIF_TERM map, const char* key, char* buf, unsigned n) {
   ERL_NIF_TERM v;
   if (!enif_get_map_value(env, map, enif_make_atom(env, key), &v)) return 0;
-  return enif_get_string(env, v, buf, n, ERL_NIF_LATIN1) > 0;
+  return enif_get_string(env, v, buf, n, ERL_NIF_LATIN1) > 0 ? 1 : -1;
+}
+static int get_u64(ErlNifEnv* env, ERL_NIF_TERM map, const char* key, uint64_t* out) {
+  ERL_NIF_TERM v; ErlNifUInt64 u;
+  if (!enif_get_map_value(env, map, enif_make_atom(env, key), &v)) return 0;
+  if (!enif_get_uint64(env, v, &u)) return -1;
+  *out = u; return 1;
 }
 
-/* fuzz_batch_nif(Ctx, Opts, {A,B,C}, FirstCase, [binary()]) */
-static ERL_NIF_TERM nif_fuzz_batch(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  (void)argc;
-  ctx_res* r; const ERL_NIF_TERM* st; int arity; ErlNifUInt64 first; unsigned n;
-  if (!enif_get_resource(env, argv[0], ctx_type, (void**)&r) || !enif_is_map(env, argv[1]) ||
-      !enif_get_tuple(env, argv[2], &arity, &st) || arity != 3 || !enif_get_uint64(env, argv[3], &first) ||
-      !enif_get_list_length(env, argv[4], &n))
-    return enif_make_badarg(env);
-  ErlNifSInt64 seed[3];
-  for (int i = 0; i < 3; i++) if (!enif_get_int64(env, st[i], &seed[i])) return enif_make_badarg(env);
+/* Opts: the strings erlamsa_mutations:tostring/1 / erlamsa_patterns:tostring/1 produce, plus the engine limits.
+ * An option of the wrong type or an over-long string is a badarg, never a silent fall-back to the default. */
+static int read_opts(ErlNifEnv* env, ERL_NIF_TERM map, opt_key* k) {
+  ERL_NIF_TERM v; int rc;
+  memset(k, 0, sizeof(*k)); k->blockscale = 1.0;
+  if ((rc = get_str(env, map, "mutations", k->muts, sizeof(k->muts))) < 0) return 0;
+  k->has_muts = rc;
+  if ((rc = get_str(env, map, "patterns", k->pats, sizeof(k->pats))) < 0) return 0;
+  k->has_pats = rc;
+  if ((rc = get_str(env, map, "ssrf_host", k->host, sizeof(k->host))) < 0) return 0;
+  k->has_host = rc;
+  if (enif_get_map_value(env, map, enif_make_atom(env, "ssrf_port"), &v) && !enif_get_int(env, v, &k->port)) return 0;
+  if (enif_get_map_value(env, map, enif_make_atom(env, "blockscale"), &v) && !enif_get_double(env, v, &k->blockscale)) return 0;
+  if (get_u64(env, map, "max_case_bytes", &k->max_case_bytes) < 0) return 0;
+  if (get_u64(env, map, "big_case_bytes", &k->big_case_bytes) < 0) return 0;
+  if (get_u64(env, map, "max_case_work", &k->max_case_work) < 0) return 0;
+  return 1;
+}
 
-  /* options: the strings erlamsa_mutations:tostring/1 / erlamsa_patterns:tostring/1 produce */
-  char muts[1024], pats[256], host[64]; double bs = 1.0; int port = 0; ERL_NIF_TERM v;
+static int configure_if_changed(ctx_res* r, const opt_key* k) {
+  if (r->configured && memcmp(&r->key, k, sizeof(*k)) == 0) return EH_OK;
   eh_options o; memset(&o, 0, sizeof(o)); o.abi_version = EH_ABI_VERSION;
-  if (get_str(env, argv[1], "mutations", muts, sizeof(muts))) o.mutations = muts;
-  if (get_str(env, argv[1], "patterns", pats, sizeof(pats))) o.patterns = pats;
-  if (get_str(env, argv[1], "ssrf_host", host, sizeof(host))) o.ssrf_host = host;
-  if (enif_get_map_value(env, argv[1], enif_make_atom(env, "ssrf_port"), &v)) enif_get_int(env, v, &port);
-  if (enif_get_map_value(env, argv[1], enif_make_atom(env, "blockscale"), &v)) enif_get_double(env, v, &bs);
-  ErlNifUInt64 u64;
-  if (enif_get_map_value(env, argv[1], enif_make_atom(env, "max_case_bytes"), &v) && enif_get_uint64(env, v, &u64)) o.max_case_bytes = u64;
-  if (enif_get_map_value(env, argv[1], enif_make_atom(env, "max_case_work"), &v) && enif_get_uint64(env, v, &u64)) o.max_case_work = u64;
-  o.ssrf_port = port; o.blockscale = bs;
+  o.mutations = k->has_muts ? k->muts : NULL;        /* NULL = the reference's default table */
+  o.patterns = k->has_pats ? k->pats : NULL;
+  o.ssrf_host = k->has_host ? k->host : NULL;
+  o.ssrf_port = k->port; o.blockscale = k->blockscale;
+  o.max_case_bytes = k->max_case_bytes; o.big_case_bytes = k->big_case_bytes; o.max_case_work = k->max_case_work;
   int rc = eh_configure(r->ctx, &o);
-  if (rc) return mk_error(env, r->ctx, rc);
-
-  /* pack the inputs: binaries are read-only and not retained past the call */
-  uint64_t* off = malloc((n + 1) * sizeof(uint64_t)); uint64_t total = 0; unsigned i = 0;
-  ERL_NIF_TERM list = argv[4], head; ErlNifBinary b;
-  for (ERL_NIF_TERM l = list; enif_get_list_cell(env, l, &head, &l); i++) {
-    if (!enif_inspect_binary(env, head, &b)) { free(off); return enif_make_badarg(env); }
-    off[i] = total; total += b.size;
-  }
-  off[n] = total;
-  uint8_t* data = malloc(total ? total : 1); i = 0;
-  for (ERL_NIF_TERM l = list; enif_get_list_cell(env, l, &head, &l); i++) { enif_inspect_binary(env, head, &b); memcpy(data + off[i], b.data, b.size); }
-  rc = eh_corpus_upload(r->ctx, data, off, n);
-  if (!rc) rc = eh_fuzz_batch(r->ctx, (const int64_t*)seed, first, 0, n, NULL);
-  free(data);
-  uint64_t in_b, out_b, nc;
-  if (!rc) rc = eh_result_totals(r->ctx, &in_b, &out_b, &nc);
-  if (rc) { free(off); return mk_error(env, r->ctx, rc); }
-  uint8_t* out = malloc(out_b ? out_b : 1); int32_t* status = malloc(n * sizeof(int32_t) + 4);
-  rc = eh_result_download(r->ctx, out, out_b, off, status);
-  if (rc) { free(out); free(off); free(status); return mk_error(env, r->ctx, rc); }
-  ERL_NIF_TERM res = enif_make_list(env, 0);
-  for (unsigned k = n; k-- > 0;) {
-    ERL_NIF_TERM bin; unsigned char* p = enif_make_new_binary(env, off[k + 1] - off[k], &bin);
-    memcpy(p, out + off[k], off[k + 1] - off[k]);
-    res = enif_make_list_cell(env, enif_make_tuple2(env, enif_make_int(env, status[k]), bin), res);
-  }
-  free(out); free(off); free(status);
-  return enif_make_tuple2(env, enif_make_atom(env, "ok"), res);
+  r->configured = rc == EH_OK;
+  if (rc == EH_OK) r->key = *k;
+  return rc;
 }
+
+/* mode 0: argv = Ctx, Opts, Seed, FirstCase, Bins;  mode 1: argv = Ctx, Opts, Seeds, Bins */
+static ERL_NIF_TERM run(ErlNifEnv* env, const ERL_NIF_TERM argv[], int mode) {
+  ctx_res* r; unsigned n = 0, ns = 0; ErlNifUInt64 first = 1; opt_key k;
+  ERL_NIF_TERM bins = argv[mode == 0 ? 4 : 3];
+  if (!enif_get_resource(env, argv[0], ctx_type, (void**)&r) || !enif_is_map(env, argv[1]) || !enif_get_list_length(env, bins, &n))
+    return enif_make_badarg(env);
+  if (!read_opts(env, argv[1], &k)) return enif_make_badarg(env);
+  ErlNifSInt64 seed[3] = {0, 0, 0};
+  int64_t* seeds = NULL; uint64_t* off = NULL; uint8_t* data = NULL; uint8_t* out = NULL; int32_t* status = NULL;
+  ERL_NIF_TERM ret;
+  if (mode == 0) {
+    const ERL_NIF_TERM* st; int arity;
+    if (!enif_get_tuple(env, argv[2], &arity, &st) || arity != 3 || !enif_get_uint64(env, argv[3], &first) || first < 1) return enif_make_badarg(env);
+    for (int i = 0; i < 3; i++) if (!enif_get_int64(env, st[i], &seed[i])) return enif_make_badarg(env);
+  } else {
+    if (!enif_get_list_length(env, argv[2], &ns) || ns != n) return enif_make_badarg(env);
+    seeds = malloc((size_t)(n ? n : 1) * 3 * sizeof(int64_t));
+    if (!seeds) return mk_err_atom(env, "enomem");
+    ERL_NIF_TERM head; unsigned i = 0;
+    for (ERL_NIF_TERM l = argv[2]; enif_get_list_cell(env, l, &head, &l); i++) {
+      const ERL_NIF_TERM* st; int arity; ErlNifSInt64 v;
+      if (!enif_get_tuple(env, head, &arity, &st) || arity != 3) { free(seeds); return enif_make_badarg(env); }
+      for (int j = 0; j < 3; j++) { if (!enif_get_int64(env, st[j], &v)) { free(seeds); return enif_make_badarg(env); } seeds[3 * i + j] = v; }
+    }
+  }
+  /* pack the inputs: binaries are read-only and not retained past the call */
+  off = malloc(((size_t)n + 1) * sizeof(uint64_t));
+  if (!off) { ret = mk_err_atom(env, "enomem"); goto done; }
+  {
+    uint64_t total = 0; unsigned i = 0; ERL_NIF_TERM head; ErlNifBinary b;
+    for (ERL_NIF_TERM l = bins; enif_get_list_cell(env, l, &head, &l); i++) {
+      if (!enif_inspect_binary(env, head, &b)) { ret = enif_make_badarg(env); goto done; }
+      off[i] = total; total += b.size;
+    }
+    off[n] = total;
+    data = malloc(total ? total : 1);
+    if (!data) { ret = mk_err_atom(env, "enomem"); goto done; }
+    i = 0;
+    for (ERL_NIF_TERM l = bins; enif_get_list_cell(env, l, &head, &l); i++) { enif_inspect_binary(env, head, &b); memcpy(data + off[i], b.data, b.size); }
+  }
+  enif_mutex_lock(r->lock);                      /* one batch at a time per context */
+  {
+    int rc = configure_if_changed(r, &k);
+    if (!rc) rc = eh_corpus_upload(r->ctx, data, off, n);
+    if (!rc) rc = mode == 0 ? eh_fuzz_batch(r->ctx, (const int64_t*)seed, first, 0, n, NULL) : eh_fuzz_calls(r->ctx, seeds, 0, n, NULL);
+    uint64_t in_b = 0, out_b = 0, nc = 0;
+    if (!rc) rc = eh_result_totals(r->ctx, &in_b, &out_b, &nc);
+    if (!rc) {
+      out = malloc(out_b ? out_b : 1); status = malloc(((size_t)n + 1) * sizeof(int32_t));
+      if (!out || !status) rc = EH_E_NOMEM;
+    }
+    if (!rc) rc = eh_result_download(r->ctx, out, out_b, off, status);
+    if (rc) { ret = mk_error(env, r->ctx, rc); enif_mutex_unlock(r->lock); goto done; }
+  }
+  enif_mutex_unlock(r->lock);
+  ret = enif_make_list(env, 0);
+  for (unsigned i = n; i-- > 0;) {
+    ERL_NIF_TERM bin; size_t len = (size_t)(off[i + 1] - off[i]);
+    unsigned char* p = enif_make_new_binary(env, len, &bin);
+    if (!p) { ret = mk_err_atom(env, "enomem"); goto done; }
+    memcpy(p, out + off[i], len);
+    ret = enif_make_list_cell(env, enif_make_tuple2(env, enif_make_int(env, status[i]), bin), ret);
+  }
+  ret = enif_make_tuple2(env, enif_make_atom(env, "ok"), ret);
+done:
+  free(seeds); free(off); free(data); free(out); free(status);
+  return ret;
+}
+
+static ERL_NIF_TERM nif_fuzz_batch(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { (void)argc; return run(env, argv, 0); }
+static ERL_NIF_TERM nif_fuzz_calls(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { (void)argc; return run(env, argv, 1); }
 
 static ErlNifFunc funcs[] = {
   {"open", 1, nif_open, 0},
   {"fuzz_batch_nif", 5, nif_fuzz_batch, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"fuzz_calls_nif", 4, nif_fuzz_calls, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 ERL_NIF_INIT(erlamsa_hip, funcs, load, NULL, NULL, NULL)

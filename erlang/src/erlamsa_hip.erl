@@ -1,15 +1,20 @@
 %% erlamsa_hip — drop-in batch path behind erlamsa_main:fuzzer/1 / erlamsa_app:fuzz/2.
 %%
-%% fuzz_batch/2 gives the same bytes as N worker iterations of erlamsa_main:fuzzer/1
-%% (paths = [direct], workers = 1) where iteration I mutates the I-th binary.  Cases whose status
-%% is not 0 (crashed = <<>> in the reference; overflow/unsupported/arena_full = engine limits) are
-%% re-run on BEAM by the caller if it wants them.
+%% fuzz_batch/2 gives the bytes N worker iterations of erlamsa_main:fuzzer/1 (paths = [direct], workers = 1) give,
+%% iteration I mutating the I-th binary; fuzz_calls/2 gives what N separate erlamsa_app:fuzz(Bin, #{seed => S}) calls
+%% give.  Both return
+%%     {ok, Outs :: [{Index, binary()}], NotRun :: [{Index, Status}]}
+%% Outs    the cases the reference would have recorded (status 0 and a non-empty result: erlamsa_main record_result/2
+%%         drops <<>>, which is also what a crashed worker — status 1 — yields), in case order, with their positions;
+%% NotRun  the cases that stopped at an ENGINE limit the reference does not have (2 overflow of big_case_bytes,
+%%         3 unsupported, 4 output arena full, 5 work budget).  The reference would have produced output for them: the
+%%         caller re-runs them on BEAM (or with larger limits) — nothing is dropped silently.
 %%
-%% Also usable as an external module (`-e erlamsa_hip`, erlamsa_cmdparse.erl:456-470):
-%% capabilities() -> {fuzzer, external}; fuzzer(Proto, Data, Opts) routes single packets of the
-%% proxy through the GPU path (erlamsa_utils:make_fuzzer/1, erlamsa_utils.erl:221-226).
+%% Also usable as an external module (`-e erlamsa_hip`, erlamsa_cmdparse.erl:456-470): capabilities() ->
+%% {fuzzer, external}; fuzzer(Proto, Data, Opts) routes single packets of the proxy through the GPU path
+%% (erlamsa_utils:make_fuzzer/1, erlamsa_utils.erl:221-226) and falls back to the unmodified packet.
 -module(erlamsa_hip).
--export([init/0, open/1, fuzz_batch/2, fuzz_batch_nif/5, capabilities/0, fuzzer/3]).
+-export([init/0, open/1, fuzz_batch/2, fuzz_calls/2, fuzz_batch_nif/5, fuzz_calls_nif/4, capabilities/0, fuzzer/3]).
 -on_load(init/0).
 
 init() ->
@@ -18,27 +23,42 @@ init() ->
 
 open(_Device) -> erlang:nif_error(nif_not_loaded).
 fuzz_batch_nif(_Ctx, _Opts, _Seed, _FirstCase, _Bins) -> erlang:nif_error(nif_not_loaded).
+fuzz_calls_nif(_Ctx, _Opts, _Seeds, _Bins) -> erlang:nif_error(nif_not_loaded).
 
-%% Opts: the Dict of erlamsa_main:fuzzer/1 (seed, mutations, patterns, blockscale)
+%% Dict: the options map of erlamsa_main:fuzzer/1 (seed, mutations, patterns, blockscale) plus first_case / device
 fuzz_batch(Bins, Dict) ->
-    Ctx = case get(erlamsa_hip_ctx) of
-              undefined -> {ok, C} = open(maps:get(device, Dict, 0)), put(erlamsa_hip_ctx, C), C;
-              C -> C
-          end,
     Seed = maps:get(seed, Dict, erlamsa_rnd:gen_urandom_seed()),
+    split(fuzz_batch_nif(ctx(Dict), opts(Dict), Seed, maps:get(first_case, Dict, 1), Bins)).
+
+%% Calls :: [{Bin, Seed}] — one erlamsa_app:fuzz(Bin, #{seed => Seed}) each
+fuzz_calls(Calls, Dict) ->
+    {Bins, Seeds} = lists:unzip(Calls),
+    split(fuzz_calls_nif(ctx(Dict), opts(Dict), Seeds, Bins)).
+
+ctx(Dict) ->
+    case get(erlamsa_hip_ctx) of
+        undefined -> {ok, C} = open(maps:get(device, Dict, 0)), put(erlamsa_hip_ctx, C), C;
+        C -> C
+    end.
+
+opts(Dict) ->
     Mutas = maps:get(mutations, Dict, erlamsa_mutations:default([])),
     Pats = maps:get(patterns, Dict, erlamsa_patterns:default()),
     {SsrfHost, SsrfPort} = erlamsa_mutations:get_ssrf_ep(),
-    Opts = #{mutations => actions(Mutas), patterns => actions(Pats),
+    Base = #{mutations => actions(Mutas), patterns => actions(Pats),
              blockscale => float(maps:get(blockscale, Dict, 1.0)),
              ssrf_host => SsrfHost, ssrf_port => SsrfPort},
-    case fuzz_batch_nif(Ctx, Opts, Seed, maps:get(first_case, Dict, 1), Bins) of
-        {ok, Res} -> [Bin || {0, Bin} <- Res, Bin =/= <<>>];   %% record_result/2 drops <<>>
-        {error, Why} -> {error, Why}                            %% caller falls back to erlamsa_main:fuzzer/1
-    end.
+    maps:merge(Base, maps:with([max_case_bytes, big_case_bytes, max_case_work], Dict)).
+
+split({error, Why}) -> {error, Why};                             %% caller falls back to erlamsa_main:fuzzer/1
+split({ok, Res}) ->
+    Indexed = lists:zip(lists:seq(1, length(Res)), Res),
+    Outs = [{I, Bin} || {I, {0, Bin}} <- Indexed, Bin =/= <<>>],  %% record_result/2 drops <<>>
+    NotRun = [{I, St} || {I, {St, _}} <- Indexed, St >= 2],
+    {ok, Outs, NotRun}.
 
 actions(L) -> string:join([atom_to_list(N) ++ "=" ++ integer_to_list(P) || {N, P} <- L], ",").
 
 capabilities() -> {fuzzer, external}.
 fuzzer(_Proto, Data, Opts) ->
-    case fuzz_batch([Data], Opts) of [Out] -> {ok, Out}; _ -> {ok, Data} end.
+    case fuzz_batch([Data], Opts) of {ok, [{1, Out}], []} -> {ok, Out}; _ -> {ok, Data} end.

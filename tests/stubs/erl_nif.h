@@ -45,4 +45,11 @@ ERL_NIF_TERM enif_make_tuple(ErlNifEnv*, unsigned cnt, ...);
 #define enif_make_tuple2(env, a, b) enif_make_tuple(env, 2, a, b)
 #define ERL_NIF_INIT(MOD, FUNCS, LOAD, RELOAD, UPGRADE, UNLOAD) \
   const ErlNifFunc* erl_nif_stub_funcs_##MOD(void) { (void)(LOAD); return FUNCS; }
+/* erl_nif.h: thread API */
+typedef struct ErlNifMutex_ ErlNifMutex;
+ErlNifMutex* enif_mutex_create(char* name);
+void enif_mutex_destroy(ErlNifMutex* mtx);
+void enif_mutex_lock(ErlNifMutex* mtx);
+void enif_mutex_unlock(ErlNifMutex* mtx);
+
 #endif
