@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/erlamsa_hip.h"
+#include "eh_otp_sort.h"
 #include "eh_device.h"
 #include "eh_text.h"
 #include "eh_lex.h"
@@ -763,71 +764,13 @@ struct eh_ctx {
 
 namespace {
 
-// --- OTP lists:sort/2 (stdlib lists.erl fsplit_*/fmergel/rfmergel), needed because
-// erlamsa_utils:sort_by_priority/1 (erlamsa_utils.erl:113-117) passes a strict '>' as the
-// ordering fun, so the order of equal priorities is whatever that merge sort produces.
+// erlamsa_utils:sort_by_priority/1 (erlamsa_utils.erl:113-117): lists:sort/2 with a strict '>' as the ordering fun — the
+// order among equal priorities is whatever stdlib's merge sort gives (eh_otp_sort.h, the one implementation).
 struct PItem { uint32_t pri; int id; };
 typedef std::vector<PItem> PL;
-static bool gt(const PItem& a, const PItem& b) { return a.pri > b.pri; }
-static PL merge_runs(const PL& t1, const PL& l2, bool rmerge) {
-  // fmerge2_*: take from T1 while Fun(H1,H2); rfmerge2_*: take from [H2|T2] while Fun(H1,H2).
-  // Both accumulate in reverse, i.e. return reverse(merged).
-  PL m; size_t i = 0, j = 0;
-  while (i < t1.size() && j < l2.size()) {
-    bool f = gt(t1[i], l2[j]);
-    if (f != rmerge) m.push_back(t1[i++]); else m.push_back(l2[j++]);
-  }
-  while (i < t1.size()) m.push_back(t1[i++]);
-  while (j < l2.size()) m.push_back(l2[j++]);
-  return PL(m.rbegin(), m.rend());
-}
-static PL mergel(std::vector<PL> ls, bool rphase, bool asc) {
-  // alternating fmergel / rfmergel passes until one list remains
-  while (true) {
-    std::vector<PL> acc;
-    size_t k = 0;
-    for (; k + 1 < ls.size(); k += 2) {
-      // fmergel asc: (T1=ls[k], L2=ls[k+1]); fmergel desc: (T1=ls[k+1], L2=ls[k]);
-      // rfmergel asc: (T1=ls[k+1], L2=ls[k]); rfmergel desc: (T1=ls[k], L2=ls[k+1]).
-      bool first_is_t1 = (asc != rphase);
-      const PL& t1 = first_is_t1 ? ls[k] : ls[k + 1];
-      const PL& l2 = first_is_t1 ? ls[k + 1] : ls[k];
-      acc.insert(acc.begin(), merge_runs(t1, l2, rphase));
-    }
-    if (k < ls.size()) {
-      if (!rphase && acc.empty()) return ls[k];           // fmergel([L], [], ..) -> L
-      acc.insert(acc.begin(), PL(ls[k].rbegin(), ls[k].rend()));
-    }
-    ls.swap(acc);
-    rphase = !rphase;
-  }
-}
 static PL otp_sort_desc_strict(const PL& in) {
-  if (in.size() < 2) return in;
-  std::vector<PL> rs;
-  PItem x = in[0], y = in[1];
-  bool asc = gt(x, y);
-  auto step = [&](const PItem& a, const PItem& b) { return asc ? gt(a, b) : !gt(a, b); };
-  PL r; bool have_s = false; PItem s{};
-  for (size_t pos = 2; pos < in.size(); pos++) {
-    PItem z = in[pos];
-    if (step(y, z)) { r.insert(r.begin(), x); x = y; y = z; }
-    else if (step(x, z)) { r.insert(r.begin(), x); x = z; }
-    else if (!have_s && r.empty()) r.push_back(z);
-    else if (!have_s) { have_s = true; s = z; }
-    else {
-      PL run{y, x}; run.insert(run.end(), r.begin(), r.end());
-      rs.insert(rs.begin(), run); r.clear();
-      if (step(s, z)) { y = z; x = s; } else { y = s; x = z; }
-      have_s = false;
-    }
-  }
-  PL run{y, x}; run.insert(run.end(), r.begin(), r.end());
-  std::vector<PL> all;
-  if (have_s) all.push_back(PL{s});
-  all.push_back(run);
-  all.insert(all.end(), rs.begin(), rs.end());
-  return mergel(all, /*rphase=*/asc, asc);
+  otp::ListsSort<PItem> srt([](const PItem& a, const PItem& b) { return a.pri > b.pri; });
+  return srt.sort(in);
 }
 
 static int lookup(const char* name, bool muta) {
