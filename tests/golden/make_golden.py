@@ -5,9 +5,9 @@ IMPORTANT: the reference (Erlang) cannot run on this image, so these vectors are
 CPU oracle (oracle/), not by erlamsa itself.  They pin the oracle against regressions and give the
 GPU tests a fixture that does not need the oracle at run time.  Format per vector:
   {seed, first_case, mutations, patterns, inputs_hex[], outputs_hex[], status[]}
-When an Erlang host is available, the same format can be filled from
-  erlamsa_main:fuzzer(#{paths=>[direct], input=>Bin, output=>return, seed=>S, mutations=>M, patterns=>P, n=>N})
-and dropped in here to pin oracle-vs-BEAM parity ("Oracle").
+When an Erlang host is available, tests/golden/capture.escript runs the real erlamsa_main:fuzzer/1 over the same inputs
+(vectors.eterm, written here too) and tests/golden/apply_beam_capture.py rewrites vectors.json from its output: that pins
+oracle-vs-BEAM parity ("Oracle").  `generator` in the file says which of the two produced it.
 """
 import json
 import os
@@ -57,6 +57,13 @@ def main():
                      "inputs_hex": [b.hex() for b in inputs], "outputs_hex": [o.hex() for o in outs], "status": [int(x) for x in st]})
     with open(os.path.join(HERE, "vectors.json"), "w") as f:
         json.dump({"generator": "oracle (C++ restatement) — NOT a BEAM run", "vectors": vecs}, f, indent=0)
+    # the same inputs as Erlang terms for tests/golden/capture.escript (file:consult/1)
+    def term(v):
+        q = lambda x: "default" if x is None else '"%s"' % x
+        return '{"%s", {%d,%d,%d}, %d, %s, %s, [%s]}' % (v["name"], *v["seed"], v["first_case"], q(v["mutations"]), q(v["patterns"]),
+                                                         ", ".join('"%s"' % h for h in v["inputs_hex"]))
+    with open(os.path.join(HERE, "vectors.eterm"), "w") as f:
+        f.write("[\n" + ",\n".join(term(v) for v in vecs) + "\n].\n")
     print("wrote", len(vecs), "vector sets")
 
 

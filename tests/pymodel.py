@@ -1,0 +1,606 @@
+"""An independent Python model of a subset of erlamsa_main:fuzzer/1, written from the reference's .erl sources (cited per
+function) WITHOUT consulting oracle/oracle.cpp: paths = [direct], generators direct + random, patterns od / nd / bu, and
+the mutators bd bei bed bf bi ber br sp sr sd ld num.  tests/test_pymodel.py diffs it against the C++ oracle.
+
+Everything is a literal, clause-by-clause transcription — Erlang lists are Python lists, binaries are bytes, lazy
+stream tails are forced in the order erlamsa_out:blocks_port forces them.  OTP pieces (random, lists:sort/2) are
+restated from the OTP sources as the author remembers them (there is no OTP in this image): they are the part of
+"parity" that only a real BEAM run can pin (tests/golden/capture.escript).
+"""
+import math
+import sys
+
+if hasattr(sys, "set_int_max_str_digits"):
+    sys.set_int_max_str_digits(0)            # numbers grow to 10^5 digits under sr
+
+class ErlCrash(Exception):
+    """the worker process dies: fuzzer/1 times out on it and records <<>>"""
+
+
+# ------------------------------------------------------------------------------------------------ OTP random (AS183)
+P1, P2, P3 = 30269, 30307, 30323
+
+
+class Random:
+    """OTP stdlib random.erl: seed/3, uniform/0, uniform/1 (process dictionary state)."""
+
+    def __init__(self):
+        self.s = (3172, 9814, 20125)           # random:seed0()
+        self.draws = 0
+
+    def seed(self, t):                          # random:seed({A1,A2,A3}) -> seed/3
+        a1, a2, a3 = t
+        self.s = (abs(a1) % (P1 - 1) + 1, abs(a2) % (P2 - 1) + 1, abs(a3) % (P3 - 1) + 1)
+
+    def uniform(self):
+        a1, a2, a3 = self.s
+        b1, b2, b3 = (a1 * 171) % P1, (a2 * 172) % P2, (a3 * 170) % P3
+        self.s = (b1, b2, b3)
+        self.draws += 1
+        r = b1 / P1 + b2 / P2 + b3 / P3
+        return r - math.trunc(r)
+
+    def uniform_n(self, n):                     # uniform(N) -> trunc(uniform() * N) + 1
+        u = self.uniform()
+        try:
+            return math.trunc(u * n) + 1
+        except OverflowError:                   # a bignum beyond the float range: badarith, the worker dies
+            raise ErlCrash("badarith: float * bignum")
+
+
+# ------------------------------------------------------------------------------------------------ OTP lists:sort/2
+def lists_sort(fun, lst):
+    """stdlib lists.erl sort/2 with its fsplit_* / fmergel / rfmergel / fmerge2_* / rfmerge2_* helpers, one Python
+    function per Erlang function, one branch per clause.  Lists are Python lists with the head at index 0."""
+    if len(lst) < 2:
+        return list(lst)
+    x, y, t = lst[0], lst[1], lst[2:]
+    if fun(x, y):
+        return _fsplit_1(y, x, fun, t, [], [])
+    return _fsplit_2(y, x, fun, t, [], [])
+
+
+def _fsplit_1(y, x, fun, l, r, rs):
+    s, in_x1 = None, False                      # in_x1: we are in fsplit_1_1 with S
+    while True:
+        if not l:
+            if in_x1:
+                return _rfmergel([[s], [y, x] + r] + rs, [], fun, "asc")
+            return _rfmergel([[y, x] + r] + rs, [], fun, "asc")
+        z, l = l[0], l[1:]
+        if fun(y, z):
+            y, x, r = z, y, [x] + r
+        elif fun(x, z):
+            x, r = z, [x] + r                   # fsplit_1(Y, Z, Fun, L, [X | R], Rs)
+        elif not in_x1 and r == []:
+            r = [z]                             # fsplit_1(Y, X, Fun, L, [Z], Rs)
+        elif not in_x1:
+            s, in_x1 = z, True                  # fsplit_1_1(Y, X, Fun, L, R, Rs, Z)
+        else:
+            rs = [[y, x] + r] + rs
+            if fun(s, z):
+                y, x = z, s                     # fsplit_1(Z, S, Fun, L, [], [[Y, X | R] | Rs])
+            else:
+                y, x = s, z                     # fsplit_1(S, Z, ...)
+            r, s, in_x1 = [], None, False
+
+
+def _fsplit_2(y, x, fun, l, r, rs):
+    s, in_x1 = None, False
+    while True:
+        if not l:
+            if in_x1:
+                return _fmergel([[s], [y, x] + r] + rs, [], fun, "desc")
+            return _fmergel([[y, x] + r] + rs, [], fun, "desc")
+        z, l = l[0], l[1:]
+        if not fun(y, z):
+            y, x, r = z, y, [x] + r
+        elif not fun(x, z):
+            x, r = z, [x] + r
+        elif not in_x1 and r == []:
+            r = [z]
+        elif not in_x1:
+            s, in_x1 = z, True
+        else:
+            rs = [[y, x] + r] + rs
+            if not fun(s, z):
+                y, x = z, s
+            else:
+                y, x = s, z
+            r, s, in_x1 = [], None, False
+
+
+def _fmergel(ls, acc, fun, o):
+    while True:
+        if len(ls) >= 2 and o == "asc":          # fmergel([T1, [H2 | T2] | L], Acc, Fun, asc)
+            t1, l2, ls = ls[0], ls[1], ls[2:]
+            acc = [_fmerge2_1(t1, l2[0], fun, l2[1:], [])] + acc
+        elif len(ls) >= 2:                       # fmergel([[H2 | T2], T1 | L], Acc, Fun, desc)
+            l2, t1, ls = ls[0], ls[1], ls[2:]
+            acc = [_fmerge2_1(t1, l2[0], fun, l2[1:], [])] + acc
+        elif len(ls) == 1 and acc == []:
+            return ls[0]
+        elif len(ls) == 1:
+            return _rfmergel([ls[0][::-1]] + acc, [], fun, o)
+        else:
+            return _rfmergel(acc, [], fun, o)
+
+
+def _rfmergel(ls, acc, fun, o):
+    while True:
+        if len(ls) >= 2 and o == "asc":          # rfmergel([[H2 | T2], T1 | L], Acc, Fun, asc)
+            l2, t1, ls = ls[0], ls[1], ls[2:]
+            acc = [_rfmerge2_1(t1, l2[0], fun, l2[1:], [])] + acc
+        elif len(ls) >= 2:                       # rfmergel([T1, [H2 | T2] | L], Acc, Fun, desc)
+            t1, l2, ls = ls[0], ls[1], ls[2:]
+            acc = [_rfmerge2_1(t1, l2[0], fun, l2[1:], [])] + acc
+        elif len(ls) == 1:
+            return _fmergel([ls[0][::-1]] + acc, [], fun, o)
+        else:
+            return _fmergel(acc, [], fun, o)
+
+
+def _fmerge2_1(t1, h2, fun, t2, m):
+    # fmerge2_1 / fmerge2_2 as one loop; m is the Erlang accumulator M (head at index 0)
+    state, h1 = 1, None
+    while True:
+        if state == 1:
+            if not t1:
+                return t2[::-1] + [h2] + m       # lists:reverse(T2, [H2 | M])
+            h1, t1 = t1[0], t1[1:]
+            if fun(h1, h2):
+                m = [h1] + m
+            else:
+                m, state = [h2] + m, 2
+        else:
+            if not t2:
+                return t1[::-1] + [h1] + m       # lists:reverse(T1, [H1 | M])
+            h2, t2 = t2[0], t2[1:]
+            if fun(h1, h2):
+                m, state = [h1] + m, 1
+            else:
+                m = [h2] + m
+
+
+def _rfmerge2_1(t1, h2, fun, t2, m):
+    state, h1 = 1, None
+    while True:
+        if state == 1:
+            if not t1:
+                return t2[::-1] + [h2] + m
+            h1, t1 = t1[0], t1[1:]
+            if fun(h1, h2):
+                m, state = [h2] + m, 2           # rfmerge2_2(H1, T1, Fun, T2, [H2 | M])
+            else:
+                m = [h1] + m
+        else:
+            if not t2:
+                return t1[::-1] + [h1] + m
+            h2, t2 = t2[0], t2[1:]
+            if fun(h1, h2):
+                m = [h2] + m
+            else:
+                m, state = [h1] + m, 1           # rfmerge2_1(T1, H2, Fun, T2, [H1 | M])
+
+
+# ------------------------------------------------------------------------------------------------ erlamsa_rnd.erl
+class Rnd:
+    def __init__(self):
+        self.r = Random()
+
+    def seed(self, t):
+        self.r.seed(t)                                                     # :65
+
+    def rand(self, n):
+        return 0 if n == 0 else self.r.uniform_n(n) - 1                    # :69-70
+
+    def erand(self, n):
+        return 0 if n == 0 else self.r.uniform_n(n)                        # :73-74
+
+    def rand_range(self, l, r):                                            # :78-83
+        if r > l:
+            return self.rand(r - l) + l
+        return l if r == l else 0
+
+    def rand_bit(self):
+        return int(math.floor(self.r.uniform() + 0.5))                     # round(random:uniform()) :95
+
+    def rand_occurs_fixed(self, nom, denom):                               # :111-118
+        n = self.rand(denom)
+        return n != 0 if nom == 1 else n < nom
+
+    def rand_nbit(self, n):                                                # :122-125
+        if n == 0:
+            return 0
+        hi = 1 << (n - 1)
+        return hi | self.rand(hi)
+
+    def rand_log(self, n):
+        return 0 if n == 0 else self.rand_nbit(self.rand(n))               # :128-130
+
+    def rand_elem(self, l):
+        return [] if not l else l[self.r.uniform_n(len(l)) - 1]            # :133-136
+
+    def random_numbers(self, bound, cnt):                                  # :163-169: built by prepending
+        acc = []
+        for _ in range(cnt):
+            acc.insert(0, self.rand(bound))
+        return acc
+
+    def random_block(self, n):
+        return bytes(self.random_numbers(256, n))                          # :154-161 (same shape)
+
+    def random_permutation(self, l):                                       # :172-178
+        if len(l) == 2:
+            return [l[1], l[0]] if self.rand(2) == 1 else l
+        return [y for _, y in sorted(((self.r.uniform(), x) for x in l))]   # lists:sort/1 of {float, X}
+
+    def rand_delta(self):
+        return 1 if self.rand_bit() == 0 else -1                           # :199-206
+
+    def gen_predictable_seed(self):
+        return (self.erand(99999), self.erand(99999), self.erand(99999))   # :57
+
+
+AVG_BLOCK_SIZE, MIN_BLOCK_SIZE = 2048, 256
+MAX_BLOCK_SIZE = 2 * AVG_BLOCK_SIZE
+ABSMAX_BINARY_BLOCK = 1000000
+MIN_SCORE, MAX_SCORE = 2.0, 10.0
+
+
+# ------------------------------------------------------------------------------------------------ erlamsa_utils.erl
+def sort_by_priority(l):                                                   # :113-117
+    sl = lists_sort(lambda a, b: a[0] > b[0], l)
+    return sl, sum(a for a, _ in sl)
+
+
+def choose_pri(l, n):                                                      # :154-160
+    for this, el in l:
+        if n == 0 or n < this:
+            return el
+        n -= this
+    raise ErlCrash("choose_pri: function_clause")
+
+
+def binarish(b):                                                           # :237-247
+    for p in range(len(b) + 1):
+        rest = b[p:]
+        if rest[:3] == b"\xef\xbb\xbf" or rest[:2] == b"\xfe\x0f":
+            return False
+        if p == 8 or not rest:
+            return False
+        if rest[0] == 0 or rest[0] & 128:
+            return True
+    return False
+
+
+def flush_bvecs(b, tail):                                                  # :168-175
+    out = []
+    while len(b) >= AVG_BLOCK_SIZE:
+        out.append(b[:AVG_BLOCK_SIZE])
+        b = b[AVG_BLOCK_SIZE:]
+    return out + [b] + tail
+
+
+# ------------------------------------------------------------------------------------------------ erlamsa_mutations.erl
+def interesting_numbers():                                                 # :65-73 (foldl prepends)
+    acc = []
+    for i in [1, 7, 8, 15, 16, 31, 32, 63, 64, 127, 128]:
+        x = 1 << i
+        acc = [x - 1, x, x + 1] + acc
+    return acc
+
+
+def mutate_num(rnd, num):                                                  # :91-112
+    n = rnd.rand(12)
+    if n == 0:
+        return num + 1
+    if n == 1:
+        return num - 1
+    if n == 2:
+        return 0
+    if n == 3:
+        return 1
+    if 3 < n < 6:
+        return rnd.rand_elem(interesting_numbers())
+    if n == 7:
+        return num + rnd.rand_elem(interesting_numbers())
+    if n == 8:
+        return num - rnd.rand_elem(interesting_numbers())
+    if n == 9:
+        return num - rnd.rand(abs(num) * 2) * (1 if num >= 0 else -1)
+    if n == 10:
+        return -num
+    k = rnd.rand_range(1, 129)
+    l = rnd.rand_log(k)
+    s = rnd.rand(3)
+    return num - l if s == 0 else num + l
+
+
+def get_num(b, pos):                                                       # :114-125 -> (value | None, position after)
+    sign = 1
+    while pos < len(b) and b[pos] == 45:                                   # '-' while no digit has been read
+        sign, pos = -1, pos + 1
+    e = pos
+    while e < len(b) and 48 <= b[e] <= 57:
+        e += 1
+    if e == pos:
+        return None, pos
+    return int(b[pos:e]) * sign, e                                         # D - 48 + N * 10 per digit
+
+
+def sed_num(rnd, ll):                                                      # :131-170
+    h, t = ll[0], ll[1:]
+    found, pos = [], 0
+    while pos < len(h):                                                    # mutate_a_num/2 on the way down
+        val, after = get_num(h, pos)
+        if val is not None:
+            found.append((pos, after, val))
+            pos = after
+        else:
+            pos += 1
+    which = rnd.rand(len(found))                                           # mutate_a_num(<<>>, NFound)
+    if found:
+        s, e, val = found[len(found) - 1 - which]                          # Which counts back from the last number
+        new = mutate_num(rnd, val)
+        lst = h[:s] + str(new).encode() + h[e:]
+        n = -1
+    else:
+        lst, n = h, 0
+    isbin = binarish(lst)
+    flushed = flush_bvecs(lst, t)
+    if n == 0:
+        return flushed, (-1 if rnd.rand(10) == 0 else 0)
+    return flushed, (-1 if isbin else 2)
+
+
+def sed_byte(rnd, ll, f):                                                  # construct_sed_byte_muta :179-185
+    h, t = ll[0], ll[1:]
+    p = rnd.rand(len(h))
+    d = rnd.rand_delta()
+    if h == b"":                                                           # edit_byte_vector(<<>>, ..) :57
+        return [h] + t, d
+    return [h[:p] + f(h[p]) + h[p + 1:]] + t, d
+
+
+def sed_bytes(rnd, ll, f):                                                 # construct_sed_bytes_muta :239-258
+    bvec, btail = ll[0], ll[1:]
+    if bvec == b"":
+        return ll, -1
+    bsize = len(bvec)
+    s = rnd.rand(bsize)
+    l = rnd.rand_range(1, bsize - s + 1)
+    c = f(bvec[:s], bvec[s:s + l], bvec[s + l:], btail)
+    d = rnd.rand_delta()
+    return c, d
+
+
+def lines(b):                                                              # :326-331
+    out, buff = [], []
+    for ch in b:
+        buff.append(ch)
+        if ch == 10:
+            out.append(buff)
+            buff = []
+    if buff:
+        out.append(buff)
+    return out
+
+
+def line_muta(rnd, ll, op):                                                # construct_line_muta :351-362
+    h, t = ll[0], ll[1:]
+    ls = lines(h)
+    if ls == [] or binarish(h):                                            # try_lines :341-348
+        return ll, -1
+    mls = op(ls, len(ls))
+    return [b"".join(bytes(x) for x in mls)] + t, 1
+
+
+def list_del(rnd, l, length):                                              # erlamsa_generic.erl:54-57
+    p = rnd.erand(length)
+    return l[:p - 1] + l[p:]
+
+
+def make_table(rnd):
+    """mutation functions by name; each: ll -> (ll', delta)"""
+    def sr(h, bs, t, btail):                                               # construct_sed_bytes_repeat :273-281
+        n = max(2, rnd.rand_log(10))
+        return [h + bs * n + t] + btail
+
+    return {
+        "num": lambda ll: sed_num(rnd, ll),
+        "bd": lambda ll: sed_byte(rnd, ll, lambda b: b""),
+        "bei": lambda ll: sed_byte(rnd, ll, lambda b: bytes([(b + 1) & 255])),
+        "bed": lambda ll: sed_byte(rnd, ll, lambda b: bytes([(b - 1) & 255])),
+        "bf": lambda ll: sed_byte(rnd, ll, lambda b: bytes([b ^ (1 << rnd.rand(8))])),
+        "bi": lambda ll: sed_byte(rnd, ll, lambda b: bytes([rnd.rand(256), b])),
+        "ber": lambda ll: sed_byte(rnd, ll, lambda b: bytes([rnd.rand(256)])),
+        "br": lambda ll: sed_byte(rnd, ll, lambda b: bytes([b, b])),
+        "sp": lambda ll: sed_bytes(rnd, ll, lambda h, bs, t, bt: [h + bytes(rnd.random_permutation(list(bs))) + t] + bt),
+        "sr": lambda ll: sed_bytes(rnd, ll, sr),
+        "sd": lambda ll: sed_bytes(rnd, ll, lambda h, bs, t, bt: [h + t] + bt),
+        "ld": lambda ll: line_muta(rnd, ll, lambda ls, n: list_del(rnd, ls, n)),
+    }
+
+
+# table order of mutations/1 (:1290-1331), restricted to what this model implements
+TABLE_ORDER = ["num", "bd", "bei", "bed", "bf", "bi", "ber", "br", "sp", "sr", "sd", "ld"]
+DEFAULT_PRI = {"num": 3}
+
+
+def adjust_priority(pri, delta):                                           # :1240-1242
+    return pri if delta == 0 else max(MIN_SCORE, min(MAX_SCORE, pri + delta))
+
+
+def weighted_permutations(rnd, pris):                                      # :1246-1250
+    ppris = [(rnd.rand(math.trunc(s * p)), (s, p, name)) for (s, p, name) in pris]
+    return [x for _, x in lists_sort(lambda a, b: a[0] >= b[0], ppris)]
+
+
+def mux_fuzzers(rnd, table, fs, ll):
+    """the fun mux_fuzzers/1 returns (:1258-1265) + mux_fuzzers_loop/4 (:1268-1281) -> (fs', ll')"""
+    if ll == [b""]:
+        return fs, ll
+    if ll == []:
+        return fs, b""                                                     # a binary, not a list: the caller's ++ crashes
+    nodes, out = weighted_permutations(rnd, fs), []
+    while nodes:
+        node, tail = nodes[0], nodes[1:]
+        if len(ll[0]) > ABSMAX_BINARY_BLOCK:
+            return out + tail, ll
+        score, pri, name = node
+        mll, delta = table[name](ll)
+        out = [(adjust_priority(score, delta), pri, name)] + out
+        if mll[0] == ll[0]:
+            nodes = tail
+            continue
+        return out + tail, mll
+    return out, ll
+
+
+# ------------------------------------------------------------------------------------------------ erlamsa_gen.erl
+def rand_block_size(rnd, scale):                                           # :54-56
+    return max(rnd.rand(round(MAX_BLOCK_SIZE * scale)), round(MIN_BLOCK_SIZE * scale))
+
+
+def finish(rnd, length):                                                   # :42-51
+    n = rnd.rand(length + 1)
+    if n == length:
+        bits = rnd.rand_range(1, 16)
+        nlen = rnd.rand(1 << bits)
+        blk = bytes(rnd.random_numbers(256, nlen))
+        return [] if blk == b"" else [blk]
+    return []
+
+
+def direct_generator(rnd, data, scale):                                    # :152-164
+    rand_block_size(rnd, scale)                 # the argument is evaluated, then split_binary's first guard
+    return [data] + finish(rnd, len(data))      # (byte_size(Wanted) of an integer) fails: never split
+
+
+def random_stream(rnd, scale):                                             # :167-177
+    out = []
+    while True:
+        n = rnd.rand_range(32, round(MAX_BLOCK_SIZE * scale))
+        out.append(rnd.random_block(n))
+        ip = rnd.rand_range(1, 100)
+        if rnd.rand(ip) == 0:
+            return out
+
+
+# ------------------------------------------------------------------------------------------------ erlamsa_patterns.erl
+REMUTATE = (4, 5)
+PAT_ORDER = [("od", 1), ("nd", 2), ("bu", 1)]                              # patterns/0 :395-404 (the three modelled)
+
+
+def run_pattern(rnd, table, pat, ll, fs, written):
+    """pat_once_dec / pat_many_dec / pat_burst (:308-349) with mutate_once/4 (:267-279) and mutate_once_loop/6
+    (:283-297); blocks are appended to `written` in the order erlamsa_out:blocks_port/5 (:642-655) writes them."""
+    while True:                                                            # one mutate_once per turn
+        if ll == [b""]:
+            return                                                         # {Mutator, Meta}: nothing more is written
+        ip = rnd.rand(24)                                                  # ?INITIAL_IP
+        if not ll:
+            this, rest = None, []
+        else:
+            this, rest = ll[0], ll[1:]
+            if len(this) > ABSMAX_BINARY_BLOCK:                            # split/1 + split_into_maxblocks/2 :44-59
+                pieces = []
+                while len(this) > ABSMAX_BINARY_BLOCK:
+                    cut = 500000 + rnd.rand(500000) - 1
+                    pieces.append(this[:cut])
+                    this = this[cut:]
+                pieces.append(this)                                        # cons_revlst(Lst, LlN): pieces in order, then LlN
+                this, rest = pieces[0], pieces[1:] + rest
+        if this is None:                                                   # Cont([], Mutator, Meta)
+            l = []
+        else:
+            while True:                                                    # mutate_once_loop
+                n = rnd.rand(ip)
+                if n == 0 or rest == []:
+                    fs, l = mux_fuzzers(rnd, table, fs, [this] + rest)
+                    break
+                written.append(this)
+                this, rest = rest[0], rest[1:]
+        # the continuation
+        if pat == "od":
+            if not isinstance(l, list):
+                raise ErlCrash("badarg: <<>> ++ [..]")
+            written.extend(l)
+            return
+        if pat == "nd":                                                    # pat_many_dec_cont :315-321
+            if rnd.rand_occurs_fixed(*REMUTATE):
+                ll = l
+                if not isinstance(ll, list):
+                    raise ErlCrash("mutate_once(<<>>): uncons of a binary")  # see note in test_pymodel.py
+                continue
+            if not isinstance(l, list):
+                raise ErlCrash("badarg: <<>> ++ [..]")
+            written.extend(l)
+            return
+        # bu: pat_burst_cont :332-345
+        n = 1
+        while True:
+            p = rnd.rand_occurs_fixed(*REMUTATE)
+            if p or n < 2:
+                if not isinstance(l, list):
+                    raise ErlCrash("mux_fuzzers: no clause for a binary")
+                fs, l = mux_fuzzers(rnd, table, fs, l)
+                n += 1
+            else:
+                if not isinstance(l, list):
+                    raise ErlCrash("badarg: <<>> ++ [..]")
+                written.extend(l)
+                return
+
+
+# ------------------------------------------------------------------------------------------------ erlamsa_main.erl
+def fuzzer(inputs, seed, mutations, patterns, blockscale=1.0, first_case=1):
+    """erlamsa_main:fuzzer/1 (:124-232) for paths = [direct], generators = default, workers = 1; iteration I mutates
+    inputs[I - first_case].  mutations / patterns: [(name, pri)].  -> [(status, bytes)], status 0 ok / 1 crashed."""
+    parent = Rnd()
+    parent.seed(seed)                                                      # :135
+    # make_mutator/2 :1371-1384 (foldl prepends) + mutators_mutator/2 :1391-1395
+    # mutations/1 (:1290-1331) is evaluated as make_mutator's fold argument: building the table runs
+    # construct_sed_bytes_randmask/1 (:311-312) for snand and srnd, and each draws its MaskFun with rand_elem/1 — two draws
+    # of the parent stream whether or not those mutators are selected.  (The first version of this model missed them;
+    # diffing against the oracle found it — the oracle had it right.)
+    parent.rand_elem(["mask_nand", "mask_or", "mask_xor"])
+    parent.rand_elem(["mask_replace"])
+    sel = dict(mutations)
+    mutas = []
+    for name in TABLE_ORDER:
+        if name in sel:
+            mutas.insert(0, (sel[name], name))
+    fs = []
+    for pri, name in mutas:
+        n = parent.rand(math.trunc(MAX_SCORE))
+        fs.insert(0, (max(2, n), pri, name))
+    # make_generator/5 :244-247 with Args = [direct]: random (1) and direct (500) survive; mux_generators/2 :193-199
+    gens, total = sort_by_priority([(1, "random"), (500, "direct")])
+    gen = choose_pri(gens, parent.rand(total))
+    # make_pattern/1 :417-429 (foldl prepends) + mux_patterns/1 :438-443
+    psel = dict(patterns)
+    pats = []
+    for name, _ in PAT_ORDER:
+        if name in psel:
+            pats.insert(0, (psel[name], name))
+    spats, ptotal = sort_by_priority(pats)
+    res = []
+    # the loop runs from case 1: skip the ThreadSeed draws of the cases before first_case
+    for _ in range(3 * (first_case - 1)):
+        parent.erand(99999)
+    for data in inputs:
+        tseed = parent.gen_predictable_seed()                              # :179
+        rnd = Rnd()
+        rnd.seed(tseed)                                                    # :183
+        table = make_table(rnd)
+        try:
+            ll = direct_generator(rnd, data, blockscale) if gen == "direct" else random_stream(rnd, blockscale)   # :185
+            pat = choose_pri(spats, rnd.rand(ptotal))                      # choose_pattern_fun :431-434
+            written = []
+            run_pattern(rnd, table, pat, ll, list(fs), written)
+            res.append((0, b"".join(written)))
+        except ErlCrash:
+            res.append((1, b""))
+    return res

@@ -1,0 +1,73 @@
+"""Oracle pinning, part 3: two independent models agree.
+
+tests/pymodel.py is a Python model of erlamsa_main:fuzzer/1 (set-up, direct/random generators, patterns od/nd/bu,
+twelve mutators) transcribed from the reference's .erl sources without consulting oracle/oracle.cpp.  Here it is diffed
+against the C++ oracle on 15 000 cases.  What both share is the author's reading of OTP's `random` and lists:sort/2 —
+the part only a BEAM run can pin (tests/golden/capture.escript)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pymodel
+import pyoracle as po
+
+MUTS = [("num", 3), ("bd", 1), ("bei", 1), ("bed", 1), ("bf", 1), ("bi", 1), ("ber", 1), ("br", 1), ("sp", 1), ("sr", 1), ("sd", 1), ("ld", 1)]
+PATS = [("od", 1), ("nd", 2), ("bu", 1)]
+
+
+def _inputs(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    words = [b"alpha", b"-12", b"4096", b" ", b"\n", b"x=", b"0", b"65535", b"--7", b"\t", b"255.0", b"-", b"beta\n", b"1e9", b"99999999999999999999"]
+    out = []
+    for i in range(n):
+        kind = i % 4
+        size = int(rng.integers(0, 600)) if i % 97 else int(rng.integers(2048, 5000))
+        if kind == 0:
+            out.append(rng.integers(0, 256, size=size, dtype=np.uint8).tobytes())
+        elif kind == 1:
+            out.append(rng.integers(32, 127, size=size, dtype=np.uint8).tobytes())
+        else:
+            b = b""
+            while len(b) < size:
+                b += words[int(rng.integers(0, len(words)))]
+            out.append(b)
+    out[:6] = [b"", b"\n", b"7", b"-", b"ab", b"a\nb\nc\n"]
+    return out
+
+
+def _diff(inputs, seed, muts, pats, first_case=1):
+    want = pymodel.fuzzer(inputs, seed, muts, pats, first_case=first_case)
+    data, off = po.pack(inputs)
+    got, st, _, _ = po.fuzz_batch(data, off, seed=seed, mutations=",".join("%s=%d" % m for m in muts),
+                                  patterns=",".join("%s=%d" % p for p in pats), first_case=first_case)
+    bad = [i for i in range(len(inputs)) if (int(st[i]), got[i]) != want[i]]
+    assert not bad, "first mismatch: case %d, input %r\n oracle %r\n model  %r" % (bad[0], inputs[bad[0]][:80], (int(st[bad[0]]), got[bad[0]][:80]), (want[bad[0]][0], want[bad[0]][1][:80]))
+
+
+def test_lists_sort_with_strict_and_nonstrict_funs():
+    """lists:sort/2 properties that hold whatever the tie rule: a permutation, ordered by the fun; and the model's result
+    equals the C++ restatement's for every short priority list (the tie order is what the engine's weighted choices use)."""
+    import itertools
+    for n in range(0, 7):
+        for pris in itertools.product([0, 1, 2], repeat=n):
+            l = [(p, i) for i, p in enumerate(pris)]
+            s = pymodel.lists_sort(lambda a, b: a[0] > b[0], l)
+            assert sorted(s) == sorted(l) and all(s[i][0] >= s[i + 1][0] for i in range(len(s) - 1))
+            s2 = pymodel.lists_sort(lambda a, b: a[0] >= b[0], l)
+            assert s2 == sorted(l, key=lambda x: -x[0])           # a proper "=<": stable
+            assert [i for _, i in s] == po.sort_by_priority([p for p in pris])
+
+
+@pytest.mark.parametrize("seed", [(1, 2, 3), (4, 5, 6), (9, 9, 9)])
+def test_model_and_oracle_agree_on_5000_cases(seed):
+    _diff(_inputs(5000, seed[0]), seed, MUTS, PATS)
+
+
+def test_model_and_oracle_agree_on_subsets_and_offsets():
+    ins = _inputs(400, 9)
+    _diff(ins, (7, 8, 9), [("bd", 1), ("sr", 2), ("num", 5)], [("od", 1)])
+    _diff(ins, (7, 8, 9), [("ld", 1), ("sp", 1)], [("nd", 1), ("bu", 3)], first_case=1001)
+    _diff(ins, (3, 1, 4), [("bf", 4), ("bi", 4), ("ber", 4), ("br", 4), ("bei", 1), ("bed", 1)], [("bu", 1)])
