@@ -870,7 +870,7 @@ static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
     ctx->ntiers = 0;
     uint64_t cap = work_cap;
     while (cap < big && ctx->ntiers < eh_ctx::MAX_TIERS) {
-      cap = cap * 4 < big ? cap * 4 : big;
+      cap = (cap * 4 < big && ctx->ntiers < eh_ctx::MAX_TIERS - 1) ? cap * 4 : big;     // the last tier always has the full size
       uint64_t stride_t = ((uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + cap + 255) & ~255ull;
       uint64_t tier_gib = 16;                                                   // an eighth of the free memory, 1 .. 32 GiB
       { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) { tier_gib = (uint64_t)fr >> 33; if (tier_gib < 1) tier_gib = 1; if (tier_gib > 32) tier_gib = 32; } }

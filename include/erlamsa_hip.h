@@ -78,14 +78,16 @@ typedef struct eh_options {
   uint64_t out_capacity;     /* output arena bytes; 0 => 8 x batch input bytes + 2 GiB */
   uint64_t max_case_work;    /* OPTIONAL per-case work budget in bytes (sum over mutator attempts, failed ones
                                 included, of block size x cost weight of the mutator: 8 for parsers and
-                                per-byte-draw mutators, 64 for the fuse family, 4 for num, 1 otherwise);
+                                per-byte-draw mutators, 64 for the fuse family, 4 for num, 1 otherwise; plus 16 x
+                                the list members of every fuse refinement round);
                                 0 => no budget (default): every case runs to completion */
   uint32_t max_slots;        /* resident wavefront slots; 0 => auto */
   uint32_t flags;            /* EH_FLAG_* */
   uint64_t big_case_bytes;   /* largest work area.  A case that outgrows its area is run again from scratch (same
-                                result) by the next tier of wavefronts: 4x the area, a quarter as many of them, up to
-                                this size; only a case that outgrows this too ends as EH_CASE_OVERFLOW.
-                                0 => 32 x max_case_bytes, at most 1 GiB; <= max_case_bytes => a single tier */
+                                result) by a later tier of wavefronts of the same dispatch: 4x the area per tier, fewer
+                                wavefronts, up to this size; only a case that outgrows this too ends as
+                                EH_CASE_OVERFLOW.  0 => 32 x max_case_bytes, at most 1 GiB; <= max_case_bytes => a
+                                single tier */
 } eh_options;
 
 #define EH_FLAG_ORDERED_OUTPUT 1u /* compact the output arena into case order after the batch */

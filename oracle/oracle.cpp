@@ -7,7 +7,14 @@
 // PARITY UNPINNED (no Erlang runtime on this image; reference tests pin no
 // byte-exact vectors).  What IS pinned: tests/test_oracle_*.py re-express the
 // reference's own eunit properties (erlamsa_mutations_test.erl) against this
-// code, plus hand-derived AS183 known answers.
+// code, plus hand-derived AS183 known answers; tests/test_pymodel.py diffs a second,
+// independent Python model of fuzzer/1 (set-up, generators, od/nd/bu, 12 mutators)
+// against it on 15 000 cases; tests/golden/capture.escript turns the golden
+// vectors into BEAM captures on a host with OTP.
+//
+// Engine limits (work-area cap, optional work budget, the cpu_baseline leg's wall
+// clock watchdog) are NOT part of the restated functions: they live in EngineGuard,
+// a null pointer unless a caller asks for caps.
 #include "oracle.h"
 
 #include <chrono>

@@ -50,3 +50,10 @@ def test_emulated_abi_behaviour(emu_lib):
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_abi.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "abi behaviour ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_emulated_tiered_work_areas(emu_lib):
+    """overflow -> re-run in a larger tier of the same dispatch; routing by requested size"""
+    env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_tiers.py"), "16"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "tiers ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
