@@ -86,8 +86,10 @@ def main():
     ap.add_argument("--cpu-case-seconds", type=float, default=10.0, help="per-case wall-clock watchdog of the CPU oracle leg "
                     "(the reference's maxrunningtime; its CLI default is 30 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle leg (0 = all host cores, at most 64)")
-    ap.add_argument("--max-slots", type=int, default=0, help="tier-0 wavefront slots per context (0 = 16 per CU)")
-    ap.add_argument("--out-gib", type=int, default=32, help="output arena capacity per context (GiB)")
+    ap.add_argument("--max-slots", type=int, default=1365, help="tier-0 wavefront slots per context (0 = 16 per CU); the default x 3 contexts = 16 per CU")
+    ap.add_argument("--tier-gib", type=int, default=8, help="device memory of every overflow tier of a context (GiB; exported as EH_TIER_GIB); "
+                    "0 = the library's own rule (an eighth of the free memory, for a single context)")
+    ap.add_argument("--out-gib", type=int, default=28, help="output arena capacity per context (GiB)")
     ap.add_argument("--case-mib", type=int, default=16, help="per-case work area of every resident wavefront (MiB), eh_options.max_case_bytes")
     ap.add_argument("--big-mib", type=int, default=1024, help="largest work area (MiB), eh_options.big_case_bytes: a case that outgrows its area "
                     "is run again by the next tier (4x the area, a quarter of the wavefronts)")
@@ -97,10 +99,13 @@ def main():
                     "0 = off (default): every case runs to completion like under the reference's 30 s CLI watchdog")
     ap.add_argument("--pcie", type=int, default=1, help="1: after the timed steps, one extra pass whose outputs are downloaded to pinned host memory "
                     "(reported as 'pcie'); 0: skip")
-    ap.add_argument("--inflight", type=int, default=1, help="passes in flight (engine contexts / HIP streams); every context owns "
-                    "its work-area tiers and output arena, about 144 GiB at the defaults")
+    ap.add_argument("--inflight", type=int, default=3, help="passes in flight (engine contexts / HIP streams): the tail of a pass — a few "
+                    "multi-second single-wavefront cases — overlaps with the bulk of the next ones.  Every context owns its work-area "
+                    "tiers and output arena: about 73 GiB at the defaults, 220 GiB for 3")
     args = ap.parse_args()
 
+    if args.tier_gib > 0:
+        os.environ["EH_TIER_GIB"] = str(args.tier_gib)
     import numpy as np
     import torch
     import erlamsa_amd as ea
@@ -239,7 +244,7 @@ def main():
                 ps = json.load(fh)
             wk = ps["workload_key"]
             if (wk["cases"], wk["size"], wk["max_case_work"], wk["max_case_bytes"], wk["mutators"], wk["patterns"]) == \
-                    (n, size, args.work_mib << 20, args.case_mib << 20, muts, pats) and nctx == wk.get("inflight", nctx):
+                    (n, size, args.work_mib << 20, args.case_mib << 20, muts, pats):       # per launch: independent of how many overlap
                 traffic = int(ps["traffic_bytes_per_launch"]["total_fetch_x2_plus_write"])
                 traffic_src = "profiles/r02_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch)"
         except (OSError, KeyError, ValueError):
@@ -261,6 +266,7 @@ def main():
                                ",".join(m for m, _, _ in ea.mutator_table() if m not in [x.split("=")[0] for x in muts.split(",")]) or "none"),
                 "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream before the W warm-up steps",
                 "max_case_bytes": args.case_mib << 20, "big_case_bytes": args.big_mib << 20, "max_case_work": args.work_mib << 20,
+                "tier0_slots_per_context": args.max_slots, "tier_gib": args.tier_gib,
             },
             "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(big_case_bytes)", "unsupported", "arena_full",
                                      "budget(max_case_work; reference analogue: maxrunningtime -> <<>>)"],

@@ -84,13 +84,15 @@ if bl:
 k = [r for r in csv.DictReader(open(os.path.join(P, tag + "_kernel_stats.csv"))) if KERNEL in r["Name"]][0]
 out = {
     "round": tag,
-    "command": "rocprofv3 --kernel-trace --stats -f csv -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 --budget-mib 0   (defaults otherwise: 65536 x 4096 B, full default mutator table, no work budget, 1 pass in flight)",
+    "command": "rocprofv3 --kernel-trace --stats -f csv -- python bench.py --steps 6 --warmup 3 --cpu-sample 0 --budget-mib 0   (defaults otherwise: 65536 x 4096 B, full default mutator table, no work budget, 3 passes in flight)",
     "pmc_command": "rocprofv3 --pmc <COUNTERS> -f csv -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 --budget-mib 0   (separate runs for FETCH_SIZE, WRITE_SIZE and the SQ set)",
     "kernel": k["Name"], "dispatches": int(k["Calls"]), "dispatches_per_launch": group, "launches": len(launches),
     "avg_ms_per_dispatch_rocprof_stats": float(k["AverageNs"]) / 1e6,
     "all_dispatches_ms": [round(x, 3) for x in spans],
     "avg_ms_timed_dispatches_rocprof": sum(spans[-bench["steps"]:]) / bench["steps"],
-    "note": "the first 1 + warmup dispatches are the context set-up pass and the warm-up steps; the last `steps` dispatches are the timed ones "
+    "timed_span_ms_per_step_rocprof": (max(int(r[0]["End_Timestamp"]) for r in launches[-bench["steps"]:]) -
+                                       min(int(r[0]["Start_Timestamp"]) for r in launches[-bench["steps"]:])) / 1e6 / bench["steps"],
+    "note": "the first (contexts + warmup) dispatches are the per-context set-up passes and the warm-up steps; the last `steps` dispatches are the timed ones "
             "bench.py's HIP events cover.  Every pass runs different case numbers: its duration follows its slowest cases (a few "
             "multi-second single-wavefront cases per 65536)",
     "avg_ms_bench_hip_events_same_run": bench["roofline"]["kernel_ms_avg"],

@@ -4,8 +4,8 @@
 tag=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --cpu-sample 0 --budget-mib 0"
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_$tag -o $tag -- $B --steps 3 --warmup 1 > $R/gpurun_out/prof_${tag}_bench.log 2>&1
+B="python $R/bench.py --cpu-sample 0 --budget-mib 0 --pcie 0"
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_$tag -o $tag -- $B --steps 6 --warmup 3 > $R/gpurun_out/prof_${tag}_bench.log 2>&1
 tail -1 $R/gpurun_out/prof_${tag}_bench.log | cut -c1-200
 timeout 120 rocprofv3 --pmc FETCH_SIZE -f csv -d $R/gpurun_out/pmc_fetch -o p -- $B --steps 1 --warmup 0 > $R/gpurun_out/pmc_fetch.log 2>&1
 timeout 120 rocprofv3 --pmc WRITE_SIZE -f csv -d $R/gpurun_out/pmc_write -o p -- $B --steps 1 --warmup 0 > $R/gpurun_out/pmc_write.log 2>&1
