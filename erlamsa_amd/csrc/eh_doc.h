@@ -37,9 +37,6 @@ EH_DEV uint64_t pieces_total(const Piece* t, uint32_t n) {
 // so an unedited stretch of a document collapses into one long piece and the gather below moves it with 16-byte
 // vectors instead of a lane per 1-byte piece.
 EH_DEV uint32_t pieces_coalesce(Piece* t, uint32_t n) {
-#ifdef EH_DBG_NOCOAL
-  return n;
-#endif
   const int l = EH_LANE;
   uint32_t nout = 0;
   uint64_t carry_end = 0; bool have_carry = false;                  // end address of the last written piece (if mergeable)
@@ -200,9 +197,7 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
     int cj = (int)__builtin_ctzll(cand); cand &= cand - 1;
     int i = base + cj;
     uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)ca, cj), b = (uint32_t)__builtin_amdgcn_readlane((int)cb, cj);
-#ifndef EH_DBG_NOACCEPT
     if (!b64_accepts(H + a, b - a)) continue;                    // error:badarg / function_clause :677-684
-#endif
     int dl = b64_decode(H + a, b - a, nullptr);
     if (!out) {                                                  // first hit: the piece list of unlex(Ms)
       cap = 2 * (uint32_t)(n - i) + 4;

@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -748,6 +750,13 @@ struct eh_ctx {
   RunState* d_run = nullptr;
   int64_t* d_seeds = nullptr; uint64_t seeds_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // request coalescing (eh_submit / eh_flush / eh_poll)
+  std::mutex co_lock;
+  uint64_t co_next_ticket = 1, co_flush_cases = 4096, co_flush_bytes = 64ull << 20;
+  std::vector<uint8_t> co_data; std::vector<uint64_t> co_off{0}; std::vector<int64_t> co_seeds; std::vector<uint64_t> co_tickets;   // pending batch
+  bool co_inflight = false; std::vector<uint64_t> co_inflight_tickets;                  // launched, results still on the device
+  struct CoResult { std::vector<uint8_t> out; int32_t status; };
+  std::map<uint64_t, CoResult> co_done;                                                 // downloaded, not polled yet
   hipStream_t last_stream = nullptr;
   uint64_t last_n = 0, last_in_bytes = 0;
   bool have_result = false;
@@ -999,6 +1008,7 @@ const char* eh_strerror(int code) {
     case EH_E_HIP: return "HIP runtime error";
     case EH_E_NOMEM: return "out of memory";
     case EH_E_STATE: return "wrong call order";
+    case EH_E_AGAIN: return "request not launched yet";
     case EH_E_UNSUPPORTED: return "mutator/pattern not available on the GPU in this build";
   }
   return "unknown error";
@@ -1181,6 +1191,82 @@ int eh_fuzz_calls(eh_ctx* ctx, const int64_t* seeds, uint64_t corpus_first, uint
   int64_t dummy[3] = {0, 0, 0};
   return launch(ctx, 1, dummy, 1, corpus_first, n, (hipStream_t)stream);
 }
+// ---- request coalescing -------------------------------------------------------------------------------------
+// co_lock held.  Brings the launched batch's results to the host (one download) and files them under their tickets.
+static int co_collect(eh_ctx* ctx) {
+  if (!ctx->co_inflight) return EH_OK;
+  uint64_t in_b = 0, out_b = 0, nc = 0;
+  int rc = eh_result_totals(ctx, &in_b, &out_b, &nc);
+  if (rc) return rc;
+  const uint64_t n = ctx->co_inflight_tickets.size();
+  std::vector<uint8_t> data(out_b ? out_b : 1); std::vector<uint64_t> off(n + 1); std::vector<int32_t> st(n ? n : 1);
+  rc = eh_result_download(ctx, data.data(), data.size(), off.data(), st.data());
+  if (rc) return rc;
+  for (uint64_t i = 0; i < n; i++) {
+    eh_ctx::CoResult r; r.out.assign(data.begin() + off[i], data.begin() + off[i + 1]); r.status = st[i];
+    ctx->co_done.emplace(ctx->co_inflight_tickets[i], std::move(r));
+  }
+  ctx->co_inflight = false; ctx->co_inflight_tickets.clear();
+  return EH_OK;
+}
+// co_lock held.  Launches the pending batch (after collecting the previous one: one result buffer per context).
+static int co_launch(eh_ctx* ctx) {
+  if (ctx->co_tickets.empty()) return EH_OK;
+  int rc = co_collect(ctx);
+  if (rc) return rc;
+  const uint64_t n = ctx->co_tickets.size();
+  rc = eh_corpus_upload(ctx, ctx->co_data.data(), ctx->co_off.data(), n);
+  if (!rc) rc = eh_fuzz_calls(ctx, ctx->co_seeds.data(), 0, n, nullptr);
+  if (rc) return rc;
+  ctx->co_inflight = true; ctx->co_inflight_tickets.swap(ctx->co_tickets);
+  ctx->co_tickets.clear(); ctx->co_data.clear(); ctx->co_off.assign(1, 0); ctx->co_seeds.clear();
+  return EH_OK;
+}
+int eh_coalesce_limits(eh_ctx* ctx, uint64_t flush_cases, uint64_t flush_bytes) {
+  if (!ctx || !flush_cases || !flush_bytes) return EH_E_INVALID;
+  std::lock_guard<std::mutex> g(ctx->co_lock);
+  ctx->co_flush_cases = flush_cases; ctx->co_flush_bytes = flush_bytes;
+  return EH_OK;
+}
+int eh_submit(eh_ctx* ctx, const uint8_t* data, uint64_t len, const int64_t seed[3], uint64_t* ticket) {
+  if (!ctx || !seed || !ticket || (!data && len)) return EH_E_INVALID;
+  if (!ctx->configured) { ctx->err = "configure first"; return EH_E_STATE; }
+  std::lock_guard<std::mutex> g(ctx->co_lock);
+  try {
+    ctx->co_data.insert(ctx->co_data.end(), data, data + len);
+    ctx->co_off.push_back(ctx->co_data.size());
+    ctx->co_seeds.insert(ctx->co_seeds.end(), seed, seed + 3);
+    ctx->co_tickets.push_back(ctx->co_next_ticket);
+  } catch (const std::bad_alloc&) { return EH_E_NOMEM; }
+  *ticket = ctx->co_next_ticket++;
+  if (ctx->co_tickets.size() >= ctx->co_flush_cases || ctx->co_data.size() >= ctx->co_flush_bytes) return co_launch(ctx);
+  return EH_OK;
+}
+int eh_flush(eh_ctx* ctx) {
+  if (!ctx) return EH_E_INVALID;
+  std::lock_guard<std::mutex> g(ctx->co_lock);
+  return co_launch(ctx);
+}
+int eh_poll(eh_ctx* ctx, uint64_t ticket, uint8_t* out, uint64_t cap, uint64_t* out_len, int32_t* status) {
+  if (!ctx || !out_len || !status) return EH_E_INVALID;
+  std::lock_guard<std::mutex> g(ctx->co_lock);
+  auto it = ctx->co_done.find(ticket);
+  if (it == ctx->co_done.end()) {
+    for (uint64_t t : ctx->co_tickets) if (t == ticket) return EH_E_AGAIN;
+    bool launched = false;
+    for (uint64_t t : ctx->co_inflight_tickets) if (t == ticket) launched = true;
+    if (!launched) { ctx->err = "unknown or already consumed ticket"; return EH_E_INVALID; }
+    int rc = co_collect(ctx);                                       // waits for the batch
+    if (rc) return rc;
+    it = ctx->co_done.find(ticket);
+  }
+  *out_len = it->second.out.size(); *status = it->second.status;
+  if (it->second.out.size() > cap || (!out && !it->second.out.empty())) { ctx->err = "eh_poll: buffer too small"; return EH_E_INVALID; }
+  if (!it->second.out.empty()) memcpy(out, it->second.out.data(), it->second.out.size());
+  ctx->co_done.erase(it);
+  return EH_OK;
+}
+
 int eh_sync(eh_ctx* ctx) {
   if (!ctx) return EH_E_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -281,9 +281,6 @@ __device__ __noinline__ int muta_json(Ctx&) {
       unsigned long long m = __ballot(i < L && !(ch == ' ' || ch == '\n' || ch == '\r' || ch == '\t'));
       if (m) p0 = base + (uint32_t)__builtin_ctzll(m);
     }
-#ifdef EH_DBG_NOQR
-    p0 = L;
-#endif
     if (p0 < L) {
       uint32_t c0 = uni(H[p0]);
       if (c0 != '[' && c0 != '{' && c0 != '"' && c0 != 't' && c0 != 'f' && c0 != 'n') {

@@ -24,6 +24,7 @@ ABI_SYMBOLS = [
     "eh_last_kernel_ms", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
+    "eh_coalesce_limits", "eh_submit", "eh_flush", "eh_poll",
 ]
 
 
@@ -77,6 +78,10 @@ def load_library():
     lib.eh_result_prof.argtypes = [vp, vp]
     lib.eh_selftest_movers.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
     lib.eh_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.eh_coalesce_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
+    lib.eh_submit.argtypes = [vp, vp, C.c_uint64, i64p, u64p]
+    lib.eh_flush.argtypes = [vp]
+    lib.eh_poll.argtypes = [vp, C.c_uint64, vp, C.c_uint64, u64p, C.POINTER(C.c_int32)]
     lib.eh_kernel_name.restype = C.c_char_p
     lib.eh_abi_version.restype = C.c_uint32
     for f in ("eh_mutator_name", "eh_pattern_name", "eh_strerror"):
@@ -246,6 +251,35 @@ class Engine:
         eq = np.zeros(len(jobs), dtype=np.uint32)
         self._chk(self.lib.eh_selftest_movers(self.h, buf.ctypes.data, buf.size, jobs.ctypes.data, len(jobs), eq.ctypes.data))
         return buf, eq
+
+    # ---- request coalescing (eh_submit / eh_flush / eh_poll)
+    def coalesce_limits(self, flush_cases, flush_bytes):
+        self._chk(self.lib.eh_coalesce_limits(self.h, flush_cases, flush_bytes))
+
+    def submit(self, data, seed):
+        """one erlamsa_app:fuzz(Bin, #{seed => Seed}) request -> ticket"""
+        b = bytes(data)
+        t = C.c_uint64()
+        buf = (C.c_char * max(len(b), 1)).from_buffer_copy(b or b"\0")
+        self._chk(self.lib.eh_submit(self.h, C.cast(buf, C.c_void_p), len(b), (C.c_int64 * 3)(*seed), C.byref(t)))
+        return t.value
+
+    def flush(self):
+        self._chk(self.lib.eh_flush(self.h))
+
+    def poll(self, ticket, cap=1 << 16):
+        """-> (status, bytes), or None while the request has not been launched (EH_E_AGAIN)"""
+        while True:
+            out = (C.c_uint8 * cap)()
+            n, st = C.c_uint64(), C.c_int32()
+            rc = self.lib.eh_poll(self.h, ticket, out, cap, C.byref(n), C.byref(st))
+            if rc == -7:
+                return None
+            if rc == -1 and n.value > cap:
+                cap = int(n.value)
+                continue
+            self._chk(rc)
+            return st.value, bytes(out[:n.value])
 
     def result_device(self):
         d, o, l, s = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()

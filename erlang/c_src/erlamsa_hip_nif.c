@@ -10,6 +10,7 @@
  *   fuzz_calls_nif(Ctx, Opts, [{A,B,C}], [binary()])          -> {ok, [{Status, binary()}]} | {error, Reason}
  *       case I is its own fuzzer/1 run with n = 1 and the I-th seed: erlamsa_app:fuzz/2      (eh_fuzz_calls)
  *   Status: enum eh_case_status.  Both run on a dirty I/O scheduler: one call = one GPU batch.
+ *   submit_nif / flush_nif / poll_nif: request coalescing, see below.
  *
  * A context remembers the options it was last configured with: eh_configure runs again only when they change.
  */
@@ -179,6 +180,53 @@ done:
   return ret;
 }
 
+/* Request coalescing (eh_submit / eh_flush / eh_poll): what a micro-batcher in erlamsa_fsupervisor calls.
+ *   submit_nif(Ctx, Opts, {A,B,C}, Bin) -> {ok, Ticket}       flush_nif(Ctx) -> ok
+ *   poll_nif(Ctx, Ticket) -> {ok, Status, Bin} | again | {error, Reason}   (dirty: waits for the ticket's batch) */
+static ERL_NIF_TERM nif_submit(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  (void)argc; ctx_res* r; opt_key k; const ERL_NIF_TERM* st; int arity; ErlNifBinary b; ErlNifSInt64 v; int64_t seed[3];
+  if (!enif_get_resource(env, argv[0], ctx_type, (void**)&r) || !enif_is_map(env, argv[1]) || !read_opts(env, argv[1], &k) ||
+      !enif_get_tuple(env, argv[2], &arity, &st) || arity != 3 || !enif_inspect_binary(env, argv[3], &b))
+    return enif_make_badarg(env);
+  for (int j = 0; j < 3; j++) { if (!enif_get_int64(env, st[j], &v)) return enif_make_badarg(env); seed[j] = v; }
+  enif_mutex_lock(r->lock);
+  uint64_t ticket = 0;
+  int rc = EH_OK;
+  if (r->configured && memcmp(&r->key, &k, sizeof(k)) != 0) rc = eh_flush(r->ctx);   /* pending requests keep the options they came with */
+  if (!rc) rc = configure_if_changed(r, &k);
+  if (!rc) rc = eh_submit(r->ctx, b.data, b.size, seed, &ticket);
+  ERL_NIF_TERM ret = rc ? mk_error(env, r->ctx, rc) : enif_make_tuple2(env, enif_make_atom(env, "ok"), enif_make_uint64(env, ticket));
+  enif_mutex_unlock(r->lock);
+  return ret;
+}
+static ERL_NIF_TERM nif_flush(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  (void)argc; ctx_res* r;
+  if (!enif_get_resource(env, argv[0], ctx_type, (void**)&r)) return enif_make_badarg(env);
+  enif_mutex_lock(r->lock);
+  int rc = eh_flush(r->ctx);
+  ERL_NIF_TERM ret = rc ? mk_error(env, r->ctx, rc) : enif_make_atom(env, "ok");
+  enif_mutex_unlock(r->lock);
+  return ret;
+}
+static ERL_NIF_TERM nif_poll(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  (void)argc; ctx_res* r; ErlNifUInt64 ticket;
+  if (!enif_get_resource(env, argv[0], ctx_type, (void**)&r) || !enif_get_uint64(env, argv[1], &ticket)) return enif_make_badarg(env);
+  uint64_t len = 0; int32_t status = 0; size_t cap = 1 << 16; ERL_NIF_TERM ret;
+  for (;;) {
+    uint8_t* buf = malloc(cap);
+    if (!buf) return mk_err_atom(env, "enomem");
+    int rc = eh_poll(r->ctx, ticket, buf, cap, &len, &status);
+    if (rc == EH_E_AGAIN) { free(buf); return enif_make_atom(env, "again"); }
+    if (rc == EH_E_INVALID && len > cap) { free(buf); cap = (size_t)len; continue; }   /* the ticket stays valid */
+    if (rc) { free(buf); return mk_error(env, r->ctx, rc); }
+    ERL_NIF_TERM bin; unsigned char* p = enif_make_new_binary(env, (size_t)len, &bin);
+    if (!p) { free(buf); return mk_err_atom(env, "enomem"); }
+    memcpy(p, buf, (size_t)len); free(buf);
+    ret = enif_make_tuple3(env, enif_make_atom(env, "ok"), enif_make_int(env, status), bin);
+    return ret;
+  }
+}
+
 static ERL_NIF_TERM nif_fuzz_batch(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { (void)argc; return run(env, argv, 0); }
 static ERL_NIF_TERM nif_fuzz_calls(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { (void)argc; return run(env, argv, 1); }
 
@@ -186,5 +234,8 @@ static ErlNifFunc funcs[] = {
   {"open", 1, nif_open, 0},
   {"fuzz_batch_nif", 5, nif_fuzz_batch, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"fuzz_calls_nif", 4, nif_fuzz_calls, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"submit_nif", 4, nif_submit, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"flush_nif", 1, nif_flush, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"poll_nif", 2, nif_poll, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 ERL_NIF_INIT(erlamsa_hip, funcs, load, NULL, NULL, NULL)

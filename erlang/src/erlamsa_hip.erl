@@ -15,6 +15,7 @@
 %% (erlamsa_utils:make_fuzzer/1, erlamsa_utils.erl:221-226) and falls back to the unmodified packet.
 -module(erlamsa_hip).
 -export([init/0, open/1, fuzz_batch/2, fuzz_calls/2, fuzz_batch_nif/5, fuzz_calls_nif/4, capabilities/0, fuzzer/3]).
+-export([submit/3, flush/1, poll/2, submit_nif/4, flush_nif/1, poll_nif/2]).
 -on_load(init/0).
 
 init() ->
@@ -24,6 +25,9 @@ init() ->
 open(_Device) -> erlang:nif_error(nif_not_loaded).
 fuzz_batch_nif(_Ctx, _Opts, _Seed, _FirstCase, _Bins) -> erlang:nif_error(nif_not_loaded).
 fuzz_calls_nif(_Ctx, _Opts, _Seeds, _Bins) -> erlang:nif_error(nif_not_loaded).
+submit_nif(_Ctx, _Opts, _Seed, _Bin) -> erlang:nif_error(nif_not_loaded).
+flush_nif(_Ctx) -> erlang:nif_error(nif_not_loaded).
+poll_nif(_Ctx, _Ticket) -> erlang:nif_error(nif_not_loaded).
 
 %% Dict: the options map of erlamsa_main:fuzzer/1 (seed, mutations, patterns, blockscale) plus first_case / device
 fuzz_batch(Bins, Dict) ->
@@ -35,9 +39,18 @@ fuzz_calls(Calls, Dict) ->
     {Bins, Seeds} = lists:unzip(Calls),
     split(fuzz_calls_nif(ctx(Dict), opts(Dict), Seeds, Bins)).
 
+%% Request coalescing for erlamsa_fsupervisor-style services: every request process submits and then polls; a timer
+%% process calls flush/1 every ~200 us (a full batch launches itself).  poll/2 -> {ok, Status, Bin} | again.
+submit(Bin, Seed, Dict) -> submit_nif(ctx(Dict), opts(Dict), Seed, Bin).
+flush(Dict) -> flush_nif(ctx(Dict)).
+poll(Ticket, Dict) -> poll_nif(ctx(Dict), Ticket).
+
+%% One GPU context per node, shared by all processes (the NIF serialises batches on it; coalescing needs the
+%% requests of different processes in the same context).  #{hip_ctx => C} overrides it.
+ctx(#{hip_ctx := C}) -> C;
 ctx(Dict) ->
-    case get(erlamsa_hip_ctx) of
-        undefined -> {ok, C} = open(maps:get(device, Dict, 0)), put(erlamsa_hip_ctx, C), C;
+    case persistent_term:get(erlamsa_hip_ctx, undefined) of
+        undefined -> {ok, C} = open(maps:get(device, Dict, 0)), persistent_term:put(erlamsa_hip_ctx, C), C;
         C -> C
     end.
 

@@ -46,7 +46,8 @@ enum eh_error {
   EH_E_HIP = -3,          /* a HIP runtime call failed (see eh_last_error) */
   EH_E_NOMEM = -4,
   EH_E_STATE = -5,        /* call order: configure -> corpus -> fuzz -> result */
-  EH_E_UNSUPPORTED = -6   /* option names a mutator/pattern this build does not run on the GPU */
+  EH_E_UNSUPPORTED = -6,  /* option names a mutator/pattern this build does not run on the GPU */
+  EH_E_AGAIN = -7         /* eh_poll: the request has not been launched yet (eh_flush it) */
 };
 
 /* per-case status (eh_result_*) */
@@ -118,6 +119,26 @@ int eh_fuzz_batch(eh_ctx* ctx, const int64_t seed[3], uint64_t first_case, uint6
 /* Case i is its own fuzzer/1 run (n = 1) with seed seeds[3i..3i+2] (host pointer). */
 int eh_fuzz_calls(eh_ctx* ctx, const int64_t* seeds, uint64_t corpus_first, uint64_t n, void* stream);
 int eh_sync(eh_ctx* ctx);
+
+/* Request coalescing for services — what erlamsa_fsupervisor / erlamsa_esi do one request at a time
+ * (erlamsa_esi.erl:86-95 call_fuzzer/3 -> erlamsa_fsupervisor:get_fuzzing_output/1, erlamsa_fsupervisor.erl:60-86: one
+ * erlamsa_app:fuzz(Bin, #{seed => S}) per HTTP request).  Requests from any number of host threads are collected and
+ * run as ONE eh_fuzz_calls batch; every request keeps the result it would have had alone (a case is a pure function of
+ * its seed, its input and the configuration).
+ *   eh_submit  copies the request into the pending batch and returns its ticket; when the pending batch reaches
+ *              `flush_cases` requests or `flush_bytes` input bytes (eh_coalesce_limits, defaults 4096 / 64 MiB) it is
+ *              launched at once.
+ *   eh_flush   launches whatever is pending (what a service calls from its 200 us timer); no-op when nothing is.
+ *   eh_poll    result of one request: EH_OK (out/out_len/status filled, the ticket is consumed), EH_E_AGAIN when the
+ *              ticket is still pending (not flushed yet), EH_E_INVALID for an unknown or already consumed ticket or when
+ *              `cap` is too small (out_len then says how much is needed and the ticket stays valid).  Waits for the
+ *              batch the ticket was launched in.
+ * The three calls are thread safe with respect to each other; they use the context's corpus slot and result buffers,
+ * so a context used for coalescing is not used for eh_fuzz_batch at the same time. */
+int eh_coalesce_limits(eh_ctx* ctx, uint64_t flush_cases, uint64_t flush_bytes);
+int eh_submit(eh_ctx* ctx, const uint8_t* data, uint64_t len, const int64_t seed[3], uint64_t* ticket);
+int eh_flush(eh_ctx* ctx);
+int eh_poll(eh_ctx* ctx, uint64_t ticket, uint8_t* out, uint64_t cap, uint64_t* out_len, int32_t* status);
 
 /* Device-side view of the last batch: out_data[out_off[i] .. out_off[i]+out_len[i]) is the
  * output of case i.  Pointers stay valid until the next eh_fuzz_* call on this context. */

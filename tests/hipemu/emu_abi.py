@@ -97,4 +97,24 @@ e3.close()
 names = [m[0] for m in ea.mutator_table()]
 assert names[0] == "sgm" and names[-1] == "nil" and len(names) == 41
 assert [p[0] for p in ea.pattern_table()] == ["od", "nd", "bu", "sk", "sz", "cs", "ar", "cp", "co", "nu"]
+# ---- request coalescing: tickets from interleaved submits get what each request gets alone (eh_fuzz_calls semantics)
+ec = ea.Engine(0)
+ec.configure(mutations="bd,bf,sr,num,ld", patterns="od,nd,bu")
+reqs = [(inputs[i % len(inputs)], (100 + i, 7 * i + 1, 3 * i + 2)) for i in range(23)]
+seeds = np.array([s for _, s in reqs], dtype=np.int64)
+dq, oq = po.pack([b for b, _ in reqs])
+wantq, wstq, _, _ = po.fuzz_batch(dq, oq, seeds=seeds, mutations="bd,bf,sr,num,ld", patterns="od,nd,bu")
+ec.coalesce_limits(8, 1 << 20)                       # a launch every 8 requests
+tickets = [ec.submit(b, s) for b, s in reqs]          # 23 requests: two full batches launched, 7 pending
+assert len(set(tickets)) == 23
+assert ec.poll(tickets[-1]) is None                   # still pending: EH_E_AGAIN
+assert ec.poll(tickets[3]) == (int(wstq[3]), wantq[3])      # first batch (already collected when the second was launched)
+assert ec.poll(tickets[12]) == (int(wstq[12]), wantq[12])   # second batch: waits for it
+ec.flush()
+for k in (22, 0, 17, 9):
+    assert ec.poll(tickets[k]) == (int(wstq[k]), wantq[k]), k
+assert code(ec.poll, tickets[0]) == -1                # consumed
+assert code(ec.poll, 999999) == -1                    # unknown
+ec.flush()                                            # nothing pending: no-op
+ec.close()
 print("abi behaviour ok")

@@ -37,12 +37,14 @@ int enif_inspect_binary(ErlNifEnv*, ERL_NIF_TERM, ErlNifBinary*);
 unsigned char* enif_make_new_binary(ErlNifEnv*, size_t, ERL_NIF_TERM*);
 ERL_NIF_TERM enif_make_atom(ErlNifEnv*, const char*);
 ERL_NIF_TERM enif_make_int(ErlNifEnv*, int);
+ERL_NIF_TERM enif_make_uint64(ErlNifEnv*, ErlNifUInt64);
 ERL_NIF_TERM enif_make_string(ErlNifEnv*, const char*, ErlNifCharEncoding);
 ERL_NIF_TERM enif_make_badarg(ErlNifEnv*);
 ERL_NIF_TERM enif_make_list(ErlNifEnv*, unsigned cnt, ...);
 ERL_NIF_TERM enif_make_list_cell(ErlNifEnv*, ERL_NIF_TERM, ERL_NIF_TERM);
 ERL_NIF_TERM enif_make_tuple(ErlNifEnv*, unsigned cnt, ...);
 #define enif_make_tuple2(env, a, b) enif_make_tuple(env, 2, a, b)
+#define enif_make_tuple3(env, a, b, c) enif_make_tuple(env, 3, a, b, c)
 #define ERL_NIF_INIT(MOD, FUNCS, LOAD, RELOAD, UPGRADE, UNLOAD) \
   const ErlNifFunc* erl_nif_stub_funcs_##MOD(void) { (void)(LOAD); return FUNCS; }
 /* erl_nif.h: thread API */
