@@ -375,3 +375,66 @@ def test_ordered_output_flag():
         assert hip.hipMemcpy(ctypes.c_void_p(offs.ctypes.data), ctypes.c_void_p(optr), ctypes.c_size_t(n * 8), 2) == 0     # device to host
         assert offs.tolist() == np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.uint64).tolist()
     eng.close()
+
+
+def test_download_in_many_chunks_and_into_caller_memory():
+    """eh_result_download gathers case-ordered chunks on the device into two alternating bounce buffers and copies chunk k
+    out while chunk k+1 is gathered: forced to ~200 small chunks here, plus download_into a caller buffer."""
+    import os
+    import pyoracle as po
+    inputs = util.corpus_mixed(2500, 600, seed=12) + [b"", b"z"]
+    data, off = po.pack(inputs)
+    muts = "bd=3,bf,bi=7,sr,ld,num,lr"
+    ora = util.oracle_batch(data, off, seed=(5, 5, 5), mutations=muts, patterns="od,nd,bu", max_case_bytes=8 << 20)
+    if util.priming():
+        pytest.skip("oracle cache primed")
+    import erlamsa_amd as ea
+    n = len(inputs)
+    eng = ea.Engine(0)
+    eng.configure(mutations=muts, patterns="od,nd,bu", max_case_bytes=8 << 20)
+    eng.upload_corpus(data, off)
+    eng.fuzz_batch(seed=(5, 5, 5))
+    whole, st = eng.download()
+    assert all(st[i] == ora.status[i] and ora.same(i, whole[i]) for i in range(n) if st[i] not in (2, 3) and ora.status[i] not in (2, 3))
+    os.environ["EH_DL_CHUNK"] = "16384"
+    try:
+        chunked, st2 = eng.download()
+        _, total, _ = eng.totals()
+        buf = np.full(total + 64, 0xAB, dtype=np.uint8)
+        offs, st3 = eng.download_into(buf.ctypes.data, total)
+    finally:
+        del os.environ["EH_DL_CHUNK"]
+    assert chunked == whole and list(st2) == list(st) and list(st3) == list(st)
+    assert int(offs[-1]) == total and bytes(buf[:total]) == b"".join(whole) and (buf[total:] == 0xAB).all()
+    eng.close()
+
+
+def test_request_coalescing_submit_flush_poll():
+    """eh_submit / eh_flush / eh_poll: single requests collected into eh_fuzz_calls batches; every ticket gets the bytes
+    the request gets alone (erlamsa_app:fuzz(Bin, #{seed => S}) per request, erlamsa_fsupervisor.erl:60-86)."""
+    import pyoracle as po
+    n = 300
+    inputs = util.corpus_mixed(n, 400, seed=33)
+    data, off = po.pack(inputs)
+    rng = np.random.Generator(np.random.PCG64(5))
+    seeds = rng.integers(1, 99999, size=(n, 3)).astype(np.int64)
+    muts = "bd,bf,bi,sr,sd,num,ld,lr,ab,uw"
+    ora = util.oracle_batch(data, off, seeds=seeds, mutations=muts, patterns="od,nd,bu", max_case_bytes=8 << 20)
+    if util.priming():
+        pytest.skip("oracle cache primed")
+    import erlamsa_amd as ea
+    eng = ea.Engine(0)
+    eng.configure(mutations=muts, patterns="od,nd,bu", max_case_bytes=8 << 20)
+    eng.coalesce_limits(64, 1 << 20)
+    tickets = [eng.submit(inputs[i], tuple(int(x) for x in seeds[i])) for i in range(n)]      # 4 full batches + 44 pending
+    assert eng.poll(tickets[-1]) is None
+    eng.flush()
+    order = list(rng.permutation(n))
+    for i in order:
+        st, out = eng.poll(tickets[i], cap=1 << 12)
+        if st in (2, 3) or ora.status[i] in (2, 3):
+            continue
+        assert st == ora.status[i] and ora.same(i, out), i
+    with pytest.raises(ea.EngineError):
+        eng.poll(tickets[0])
+    eng.close()
