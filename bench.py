@@ -64,7 +64,14 @@ def cpu_baseline_leg(mat, seed, muts, pats, args):
     for t in ts:
         t.join()
     ct = time.perf_counter() - t0
-    return {"value": round(state["bytes"] / ct / 1e6, 3), "unit": "MB/s", "cores": threads, "kind": "port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), model)
+    except OSError:
+        pass
+    return {"value": round(state["bytes"] / ct / 1e6, 3), "unit": "MB/s", "cores": threads, "kind": "port", "cpu_model": model,
+            "host_cpus": os.cpu_count(),
             "cases_per_s": round(state["cases"] / ct, 2), "cases_cut_by_watchdog": state["timeouts"],
             "sample": "cases 1..%d of the same run (same corpus rows, seed, mutators, patterns, work-area limit), oracle/ C++ restatement, "
                       "%d threads, %.1f s wall; per-case watchdog %.0f s (maxrunningtime semantics: time counted, output <<>>)"

@@ -71,3 +71,13 @@ def test_model_and_oracle_agree_on_subsets_and_offsets():
     _diff(ins, (7, 8, 9), [("bd", 1), ("sr", 2), ("num", 5)], [("od", 1)])
     _diff(ins, (7, 8, 9), [("ld", 1), ("sp", 1)], [("nd", 1), ("bu", 3)], first_case=1001)
     _diff(ins, (3, 1, 4), [("bf", 4), ("bi", 4), ("ber", 4), ("br", 4), ("bei", 1), ("bed", 1)], [("bu", 1)])
+
+
+@pytest.mark.parametrize("seed", [(1459, 2919, 4379)])
+def test_model_and_oracle_agree_when_the_random_generator_is_drawn(seed):
+    """mux_generators picks `random` with probability 1/501 per run: these parent seeds do (with the 12 mutators selected),
+    so every case mutates a random_stream/1 instead of its input."""
+    ins = _inputs(64, 4)
+    want = pymodel.fuzzer(ins, seed, MUTS, PATS)
+    assert len({w[1] for w in want}) > 50 and all(w[1][:20] != i[:20] for w, i in zip(want[10:60], ins[10:60]))
+    _diff(ins, seed, MUTS, PATS)
