@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs golden vector sets through the engine and the oracle (with its meta trace) and prints the differing cases."""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import pyoracle as po
 import erlamsa_amd as ea
