@@ -438,3 +438,40 @@ def test_request_coalescing_submit_flush_poll():
     with pytest.raises(ea.EngineError):
         eng.poll(tickets[0])
     eng.close()
+
+
+def test_full_size_bench_workload_is_independent_of_tiers_and_slots():
+    """BASELINE configs[2] at its full size (65 536 x 4 KiB, the full default mutator table, no work budget — the bench
+    workload): two very different memory configurations (4 096 slots of 16 MiB vs 1 024 slots of 64 MiB, hence different
+    tier routing and re-runs) must agree on every case's status, output length and PRNG draw count, and byte for byte on a
+    4 096-case sample.  No oracle at this size (the CPU needs ~3 h for it); the oracle pins the same table on smaller sets."""
+    if util.priming():
+        pytest.skip("no oracle involved")
+    import hashlib
+    import erlamsa_amd as ea
+    from erlamsa_amd import synth
+    n = 65536
+    mat = synth.mixed(n, 4096)
+    data, off = synth.as_arena(mat)
+
+    def run(max_slots, case_mib):
+        eng = ea.Engine(0)
+        eng.configure(patterns="od,nd,bu", max_slots=max_slots, max_case_bytes=case_mib << 20, big_case_bytes=1 << 30, out_capacity=30 << 30)
+        eng.upload_corpus(data, off)
+        eng.fuzz_batch(seed=(1, 2, 3))
+        lens = np.zeros(n + 1, dtype=np.uint64)
+        st = np.zeros(n, dtype=np.int32)
+        eng._chk(eng.lib.eh_result_download(eng.h, None, 0, lens.ctypes.data, st.ctypes.data))
+        draws, _ = eng.diag()
+        eng.fuzz_batch(seed=(1, 2, 3), first_case=20001, corpus_first=20000, n=4096)
+        outs, st2 = eng.download()
+        eng.close()
+        return np.diff(lens), st, draws.copy(), [hashlib.sha1(o).digest() for o in outs], [int(x) for x in st2]
+
+    a = run(0, 16)
+    b = run(1024, 64)
+    assert (a[1] == b[1]).all(), "statuses differ at %s" % np.nonzero(a[1] != b[1])[0][:10]
+    ok = a[1] == 0
+    assert (a[0][ok] == b[0][ok]).all() and (a[2][ok] == b[2][ok]).all()
+    assert a[4] == b[4] and a[3] == b[3]
+    assert ok.mean() > 0.995 and int(a[0].sum()) > 15 << 30          # the workload really is the heavy one
