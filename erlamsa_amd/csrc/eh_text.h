@@ -307,7 +307,8 @@ __device__ __noinline__ int muta_st_line(Ctx&, int fn, StState* st) {
       wave_sync();
     }
     if (l == 0) st->count = count;
-  } else {
+  }
+  {                                                                   // clause 1 recurses into clause 2: also on the filling call
     uint32_t up = rng_erand(c.rng, 20);
     if (up < 10) {
       uint32_t ep = rng_erand(c.rng, N);

@@ -512,9 +512,11 @@ int st_line_muta(Ctx& c, BList& ll, Muta& m) {                                //
   if (!try_lines(ll[0], &ls)) return -1;
   size_t n = ls.size();
   // step_state/3 erlamsa_generic.erl:123-139
-  if (m.st_count < 10) {
-    while (m.st_count < 10) { uint64_t p = c.rnd.erand(n); m.st_lines.insert(m.st_lines.begin(), stline_of(ls[p - 1])); m.st_count++; }
-  } else {
+  // clause 1 (:123-129) fills the store and RECURSES: once the count reaches 10 the same call goes on into clause 2
+  // (:130-139), so the update draw happens on the filling call as well.  (Rounds 1-2 of this oracle skipped it there;
+  // tests/pymodel.py, the independent model, found the difference.)
+  while (m.st_count < 10) { uint64_t p = c.rnd.erand(n); m.st_lines.insert(m.st_lines.begin(), stline_of(ls[p - 1])); m.st_count++; }
+  {
     uint64_t up = c.rnd.erand(20);
     if (up < 10) {
       uint64_t ep = c.rnd.erand(n);

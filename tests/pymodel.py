@@ -1,6 +1,6 @@
 """An independent Python model of a subset of erlamsa_main:fuzzer/1, written from the reference's .erl sources (cited per
 function) WITHOUT consulting oracle/oracle.cpp: paths = [direct], generators direct + random, patterns od / nd / bu, and
-the mutators bd bei bed bf bi ber br sp sr sd ld num.  tests/test_pymodel.py diffs it against the C++ oracle.
+the mutators uw ui num bd bei bed bf bi ber br sp sr sd snand srnd ld lds lr2 lri lr ls lp lis lrs nil.  tests/test_pymodel.py diffs it against the C++ oracle.
 
 Everything is a literal, clause-by-clause transcription — Erlang lists are Python lists, binaries are bytes, lazy
 stream tails are forced in the order erlamsa_out:blocks_port forces them.  OTP pieces (random, lists:sort/2) are
@@ -401,13 +401,170 @@ def list_del(rnd, l, length):                                              # erl
     return l[:p - 1] + l[p:]
 
 
-def make_table(rnd):
-    """mutation functions by name; each: ll -> (ll', delta)"""
+def applynth(i, l, fun):                                                   # erlamsa_utils.erl:188-190 (1-based)
+    if i < 1 or i > len(l):
+        raise ErlCrash("applynth: function_clause")
+    return l[:i - 1] + fun(l[i - 1], l[i:])
+
+
+# erlamsa_generic.erl:54-116
+def list_del_seq(rnd, l, length):
+    start = rnd.erand(length)
+    n = rnd.erand(length - start + 1)
+    return applynth(start, l, lambda _e, r: r[n - 1:n - 1 + length])          # lists:sublist(R, N, Len)
+
+
+def list_dup(rnd, l, length):
+    return applynth(rnd.erand(length), l, lambda e, r: [e, e] + r)
+
+
+def list_repeat(rnd, l, length):
+    p = rnd.erand(length)
+    n = max(2, rnd.rand_log(10))
+    return applynth(p, l, lambda e, r: [e] * n + r)
+
+
+def list_clone(rnd, l, length):
+    frm = rnd.erand(length)
+    to = rnd.erand(length)
+    elem = l[frm - 1]
+    return applynth(to, l, lambda _e, r: [elem] + r)
+
+
+def list_swap(rnd, l, length):
+    if length < 2:
+        return l
+    return applynth(rnd.erand(length - 1), l, lambda e, r: [r[0], e] + r[1:])
+
+
+def list_perm(rnd, l, length):
+    if length < 3:
+        return l
+    frm = rnd.erand(length - 1)
+    a = rnd.rand_range(2, length - frm)
+    b = rnd.rand_log(10)
+    n = max(2, min(a, b))
+
+    def f(e, r):
+        if n - 1 > len(r):
+            raise ErlCrash("lists:split badarg")
+        return rnd.random_permutation([e] + r[:n - 1]) + r[n - 1:]
+    return applynth(frm, l, f)
+
+
+def flat(x):                                                               # iolist of a stored line -> bytes
+    out = bytearray()
+    stack = [x]
+    while stack:
+        y = stack.pop()
+        if isinstance(y, list):
+            stack.extend(reversed(y))
+        else:
+            out.append(y)
+    return bytes(out)
+
+
+def step_state(rnd, st, l, length):                                        # erlamsa_generic.erl:121-139
+    while st[0] < 10:
+        p = rnd.erand(length)
+        st = [st[0] + 1, l[p - 1]] + st[1:]
+    up = rnd.erand(20)
+    if up < 10:
+        new = l[rnd.erand(length) - 1]
+
+        def f(e, r):
+            if not isinstance(e, list) or not e:
+                raise ErlCrash("step_state: function_clause")
+            return [[new] + e[1:]] + r                                     # [[New | T] | R]: an iolist
+        return applynth(up + 1, st, f)
+    return st
+
+
+def st_list_mod(rnd, st, l, fun):                                          # :146-153
+    n = len(l)
+    stp = step_state(rnd, st, l, n)
+    x = stp[1:][rnd.erand(stp[0]) - 1]                                     # pick_state/1
+    p = rnd.erand(n)
+    return stp, applynth(p, l, fun(x))
+
+
+def st_line_muta(rnd, ll, st, fun):                                        # construct_st_line_muta :366-378
+    h, t = ll[0], ll[1:]
+    ls = lines(h)
+    if ls == [] or binarish(h):
+        return ll, -1, st
+    stp, newls = st_list_mod(rnd, st, ls, fun)
+    return [b"".join(flat(x) for x in newls)] + t, 1, stp
+
+
+def funny_unicode():                                                       # :1051-1078
+    manual = [[239, 191, 191], [240, 144, 128, 128], [0xef, 0xbb, 0xbf], [0xfe, 0xff], [0xff, 0xfe], [0, 0, 0xff, 0xff],
+              [0xff, 0xff, 0, 0], [43, 47, 118, 56], [43, 47, 118, 57], [43, 47, 118, 43], [43, 47, 118, 47], [247, 100, 76],
+              [221, 115, 102, 115], [14, 254, 255], [251, 238, 40], [251, 238, 40, 255], [132, 49, 149, 51]]
+    codes = [[0x0009, 0x000d], 0x008D, 0x00a0, 0x1680, 0x180e, [0x2000, 0x200a], 0x2028, 0x2029, 0x202f, 0x205f, 0x3000,
+             [0x200e, 0x200f], [0x202a, 0x202e], [0x200c, 0x200d], 0x0345, 0x00b7, [0x02d0, 0x02d1], 0xff70, [0x02b0, 0x02b8],
+             0xfdd0, 0x034f, [0x115f, 0x1160], [0x2065, 0x2069], 0x3164, 0xffa0, 0xe0001, [0xe0020, 0xe007f], [0x0e40, 0x0e44],
+             0x1f4a9]
+    numbers = []
+    for c in codes:                                                        # foldl: seq(X,Y) ++ Acc | [X | Acc]
+        numbers = (list(range(c[0], c[1] + 1)) if isinstance(c, list) else [c]) + numbers
+
+    def ext(n):
+        return (n & 0x3f) | 0x80
+
+    def enc(pt):                                                           # encode_point/1 :1034-1048
+        if pt < 0x80:
+            return [pt]
+        if pt < 0x800:
+            return [0xc0 | (0x1f & (pt >> 6)), ext(pt)]
+        if pt < 0x10000:
+            return [0xe0 | (0x0f & (pt >> 12)), ext(pt >> 6), ext(pt)]
+        return [0xf0 | (7 & (pt >> 18)), ext(pt >> 12), ext(pt >> 6), ext(pt)]
+    return manual + [enc(x) for x in numbers]
+
+
+FUNNY = funny_unicode()
+
+
+def randmask(rnd, maskfun, bs):                                            # :281-293
+    prob = rnd.erand(100)
+    flag = rnd.rand_occurs_fixed(prob, 100)
+    out = []
+    for b in bs:
+        nxt = rnd.rand_occurs_fixed(prob, 100)                             # argument order: the next flag is drawn first
+        out.append(maskfun(b) if flag else b)
+        flag = nxt
+    return out
+
+
+def make_table(rnd, snand_mask):
+    """mutation functions by name; each: (ll, state) -> (ll', delta, state')"""
     def sr(h, bs, t, btail):                                               # construct_sed_bytes_repeat :273-281
         n = max(2, rnd.rand_log(10))
         return [h + bs * n + t] + btail
 
-    return {
+    masks = {"mask_nand": lambda b: b & ~(1 << rnd.rand(8)) & 255, "mask_or": lambda b: b | (1 << rnd.rand(8)),
+             "mask_xor": lambda b: b ^ (1 << rnd.rand(8)), "mask_replace": lambda b: rnd.rand(256)}       # :295-307
+
+    def uw(ll):                                                            # sed_utf8_widen :1081-1089
+        return sed_byte(rnd, ll, lambda b: bytes([0xC0, b | 0x80]) if b == b & 0x3f else bytes([b]))
+
+    def ui(ll):                                                            # sed_utf8_insert :1092-1099
+        h, t = ll[0], ll[1:]
+        p = rnd.rand(len(h))
+        d = rnd.rand_delta()
+        ins = bytes(rnd.rand_elem(FUNNY))
+        if h == b"":
+            return [h] + t, d
+        return [h[:p + 1] + ins + h[p + 1:]] + t, d
+
+    def stateless(f):
+        return lambda ll, st: f(ll) + (st,)
+
+    def line(op):
+        return stateless(lambda ll: line_muta(rnd, ll, lambda ls, n: op(rnd, ls, n)))
+
+    tab = {
         "num": lambda ll: sed_num(rnd, ll),
         "bd": lambda ll: sed_byte(rnd, ll, lambda b: b""),
         "bei": lambda ll: sed_byte(rnd, ll, lambda b: bytes([(b + 1) & 255])),
@@ -419,13 +576,22 @@ def make_table(rnd):
         "sp": lambda ll: sed_bytes(rnd, ll, lambda h, bs, t, bt: [h + bytes(rnd.random_permutation(list(bs))) + t] + bt),
         "sr": lambda ll: sed_bytes(rnd, ll, sr),
         "sd": lambda ll: sed_bytes(rnd, ll, lambda h, bs, t, bt: [h + t] + bt),
-        "ld": lambda ll: line_muta(rnd, ll, lambda ls, n: list_del(rnd, ls, n)),
+        "snand": lambda ll: sed_bytes(rnd, ll, lambda h, bs, t, bt: [h + bytes(randmask(rnd, masks[snand_mask], list(bs))) + t] + bt),
+        "srnd": lambda ll: sed_bytes(rnd, ll, lambda h, bs, t, bt: [h + bytes(randmask(rnd, masks["mask_replace"], list(bs))) + t] + bt),
+        "uw": uw, "ui": ui,
+        "nil": lambda ll: (ll, -1),                                        # nomutation/2 :1104-1105
     }
+    tab = {k: stateless(v) for k, v in tab.items()}
+    tab.update({"ld": line(list_del), "lds": line(list_del_seq), "lr2": line(list_dup), "lri": line(list_clone),
+                "lr": line(list_repeat), "ls": line(list_swap), "lp": line(list_perm),
+                "lis": lambda ll, st: st_line_muta(rnd, ll, st, lambda x: lambda t, r: [x, t] + r),          # st_list_ins :156-158
+                "lrs": lambda ll, st: st_line_muta(rnd, ll, st, lambda x: lambda _t, r: [x] + r)})           # st_list_replace :161-163
+    return tab
 
 
 # table order of mutations/1 (:1290-1331), restricted to what this model implements
-TABLE_ORDER = ["num", "bd", "bei", "bed", "bf", "bi", "ber", "br", "sp", "sr", "sd", "ld"]
-DEFAULT_PRI = {"num": 3}
+TABLE_ORDER = ["uw", "ui", "num", "bd", "bei", "bed", "bf", "bi", "ber", "br", "sp", "sr", "sd", "snand", "srnd",
+               "ld", "lds", "lr2", "lri", "lr", "ls", "lp", "lis", "lrs", "nil"]
 
 
 def adjust_priority(pri, delta):                                           # :1240-1242
@@ -433,7 +599,7 @@ def adjust_priority(pri, delta):                                           # :12
 
 
 def weighted_permutations(rnd, pris):                                      # :1246-1250
-    ppris = [(rnd.rand(math.trunc(s * p)), (s, p, name)) for (s, p, name) in pris]
+    ppris = [(rnd.rand(math.trunc(x[0] * x[1])), x) for x in pris]
     return [x for _, x in lists_sort(lambda a, b: a[0] >= b[0], ppris)]
 
 
@@ -448,9 +614,9 @@ def mux_fuzzers(rnd, table, fs, ll):
         node, tail = nodes[0], nodes[1:]
         if len(ll[0]) > ABSMAX_BINARY_BLOCK:
             return out + tail, ll
-        score, pri, name = node
-        mll, delta = table[name](ll)
-        out = [(adjust_priority(score, delta), pri, name)] + out
+        score, pri, name, st = node
+        mll, delta, st = table[name](ll, st)
+        out = [(adjust_priority(score, delta), pri, name, st)] + out
         if mll[0] == ll[0]:
             nodes = tail
             continue
@@ -565,7 +731,7 @@ def fuzzer(inputs, seed, mutations, patterns, blockscale=1.0, first_case=1):
     # construct_sed_bytes_randmask/1 (:311-312) for snand and srnd, and each draws its MaskFun with rand_elem/1 — two draws
     # of the parent stream whether or not those mutators are selected.  (The first version of this model missed them;
     # diffing against the oracle found it — the oracle had it right.)
-    parent.rand_elem(["mask_nand", "mask_or", "mask_xor"])
+    snand_mask = parent.rand_elem(["mask_nand", "mask_or", "mask_xor"])
     parent.rand_elem(["mask_replace"])
     sel = dict(mutations)
     mutas = []
@@ -575,7 +741,7 @@ def fuzzer(inputs, seed, mutations, patterns, blockscale=1.0, first_case=1):
     fs = []
     for pri, name in mutas:
         n = parent.rand(math.trunc(MAX_SCORE))
-        fs.insert(0, (max(2, n), pri, name))
+        fs.insert(0, (max(2, n), pri, name, [0]))                          # [0]: InitialState of lis / lrs, unused elsewhere
     # make_generator/5 :244-247 with Args = [direct]: random (1) and direct (500) survive; mux_generators/2 :193-199
     gens, total = sort_by_priority([(1, "random"), (500, "direct")])
     gen = choose_pri(gens, parent.rand(total))
@@ -594,7 +760,7 @@ def fuzzer(inputs, seed, mutations, patterns, blockscale=1.0, first_case=1):
         tseed = parent.gen_predictable_seed()                              # :179
         rnd = Rnd()
         rnd.seed(tseed)                                                    # :183
-        table = make_table(rnd)
+        table = make_table(rnd, snand_mask)
         try:
             ll = direct_generator(rnd, data, blockscale) if gen == "direct" else random_stream(rnd, blockscale)   # :185
             pat = choose_pri(spats, rnd.rand(ptotal))                      # choose_pattern_fun :431-434

@@ -1,7 +1,7 @@
 """Oracle pinning, part 3: two independent models agree.
 
 tests/pymodel.py is a Python model of erlamsa_main:fuzzer/1 (set-up, direct/random generators, patterns od/nd/bu,
-twelve mutators) transcribed from the reference's .erl sources without consulting oracle/oracle.cpp.  Here it is diffed
+25 mutators) transcribed from the reference's .erl sources without consulting oracle/oracle.cpp.  Here it is diffed
 against the C++ oracle on 15 000 cases.  What both share is the author's reading of OTP's `random` and lists:sort/2 —
 the part only a BEAM run can pin (tests/golden/capture.escript)."""
 import os
@@ -14,7 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import pymodel
 import pyoracle as po
 
-MUTS = [("num", 3), ("bd", 1), ("bei", 1), ("bed", 1), ("bf", 1), ("bi", 1), ("ber", 1), ("br", 1), ("sp", 1), ("sr", 1), ("sd", 1), ("ld", 1)]
+MUTS = [("uw", 1), ("ui", 2), ("num", 3), ("bd", 1), ("bei", 1), ("bed", 1), ("bf", 1), ("bi", 1), ("ber", 1), ("br", 1), ("sp", 1), ("sr", 1),
+        ("sd", 1), ("snand", 1), ("srnd", 1), ("ld", 1), ("lds", 1), ("lr2", 1), ("lri", 1), ("lr", 1), ("ls", 1), ("lp", 1), ("lis", 1),
+        ("lrs", 1), ("nil", 0)]
 PATS = [("od", 1), ("nd", 2), ("bu", 1)]
 
 
@@ -70,12 +72,14 @@ def test_model_and_oracle_agree_on_subsets_and_offsets():
     ins = _inputs(400, 9)
     _diff(ins, (7, 8, 9), [("bd", 1), ("sr", 2), ("num", 5)], [("od", 1)])
     _diff(ins, (7, 8, 9), [("ld", 1), ("sp", 1)], [("nd", 1), ("bu", 3)], first_case=1001)
+    _diff(ins, (2, 7, 1), [("lis", 2), ("lrs", 2), ("lp", 1), ("lds", 1), ("snand", 3), ("srnd", 1), ("ui", 1), ("uw", 1)], PATS)
+    _diff(ins, (5, 5, 5), [("lis", 1), ("lrs", 1)], [("nd", 1), ("bu", 1)])          # state carried across the calls of a case
     _diff(ins, (3, 1, 4), [("bf", 4), ("bi", 4), ("ber", 4), ("br", 4), ("bei", 1), ("bed", 1)], [("bu", 1)])
 
 
-@pytest.mark.parametrize("seed", [(1459, 2919, 4379)])
+@pytest.mark.parametrize("seed", [(338, 677, 1016)])
 def test_model_and_oracle_agree_when_the_random_generator_is_drawn(seed):
-    """mux_generators picks `random` with probability 1/501 per run: these parent seeds do (with the 12 mutators selected),
+    """mux_generators picks `random` with probability 1/501 per run: this parent seed does (with the 25 mutators selected),
     so every case mutates a random_stream/1 instead of its input."""
     ins = _inputs(64, 4)
     want = pymodel.fuzzer(ins, seed, MUTS, PATS)
