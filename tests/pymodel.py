@@ -1,6 +1,6 @@
 """An independent Python model of a subset of erlamsa_main:fuzzer/1, written from the reference's .erl sources (cited per
 function) WITHOUT consulting oracle/oracle.cpp: paths = [direct], generators direct + random, patterns od / nd / bu, and
-the mutators uw ui num bd bei bed bf bi ber br sp sr sd snand srnd ld lds lr2 lri lr ls lp lis lrs nil.  tests/test_pymodel.py diffs it against the C++ oracle.
+the mutators uw ui num bd bei bed bf bi ber br sp sr sd snand srnd ld lds lr2 lri lr ls lp lis lrs ft fn fo nil.  tests/test_pymodel.py diffs it against the C++ oracle.
 
 Everything is a literal, clause-by-clause transcription — Erlang lists are Python lists, binaries are bytes, lazy
 stream tails are forced in the order erlamsa_out:blocks_port forces them.  OTP pieces (random, lists:sort/2) are
@@ -537,6 +537,91 @@ def randmask(rnd, maskfun, bs):                                            # :28
     return out
 
 
+# ------------------------------------------------------------------------------------------------ erlamsa_fuse.erl
+# A suffix of a list is represented by its start position (len = the empty suffix []): suffixes of one list have distinct
+# lengths, so the value comparisons of the reference (jump/3's first clause, fix_empty_list/1) are position comparisons.
+def char_suffixes(x, sufs):                                                # :62-71 -> {char: [suffix, ...]} (latest first)
+    subs = {}
+    for p in sufs:
+        if p == len(x):
+            continue                                                       # ([], Subs) -> Subs
+        el = [p + 1] + subs.get(x[p], [])
+        if el == [len(x)]:
+            el = []                                                        # fix_empty_list([[]]) -> []
+        subs[x[p]] = el
+    return subs
+
+
+def fuse_split(a, b, node, acc):                                           # split/2 :85-100
+    froms, tos = node
+    sas, sbs = char_suffixes(a, froms), char_suffixes(b, tos)
+    for ch in sorted(sas):                                                 # gb_trees:to_list/1: ascending keys
+        sufs = sas[ch]
+        if sufs == []:
+            acc = [([len(a)], [len(b)])] + acc                             # [[[]], []]
+        elif ch in sbs:
+            acc = [(sufs, sbs[ch])] + acc
+    return acc
+
+
+def fuse(rnd, al, bl):                                                     # fuse/2 :131-134
+    if not al:
+        return bl
+    if not bl:
+        return al
+    nodes = [(list(range(len(al))), list(range(len(bl))))]                 # find_jump_points/2 :103-107 (non-empty suffixes)
+    fuel = 100000
+    while True:                                                            # find_jump_points_loop/2 :115-128
+        if fuel < 0:
+            break
+        if rnd.rand(8) == 0:
+            break
+        nodesp = []
+        for nd in nodes:
+            nodesp = fuse_split(al, bl, nd, nodesp)
+        if not nodesp:
+            break
+        nodes, fuel = nodesp, fuel - len(nodesp)
+    froms, tos = rnd.rand_elem(nodes)                                      # any_position_pair/1 :73-77
+    frm = rnd.rand_elem(froms)
+    to = rnd.rand_elem(tos)
+    frm = len(al) if frm == [] else frm                                    # rand_elem([]) -> [] = the empty suffix
+    to = len(bl) if to == [] else to
+    return al[:frm] + bl[to:]                                              # jump/3 :47-50
+
+
+def halve(l):                                                              # erlamsa_utils.erl:136-145
+    k = len(l) // 2
+    return l[:k], l[k:]
+
+
+def sed_fuse_this(rnd, ll, st):                                            # :386-390
+    b = fuse(rnd, ll[0], ll[0])
+    return [b] + ll[1:], rnd.rand_delta(), st
+
+
+def sed_fuse_next(rnd, ll, st):                                            # :393-402
+    h, t = ll[0], ll[1:]
+    al1, al2 = halve(h)
+    b, rest = (t[0], t[1:]) if t else (h, [])                              # uncons(T, H)
+    abl = fuse(rnd, al1, b)
+    abal = fuse(rnd, abl, al2)
+    d = rnd.rand_delta()
+    return flush_bvecs(abal, rest), d, st
+
+
+def sed_fuse_old(rnd, ll, st):                                             # :405-427, state = the remembered block
+    h, t = ll[0], ll[1:]
+    block = h if st is None else st
+    al1, al2 = halve(h)
+    ol1, ol2 = halve(block)
+    a = fuse(rnd, al1, ol1)
+    b = fuse(rnd, ol2, al2)
+    swap = rnd.rand(3)
+    d = rnd.rand_delta()
+    return flush_bvecs(a, flush_bvecs(b, t)), d, (h if swap == 0 else block)
+
+
 def make_table(rnd, snand_mask):
     """mutation functions by name; each: (ll, state) -> (ll', delta, state')"""
     def sr(h, bs, t, btail):                                               # construct_sed_bytes_repeat :273-281
@@ -584,6 +669,8 @@ def make_table(rnd, snand_mask):
     tab = {k: stateless(v) for k, v in tab.items()}
     tab.update({"ld": line(list_del), "lds": line(list_del_seq), "lr2": line(list_dup), "lri": line(list_clone),
                 "lr": line(list_repeat), "ls": line(list_swap), "lp": line(list_perm),
+                "ft": lambda ll, st: sed_fuse_this(rnd, ll, st), "fn": lambda ll, st: sed_fuse_next(rnd, ll, st),
+                "fo": lambda ll, st: sed_fuse_old(rnd, ll, st),
                 "lis": lambda ll, st: st_line_muta(rnd, ll, st, lambda x: lambda t, r: [x, t] + r),          # st_list_ins :156-158
                 "lrs": lambda ll, st: st_line_muta(rnd, ll, st, lambda x: lambda _t, r: [x] + r)})           # st_list_replace :161-163
     return tab
@@ -591,7 +678,7 @@ def make_table(rnd, snand_mask):
 
 # table order of mutations/1 (:1290-1331), restricted to what this model implements
 TABLE_ORDER = ["uw", "ui", "num", "bd", "bei", "bed", "bf", "bi", "ber", "br", "sp", "sr", "sd", "snand", "srnd",
-               "ld", "lds", "lr2", "lri", "lr", "ls", "lp", "lis", "lrs", "nil"]
+               "ld", "lds", "lr2", "lri", "lr", "ls", "lp", "lis", "lrs", "ft", "fn", "fo", "nil"]
 
 
 def adjust_priority(pri, delta):                                           # :1240-1242
@@ -741,7 +828,7 @@ def fuzzer(inputs, seed, mutations, patterns, blockscale=1.0, first_case=1):
     fs = []
     for pri, name in mutas:
         n = parent.rand(math.trunc(MAX_SCORE))
-        fs.insert(0, (max(2, n), pri, name, [0]))                          # [0]: InitialState of lis / lrs, unused elsewhere
+        fs.insert(0, (max(2, n), pri, name, None if name == "fo" else [0]))   # [0]: InitialState of lis / lrs; fo: no block remembered yet
     # make_generator/5 :244-247 with Args = [direct]: random (1) and direct (500) survive; mux_generators/2 :193-199
     gens, total = sort_by_priority([(1, "random"), (500, "direct")])
     gen = choose_pri(gens, parent.rand(total))
