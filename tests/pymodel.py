@@ -1,5 +1,6 @@
 """An independent Python model of a subset of erlamsa_main:fuzzer/1, written from the reference's .erl sources (cited per
-function) WITHOUT consulting oracle/oracle.cpp: paths = [direct], generators direct + random, patterns od / nd / bu, and
+function) WITHOUT consulting oracle/oracle.cpp: paths = [direct], generators direct + random, patterns od / nd / bu / sk / co / nu (a skipper whose continuation is a sizer, csum, archiver or compressed pattern is
+reported as unmodelled: fuzzer/5 returns None for that case), and
 the mutators uw ui num bd bei bed bf bi ber br sp sr sd snand srnd ld lds lr2 lri lr ls lp lis lrs ft fn fo nil.  tests/test_pymodel.py diffs it against the C++ oracle.
 
 Everything is a literal, clause-by-clause transcription — Erlang lists are Python lists, binaries are bytes, lazy
@@ -743,68 +744,102 @@ def random_stream(rnd, scale):                                             # :16
 
 # ------------------------------------------------------------------------------------------------ erlamsa_patterns.erl
 REMUTATE = (4, 5)
-PAT_ORDER = [("od", 1), ("nd", 2), ("bu", 1)]                              # patterns/0 :395-404 (the three modelled)
+ALL_PATTERNS = ["od", "nd", "bu", "sk", "sz", "cs", "ar", "cp", "co", "nu"]       # patterns/0 :395-404, in table order
+MODELLED_PATTERNS = ("od", "nd", "bu", "sk", "co", "nu")
 
 
-def run_pattern(rnd, table, pat, ll, fs, written):
-    """pat_once_dec / pat_many_dec / pat_burst (:308-349) with mutate_once/4 (:267-279) and mutate_once_loop/6
-    (:283-297); blocks are appended to `written` in the order erlamsa_out:blocks_port/5 (:642-655) writes them."""
-    while True:                                                            # one mutate_once per turn
+class Unmodelled(Exception):
+    """the case took a path this model does not cover (a sizer / csum / archiver / compressed continuation)"""
+
+
+class Patterns:
+    """pat_once_dec / pat_many_dec / pat_burst / skipper / pat_50_muta / pat_nomuta (:146-163, :308-394) over mutate_once/4
+    (:267-279) and mutate_once_loop/6 (:283-297).  Blocks go to `written` in the order erlamsa_out:blocks_port/5
+    (:642-655) writes them; continuations are Python closures (l, fs) -> None."""
+
+    def __init__(self, rnd, table, written):
+        self.rnd, self.table, self.written = rnd, table, written
+
+    def emit(self, l):                                                     # L ++ [{M, Mt}], then written by blocks_port
+        if not isinstance(l, list):
+            raise ErlCrash("badarg: <<>> ++ [..]")
+        self.written.extend(l)
+
+    def split(self, this, rest):                                           # split/1 + split_into_maxblocks/2 :44-59
+        if len(this) > ABSMAX_BINARY_BLOCK:
+            pieces = []
+            while len(this) > ABSMAX_BINARY_BLOCK:
+                cut = 500000 + self.rnd.rand(500000) - 1
+                pieces.append(this[:cut])
+                this = this[cut:]
+            pieces.append(this)                                            # cons_revlst(Lst, LlN): pieces in order, then LlN
+            this, rest = pieces[0], pieces[1:] + rest
+        return this, rest
+
+    def mutate_once(self, ll, fs, cont):
         if ll == [b""]:
             return                                                         # {Mutator, Meta}: nothing more is written
-        ip = rnd.rand(24)                                                  # ?INITIAL_IP
+        if not isinstance(ll, list):
+            raise ErlCrash("a binary where the block list should be")      # unreachable with these mutators
+        ip = self.rnd.rand(24)                                             # ?INITIAL_IP
         if not ll:
-            this, rest = None, []
-        else:
-            this, rest = ll[0], ll[1:]
-            if len(this) > ABSMAX_BINARY_BLOCK:                            # split/1 + split_into_maxblocks/2 :44-59
-                pieces = []
-                while len(this) > ABSMAX_BINARY_BLOCK:
-                    cut = 500000 + rnd.rand(500000) - 1
-                    pieces.append(this[:cut])
-                    this = this[cut:]
-                pieces.append(this)                                        # cons_revlst(Lst, LlN): pieces in order, then LlN
-                this, rest = pieces[0], pieces[1:] + rest
-        if this is None:                                                   # Cont([], Mutator, Meta)
-            l = []
-        else:
-            while True:                                                    # mutate_once_loop
-                n = rnd.rand(ip)
-                if n == 0 or rest == []:
-                    fs, l = mux_fuzzers(rnd, table, fs, [this] + rest)
-                    break
-                written.append(this)
-                this, rest = rest[0], rest[1:]
-        # the continuation
-        if pat == "od":
-            if not isinstance(l, list):
-                raise ErlCrash("badarg: <<>> ++ [..]")
-            written.extend(l)
-            return
-        if pat == "nd":                                                    # pat_many_dec_cont :315-321
-            if rnd.rand_occurs_fixed(*REMUTATE):
-                ll = l
-                if not isinstance(ll, list):
-                    raise ErlCrash("mutate_once(<<>>): uncons of a binary")  # see note in test_pymodel.py
-                continue
-            if not isinstance(l, list):
-                raise ErlCrash("badarg: <<>> ++ [..]")
-            written.extend(l)
-            return
-        # bu: pat_burst_cont :332-345
-        n = 1
+            return cont([], fs)                                            # uncons([], false): Cont([], Mutator, Meta)
+        this, rest = self.split(ll[0], ll[1:])
+        return self.mutate_once_loop(ip, this, rest, fs, cont)
+
+    def mutate_once_loop(self, ip, this, rest, fs, cont):
         while True:
-            p = rnd.rand_occurs_fixed(*REMUTATE)
-            if p or n < 2:
-                if not isinstance(l, list):
-                    raise ErlCrash("mux_fuzzers: no clause for a binary")
-                fs, l = mux_fuzzers(rnd, table, fs, l)
-                n += 1
-            else:
-                if not isinstance(l, list):
-                    raise ErlCrash("badarg: <<>> ++ [..]")
-                written.extend(l)
-                return
+            n = self.rnd.rand(ip)
+            if n == 0 or rest == []:
+                fs, l = mux_fuzzers(self.rnd, self.table, fs, [this] + rest)
+                return cont(l, fs)
+            self.written.append(this)
+            this, rest = rest[0], rest[1:]
+
+    def run(self, name, ll, fs):
+        rnd = self.rnd
+        if name == "od":                                                   # pat_once_dec :308-309
+            return self.mutate_once(ll, fs, lambda l, fs2: self.emit(l))
+        if name == "nd":                                                   # pat_many_dec :325-326 + _cont :315-321
+            def cont(l, fs2):
+                if rnd.rand_occurs_fixed(*REMUTATE):
+                    return self.run("nd", l, fs2)
+                return self.emit(l)
+            return self.mutate_once(ll, fs, cont)
+        if name == "bu":                                                   # pat_burst :348-349 + _cont :332-345
+            def cont(l, fs2):
+                n = 1
+                while True:
+                    p = rnd.rand_occurs_fixed(*REMUTATE)
+                    if p or n < 2:
+                        if not isinstance(l, list):
+                            raise ErlCrash("mux_fuzzers: no clause for a binary")
+                        fs2, l = mux_fuzzers(rnd, self.table, fs2, l)
+                        n += 1
+                    else:
+                        return self.emit(l)
+            return self.mutate_once(ll, fs, cont)
+        if name == "sk":                                                   # make_complex_pat :351-355 + mutate_once_skipper :147-163
+            nxt = rnd.rand_elem(ALL_PATTERNS)
+            ip = rnd.rand(24)
+            if not ll:
+                raise ErlCrash("size(false)")
+            b, rest = ll[0], ll[1:]
+            length = rnd.rand(math.trunc(len(b) / 2))
+            head, tail = b[:length], b[length:]
+            this, rest = self.split(tail, rest)
+            self.written.append(head)                                      # [<<HeadBin:Len>> | Res]
+            if nxt not in MODELLED_PATTERNS:
+                raise Unmodelled(nxt)
+            return self.mutate_once_loop(ip, this, rest, fs, lambda l, fs2: self.run(nxt, l, fs2))
+        if name == "co":                                                   # pat_50_muta :378-382
+            return self.run("nu" if rnd.erand(2) == 1 else "od", ll, fs)
+        if name == "nu":                                                   # pat_nomuta :386-388
+            if ll:
+                this, rest = self.split(ll[0], ll[1:])
+                self.written.extend([this] + rest)
+            return
+        raise Unmodelled(name)
 
 
 # ------------------------------------------------------------------------------------------------ erlamsa_main.erl
@@ -835,7 +870,7 @@ def fuzzer(inputs, seed, mutations, patterns, blockscale=1.0, first_case=1):
     # make_pattern/1 :417-429 (foldl prepends) + mux_patterns/1 :438-443
     psel = dict(patterns)
     pats = []
-    for name, _ in PAT_ORDER:
+    for name in ALL_PATTERNS:
         if name in psel:
             pats.insert(0, (psel[name], name))
     spats, ptotal = sort_by_priority(pats)
@@ -852,8 +887,10 @@ def fuzzer(inputs, seed, mutations, patterns, blockscale=1.0, first_case=1):
             ll = direct_generator(rnd, data, blockscale) if gen == "direct" else random_stream(rnd, blockscale)   # :185
             pat = choose_pri(spats, rnd.rand(ptotal))                      # choose_pattern_fun :431-434
             written = []
-            run_pattern(rnd, table, pat, ll, list(fs), written)
+            Patterns(rnd, table, written).run(pat, ll, list(fs))
             res.append((0, b"".join(written)))
         except ErlCrash:
             res.append((1, b""))
+        except Unmodelled:
+            res.append(None)
     return res
