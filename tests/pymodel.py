@@ -1,7 +1,7 @@
 """An independent Python model of a subset of erlamsa_main:fuzzer/1, written from the reference's .erl sources (cited per
 function) WITHOUT consulting oracle/oracle.cpp: paths = [direct], generators direct + random, patterns od / nd / bu / sk / co / nu (a skipper whose continuation is a sizer, csum, archiver or compressed pattern is
 reported as unmodelled: fuzzer/5 returns None for that case), and
-the mutators uw ui num bd bei bed bf bi ber br sp sr sd snand srnd ld lds lr2 lri lr ls lp lis lrs ft fn fo nil.  tests/test_pymodel.py diffs it against the C++ oracle.
+the mutators uw ui num bd bei bed bf bi ber br sp sr sd snand srnd ld lds lr2 lri lr ls lp lis lrs ft fn fo tr2 td ts1 ts2 tr nil.  tests/test_pymodel.py diffs it against the C++ oracle.
 
 Everything is a literal, clause-by-clause transcription — Erlang lists are Python lists, binaries are bytes, lazy
 stream tails are forced in the order erlamsa_out:blocks_port forces them.  OTP pieces (random, lists:sort/2) are
@@ -11,8 +11,14 @@ restated from the OTP sources as the author remembers them (there is no OTP in t
 import math
 import sys
 
+sys.setrecursionlimit(max(sys.getrecursionlimit(), 6000))
 if hasattr(sys, "set_int_max_str_digits"):
     sys.set_int_max_str_digits(0)            # numbers grow to 10^5 digits under sr
+
+class Unmodelled(Exception):
+    """the case took a path this model does not cover (a sizer / csum / archiver / compressed continuation, a tree result
+    beyond the model's size limit)"""
+
 
 class ErlCrash(Exception):
     """the worker process dies: fuzzer/1 times out on it and records <<>>"""
@@ -538,6 +544,187 @@ def randmask(rnd, maskfun, bs):                                            # :28
     return out
 
 
+# ------------------------------------------------------------------------------------------------ guessed parse trees
+# erlamsa_mutations.erl:787-1023, transcribed with Python lists as Erlang lists (bytes are ints, nodes are lists, all
+# comparisons are by VALUE like =:=).  FALSE stands for the atom false (a Python False would equal the byte 0).
+FALSE = object()
+TREE_LIMIT = 128 << 10                                                      # bytes; beyond it the case is reported unmodelled
+
+
+def usual_delims(c):                                                       # :793-799
+    return {40: 41, 91: 93, 60: 62, 123: 125, 34: 34, 39: 39}.get(c, FALSE)
+
+
+def grow(s, i, close, depth=0):                                            # :805-823 -> (node, next index | None)
+    if depth > 1200:
+        raise Unmodelled("nesting deeper than this model's Python recursion allows")
+    rout = []
+    while True:
+        if i >= len(s):
+            return rout, None                                              # out of data: partial parse
+        h = s[i]
+        if h == close:
+            return rout + [close], i + 1
+        nc = usual_delims(h)
+        if nc is FALSE:
+            rout.append(h)
+            i += 1
+            continue
+        this, nxt = grow(s, i + 1, nc, depth + 1)
+        if nxt is None:
+            return rout + [h] + this, None                                 # lists:reverse(Rout) ++ [H | This]
+        rout.append([h] + this)
+        i = nxt
+
+
+def partial_parse(s):                                                      # :892-905
+    rout, i = [], 0
+    while i < len(s):
+        h = s[i]
+        cp = usual_delims(h)
+        if cp is FALSE:
+            rout.append(h)
+            i += 1
+            continue
+        this, nxt = grow(s, i + 1, cp)
+        if nxt is None:
+            return rout + [h] + this
+        rout.append([h] + this)
+        i = nxt
+    return rout
+
+
+def sublists(lst, found):                                                  # :838-845 (latest found first)
+    for h in lst:
+        if isinstance(h, list):
+            found = sublists(h, [h] + found)
+    return found
+
+
+def edit_sublist(lst, sub, op):                                            # :858-869
+    if not isinstance(lst, list):
+        return [lst]                                                       # a byte: wrapped, an iolist all the same
+    out = []
+    for i, h in enumerate(lst):
+        if h == sub:
+            out.append(op(lst[i:]))                                        # Op gets the node AND its right siblings, and the walk ends
+            return out
+        out.append(edit_sublist(h, sub, op))
+    out.append([])                                                         # the list's own [] tail goes through the last clause too
+    return out
+
+
+def edit_sublists(lst, mapping):                                           # :873-884; mapping = [(key node, replacement)]
+    if not isinstance(lst, list):
+        return lst
+    out = []
+    for h in lst:
+        if isinstance(h, list):
+            rep = next((r for k, r in mapping if k == h), FALSE)           # gb_trees lookup by value
+            out.append(edit_sublists(h, mapping) if rep is FALSE else rep)
+        else:
+            out.append(h)
+    return out
+
+
+def io_len(x, memo):
+    """flattened length of an iolist whose sublists may be shared (a DAG): iterative post-order, memo by identity"""
+    if not isinstance(x, list):
+        return 1
+    stack = [(x, False)]
+    while stack:
+        node, done = stack.pop()
+        k = id(node)
+        if k in memo:
+            continue
+        if done:
+            memo[k] = sum(memo[id(y)] if isinstance(y, list) else 1 for y in node)
+        else:
+            stack.append((node, True))
+            stack.extend((y, False) for y in node if isinstance(y, list) and id(y) not in memo)
+    return memo[id(x)]
+
+
+def iolist_to_binary(x):
+    if io_len(x, {}) > TREE_LIMIT:
+        raise Unmodelled("tree result beyond the model's size limit")
+    return flat(x)
+
+
+def reservoir_sample(rnd, ll, k):                                          # erlamsa_rnd.erl:201-214
+    if k >= len(ll):
+        return ll
+    r = ll[:k]
+    for i in range(k + 1, len(ll) + 1):
+        j = rnd.erand(i)
+        if j <= k:
+            r = r[:j - 1] + [ll[i - 1]] + r[j:]
+    return r
+
+
+def sed_tree_op(rnd, ll, op):                                              # :917-928
+    h, t = ll[0], ll[1:]
+    if binarish(h):
+        return ll, -1
+    if len(h) > TREE_LIMIT:
+        raise Unmodelled("block too large for the Python tree model")
+    lst = partial_parse(list(h))
+    subs = sublists(lst, [])
+    sub = rnd.rand_elem(subs) if subs else FALSE                           # pick_sublist/1 :847-853
+    return [iolist_to_binary(edit_sublist(lst, sub, op))] + t, 1
+
+
+def sed_tree_swap(rnd, ll, two):                                           # :940-971
+    h, t = ll[0], ll[1:]
+    if binarish(h):
+        return ll, -1
+    lst = partial_parse(list(h))
+    subs = sublists(lst, [])
+    if len(subs) < 2:
+        return ll, -1
+    if len(h) > TREE_LIMIT:
+        raise Unmodelled("block too large for the Python tree model")
+    toswap = reservoir_sample(rnd, subs, 2)
+    if two:
+        a, b = toswap[0], toswap[1]
+        mapping = [(b, a)] if a == b else [(a, b), (b, a)]                 # enter(A -> B) then enter(B -> A): equal keys overwrite
+        new = edit_sublists(lst, mapping)
+    else:
+        perm = rnd.random_permutation(toswap)
+        a, b = perm[0], perm[1]
+        new = edit_sublist(lst, a, lambda l: [b] + l[1:])
+    return [iolist_to_binary(new)] + t, 1
+
+
+def sed_tree_stutter(rnd, ll):                                             # :1005-1023
+    h, t = ll[0], ll[1:]
+    if binarish(h):
+        return ll, -1
+    if len(h) > TREE_LIMIT:
+        raise Unmodelled("block too large for the Python tree model")
+    lst = partial_parse(list(h))
+    subs = sublists(lst, [])
+    randsubs = rnd.random_permutation(subs)
+    parent, child = FALSE, FALSE
+    for cand in randsubs:                                                  # choose_stutr_nodes/1 :996-1002
+        csubs = sublists(cand, [])
+        if csubs:
+            parent, child = cand, rnd.rand_elem(csubs)                     # choose_child/1 :988-993
+            break
+    n_reps = rnd.rand_log(10)
+    if parent is FALSE:
+        return ll, -1
+    r = parent                                                             # repeat_path/3 :975-985, bottom-up (the 256 MB guard is the
+    memo = {}                                                              # engine's work-area cap: not modelled, see TREE_LIMIT)
+    for _ in range(2, n_reps + 1):
+        prev = r
+        r = edit_sublist(parent, child, lambda l, prev=prev: [prev] + l[1:])
+        if io_len(r, memo) > TREE_LIMIT:
+            raise Unmodelled("tree stutter beyond the model's size limit")
+    new = edit_sublist(lst, child, lambda l: [r] + l[1:])
+    return [iolist_to_binary(new)] + t, 1
+
+
 # ------------------------------------------------------------------------------------------------ erlamsa_fuse.erl
 # A suffix of a list is represented by its start position (len = the empty suffix []): suffixes of one list have distinct
 # lengths, so the value comparisons of the reference (jump/3's first clause, fix_empty_list/1) are position comparisons.
@@ -665,6 +852,10 @@ def make_table(rnd, snand_mask):
         "snand": lambda ll: sed_bytes(rnd, ll, lambda h, bs, t, bt: [h + bytes(randmask(rnd, masks[snand_mask], list(bs))) + t] + bt),
         "srnd": lambda ll: sed_bytes(rnd, ll, lambda h, bs, t, bt: [h + bytes(randmask(rnd, masks["mask_replace"], list(bs))) + t] + bt),
         "uw": uw, "ui": ui,
+        "tr2": lambda ll: sed_tree_op(rnd, ll, lambda node: [node[0]] + node),                    # sed_tree_dup :931-932
+        "td": lambda ll: sed_tree_op(rnd, ll, lambda node: node[1:]),                             # sed_tree_del :935-936
+        "ts1": lambda ll: sed_tree_swap(rnd, ll, False), "ts2": lambda ll: sed_tree_swap(rnd, ll, True),
+        "tr": lambda ll: sed_tree_stutter(rnd, ll),
         "nil": lambda ll: (ll, -1),                                        # nomutation/2 :1104-1105
     }
     tab = {k: stateless(v) for k, v in tab.items()}
@@ -678,7 +869,7 @@ def make_table(rnd, snand_mask):
 
 
 # table order of mutations/1 (:1290-1331), restricted to what this model implements
-TABLE_ORDER = ["uw", "ui", "num", "bd", "bei", "bed", "bf", "bi", "ber", "br", "sp", "sr", "sd", "snand", "srnd",
+TABLE_ORDER = ["uw", "ui", "tr2", "td", "num", "ts1", "tr", "ts2", "bd", "bei", "bed", "bf", "bi", "ber", "br", "sp", "sr", "sd", "snand", "srnd",
                "ld", "lds", "lr2", "lri", "lr", "ls", "lp", "lis", "lrs", "ft", "fn", "fo", "nil"]
 
 
@@ -746,10 +937,6 @@ def random_stream(rnd, scale):                                             # :16
 REMUTATE = (4, 5)
 ALL_PATTERNS = ["od", "nd", "bu", "sk", "sz", "cs", "ar", "cp", "co", "nu"]       # patterns/0 :395-404, in table order
 MODELLED_PATTERNS = ("od", "nd", "bu", "sk", "co", "nu")
-
-
-class Unmodelled(Exception):
-    """the case took a path this model does not cover (a sizer / csum / archiver / compressed continuation)"""
 
 
 class Patterns:

@@ -40,12 +40,13 @@ def _inputs(n, seed):
     return out
 
 
-def _diff(inputs, seed, muts, pats, first_case=1):
+def _diff(inputs, seed, muts, pats, first_case=1, oracle_cap=0):
     want = pymodel.fuzzer(inputs, seed, muts, pats, first_case=first_case)
     data, off = po.pack(inputs)
     got, st, _, _ = po.fuzz_batch(data, off, seed=seed, mutations=",".join("%s=%d" % m for m in muts),
-                                  patterns=",".join("%s=%d" % p for p in pats), first_case=first_case)
-    bad = [i for i in range(len(inputs)) if want[i] is not None and (int(st[i]), got[i]) != want[i]]
+                                  patterns=",".join("%s=%d" % p for p in pats), first_case=first_case, max_case_bytes=oracle_cap)
+    # a case the model does not cover (None) or the oracle's test cap cut (status 2) is not compared
+    bad = [i for i in range(len(inputs)) if want[i] is not None and st[i] != 2 and (int(st[i]), got[i]) != want[i]]
     assert sum(w is None for w in want) <= 0.5 * len(want)
     assert not bad, "first mismatch: case %d, input %r\n oracle %r\n model  %r" % (bad[0], inputs[bad[0]][:80], (int(st[bad[0]]), got[bad[0]][:80]), (want[bad[0]][0], want[bad[0]][1][:80]))
 
@@ -101,3 +102,22 @@ def test_model_and_oracle_agree_when_the_random_generator_is_drawn(seed):
     want = pymodel.fuzzer(ins, seed, NOFUSE, PATS)
     assert len({w[1] for w in want}) > 50 and all(w[1][:20] != i[:20] for w, i in zip(want[10:60], ins[10:60]))
     _diff(ins, seed, NOFUSE, PATS)
+
+
+def _bracket_inputs(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    frags = [b"(", b")", b"[", b"]", b"<", b">", b"{", b"}", b"\"", b"'", b"x", b"Y", b" ", b"ab", b"()", b"(x)", b"(x (Y x))", b"\n", b"foo", b"[1,2]"]
+    out = [b"(x (Y x))", b"()", b"(", b")", b"(()", b"(())", b"((x)(x))", b"\"a\"\"a\"", b"(a)(a)(a)", b"[(a)](a)", b"x", b"((a)((a)))"]
+    for _ in range(n):
+        out.append(b"".join(frags[int(i)] for i in rng.integers(0, len(frags), size=int(rng.integers(1, 60)))))
+    return out
+
+
+@pytest.mark.parametrize("seed", [(1, 2, 3), (3, 1, 4)])
+def test_model_and_oracle_agree_on_the_tree_mutators(seed):
+    """tr2 td ts1 ts2 tr: partial_parse / sublists / edit_sublist(s) compare nodes by VALUE, so equal subtrees in different
+    places are all edited; tree stutter grows exponentially (cases beyond 8 MB are not compared)."""
+    ins = _bracket_inputs(400, seed[1])
+    trees = [("tr2", 1), ("td", 1), ("ts1", 2), ("tr", 2), ("ts2", 2)]
+    _diff(ins, seed, trees, PATS, oracle_cap=32 << 20)
+    _diff(ins, seed, trees + [("bd", 1), ("sr", 1)], [("od", 1), ("nd", 1)], oracle_cap=32 << 20)
