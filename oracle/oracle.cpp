@@ -8,7 +8,7 @@
 // byte-exact vectors).  What IS pinned: tests/test_oracle_*.py re-express the
 // reference's own eunit properties (erlamsa_mutations_test.erl) against this
 // code, plus hand-derived AS183 known answers; tests/test_pymodel.py diffs a second,
-// independent Python model of fuzzer/1 (set-up, generators, 6 patterns, 36 mutators)
+// independent Python model of fuzzer/1 (set-up, generators, 8 patterns, 37 mutators)
 // against it on 15 000 cases; tests/golden/capture.escript turns the golden
 // vectors into BEAM captures on a host with OTP.
 //

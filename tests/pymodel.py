@@ -1,7 +1,7 @@
 """An independent Python model of a subset of erlamsa_main:fuzzer/1, written from the reference's .erl sources (cited per
-function) WITHOUT consulting oracle/oracle.cpp: paths = [direct], generators direct + random, patterns od / nd / bu / sk / co / nu (a skipper whose continuation is a sizer, csum, archiver or compressed pattern is
+function) WITHOUT consulting oracle/oracle.cpp: paths = [direct], generators direct + random, patterns od / nd / bu / sk / sz / cs / co / nu (a complex pattern whose continuation is an archiver or compressed pattern is
 reported as unmodelled: fuzzer/5 returns None for that case), and
-the mutators uw ui num bd bei bed bf bi ber br sp sr sd snand srnd ld lds lr2 lri lr ls lp lis lrs ft fn fo tr2 td ts1 ts2 tr ab ad uri nil.  tests/test_pymodel.py diffs it against the C++ oracle.
+the mutators uw ui num bd bei bed bf bi ber br sp sr sd snand srnd ld lds lr2 lri lr ls lp lis lrs ft fn fo tr2 td ts1 ts2 tr ab ad uri len nil.  tests/test_pymodel.py diffs it against the C++ oracle.
 
 Everything is a literal, clause-by-clause transcription — Erlang lists are Python lists, binaries are bytes, lazy
 stream tails are forced in the order erlamsa_out:blocks_port forces them.  OTP pieces (random, lists:sort/2) are
@@ -229,10 +229,8 @@ class Rnd:
         return [] if not l else l[self.r.uniform_n(len(l)) - 1]            # :133-136
 
     def random_numbers(self, bound, cnt):                                  # :163-169: built by prepending
-        acc = []
-        for _ in range(cnt):
-            acc.insert(0, self.rand(bound))
-        return acc
+        acc = [self.rand(bound) for _ in range(cnt)]
+        return acc[::-1]
 
     def random_block(self, n):
         return bytes(self.random_numbers(256, n))                          # :154-161 (same shape)
@@ -541,6 +539,120 @@ def randmask(rnd, maskfun, bs):                                            # :28
         nxt = rnd.rand_occurs_fixed(prob, 100)                             # argument order: the next flag is drawn first
         out.append(maskfun(b) if flag else b)
         flag = nxt
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ erlamsa_field_predict.erl
+SIZER_MAX_FIRST_BYTES, PREAMBLE_MAX_BYTES = 512, 32
+
+
+def basic_u8len(a, b, x):                                                  # :51-59
+    if a < b and b > 0 and a < len(x) and len(x) >= a + 1:
+        ln = x[a]
+        if ln == b - a - 1 and ln > 2:
+            return [("ok", 8, "big", ln, a, b)]
+    return []
+
+
+def simple_u8len(a, x):                                                    # :62-65
+    return [e for k in range(0, 9) for e in basic_u8len(a, len(x) - k, x)]
+
+
+def basic_len(a, b, x):                                                    # :68-80: first matching clause
+    if a < b and b > 0 and a < len(x):
+        for size, endian in ((16, "big"), (32, "big"), (64, "big"), (16, "little"), (32, "little"), (64, "little")):
+            nb = size // 8
+            if len(x) >= a + nb:
+                ln = int.from_bytes(x[a:a + nb], endian)
+                if ln == b - a - nb and ln > 2:
+                    return [("ok", size, endian, ln, a, b)]
+    return []
+
+
+def simple_len(a, b, x):                                                   # :83-90
+    return [e for bb in (b, b - 1, b - 2, b - 4, b - 8) for e in basic_len(a, bb, x)]
+
+
+PY_FIELD_LIMIT = 700               # blocks beyond it are reported unmodelled: 1.3 M candidate checks / 961 CRCs per megabyte in Python
+
+
+def get_possible_simple_lens(rnd, x):                                      # :93-109
+    if len(x) > PY_FIELD_LIMIT:
+        raise Unmodelled("block too large for the Python field_predict model")
+    if len(x) > 10:
+        ln = len(x)
+        sub = min(math.trunc(ln / 5), SIZER_MAX_FIRST_BYTES)
+        first = list(range(0, sub + 1))
+        varb = [rnd.rand_range(sub, ln) for _ in first]
+        ranges = [(a, b) for a in first for b in varb]
+        allr = [(a, ln) for a in first] + ranges
+        big = []
+        for a, b in allr:                                                  # foldl prepends: the last range comes first
+            big = [simple_len(a, b, x)] + big
+        small = [simple_u8len(a, x) for a in first]
+        return [e for grp in small for e in grp] + [e for grp in big for e in grp]
+    return [e for a in range(0, 4) for e in simple_len(a, len(x), x) + simple_u8len(a, x)]
+
+
+def field(v, size, endian):
+    return (v % (1 << size)).to_bytes(size // 8, endian)
+
+
+def length_predict(rnd, ll):                                               # :1140-1143 + mutate_length :1113-1137
+    h, t = ll[0], ll[1:]
+    elem = rnd.rand_elem(get_possible_simple_lens(rnd, h))
+    if elem == []:
+        return [h] + t, -2
+    _ok, size, endian, ln, a, _b = elem
+    nb = size // 8
+    head, blob, rest = h[:a], h[a + nb:a + nb + ln], h[a + nb + ln:]
+    tmp = int.from_bytes(rnd.random_block(nb), "big")
+    newlen = min(ABSMAX_BINARY_BLOCK, tmp * 2)
+    k = rnd.rand(7)
+    if k == 0:
+        res = head + bytes(nb) + blob + rest
+    elif k == 1:
+        res = head + b"\xff" * nb + blob + rest
+    elif k == 2:                                                           # fast_pseudorandom_block/1 erlamsa_rnd.erl:155-160
+        if newlen < 500000:
+            rb = rnd.random_block(newlen)
+        else:
+            z = newlen - 500000                                            # <<42:Z8L>> is Z8L BITS wide (sic)
+            blk = rnd.random_block(500000)
+            if z % 8:
+                raise ErlCrash("badarg: a bitstring where a binary is needed")
+            rb = (42).to_bytes(z // 8, "big") + blk if z else blk
+        res = head + field(ln, size, endian) + blob + rb + rest
+    elif k == 3:
+        res = head + field(newlen, size, endian) + rest
+    else:
+        res = head + field(newlen, size, endian) + blob + rest
+    return [res] + t, 1
+
+
+def crc32(b):
+    import zlib
+    return zlib.crc32(b) & 0xffffffff
+
+
+def get_possible_csum_locations(x):                                        # :155-161
+    if not x:
+        return []
+    if len(x) > PY_FIELD_LIMIT:
+        raise Unmodelled("block too large for the Python field_predict model")
+    ln = len(x)
+    seq = range(0, min(math.trunc(2 * ln / 3), 30 * PREAMBLE_MAX_BYTES) + 1)
+    out = []
+    for a in seq:                                                          # has_xor8_checksum/3 :131-138
+        body = x[a:ln - 1]
+        v = 0
+        for c in body:
+            v ^= c
+        if v == x[ln - 1]:
+            out.append(("xor8", 8, a, ln - a - 1))
+    for a in seq:                                                          # has_crc32_checksum/3 :141-150
+        if ln - a >= 4 and crc32(x[a:ln - 4]) == int.from_bytes(x[ln - 4:], "big"):
+            out.append(("crc32", 32, a, ln - a - 4))
     return out
 
 
@@ -1107,6 +1219,7 @@ def make_table(rnd, snand_mask):
         "snand": lambda ll: sed_bytes(rnd, ll, lambda h, bs, t, bt: [h + bytes(randmask(rnd, masks[snand_mask], list(bs))) + t] + bt),
         "srnd": lambda ll: sed_bytes(rnd, ll, lambda h, bs, t, bt: [h + bytes(randmask(rnd, masks["mask_replace"], list(bs))) + t] + bt),
         "uw": uw, "ui": ui,
+        "len": lambda ll: length_predict(rnd, ll),
         "ab": lambda ll: ascii_mutator(rnd, ll, lambda cs: string_generic_mutate(rnd, cs, AB_KINDS)),       # :605-611
         "ad": lambda ll: ascii_mutator(rnd, ll, lambda cs: string_delimeter_mutate(rnd, cs)),               # :647-651
         "tr2": lambda ll: sed_tree_op(rnd, ll, lambda node: [node[0]] + node),                    # sed_tree_dup :931-932
@@ -1128,7 +1241,7 @@ def make_table(rnd, snand_mask):
 
 # table order of mutations/1 (:1290-1331), restricted to what this model implements
 TABLE_ORDER = ["uw", "ui", "ab", "ad", "tr2", "td", "num", "ts1", "tr", "ts2", "bd", "bei", "bed", "bf", "bi", "ber", "br", "sp", "sr", "sd", "snand", "srnd",
-               "ld", "lds", "lr2", "lri", "lr", "ls", "lp", "lis", "lrs", "ft", "fn", "fo", "uri", "nil"]
+               "ld", "lds", "lr2", "lri", "lr", "ls", "lp", "lis", "lrs", "ft", "fn", "fo", "len", "uri", "nil"]
 
 
 def adjust_priority(pri, delta):                                           # :1240-1242
@@ -1194,7 +1307,7 @@ def random_stream(rnd, scale):                                             # :16
 # ------------------------------------------------------------------------------------------------ erlamsa_patterns.erl
 REMUTATE = (4, 5)
 ALL_PATTERNS = ["od", "nd", "bu", "sk", "sz", "cs", "ar", "cp", "co", "nu"]       # patterns/0 :395-404, in table order
-MODELLED_PATTERNS = ("od", "nd", "bu", "sk", "co", "nu")
+MODELLED_PATTERNS = ("od", "nd", "bu", "sk", "sz", "cs", "co", "nu")
 
 
 class Patterns:
@@ -1277,6 +1390,43 @@ class Patterns:
             if nxt not in MODELLED_PATTERNS:
                 raise Unmodelled(nxt)
             return self.mutate_once_loop(ip, this, rest, fs, lambda l, fs2: self.run(nxt, l, fs2))
+        if name in ("sz", "cs"):                                           # make_complex_pat + mutate_once_sizer / _csum :83-145
+            nxt = rnd.rand_elem(ALL_PATTERNS)
+            ip = rnd.rand(24)
+            if not ll:
+                raise ErlCrash("size(false)")
+            b, rest = ll[0], ll[1:]
+            locs = get_possible_simple_lens(rnd, b) if name == "sz" else get_possible_csum_locations(b)
+            elem = rnd.rand_elem(locs)
+            if nxt not in MODELLED_PATTERNS:
+                raise Unmodelled(nxt)
+            cont = lambda l, fs2: self.run(nxt, l, fs2)
+            if elem == []:                                                 # "failed": the whole block, next pattern as continuation
+                this, rest = self.split(b, rest)
+                return self.mutate_once_loop(ip, this, rest, fs, cont)
+            if name == "sz":
+                _ok, size, endian, ln, a, _b = elem
+                nb = size // 8
+                head, blob, tail = b[:a], b[a + nb:a + nb + ln], b[a + nb + ln:]
+            else:
+                typ, size, plen, blen = elem
+                head, blob, tail = b[:plen], b[plen:plen + blen], None
+            this, rest = self.split(blob, rest)
+            outer, self.written = self.written, []                         # prepare4sizer/1 :62-78 forces and joins everything
+            try:                                                           # the inner evaluation writes
+                self.mutate_once_loop(ip, this, rest, fs, cont)
+                newblob = b"".join(self.written)
+            finally:
+                self.written = outer
+            if name == "sz":
+                self.written.extend([head + field(len(newblob), size, endian) + newblob, tail])
+            else:
+                v = crc32(newblob) if typ == "crc32" else 0
+                if typ == "xor8":
+                    for c in newblob:
+                        v ^= c
+                self.written.append(head + newblob + field(v, size, "big"))
+            return
         if name == "co":                                                   # pat_50_muta :378-382
             return self.run("nu" if rnd.erand(2) == 1 else "od", ll, fs)
         if name == "nu":                                                   # pat_nomuta :386-388
