@@ -22,12 +22,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DESC_BYTES = 24        # per-case descriptor: out_off, out_len, status/draws
 
 
-def cpu_baseline_leg(mat, seed, muts, pats, args):
+def cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref=None):
     """oracle/ timed on the host: the first `--cpu-sample` cases of the same run (same corpus rows, options and work-area
     limit as the GPU run), in chunks of 8, handed to `--cpu-threads` worker threads (the ctypes call releases the GIL).
     Every case runs under a wall-clock watchdog of `--cpu-case-seconds` — the reference's own maxrunningtime semantics
     (erlamsa_main.erl:197-204: the worker is killed and the case yields <<>>; its CLI default is 30 s): the time of such a
-    case counts, its output does not.  Reported: the aggregate rate over all threads and the threads actually used."""
+    case counts, its output does not.  Reported: the aggregate rate over all threads and the threads actually used.
+    The same outputs are the CHECKER of the run that was timed: gpu_ref holds status / length / draw count / SHA-1 of the
+    engine's results for the same case numbers (taken from the device before the timed steps); every case the oracle
+    finished must agree, or the bench fails.  Engine-only statuses (2, 3) and cases cut by the watchdog are counted, not
+    compared."""
+    import hashlib
     import threading
     from erlamsa_amd import synth
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -38,7 +43,7 @@ def cpu_baseline_leg(mat, seed, muts, pats, args):
     threads = max(1, args.cpu_threads or min(os.cpu_count() or 1, 64))
     CH = 8
     lock = threading.Lock()
-    state = {"next": 0, "cases": 0, "bytes": 0, "timeouts": 0}
+    state = {"next": 0, "cases": 0, "bytes": 0, "timeouts": 0, "checked": 0, "skipped": 0, "bad": []}
     t0 = time.perf_counter()
 
     def worker():
@@ -50,13 +55,24 @@ def cpu_baseline_leg(mat, seed, muts, pats, args):
                 state["next"] = a + CH
             b = min(a + CH, limit)
             d, o = synth.as_arena(mat[a:b])
-            outs, st, _, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, first_case=a + 1,
+            outs, st, dr, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, first_case=a + 1,
                                            max_case_bytes=args.big_mib << 20, max_case_work=args.work_mib << 20,
                                            max_case_seconds=args.cpu_case_seconds)
             with lock:
                 state["cases"] += b - a
                 state["bytes"] += sum(len(x) for x in outs)
                 state["timeouts"] += int((st == 6).sum())
+                if gpu_ref is not None:
+                    gst, gln, gdr, gsha = gpu_ref
+                    for j in range(b - a):
+                        i = a + j
+                        if st[j] in (2, 3, 6) or gst[i] in (2, 3):
+                            state["skipped"] += 1
+                        elif int(st[j]) != int(gst[i]) or len(outs[j]) != int(gln[i]) or (st[j] == 0 and int(dr[j]) != int(gdr[i])) \
+                                or hashlib.sha1(outs[j]).digest() != gsha[i]:
+                            state["bad"].append(i + 1)
+                        else:
+                            state["checked"] += 1
 
     ts = [threading.Thread(target=worker) for _ in range(threads)]
     for t in ts:
@@ -70,7 +86,10 @@ def cpu_baseline_leg(mat, seed, muts, pats, args):
             model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), model)
     except OSError:
         pass
-    return {"value": round(state["bytes"] / ct / 1e6, 3), "unit": "MB/s", "cores": threads, "kind": "port", "cpu_model": model,
+    if state["bad"]:
+        raise RuntimeError("PARITY FAILURE: the engine's results of cases %s differ from the oracle's" % state["bad"][:16])
+    return {"parity_checked": state["checked"], "parity_skipped": state["skipped"],
+            "value": round(state["bytes"] / ct / 1e6, 3), "unit": "MB/s", "cores": threads, "kind": "port", "cpu_model": model,
             "host_cpus": os.cpu_count(),
             "cases_per_s": round(state["cases"] / ct, 2), "cases_cut_by_watchdog": state["timeouts"],
             "sample": "cases 1..%d of the same run (same corpus rows, seed, mutators, patterns, work-area limit), oracle/ C++ restatement, "
@@ -94,7 +113,7 @@ def main():
                     "(the reference's maxrunningtime; its CLI default is 30 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle leg (0 = all host cores, at most 64)")
     ap.add_argument("--max-slots", type=int, default=1365, help="tier-0 wavefront slots per context (0 = 16 per CU); the default x 3 contexts = 16 per CU")
-    ap.add_argument("--tier-gib", type=int, default=8, help="device memory of every overflow tier of a context (GiB; exported as EH_TIER_GIB); "
+    ap.add_argument("--tier-gib", type=int, default=8, help="device memory of every overflow tier of a context (GiB), eh_options.tier_bytes; "
                     "0 = the library's own rule (an eighth of the free memory, for a single context)")
     ap.add_argument("--out-gib", type=int, default=28, help="output arena capacity per context (GiB)")
     ap.add_argument("--case-mib", type=int, default=16, help="per-case work area of every resident wavefront (MiB), eh_options.max_case_bytes")
@@ -111,8 +130,6 @@ def main():
                     "tiers and output arena: about 73 GiB at the defaults, 220 GiB for 3")
     args = ap.parse_args()
 
-    if args.tier_gib > 0:
-        os.environ["EH_TIER_GIB"] = str(args.tier_gib)
     import numpy as np
     import torch
     import erlamsa_amd as ea
@@ -153,7 +170,8 @@ def main():
     for _ in range(nctx):
         e = ea.Engine(local)
         e.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
-                    max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20, big_case_bytes=args.big_mib << 20)
+                    max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20, big_case_bytes=args.big_mib << 20,
+                    tier_bytes=args.tier_gib << 30)
         e.attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
         engines.append(e)
         streams.append(torch.cuda.Stream(device=dev))
@@ -168,6 +186,14 @@ def main():
         e.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=n, stream=st.cuda_stream)
     for e in engines:
         e.sync()
+    # The set-up pass ran cases 1 .. n: keep what the engine produced for the cases the CPU oracle leg will run (status,
+    # length, draw count, SHA-1 of the bytes), so that leg doubles as the parity check of this very run.
+    gpu_ref = None
+    if args.cpu_sample > 0 and world == 1:
+        import hashlib
+        e0, m = engines[0], min(args.cpu_sample, n)
+        st0, ln0, dr0 = e0.status()[:m].copy(), e0.lens()[:m].copy(), e0.diag()[0][:m].copy()
+        gpu_ref = (st0, ln0, dr0, [hashlib.sha1(e0.fetch(i, int(ln0[i]))).digest() for i in range(m)])
 
     raw = [st.cuda_stream for st in streams]
     # rank r, step k -> case numbers ((k*world + r) * n) + 1 ... (shard.run_steps, the loop tests/test_dist_gloo.py drives too)
@@ -219,7 +245,8 @@ def main():
     if args.budget_mib > 0 and args.work_mib == 0 and world == 1:
         for e in engines:
             e.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
-                        max_case_bytes=args.case_mib << 20, max_case_work=args.budget_mib << 20, big_case_bytes=args.big_mib << 20)
+                        max_case_bytes=args.case_mib << 20, max_case_work=args.budget_mib << 20, big_case_bytes=args.big_mib << 20,
+                        tier_bytes=args.tier_gib << 30)
         bsteps = min(3, args.steps)
         torch.cuda.synchronize()
         tb = time.perf_counter()
@@ -291,7 +318,12 @@ def main():
             res["pcie"] = pcie
         # ---- CPU baseline: the oracle (C++ restatement of the reference) on the host cores, N=1 only
         if args.cpu_sample > 0 and world == 1:
-            res["cpu_baseline"] = cpu_baseline_leg(mat, seed, muts, pats, args)
+            cb = cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref)
+            res["parity_checked"] = cb.pop("parity_checked")
+            res["parity"] = {"checked_bit_exact": res["parity_checked"], "not_compared": cb.pop("parity_skipped"),
+                             "what": "cases 1..%d of this run (set-up pass of context 0): status, length, PRNG draw count and SHA-1 of every "
+                                     "output vs the oracle's; not compared = engine-only status (2, 3) or cut by the oracle leg's watchdog" % min(args.cpu_sample, n)}
+            res["cpu_baseline"] = cb
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

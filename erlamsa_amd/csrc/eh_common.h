@@ -89,6 +89,7 @@ struct KParams {
   uint64_t slot_stride;
   uint64_t work_cap;          // bytes of the linear work area
   uint64_t work_budget;       // per-case byte budget (sum of block sizes handed to mutators)
+  uint64_t fuse_stream_min;   // fuse/2 on la + lb >= this many bytes runs as the position-indexed refinement of eh_fuse2.h
   // outputs
   uint8_t* out;
   uint64_t out_cap;

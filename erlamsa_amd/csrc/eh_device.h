@@ -681,7 +681,10 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
       // once the work area is more than 1/8 full: the typical case (a 4 KiB block, ~10 rounds) never
       // gets there and simply leaves its dead candidates behind.
       uint8_t* lo = c.ws + mark;
-      if (c.ws_used > c.ws_cap / 8 && !c.r2 && c.r_ptr >= lo && c.r_ptr + c.r_len <= c.ws + c.ws_used) {
+      // A candidate of more than a few MiB stays where it is: mux_fuzzers never hands out a block above
+      // ABSMAX_BINARY_BLOCK again (:1269, split_into_maxblocks), so nothing will copy it as a whole any more, and sliding
+      // a 1 GiB tree-stutter result took a lone wavefront 0.7 s.
+      if (c.ws_used > c.ws_cap / 8 && c.r_len <= (4u << 20) && !c.r2 && c.r_ptr >= lo && c.r_ptr + c.r_len <= c.ws + c.ws_used) {
         uint8_t* dst = lo;
         uint8_t* hp = (uint8_t*)h0.ptr;
         bool state_refs = uni(((const uint32_t*)c.aux)[0]) != 0 || uni(((const uint32_t*)(c.aux + 336))[0]) != 0 || uni(((const uint32_t*)(c.aux + 704))[3]) != 0;

@@ -29,6 +29,7 @@
 #include "eh_tree.h"
 #include "eh_field.h"
 #include "eh_fuse.h"
+#include "eh_fuse2.h"
 #include "eh_doc.h"
 #include "eh_sgml.h"
 #include "eh_json.h"
@@ -497,8 +498,11 @@ EH_DEV void gen_random(Ctx& c) {                                       // random
 // =============================================================================================
 // the mutate kernel
 // =============================================================================================
+// 2 wavefronts per SIMD = up to 256 VGPRs: at 4 (128 VGPRs) the scheduler loops and the candidate loop of base64_mutator
+// reload spilled registers from scratch on every iteration (7.5 M instead of 1.6 M memory instructions for one
+// b64-heavy case, twice the time, profiles/r03_summary.json "occupancy"); the longest cases set the duration of a pass.
 #ifndef EH_WAVES_PER_SIMD
-#define EH_WAVES_PER_SIMD 4
+#define EH_WAVES_PER_SIMD 2
 #endif
 // The argument block lives in device memory: taking the address of a by-value kernel argument (c.p) made the
 // compiler keep a ~700-byte private copy of it per lane.
@@ -721,11 +725,12 @@ struct eh_ctx {
   bool configured = false;
   DevConfig cfg;
   uint64_t max_case_bytes = 0, out_capacity_opt = 0, work_budget = 0;
+  uint64_t fuse_stream_min = 16384, tier_bytes_opt = 0, dl_chunk = 256ull << 20;   // eh_options (ABI 4)
   uint32_t max_slots_opt = 0, flags = 0;
   KParams* d_params = nullptr;                          // argument block of eh_mutate_kernel
   // eh_result_download: case-ordered chunks are gathered on the device into two bounce buffers; chunk k goes over PCIe
   // while chunk k+1 is gathered
-  uint8_t* d_bounce[2] = {nullptr, nullptr}; uint64_t bounce_cap = 0; hipStream_t dl_gather = nullptr, dl_copy = nullptr;
+  uint8_t* d_bounce[2] = {nullptr, nullptr}; uint64_t bounce_cap = 0, bounce_chunk = 0; hipStream_t dl_gather = nullptr, dl_copy = nullptr;
   hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_c[2] = {nullptr, nullptr};
   uint8_t* d_out2 = nullptr; uint64_t out2_cap = 0;   // EH_FLAG_ORDERED_OUTPUT: second arena (case order)
   uint64_t* d_ord = nullptr; uint64_t ord_cap = 0;      // ordered offsets (n + 1)
@@ -741,7 +746,7 @@ struct eh_ctx {
   static constexpr int MAX_TIERS = 5;
   int ntiers = 0;                                      // tiers above tier 0
   uint8_t* d_tslots[MAX_TIERS] = {}; uint64_t tstride[MAX_TIERS] = {}, tcap[MAX_TIERS] = {}; uint32_t tnslots[MAX_TIERS] = {};
-  uint32_t* d_retry = nullptr; uint64_t retry_cap = 0; uint64_t big_case_bytes = 0; uint64_t tier_base = 0, tier_big = 0;
+  uint32_t* d_retry = nullptr; uint64_t retry_cap = 0; uint64_t big_case_bytes = 0; uint64_t tier_base = 0, tier_big = 0, tier_bytes_used = 0;
   // outputs
   uint8_t* d_out = nullptr; uint64_t out_cap = 0;
   uint64_t* d_off = nullptr; uint64_t* d_len = nullptr; int32_t* d_status = nullptr; uint64_t* d_draws = nullptr; int32_t* d_lastm = nullptr; uint64_t* d_cycles = nullptr;
@@ -860,7 +865,7 @@ static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc = ensure_results(ctx, n ? n : 1);
   if (rc) return rc;
-  uint32_t want_slots = ctx->max_slots_opt ? ctx->max_slots_opt : (uint32_t)ctx->cus * 16u;
+  uint32_t want_slots = ctx->max_slots_opt ? ctx->max_slots_opt : (uint32_t)ctx->cus * 4u * EH_WAVES_PER_SIMD;
   if (want_slots > n) want_slots = (uint32_t)(n ? n : 1);
   uint64_t work_cap = ctx->max_case_bytes ? ctx->max_case_bytes : (8ull << 20);
   uint64_t stride = (uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + work_cap;
@@ -874,7 +879,7 @@ static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
   // tiers above 0: 4x the area and a quarter of the wavefronts each, up to big_case_bytes (default 32 x max_case_bytes,
   // at most 1 GiB); every tier gets an eighth of the free device memory, at most 32 GiB (the emulator: two slots)
   uint64_t big = ctx->big_case_bytes ? ctx->big_case_bytes : (32 * work_cap < (1024ull << 20) ? 32 * work_cap : (1024ull << 20));
-  if (ctx->tier_base != work_cap || ctx->tier_big != big) {
+  if (ctx->tier_base != work_cap || ctx->tier_big != big || ctx->tier_bytes_used != ctx->tier_bytes_opt) {
     for (int t = 0; t < ctx->ntiers; t++) { (void)hipFree(ctx->d_tslots[t]); ctx->d_tslots[t] = nullptr; }
     ctx->ntiers = 0;
     uint64_t cap = work_cap;
@@ -883,14 +888,14 @@ static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
       uint64_t stride_t = ((uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + cap + 255) & ~255ull;
       uint64_t tier_gib = 16;                                                   // an eighth of the free memory, 1 .. 32 GiB
       { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) { tier_gib = (uint64_t)fr >> 33; if (tier_gib < 1) tier_gib = 1; if (tier_gib > 32) tier_gib = 32; } }
-      if (const char* e = getenv("EH_TIER_GIB")) { tier_gib = strtoull(e, nullptr, 10); if (tier_gib < 1) tier_gib = 1; }   // tuning knob
-      uint64_t cnt = (tier_gib << 30) / stride_t; if (cnt < 8) cnt = 8; if (cnt > 1024) cnt = 1024;
+      uint64_t tier_bytes = ctx->tier_bytes_opt ? ctx->tier_bytes_opt : (tier_gib << 30);      // eh_options.tier_bytes
+      uint64_t cnt = tier_bytes / stride_t; if (cnt < 2) cnt = 2; if (cnt > 1024) cnt = 1024;  // (one area is enough for correctness)
       if (ctx->cus < 64) cnt = 2;
       int t = ctx->ntiers;
       HIPCHK(ctx, hipMalloc(&ctx->d_tslots[t], stride_t * cnt));
       ctx->tstride[t] = stride_t; ctx->tcap[t] = cap; ctx->tnslots[t] = (uint32_t)cnt; ctx->ntiers++;
     }
-    ctx->tier_base = work_cap; ctx->tier_big = big;
+    ctx->tier_base = work_cap; ctx->tier_big = big; ctx->tier_bytes_used = ctx->tier_bytes_opt;
   }
   if (ctx->ntiers > 0 && (!ctx->d_retry || ctx->retry_cap < n)) {
     if (ctx->d_retry) (void)hipFree(ctx->d_retry);
@@ -925,6 +930,7 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.mode = mode; p.run = ctx->d_run; p.seeds = ctx->d_seeds; p.cfg = ctx->cfg;
   p.slot_base = ctx->d_slots; p.slot_stride = ctx->slot_stride; p.work_cap = ctx->work_cap;
   p.work_budget = ctx->work_budget;                                            // 0 = no budget (the default)
+  p.fuse_stream_min = ctx->fuse_stream_min;
   p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
   p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles;
   p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;
@@ -1030,7 +1036,6 @@ int eh_create(int device, eh_ctx** out) {
   // eh_mutate_kernel recurses (nested scheduler calls of b64 / sgm / js, depth <= MAX_NEST): ~0.6 KiB of private stack
   // per level on top of the kernel's fixed 1.2 KiB
   size_t stack_bytes = 16384;
-  if (const char* e = getenv("EH_STACK_BYTES")) stack_bytes = (size_t)strtoul(e, nullptr, 10);   // diagnostic override
   if (hipDeviceSetLimit(hipLimitStackSize, stack_bytes) != hipSuccess) { delete ctx; return EH_E_HIP; }
   uint16_t t1[65], t2[65], t3[65];
   init_tables(t1, t2, t3);
@@ -1125,6 +1130,8 @@ int eh_configure(eh_ctx* ctx, const eh_options* o) {
   ctx->cfg = cfg;
   ctx->work_budget = o->max_case_work;
   ctx->big_case_bytes = o->big_case_bytes; ctx->max_case_bytes = o->max_case_bytes; ctx->out_capacity_opt = o->out_capacity; ctx->max_slots_opt = o->max_slots; ctx->flags = o->flags;
+  ctx->fuse_stream_min = o->fuse_stream_min ? o->fuse_stream_min : 16384;
+  ctx->tier_bytes_opt = o->tier_bytes; ctx->dl_chunk = o->download_chunk_bytes ? o->download_chunk_bytes : (256ull << 20);
   ctx->configured = true;
   return EH_OK;
 }
@@ -1325,8 +1332,7 @@ int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, 
     // copy it out (full PCIe rate when `data` is pinned or registered host memory) while the next chunk is gathered
     if (total == 0) return EH_OK;
     uint64_t maxlen = 0; for (uint64_t i = 0; i < n; i++) if (len[i] > maxlen) maxlen = len[i];
-    uint64_t chunk = 256ull << 20;
-    if (const char* e = getenv("EH_DL_CHUNK")) { chunk = strtoull(e, nullptr, 10); if (chunk < 64) chunk = 64; }   // tests: many small chunks
+    uint64_t chunk = ctx->dl_chunk < 64 ? 64 : ctx->dl_chunk;        // eh_options.download_chunk_bytes
     uint64_t want = maxlen > chunk ? maxlen : chunk;
     if (want > total) want = total;
     want = (want + 4095) & ~4095ull;
@@ -1335,11 +1341,11 @@ int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, 
       HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->dl_copy, hipStreamNonBlocking));
       for (int k = 0; k < 2; k++) { HIPCHK(ctx, hipEventCreate(&ctx->ev_g[k])); HIPCHK(ctx, hipEventCreate(&ctx->ev_c[k])); }
     }
-    if (ctx->bounce_cap < want || getenv("EH_DL_CHUNK")) {
+    if (ctx->bounce_cap < want || ctx->bounce_chunk != chunk) {
       for (int k = 0; k < 2; k++) { if (ctx->d_bounce[k]) (void)hipFree(ctx->d_bounce[k]); ctx->d_bounce[k] = nullptr; }
       ctx->bounce_cap = 0;
       for (int k = 0; k < 2; k++) HIPCHK(ctx, hipMalloc(&ctx->d_bounce[k], want));
-      ctx->bounce_cap = want;
+      ctx->bounce_cap = want; ctx->bounce_chunk = chunk;
     }
     if (!ctx->d_ord || ctx->ord_cap < n + 1) {
       if (ctx->d_ord) (void)hipFree(ctx->d_ord);
@@ -1372,6 +1378,19 @@ int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, 
     HIPCHK(ctx, hipStreamSynchronize(ctx->dl_copy));
     HIPCHK(ctx, hipGetLastError());
   }
+  return EH_OK;
+}
+int eh_result_fetch(eh_ctx* ctx, uint64_t i, uint8_t* buf, uint64_t cap, uint64_t* out_len) {
+  if (!ctx || !out_len) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  int rc = eh_sync(ctx); if (rc) return rc;
+  if (i >= ctx->last_n) { ctx->err = "eh_result_fetch: case index outside the last batch"; return EH_E_INVALID; }
+  uint64_t ol[2];
+  HIPCHK(ctx, hipMemcpy(&ol[0], ctx->d_off + i, 8, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(&ol[1], ctx->d_len + i, 8, hipMemcpyDeviceToHost));
+  *out_len = ol[1];
+  if (ol[1] > cap || (!buf && ol[1])) { ctx->err = "eh_result_fetch: buffer too small"; return EH_E_INVALID; }
+  if (ol[1]) HIPCHK(ctx, hipMemcpy(buf, ctx->d_out + ol[0], ol[1], hipMemcpyDeviceToHost));
   return EH_OK;
 }
 int eh_result_diag(eh_ctx* ctx, uint64_t* draws, int32_t* last_mutator) {

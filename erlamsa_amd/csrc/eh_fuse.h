@@ -29,7 +29,10 @@ namespace eh {
 // Likewise to / tc / T.  Most nodes are {1,1} after a round or two and then cost one 16-byte load and store per round.
 struct FNode { uint32_t fo, fc, to, tc; };
 // big-node path: [0,256) source count -> cursor, [256,512) target, [512,768) child index of the bin, [768,1024) flags
-EH_LDS_ARRAY(uint32_t, g_fuse_lds, 1024);
+#ifndef EH_FUSE_LDS_WORDS
+#define EH_FUSE_LDS_WORDS 2048
+#endif
+EH_LDS_ARRAY(uint32_t, g_fuse_lds, EH_FUSE_LDS_WORDS);     // (eh_fuse2.h: bitmaps of <= EH_FUSE_LDS_WORDS / 8 nodes)
 
 // ascending bitonic sort of one 32-bit key per lane
 EH_DEV uint32_t wave_sort64(uint32_t key) {
@@ -324,47 +327,68 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
   return cn;
 }
 
+__device__ bool fuse_jump_stream(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, bool sym, uint32_t* from, uint32_t* tpos, uint32_t* rounds);   // eh_fuse2.h
+
 // fuse(Al, Bl) -> new byte list in the work area
+#ifdef EH_FUSE_INLINE
 EH_DEV bool fuse_lists(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, uint8_t** out, uint32_t* outlen) {
+#else
+__device__ __noinline__ bool fuse_lists(Ctx&, const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, uint8_t** out, uint32_t* outlen) {
+  EH_CTX;
+#endif
   const int l = EH_LANE;
   if (la == 0) { *out = (uint8_t*)B; *outlen = lb; return true; }   // fuse([], Bl) -> Bl
   if (lb == 0) { *out = (uint8_t*)A; *outlen = la; return true; }
   uint64_t mark = c.ws_used;
   const bool sym = A == B && la == lb;                             // sed_fuse_this: fuse(Lst, Lst)
-  FuseGen g[2];
-  for (int k = 0; k < 2; k++) {
-    g[k].nd = (FNode*)ws_alloc(c, ((uint64_t)la + 4) * sizeof(FNode));     // every node owns >= 1 source entry
-    g[k].F = (uint32_t*)ws_alloc(c, ((uint64_t)la + 4) * 4);
-    g[k].T = sym ? g[k].F : (uint32_t*)ws_alloc(c, ((uint64_t)lb + 4) * 4);
-    if (!g[k].nd || !g[k].F || !g[k].T) return false;
-  }
-  // find_jump_points (:103-107): one node with all non-empty suffixes of both lists
-  if (la > 1) for (uint32_t i = l; i < la; i += 64) g[0].F[i] = i;
-  if (lb > 1 && !sym) for (uint32_t i = l; i < lb; i += 64) g[0].T[i] = i;
-  if (l == 0) { FNode n0; n0.fo = 0; n0.fc = la; n0.to = 0; n0.tc = lb; g[0].nd[0] = n0; }   // (a single suffix: position 0 = offset 0)
-  uint32_t nn = 1, par = 0;
-  int64_t fuel = 100000;                                           // ?SEARCH_FUEL
-  uint64_t gen_entries = (uint64_t)la + lb;
-  wave_sync();
-  while (true) {                                                   // find_jump_points_loop (:115-128)
-    if (fuel < 0) break;
-    if (rng_rand(c.rng, 8) == 0) break;                            // ?SEARCH_STOP_IP
-    if (c.work_budget) {                                           // optional engine guard: a round costs its list members
-      c.work += 16ull * gen_entries;
-      if (c.work > c.work_budget) { c.status = CASE_BUDGET; c.ws_used = mark; return false; }
-    }
-    uint32_t nchild = fuse_round(A, la, B, lb, g[par], nn, g[par ^ 1], par, sym, &gen_entries);
-    if (nchild == 0) break;                                        // NoDesp =:= [] -> any_position_pair(Nodes)
-    par ^= 1; nn = nchild;
-    fuel -= (int64_t)nchild;
-  }
-  // any_position_pair/1 (:73-77); odd generations are stored reversed
-  uint32_t ni = rng_rand(c.rng, nn);
-  FNode nd = g[par].nd[par ? nn - 1 - ni : ni];
-  uint32_t fo = uni(nd.fo), fc = uni(nd.fc), to = sym ? fo : uni(nd.to), tc = sym ? fc : uni(nd.tc);
+  EH_PT0;
   uint32_t from = la, tpos = lb;
-  if (fc > 0) { uint32_t j = rng_rand(c.rng, fc); from = fc == 1 ? fo : uni(g[par].F[fo + (par ? fc - 1 - j : j)]); }
-  if (tc > 0) { uint32_t j = rng_rand(c.rng, tc); tpos = tc == 1 ? to : uni(g[par].T[to + (par ? tc - 1 - j : j)]); }
+  uint32_t prof_rounds = 0;
+  if ((uint64_t)la + lb >= c.p->fuse_stream_min) {                 // large lists: position-indexed refinement (eh_fuse2.h)
+    if (!fuse_jump_stream(c, A, la, B, lb, sym, &from, &tpos, &prof_rounds)) { if (c.status == CASE_BUDGET) c.ws_used = mark; return false; }
+  } else {
+    FuseGen g[2];
+    for (int k = 0; k < 2; k++) {
+      g[k].nd = (FNode*)ws_alloc(c, ((uint64_t)la + 4) * sizeof(FNode));     // every node owns >= 1 source entry
+      g[k].F = (uint32_t*)ws_alloc(c, ((uint64_t)la + 4) * 4);
+      g[k].T = sym ? g[k].F : (uint32_t*)ws_alloc(c, ((uint64_t)lb + 4) * 4);
+      if (!g[k].nd || !g[k].F || !g[k].T) return false;
+    }
+    // find_jump_points (:103-107): one node with all non-empty suffixes of both lists
+    if (la > 1) for (uint32_t i = l; i < la; i += 64) g[0].F[i] = i;
+    if (lb > 1 && !sym) for (uint32_t i = l; i < lb; i += 64) g[0].T[i] = i;
+    if (l == 0) { FNode n0; n0.fo = 0; n0.fc = la; n0.to = 0; n0.tc = lb; g[0].nd[0] = n0; }   // (a single suffix: position 0 = offset 0)
+    uint32_t nn = 1, par = 0;
+    int64_t fuel = 100000;                                           // ?SEARCH_FUEL
+    uint64_t gen_entries = (uint64_t)la + lb;
+    wave_sync();
+    while (true) {                                                   // find_jump_points_loop (:115-128)
+      if (fuel < 0) break;
+      if (rng_rand(c.rng, 8) == 0) break;                            // ?SEARCH_STOP_IP
+      if (c.work_budget) {                                           // optional engine guard: a round costs its list members
+        c.work += 16ull * gen_entries;
+        if (c.work > c.work_budget) { c.status = CASE_BUDGET; c.ws_used = mark; return false; }
+      }
+      uint32_t nchild = fuse_round(A, la, B, lb, g[par], nn, g[par ^ 1], par, sym, &gen_entries);
+      if (nchild == 0) break;                                        // NoDesp =:= [] -> any_position_pair(Nodes)
+      par ^= 1; nn = nchild;
+      fuel -= (int64_t)nchild;
+      prof_rounds++;
+    }
+    // any_position_pair/1 (:73-77); odd generations are stored reversed
+    uint32_t ni = rng_rand(c.rng, nn);
+    FNode nd = g[par].nd[par ? nn - 1 - ni : ni];
+    uint32_t fo = uni(nd.fo), fc = uni(nd.fc), to = sym ? fo : uni(nd.to), tc = sym ? fc : uni(nd.tc);
+    if (fc > 0) { uint32_t j = rng_rand(c.rng, fc); from = fc == 1 ? fo : uni(g[par].F[fo + (par ? fc - 1 - j : j)]); }
+    if (tc > 0) { uint32_t j = rng_rand(c.rng, tc); tpos = tc == 1 ? to : uni(g[par].T[to + (par ? tc - 1 - j : j)]); }
+  }
+#ifdef EH_PROF
+  {                                                                // slots 112..125: fuse calls by log2(la + lb), 126: rounds
+    uint32_t tot = la + lb, b = 0; while ((256u << b) < tot && b < 13) b++;
+    EH_PT(c, 112 + b);
+    if (EH_LANE == 0) { atomicAdd(&c.p->prof[2 * 126], (unsigned long long)prof_rounds); atomicAdd(&c.p->prof[2 * 126 + 1], 1ull); }
+  }
+#endif
   c.ws_used = mark;                                                // release all tables
   // jump/3 (:47-50): Al up to From, then To
   uint32_t nl = from + (lb - tpos);

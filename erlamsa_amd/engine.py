@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ERLAMSA_HIP_LIB") or os.path.join(_HERE, "liberlamsa_hip.so")
 
-EH_ABI_VERSION = 3
+EH_ABI_VERSION = 4
 EH_FLAG_ORDERED_OUTPUT = 1
 
 CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BUDGET = 0, 1, 2, 3, 4, 5
@@ -20,7 +20,7 @@ CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BU
 # every symbol include/erlamsa_hip.h declares
 ABI_SYMBOLS = [
     "eh_create", "eh_destroy", "eh_configure", "eh_corpus_upload", "eh_corpus_attach", "eh_fuzz_batch",
-    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_prof", "eh_selftest_movers",
+    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_fetch", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_prof", "eh_selftest_movers",
     "eh_last_kernel_ms", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
@@ -32,7 +32,8 @@ class EhOptions(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("mutations", C.c_char_p), ("patterns", C.c_char_p),
                 ("generators", C.c_char_p), ("blockscale", C.c_double), ("ssrf_host", C.c_char_p),
                 ("ssrf_port", C.c_int32), ("max_case_bytes", C.c_uint64), ("out_capacity", C.c_uint64),
-                ("max_case_work", C.c_uint64), ("max_slots", C.c_uint32), ("flags", C.c_uint32), ("big_case_bytes", C.c_uint64)]
+                ("max_case_work", C.c_uint64), ("max_slots", C.c_uint32), ("flags", C.c_uint32), ("big_case_bytes", C.c_uint64),
+                ("tier_bytes", C.c_uint64), ("download_chunk_bytes", C.c_uint64), ("fuse_stream_min", C.c_uint64)]
 
 
 class EngineError(RuntimeError):
@@ -73,6 +74,7 @@ def load_library():
     lib.eh_result_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u64p]
     lib.eh_result_download.argtypes = [vp, vp, C.c_uint64, vp, vp]
     lib.eh_result_totals.argtypes = [vp, u64p, u64p, u64p]
+    lib.eh_result_fetch.argtypes = [vp, C.c_uint64, vp, C.c_uint64, u64p]
     lib.eh_result_diag.argtypes = [vp, vp, vp]
     lib.eh_result_cycles.argtypes = [vp, vp]
     lib.eh_result_prof.argtypes = [vp, vp]
@@ -142,7 +144,8 @@ class Engine:
             raise EngineError(rc, self.lib.eh_last_error(self.h).decode() or self.lib.eh_strerror(rc).decode())
 
     def configure(self, mutations=None, patterns=None, generators=None, blockscale=1.0, ssrf_host=None, ssrf_port=0,
-                  max_case_bytes=0, out_capacity=0, max_slots=0, flags=0, max_case_work=0, big_case_bytes=0):
+                  max_case_bytes=0, out_capacity=0, max_slots=0, flags=0, max_case_work=0, big_case_bytes=0,
+                  tier_bytes=0, download_chunk_bytes=0, fuse_stream_min=0):
         o = EhOptions()
         o.abi_version = EH_ABI_VERSION
         o.mutations = mutations.encode() if mutations is not None else None
@@ -153,6 +156,7 @@ class Engine:
         o.ssrf_port = ssrf_port
         o.max_case_bytes = max_case_bytes
         o.big_case_bytes = big_case_bytes
+        o.tier_bytes, o.download_chunk_bytes, o.fuse_stream_min = tier_bytes, download_chunk_bytes, fuse_stream_min
         o.out_capacity = out_capacity
         o.max_slots = max_slots
         o.max_case_work = max_case_work
@@ -211,6 +215,25 @@ class Engine:
         buf = data.tobytes()
         outs = [buf[int(off[i]):int(off[i + 1])] for i in range(n)]
         return outs, status[:n]
+
+    def lens(self):
+        """output length of every case of the last batch, uint64[n] (no bytes are copied)"""
+        n = self.last_n
+        off = np.zeros(n + 1, dtype=np.uint64)
+        self._chk(self.lib.eh_result_download(self.h, None, 0, off.ctypes.data, None))
+        return np.diff(off)
+
+    def fetch(self, i, length=None):
+        """output bytes of case i of the last batch (eh_result_fetch)"""
+        ln = C.c_uint64()
+        if length is None:
+            rc = self.lib.eh_result_fetch(self.h, i, None, 0, C.byref(ln))
+            if rc == 0:
+                return b""
+            length = ln.value
+        buf = np.zeros(max(int(length), 1), dtype=np.uint8)
+        self._chk(self.lib.eh_result_fetch(self.h, i, buf.ctypes.data, int(length), C.byref(ln)))
+        return buf[:ln.value].tobytes()
 
     def download_into(self, host_ptr, cap):
         """Case-ordered outputs of the last batch into caller memory at `host_ptr` (`cap` bytes; pinned or registered

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EH_ABI_VERSION 3
+#define EH_ABI_VERSION 4
 
 typedef struct eh_ctx eh_ctx;
 
@@ -89,6 +89,13 @@ typedef struct eh_options {
                                 wavefronts, up to this size; only a case that outgrows this too ends as
                                 EH_CASE_OVERFLOW.  0 => 32 x max_case_bytes, at most 1 GiB; <= max_case_bytes => a
                                 single tier */
+  /* ABI 4: engine tuning that used to be environment variables of the library */
+  uint64_t tier_bytes;       /* device memory of every overflow tier; 0 => an eighth of the memory that is free when the
+                                tiers are reserved, 1 .. 32 GiB.  Every tier holds at least 2 work areas */
+  uint64_t download_chunk_bytes; /* bounce-buffer size of eh_result_download's device gather; 0 => 256 MiB */
+  uint64_t fuse_stream_min;  /* erlamsa_fuse:fuse/2 on la + lb >= this many bytes runs as the position-indexed class
+                                refinement (csrc/eh_fuse2.h) instead of the node-list refinement (csrc/eh_fuse.h);
+                                results are identical.  0 => 16384 */
 } eh_options;
 
 #define EH_FLAG_ORDERED_OUTPUT 1u /* compact the output arena into case order after the batch */
@@ -147,6 +154,9 @@ int eh_result_device(eh_ctx* ctx, const uint8_t** d_data, const uint64_t** d_off
 /* Copies to host: `data` receives total_bytes (<= cap) bytes laid out in case order
  * regardless of EH_FLAG_ORDERED_OUTPUT; off has n+1 entries.  Any pointer may be NULL. */
 int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, int32_t* status);
+/* One case of the last batch: copies its output (<= cap bytes) to `buf` and stores its length; EH_E_INVALID with
+ * *out_len set when cap is too small.  For consumers that want a few results of a large batch. */
+int eh_result_fetch(eh_ctx* ctx, uint64_t i, uint8_t* buf, uint64_t cap, uint64_t* out_len);
 /* Totals of the last batch (sum of input bytes read, output bytes written, cases). */
 int eh_result_totals(eh_ctx* ctx, uint64_t* in_bytes, uint64_t* out_bytes, uint64_t* n_cases);
 /* Per-case diagnostics of the last batch (device->host): PRNG draws consumed by the worker and

@@ -54,10 +54,10 @@ assert g == want and list(s) == list(wst)
 inb, outb, nc = eng.totals()
 assert nc == 40 and inb == 40 * 200 and outb == sum(map(len, want))
 # the download path in many chunks (device gather into two alternating bounce buffers)
-os.environ["EH_DL_CHUNK"] = "700"
+eng.configure(mutations="bd=3,bf,bi=7", patterns="od,nd=2", generators="direct=500,random=1", download_chunk_bytes=700)   # results stay valid
 gc, sc = eng.download()
-del os.environ["EH_DL_CHUNK"]
 assert gc == want and list(sc) == list(wst)
+assert eng.fetch(3) == want[3] and list(eng.lens()) == [len(x) for x in want]
 # a sub-range with the matching first_case reproduces the same cases
 eng.fuzz_batch(seed=(1, 2, 3), first_case=11, corpus_first=10, n=5)
 g5, _ = eng.download()

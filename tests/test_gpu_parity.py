@@ -282,6 +282,57 @@ def test_bench_workload_sample_with_bench_limits():
              oracle_cap=8 << 20, engine_cap=8 << 20, work=8 << 20)
 
 
+# EH_SET_OVERFLOW sites (csrc/) that are limits of the ENGINE on a single result, not bugs: 102 the largest work area
+# (big_case_bytes) is exhausted, 802 a tree stutter (tr) whose result k^reps x |node| exceeds it (the reference builds the
+# same binary until its 256 MB process guard truncates the stutter, erlamsa_mutations.erl:978-984), 803 / 103 a single
+# result of 4 GiB or more.
+ENGINE_LIMIT_SITES = (102, 103, 802, 803)
+
+
+def test_bench_workload_full_table_vs_oracle():
+    """THE WORKLOAD bench.py TIMES, against the oracle: BASELINE configs[2] — synth.mixed(65536, 4096), the reference's full
+    default mutator table (41 entries), patterns od,nd,bu, no work budget, max_case_bytes 16 MiB / big_case_bytes 1 GiB —
+    run as one pass of 65 536 cases; compared with tests/golden/bench_r03.npz (made by tests/golden/make_bench_golden.py
+    from the oracle with the same 1 GiB cap) on rows 0..4095 and on the 200 heaviest cases of the pass
+    (tests/golden/bench_heavy_cases.json: multi-megabyte blocks under fuse / sgm / b64 / tree mutators, outputs up to
+    1 GB): status, PRNG draw count, length and SHA-1 of every output.  A case may only end with an engine-only status when
+    the capacity check that gave up is one of ENGINE_LIMIT_SITES — and then the oracle, under the same cap, must agree."""
+    import hashlib
+    import os
+    if util.priming():
+        pytest.skip("golden file, no live oracle")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_r03.npz"))
+    import erlamsa_amd as ea
+    from erlamsa_amd import synth
+    n = 65536
+    mat = synth.mixed(n, 4096)
+    data, off = synth.as_arena(mat)
+    eng = ea.Engine(0)
+    eng.configure(patterns="od,nd,bu", max_case_bytes=16 << 20, big_case_bytes=1 << 30, out_capacity=40 << 30)
+    eng.upload_corpus(data, off)
+    eng.fuzz_batch(seed=(1, 2, 3))
+    st = eng.status(); draws, lm = eng.diag(); lens = eng.lens()
+    assert (st != 4).all(), "output arena too small"
+    limited = np.nonzero(st == 2)[0]
+    assert all(-int(lm[i]) in ENGINE_LIMIT_SITES for i in limited), "a case overflowed at a site that is not a single-result limit: %s" % \
+        sorted(set(-int(lm[i]) for i in limited))
+    assert len(limited) <= n // 400 and (st == 3).sum() == 0 and (st == 5).sum() == 0
+    bad = []
+    for k, i in enumerate(z["idx"]):
+        i = int(i)
+        if int(st[i]) != int(z["status"][k]):
+            bad.append((i, "status %d vs oracle %d (site %d)" % (st[i], z["status"][k], -lm[i] if st[i] == 2 else 0)))
+            continue
+        if st[i] != 0:
+            continue
+        if int(lens[i]) != int(z["lens"][k]) or int(draws[i]) != int(z["draws"][k]):
+            bad.append((i, "len %d vs %d, draws %d vs %d" % (lens[i], z["lens"][k], draws[i], z["draws"][k])))
+        elif hashlib.sha1(eng.fetch(i, int(lens[i]))).digest() != z["sha1"][k].tobytes():
+            bad.append((i, "bytes differ (len %d)" % lens[i]))
+    eng.close()
+    assert not bad, "%d of %d cases differ from the oracle: %s" % (len(bad), len(z["idx"]), bad[:8])
+
+
 def test_results_do_not_depend_on_slot_count_or_batch_cut():
     """Full-size property (no oracle): the same 16384 cases through 4096 slots in one call, and through 256
     slots in three calls, give identical bytes and statuses — results are a pure function of
@@ -396,14 +447,12 @@ def test_download_in_many_chunks_and_into_caller_memory():
     eng.fuzz_batch(seed=(5, 5, 5))
     whole, st = eng.download()
     assert all(st[i] == ora.status[i] and ora.same(i, whole[i]) for i in range(n) if st[i] not in (2, 3) and ora.status[i] not in (2, 3))
-    os.environ["EH_DL_CHUNK"] = "16384"
-    try:
-        chunked, st2 = eng.download()
-        _, total, _ = eng.totals()
-        buf = np.full(total + 64, 0xAB, dtype=np.uint8)
-        offs, st3 = eng.download_into(buf.ctypes.data, total)
-    finally:
-        del os.environ["EH_DL_CHUNK"]
+    eng.configure(mutations=muts, patterns="od,nd,bu", max_case_bytes=8 << 20, download_chunk_bytes=16384)   # results stay valid
+    chunked, st2 = eng.download()
+    _, total, _ = eng.totals()
+    buf = np.full(total + 64, 0xAB, dtype=np.uint8)
+    offs, st3 = eng.download_into(buf.ctypes.data, total)
+    assert eng.fetch(7) == whole[7] and eng.fetch(n - 1) == whole[n - 1] and list(eng.lens()) == [len(x) for x in whole]
     assert chunked == whole and list(st2) == list(st) and list(st3) == list(st)
     assert int(offs[-1]) == total and bytes(buf[:total]) == b"".join(whole) and (buf[total:] == 0xAB).all()
     eng.close()

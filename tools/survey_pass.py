@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""One full pass of the bench workload (BASELINE configs[2], case ids BASE+1 .. BASE+65536) with the EH_PROF build:
+per-case cycles / status / draws / last mutator / output length saved to gpurun_out/<tag>_cases.npz, the per-mutator
+and per-size fuse totals printed, the heaviest TOP cases listed.
+usage: ERLAMSA_HIP_LIB=build/liberlamsa_hip_prof.so tools/survey_pass.py TAG [BASE] [TOP] [N]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import erlamsa_amd as ea
+from erlamsa_amd import synth
+
+tag = sys.argv[1]
+base = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
+mat = synth.mixed(65536, 4096)[:n]
+data, off = synth.as_arena(mat)
+names = [m[0] for m in ea.mutator_table()]
+eng = ea.Engine(0)
+eng.configure(fuse_stream_min=int(os.environ.get("FUSE_STREAM_MIN", "0")), patterns="od,nd,bu", out_capacity=40 << 30, max_case_bytes=16 << 20, big_case_bytes=1024 << 20,
+              max_slots=int(os.environ.get("MAX_SLOTS", "0")))
+eng.upload_corpus(data, off)
+eng.fuzz_batch(seed=(1, 2, 3), first_case=base + 1, corpus_first=0, n=n)
+eng.sync()
+cyc = eng.cycles().astype(np.float64)
+st = eng.status()
+dr, lm = eng.diag()
+_, ob, _ = eng.totals()
+import ctypes as C
+lens = np.zeros(n, dtype=np.uint64)
+print("kernel %.1f ms, total %.1f Gcyc, max %.1f Mcyc, out %.2f GB, status %s" % (
+    eng.kernel_ms(), cyc.sum() / 1e9, cyc.max() / 1e6, ob / 1e9, np.bincount(st, minlength=6).tolist()))
+pct = np.percentile(cyc, [50, 90, 99, 99.9, 99.99])
+print("percentiles Mcyc 50/90/99/99.9/99.99:", (pct / 1e6).round(2).tolist())
+srt = np.sort(cyc)[::-1]
+for k in (1, 10, 100, 1000, 4096):
+    print("  sum of the %d heaviest: %.1f Gcyc (%.1f%%)" % (k, srt[:k].sum() / 1e9, 100 * srt[:k].sum() / cyc.sum()))
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", tag + "_cases.npz"), cycles=cyc, status=st, draws=dr, lastm=lm)
+order = np.argsort(-cyc)[:top]
+print("top cases:")
+for i in order[:40]:
+    print("  case %d: %.0f Mcyc status %d draws %d last %s" % (i, cyc[i] / 1e6, st[i], dr[i], names[lm[i]] if 0 <= lm[i] < len(names) else str(lm[i])))
+pr = eng.prof().astype(np.float64)
+if pr.sum() > 0:
+    print("EH_PROF per mutator attempt (calls, mean kcyc, total Gcyc, share):")
+    tot = sum(pr[2 * m] for m in range(len(names)))
+    for m in range(len(names)):
+        if pr[2 * m + 1] > 0:
+            print("  %-6s %9d %10.1f %10.2f %5.1f%%" % (names[m], pr[2 * m + 1], pr[2 * m] / pr[2 * m + 1] / 1e3, pr[2 * m] / 1e9, 100 * pr[2 * m] / tot))
+    print("fuse_lists calls by la+lb (<= bytes: calls, mean kcyc, total Gcyc):")
+    for b in range(14):
+        k = 112 + b
+        if pr[2 * k + 1] > 0:
+            print("  <=%8d %9d %10.1f %10.2f" % (256 << b, pr[2 * k + 1], pr[2 * k] / pr[2 * k + 1] / 1e3, pr[2 * k] / 1e9))
+    if pr[2 * 126 + 1] > 0:
+        print("  rounds per fuse_lists call: %.2f" % (pr[2 * 126] / pr[2 * 126 + 1]))
+    for k in range(64, 112):
+        if pr[2 * k + 1] > 0:
+            print("  slot %3d calls %9d mean %10.1f kcyc total %8.2f Gcyc" % (k, pr[2 * k + 1], pr[2 * k] / pr[2 * k + 1] / 1e3, pr[2 * k] / 1e9))
