@@ -17,6 +17,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# passes in flight run on separate HIP streams; the runtime maps streams onto this many hardware queues (default 4), and
+# two batches on one hardware queue run one after the other.  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DESC_BYTES = 24        # per-case descriptor: out_off, out_len, status/draws
@@ -112,9 +115,10 @@ def main():
     ap.add_argument("--cpu-case-seconds", type=float, default=10.0, help="per-case wall-clock watchdog of the CPU oracle leg "
                     "(the reference's maxrunningtime; its CLI default is 30 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle leg (0 = all host cores, at most 64)")
-    ap.add_argument("--max-slots", type=int, default=1365, help="tier-0 wavefront slots per context (0 = 16 per CU); the default x 3 contexts = 16 per CU")
-    ap.add_argument("--tier-gib", type=int, default=8, help="device memory of every overflow tier of a context (GiB), eh_options.tier_bytes; "
-                    "0 = the library's own rule (an eighth of the free memory, for a single context)")
+    ap.add_argument("--max-slots", type=int, default=0, help="persistent workgroups of one pass (0 = one per wavefront the device holds: "
+                    "8 per CU); passes in flight oversubscribe the device and share one pool of work areas")
+    ap.add_argument("--tier-gib", type=int, default=8, help="device memory of every tier of larger work areas of the shared pool (GiB), "
+                    "eh_options.tier_bytes; 0 = the library's own rule (an eighth of the free memory)")
     ap.add_argument("--out-gib", type=int, default=28, help="output arena capacity per context (GiB)")
     ap.add_argument("--case-mib", type=int, default=16, help="per-case work area of every resident wavefront (MiB), eh_options.max_case_bytes")
     ap.add_argument("--big-mib", type=int, default=1024, help="largest work area (MiB), eh_options.big_case_bytes: a case that outgrows its area "
@@ -125,9 +129,9 @@ def main():
                     "0 = off (default): every case runs to completion like under the reference's 30 s CLI watchdog")
     ap.add_argument("--pcie", type=int, default=1, help="1: after the timed steps, one extra pass whose outputs are downloaded to pinned host memory "
                     "(reported as 'pcie'); 0: skip")
-    ap.add_argument("--inflight", type=int, default=3, help="passes in flight (engine contexts / HIP streams): the tail of a pass — a few "
-                    "multi-second single-wavefront cases — overlaps with the bulk of the next ones.  Every context owns its work-area "
-                    "tiers and output arena: about 73 GiB at the defaults, 220 GiB for 3")
+    ap.add_argument("--inflight", type=int, default=6, help="passes in flight (engine contexts / HIP streams): the tail of a pass — a few "
+                    "long single-wavefront cases — overlaps with the bulk of the next ones.  Every context owns its output arena (--out-gib); "
+                    "the work areas come from one pool shared by all contexts (about 33 GiB + 3 x --tier-gib at the defaults)")
     args = ap.parse_args()
 
     import numpy as np

@@ -84,10 +84,7 @@ struct KParams {
   const RunState* run;        // mode 0
   const int64_t* seeds;       // mode 1: 3n
   DevConfig cfg;
-  // per-slot memory
-  uint8_t* slot_base;
-  uint64_t slot_stride;
-  uint64_t work_cap;          // bytes of the linear work area
+  uint64_t work_cap;          // bytes of the linear work area of a tier-0 slot
   uint64_t work_budget;       // per-case byte budget (sum of block sizes handed to mutators)
   uint64_t fuse_stream_min;   // fuse/2 on la + lb >= this many bytes runs as the position-indexed refinement of eh_fuse2.h
   // outputs
@@ -100,30 +97,23 @@ struct KParams {
   uint64_t* draws;
   int32_t* lastm;
   uint64_t* cycles;           // per-case shader-clock ticks (diagnostic)
+  uint64_t* peak;             // per-case work-memory high-water mark in bytes (diagnostic)
   unsigned long long* prof;   // EH_PROF builds: [2*k] cycles, [2*k+1] calls; k < 64 mutator fn, 64.. phases
   unsigned long long* ticket;
   unsigned long long* in_bytes;
-  // Tiered work areas.  Tier 0: every resident wavefront has a small area (max_case_bytes).  A case that outgrows its
-  // area is queued and run again from scratch (same result: a case is a pure function of its number) by the next
-  // tier: 4x larger areas, fewer wavefronts, up to big_case_bytes.  All tiers of a batch are ONE dispatch: workgroups
-  // [0, tier_wg_end[0]) are tier 0, [tier_wg_end[0], tier_wg_end[1]) tier 1, ... (the argument block is an array, one
-  // entry per tier).  Workgroups are dispatched in index order, so the producers are resident before the consumers;
-  // tier t > 0 consumes its queue while the tiers below are still filling it (entries start as 0xFFFFFFFF and are
-  // published after a fence; a consumer leaves when the entry it waits for is still empty after every workgroup of
-  // tier t-1 has left, which in turn left only after the tiers below it).
-  int32_t tier;
-  uint32_t* in_q;                // tier > 0: case indices (of this batch) to run
-  unsigned long long* prod_done; // tier > 0: workgroups of tier t-1 that have finished ...
-  uint64_t prod_grid;            // ... out of this many
-  // a case that overflows here goes to the first later tier whose area is at least twice what it had asked for (the
-  // next one if that is unknown), or to none if a single request exceeds the largest area
+  // Work areas come from a POOL that all contexts of a device share (eh_engine.hip, DevPool): a workgroup pops a tier-0
+  // slot (block tables + max_case_bytes of work area) when it starts and pushes it back when it leaves, so the memory is
+  // sized by the wavefronts the GPU can hold, not by the number of batches in flight.  A case that outgrows its area is
+  // run again from scratch (same result: a case is a pure function of its number) by the SAME wavefront in a larger
+  // area borrowed from tier 1.. (4x the area per tier up to big_case_bytes), chosen by what the case had asked for.
+  // Every tier is a ring of free area indices: pool_ctr[2t] = pop tickets, pool_ctr[2t+1] = push tickets.
   int32_t ntiers;                // tiers above 0
-  uint32_t tier_wg_end[6];       // entry 0 only: workgroup ranges of the tiers (see above)
-  uint64_t tier_cap[5];          // work area of tier 1 .. ntiers
-  uint32_t* q_base;              // queue of tier t: q_base + (t-1) * q_stride, q_stride entries
-  uint64_t q_stride;
-  unsigned long long* q_count;   // entries queued for tier t: q_count[4 * t]
-  unsigned long long* my_done;   // finished workgroups of this tier (nullptr: last tier)
+  uint8_t* pool_base[6];         // tier t: area k at pool_base[t] + k * pool_stride[t]
+  uint64_t pool_stride[6];
+  uint64_t pool_cap[6];          // work-area bytes of an area of tier t (pool_cap[0] == work_cap)
+  uint32_t pool_cnt[6];
+  uint32_t* pool_ring[6];
+  unsigned long long* pool_ctr;
 };
 
 struct MutaInfo { const char* name; int pri; int on_gpu; };

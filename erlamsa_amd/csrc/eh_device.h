@@ -219,6 +219,10 @@ EH_DEV bool wave_equal(const uint8_t* a, const uint8_t* b, uint32_t n) {
 // Per-case context (all wave-uniform)
 // ---------------------------------------------------------------------------------------------
 // site: 1xx eh_device.h, 2xx eh_doc.h, 3xx eh_engine.hip, 4xx eh_json.h, 5xx eh_lex.h, 6xx eh_sgml.h, 7xx eh_text.h, 8xx eh_tree.h
+constexpr int MAX_CHUNKS = 6;
+constexpr int MAX_NEST = 6;         // nested scheduler calls (b64 / sgm / js inner mutations)
+constexpr int LEX_LEVELS = MAX_NEST + 1;
+constexpr int ST_STATE_WORDS = 84;  // sizeof(StState) / 4 (eh_text.h; checked there)
 #define EH_SET_OVERFLOW(c, site) ((c).ovf_line = (site), (c).ovf_need = 0, (c).ovf_req = 0, (c).status = CASE_OVERFLOW)
 struct Ctx {
   Rng rng;
@@ -232,7 +236,16 @@ struct Ctx {
   uint8_t* aux;        // per-slot mutator state (lis/lrs lines, fo block)
   // linear work allocator
   uint8_t* ws;
+  // ws + ws_used is the next free byte; ws_used and ws_cap are VIRTUAL offsets that run on across the chunks of the work
+  // area (chunk 0 = the slot's own area, chunks 1.. = larger areas borrowed from the pool when the case outgrows what it has,
+  // see ws_grow), and ws is the current chunk's base minus the chunk's virtual start, so the arithmetic is that of one area
   uint64_t ws_used, ws_cap;
+  int nchunk;          // chunks above the slot's own
+  int view;            // chunk ws / ws_lo / ws_cap describe (the one the last allocation came from)
+  uint64_t ws_lo;      // its virtual start
+  uint64_t ch_vstart[MAX_CHUNKS], ch_vend[MAX_CHUNKS]; uint8_t* ch_base[MAX_CHUNKS]; uint32_t ch_area[MAX_CHUNKS]; int32_t ch_tier[MAX_CHUNKS];
+  uint64_t lex_ptr[LEX_LEVELS];   // block the lex cache of nesting level d holds a table for (mirror of LexCache::ptr; 0: none)
+  uint64_t ws_peak, ws_top;   // diagnostics: highest ws_used, bytes taken from the top of chunks (eh_result_peak)
   int status;
   int lastm;
   uint64_t work;       // bytes handed to mutators so far (deterministic stand-in for maxrunningtime)
@@ -268,6 +281,7 @@ __shared__ Ctx g_ctx;
 // program order, so nothing is emitted; on the emulator the ballot is a rendezvous of the lane fibers.
 EH_DEV void lanes_sync() { (void)__ballot(1); }
 #define EH_CTX Ctx& c = g_ctx
+EH_LDS_ARRAY(uint32_t, g_st_save, ST_STATE_WORDS);   // lis / lrs store as it was before the running attempt (mux_fuzzers)
 // per-lane mux_fuzzers entry (lane i = list position i); private registers, never in LDS
 struct LaneTab {
   uint32_t e_pri;
@@ -284,12 +298,152 @@ enum { R_SAME = 0, R_NEW = 1 };
 #define EH_PT(c, k) do {} while (0)
 #endif
 
+// ---- work-area pool (see KParams): lane 0 talks to the rings, the wave takes the result.  A popper owns ring entry
+// (ticket mod count) and waits until a pusher has filled it; a pusher waits until the entry's previous value has been
+// taken.  A wavefront only ever waits for an area of a HIGHER tier than any it holds, so the waits end.
+EH_DEV void pool_nap() {
+#ifndef HIPEMU
+  __builtin_amdgcn_s_sleep(64);
+#else
+  fprintf(stderr, "hipemu: a wait for a pool area can never end with one wavefront running (block %u)\n", blockIdx.x); abort();
+#endif
+}
+EH_DEV uint32_t pool_pop(const KParams& p, int t) {
+  uint32_t v = 0xFFFFFFFFu;
+  if (EH_LANE == 0) {
+    unsigned long long h = atomicAdd(&p.pool_ctr[2 * t], 1ull);
+    uint32_t* e = p.pool_ring[t] + (h % p.pool_cnt[t]);
+    v = atomicExch(e, 0xFFFFFFFFu);
+    if (v == 0xFFFFFFFFu) {                                          // every area of the tier is out: wait for a push (eh_pool_stats counts the cycles)
+      uint64_t w0 = __builtin_readcyclecounter();
+      for (;;) { pool_nap(); v = atomicExch(e, 0xFFFFFFFFu); if (v != 0xFFFFFFFFu) break; }
+      atomicAdd(&p.pool_ctr[16 + t], (unsigned long long)(__builtin_readcyclecounter() - w0));
+      atomicAdd(&p.pool_ctr[24 + t], 1ull);
+    }
+  }
+  __threadfence();                                                   // the previous owner's stores (another XCD's L2) are behind us
+  return uni(v);
+}
+EH_DEV void pool_push(const KParams& p, int t, uint32_t v) {
+  __threadfence();                                                   // our stores to the area are written back before it changes hands
+  if (EH_LANE == 0) {
+    unsigned long long h = atomicAdd(&p.pool_ctr[2 * t + 1], 1ull);
+    uint32_t* e = p.pool_ring[t] + (h % p.pool_cnt[t]);
+    while (atomicCAS(e, 0xFFFFFFFFu, v) != 0xFFFFFFFFu) pool_nap();
+  }
+}
+
+// Lex caches (eh_lex.h), one per nesting level of the scheduler: a mutator that walks its block's chunk table may call the
+// scheduler on a piece of it (base64 chunks, inner texts), and the mutators down there lex their own blocks.  A table lives at
+// the top of a work-area chunk and survives candidate discards; tcap = entries it has room for (0: no table).
+struct LexChunk;
+struct LexCache { uint64_t ptr; uint32_t len; int32_t n; LexChunk* tab; uint32_t tcap; uint32_t pad; };
+constexpr uint32_t AUX_LEXCACHE = 2048;                              // offset in Ctx::aux of LexCache[LEX_LEVELS]
+constexpr uint64_t AUX_BYTES = 4096;
+EH_DEV LexCache& lex_slot(Ctx& c) { return ((LexCache*)(c.aux + AUX_LEXCACHE))[c.depth]; }
+// Work memory at virtual offsets >= v0 is about to be reused: a lexed block that lives there (a decoded base64 chunk, an
+// inner text — temporaries of a mutator attempt) is gone, and the cache is keyed by address.  Only this level's key can
+// be up there: the blocks of the levels above are older than anything the running attempt allocated.
+EH_DEV void lex_forget_from(Ctx& c, uint64_t v0) {
+  const uint64_t key = c.lex_ptr[c.depth];
+  if (key == 0) return;
+  bool dead = false;
+  for (int j = 0; j <= c.nchunk; j++) {
+    uint64_t v = key - (uint64_t)(uintptr_t)c.ch_base[j], lo = v0 > c.ch_vstart[j] ? v0 : c.ch_vstart[j];
+    if (v >= lo && v < c.ch_vstart[j] + c.p->pool_cap[c.ch_tier[j]]) dead = true;
+  }
+  if (dead) { c.lex_ptr[c.depth] = 0; if (EH_LANE == 0) lex_slot(c).n = -1; }
+}
+// ---- the work area of a case: a stack of chunks ---------------------------------------------------------------------
+// Chunk 0 is the slot's own area; chunks 1..nchunk are larger areas the case borrowed when it outgrew what it had.  The
+// allocator below never talks to the pool — mutators stay leaf functions without a frame — it only moves between the
+// chunks the case HOLDS (`view`): memory is released by plain assignments to ws_used all over the code, so an allocation
+// may find ws_used below the chunk it last used, or find that the request fits the next chunk up.  When nothing the case
+// holds can serve a request the allocation fails with CASE_OVERFLOW and ovf_need / ovf_req say what was asked for; the
+// callers that can afford it (the scheduler around a mutator attempt, the pattern code) then borrow an area of a higher
+// tier and repeat ONLY that attempt (ws_regrow), so nothing a case has done is run again.
+EH_DEV void ws_set_view(Ctx& c, int j) { c.view = j; c.ws = c.ch_base[j]; c.ws_lo = c.ch_vstart[j]; c.ws_cap = c.ch_vend[j]; }
+EH_DEV bool ws_slow(Ctx& c, uint64_t need, int site) {
+  int j = c.nchunk;
+  while (j > 0 && c.ws_used < c.ch_vstart[j]) j--;
+  for (; j <= c.nchunk; j++) {
+    uint64_t at = c.ws_used > c.ch_vstart[j] ? c.ws_used : c.ch_vstart[j];
+    if (at + need <= c.ch_vend[j]) { c.ws_used = at; ws_set_view(c, j); return true; }
+  }
+  EH_SET_OVERFLOW(c, site); c.ovf_need = c.ws_used + need; c.ovf_req = need;
+  return false;
+}
+EH_DEV uint64_t ws_max_request(const Ctx& c) { return c.p->pool_cap[c.p->ntiers]; }   // the largest single allocation a case can get
 EH_DEV uint8_t* ws_alloc(Ctx& c, uint64_t n) {
   uint64_t need = (n + 15) & ~(uint64_t)15;
-  if (c.ws_used + need > c.ws_cap) { EH_SET_OVERFLOW(c, 102); c.ovf_need = c.ws_used + need; c.ovf_req = need; return nullptr; }
+  if ((c.ws_used < c.ws_lo || c.ws_used + need > c.ws_cap) && !ws_slow(c, need, 102)) return nullptr;
   uint8_t* p = c.ws + c.ws_used;
   c.ws_used += need;
+  if (c.ws_used > c.ws_peak) c.ws_peak = c.ws_used;
   return p;
+}
+// from the TOP of the chunk (tables that must survive candidate discards: the lex caches)
+EH_DEV uint8_t* ws_alloc_top(Ctx& c, uint64_t n) {
+  uint64_t need = (n + 15) & ~(uint64_t)15;
+  if ((c.ws_used < c.ws_lo || c.ws_used + need > c.ws_cap) && !ws_slow(c, need, 501)) return nullptr;
+  c.ws_cap -= need; c.ch_vend[c.view] = c.ws_cap; c.ws_top += need;
+  return c.ws + c.ws_cap;
+}
+// ws_used = mark, and borrowed areas that are empty now go back to the pool.  Not for leaf functions.
+__device__ __noinline__ void ws_release_to(Ctx&, uint64_t mark) {
+  Ctx& c = g_ctx;
+  c.ws_used = mark;
+  while (c.nchunk > 0 && mark <= c.ch_vstart[c.nchunk]) {
+    const int k = c.nchunk;
+    const KParams& p = *c.p;
+    uint8_t* lo = c.ch_base[k] + c.ch_vstart[k]; uint8_t* hi = lo + p.pool_cap[c.ch_tier[k]];
+    for (int d = 0; d < LEX_LEVELS; d++) {                           // lex tables and lexed blocks inside the chunk: forget them
+      LexCache* lc = (LexCache*)(c.aux + AUX_LEXCACHE) + d;
+      uint64_t tab = uni64((uint64_t)lc->tab), key = c.lex_ptr[d];
+      bool tin = uni(lc->tcap) != 0 && tab >= (uint64_t)lo && tab < (uint64_t)hi, kin = key >= (uint64_t)lo && key < (uint64_t)hi;
+      if (tin || kin) { c.lex_ptr[d] = 0; if (EH_LANE == 0) { lc->n = -1; if (tin) lc->tcap = 0; } }
+    }
+    wave_sync();
+    pool_push(p, c.ch_tier[k], c.ch_area[k]);
+    c.nchunk = k - 1;
+  }
+  int j = c.nchunk;
+  while (j > 0 && mark < c.ch_vstart[j]) j--;
+  ws_set_view(c, j);
+}
+// An allocation above `mark` failed (CASE_OVERFLOW with ovf_need set) and everything above mark has been given up: borrow
+// an area of a higher tier, large enough for twice what had been asked for above mark when it failed (at least the failed
+// request), and make it the top chunk starting at mark.  Waits for an area if the tier is out.  true: status is CASE_OK
+// again and the caller repeats its attempt; false: CASE_OVERFLOW stands (request above the largest area, or already there).
+__device__ __noinline__ bool ws_regrow(Ctx&, uint64_t mark) {
+  Ctx& c = g_ctx;
+  const KParams& p = *c.p;
+  const uint64_t asked = c.ovf_need > mark ? c.ovf_need - mark : c.ovf_req, req = c.ovf_req;
+  const int site = c.ovf_line;
+  ws_release_to(c, mark);
+  int tt = c.ch_tier[c.nchunk] + 1;
+  if (tt > p.ntiers || c.nchunk + 1 >= MAX_CHUNKS || req > p.pool_cap[p.ntiers] || asked > p.pool_cap[p.ntiers]) {
+    EH_SET_OVERFLOW(c, site); c.ovf_need = mark + asked; c.ovf_req = req; return false;
+  }
+  while (tt < p.ntiers && p.pool_cap[tt] < 2 * asked) tt++;
+  wave_sync();
+  const uint32_t area = pool_pop(p, tt);
+  const int k = c.nchunk + 1;
+  c.ch_vstart[k] = mark; c.ch_vend[k] = mark + p.pool_cap[tt]; c.ch_tier[k] = tt; c.ch_area[k] = area;
+  c.ch_base[k] = (uint8_t*)((uintptr_t)(p.pool_base[tt] + (uint64_t)area * p.pool_stride[tt]) - (uintptr_t)mark);
+  c.nchunk = k;
+  ws_set_view(c, k);
+  c.status = CASE_OK;
+  return true;
+}
+// ws_alloc for code that is not inside a mutator attempt (patterns, generators): grows the work area on the spot
+__device__ __noinline__ uint8_t* ws_alloc_grow(Ctx&, uint64_t n) {
+  Ctx& c = g_ctx;
+  for (;;) {
+    uint8_t* q = ws_alloc(c, n);
+    if (q || c.status != CASE_OVERFLOW || c.ovf_need == 0) return q;
+    if (!ws_regrow(c, c.ws_used)) return nullptr;
+  }
 }
 EH_DEV Blk blk_load(const Blk* t, int i) {
   Blk b = t[i];
@@ -653,7 +807,23 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
 #ifdef EH_PROF
     uint64_t pt0 = __builtin_readcyclecounter();
 #endif
-    int delta = run_mutator(c, fn, em_mask(meta));
+    // An attempt that runs out of work memory is repeated — that attempt only, from the same PRNG state — after the case
+    // has borrowed a larger area (ws_regrow).  lis / lrs update their store before they allocate: it is put back as well.
+    const Rng rng0 = c.rng; const uint64_t work0 = c.work;
+    const bool stateful = fn == M_LIS || fn == M_LRS;
+    if (stateful) { const uint32_t* ax = (const uint32_t*)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) g_st_save[i] = ax[i]; }
+    int delta;
+    for (;;) {
+      delta = run_mutator(c, fn, em_mask(meta));
+      if (c.status != CASE_OVERFLOW || c.ovf_need == 0) break;
+      wave_sync();
+      if (!ws_regrow(c, mark)) break;
+      lex_forget_from(c, mark);
+      c.rng = rng0; c.work = work0;
+      c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
+      if (stateful) { lanes_sync(); uint32_t* ax = (uint32_t*)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) ax[i] = g_st_save[i]; }
+      wave_sync();
+    }
 #ifdef EH_PROF
     if (l == 0) { atomicAdd(&c.p->prof[2 * fn], (unsigned long long)(__builtin_readcyclecounter() - pt0)); atomicAdd(&c.p->prof[2 * fn + 1], 1ull); }
 #endif
@@ -683,19 +853,22 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
       uint8_t* lo = c.ws + mark;
       // A candidate of more than a few MiB stays where it is: mux_fuzzers never hands out a block above
       // ABSMAX_BINARY_BLOCK again (:1269, split_into_maxblocks), so nothing will copy it as a whole any more, and sliding
-      // a 1 GiB tree-stutter result took a lone wavefront 0.7 s.
-      if (c.ws_used > c.ws_cap / 8 && c.r_len <= (4u << 20) && !c.r2 && c.r_ptr >= lo && c.r_ptr + c.r_len <= c.ws + c.ws_used) {
+      // a 1 GiB tree-stutter result took a lone wavefront 0.7 s.  (mark below the chunk the candidate is in: the attempt
+      // went on in the next area up; not worth a copy across areas.)
+      const uint64_t vs = c.ws_lo;
+      if (mark >= vs && c.ws_used - vs > (c.ws_cap - vs) / 8 && c.r_len <= (4u << 20) && !c.r2 && c.r_ptr >= lo && c.r_ptr + c.r_len <= c.ws + c.ws_used) {
         uint8_t* dst = lo;
         uint8_t* hp = (uint8_t*)h0.ptr;
         bool state_refs = uni(((const uint32_t*)c.aux)[0]) != 0 || uni(((const uint32_t*)(c.aux + 336))[0]) != 0 || uni(((const uint32_t*)(c.aux + 704))[3]) != 0;
-        if (!state_refs && hp >= c.ws && hp + ((h0.len + 15u) & ~15u) == lo && ((uintptr_t)hp & 15) == 0) dst = hp;
-        if (dst == hp && EH_LANE == 0) ((int32_t*)(c.aux + 1024))[3] = -1;       // the lex cache is keyed by (ptr, len): H's memory is being reused
+        if (!state_refs && hp >= c.ws + vs && hp + ((h0.len + 15u) & ~15u) == lo && ((uintptr_t)hp & 15) == 0) dst = hp;
         if (dst != c.r_ptr) { wave_sync(); wave_move_down(dst, c.r_ptr, c.r_len); wave_sync(); c.r_ptr = dst; }   // candidate stores must have landed
         c.ws_used = (uint64_t)(dst - c.ws) + (((uint64_t)c.r_len + 15) & ~(uint64_t)15);
+        lex_forget_from(c, (uint64_t)(dst - c.ws));                               // (H's own memory included when the candidate took its place)
       }
       commit_result(c); used = true; break;
     }
-    c.ws_used = mark;                                                             // discard candidate
+    if (c.nchunk > 0) ws_release_to(c, mark); else c.ws_used = mark;              // discard candidate
+    lex_forget_from(c, mark);
   }
   // --- new list: reverse(tried) ++ untried (sorted order)   :1268,1270,1279
   // dropped (:1270): the entry at sorted position `tried` leaves the list.

@@ -36,7 +36,6 @@
 
 namespace eh {
 
-constexpr uint64_t AUX_BYTES = 2048;
 
 EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
   (void)mask;
@@ -46,9 +45,9 @@ EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
     case M_LIS: return muta_st_line(c, (int)fn, st);
     case M_LRS: return muta_st_line(c, (int)fn, st + 1);
     case M_NUM: return muta_num(c);
-    case M_AB: case M_AD: return muta_ascii(c, *(LexCache*)(c.aux + 1024), (int)fn);
-    case M_URI: return muta_uri(c, *(LexCache*)(c.aux + 1024));
-    case M_B64: return muta_b64(c, *(LexCache*)(c.aux + 1024));
+    case M_AB: case M_AD: return muta_ascii(c, lex_slot(c), (int)fn);
+    case M_URI: return muta_uri(c, lex_slot(c));
+    case M_B64: return muta_b64(c, lex_slot(c));
     case M_ZIP: return muta_zip(c);
     case M_LEN: return muta_len(c);
     case M_FT: case M_FN: case M_FO: return muta_fuse(c, (int)fn, (FoState*)(c.aux + 704));
@@ -62,7 +61,6 @@ EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
 // Nested scheduler call (see eh_doc.h).  The inner list [Bin] lives above the outer block list; the stateful
 // mutators of the inner table (lis, lrs, fo) start from their initial state, as the closures of a fresh
 // mutators_mutator/1 do, so the outer states are parked in the work area for the duration of the call.
-constexpr int MAX_NEST = 6;
 __device__ __noinline__ int nested_fuzz(Ctx&, uint32_t e_pri, uint32_t e_meta, int nfs, const uint8_t* bin, uint32_t len) {
   EH_CTX;
   const int l = EH_LANE;
@@ -78,6 +76,8 @@ __device__ __noinline__ int nested_fuzz(Ctx&, uint32_t e_pri, uint32_t e_meta, i
   blk_store(c.bl, nb0, (uint64_t)bin, len);
   wave_sync();
   c.cur = nb0; c.nb = nb0 + 1; c.nfs = nfs; c.depth++;
+  c.lex_ptr[c.depth] = 0;                                                  // this level's last lexed block was a temporary of an earlier call
+  if (l == 0) lex_slot(c).n = -1;
   LaneTab lt; lt.e_pri = e_pri; lt.e_meta = e_meta;
   mux_fuzzers(c, lt);
   c.depth--;
@@ -237,7 +237,7 @@ __device__ __noinline__ int pick_csum(Ctx&, const uint8_t* H, uint32_t L, uint32
   uint32_t tot = wave_xor8(H, L - 1);
   uint32_t target = tot ^ last;
   uint64_t mark = c.ws_used;
-  uint8_t* flags = ws_alloc(c, (uint64_t)np * 2);                  // [0,np): xor8 hit, [np,2np): crc32 hit
+  uint8_t* flags = ws_alloc_grow(c, (uint64_t)np * 2);                  // [0,np): xor8 hit, [np,2np): crc32 hit
   if (!flags) return -1;
   uint32_t carry = 0, nx = 0;
   for (uint32_t base = 0; base < np; base += 64) {
@@ -261,7 +261,7 @@ __device__ __noinline__ int pick_csum(Ctx&, const uint8_t* H, uint32_t L, uint32
     uint32_t E = L - 4;
     uint32_t whole = wave_crc32(H, E);                             // crc(0..E)
     // prefix CRCs crc(0..A) for A <= maxp: one sequential table walk shared by the wave ...
-    uint32_t* pre = (uint32_t*)ws_alloc(c, (uint64_t)np * 4);
+    uint32_t* pre = (uint32_t*)ws_alloc_grow(c, (uint64_t)np * 4);
     if (!pre) return -1;
     uint32_t run = 0xFFFFFFFFu;
     ByteReader r; br_init(r, H, L);
@@ -326,13 +326,21 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               wave_sync();
             } else if (pat == P_SZ) {                                                 // mutate_once_sizer :81-111
               SizerElem e;
-              int r = pick_simple_len(c, H, b.len, &e);
+              int r;
+              {                                                                       // (out of work memory: borrow a larger area, pick again)
+                const Rng rng0 = c.rng; const uint64_t mark = c.ws_used;
+                for (;;) {
+                  r = pick_simple_len(c, H, b.len, &e);
+                  if (c.status != CASE_OVERFLOW || c.ovf_need == 0 || !ws_regrow(c, mark)) break;
+                  c.rng = rng0;
+                }
+              }
               if (r < 0) break;
               if (r == 1) {
                 uint32_t nbytes = e.size_bits / 8;
                 if ((uint64_t)e.a + nbytes + e.len > b.len) { c.status = CASE_CRASHED; break; }
                 if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 306); break; }
-                uint8_t* fld = ws_alloc(c, 16);
+                uint8_t* fld = ws_alloc_grow(c, 16);
                 if (!fld) break;
                 emit_ref(c, b.ptr, e.a);                                              // H
                 if (EH_LANE == 0) {
@@ -365,7 +373,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               uint64_t tot = 0; for (int i = c.cur; i < c.nb; i++) tot += blk_load(c.bl, i).len;
               if (tot > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 308); break; }
               if (c.nb - c.cur > 1) {
-                uint8_t* all = ws_alloc(c, tot);
+                uint8_t* all = ws_alloc_grow(c, tot);
                 if (!all) break;
                 uint64_t o = 0;
                 for (int i = c.cur; i < c.nb; i++) { Blk x = blk_load(c.bl, i); wave_copy(all + o, (const uint8_t*)x.ptr, x.len); o += x.len; }
@@ -439,7 +447,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
           // NewC = recalc_csum(Type, NewBlob): gather the inner pieces, checksum, append  (:139-143)
           uint64_t tot = 0; for (int k = f.em_field; k < c.nem; k++) tot += blk_load(c.em, k).len;
           if (tot > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 310); break; }
-          uint8_t* blob = ws_alloc(c, tot + 16);
+          uint8_t* blob = ws_alloc_grow(c, tot + 16);
           if (!blob) break;
           uint64_t o = 0;
           for (int k = f.em_field; k < c.nem; k++) { Blk x = blk_load(c.em, k); wave_copy(blob + o, (const uint8_t*)x.ptr, x.len); o += x.len; }
@@ -470,7 +478,7 @@ EH_DEV void gen_direct(Ctx& c, const uint8_t* in, uint32_t L) {       // erlamsa
     uint32_t bits = rng_range(c.rng, 1, 16);
     uint32_t nlen = rng_rand(c.rng, 1u << bits);
     if (nlen > 0) {                                                    // check_empty
-      uint8_t* dst = ws_alloc(c, nlen);
+      uint8_t* dst = ws_alloc_grow(c, nlen);
       if (!dst) return;
       random_block_rev(c, dst, nlen);
       blk_store(c.bl, 1, (uint64_t)dst, nlen);
@@ -484,7 +492,7 @@ EH_DEV void gen_random(Ctx& c) {                                       // random
   c.nb = 0;
   while (c.status == CASE_OK) {
     uint32_t n = rng_range(c.rng, 32, cfg.max_block_scaled);
-    uint8_t* dst = ws_alloc(c, n);
+    uint8_t* dst = ws_alloc_grow(c, n);
     if (!dst) return;
     random_block_rev(c, dst, n);
     if (c.nb >= MAX_BLOCKS) { EH_SET_OVERFLOW(c, 311); return; }
@@ -508,26 +516,19 @@ EH_DEV void gen_random(Ctx& c) {                                       // random
 // compiler keep a ~700-byte private copy of it per lane.
 __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const KParams* __restrict__ pp) {
   const int l = EH_LANE;
-  uint32_t wg = blockIdx.x;
-  {                                                                  // which tier this workgroup serves
-    int tier = 0;
-    const int nt = pp->ntiers;
-    while (tier < nt && wg >= pp->tier_wg_end[tier]) tier++;
-    if (tier > 0) wg -= pp->tier_wg_end[tier - 1];
-    pp += tier;
-  }
   const KParams& p = *pp;
   Ctx& c = g_ctx;
   LaneTab lt;
   c.p = pp;
   c.work_budget = p.work_budget;
-  uint8_t* slot = p.slot_base + (uint64_t)wg * p.slot_stride;
+  // this workgroup's tier-0 slot: block tables + work area, held until the workgroup leaves
+  const uint32_t slot_id = pool_pop(p, 0);
+  uint8_t* slot = p.pool_base[0] + (uint64_t)slot_id * p.pool_stride[0];
   c.bl = (Blk*)slot;
   c.bl2 = c.bl + MAX_BLOCKS;
   c.em = c.bl2 + MAX_BLOCKS;
   c.aux = (uint8_t*)(c.em + MAX_EMITS);
-  c.ws = c.aux + AUX_BYTES;
-  c.ws_cap = p.work_cap;
+  uint8_t* const ws0 = c.aux + AUX_BYTES;
 
   // mode 0: the run state is shared by all cases
   Rng parent; int gen0 = 0; uint32_t pri0 = 0, meta0 = 0; int nfs0 = 0;
@@ -542,7 +543,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     }
   }
 
-  const uint64_t TICKET_BATCH = p.tier ? 1 : 4;   // cases claimed per atomic (one counter saturates at ~88 dequeues/us)
+  const uint64_t TICKET_BATCH = 4;                // cases claimed per atomic (one counter saturates at ~88 dequeues/us)
   uint64_t tk_next = 0, tk_end = 0;
   while (true) {
     if (tk_next == tk_end) {
@@ -552,30 +553,16 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     }
     uint64_t i = tk_next++;
     if (i >= p.n) break;
-    if (p.tier) {
-      // entry i of the queue tier-1 fills while it runs: wait for it, or for the producer to be gone
-      uint32_t ent = 0xFFFFFFFFu;
-      if (l == 0) {
-        for (;;) {
-          ent = atomicAdd(&p.in_q[i], 0u);
-          if (ent != 0xFFFFFFFFu) break;
-          if (atomicAdd(p.prod_done, 0ull) >= p.prod_grid) { __threadfence(); ent = atomicAdd(&p.in_q[i], 0u); break; }
-#ifndef HIPEMU
-          __builtin_amdgcn_s_sleep(127);
-#endif
-        }
-        __threadfence();
-      }
-      ent = uni(ent);
-      if (ent == 0xFFFFFFFFu) break;
-      i = ent;
-    }
     uint64_t tick0 = __builtin_readcyclecounter();
+    c.nchunk = 0; c.ws_peak = 0; c.ws_top = 0;
+    c.ch_vstart[0] = 0; c.ch_vend[0] = p.work_cap; c.ch_base[0] = ws0; c.ch_tier[0] = 0; c.ch_area[0] = slot_id;
+    ws_set_view(c, 0);
+    for (int d = 0; d < LEX_LEVELS; d++) c.lex_ptr[d] = 0;
+    unsigned long long base = 0; uint64_t total = 0;
     c.work = 0; c.depth = 0;
     c.status = CASE_OK; c.lastm = -1; c.nb = 0; c.cur = 0; c.nem = 0; c.ws_used = 0;
     c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r2 = 0;
-    if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; ((LexCache*)(c.aux + 1024))->n = -1; ((FoState*)(c.aux + 704))->has = 0; }
-    c.ws_cap = p.work_cap;
+    if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; for (int d = 0; d < LEX_LEVELS; d++) { LexCache& lc = ((LexCache*)(c.aux + AUX_LEXCACHE))[d]; lc.n = -1; lc.tcap = 0; } ((FoState*)(c.aux + 704))->has = 0; }
     wave_sync();
     int gen;
     Rng pr;
@@ -590,7 +577,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     }
 #ifdef EH_PROF
 #define EH_PH(k) do { uint64_t now_ = __builtin_readcyclecounter(); if (l == 0) { atomicAdd(&p.prof[2 * (64 + (k))], (unsigned long long)(now_ - ph0)); atomicAdd(&p.prof[2 * (64 + (k)) + 1], 1ull); } ph0 = now_; } while (0)
-    uint64_t ph0 = tick0;
+    uint64_t ph0 = __builtin_readcyclecounter();
 #else
 #define EH_PH(k) do {} while (0)
 #endif
@@ -617,10 +604,8 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
 
     EH_PH(2);
     // ---- erlamsa_out:output/4: concatenate the written blocks into the output arena
-    uint64_t total = 0;
+    total = 0; base = 0;
     if (c.status == CASE_OK) for (int k = 0; k < c.nem; k++) total += blk_load(c.em, k).len;
-    else total = 0;
-    unsigned long long base = 0;
     if (total > 0) {
       if (l == 0) base = atomicAdd(p.out_cursor, (unsigned long long)((total + 15) & ~15ull));
       base = uni64(base);
@@ -631,19 +616,18 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
       for (int k = 0; k < c.nem; k++) { Blk b = blk_load(c.em, k); wave_copy(p.out + pos, (const uint8_t*)b.ptr, b.len); pos += b.len; }
     }
     EH_PH(3);
+    // larger areas the case borrowed go back to the pool (the output has been copied out of them)
+    wave_sync();
+    if (c.nchunk > 0) ws_release_to(c, 0);
     if (l == 0) {
       p.out_off[i] = base; p.out_len[i] = total; p.status[i] = c.status;
       p.draws[i] = c.rng.draws; p.lastm[i] = c.status == CASE_OVERFLOW ? -c.ovf_line : c.lastm; p.cycles[i] = __builtin_readcyclecounter() - tick0;
-      if (c.status == CASE_OVERFLOW && p.tier < p.ntiers && c.ovf_req <= p.tier_cap[p.ntiers - 1]) {
-        int tt = p.tier + 1;
-        while (tt < p.ntiers && p.tier_cap[tt - 1] < 2 * c.ovf_need) tt++;
-        __threadfence();                                                 // that tier's results for i must land after these
-        atomicExch(&p.q_base[(uint64_t)(tt - 1) * p.q_stride + atomicAdd(&p.q_count[4 * tt], 1ull)], (uint32_t)i);
-      }
+      p.peak[i] = c.ws_peak + c.ws_top;
     }
     wave_sync();
   }
-  if (l == 0 && p.my_done) { __threadfence(); atomicAdd(p.my_done, 1ull); }
+  wave_sync();
+  pool_push(p, 0, slot_id);
 }
 
 // kernel-level self tests of the byte movers (driven by tests/test_gpu_primitives.py)
@@ -718,6 +702,15 @@ static const PatInfo PATS[P_COUNT] = {{"od", 1, 1}, {"nd", 2, 1}, {"bu", 1, 1}, 
 
 using namespace eh;
 
+// the work-area pool of a device (see pool_acquire)
+struct DevPool {
+  int device = 0; uint64_t work_cap = 0, big = 0, tier_bytes_opt = 0;
+  int refs = 0;
+  int ntiers = 0;                                       // tiers above 0
+  uint8_t* base[6] = {}; uint64_t stride[6] = {}, cap[6] = {}; uint32_t cnt[6] = {};
+  uint32_t* d_rings = nullptr; uint32_t* ring[6] = {}; unsigned long long* d_ctr = nullptr;
+};
+
 struct eh_ctx {
   int device = 0;
   int cus = 0;
@@ -740,16 +733,12 @@ struct eh_ctx {
   uint64_t own_corpus_cap = 0, own_coff_cap = 0;         // capacity of the owned buffers: eh_corpus_upload reuses them when they fit
   uint64_t n_corpus = 0, corpus_bytes = 0;
   std::vector<uint64_t> h_coff;  // host copy of offsets (for totals)
-  // slots
-  uint8_t* d_slots = nullptr; uint64_t slot_stride = 0, work_cap = 0; uint32_t nslots = 0;
-  // tiers 1.. (see KParams): areas of 4x, 16x, ... max_case_bytes up to big_case_bytes, ~16 GiB per tier
-  static constexpr int MAX_TIERS = 5;
-  int ntiers = 0;                                      // tiers above tier 0
-  uint8_t* d_tslots[MAX_TIERS] = {}; uint64_t tstride[MAX_TIERS] = {}, tcap[MAX_TIERS] = {}; uint32_t tnslots[MAX_TIERS] = {};
-  uint32_t* d_retry = nullptr; uint64_t retry_cap = 0; uint64_t big_case_bytes = 0; uint64_t tier_base = 0, tier_big = 0, tier_bytes_used = 0;
+  // work areas: a pool shared by every context of the device with the same sizes (DevPool below)
+  DevPool* pool = nullptr;
+  uint64_t big_case_bytes = 0;
   // outputs
   uint8_t* d_out = nullptr; uint64_t out_cap = 0;
-  uint64_t* d_off = nullptr; uint64_t* d_len = nullptr; int32_t* d_status = nullptr; uint64_t* d_draws = nullptr; int32_t* d_lastm = nullptr; uint64_t* d_cycles = nullptr;
+  uint64_t* d_off = nullptr; uint64_t* d_len = nullptr; int32_t* d_status = nullptr; uint64_t* d_draws = nullptr; int32_t* d_lastm = nullptr; uint64_t* d_cycles = nullptr; uint64_t* d_peak = nullptr;
   uint64_t res_cap = 0;
   unsigned long long* d_counters = nullptr;  // [0] ticket, [1] out cursor
   RunState* d_run = nullptr;
@@ -847,8 +836,9 @@ static int build_funny(uint8_t (*out)[5]) {
 
 static int ensure_results(eh_ctx* ctx, uint64_t n) {
   if (n <= ctx->res_cap) return EH_OK;
-  if (ctx->d_off) { (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len); (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); }
+  if (ctx->d_off) { (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len); (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_peak); }
   HIPCHK(ctx, hipMalloc(&ctx->d_cycles, n * 8));
+  HIPCHK(ctx, hipMalloc(&ctx->d_peak, n * 8));
   HIPCHK(ctx, hipMalloc(&ctx->d_off, n * 8));
   HIPCHK(ctx, hipMalloc(&ctx->d_len, n * 8));
   HIPCHK(ctx, hipMalloc(&ctx->d_status, n * 4));
@@ -858,51 +848,97 @@ static int ensure_results(eh_ctx* ctx, uint64_t n) {
   return EH_OK;
 }
 
-// Device memory for batches of up to `n` cases over `in_bytes` input bytes: result arrays, per-slot work
-// areas, output arena.  Buffers only ever grow, so after eh_reserve (or a first batch of the largest
-// size) no launch allocates or frees — hipFree synchronises the whole device.
+// ---- the work-area pool ------------------------------------------------------------------------------------------
+// One pool per (device, max_case_bytes, big_case_bytes, tier_bytes), shared by all contexts that ask for those sizes and
+// freed with the last of them.  Tier 0 has one slot (block tables + max_case_bytes) for every wavefront the device can hold
+// of eh_mutate_kernel — workgroups of any number of batches in flight, on any streams, take their slot from it — and
+// tiers 1.. hold the larger areas (4x per tier up to big_case_bytes) a wavefront borrows for a case that outgrew its slot.
+static std::mutex g_pool_lock;
+static std::vector<DevPool*> g_pools;
+
+static void pool_free(DevPool* pl) {
+  (void)hipSetDevice(pl->device);
+  (void)hipDeviceSynchronize();
+  for (int t = 0; t <= pl->ntiers; t++) if (pl->base[t]) (void)hipFree(pl->base[t]);
+  if (pl->d_rings) (void)hipFree(pl->d_rings);
+  if (pl->d_ctr) (void)hipFree(pl->d_ctr);
+  delete pl;
+}
+static void pool_release(eh_ctx* ctx) {
+  if (!ctx->pool) return;
+  std::lock_guard<std::mutex> g(g_pool_lock);
+  DevPool* pl = ctx->pool; ctx->pool = nullptr;
+  if (--pl->refs > 0) return;
+  for (size_t i = 0; i < g_pools.size(); i++) if (g_pools[i] == pl) { g_pools.erase(g_pools.begin() + i); break; }
+  pool_free(pl);
+}
+static int pool_acquire(eh_ctx* ctx, uint64_t work_cap, uint64_t big, uint64_t tier_bytes_opt) {
+  if (ctx->pool && ctx->pool->work_cap == work_cap && ctx->pool->big == big && ctx->pool->tier_bytes_opt == tier_bytes_opt) return EH_OK;
+  pool_release(ctx);
+  std::lock_guard<std::mutex> g(g_pool_lock);
+  for (DevPool* q : g_pools)
+    if (q->device == ctx->device && q->work_cap == work_cap && q->big == big && q->tier_bytes_opt == tier_bytes_opt) { q->refs++; ctx->pool = q; return EH_OK; }
+  DevPool* pl = new (std::nothrow) DevPool();
+  if (!pl) return EH_E_NOMEM;
+  pl->device = ctx->device; pl->work_cap = work_cap; pl->big = big; pl->tier_bytes_opt = tier_bytes_opt;
+  const uint64_t tables = (uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES;
+  // tier 0: a slot per wavefront the device holds at EH_WAVES_PER_SIMD; fewer when memory is short (a workgroup then waits
+  // for a slot: correct, slower)
+  uint32_t want = (uint32_t)ctx->cus * 4u * EH_WAVES_PER_SIMD;
+  pl->stride[0] = (tables + work_cap + 255) & ~255ull; pl->cap[0] = work_cap;
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)16 << 30;
+  while (want > 4 && pl->stride[0] * want > (uint64_t)fr / 2) want /= 2;
+  hipError_t e = hipErrorOutOfMemory;
+  for (; want >= 1; want /= 2) { e = hipMalloc(&pl->base[0], pl->stride[0] * want); if (e == hipSuccess) break; pl->base[0] = nullptr; }
+  if (e != hipSuccess) { delete pl; ctx->err = "work-area pool: out of device memory"; return EH_E_NOMEM; }
+  pl->cnt[0] = want;
+  // tiers above 0: 4x the area each up to `big`; every tier gets tier_bytes (default: an eighth of the free memory, 1..32 GiB),
+  // at least one area, at most 1024; a tier that cannot be allocated at all ends the ladder
+  uint64_t cap = work_cap;
+  while (cap < big && pl->ntiers < 5) {
+    cap = (cap * 4 < big && pl->ntiers < 4) ? cap * 4 : big;                      // the last tier always has the full size
+    uint64_t stride_t = (cap + 255) & ~255ull;
+    uint64_t tier_gib = 16;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) { tier_gib = (uint64_t)fr >> 33; if (tier_gib < 1) tier_gib = 1; if (tier_gib > 32) tier_gib = 32; }
+    uint64_t tier_bytes = tier_bytes_opt ? tier_bytes_opt : (tier_gib << 30);
+    uint64_t cnt = tier_bytes / stride_t; if (cnt < 1) cnt = 1; if (cnt > 1024) cnt = 1024;
+    if (ctx->cus < 64 && cnt > 2) cnt = 2;                                         // (the emulator)
+    int t = pl->ntiers + 1;
+    for (; cnt >= 1; cnt /= 2) { e = hipMalloc(&pl->base[t], stride_t * cnt); if (e == hipSuccess) break; pl->base[t] = nullptr; }
+    if (e != hipSuccess) break;
+    pl->stride[t] = stride_t; pl->cap[t] = cap; pl->cnt[t] = (uint32_t)cnt; pl->ntiers++;
+  }
+  uint64_t nring = 0;
+  for (int t = 0; t <= pl->ntiers; t++) nring += pl->cnt[t];
+  std::vector<uint32_t> init(nring);
+  std::vector<unsigned long long> ctr(32, 0ull);
+  if (hipMalloc(&pl->d_rings, nring * 4) != hipSuccess || hipMalloc(&pl->d_ctr, 32 * 8) != hipSuccess) { pool_free(pl); ctx->err = "work-area pool: out of device memory"; return EH_E_NOMEM; }
+  uint64_t o = 0;
+  for (int t = 0; t <= pl->ntiers; t++) {
+    pl->ring[t] = pl->d_rings + o;
+    for (uint32_t k = 0; k < pl->cnt[t]; k++) init[o + k] = k;
+    ctr[2 * t] = 0; ctr[2 * t + 1] = pl->cnt[t];                                   // pop tickets, push tickets
+    o += pl->cnt[t];
+  }
+  if (hipMemcpy(pl->d_rings, init.data(), nring * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(pl->d_ctr, ctr.data(), 32 * 8, hipMemcpyHostToDevice) != hipSuccess) { pool_free(pl); ctx->err = "work-area pool: hipMemcpy failed"; return EH_E_HIP; }
+  pl->refs = 1; g_pools.push_back(pl); ctx->pool = pl;
+  return EH_OK;
+}
+
+// Device memory for batches of up to `n` cases over `in_bytes` input bytes: result arrays, the work-area pool, output
+// arena.  Buffers only ever grow, so after eh_reserve (or a first batch of the largest size) no launch allocates or
+// frees — hipFree synchronises the whole device.
 static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc = ensure_results(ctx, n ? n : 1);
   if (rc) return rc;
-  uint32_t want_slots = ctx->max_slots_opt ? ctx->max_slots_opt : (uint32_t)ctx->cus * 4u * EH_WAVES_PER_SIMD;
-  if (want_slots > n) want_slots = (uint32_t)(n ? n : 1);
   uint64_t work_cap = ctx->max_case_bytes ? ctx->max_case_bytes : (8ull << 20);
-  uint64_t stride = (uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + work_cap;
-  stride = (stride + 255) & ~255ull;
-  if (!ctx->d_slots || ctx->nslots < want_slots || ctx->work_cap != work_cap) {
-    if (ctx->d_slots) (void)hipFree(ctx->d_slots);
-    ctx->d_slots = nullptr;
-    HIPCHK(ctx, hipMalloc(&ctx->d_slots, stride * want_slots));
-    ctx->nslots = want_slots; ctx->work_cap = work_cap; ctx->slot_stride = stride;
-  }
-  // tiers above 0: 4x the area and a quarter of the wavefronts each, up to big_case_bytes (default 32 x max_case_bytes,
-  // at most 1 GiB); every tier gets an eighth of the free device memory, at most 32 GiB (the emulator: two slots)
   uint64_t big = ctx->big_case_bytes ? ctx->big_case_bytes : (32 * work_cap < (1024ull << 20) ? 32 * work_cap : (1024ull << 20));
-  if (ctx->tier_base != work_cap || ctx->tier_big != big || ctx->tier_bytes_used != ctx->tier_bytes_opt) {
-    for (int t = 0; t < ctx->ntiers; t++) { (void)hipFree(ctx->d_tslots[t]); ctx->d_tslots[t] = nullptr; }
-    ctx->ntiers = 0;
-    uint64_t cap = work_cap;
-    while (cap < big && ctx->ntiers < eh_ctx::MAX_TIERS) {
-      cap = (cap * 4 < big && ctx->ntiers < eh_ctx::MAX_TIERS - 1) ? cap * 4 : big;     // the last tier always has the full size
-      uint64_t stride_t = ((uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + cap + 255) & ~255ull;
-      uint64_t tier_gib = 16;                                                   // an eighth of the free memory, 1 .. 32 GiB
-      { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) { tier_gib = (uint64_t)fr >> 33; if (tier_gib < 1) tier_gib = 1; if (tier_gib > 32) tier_gib = 32; } }
-      uint64_t tier_bytes = ctx->tier_bytes_opt ? ctx->tier_bytes_opt : (tier_gib << 30);      // eh_options.tier_bytes
-      uint64_t cnt = tier_bytes / stride_t; if (cnt < 2) cnt = 2; if (cnt > 1024) cnt = 1024;  // (one area is enough for correctness)
-      if (ctx->cus < 64) cnt = 2;
-      int t = ctx->ntiers;
-      HIPCHK(ctx, hipMalloc(&ctx->d_tslots[t], stride_t * cnt));
-      ctx->tstride[t] = stride_t; ctx->tcap[t] = cap; ctx->tnslots[t] = (uint32_t)cnt; ctx->ntiers++;
-    }
-    ctx->tier_base = work_cap; ctx->tier_big = big; ctx->tier_bytes_used = ctx->tier_bytes_opt;
-  }
-  if (ctx->ntiers > 0 && (!ctx->d_retry || ctx->retry_cap < n)) {
-    if (ctx->d_retry) (void)hipFree(ctx->d_retry);
-    ctx->d_retry = nullptr;
-    HIPCHK(ctx, hipMalloc(&ctx->d_retry, (n ? n : 1) * 4 * (uint64_t)eh_ctx::MAX_TIERS));
-    ctx->retry_cap = n ? n : 1;
-  }
+  if (big < work_cap) big = work_cap;
+  rc = pool_acquire(ctx, work_cap, big, ctx->tier_bytes_opt);
+  if (rc) return rc;
   uint64_t want_out = ctx->out_capacity_opt ? ctx->out_capacity_opt : (8 * (in_bytes ? in_bytes : ctx->corpus_bytes) + (2048ull << 20));
   if (!ctx->d_out || ctx->out_cap < want_out) {
     if (ctx->d_out) (void)hipFree(ctx->d_out);
@@ -921,45 +957,31 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   if (!ctx->h_coff.empty()) in_bytes = ctx->h_coff[corpus_first + n] - ctx->h_coff[corpus_first];
   int rc = reserve(ctx, n, in_bytes);
   if (rc) return rc;
-  if (!ctx->d_counters) { HIPCHK(ctx, hipMalloc(&ctx->d_counters, 4096)); HIPCHK(ctx, hipMalloc(&ctx->d_run, sizeof(RunState))); HIPCHK(ctx, hipMalloc(&ctx->d_params, (eh_ctx::MAX_TIERS + 1) * sizeof(KParams))); }
+  if (!ctx->d_counters) { HIPCHK(ctx, hipMalloc(&ctx->d_counters, 4096)); HIPCHK(ctx, hipMalloc(&ctx->d_run, sizeof(RunState))); HIPCHK(ctx, hipMalloc(&ctx->d_params, sizeof(KParams))); }
   HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 4096, st));
 
   KParams p;
   memset(&p, 0, sizeof(p));
   p.corpus = ctx->d_corpus; p.coff = ctx->d_coff; p.corpus_first = corpus_first; p.n = n; p.first_case = first_case;
   p.mode = mode; p.run = ctx->d_run; p.seeds = ctx->d_seeds; p.cfg = ctx->cfg;
-  p.slot_base = ctx->d_slots; p.slot_stride = ctx->slot_stride; p.work_cap = ctx->work_cap;
+  const DevPool* pl = ctx->pool;
+  p.work_cap = pl->work_cap;
   p.work_budget = ctx->work_budget;                                            // 0 = no budget (the default)
   p.fuse_stream_min = ctx->fuse_stream_min;
   p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
-  p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles;
-  p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;
-  // counters: [300 + 4t] ticket of tier t, [301 + 4t] entries queued for tier t, [302 + 4t] finished workgroups of tier t;
-  // [8, 264) = prof
-  const int ntiers = ctx->ntiers;
-  const uint32_t grid0 = ctx->nslots < n ? ctx->nslots : (uint32_t)n;
-  p.tier = 0; p.in_q = nullptr; p.prod_done = nullptr; p.prod_grid = 0;
-  p.ntiers = ntiers; p.q_base = ctx->d_retry; p.q_stride = ctx->retry_cap; p.q_count = ctx->d_counters + 301;
-  for (int t = 0; t < ntiers; t++) p.tier_cap[t] = ctx->tcap[t];
-  p.my_done = ntiers > 0 ? ctx->d_counters + 302 : nullptr;
-  std::vector<KParams> all(ntiers + 1, p);
-  for (int t = 1; t <= ntiers; t++) {                                          // tier t over the queue the tiers below it fill
-    KParams& q = all[t];
-    q.tier = t; q.slot_base = ctx->d_tslots[t - 1]; q.slot_stride = ctx->tstride[t - 1]; q.work_cap = ctx->tcap[t - 1];
-    q.ticket = ctx->d_counters + 300 + 4 * t;
-    q.in_q = ctx->d_retry + (uint64_t)(t - 1) * ctx->retry_cap;
-    q.prod_done = ctx->d_counters + 302 + 4 * (t - 1); q.prod_grid = t == 1 ? grid0 : ctx->tnslots[t - 2];   // tier t-1 leaves after all below it
-    q.my_done = t < ntiers ? ctx->d_counters + 302 + 4 * t : nullptr;
-  }
-  uint32_t total_wg = grid0;
-  all[0].tier_wg_end[0] = grid0;
-  for (int t = 1; t <= ntiers; t++) { total_wg += ctx->tnslots[t - 1]; all[0].tier_wg_end[t] = total_wg; }
+  p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles; p.peak = ctx->d_peak;
+  p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;   // counters [8, 264) = prof
+  p.ntiers = pl->ntiers; p.pool_ctr = pl->d_ctr;
+  for (int t = 0; t <= pl->ntiers; t++) { p.pool_base[t] = pl->base[t]; p.pool_stride[t] = pl->stride[t]; p.pool_cap[t] = pl->cap[t]; p.pool_cnt[t] = pl->cnt[t]; p.pool_ring[t] = pl->ring[t]; }
+  // persistent workgroups: one per wavefront the device holds (or max_slots), each pulling cases from the ticket counter.
+  // Several batches in flight oversubscribe the device; the dispatcher starts a batch's workgroups as earlier ones leave.
+  uint32_t grid0 = ctx->max_slots_opt ? ctx->max_slots_opt : (uint32_t)ctx->cus * 4u * EH_WAVES_PER_SIMD;
+  if (grid0 > n) grid0 = (uint32_t)n;
 
   if (mode == 0) hipLaunchKernelGGL(eh_setup_kernel, dim3(1), dim3(64), 0, st, ctx->cfg, seed[0], seed[1], seed[2], ctx->d_run);
   HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, all.data(), all.size() * sizeof(KParams), hipMemcpyHostToDevice, st));   // pageable source: staged before the call returns
-  if (ntiers > 0 && n > 0) HIPCHK(ctx, hipMemsetAsync(ctx->d_retry, 0xFF, ctx->retry_cap * 4 * (uint64_t)ntiers, st));
-  if (n > 0) hipLaunchKernelGGL(eh_mutate_kernel, dim3(total_wg), dim3(64), 0, st, (const KParams*)ctx->d_params);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, &p, sizeof(KParams), hipMemcpyHostToDevice, st));   // pageable source: staged before the call returns
+  if (n > 0) hipLaunchKernelGGL(eh_mutate_kernel, dim3(grid0), dim3(64), 0, st, (const KParams*)ctx->d_params);
   HIPCHK(ctx, hipEventRecord(ctx->ev1, st));
   HIPCHK(ctx, hipGetLastError());
   ctx->ordered = false;
@@ -1035,7 +1057,10 @@ int eh_create(int device, eh_ctx** out) {
   ctx->cus = prop.multiProcessorCount;
   // eh_mutate_kernel recurses (nested scheduler calls of b64 / sgm / js, depth <= MAX_NEST): ~0.6 KiB of private stack
   // per level on top of the kernel's fixed 1.2 KiB
-  size_t stack_bytes = 16384;
+  // worst chain (per-function frames from the assembler's private_seg_size expressions): kernel 192 + (MAX_NEST + 1) x
+  // (muta_sgml 272 + nested_fuzz 288) = 4.1 KiB.  The runtime sizes every hardware queue's scratch for all wavefront
+  // slots of the device at this size (16 KiB meant ~8 GiB per queue).
+  size_t stack_bytes = 6144;
   if (hipDeviceSetLimit(hipLimitStackSize, stack_bytes) != hipSuccess) { delete ctx; return EH_E_HIP; }
   uint16_t t1[65], t2[65], t3[65];
   init_tables(t1, t2, t3);
@@ -1061,15 +1086,14 @@ void eh_destroy(eh_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   if (ctx->own_corpus) { (void)hipFree(ctx->d_corpus); (void)hipFree(ctx->d_coff); }
-  (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
-  (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_counters);
+  pool_release(ctx);
+  (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
+  (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_peak); (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_run); (void)hipFree(ctx->d_seeds);
   for (int k = 0; k < 2; k++) { if (ctx->d_bounce[k]) (void)hipFree(ctx->d_bounce[k]); if (ctx->ev_g[k]) (void)hipEventDestroy(ctx->ev_g[k]); if (ctx->ev_c[k]) (void)hipEventDestroy(ctx->ev_c[k]); }
   if (ctx->dl_gather) (void)hipStreamDestroy(ctx->dl_gather);
   if (ctx->dl_copy) (void)hipStreamDestroy(ctx->dl_copy);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
-  for (int t = 0; t < ctx->ntiers; t++) (void)hipFree(ctx->d_tslots[t]);
-  if (ctx->d_retry) (void)hipFree(ctx->d_retry);
   if (ctx->d_out2) (void)hipFree(ctx->d_out2);
   if (ctx->d_ord) (void)hipFree(ctx->d_ord);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1409,6 +1433,13 @@ int eh_result_cycles(eh_ctx* ctx, uint64_t* cycles) {
   if (ctx->last_n) HIPCHK(ctx, hipMemcpy(cycles, ctx->d_cycles, ctx->last_n * 8, hipMemcpyDeviceToHost));
   return EH_OK;
 }
+int eh_result_peak(eh_ctx* ctx, uint64_t* peak) {
+  if (!ctx || !peak) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  int rc = eh_sync(ctx); if (rc) return rc;
+  if (ctx->last_n) HIPCHK(ctx, hipMemcpy(peak, ctx->d_peak, ctx->last_n * 8, hipMemcpyDeviceToHost));
+  return EH_OK;
+}
 int eh_result_prof(eh_ctx* ctx, uint64_t* prof /* 256 values */) {
   if (!ctx || !prof) return EH_E_INVALID;
   if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
@@ -1438,6 +1469,16 @@ int eh_selftest_movers(eh_ctx* ctx, uint8_t* buf, uint64_t buf_len, const uint32
   if (dj) (void)hipFree(dj);
   if (de) (void)hipFree(de);
   HIPCHK(ctx, e);
+  return EH_OK;
+}
+int eh_pool_stats(eh_ctx* ctx, uint64_t* out /* 40 values */) {
+  if (!ctx || !out) return EH_E_INVALID;
+  if (!ctx->pool) { ctx->err = "no work-area pool yet (eh_reserve or a first batch creates it)"; return EH_E_STATE; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpy(out, ctx->pool->d_ctr, 32 * 8, hipMemcpyDeviceToHost));   // (a plain copy: fine while batches run)
+  out[32] = (uint64_t)ctx->pool->ntiers;
+  for (int t = 0; t < 6; t++) out[33 + t] = t <= ctx->pool->ntiers ? ctx->pool->cnt[t] : 0;
+  out[39] = (uint64_t)ctx->pool->refs;
   return EH_OK;
 }
 int eh_last_kernel_ms(eh_ctx* ctx, float* ms) {

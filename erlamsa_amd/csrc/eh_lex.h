@@ -134,24 +134,25 @@ __device__ __noinline__ int lex_block(const uint8_t* H, uint32_t L, LexChunk* ta
   return n <= cap ? (int)n : -1;
 }
 
-// Per-case lex cache (top-of-work-area storage, survives candidate discards)
-struct LexCache { uint64_t ptr; uint32_t len; int32_t n; LexChunk* tab; };
-
-EH_DEV uint8_t* ws_alloc_top(Ctx& c, uint64_t n) {
-  uint64_t need = (n + 15) & ~(uint64_t)15;
-  if (c.ws_used + need > c.ws_cap) { EH_SET_OVERFLOW(c, 501); c.ovf_need = c.ws_used + need + (c.p->work_cap - c.ws_cap); c.ovf_req = need; return nullptr; }
-  c.ws_cap -= need;
-  return c.ws + c.ws_cap;
-}
 // returns chunk count (>= 0) and *tab, or -1 after setting c.status
 EH_DEV int lex_cached(Ctx& c, LexCache& lc, const uint8_t* H, uint32_t L, LexChunk** tab) {
-  if (lc.n >= 0 && lc.ptr == (uint64_t)H && lc.len == L) { *tab = lc.tab; return lc.n; }
+  if (c.lex_ptr[c.depth] == (uint64_t)H && lc.n >= 0 && lc.ptr == (uint64_t)H && lc.len == L) { *tab = lc.tab; return lc.n; }
   uint32_t cap = L + 2 < (1u << 18) ? L + 2 : (1u << 18);   // every chunk covers >= 1 byte
-  LexChunk* t = (LexChunk*)ws_alloc_top(c, (uint64_t)cap * sizeof(LexChunk));
+  // the previous table is reused when it is large enough (a case that keeps lexing changing blocks used to leave one
+  // table per miss behind at the top of its work area)
+  uint32_t have = uni(lc.tcap);
+  LexChunk* t = have >= cap ? (LexChunk*)uni64((uint64_t)lc.tab) : (LexChunk*)ws_alloc_top(c, (uint64_t)cap * sizeof(LexChunk));
   if (!t) return -1;
+  wave_sync();
+  if (EH_LANE == 0) { lc.n = -1; if (have < cap) { lc.tab = t; lc.tcap = cap; } }
+  c.lex_ptr[c.depth] = 0;
+  wave_sync();
   int n = lex_block(H, L, t, cap);
   if (n < 0) { EH_SET_OVERFLOW(c, 502); return -1; }
-  lc.ptr = (uint64_t)H; lc.len = L; lc.n = n; lc.tab = t; *tab = t;
+  wave_sync();
+  if (EH_LANE == 0) { lc.ptr = (uint64_t)H; lc.len = L; lc.n = n; }
+  *tab = t; c.lex_ptr[c.depth] = (uint64_t)H;
+  wave_sync();
   return n;
 }
 

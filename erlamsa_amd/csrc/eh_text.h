@@ -162,6 +162,7 @@ EH_DEV uint32_t li_start(const LineIdx& li, uint32_t j) {
 // per-mutator state of lis/lrs: [Count | Lines], each stored line = optional nested line + plain tail
 struct StLineRef { uint64_t nptr; uint64_t pptr; uint32_t nlen; uint32_t plen; uint32_t has_nested; uint32_t pad; };
 struct StState { int32_t count; int32_t pad[3]; StLineRef ln[10]; };
+static_assert(sizeof(StState) == 4 * ST_STATE_WORDS, "ST_STATE_WORDS");
 
 __device__ __noinline__ int muta_line(Ctx&, int fn) {
   EH_CTX;                       // construct_line_muta :351-362

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ERLAMSA_HIP_LIB") or os.path.join(_HERE, "liberlamsa_hip.so")
 
-EH_ABI_VERSION = 4
+EH_ABI_VERSION = 5
 EH_FLAG_ORDERED_OUTPUT = 1
 
 CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BUDGET = 0, 1, 2, 3, 4, 5
@@ -20,8 +20,8 @@ CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BU
 # every symbol include/erlamsa_hip.h declares
 ABI_SYMBOLS = [
     "eh_create", "eh_destroy", "eh_configure", "eh_corpus_upload", "eh_corpus_attach", "eh_fuzz_batch",
-    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_fetch", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_prof", "eh_selftest_movers",
-    "eh_last_kernel_ms", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
+    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_fetch", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_peak", "eh_result_prof", "eh_selftest_movers",
+    "eh_last_kernel_ms", "eh_pool_stats", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
     "eh_coalesce_limits", "eh_submit", "eh_flush", "eh_poll",
@@ -77,9 +77,11 @@ def load_library():
     lib.eh_result_fetch.argtypes = [vp, C.c_uint64, vp, C.c_uint64, u64p]
     lib.eh_result_diag.argtypes = [vp, vp, vp]
     lib.eh_result_cycles.argtypes = [vp, vp]
+    lib.eh_result_peak.argtypes = [vp, vp]
     lib.eh_result_prof.argtypes = [vp, vp]
     lib.eh_selftest_movers.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
     lib.eh_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.eh_pool_stats.argtypes = [vp, vp]
     lib.eh_coalesce_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
     lib.eh_submit.argtypes = [vp, vp, C.c_uint64, i64p, u64p]
     lib.eh_flush.argtypes = [vp]
@@ -204,6 +206,14 @@ class Engine:
         self._chk(self.lib.eh_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
 
+    def pool_stats(self):
+        """Work-area pool of the device (eh_pool_stats): dict with per-tier areas, takes, waits."""
+        v = np.zeros(40, dtype=np.uint64)
+        self._chk(self.lib.eh_pool_stats(self.h, v.ctypes.data_as(C.c_void_p)))
+        nt = int(v[32]) + 1
+        return {"areas": [int(x) for x in v[33:33 + nt]], "taken": [int(v[2 * t]) for t in range(nt)],
+                "waits": [int(v[24 + t]) for t in range(nt)], "wait_ticks": [int(v[16 + t]) for t in range(nt)], "contexts": int(v[39])}
+
     def download(self):
         """-> (list[bytes] per case, status int32[n])"""
         n = self.last_n
@@ -262,6 +272,13 @@ class Engine:
         cyc = np.zeros(max(n, 1), dtype=np.uint64)
         self._chk(self.lib.eh_result_cycles(self.h, cyc.ctypes.data))
         return cyc[:n]
+
+    def peak(self):
+        """Per-case high-water mark of work memory (bytes)."""
+        n = self.last_n
+        pk = np.zeros(max(n, 1), dtype=np.uint64)
+        self._chk(self.lib.eh_result_peak(self.h, pk.ctypes.data))
+        return pk[:n]
 
     def prof(self):
         pr = np.zeros(256, dtype=np.uint64)

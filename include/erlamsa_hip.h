@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EH_ABI_VERSION 4
+#define EH_ABI_VERSION 5
 
 typedef struct eh_ctx eh_ctx;
 
@@ -75,23 +75,27 @@ typedef struct eh_options {
   double blockscale;         /* 0 => 1.0 (erlamsa_gen.erl:206) */
   const char* ssrf_host;     /* NULL => "localhost" */
   int32_t ssrf_port;         /* 0 => 51234 */
-  uint64_t max_case_bytes;   /* per-case work area of every resident wavefront (tier 0); 0 => default (8 MiB) */
+  uint64_t max_case_bytes;   /* work area of a tier-0 slot of the device's work-area pool: every resident wavefront holds one;
+                                0 => default (8 MiB).  Contexts of one device that ask for the same max_case_bytes,
+                                big_case_bytes and tier_bytes share one pool (sized by the wavefronts the device holds, not
+                                by the number of batches in flight) */
   uint64_t out_capacity;     /* output arena bytes; 0 => 8 x batch input bytes + 2 GiB */
   uint64_t max_case_work;    /* OPTIONAL per-case work budget in bytes (sum over mutator attempts, failed ones
                                 included, of block size x cost weight of the mutator: 8 for parsers and
                                 per-byte-draw mutators, 64 for the fuse family, 4 for num, 1 otherwise; plus 16 x
                                 the list members of every fuse refinement round);
                                 0 => no budget (default): every case runs to completion */
-  uint32_t max_slots;        /* resident wavefront slots; 0 => auto */
+  uint32_t max_slots;        /* persistent workgroups (wavefronts) of one batch; 0 => one per wavefront the device holds.
+                                Batches in flight on several streams oversubscribe the device: a batch's workgroups start
+                                as those of earlier batches leave */
   uint32_t flags;            /* EH_FLAG_* */
   uint64_t big_case_bytes;   /* largest work area.  A case that outgrows its area is run again from scratch (same
-                                result) by a later tier of wavefronts of the same dispatch: 4x the area per tier, fewer
-                                wavefronts, up to this size; only a case that outgrows this too ends as
-                                EH_CASE_OVERFLOW.  0 => 32 x max_case_bytes, at most 1 GiB; <= max_case_bytes => a
-                                single tier */
+                                result) by the same wavefront in a larger area borrowed from the pool: 4x the area per
+                                tier up to this size; only a case that outgrows this too ends as EH_CASE_OVERFLOW.
+                                0 => 32 x max_case_bytes, at most 1 GiB; <= max_case_bytes => a single tier */
   /* ABI 4: engine tuning that used to be environment variables of the library */
-  uint64_t tier_bytes;       /* device memory of every overflow tier; 0 => an eighth of the memory that is free when the
-                                tiers are reserved, 1 .. 32 GiB.  Every tier holds at least 2 work areas */
+  uint64_t tier_bytes;       /* device memory of every tier of larger areas of the pool; 0 => an eighth of the memory that is
+                                free when the pool is made, 1 .. 32 GiB.  Every tier holds at least one area */
   uint64_t download_chunk_bytes; /* bounce-buffer size of eh_result_download's device gather; 0 => 256 MiB */
   uint64_t fuse_stream_min;  /* erlamsa_fuse:fuse/2 on la + lb >= this many bytes runs as the position-indexed class
                                 refinement (csrc/eh_fuse2.h) instead of the node-list refinement (csrc/eh_fuse.h);
@@ -167,6 +171,9 @@ int eh_result_diag(eh_ctx* ctx, uint64_t* draws, int32_t* last_mutator);
 /* Per-case shader-clock ticks spent by the wavefront that ran the case (diagnostic). */
 int eh_result_cycles(eh_ctx* ctx, uint64_t* cycles);
 
+/* Per-case high-water mark of work memory in bytes (diagnostic; what sizes max_case_bytes and the pool's tiers). */
+int eh_result_peak(eh_ctx* ctx, uint64_t* peak);
+
 /* Profiling builds (-DEH_PROF) only: prof[2k] = ticks, prof[2k+1] = calls; k < 64 is a mutator
  * id, 64.. are phases (setup, generator, pattern+mutators, output copy).  256 values. */
 int eh_result_prof(eh_ctx* ctx, uint64_t* prof);
@@ -174,6 +181,12 @@ int eh_result_prof(eh_ctx* ctx, uint64_t* prof);
 /* Kernel self-test hook for the wave-level byte movers (tests only): jobs = njobs x
  * {kind (0 copy, 1 periodic fill, 2 equal), dst_off, src_off, n, plen} over the buffer image. */
 int eh_selftest_movers(eh_ctx* ctx, uint8_t* buf, uint64_t buf_len, const uint32_t* jobs, uint32_t njobs, uint32_t* eq_out);
+
+/* Work-area pool of this context's device (diagnostic), 40 values: out[2t] / out[2t+1] = areas of tier t taken / returned
+ * since the pool was made (+ the tier's size for the latter), out[16+t] = shader-clock ticks wavefronts waited for an area
+ * of tier t, out[24+t] = how many had to wait, out[32] = tiers above 0, out[33+t] = areas of tier t, out[39] = contexts
+ * sharing the pool. */
+int eh_pool_stats(eh_ctx* ctx, uint64_t* out);
 
 /* Elapsed GPU time of the mutate kernel of the last batch in ms (HIP events on the launch
  * stream), and its name for matching against a rocprofv3 kernel trace. */

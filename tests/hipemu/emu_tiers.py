@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Tiered work areas on the emulator: the same cases with a small tier-0 area and (a) no larger tier, (b) tiers up to
+"""Work areas on the emulator: the same cases with a small slot area and (a) no larger tier in the pool, (b) tiers up to
 32 MiB.  Whatever the tiers, a case that completes gives the oracle's bytes, statuses and draw counts; with (b) nothing
-overflows; the routing by requested size sends cases past tiers they could not fit.  Run with ERLAMSA_HIP_LIB=<emu lib>."""
+overflows: a case that outgrows what it holds borrows an area of a higher tier and goes on.  Run with ERLAMSA_HIP_LIB=<emu lib>."""
 import os
 import sys
 

@@ -210,6 +210,7 @@ inline unsigned long long __builtin_readcyclecounter() {
 template <class T, class U> inline T atomicAdd(T* p, U v) { T old = *p; *p = (T)(old + (T)v); return old; }
 template <class T, class U> inline T atomicExch(T* p, U v) { T old = *p; *p = (T)v; return old; }
 template <class T, class U> inline T atomicOr(T* p, U v) { T old = *p; *p = (T)(old | (T)v); return old; }
+template <class T, class U, class V> inline T atomicCAS(T* p, U cmp, V v) { T old = *p; if (old == (T)cmp) *p = (T)v; return old; }
 
 // ---- the slice of the HIP runtime API the engine's host side uses -----------------------------------
 typedef int hipError_t;

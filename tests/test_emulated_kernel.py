@@ -53,7 +53,15 @@ def test_emulated_abi_behaviour(emu_lib):
 
 
 def test_emulated_tiered_work_areas(emu_lib):
-    """overflow -> re-run in a larger tier of the same dispatch; routing by requested size"""
+    """a case that outgrows its slot goes on in areas borrowed from the pool's tiers; without larger tiers it overflows"""
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_tiers.py"), "16"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "tiers ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_emulated_chunked_work_areas_default_tables(emu_lib):
+    """16 KiB slots, the full default tables: attempts that run out of memory (also inside nested scheduler calls) are
+    repeated after the case has borrowed a larger area; bytes, statuses and draw counts are the oracle's"""
+    env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_chunks.py"), "24"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "chunks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

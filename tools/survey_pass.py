@@ -31,13 +31,17 @@ import ctypes as C
 lens = np.zeros(n, dtype=np.uint64)
 print("kernel %.1f ms, total %.1f Gcyc, max %.1f Mcyc, out %.2f GB, status %s" % (
     eng.kernel_ms(), cyc.sum() / 1e9, cyc.max() / 1e6, ob / 1e9, np.bincount(st, minlength=6).tolist()))
+pk = eng.peak().astype(np.float64)
+print("work memory high-water MiB 50/90/99/99.9/max:", (np.percentile(pk, [50, 90, 99, 99.9, 100]) / 2**20).round(2).tolist(),
+      " cases above 1/2/4/8/16/32/64/256 MiB:", [int((pk > (m << 20)).sum()) for m in (1, 2, 4, 8, 16, 32, 64, 256)])
+print("pool:", eng.pool_stats())
 pct = np.percentile(cyc, [50, 90, 99, 99.9, 99.99])
 print("percentiles Mcyc 50/90/99/99.9/99.99:", (pct / 1e6).round(2).tolist())
 srt = np.sort(cyc)[::-1]
 for k in (1, 10, 100, 1000, 4096):
     print("  sum of the %d heaviest: %.1f Gcyc (%.1f%%)" % (k, srt[:k].sum() / 1e9, 100 * srt[:k].sum() / cyc.sum()))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-np.savez_compressed(os.path.join(ROOT, "gpurun_out", tag + "_cases.npz"), cycles=cyc, status=st, draws=dr, lastm=lm)
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", tag + "_cases.npz"), cycles=cyc, status=st, draws=dr, lastm=lm, peak=pk)
 order = np.argsort(-cyc)[:top]
 print("top cases:")
 for i in order[:40]:
