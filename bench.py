@@ -115,14 +115,15 @@ def main():
     ap.add_argument("--cpu-case-seconds", type=float, default=10.0, help="per-case wall-clock watchdog of the CPU oracle leg "
                     "(the reference's maxrunningtime; its CLI default is 30 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle leg (0 = all host cores, at most 64)")
-    ap.add_argument("--max-slots", type=int, default=0, help="persistent workgroups of one pass (0 = one per wavefront the device holds: "
-                    "8 per CU); passes in flight oversubscribe the device and share one pool of work areas")
-    ap.add_argument("--tier-gib", type=int, default=8, help="device memory of every tier of larger work areas of the shared pool (GiB), "
-                    "eh_options.tier_bytes; 0 = the library's own rule (an eighth of the free memory)")
-    ap.add_argument("--out-gib", type=int, default=28, help="output arena capacity per context (GiB)")
-    ap.add_argument("--case-mib", type=int, default=16, help="per-case work area of every resident wavefront (MiB), eh_options.max_case_bytes")
+    ap.add_argument("--max-slots", type=int, default=2048, help="slots = persistent workgroups of one pass (0 = one per wavefront the device holds: "
+                    "8 per CU); passes in flight oversubscribe the device")
+    ap.add_argument("--pool-gib", type=int, default=56, help="device memory of the work-area pool all contexts share (GiB), eh_options.pool_bytes; "
+                    "0 = the library's own rule (a quarter of the free memory, at most 64 GiB)")
+    ap.add_argument("--out-gib", type=int, default=27, help="output arena capacity per context (GiB)")
+    ap.add_argument("--case-mib", type=int, default=4, help="work area of a slot (MiB), eh_options.max_case_bytes; every workgroup of a pass owns a slot, a case that "
+                    "outgrows it borrows larger areas from the pool")
     ap.add_argument("--big-mib", type=int, default=1024, help="largest work area (MiB), eh_options.big_case_bytes: a case that outgrows its area "
-                    "is run again by the next tier (4x the area, a quarter of the wavefronts)")
+                    "borrows areas of 2x, 4x, ... from the pool, up to this size")
     ap.add_argument("--budget-mib", type=int, default=64, help="after the headline run (no budget), repeat 3 steps with this per-case work "
                     "budget (eh_options.max_case_work) and report them under 'with_work_budget'; 0 = skip")
     ap.add_argument("--work-mib", type=int, default=0, help="optional per-case work budget (MiB), eh_options.max_case_work; "
@@ -130,8 +131,8 @@ def main():
     ap.add_argument("--pcie", type=int, default=1, help="1: after the timed steps, one extra pass whose outputs are downloaded to pinned host memory "
                     "(reported as 'pcie'); 0: skip")
     ap.add_argument("--inflight", type=int, default=6, help="passes in flight (engine contexts / HIP streams): the tail of a pass — a few "
-                    "long single-wavefront cases — overlaps with the bulk of the next ones.  Every context owns its output arena (--out-gib); "
-                    "the work areas come from one pool shared by all contexts (about 33 GiB + 3 x --tier-gib at the defaults)")
+                    "long single-wavefront cases — overlaps with the bulk of the next ones.  Every context owns its output arena (--out-gib) and its slots "
+                    "(--max-slots x --case-mib); larger work areas come from one pool shared by all contexts (--pool-gib)")
     args = ap.parse_args()
 
     import numpy as np
@@ -175,7 +176,7 @@ def main():
         e = ea.Engine(local)
         e.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
                     max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20, big_case_bytes=args.big_mib << 20,
-                    tier_bytes=args.tier_gib << 30)
+                    pool_bytes=args.pool_gib << 30)
         e.attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
         engines.append(e)
         streams.append(torch.cuda.Stream(device=dev))
@@ -250,7 +251,7 @@ def main():
         for e in engines:
             e.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
                         max_case_bytes=args.case_mib << 20, max_case_work=args.budget_mib << 20, big_case_bytes=args.big_mib << 20,
-                        tier_bytes=args.tier_gib << 30)
+                        pool_bytes=args.pool_gib << 30)
         bsteps = min(3, args.steps)
         torch.cuda.synchronize()
         tb = time.perf_counter()
@@ -265,9 +266,6 @@ def main():
     dt_all, out_all, cases_all = shard.reduce_over_ranks(dt, out_bytes, n * args.steps, dist, dev)
 
     if rank == 0:
-        ntier, cap = 0, args.case_mib
-        while cap < args.big_mib and ntier < 5:
-            cap, ntier = min(cap * 4, args.big_mib), ntier + 1
         mbps = out_all / dt_all / 1e6
         in_bytes = float(n * size)
         avg_kern_s = float(np.mean(kern_ms)) / 1e3
@@ -304,7 +302,8 @@ def main():
                                ",".join(m for m, _, _ in ea.mutator_table() if m not in [x.split("=")[0] for x in muts.split(",")]) or "none"),
                 "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream before the W warm-up steps",
                 "max_case_bytes": args.case_mib << 20, "big_case_bytes": args.big_mib << 20, "max_case_work": args.work_mib << 20,
-                "tier0_slots_per_context": args.max_slots, "tier_gib": args.tier_gib,
+                "workgroups_per_pass": args.max_slots or "one per wavefront the device holds (8 per CU)", "pool_gib": args.pool_gib,
+                "work_area_pool": engines[0].pool_stats(),
             },
             "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(big_case_bytes)", "unsupported", "arena_full",
                                      "budget(max_case_work; reference analogue: maxrunningtime -> <<>>)"],
@@ -313,8 +312,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ea.load_library().eh_kernel_name().decode(), "kernel_ms_avg": round(avg_kern_s * 1e3, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "launch": "one eh_fuzz_batch = 1 dispatch of the kernel (tier 0 + %d overflow tiers as workgroup ranges of one grid); "
-                                   "kernel_ms_avg from HIP events on the launch stream" % ntier},
+                         "launch": "one eh_fuzz_batch = 1 dispatch of the kernel; kernel_ms_avg from HIP events on the launch stream.  %d passes are "
+                                   "in flight: a dispatch shares the device with the others for its whole duration, so the per-launch rate is "
+                                   "about 1/%d of the device's" % (nctx, nctx),
+                         "achieved_all_in_flight": round(alg_bytes / (dt_all / args.steps) / 1e9, 2)},
         }
         if budgeted is not None:
             res["with_work_budget"] = budgeted

@@ -22,6 +22,7 @@ constexpr int MAX_FS = 64;          // mux_fuzzers list entries (one per lane of
 constexpr int MAX_BLOCKS = 2048;    // block-list entries per case
 constexpr int MAX_EMITS = 4096;     // deferred output pieces per case
 constexpr int MAX_FRAMES = 16;      // nested sizer/csum wrappers
+constexpr int POOL_TIERS = 8;       // tiers of larger work areas a case can borrow from
 
 // erlamsa.hrl:44-58
 constexpr uint32_t INITIAL_IP = 24;
@@ -101,18 +102,20 @@ struct KParams {
   unsigned long long* prof;   // EH_PROF builds: [2*k] cycles, [2*k+1] calls; k < 64 mutator fn, 64.. phases
   unsigned long long* ticket;
   unsigned long long* in_bytes;
-  // Work areas come from a POOL that all contexts of a device share (eh_engine.hip, DevPool): a workgroup pops a tier-0
-  // slot (block tables + max_case_bytes of work area) when it starts and pushes it back when it leaves, so the memory is
-  // sized by the wavefronts the GPU can hold, not by the number of batches in flight.  A case that outgrows its area is
-  // run again from scratch (same result: a case is a pure function of its number) by the SAME wavefront in a larger
-  // area borrowed from tier 1.. (4x the area per tier up to big_case_bytes), chosen by what the case had asked for.
-  // Every tier is a ring of free area indices: pool_ctr[2t] = pop tickets, pool_ctr[2t+1] = push tickets.
-  int32_t ntiers;                // tiers above 0
-  uint8_t* pool_base[6];         // tier t: area k at pool_base[t] + k * pool_stride[t]
-  uint64_t pool_stride[6];
-  uint64_t pool_cap[6];          // work-area bytes of an area of tier t (pool_cap[0] == work_cap)
-  uint32_t pool_cnt[6];
-  uint32_t* pool_ring[6];
+  // Work areas.  Workgroup w of a batch owns slot w of the context (block tables + work_cap bytes of work area): a slot per
+  // launched workgroup, so no wavefront ever waits for one.  A case that outgrows what it holds borrows a larger area from
+  // a POOL all contexts of the device share (eh_engine.hip, DevPool; tiers 1..ntiers, twice the area per tier up to
+  // big_case_bytes) and goes on there; only the mutator attempt that ran out of memory is repeated (eh_device.h, ws_regrow).
+  // Every tier is a ring of free area indices: pool_ctr[2t] = pop tickets, pool_ctr[2t+1] = push tickets,
+  // pool_ctr[20+t] = ticks wavefronts waited for an area of tier t, pool_ctr[30+t] = how many had to wait.
+  uint8_t* slot_base;
+  uint64_t slot_stride;
+  int32_t ntiers;                // tiers of the pool (1..ntiers)
+  uint8_t* pool_base[POOL_TIERS + 1];   // tier t: area k at pool_base[t] + k * pool_stride[t]
+  uint64_t pool_stride[POOL_TIERS + 1];
+  uint64_t pool_cap[POOL_TIERS + 1];    // work-area bytes of an area of tier t (pool_cap[0] == work_cap: the slot's own)
+  uint32_t pool_cnt[POOL_TIERS + 1];
+  uint32_t* pool_ring[POOL_TIERS + 1];
   unsigned long long* pool_ctr;
 };
 

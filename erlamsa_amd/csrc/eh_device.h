@@ -219,7 +219,7 @@ EH_DEV bool wave_equal(const uint8_t* a, const uint8_t* b, uint32_t n) {
 // Per-case context (all wave-uniform)
 // ---------------------------------------------------------------------------------------------
 // site: 1xx eh_device.h, 2xx eh_doc.h, 3xx eh_engine.hip, 4xx eh_json.h, 5xx eh_lex.h, 6xx eh_sgml.h, 7xx eh_text.h, 8xx eh_tree.h
-constexpr int MAX_CHUNKS = 6;
+constexpr int MAX_CHUNKS = POOL_TIERS + 1;
 constexpr int MAX_NEST = 6;         // nested scheduler calls (b64 / sgm / js inner mutations)
 constexpr int LEX_LEVELS = MAX_NEST + 1;
 constexpr int ST_STATE_WORDS = 84;  // sizeof(StState) / 4 (eh_text.h; checked there)
@@ -317,15 +317,19 @@ EH_DEV uint32_t pool_pop(const KParams& p, int t) {
     if (v == 0xFFFFFFFFu) {                                          // every area of the tier is out: wait for a push (eh_pool_stats counts the cycles)
       uint64_t w0 = __builtin_readcyclecounter();
       for (;;) { pool_nap(); v = atomicExch(e, 0xFFFFFFFFu); if (v != 0xFFFFFFFFu) break; }
-      atomicAdd(&p.pool_ctr[16 + t], (unsigned long long)(__builtin_readcyclecounter() - w0));
-      atomicAdd(&p.pool_ctr[24 + t], 1ull);
+      atomicAdd(&p.pool_ctr[20 + t], (unsigned long long)(__builtin_readcyclecounter() - w0));
+      atomicAdd(&p.pool_ctr[30 + t], 1ull);
     }
   }
+#ifndef EH_NO_POOL_FENCE
   __threadfence();                                                   // the previous owner's stores (another XCD's L2) are behind us
+#endif
   return uni(v);
 }
 EH_DEV void pool_push(const KParams& p, int t, uint32_t v) {
+#ifndef EH_NO_POOL_FENCE
   __threadfence();                                                   // our stores to the area are written back before it changes hands
+#endif
   if (EH_LANE == 0) {
     unsigned long long h = atomicAdd(&p.pool_ctr[2 * t + 1], 1ull);
     uint32_t* e = p.pool_ring[t] + (h % p.pool_cnt[t]);
@@ -370,7 +374,9 @@ EH_DEV bool ws_slow(Ctx& c, uint64_t need, int site) {
     uint64_t at = c.ws_used > c.ch_vstart[j] ? c.ws_used : c.ch_vstart[j];
     if (at + need <= c.ch_vend[j]) { c.ws_used = at; ws_set_view(c, j); return true; }
   }
-  EH_SET_OVERFLOW(c, site); c.ovf_need = c.ws_used + need; c.ovf_req = need;
+  // (what the top of the chunk holds — lex tables made above the caller's mark — is part of what was asked for)
+  const int k = c.nchunk;
+  EH_SET_OVERFLOW(c, site); c.ovf_need = c.ws_used + need + (c.ch_vstart[k] + c.p->pool_cap[c.ch_tier[k]] - c.ch_vend[k]); c.ovf_req = need;
   return false;
 }
 EH_DEV uint64_t ws_max_request(const Ctx& c) { return c.p->pool_cap[c.p->ntiers]; }   // the largest single allocation a case can get
@@ -412,20 +418,21 @@ __device__ __noinline__ void ws_release_to(Ctx&, uint64_t mark) {
   ws_set_view(c, j);
 }
 // An allocation above `mark` failed (CASE_OVERFLOW with ovf_need set) and everything above mark has been given up: borrow
-// an area of a higher tier, large enough for twice what had been asked for above mark when it failed (at least the failed
-// request), and make it the top chunk starting at mark.  Waits for an area if the tier is out.  true: status is CASE_OK
-// again and the caller repeats its attempt; false: CASE_OVERFLOW stands (request above the largest area, or already there).
-__device__ __noinline__ bool ws_regrow(Ctx&, uint64_t mark) {
+// an area of a higher tier, large enough for what had been asked for above mark when it failed plus a quarter (allocations
+// mostly come before the work, so guessing low costs little), and make it the top chunk starting at mark.  Waits for an area if the tier is out.  *last_tier: the tier the
+// previous repetition of the same attempt was given (0: none) — the next one is strictly higher, so the repetitions end.
+// true: status is CASE_OK again and the caller repeats its attempt; false: CASE_OVERFLOW stands for good (ovf_need = 0,
+// so that callers further out do not try again): request above the largest area, or the case is already there.
+__device__ __noinline__ bool ws_regrow(Ctx&, uint64_t mark, int* last_tier) {
   Ctx& c = g_ctx;
   const KParams& p = *c.p;
   const uint64_t asked = c.ovf_need > mark ? c.ovf_need - mark : c.ovf_req, req = c.ovf_req;
   const int site = c.ovf_line;
   ws_release_to(c, mark);
   int tt = c.ch_tier[c.nchunk] + 1;
-  if (tt > p.ntiers || c.nchunk + 1 >= MAX_CHUNKS || req > p.pool_cap[p.ntiers] || asked > p.pool_cap[p.ntiers]) {
-    EH_SET_OVERFLOW(c, site); c.ovf_need = mark + asked; c.ovf_req = req; return false;
-  }
-  while (tt < p.ntiers && p.pool_cap[tt] < 2 * asked) tt++;
+  if (tt <= *last_tier) tt = *last_tier + 1;
+  while (tt < p.ntiers && p.pool_cap[tt] < asked + asked / 4) tt++;
+  if (tt > p.ntiers || c.nchunk + 1 >= MAX_CHUNKS || req > p.pool_cap[tt] || asked > p.pool_cap[tt]) { EH_SET_OVERFLOW(c, site); return false; }
   wave_sync();
   const uint32_t area = pool_pop(p, tt);
   const int k = c.nchunk + 1;
@@ -434,15 +441,17 @@ __device__ __noinline__ bool ws_regrow(Ctx&, uint64_t mark) {
   c.nchunk = k;
   ws_set_view(c, k);
   c.status = CASE_OK;
+  *last_tier = tt;
   return true;
 }
 // ws_alloc for code that is not inside a mutator attempt (patterns, generators): grows the work area on the spot
 __device__ __noinline__ uint8_t* ws_alloc_grow(Ctx&, uint64_t n) {
   Ctx& c = g_ctx;
+  int last_tier = 0;
   for (;;) {
     uint8_t* q = ws_alloc(c, n);
     if (q || c.status != CASE_OVERFLOW || c.ovf_need == 0) return q;
-    if (!ws_regrow(c, c.ws_used)) return nullptr;
+    if (!ws_regrow(c, c.ws_used, &last_tier)) return nullptr;
   }
 }
 EH_DEV Blk blk_load(const Blk* t, int i) {
@@ -812,12 +821,12 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
     const Rng rng0 = c.rng; const uint64_t work0 = c.work;
     const bool stateful = fn == M_LIS || fn == M_LRS;
     if (stateful) { const uint32_t* ax = (const uint32_t*)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) g_st_save[i] = ax[i]; }
-    int delta;
+    int delta, last_tier = 0;
     for (;;) {
       delta = run_mutator(c, fn, em_mask(meta));
       if (c.status != CASE_OVERFLOW || c.ovf_need == 0) break;
       wave_sync();
-      if (!ws_regrow(c, mark)) break;
+      if (!ws_regrow(c, mark, &last_tier)) break;
       lex_forget_from(c, mark);
       c.rng = rng0; c.work = work0;
       c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
@@ -850,6 +859,22 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
       // The slide is a second full copy of the block plus two memory round trips, so it is only done
       // once the work area is more than 1/8 full: the typical case (a 4 KiB block, ~10 rounds) never
       // gets there and simply leaves its dead candidates behind.
+      // The attempt went on in areas borrowed from the pool (it ran out of memory and was repeated): when the candidate
+      // fits where the attempt began, it moves there and the areas go back at once — most borrowers are fuse calls whose
+      // tables need tens of megabytes for a result of one or two.
+      if (c.nchunk > 0 && mark <= c.ch_vstart[c.nchunk] && !c.r2) {
+        int j = c.nchunk;
+        while (j > 0 && mark <= c.ch_vstart[j]) j--;
+        const uint64_t need = ((uint64_t)c.r_len + 15) & ~(uint64_t)15;
+        if (mark + need <= c.ch_vend[j]) {
+          uint8_t* dst = c.ch_base[j] + mark;
+          wave_sync(); wave_copy(dst, c.r_ptr, c.r_len); wave_sync();
+          c.r_ptr = dst;
+          ws_release_to(c, mark);
+          c.ws_used = mark + need;
+          if (c.ws_used > c.ws_peak) c.ws_peak = c.ws_used;
+        }
+      }
       uint8_t* lo = c.ws + mark;
       // A candidate of more than a few MiB stays where it is: mux_fuzzers never hands out a block above
       // ABSMAX_BINARY_BLOCK again (:1269, split_into_maxblocks), so nothing will copy it as a whole any more, and sliding

@@ -328,10 +328,10 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               SizerElem e;
               int r;
               {                                                                       // (out of work memory: borrow a larger area, pick again)
-                const Rng rng0 = c.rng; const uint64_t mark = c.ws_used;
+                const Rng rng0 = c.rng; const uint64_t mark = c.ws_used; int last_tier = 0;
                 for (;;) {
                   r = pick_simple_len(c, H, b.len, &e);
-                  if (c.status != CASE_OVERFLOW || c.ovf_need == 0 || !ws_regrow(c, mark)) break;
+                  if (c.status != CASE_OVERFLOW || c.ovf_need == 0 || !ws_regrow(c, mark, &last_tier)) break;
                   c.rng = rng0;
                 }
               }
@@ -521,9 +521,9 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
   LaneTab lt;
   c.p = pp;
   c.work_budget = p.work_budget;
-  // this workgroup's tier-0 slot: block tables + work area, held until the workgroup leaves
-  const uint32_t slot_id = pool_pop(p, 0);
-  uint8_t* slot = p.pool_base[0] + (uint64_t)slot_id * p.pool_stride[0];
+  // this workgroup's slot: block tables + work area
+  const uint32_t slot_id = blockIdx.x;
+  uint8_t* slot = p.slot_base + (uint64_t)slot_id * p.slot_stride;
   c.bl = (Blk*)slot;
   c.bl2 = c.bl + MAX_BLOCKS;
   c.em = c.bl2 + MAX_BLOCKS;
@@ -626,8 +626,6 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     }
     wave_sync();
   }
-  wave_sync();
-  pool_push(p, 0, slot_id);
 }
 
 // kernel-level self tests of the byte movers (driven by tests/test_gpu_primitives.py)
@@ -704,11 +702,11 @@ using namespace eh;
 
 // the work-area pool of a device (see pool_acquire)
 struct DevPool {
-  int device = 0; uint64_t work_cap = 0, big = 0, tier_bytes_opt = 0;
+  int device = 0; uint64_t work_cap = 0, big = 0, pool_bytes_opt = 0;
   int refs = 0;
-  int ntiers = 0;                                       // tiers above 0
-  uint8_t* base[6] = {}; uint64_t stride[6] = {}, cap[6] = {}; uint32_t cnt[6] = {};
-  uint32_t* d_rings = nullptr; uint32_t* ring[6] = {}; unsigned long long* d_ctr = nullptr;
+  int ntiers = 0;                                       // tiers 1..ntiers
+  uint8_t* base[POOL_TIERS + 1] = {}; uint64_t stride[POOL_TIERS + 1] = {}, cap[POOL_TIERS + 1] = {}; uint32_t cnt[POOL_TIERS + 1] = {};
+  uint32_t* d_rings = nullptr; uint32_t* ring[POOL_TIERS + 1] = {}; unsigned long long* d_ctr = nullptr;
 };
 
 struct eh_ctx {
@@ -718,7 +716,7 @@ struct eh_ctx {
   bool configured = false;
   DevConfig cfg;
   uint64_t max_case_bytes = 0, out_capacity_opt = 0, work_budget = 0;
-  uint64_t fuse_stream_min = 16384, tier_bytes_opt = 0, dl_chunk = 256ull << 20;   // eh_options (ABI 4)
+  uint64_t fuse_stream_min = 16384, pool_bytes_opt = 0, dl_chunk = 256ull << 20;   // eh_options (ABI 4)
   uint32_t max_slots_opt = 0, flags = 0;
   KParams* d_params = nullptr;                          // argument block of eh_mutate_kernel
   // eh_result_download: case-ordered chunks are gathered on the device into two bounce buffers; chunk k goes over PCIe
@@ -735,6 +733,7 @@ struct eh_ctx {
   std::vector<uint64_t> h_coff;  // host copy of offsets (for totals)
   // work areas: a pool shared by every context of the device with the same sizes (DevPool below)
   DevPool* pool = nullptr;
+  uint8_t* d_slots = nullptr; uint64_t slot_stride = 0, slot_cap = 0; uint32_t nslots = 0;   // a slot per workgroup of a batch
   uint64_t big_case_bytes = 0;
   // outputs
   uint8_t* d_out = nullptr; uint64_t out_cap = 0;
@@ -849,7 +848,7 @@ static int ensure_results(eh_ctx* ctx, uint64_t n) {
 }
 
 // ---- the work-area pool ------------------------------------------------------------------------------------------
-// One pool per (device, max_case_bytes, big_case_bytes, tier_bytes), shared by all contexts that ask for those sizes and
+// One pool per (device, max_case_bytes, big_case_bytes, pool_bytes), shared by all contexts that ask for those sizes and
 // freed with the last of them.  Tier 0 has one slot (block tables + max_case_bytes) for every wavefront the device can hold
 // of eh_mutate_kernel — workgroups of any number of batches in flight, on any streams, take their slot from it — and
 // tiers 1.. hold the larger areas (4x per tier up to big_case_bytes) a wavefront borrows for a case that outgrew its slot.
@@ -859,7 +858,7 @@ static std::vector<DevPool*> g_pools;
 static void pool_free(DevPool* pl) {
   (void)hipSetDevice(pl->device);
   (void)hipDeviceSynchronize();
-  for (int t = 0; t <= pl->ntiers; t++) if (pl->base[t]) (void)hipFree(pl->base[t]);
+  for (int t = 1; t <= pl->ntiers; t++) if (pl->base[t]) (void)hipFree(pl->base[t]);
   if (pl->d_rings) (void)hipFree(pl->d_rings);
   if (pl->d_ctr) (void)hipFree(pl->d_ctr);
   delete pl;
@@ -872,57 +871,53 @@ static void pool_release(eh_ctx* ctx) {
   for (size_t i = 0; i < g_pools.size(); i++) if (g_pools[i] == pl) { g_pools.erase(g_pools.begin() + i); break; }
   pool_free(pl);
 }
-static int pool_acquire(eh_ctx* ctx, uint64_t work_cap, uint64_t big, uint64_t tier_bytes_opt) {
-  if (ctx->pool && ctx->pool->work_cap == work_cap && ctx->pool->big == big && ctx->pool->tier_bytes_opt == tier_bytes_opt) return EH_OK;
+static int pool_acquire(eh_ctx* ctx, uint64_t work_cap, uint64_t big, uint64_t pool_bytes_opt) {
+  if (ctx->pool && ctx->pool->work_cap == work_cap && ctx->pool->big == big && ctx->pool->pool_bytes_opt == pool_bytes_opt) return EH_OK;
   pool_release(ctx);
   std::lock_guard<std::mutex> g(g_pool_lock);
   for (DevPool* q : g_pools)
-    if (q->device == ctx->device && q->work_cap == work_cap && q->big == big && q->tier_bytes_opt == tier_bytes_opt) { q->refs++; ctx->pool = q; return EH_OK; }
+    if (q->device == ctx->device && q->work_cap == work_cap && q->big == big && q->pool_bytes_opt == pool_bytes_opt) { q->refs++; ctx->pool = q; return EH_OK; }
   DevPool* pl = new (std::nothrow) DevPool();
   if (!pl) return EH_E_NOMEM;
-  pl->device = ctx->device; pl->work_cap = work_cap; pl->big = big; pl->tier_bytes_opt = tier_bytes_opt;
-  const uint64_t tables = (uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES;
-  // tier 0: a slot per wavefront the device holds at EH_WAVES_PER_SIMD; fewer when memory is short (a workgroup then waits
-  // for a slot: correct, slower)
-  uint32_t want = (uint32_t)ctx->cus * 4u * EH_WAVES_PER_SIMD;
-  pl->stride[0] = (tables + work_cap + 255) & ~255ull; pl->cap[0] = work_cap;
+  pl->device = ctx->device; pl->work_cap = work_cap; pl->big = big; pl->pool_bytes_opt = pool_bytes_opt;
+  pl->cap[0] = work_cap;
+  // twice the area per tier (most cases that outgrow what they hold need less than twice as much); the last tier has `big`.
+  // The pool's memory (pool_bytes; default: a quarter of the free memory, at most 64 GiB) is split over the tiers in the
+  // proportions the bench workload asks for them (BASELINE configs[2], 4 MiB slots: by far most borrowers are fuse calls on
+  // blocks of 0.1-1 MB, whose tables take 5-20 MB): 12 / 33 / 25 / 9 / 6 / 6 / 3 / 6 percent from the smallest tier up.
+  // Every tier holds at least one area, at most 4096; a tier that cannot be allocated at all ends the ladder.
+  static const uint32_t SHARE[POOL_TIERS] = {12, 33, 25, 9, 6, 6, 3, 6};
   size_t fr = 0, tot = 0;
-  if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)16 << 30;
-  while (want > 4 && pl->stride[0] * want > (uint64_t)fr / 2) want /= 2;
-  hipError_t e = hipErrorOutOfMemory;
-  for (; want >= 1; want /= 2) { e = hipMalloc(&pl->base[0], pl->stride[0] * want); if (e == hipSuccess) break; pl->base[0] = nullptr; }
-  if (e != hipSuccess) { delete pl; ctx->err = "work-area pool: out of device memory"; return EH_E_NOMEM; }
-  pl->cnt[0] = want;
-  // tiers above 0: 4x the area each up to `big`; every tier gets tier_bytes (default: an eighth of the free memory, 1..32 GiB),
-  // at least one area, at most 1024; a tier that cannot be allocated at all ends the ladder
-  uint64_t cap = work_cap;
-  while (cap < big && pl->ntiers < 5) {
-    cap = (cap * 4 < big && pl->ntiers < 4) ? cap * 4 : big;                      // the last tier always has the full size
-    uint64_t stride_t = (cap + 255) & ~255ull;
-    uint64_t tier_gib = 16;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess) { tier_gib = (uint64_t)fr >> 33; if (tier_gib < 1) tier_gib = 1; if (tier_gib > 32) tier_gib = 32; }
-    uint64_t tier_bytes = tier_bytes_opt ? tier_bytes_opt : (tier_gib << 30);
-    uint64_t cnt = tier_bytes / stride_t; if (cnt < 1) cnt = 1; if (cnt > 1024) cnt = 1024;
+  hipError_t e = hipSuccess;
+  uint64_t pool_bytes = pool_bytes_opt;
+  if (!pool_bytes) { pool_bytes = 16ull << 30; if (hipMemGetInfo(&fr, &tot) == hipSuccess) { pool_bytes = (uint64_t)fr / 4; if (pool_bytes > (64ull << 30)) pool_bytes = 64ull << 30; if (pool_bytes < (1ull << 30)) pool_bytes = 1ull << 30; } }
+  uint64_t caps[POOL_TIERS]; int nt = 0;
+  for (uint64_t cap = work_cap; cap < big && nt < POOL_TIERS; ) { cap = (cap * 2 < big && nt < POOL_TIERS - 1) ? cap * 2 : big; caps[nt++] = cap; }   // the last tier always has the full size
+  uint32_t share_sum = 0;
+  for (int k = 0; k < nt; k++) share_sum += SHARE[k == nt - 1 ? POOL_TIERS - 1 : k];
+  for (int k = 0; k < nt; k++) {
+    uint64_t stride_t = (caps[k] + 255) & ~255ull;
+    uint64_t cnt = pool_bytes / share_sum * SHARE[k == nt - 1 ? POOL_TIERS - 1 : k] / stride_t; if (cnt < 1) cnt = 1; if (cnt > 4096) cnt = 4096;
     if (ctx->cus < 64 && cnt > 2) cnt = 2;                                         // (the emulator)
     int t = pl->ntiers + 1;
     for (; cnt >= 1; cnt /= 2) { e = hipMalloc(&pl->base[t], stride_t * cnt); if (e == hipSuccess) break; pl->base[t] = nullptr; }
     if (e != hipSuccess) break;
-    pl->stride[t] = stride_t; pl->cap[t] = cap; pl->cnt[t] = (uint32_t)cnt; pl->ntiers++;
+    pl->stride[t] = stride_t; pl->cap[t] = caps[k]; pl->cnt[t] = (uint32_t)cnt; pl->ntiers++;
   }
-  uint64_t nring = 0;
-  for (int t = 0; t <= pl->ntiers; t++) nring += pl->cnt[t];
+  uint64_t nring = 4;
+  for (int t = 1; t <= pl->ntiers; t++) nring += pl->cnt[t];
   std::vector<uint32_t> init(nring);
-  std::vector<unsigned long long> ctr(32, 0ull);
-  if (hipMalloc(&pl->d_rings, nring * 4) != hipSuccess || hipMalloc(&pl->d_ctr, 32 * 8) != hipSuccess) { pool_free(pl); ctx->err = "work-area pool: out of device memory"; return EH_E_NOMEM; }
+  std::vector<unsigned long long> ctr(64, 0ull);
+  if (hipMalloc(&pl->d_rings, nring * 4) != hipSuccess || hipMalloc(&pl->d_ctr, 64 * 8) != hipSuccess) { pool_free(pl); ctx->err = "work-area pool: out of device memory"; return EH_E_NOMEM; }
   uint64_t o = 0;
-  for (int t = 0; t <= pl->ntiers; t++) {
+  for (int t = 1; t <= pl->ntiers; t++) {
     pl->ring[t] = pl->d_rings + o;
     for (uint32_t k = 0; k < pl->cnt[t]; k++) init[o + k] = k;
     ctr[2 * t] = 0; ctr[2 * t + 1] = pl->cnt[t];                                   // pop tickets, push tickets
     o += pl->cnt[t];
   }
   if (hipMemcpy(pl->d_rings, init.data(), nring * 4, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(pl->d_ctr, ctr.data(), 32 * 8, hipMemcpyHostToDevice) != hipSuccess) { pool_free(pl); ctx->err = "work-area pool: hipMemcpy failed"; return EH_E_HIP; }
+      hipMemcpy(pl->d_ctr, ctr.data(), 64 * 8, hipMemcpyHostToDevice) != hipSuccess) { pool_free(pl); ctx->err = "work-area pool: hipMemcpy failed"; return EH_E_HIP; }
   pl->refs = 1; g_pools.push_back(pl); ctx->pool = pl;
   return EH_OK;
 }
@@ -937,8 +932,18 @@ static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
   uint64_t work_cap = ctx->max_case_bytes ? ctx->max_case_bytes : (8ull << 20);
   uint64_t big = ctx->big_case_bytes ? ctx->big_case_bytes : (32 * work_cap < (1024ull << 20) ? 32 * work_cap : (1024ull << 20));
   if (big < work_cap) big = work_cap;
-  rc = pool_acquire(ctx, work_cap, big, ctx->tier_bytes_opt);
+  rc = pool_acquire(ctx, work_cap, big, ctx->pool_bytes_opt);
   if (rc) return rc;
+  // a slot per workgroup of a batch: one workgroup per wavefront the device holds (EH_WAVES_PER_SIMD), or max_slots
+  uint32_t want_slots = ctx->max_slots_opt ? ctx->max_slots_opt : (uint32_t)ctx->cus * 4u * EH_WAVES_PER_SIMD;
+  if (want_slots > n) want_slots = (uint32_t)(n ? n : 1);
+  uint64_t stride = ((uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + work_cap + 255) & ~255ull;
+  if (!ctx->d_slots || ctx->nslots < want_slots || ctx->slot_cap != work_cap) {
+    if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    ctx->d_slots = nullptr;
+    HIPCHK(ctx, hipMalloc(&ctx->d_slots, stride * want_slots));
+    ctx->nslots = want_slots; ctx->slot_cap = work_cap; ctx->slot_stride = stride;
+  }
   uint64_t want_out = ctx->out_capacity_opt ? ctx->out_capacity_opt : (8 * (in_bytes ? in_bytes : ctx->corpus_bytes) + (2048ull << 20));
   if (!ctx->d_out || ctx->out_cap < want_out) {
     if (ctx->d_out) (void)hipFree(ctx->d_out);
@@ -971,12 +976,12 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
   p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles; p.peak = ctx->d_peak;
   p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;   // counters [8, 264) = prof
-  p.ntiers = pl->ntiers; p.pool_ctr = pl->d_ctr;
-  for (int t = 0; t <= pl->ntiers; t++) { p.pool_base[t] = pl->base[t]; p.pool_stride[t] = pl->stride[t]; p.pool_cap[t] = pl->cap[t]; p.pool_cnt[t] = pl->cnt[t]; p.pool_ring[t] = pl->ring[t]; }
-  // persistent workgroups: one per wavefront the device holds (or max_slots), each pulling cases from the ticket counter.
-  // Several batches in flight oversubscribe the device; the dispatcher starts a batch's workgroups as earlier ones leave.
-  uint32_t grid0 = ctx->max_slots_opt ? ctx->max_slots_opt : (uint32_t)ctx->cus * 4u * EH_WAVES_PER_SIMD;
-  if (grid0 > n) grid0 = (uint32_t)n;
+  p.slot_base = ctx->d_slots; p.slot_stride = ctx->slot_stride;
+  p.ntiers = pl->ntiers; p.pool_ctr = pl->d_ctr; p.pool_cap[0] = pl->work_cap;
+  for (int t = 1; t <= pl->ntiers; t++) { p.pool_base[t] = pl->base[t]; p.pool_stride[t] = pl->stride[t]; p.pool_cap[t] = pl->cap[t]; p.pool_cnt[t] = pl->cnt[t]; p.pool_ring[t] = pl->ring[t]; }
+  // persistent workgroups, each pulling cases from the ticket counter.  Batches in flight on several streams may
+  // oversubscribe the device: the dispatcher starts a batch's workgroups as those of earlier ones leave.
+  uint32_t grid0 = ctx->nslots < n ? ctx->nslots : (uint32_t)n;
 
   if (mode == 0) hipLaunchKernelGGL(eh_setup_kernel, dim3(1), dim3(64), 0, st, ctx->cfg, seed[0], seed[1], seed[2], ctx->d_run);
   HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
@@ -1087,7 +1092,7 @@ void eh_destroy(eh_ctx* ctx) {
   (void)hipDeviceSynchronize();
   if (ctx->own_corpus) { (void)hipFree(ctx->d_corpus); (void)hipFree(ctx->d_coff); }
   pool_release(ctx);
-  (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
+  (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
   (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_peak); (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_run); (void)hipFree(ctx->d_seeds);
   for (int k = 0; k < 2; k++) { if (ctx->d_bounce[k]) (void)hipFree(ctx->d_bounce[k]); if (ctx->ev_g[k]) (void)hipEventDestroy(ctx->ev_g[k]); if (ctx->ev_c[k]) (void)hipEventDestroy(ctx->ev_c[k]); }
@@ -1155,7 +1160,7 @@ int eh_configure(eh_ctx* ctx, const eh_options* o) {
   ctx->work_budget = o->max_case_work;
   ctx->big_case_bytes = o->big_case_bytes; ctx->max_case_bytes = o->max_case_bytes; ctx->out_capacity_opt = o->out_capacity; ctx->max_slots_opt = o->max_slots; ctx->flags = o->flags;
   ctx->fuse_stream_min = o->fuse_stream_min ? o->fuse_stream_min : 16384;
-  ctx->tier_bytes_opt = o->tier_bytes; ctx->dl_chunk = o->download_chunk_bytes ? o->download_chunk_bytes : (256ull << 20);
+  ctx->pool_bytes_opt = o->pool_bytes; ctx->dl_chunk = o->download_chunk_bytes ? o->download_chunk_bytes : (256ull << 20);
   ctx->configured = true;
   return EH_OK;
 }
@@ -1471,14 +1476,14 @@ int eh_selftest_movers(eh_ctx* ctx, uint8_t* buf, uint64_t buf_len, const uint32
   HIPCHK(ctx, e);
   return EH_OK;
 }
-int eh_pool_stats(eh_ctx* ctx, uint64_t* out /* 40 values */) {
+int eh_pool_stats(eh_ctx* ctx, uint64_t* out /* 64 values */) {
   if (!ctx || !out) return EH_E_INVALID;
   if (!ctx->pool) { ctx->err = "no work-area pool yet (eh_reserve or a first batch creates it)"; return EH_E_STATE; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipMemcpy(out, ctx->pool->d_ctr, 32 * 8, hipMemcpyDeviceToHost));   // (a plain copy: fine while batches run)
-  out[32] = (uint64_t)ctx->pool->ntiers;
-  for (int t = 0; t < 6; t++) out[33 + t] = t <= ctx->pool->ntiers ? ctx->pool->cnt[t] : 0;
-  out[39] = (uint64_t)ctx->pool->refs;
+  HIPCHK(ctx, hipMemcpy(out, ctx->pool->d_ctr, 40 * 8, hipMemcpyDeviceToHost));   // (a plain copy: fine while batches run)
+  out[40] = (uint64_t)ctx->pool->ntiers;
+  for (int t = 0; t <= POOL_TIERS; t++) { out[41 + t] = t >= 1 && t <= ctx->pool->ntiers ? ctx->pool->cnt[t] : 0; out[51 + t] = t <= ctx->pool->ntiers ? ctx->pool->cap[t] : 0; }
+  out[61] = (uint64_t)ctx->pool->refs; out[62] = ctx->nslots; out[63] = 0;
   return EH_OK;
 }
 int eh_last_kernel_ms(eh_ctx* ctx, float* ms) {

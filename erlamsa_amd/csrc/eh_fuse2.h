@@ -181,6 +181,10 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
         rk[u][k] = r;                                              // mask 0: not a member of any child
       }
     }
+    // new ids first, then (MODE 2) the 16 bitmap tests of the step as ONE batch of loads, then the atomics that are still
+    // needed: tested one after the other behind their branches, every test was a memory round trip of its own and a step
+    // cost sixteen of them (4.4 M cycles per pass in the bench workload's profile, 36 % of all wave cycles).
+    uint32_t w2v[U][4], bit2v[U][4];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint32_t p = base + 256u * u + 4u * l;
@@ -194,17 +198,34 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
         if (rk[u][k].mask & bit) nid = rk[u][k].prefix + (uint32_t)__popc(rk[u][k].mask & (bit - 1u));
         if (nid == kill || (pos == e_pos && e_kill)) nid = FB_DEAD;
         nw[k] = nid;
+        w2v[u][k] = 0; bit2v[u][k] = 0;                            // bit2 == 0: nothing to set
         if (nid != FB_DEAD) {
           alive++;
           if (Mn && pos + g + 2 < len) {
             uint32_t b2 = fb_tr((uint32_t)(byv[u] >> (8 * k + 8)) & 255u, g + 1);
-            const uint32_t w2 = nid * 8u + (b2 >> 5), bit2 = 1u << (b2 & 31u);
-            if (MODE == 1) atomicOr(&g_fuse_lds[w2], bit2);
-            else if (MODE == 0 || !(fb_ld(&Mn[w2]) & bit2)) atomicOr(&Mn[w2], bit2);
+            w2v[u][k] = nid * 8u + (b2 >> 5); bit2v[u][k] = 1u << (b2 & 31u);
           }
         }
       }
       if (p < len) { uint4 v; v.x = nw[0]; v.y = nw[1]; v.z = nw[2]; v.w = nw[3]; *reinterpret_cast<uint4*>(ids + p) = v; }
+    }
+    if (Mn) {
+      if (MODE == 2) {
+        uint32_t have[U][4];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (uint32_t k = 0; k < 4; k++) have[u][k] = fb_ld(&Mn[w2v[u][k]]);      // (word 0 for the lanes with nothing to set)
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (uint32_t k = 0; k < 4; k++) if (bit2v[u][k] & ~have[u][k]) atomicOr(&Mn[w2v[u][k]], bit2v[u][k]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (uint32_t k = 0; k < 4; k++) if (bit2v[u][k]) { if (MODE == 1) atomicOr(&g_fuse_lds[w2v[u][k]], bit2v[u][k]); else atomicOr(&Mn[w2v[u][k]], bit2v[u][k]); }
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) { idv[u] = nidv[u]; byv[u] = nbyv[u]; }
@@ -262,6 +283,7 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t l
   uint32_t* ids[2] = {nullptr, nullptr};
   uint32_t* M[2] = {nullptr, nullptr};
   RkWord* RK = nullptr;
+  uint32_t rk_rows = 0, m_rows = 0;                                // nodes RK / M[] have room for
   const uint8_t* S[2] = {A, B};
   const uint32_t len[2] = {la, lb};
   const int nside = sym ? 1 : 2;
@@ -278,15 +300,20 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t l
       c.work += 16ull * gen_entries;
       if (c.work > c.work_budget) { c.status = CASE_BUDGET; return false; }
     }
-    if (!RK) {                                                     // first round: tables for <= min(la, 100000) nodes
-      uint64_t rows = (la < 100000u ? la : 100000u) + 4;
-      for (int s = 0; s < nside; s++) {
-        ids[s] = (uint32_t*)ws_alloc(c, ((uint64_t)len[s] + 8) * 4);
-        M[s] = (uint32_t*)ws_alloc(c, rows * 32);
-        if (!ids[s] || !M[s]) return false;
-      }
-      RK = (RkWord*)ws_alloc(c, rows * 64);
+    // Tables grow with the generations (n_g <= 256 n_{g-1}, and the fuel keeps n_g <= 100 000): a table that has become
+    // too small is left behind and a larger one allocated — what is left behind is a fraction of what replaces it.  Sizing
+    // everything for 100 000 nodes up front made every fuse of a block of 100 KB and more ask for 13 to 21 MB.
+    if (!ids[0]) {
+      for (int s = 0; s < nside; s++) { ids[s] = (uint32_t*)ws_alloc(c, ((uint64_t)len[s] + 8) * 4); if (!ids[s]) return false; }
+    }
+    if (nn > rk_rows) {
+      rk_rows = nn < 1024u ? 1024u : nn;
+      RK = (RkWord*)ws_alloc(c, ((uint64_t)rk_rows + 4) * 64);
       if (!RK) return false;
+    }
+    if (nn > m_rows) {                                             // (only generation 0 comes here: later bitmaps are sized below)
+      m_rows = nn < 1024u ? 1024u : nn;
+      for (int s = 0; s < nside; s++) { M[s] = (uint32_t*)ws_alloc(c, ((uint64_t)m_rows + 4) * 32); if (!M[s]) return false; }
     }
     const uint32_t nwords = nn * 8u;
     EH_PT(c, 100);
@@ -317,6 +344,10 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t l
     fuel -= (int64_t)nchild;
     const bool next = fuel >= 0 && (uint32_t)(rng_peek(c.rng, 1) * 8.0) != 0;
     const bool lds = next && nchild * 8u <= FB_LDS_WORDS;
+    if (next && nchild > m_rows) {                                 // the next generation's bitmaps (this one's are in RK now)
+      m_rows = nchild;
+      for (int s = 0; s < nside; s++) { M[s] = (uint32_t*)ws_alloc(c, ((uint64_t)m_rows + 4) * 32); if (!M[s]) return false; }
+    }
     uint64_t entries = 0;
     for (int s = 0; s < nside; s++) {
       if (next) {

@@ -450,7 +450,7 @@ __device__ __noinline__ int muta_tree(Ctx&, int fn) {
   uint64_t fixed = plen - matched_bytes;                          // bytes of P outside the matched children
   // size of R_n
   uint64_t rsz = plen;
-  for (uint32_t t = 2; t <= nreps; t++) { rsz = (uint64_t)k_in * rsz + fixed; if (rsz > ws_max_request(c)) { EH_SET_OVERFLOW(c, 802); c.ovf_need = c.ws_used + rsz; c.ovf_req = rsz; return 1; } }
+  for (uint32_t t = 2; t <= nreps; t++) { rsz = (uint64_t)k_in * rsz + fixed; if (rsz > ws_max_request(c)) { EH_SET_OVERFLOW(c, 802); c.ovf_req = rsz; return 1; } }
   uint8_t* R = nullptr;
   if (nreps < 2) R = (uint8_t*)(H + P.open);
   else if (k_in == 1) {

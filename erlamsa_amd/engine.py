@@ -33,7 +33,7 @@ class EhOptions(C.Structure):
                 ("generators", C.c_char_p), ("blockscale", C.c_double), ("ssrf_host", C.c_char_p),
                 ("ssrf_port", C.c_int32), ("max_case_bytes", C.c_uint64), ("out_capacity", C.c_uint64),
                 ("max_case_work", C.c_uint64), ("max_slots", C.c_uint32), ("flags", C.c_uint32), ("big_case_bytes", C.c_uint64),
-                ("tier_bytes", C.c_uint64), ("download_chunk_bytes", C.c_uint64), ("fuse_stream_min", C.c_uint64)]
+                ("pool_bytes", C.c_uint64), ("download_chunk_bytes", C.c_uint64), ("fuse_stream_min", C.c_uint64)]
 
 
 class EngineError(RuntimeError):
@@ -147,7 +147,7 @@ class Engine:
 
     def configure(self, mutations=None, patterns=None, generators=None, blockscale=1.0, ssrf_host=None, ssrf_port=0,
                   max_case_bytes=0, out_capacity=0, max_slots=0, flags=0, max_case_work=0, big_case_bytes=0,
-                  tier_bytes=0, download_chunk_bytes=0, fuse_stream_min=0):
+                  pool_bytes=0, download_chunk_bytes=0, fuse_stream_min=0):
         o = EhOptions()
         o.abi_version = EH_ABI_VERSION
         o.mutations = mutations.encode() if mutations is not None else None
@@ -158,7 +158,7 @@ class Engine:
         o.ssrf_port = ssrf_port
         o.max_case_bytes = max_case_bytes
         o.big_case_bytes = big_case_bytes
-        o.tier_bytes, o.download_chunk_bytes, o.fuse_stream_min = tier_bytes, download_chunk_bytes, fuse_stream_min
+        o.pool_bytes, o.download_chunk_bytes, o.fuse_stream_min = pool_bytes, download_chunk_bytes, fuse_stream_min
         o.out_capacity = out_capacity
         o.max_slots = max_slots
         o.max_case_work = max_case_work
@@ -207,12 +207,14 @@ class Engine:
         return ms.value
 
     def pool_stats(self):
-        """Work-area pool of the device (eh_pool_stats): dict with per-tier areas, takes, waits."""
-        v = np.zeros(40, dtype=np.uint64)
+        """Work-area pool of the device (eh_pool_stats): per-tier (1..) area bytes, areas, takes, waits."""
+        v = np.zeros(64, dtype=np.uint64)
         self._chk(self.lib.eh_pool_stats(self.h, v.ctypes.data_as(C.c_void_p)))
-        nt = int(v[32]) + 1
-        return {"areas": [int(x) for x in v[33:33 + nt]], "taken": [int(v[2 * t]) for t in range(nt)],
-                "waits": [int(v[24 + t]) for t in range(nt)], "wait_ticks": [int(v[16 + t]) for t in range(nt)], "contexts": int(v[39])}
+        nt = int(v[40])
+        ts = range(1, nt + 1)
+        return {"slot_bytes": int(v[51]), "slots": int(v[62]), "area_bytes": [int(v[51 + t]) for t in ts], "areas": [int(v[41 + t]) for t in ts],
+                "taken": [int(v[2 * t]) for t in ts], "waits": [int(v[30 + t]) for t in ts], "wait_ticks": [int(v[20 + t]) for t in ts],
+                "contexts": int(v[61])}
 
     def download(self):
         """-> (list[bytes] per case, status int32[n])"""

@@ -75,27 +75,26 @@ typedef struct eh_options {
   double blockscale;         /* 0 => 1.0 (erlamsa_gen.erl:206) */
   const char* ssrf_host;     /* NULL => "localhost" */
   int32_t ssrf_port;         /* 0 => 51234 */
-  uint64_t max_case_bytes;   /* work area of a tier-0 slot of the device's work-area pool: every resident wavefront holds one;
-                                0 => default (8 MiB).  Contexts of one device that ask for the same max_case_bytes,
-                                big_case_bytes and tier_bytes share one pool (sized by the wavefronts the device holds, not
-                                by the number of batches in flight) */
+  uint64_t max_case_bytes;   /* work area of a slot; every workgroup (= wavefront) of a batch owns one; 0 => default (8 MiB).
+                                A case that outgrows it goes on in larger areas borrowed from the device's work-area pool,
+                                which contexts that ask for the same max_case_bytes, big_case_bytes and pool_bytes share */
   uint64_t out_capacity;     /* output arena bytes; 0 => 8 x batch input bytes + 2 GiB */
   uint64_t max_case_work;    /* OPTIONAL per-case work budget in bytes (sum over mutator attempts, failed ones
                                 included, of block size x cost weight of the mutator: 8 for parsers and
                                 per-byte-draw mutators, 64 for the fuse family, 4 for num, 1 otherwise; plus 16 x
                                 the list members of every fuse refinement round);
                                 0 => no budget (default): every case runs to completion */
-  uint32_t max_slots;        /* persistent workgroups (wavefronts) of one batch; 0 => one per wavefront the device holds.
-                                Batches in flight on several streams oversubscribe the device: a batch's workgroups start
-                                as those of earlier batches leave */
+  uint32_t max_slots;        /* slots = persistent workgroups (wavefronts) of one batch; 0 => one per wavefront the device holds.
+                                Batches in flight on several streams may oversubscribe the device: a batch's workgroups
+                                start as those of earlier batches leave */
   uint32_t flags;            /* EH_FLAG_* */
-  uint64_t big_case_bytes;   /* largest work area.  A case that outgrows its area is run again from scratch (same
-                                result) by the same wavefront in a larger area borrowed from the pool: 4x the area per
-                                tier up to this size; only a case that outgrows this too ends as EH_CASE_OVERFLOW.
-                                0 => 32 x max_case_bytes, at most 1 GiB; <= max_case_bytes => a single tier */
+  uint64_t big_case_bytes;   /* largest work area of the pool.  A case that outgrows what it holds goes on in a larger area
+                                borrowed from the pool (2x per tier, at most 8 tiers, the last one has this size; only the mutator
+                                attempt that ran out of memory is repeated); a case that outgrows this too ends as
+                                EH_CASE_OVERFLOW.  0 => 32 x max_case_bytes, at most 1 GiB; <= max_case_bytes => slots only */
   /* ABI 4: engine tuning that used to be environment variables of the library */
-  uint64_t tier_bytes;       /* device memory of every tier of larger areas of the pool; 0 => an eighth of the memory that is
-                                free when the pool is made, 1 .. 32 GiB.  Every tier holds at least one area */
+  uint64_t pool_bytes;       /* device memory of the work-area pool (all tiers together); 0 => a quarter of the memory that is
+                                free when the pool is made, 1 .. 64 GiB.  Every tier holds at least one area */
   uint64_t download_chunk_bytes; /* bounce-buffer size of eh_result_download's device gather; 0 => 256 MiB */
   uint64_t fuse_stream_min;  /* erlamsa_fuse:fuse/2 on la + lb >= this many bytes runs as the position-indexed class
                                 refinement (csrc/eh_fuse2.h) instead of the node-list refinement (csrc/eh_fuse.h);
@@ -182,10 +181,11 @@ int eh_result_prof(eh_ctx* ctx, uint64_t* prof);
  * {kind (0 copy, 1 periodic fill, 2 equal), dst_off, src_off, n, plen} over the buffer image. */
 int eh_selftest_movers(eh_ctx* ctx, uint8_t* buf, uint64_t buf_len, const uint32_t* jobs, uint32_t njobs, uint32_t* eq_out);
 
-/* Work-area pool of this context's device (diagnostic), 40 values: out[2t] / out[2t+1] = areas of tier t taken / returned
- * since the pool was made (+ the tier's size for the latter), out[16+t] = shader-clock ticks wavefronts waited for an area
- * of tier t, out[24+t] = how many had to wait, out[32] = tiers above 0, out[33+t] = areas of tier t, out[39] = contexts
- * sharing the pool. */
+/* Work-area pool of this context's device (diagnostic), 64 values; t = tier 1 .. out[40]: out[2t] / out[2t+1] = areas
+ * of tier t taken / returned since the pool was made (+ the tier's size for the latter), out[20+t] = shader-clock ticks
+ * wavefronts waited for an area of tier t, out[30+t] = how many had to wait, out[40] = tiers, out[41+t] = areas of tier t,
+ * out[51+t] = bytes of an area of tier t (out[51] = the slots'), out[61] = contexts sharing the pool, out[62] = slots
+ * (= workgroups of a batch) of this context. */
 int eh_pool_stats(eh_ctx* ctx, uint64_t* out);
 
 /* Elapsed GPU time of the mutate kernel of the last batch in ms (HIP events on the launch
