@@ -130,6 +130,8 @@ def main():
                     "0 = off (default): every case runs to completion like under the reference's 30 s CLI watchdog")
     ap.add_argument("--pcie", type=int, default=1, help="1: after the timed steps, one extra pass whose outputs are downloaded to pinned host memory "
                     "(reported as 'pcie'); 0: skip")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak (default): every rank runs its own 64 K case numbers per step; "
+                    "strong: a step is ONE run of --cases cases split over the ranks by shard.case_range (erlamsa_main.erl:95-108)")
     ap.add_argument("--inflight", type=int, default=6, help="passes in flight (engine contexts / HIP streams): the tail of a pass — a few "
                     "long single-wavefront cases — overlaps with the bulk of the next ones.  Every context owns its output arena (--out-gib) and its slots "
                     "(--max-slots x --case-mib); larger work areas come from one pool shared by all contexts (--pool-gib)")
@@ -202,13 +204,24 @@ def main():
 
     raw = [st.cuda_stream for st in streams]
     # rank r, step k -> case numbers ((k*world + r) * n) + 1 ... (shard.run_steps, the loop tests/test_dist_gloo.py drives too)
-    shard.run_steps(engines, raw, 0, args.warmup, rank, world, n, seed)
+    strong = args.scaling == "strong"
+    overflow_sites = {}
+    names = [m for m, _, _ in ea.mutator_table()]
+
+    def on_result(k, e):                                      # which capacity check gave up, for the cases that end as EH_CASE_OVERFLOW
+        st = e.status()
+        if (st == 2).any():
+            _, lm = e.diag()
+            for site in (-lm[st == 2]).tolist():
+                overflow_sites[site] = overflow_sites.get(site, 0) + 1
+
+    shard.run_steps(engines, raw, 0, args.warmup, rank, world, n, seed, strong=strong)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    timed = shard.run_steps(engines, raw, args.warmup, args.steps, rank, world, n, seed)
+    timed = shard.run_steps(engines, raw, args.warmup, args.steps, rank, world, n, seed, on_result=on_result, strong=strong)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -263,13 +276,15 @@ def main():
                     "cases_per_s": round(n * bsteps / bdt, 1), "ms_per_step": round(bdt / bsteps * 1e3, 3),
                     "case_status_budget": int(bstat[5]), "case_status_overflow": int(bstat[2])}
 
-    dt_all, out_all, cases_all = shard.reduce_over_ranks(dt, out_bytes, n * args.steps, dist, dev)
+    my_cases = (shard.case_range(n, rank, world)[1] if strong else n) * args.steps
+    dt_all, out_all, cases_all = shard.reduce_over_ranks(dt, out_bytes, my_cases, dist, dev)
 
     if rank == 0:
         mbps = out_all / dt_all / 1e6
-        in_bytes = float(n * size)
+        nloc = shard.case_range(n, rank, world)[1] if strong else n
+        in_bytes = float(nloc * size)
         avg_kern_s = float(np.mean(kern_ms)) / 1e3
-        alg_bytes = in_bytes + out_bytes / args.steps + DESC_BYTES * n       # per launch (this rank)
+        alg_bytes = in_bytes + out_bytes / args.steps + DESC_BYTES * nloc    # per launch (this rank)
         achieved = alg_bytes / avg_kern_s / 1e9
         # HBM-side bytes per launch cannot be measured from inside this process (PMC counters need
         # rocprofv3 around it); the figure of the committed counter run of this same workload is attached
@@ -290,7 +305,7 @@ def main():
             "cases_per_s": round(cases_all / dt_all, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_all / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8 (byte edits) + f64 (AS183 draws)", "data": "synthetic",
             "config": {
                 "workload": "%s: %d seeds x %d B %s, generator direct=500/random=1, patterns %s, "
@@ -308,6 +323,12 @@ def main():
             "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(big_case_bytes)", "unsupported", "arena_full",
                                      "budget(max_case_work; reference analogue: maxrunningtime -> <<>>)"],
                                     [int(x) for x in status_counts])),
+            "overflow_by_capacity_check": {
+                "what": "the EH_CASE_OVERFLOW cases of the timed steps by the check that gave up (EH_SET_OVERFLOW sites in csrc/): 802 = a tree "
+                        "stutter (mutator tr) whose result k^reps x |node| exceeds big_case_bytes — the reference builds the same binary until "
+                        "its 256 MB process guard truncates it (erlamsa_mutations.erl:978-984); 102 = the largest work area is exhausted; "
+                        "103 / 803 = a single result of 4 GiB or more (sr / tree)",
+                "counts": {str(k): v for k, v in sorted(overflow_sites.items())}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ea.load_library().eh_kernel_name().decode(), "kernel_ms_avg": round(avg_kern_s * 1e3, 3),

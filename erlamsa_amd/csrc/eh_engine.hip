@@ -521,6 +521,10 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
   LaneTab lt;
   c.p = pp;
   c.work_budget = p.work_budget;
+#ifdef EH_PROF
+  // how many workgroups the device holds at once: earliest / latest workgroup start of the dispatch (100 MHz wall clock)
+  if (l == 0) { unsigned long long t = __builtin_amdgcn_s_memrealtime(); atomicMin(&pp->prof[2 * 127], t ? t : 1ull); atomicMax(&pp->prof[2 * 127 + 1], t); }
+#endif
   // this workgroup's slot: block tables + work area
   const uint32_t slot_id = blockIdx.x;
   uint8_t* slot = p.slot_base + (uint64_t)slot_id * p.slot_stride;
@@ -744,11 +748,13 @@ struct eh_ctx {
   int64_t* d_seeds = nullptr; uint64_t seeds_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // request coalescing (eh_submit / eh_flush / eh_poll)
-  std::mutex co_lock;
+  std::recursive_mutex co_lock;
+  bool co_internal = false;                             // co_launch / co_collect are calling the batch entry points themselves
   uint64_t co_next_ticket = 1, co_flush_cases = 4096, co_flush_bytes = 64ull << 20;
   std::vector<uint8_t> co_data; std::vector<uint64_t> co_off{0}; std::vector<int64_t> co_seeds; std::vector<uint64_t> co_tickets;   // pending batch
   bool co_inflight = false; std::vector<uint64_t> co_inflight_tickets;                  // launched, results still on the device
   struct CoResult { std::vector<uint8_t> out; int32_t status; };
+  std::vector<uint64_t> co_cancelled;                                                   // in-flight tickets nobody will poll
   std::map<uint64_t, CoResult> co_done;                                                 // downloaded, not polled yet
   hipStream_t last_stream = nullptr;
   uint64_t last_n = 0, last_in_bytes = 0;
@@ -763,6 +769,15 @@ struct eh_ctx {
       return EH_E_HIP;                                                                                \
     }                                                                                                 \
   } while (0)
+
+// A context that has coalesced requests pending or in flight (eh_submit .. eh_poll) belongs to the coalescer: a batch,
+// a corpus or a configuration from outside would overwrite the buffers and options those requests run with.
+#define CO_GUARD(ctx)                                                                                              \
+  std::lock_guard<std::recursive_mutex> co_guard_((ctx)->co_lock);                                                  \
+  if (!(ctx)->co_internal && ((ctx)->co_inflight || !(ctx)->co_tickets.empty())) {                                  \
+    (ctx)->err = "coalesced requests are pending on this context: eh_flush and eh_poll them first, or use a context of its own"; \
+    return EH_E_STATE;                                                                                              \
+  }
 
 namespace {
 
@@ -964,6 +979,9 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   if (rc) return rc;
   if (!ctx->d_counters) { HIPCHK(ctx, hipMalloc(&ctx->d_counters, 4096)); HIPCHK(ctx, hipMalloc(&ctx->d_run, sizeof(RunState))); HIPCHK(ctx, hipMalloc(&ctx->d_params, sizeof(KParams))); }
   HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 4096, st));
+#ifdef EH_PROF
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_counters + 8 + 2 * 127, 0xFF, 8, st));   // earliest workgroup start: atomicMin
+#endif
 
   KParams p;
   memset(&p, 0, sizeof(p));
@@ -1109,6 +1127,7 @@ void eh_destroy(eh_ctx* ctx) {
 int eh_configure(eh_ctx* ctx, const eh_options* o) {
   if (!ctx || !o) return EH_E_INVALID;
   if (o->abi_version != EH_ABI_VERSION) { ctx->err = "eh_options.abi_version mismatch"; return EH_E_INVALID; }
+  CO_GUARD(ctx);
   DevConfig cfg;
   memset(&cfg, 0, sizeof(cfg));
   std::vector<long> mp, pp;
@@ -1172,6 +1191,7 @@ static int set_corpus(eh_ctx* ctx, uint8_t* d, uint64_t* doff, bool own, uint64_
 }
 int eh_corpus_upload(eh_ctx* ctx, const uint8_t* data, const uint64_t* off, uint64_t n) {
   if (!ctx || !off || (!data && off[n] > 0)) return EH_E_INVALID;
+  CO_GUARD(ctx);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   uint64_t nbytes = off[n];
   HIPCHK(ctx, hipDeviceSynchronize());                       // no launch may still read the previous corpus
@@ -1196,6 +1216,7 @@ int eh_corpus_upload(eh_ctx* ctx, const uint8_t* data, const uint64_t* off, uint
 }
 int eh_corpus_attach(eh_ctx* ctx, const void* d_data, const void* d_off, uint64_t n, uint64_t nbytes) {
   if (!ctx || !d_off) return EH_E_INVALID;
+  CO_GUARD(ctx);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->h_coff.resize(n + 1);
   HIPCHK(ctx, hipMemcpy(ctx->h_coff.data(), d_off, (n + 1) * 8, hipMemcpyDeviceToHost));
@@ -1211,10 +1232,12 @@ int eh_reserve(eh_ctx* ctx, uint64_t max_cases) {
 
 int eh_fuzz_batch(eh_ctx* ctx, const int64_t seed[3], uint64_t first_case, uint64_t corpus_first, uint64_t n, void* stream) {
   if (!ctx || !seed) return EH_E_INVALID;
+  CO_GUARD(ctx);
   return launch(ctx, 0, seed, first_case, corpus_first, n, (hipStream_t)stream);
 }
 int eh_fuzz_calls(eh_ctx* ctx, const int64_t* seeds, uint64_t corpus_first, uint64_t n, void* stream) {
   if (!ctx || !seeds) return EH_E_INVALID;
+  CO_GUARD(ctx);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (n > ctx->seeds_cap) {
     if (ctx->d_seeds) (void)hipFree(ctx->d_seeds);
@@ -1235,13 +1258,18 @@ static int co_collect(eh_ctx* ctx) {
   int rc = eh_result_totals(ctx, &in_b, &out_b, &nc);
   if (rc) return rc;
   const uint64_t n = ctx->co_inflight_tickets.size();
+  if (nc != n) { ctx->err = "coalescer: the context's last batch is not the one that was flushed"; return EH_E_STATE; }
   std::vector<uint8_t> data(out_b ? out_b : 1); std::vector<uint64_t> off(n + 1); std::vector<int32_t> st(n ? n : 1);
   rc = eh_result_download(ctx, data.data(), data.size(), off.data(), st.data());
   if (rc) return rc;
   for (uint64_t i = 0; i < n; i++) {
+    bool dropped = false;
+    for (uint64_t t : ctx->co_cancelled) if (t == ctx->co_inflight_tickets[i]) dropped = true;
+    if (dropped) continue;
     eh_ctx::CoResult r; r.out.assign(data.begin() + off[i], data.begin() + off[i + 1]); r.status = st[i];
     ctx->co_done.emplace(ctx->co_inflight_tickets[i], std::move(r));
   }
+  ctx->co_cancelled.clear();
   ctx->co_inflight = false; ctx->co_inflight_tickets.clear();
   return EH_OK;
 }
@@ -1251,8 +1279,10 @@ static int co_launch(eh_ctx* ctx) {
   int rc = co_collect(ctx);
   if (rc) return rc;
   const uint64_t n = ctx->co_tickets.size();
+  ctx->co_internal = true;
   rc = eh_corpus_upload(ctx, ctx->co_data.data(), ctx->co_off.data(), n);
   if (!rc) rc = eh_fuzz_calls(ctx, ctx->co_seeds.data(), 0, n, nullptr);
+  ctx->co_internal = false;
   if (rc) return rc;
   ctx->co_inflight = true; ctx->co_inflight_tickets.swap(ctx->co_tickets);
   ctx->co_tickets.clear(); ctx->co_data.clear(); ctx->co_off.assign(1, 0); ctx->co_seeds.clear();
@@ -1260,32 +1290,55 @@ static int co_launch(eh_ctx* ctx) {
 }
 int eh_coalesce_limits(eh_ctx* ctx, uint64_t flush_cases, uint64_t flush_bytes) {
   if (!ctx || !flush_cases || !flush_bytes) return EH_E_INVALID;
-  std::lock_guard<std::mutex> g(ctx->co_lock);
+  std::lock_guard<std::recursive_mutex> g(ctx->co_lock);
   ctx->co_flush_cases = flush_cases; ctx->co_flush_bytes = flush_bytes;
   return EH_OK;
 }
 int eh_submit(eh_ctx* ctx, const uint8_t* data, uint64_t len, const int64_t seed[3], uint64_t* ticket) {
   if (!ctx || !seed || !ticket || (!data && len)) return EH_E_INVALID;
   if (!ctx->configured) { ctx->err = "configure first"; return EH_E_STATE; }
-  std::lock_guard<std::mutex> g(ctx->co_lock);
+  std::lock_guard<std::recursive_mutex> g(ctx->co_lock);
+  const size_t d0 = ctx->co_data.size(), o0 = ctx->co_off.size(), s0 = ctx->co_seeds.size(), t0 = ctx->co_tickets.size();
+  auto rollback = [&]() { ctx->co_data.resize(d0); ctx->co_off.resize(o0); ctx->co_seeds.resize(s0); ctx->co_tickets.resize(t0); };
   try {
     ctx->co_data.insert(ctx->co_data.end(), data, data + len);
     ctx->co_off.push_back(ctx->co_data.size());
     ctx->co_seeds.insert(ctx->co_seeds.end(), seed, seed + 3);
     ctx->co_tickets.push_back(ctx->co_next_ticket);
-  } catch (const std::bad_alloc&) { return EH_E_NOMEM; }
+  } catch (const std::bad_alloc&) { rollback(); return EH_E_NOMEM; }
+  if (ctx->co_tickets.size() >= ctx->co_flush_cases || ctx->co_data.size() >= ctx->co_flush_bytes) {
+    int rc = co_launch(ctx);
+    // a launch that fails takes this request back out (the caller gets no ticket for it); the others stay queued for the next flush
+    if (rc) { if (!ctx->co_tickets.empty()) rollback(); return rc; }
+  }
   *ticket = ctx->co_next_ticket++;
-  if (ctx->co_tickets.size() >= ctx->co_flush_cases || ctx->co_data.size() >= ctx->co_flush_bytes) return co_launch(ctx);
   return EH_OK;
+}
+int eh_cancel(eh_ctx* ctx, uint64_t ticket) {
+  if (!ctx) return EH_E_INVALID;
+  std::lock_guard<std::recursive_mutex> g(ctx->co_lock);
+  if (ctx->co_done.erase(ticket)) return EH_OK;
+  for (size_t i = 0; i < ctx->co_tickets.size(); i++) if (ctx->co_tickets[i] == ticket) {      // not launched yet: leaves the batch
+    const uint64_t a = ctx->co_off[i], b = ctx->co_off[i + 1];
+    ctx->co_data.erase(ctx->co_data.begin() + a, ctx->co_data.begin() + b);
+    ctx->co_off.erase(ctx->co_off.begin() + i + 1);
+    for (size_t k = i + 1; k < ctx->co_off.size(); k++) ctx->co_off[k] -= b - a;
+    ctx->co_seeds.erase(ctx->co_seeds.begin() + 3 * i, ctx->co_seeds.begin() + 3 * i + 3);
+    ctx->co_tickets.erase(ctx->co_tickets.begin() + i);
+    return EH_OK;
+  }
+  for (uint64_t t : ctx->co_inflight_tickets) if (t == ticket) { ctx->co_cancelled.push_back(ticket); return EH_OK; }   // dropped when the batch is collected
+  ctx->err = "unknown or already consumed ticket";
+  return EH_E_INVALID;
 }
 int eh_flush(eh_ctx* ctx) {
   if (!ctx) return EH_E_INVALID;
-  std::lock_guard<std::mutex> g(ctx->co_lock);
+  std::lock_guard<std::recursive_mutex> g(ctx->co_lock);
   return co_launch(ctx);
 }
 int eh_poll(eh_ctx* ctx, uint64_t ticket, uint8_t* out, uint64_t cap, uint64_t* out_len, int32_t* status) {
   if (!ctx || !out_len || !status) return EH_E_INVALID;
-  std::lock_guard<std::mutex> g(ctx->co_lock);
+  std::lock_guard<std::recursive_mutex> g(ctx->co_lock);
   auto it = ctx->co_done.find(ticket);
   if (it == ctx->co_done.end()) {
     for (uint64_t t : ctx->co_tickets) if (t == ticket) return EH_E_AGAIN;

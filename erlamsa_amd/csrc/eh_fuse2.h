@@ -77,59 +77,99 @@ __device__ __noinline__ void fb_bits0(const uint8_t* S, uint32_t len, uint32_t* 
   wave_sync();
 }
 
-// Children of one round: RK[w] = {MA[w] & MB[w], children before word w}; returns the number of children.  A source
-// group that is [] (its only member was the dropped one) is a child whatever the target side holds: force_bit in
-// word force_w; *special = its index.  Lane l owns 16 consecutive words of every 1024-word step (one shuffle scan per
-// step, 4 + 4 vector loads in flight).
-__device__ __noinline__ uint32_t fb_scan(const uint32_t* MA, const uint32_t* MB, uint32_t nwords, uint32_t force_w, uint32_t force_bit, RkWord* RK, uint32_t* special) {
+// A node's next bytes are recorded in two levels (fb_pass, INS 3): N1[node] = 0 (none yet), byte' + 1 (exactly one
+// byte so far), FB_MULTI (several: they are in the node's bitmap row).  On repetitive data — where the large blocks come
+// from: sr, lr, tr and sgm pumps — a k-gram nearly always has ONE continuation, so a position touches a 4-byte entry
+// (sixteen nodes to a cache line) instead of a 32-byte row, and the rows of single-byte nodes are never written.
+constexpr uint32_t FB_MULTI = 0xFFFFFFFFu;
+// The lookup side of the same idea: SC[node] = {mask, prefix | word << 24 | kind << 28}, kind 0: no child, 1: all
+// children in ONE mask word (the entry is the whole answer), 2: several words — see RK.
+struct ScEnt { uint32_t mask, meta; };
+
+// the eight mask words of `node` (bitmap row, or decoded from N1), and the tables left ZERO for the next generation
+EH_DEV void fb_row(uint32_t* M, uint32_t* N1, uint32_t node, bool valid, uint32_t w[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) w[k] = 0;
+  if (!valid) return;
+  uint32_t* row = M + 8u * node;
+  bool full = true;
+  if (N1) {
+    uint32_t n1 = fb_ld(&N1[node]);
+    full = n1 == FB_MULTI;
+    if (n1 != 0) N1[node] = 0;
+    if (!full && n1 != 0) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) if ((uint32_t)k == ((n1 - 1u) >> 5)) w[k] = 1u << ((n1 - 1u) & 31u);
+    }
+  }
+  if (full) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = fb_ld(row + k);
+    uint4 z; z.x = z.y = z.z = z.w = 0;
+    *reinterpret_cast<uint4*>(row) = z; *reinterpret_cast<uint4*>(row + 4) = z;
+  }
+}
+
+// Children of one round: RK[w] = {MA[w] & MB[w], children before word w} and SC[node]; returns the number of children,
+// *nfull = nodes whose children spread over several mask words.  A source group that is [] (its only member was the
+// dropped one) is a child whatever the target side holds: force_bit in word force_w; *special = its index.  Lane l owns
+// two nodes (16 consecutive words) of every 128-node step.  The bitmap rows and N1 entries it reads are zeroed: the
+// tables of a generation are clean when the next one starts to fill them.
+__device__ __noinline__ uint32_t fb_scan(uint32_t* MA, uint32_t* MB, uint32_t* N1A, uint32_t* N1B, uint32_t nwords, uint32_t force_w, uint32_t force_bit,
+                                         RkWord* RK, ScEnt* SC, uint32_t* special, uint32_t* nfull) {
   const uint32_t l = (uint32_t)EH_LANE;
-  uint32_t running = 0, sp = FB_DEAD;
+  uint32_t running = 0, sp = FB_DEAD, full = 0;
   for (uint32_t base = 0; base < nwords; base += 1024) {
     const uint32_t w0 = base + 16u * l;
     uint32_t m[16];
-    uint4 va[4], vb[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      uint4 z; z.x = z.y = z.z = z.w = 0; va[u] = z; vb[u] = z;
-      if (w0 + 4u * u < nwords) {                                  // (word by word: bitmap words are read at L2, see fb_ld)
-        const uint32_t* a = MA + w0 + 4 * u; va[u].x = fb_ld(a); va[u].y = fb_ld(a + 1); va[u].z = fb_ld(a + 2); va[u].w = fb_ld(a + 3);
-        if (MB) { const uint32_t* b = MB + w0 + 4 * u; vb[u].x = fb_ld(b); vb[u].y = fb_ld(b + 1); vb[u].z = fb_ld(b + 2); vb[u].w = fb_ld(b + 3); }
+    for (int h = 0; h < 2; h++) {
+      const uint32_t node = (w0 >> 3) + (uint32_t)h;
+      const bool valid = node * 8u < nwords;
+      uint32_t a[8], b[8];
+      fb_row(MA, N1A, node, valid, a);
+      if (MB) fb_row(MB, N1B, node, valid, b);
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        uint32_t v = MB ? (a[k] & b[k]) : a[k];
+        if (node * 8u + (uint32_t)k == force_w) v |= force_bit;
+        m[8 * h + k] = v;
       }
     }
     uint32_t cnt = 0;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      uint32_t a4[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, b4[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        uint32_t w = w0 + 4u * u + k;
-        uint32_t v = MB ? (a4[k] & b4[k]) : a4[k];
-        if (w == force_w) v |= force_bit;
-        m[4 * u + k] = v; cnt += (uint32_t)__popc(v);
-      }
-    }
+    for (int k = 0; k < 16; k++) cnt += (uint32_t)__popc(m[k]);
     uint32_t inc = wave_incl_scan(cnt);
     uint32_t ex = running + inc - cnt;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (w0 + 4u * u < nwords) {
-        uint32_t pre[4];
+    for (int h = 0; h < 2; h++) {
+      const uint32_t node = (w0 >> 3) + (uint32_t)h;
+      if (node * 8u < nwords) {
+        uint32_t pre[8], nz = 0, wsel = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 8; k++) {
           pre[k] = ex;
-          if (w0 + 4u * u + k == force_w && force_bit) sp = ex + (uint32_t)__popc(m[4 * u + k] & (force_bit - 1u));
-          ex += (uint32_t)__popc(m[4 * u + k]);
+          if (node * 8u + (uint32_t)k == force_w && force_bit) sp = ex + (uint32_t)__popc(m[8 * h + k] & (force_bit - 1u));
+          if (m[8 * h + k]) { nz++; wsel = (uint32_t)k; }
+          ex += (uint32_t)__popc(m[8 * h + k]);
         }
-        uint4 s0, s1;
-        s0.x = m[4 * u]; s0.y = pre[0]; s0.z = m[4 * u + 1]; s0.w = pre[1];
-        s1.x = m[4 * u + 2]; s1.y = pre[2]; s1.z = m[4 * u + 3]; s1.w = pre[3];
-        *reinterpret_cast<uint4*>(RK + w0 + 4 * u) = s0;
-        *reinterpret_cast<uint4*>(RK + w0 + 4 * u + 2) = s1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          uint4 s0; s0.x = m[8 * h + 2 * q]; s0.y = pre[2 * q]; s0.z = m[8 * h + 2 * q + 1]; s0.w = pre[2 * q + 1];
+          *reinterpret_cast<uint4*>(RK + node * 8u + 2 * q) = s0;
+        }
+        ScEnt e; e.mask = 0; e.meta = 0;
+        if (nz == 1) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) if ((uint32_t)k == wsel) { e.mask = m[8 * h + k]; e.meta = pre[k] | (wsel << 24) | (1u << 28); }
+        } else if (nz > 1) { e.meta = 2u << 28; full++; }
+        SC[node] = e;
       }
     }
     running += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
   }
   *special = wave_min(sp);
+  *nfull = wave_sum(full);
   wave_sync();
   return running;
 }
@@ -141,14 +181,15 @@ EH_DEV uint64_t fb_ld8(const uint8_t* S, uint32_t q, uint32_t len) {
   else { for (uint32_t k = 0; k < 5; k++) if (q + k < len) by |= (uint64_t)S[q + k] << (8 * k); }
   return by;
 }
-// One streaming pass over the suffixes of one side: id_{g+1} from id_g (g == 0: every suffix is in node 0) through RK,
-// and, when Mn != nullptr, the bitmap of the NEXT round (every live member of generation g+1 that is not empty and not
-// the member at len-1).  kill: target members that fall into the special child; e_pos/e_kill: the member at len-1 of
+// One streaming pass over the suffixes of one side: id_{g+1} from id_g (g == 0: every suffix is in node 0) through SC / RK,
+// and, when Mn != nullptr, the next-byte table of the NEXT round (every live member of generation g+1 that is not empty and
+// not the member at len-1).  kill: target members that fall into the special child; e_pos/e_kill: the member at len-1 of
 // THIS round and whether it leaves its group.  Returns the number of live members of generation g+1.
 // A lone wavefront is bound by memory round trips, not by bytes: 1024 positions per step (16 per lane), the ids and
-// bytes of the NEXT step are requested before this step's 16 RK gathers, so a step costs about one round trip.
-template <int MODE>   // how the next bitmap is written: 0 global atomics, 1 LDS atomics, 2 global, test (at L2) before the atomic
-__device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_t* ids, uint32_t g, const RkWord* RK, uint32_t kill, uint32_t e_pos, bool e_kill, uint32_t* Mn) {
+// bytes of the NEXT step are requested before this step's 16 lookups, and every kind of access of a step (lookups,
+// tests of the next table) is issued as one batch, so a step costs a few round trips.
+template <int INS>   // how the next table is written: 0 bitmap, global atomics; 1 bitmap in LDS; 2 bitmap, test (at L2) before the atomic; 3 N1 + bitmap rows
+__device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_t* ids, uint32_t g, const RkWord* RK, const ScEnt* SC, uint32_t kill, uint32_t e_pos, bool e_kill, uint32_t* Mn, uint32_t* N1n) {
   const uint32_t l = (uint32_t)EH_LANE;
   constexpr int U = 4;
   uint32_t alive = 0;
@@ -168,23 +209,52 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
       if (p < len) { if (g > 0) nidv[u] = *reinterpret_cast<const uint4*>(ids + p); nbyv[u] = fb_ld8(S, p + g, len); }
     }
     RkWord rk[U][4];
+    if (SC) {                                                      // compact entries first, rows only for the nodes that need them
+      ScEnt sc[U][4];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const uint32_t p = base + 256u * u + 4u * l;
-      const uint32_t o[4] = {idv[u].x, idv[u].y, idv[u].z, idv[u].w};
+      for (int u = 0; u < U; u++) {
+        const uint32_t p = base + 256u * u + 4u * l;
+        const uint32_t o[4] = {idv[u].x, idv[u].y, idv[u].z, idv[u].w};
 #pragma unroll
-      for (uint32_t k = 0; k < 4; k++) {
-        const bool ok = p + k + g < len && o[k] != FB_DEAD;        // (positions past the end have id 0: p + k + g < len excludes them)
-        const uint32_t b = fb_tr((uint32_t)(byv[u] >> (8 * k)) & 255u, g);
-        RkWord r; r.mask = 0; r.prefix = 0;
-        if (ok) r = RK[o[k] * 8u + (b >> 5)];
-        rk[u][k] = r;                                              // mask 0: not a member of any child
+        for (uint32_t k = 0; k < 4; k++) {
+          const bool ok = p + k + g < len && o[k] != FB_DEAD;
+          ScEnt e; e.mask = 0; e.meta = 0;
+          if (ok) e = SC[o[k]];
+          sc[u][k] = e;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t o[4] = {idv[u].x, idv[u].y, idv[u].z, idv[u].w};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+          const uint32_t b = fb_tr((uint32_t)(byv[u] >> (8 * k)) & 255u, g);
+          const uint32_t kind = sc[u][k].meta >> 28;
+          RkWord r; r.mask = 0; r.prefix = 0;
+          if (kind == 1u && (b >> 5) == ((sc[u][k].meta >> 24) & 7u)) { r.mask = sc[u][k].mask; r.prefix = sc[u][k].meta & 0xFFFFFFu; }
+          if (kind == 2u) r = RK[o[k] * 8u + (b >> 5)];
+          rk[u][k] = r;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t p = base + 256u * u + 4u * l;
+        const uint32_t o[4] = {idv[u].x, idv[u].y, idv[u].z, idv[u].w};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+          const bool ok = p + k + g < len && o[k] != FB_DEAD;      // (positions past the end have id 0: p + k + g < len excludes them)
+          const uint32_t b = fb_tr((uint32_t)(byv[u] >> (8 * k)) & 255u, g);
+          RkWord r; r.mask = 0; r.prefix = 0;
+          if (ok) r = RK[o[k] * 8u + (b >> 5)];
+          rk[u][k] = r;                                            // mask 0: not a member of any child
+        }
       }
     }
-    // new ids first, then (MODE 2) the 16 bitmap tests of the step as ONE batch of loads, then the atomics that are still
-    // needed: tested one after the other behind their branches, every test was a memory round trip of its own and a step
-    // cost sixteen of them (4.4 M cycles per pass in the bench workload's profile, 36 % of all wave cycles).
-    uint32_t w2v[U][4], bit2v[U][4];
+    // new ids first, then the tests of the next table as ONE batch of loads, then the atomics that are still needed:
+    // tested one after the other behind their branches, every test was a memory round trip of its own and a step cost
+    // sixteen of them (4.4 M cycles per pass in the bench workload's profile, 36 % of all wave cycles).
+    uint32_t w2v[U][4], bit2v[U][4], nidn[U][4];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint32_t p = base + 256u * u + 4u * l;
@@ -198,19 +268,41 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
         if (rk[u][k].mask & bit) nid = rk[u][k].prefix + (uint32_t)__popc(rk[u][k].mask & (bit - 1u));
         if (nid == kill || (pos == e_pos && e_kill)) nid = FB_DEAD;
         nw[k] = nid;
-        w2v[u][k] = 0; bit2v[u][k] = 0;                            // bit2 == 0: nothing to set
+        w2v[u][k] = 0; bit2v[u][k] = 0; nidn[u][k] = 0;            // bit2 == 0: nothing to set
         if (nid != FB_DEAD) {
           alive++;
           if (Mn && pos + g + 2 < len) {
             uint32_t b2 = fb_tr((uint32_t)(byv[u] >> (8 * k + 8)) & 255u, g + 1);
-            w2v[u][k] = nid * 8u + (b2 >> 5); bit2v[u][k] = 1u << (b2 & 31u);
+            w2v[u][k] = nid * 8u + (b2 >> 5); bit2v[u][k] = 1u << (b2 & 31u); nidn[u][k] = nid;
           }
         }
       }
       if (p < len) { uint4 v; v.x = nw[0]; v.y = nw[1]; v.z = nw[2]; v.w = nw[3]; *reinterpret_cast<uint4*>(ids + p) = v; }
     }
     if (Mn) {
-      if (MODE == 2) {
+      if (INS == 3) {
+        uint32_t have[U][4];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (uint32_t k = 0; k < 4; k++) have[u][k] = fb_ld(&N1n[nidn[u][k]]);     // (entry 0 for the lanes with nothing to set)
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (uint32_t k = 0; k < 4; k++) {
+            if (!bit2v[u][k]) continue;
+            const uint32_t key = ((w2v[u][k] & 7u) << 5) + (uint32_t)__builtin_ctz(bit2v[u][k]) + 1u;     // byte' + 1
+            uint32_t old = have[u][k];
+            if (old == key) continue;
+            if (old == 0) old = atomicCAS(&N1n[nidn[u][k]], 0u, key);
+            if (old == 0 || old == key) continue;
+            if (old != FB_MULTI) {                                 // a second byte under this node: both go to its bitmap row
+              atomicOr(&Mn[nidn[u][k] * 8u + ((old - 1u) >> 5)], 1u << ((old - 1u) & 31u));
+              atomicExch(&N1n[nidn[u][k]], FB_MULTI);
+            }
+            atomicOr(&Mn[w2v[u][k]], bit2v[u][k]);
+          }
+      } else if (INS == 2) {
         uint32_t have[U][4];
 #pragma unroll
         for (int u = 0; u < U; u++)
@@ -224,7 +316,7 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
-          for (uint32_t k = 0; k < 4; k++) if (bit2v[u][k]) { if (MODE == 1) atomicOr(&g_fuse_lds[w2v[u][k]], bit2v[u][k]); else atomicOr(&Mn[w2v[u][k]], bit2v[u][k]); }
+          for (uint32_t k = 0; k < 4; k++) if (bit2v[u][k]) { if (INS == 1) atomicOr(&g_fuse_lds[w2v[u][k]], bit2v[u][k]); else atomicOr(&Mn[w2v[u][k]], bit2v[u][k]); }
       }
     }
 #pragma unroll
@@ -275,6 +367,24 @@ __device__ __noinline__ uint32_t fb_find(const uint32_t* ids, uint32_t len, uint
   return len;
 }
 
+// The member at len-1 of a round: records its (node, byte') in the next-byte tables of the current generation and tells
+// whether another member had put it there already (then it is not alone in its group).
+EH_DEV uint32_t fb_end_member(uint32_t* M, uint32_t* N1, uint32_t id, uint32_t b) {
+  uint32_t was = 0;
+  if (EH_LANE == 0) {
+    const uint32_t w = id * 8u + (b >> 5), bit = 1u << (b & 31u), key = b + 1u;
+    if (!N1) was = (atomicOr(&M[w], bit) & bit) ? 1u : 0u;
+    else {
+      const uint32_t n1 = fb_ld(&N1[id]);
+      if (n1 == key) was = 1u;
+      else if (n1 == 0) (void)atomicExch(&N1[id], key);
+      else if (n1 == FB_MULTI) was = (atomicOr(&M[w], bit) & bit) ? 1u : 0u;
+      else { (void)atomicOr(&M[id * 8u + ((n1 - 1u) >> 5)], 1u << ((n1 - 1u) & 31u)); (void)atomicOr(&M[w], bit); (void)atomicExch(&N1[id], FB_MULTI); }
+    }
+  }
+  return uni(was);
+}
+
 // find_jump_points/2 + any_position_pair/1: *from / *tpos = the positions jump/3 (:47-50) cuts at.  Same draws, same fuel,
 // same work accounting as fuse_lists' node-list version (eh_fuse.h).  false: work area exhausted / budget.
 __device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, bool sym, uint32_t* from, uint32_t* tpos, uint32_t* rounds) {
@@ -282,15 +392,17 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t l
   const uint32_t l = (uint32_t)EH_LANE;
   uint32_t* ids[2] = {nullptr, nullptr};
   uint32_t* M[2] = {nullptr, nullptr};
-  RkWord* RK = nullptr;
-  uint32_t rk_rows = 0, m_rows = 0;                                // nodes RK / M[] have room for
+  uint32_t* N1[2] = {nullptr, nullptr};
+  RkWord* RK = nullptr; ScEnt* SC = nullptr;
+  uint32_t rk_rows = 0, m_rows = 0;                                // nodes RK + SC / M[] + N1[] have room for
   const uint8_t* S[2] = {A, B};
   const uint32_t len[2] = {la, lb};
   const int nside = sym ? 1 : 2;
   uint32_t nn = 1, g = 0;                                          // nodes of generation g
   int64_t fuel = 100000;                                           // ?SEARCH_FUEL
   uint64_t gen_entries = (uint64_t)la + lb;
-  bool have_bits = false;                                          // M holds the bitmap of generation g
+  bool have_bits = false;                                          // M holds the next bytes of generation g
+  bool cur_n1 = false;                                             // ... in two levels (N1 + rows of the nodes with several bytes)
   EH_PT0;
   uint32_t special_node = FB_DEAD;                                 // generation g's {[[]], [[]]} node (two distinct lists only)
   while (true) {                                                   // find_jump_points_loop (:115-128)
@@ -302,18 +414,25 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t l
     }
     // Tables grow with the generations (n_g <= 256 n_{g-1}, and the fuel keeps n_g <= 100 000): a table that has become
     // too small is left behind and a larger one allocated — what is left behind is a fraction of what replaces it.  Sizing
-    // everything for 100 000 nodes up front made every fuse of a block of 100 KB and more ask for 13 to 21 MB.
+    // everything for 100 000 nodes up front made every fuse of a block of 100 KB and more ask for 13 to 21 MB.  The
+    // next-byte tables (M, N1) are zero when they are allocated and fb_scan leaves zero what it has read.
     if (!ids[0]) {
       for (int s = 0; s < nside; s++) { ids[s] = (uint32_t*)ws_alloc(c, ((uint64_t)len[s] + 8) * 4); if (!ids[s]) return false; }
     }
     if (nn > rk_rows) {
       rk_rows = nn < 1024u ? 1024u : nn;
       RK = (RkWord*)ws_alloc(c, ((uint64_t)rk_rows + 4) * 64);
-      if (!RK) return false;
+      SC = (ScEnt*)ws_alloc(c, ((uint64_t)rk_rows + 4) * 8);
+      if (!RK || !SC) return false;
     }
-    if (nn > m_rows) {                                             // (only generation 0 comes here: later bitmaps are sized below)
+    if (nn > m_rows) {                                             // (only generation 0 comes here: later tables are sized below)
       m_rows = nn < 1024u ? 1024u : nn;
-      for (int s = 0; s < nside; s++) { M[s] = (uint32_t*)ws_alloc(c, ((uint64_t)m_rows + 4) * 32); if (!M[s]) return false; }
+      for (int s = 0; s < nside; s++) {
+        M[s] = (uint32_t*)ws_alloc(c, ((uint64_t)m_rows + 4) * 32); N1[s] = (uint32_t*)ws_alloc(c, ((uint64_t)m_rows + 8) * 4);
+        if (!M[s] || !N1[s]) return false;
+        fb_clear(M[s], (m_rows + 4) * 8u); fb_clear(N1[s], (m_rows + 8u) & ~3u);
+      }
+      wave_sync();
     }
     const uint32_t nwords = nn * 8u;
     EH_PT(c, 100);
@@ -328,48 +447,54 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t l
       if (id == FB_DEAD) continue;
       uint32_t b = fb_tr(uni(S[s][len[s] - 1]), g);
       e_pos[s] = ep; e_w[s] = id * 8u + (b >> 5); e_bit[s] = 1u << (b & 31u);
-      uint32_t old = 0;
-      if (l == 0) old = atomicOr(&M[s][e_w[s]], e_bit[s]);
-      e_alone[s] = (uni(old) & e_bit[s]) ? 0u : 1u;
+      e_alone[s] = fb_end_member(M[s], cur_n1 ? N1[s] : nullptr, id, b) ? 0u : 1u;
     }
     wave_sync();
     EH_PT(c, 102);
     // ---- children
     const bool forced = !sym && e_pos[0] != FB_DEAD && e_alone[0];
-    uint32_t sp = FB_DEAD;
-    uint32_t nchild = fb_scan(M[0], sym ? nullptr : M[1], nwords, forced ? e_w[0] : FB_DEAD, forced ? e_bit[0] : 0u, RK, &sp);
+    uint32_t sp = FB_DEAD, nfull = 0;
+    uint32_t nchild = fb_scan(M[0], sym ? nullptr : M[1], cur_n1 ? N1[0] : nullptr, (cur_n1 && !sym) ? N1[1] : nullptr, nwords,
+                              forced ? e_w[0] : FB_DEAD, forced ? e_bit[0] : 0u, RK, SC, &sp, &nfull);
     EH_PT(c, 103);
     if (nchild == 0) break;                                        // NoDesp =:= [] -> any_position_pair(Nodes)
-    // ---- commit: ids of generation g+1 (+ the bitmap of the next round when it is going to run)
+    // ---- commit: ids of generation g+1 (+ the next-byte tables of the next round when it is going to run)
     fuel -= (int64_t)nchild;
     const bool next = fuel >= 0 && (uint32_t)(rng_peek(c.rng, 1) * 8.0) != 0;
     const bool lds = next && nchild * 8u <= FB_LDS_WORDS;
-    if (next && nchild > m_rows) {                                 // the next generation's bitmaps (this one's are in RK now)
+    // two-level tables when the nodes of this round had two children on average at most: low-entropy data, where the node
+    // counts stay small over many rounds; lookups through the compact entries when few nodes spread over several words
+    const bool n1 = next && !lds && nchild <= 2u * nn;
+    const ScEnt* look = nfull * 4u <= nn ? SC : nullptr;
+    if (next && nchild > m_rows) {                                 // the next generation's tables (this one's are in RK now)
       m_rows = nchild;
-      for (int s = 0; s < nside; s++) { M[s] = (uint32_t*)ws_alloc(c, ((uint64_t)m_rows + 4) * 32); if (!M[s]) return false; }
+      for (int s = 0; s < nside; s++) {
+        M[s] = (uint32_t*)ws_alloc(c, ((uint64_t)m_rows + 4) * 32); N1[s] = (uint32_t*)ws_alloc(c, ((uint64_t)m_rows + 8) * 4);
+        if (!M[s] || !N1[s]) return false;
+        fb_clear(M[s], (m_rows + 4) * 8u); fb_clear(N1[s], (m_rows + 8u) & ~3u);
+      }
+      wave_sync();
     }
     uint64_t entries = 0;
     for (int s = 0; s < nside; s++) {
-      if (next) {
-        if (lds) { for (uint32_t i = l; i < nchild * 8u; i += 64) g_fuse_lds[i] = 0; lanes_sync(); }
-        else { fb_clear(M[s], nchild * 8u); wave_sync(); }
-      }
+      if (lds) { for (uint32_t i = l; i < nchild * 8u; i += 64) g_fuse_lds[i] = 0; lanes_sync(); }
       EH_PT(c, 104);
       // the member at len-1: leaves when it was inserted first (alone, or an odd generation).  One list on both sides:
       // alone = the special node = the member itself, now empty, so it stays.
       bool ek = sym ? (!e_alone[0] && (g & 1u)) : (e_alone[s] || (g & 1u));
       uint32_t kill = (s == 1 && forced) ? sp : FB_DEAD;
-      uint32_t alive = lds ? fb_pass<1>(S[s], len[s], ids[s], g, RK, kill, e_pos[s], ek, M[s])
-                           : (next && nchild * 8u <= FB_TEST_WORDS) ? fb_pass<2>(S[s], len[s], ids[s], g, RK, kill, e_pos[s], ek, M[s])
-                           : fb_pass<0>(S[s], len[s], ids[s], g, RK, kill, e_pos[s], ek, next ? M[s] : nullptr);
+      uint32_t alive = lds ? fb_pass<1>(S[s], len[s], ids[s], g, RK, look, kill, e_pos[s], ek, M[s], nullptr)
+                     : n1 ? fb_pass<3>(S[s], len[s], ids[s], g, RK, look, kill, e_pos[s], ek, M[s], N1[s])
+                     : (next && nchild * 8u <= FB_TEST_WORDS) ? fb_pass<2>(S[s], len[s], ids[s], g, RK, look, kill, e_pos[s], ek, M[s], nullptr)
+                     : fb_pass<0>(S[s], len[s], ids[s], g, RK, look, kill, e_pos[s], ek, next ? M[s] : nullptr, nullptr);
       entries += alive;
-      EH_PT(c, lds ? 105 : (next ? (nchild * 8u <= FB_TEST_WORDS ? 110 : 106) : 107));
+      EH_PT(c, lds ? 105 : (n1 ? 111 : (next ? (nchild * 8u <= FB_TEST_WORDS ? 110 : 106) : 107)));
       if (lds) { lanes_sync(); for (uint32_t i = l; i < nchild * 8u; i += 64) M[s][i] = g_fuse_lds[i]; wave_sync(); }
     }
     if (sym) entries *= 2; else if (forced) entries += 2;
     gen_entries = entries;
     special_node = forced ? sp : FB_DEAD;
-    nn = nchild; g++; have_bits = next;
+    nn = nchild; g++; have_bits = next; cur_n1 = n1;
     EH_PT(c, 108);
     (*rounds)++;
   }

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "eh_last_kernel_ms", "eh_pool_stats", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
-    "eh_coalesce_limits", "eh_submit", "eh_flush", "eh_poll",
+    "eh_coalesce_limits", "eh_submit", "eh_flush", "eh_poll", "eh_cancel",
 ]
 
 
@@ -85,6 +85,7 @@ def load_library():
     lib.eh_coalesce_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
     lib.eh_submit.argtypes = [vp, vp, C.c_uint64, i64p, u64p]
     lib.eh_flush.argtypes = [vp]
+    lib.eh_cancel.argtypes = [vp, C.c_uint64]
     lib.eh_poll.argtypes = [vp, C.c_uint64, vp, C.c_uint64, u64p, C.POINTER(C.c_int32)]
     lib.eh_kernel_name.restype = C.c_char_p
     lib.eh_abi_version.restype = C.c_uint32
@@ -308,6 +309,10 @@ class Engine:
 
     def flush(self):
         self._chk(self.lib.eh_flush(self.h))
+
+    def cancel(self, ticket):
+        """Gives a ticket up (its result is dropped / freed)."""
+        self._chk(self.lib.eh_cancel(self.h, ticket))
 
     def poll(self, ticket, cap=1 << 16):
         """-> (status, bytes), or None while the request has not been launched (EH_E_AGAIN)"""

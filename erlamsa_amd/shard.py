@@ -36,11 +36,12 @@ def rank_env(env=None):
     return int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1")), int(env.get("LOCAL_RANK", "0"))
 
 
-def run_steps(engines, streams, first_step, steps, rank, world, n, seed, on_result=None):
+def run_steps(engines, streams, first_step, steps, rank, world, n, seed, on_result=None, strong=False):
     """The step loop of bench.py (and of tests/test_dist_gloo.py): step k of this rank is one eh_fuzz_batch over the
     whole attached corpus with case numbers weak_first_case(k, rank, world, n).., on context k % len(engines) and that
-    context's stream; a context's previous results are collected before it is reused.  `streams` are raw stream handles
-    (0 = the null stream).  Returns {"out_bytes", "kernel_ms": [...], "status_counts": int64[6]}; `on_result(step,
+    context's stream (strong=True: step k is ONE run of n cases over all ranks — this rank takes case_range(n, rank, world)
+    of it, the shape of erlamsa_main:get_threading_mode/3); a context's previous results are collected before it is reused.
+    `streams` are raw stream handles (0 = the null stream).  Returns {"out_bytes", "kernel_ms": [...], "status_counts": int64[6]}; `on_result(step,
     engine)` is called at collection time (the engine still holds that step's results)."""
     import numpy as np
     nctx = len(engines)
@@ -58,8 +59,12 @@ def run_steps(engines, streams, first_step, steps, rank, world, n, seed, on_resu
     for k in range(first_step, first_step + steps):
         if k - first_step >= nctx:
             collect(k - nctx)
-        engines[k % nctx].fuzz_batch(seed=seed, first_case=weak_first_case(k, rank, world, n), corpus_first=0, n=n,
-                                     stream=streams[k % nctx])
+        if strong:
+            first, cnt = case_range(n, rank, world)
+            engines[k % nctx].fuzz_batch(seed=seed, first_case=k * n + first + 1, corpus_first=first, n=cnt, stream=streams[k % nctx])
+        else:
+            engines[k % nctx].fuzz_batch(seed=seed, first_case=weak_first_case(k, rank, world, n), corpus_first=0, n=n,
+                                         stream=streams[k % nctx])
     for k in range(max(first_step, first_step + steps - nctx), first_step + steps):
         collect(k)
     return res

@@ -215,10 +215,12 @@ static ERL_NIF_TERM nif_poll(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]
   for (;;) {
     uint8_t* buf = malloc(cap);
     if (!buf) return mk_err_atom(env, "enomem");
+    enif_mutex_lock(r->lock);                    /* the error text of the context is read under the same lock */
     int rc = eh_poll(r->ctx, ticket, buf, cap, &len, &status);
+    if (rc && rc != EH_E_AGAIN && !(rc == EH_E_INVALID && len > cap)) { ERL_NIF_TERM e = mk_error(env, r->ctx, rc); enif_mutex_unlock(r->lock); free(buf); return e; }
+    enif_mutex_unlock(r->lock);
     if (rc == EH_E_AGAIN) { free(buf); return enif_make_atom(env, "again"); }
     if (rc == EH_E_INVALID && len > cap) { free(buf); cap = (size_t)len; continue; }   /* the ticket stays valid */
-    if (rc) { free(buf); return mk_error(env, r->ctx, rc); }
     ERL_NIF_TERM bin; unsigned char* p = enif_make_new_binary(env, (size_t)len, &bin);
     if (!p) { free(buf); return mk_err_atom(env, "enomem"); }
     memcpy(p, buf, (size_t)len); free(buf);

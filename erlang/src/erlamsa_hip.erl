@@ -41,9 +41,18 @@ fuzz_calls(Calls, Dict) ->
 
 %% Request coalescing for erlamsa_fsupervisor-style services: every request process submits and then polls; a timer
 %% process calls flush/1 every ~200 us (a full batch launches itself).  poll/2 -> {ok, Status, Bin} | again.
-submit(Bin, Seed, Dict) -> submit_nif(ctx(Dict), opts(Dict), Seed, Bin).
-flush(Dict) -> flush_nif(ctx(Dict)).
-poll(Ticket, Dict) -> poll_nif(ctx(Dict), Ticket).
+%% The coalescer has a context of its own: the engine refuses batches, corpora and configurations on a context with
+%% requests pending ({error, wrong_call_order}), because they would overwrite what those requests run with.
+submit(Bin, Seed, Dict) -> submit_nif(co_ctx(Dict), opts(Dict), Seed, Bin).
+flush(Dict) -> flush_nif(co_ctx(Dict)).
+poll(Ticket, Dict) -> poll_nif(co_ctx(Dict), Ticket).
+
+co_ctx(#{hip_co_ctx := C}) -> C;
+co_ctx(Dict) ->
+    case persistent_term:get(erlamsa_hip_co_ctx, undefined) of
+        undefined -> {ok, C} = open(maps:get(device, Dict, 0)), persistent_term:put(erlamsa_hip_co_ctx, C), C;
+        C -> C
+    end.
 
 %% One GPU context per node, shared by all processes (the NIF serialises batches on it; coalescing needs the
 %% requests of different processes in the same context).  #{hip_ctx => C} overrides it.

@@ -149,6 +149,9 @@ int eh_coalesce_limits(eh_ctx* ctx, uint64_t flush_cases, uint64_t flush_bytes);
 int eh_submit(eh_ctx* ctx, const uint8_t* data, uint64_t len, const int64_t seed[3], uint64_t* ticket);
 int eh_flush(eh_ctx* ctx);
 int eh_poll(eh_ctx* ctx, uint64_t ticket, uint8_t* out, uint64_t cap, uint64_t* out_len, int32_t* status);
+/* Gives a ticket up: a request that has not been launched leaves its batch, a launched one is dropped when the batch is
+ * collected, a finished one is freed (a service whose client timed out or died calls this so that results do not pile up). */
+int eh_cancel(eh_ctx* ctx, uint64_t ticket);
 
 /* Device-side view of the last batch: out_data[out_off[i] .. out_off[i]+out_len[i]) is the
  * output of case i.  Pointers stay valid until the next eh_fuzz_* call on this context. */

@@ -108,6 +108,8 @@ ec.coalesce_limits(8, 1 << 20)                       # a launch every 8 requests
 tickets = [ec.submit(b, s) for b, s in reqs]          # 23 requests: two full batches launched, 7 pending
 assert len(set(tickets)) == 23
 assert ec.poll(tickets[-1]) is None                   # still pending: EH_E_AGAIN
+# a context with coalesced requests pending or in flight belongs to the coalescer: batches, corpora, configurations are refused
+assert code(ec.fuzz_batch, seed=(1, 2, 3)) == -5 and code(ec.upload_corpus, dq, oq) == -5 and code(ec.configure, mutations="bd") == -5
 assert ec.poll(tickets[3]) == (int(wstq[3]), wantq[3])      # first batch (already collected when the second was launched)
 assert ec.poll(tickets[12]) == (int(wstq[12]), wantq[12])   # second batch: waits for it
 ec.flush()
@@ -116,5 +118,15 @@ for k in (22, 0, 17, 9):
 assert code(ec.poll, tickets[0]) == -1                # consumed
 assert code(ec.poll, 999999) == -1                    # unknown
 ec.flush()                                            # nothing pending: no-op
+# eh_cancel: a pending request leaves its batch, a launched one is dropped at collection, a finished one is freed
+tk = [ec.submit(b, s) for b, s in reqs[:5]]
+ec.cancel(tk[1])                                      # pending
+ec.flush()
+ec.cancel(tk[3])                                      # launched
+assert ec.poll(tk[0]) == (int(wstq[0]), wantq[0]) and ec.poll(tk[2]) == (int(wstq[2]), wantq[2])
+assert code(ec.poll, tk[1]) == -1 and code(ec.poll, tk[3]) == -1
+ec.cancel(tk[4])                                      # finished, never polled
+assert code(ec.poll, tk[4]) == -1 and code(ec.cancel, tk[4]) == -1
+ec.fuzz_batch(seed=(1, 2, 3))                         # the coalescer is idle again: the context takes batches
 ec.close()
 print("abi behaviour ok")

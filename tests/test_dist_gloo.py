@@ -16,7 +16,7 @@ MUTS, PATS, SEED = "bd,bf,bi,sr,num,ld,ab", "od,nd,bu", (1, 2, 3)
 N, SIZE, STEPS = 24, 160, 2
 
 
-def _worker(rank, world, port, emu_lib, q):
+def _worker(rank, world, port, emu_lib, q, strong=False):
     os.environ["ERLAMSA_HIP_LIB"] = emu_lib
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
@@ -44,8 +44,9 @@ def _worker(rank, world, port, emu_lib, q):
         outs, st = e.download()
         got[step] = (outs, st.tolist())
 
-    res = shard.run_steps(engines, [0, 0], 0, STEPS, r, w, N, SEED, on_result=keep)
-    dt_all, out_all, cases_all = shard.reduce_over_ranks(1.0 + r, res["out_bytes"], N * STEPS, dist, None)
+    res = shard.run_steps(engines, [0, 0], 0, STEPS, r, w, N, SEED, on_result=keep, strong=strong)
+    mine = shard.case_range(N, r, w)[1] if strong else N
+    dt_all, out_all, cases_all = shard.reduce_over_ranks(1.0 + r, res["out_bytes"], mine * STEPS, dist, None)
     gathered = [None] * w
     dist.all_gather_object(gathered, (r, got, int(res["out_bytes"]), res["status_counts"].tolist()))
     if r == 0:
@@ -91,3 +92,33 @@ def test_sharded_engine_run_equals_single_process_oracle(world):
     # no two (rank, step) pairs share a case number
     blocks = sorted(shard.weak_first_case(s, r, world, N) for r in range(world) for s in range(STEPS))
     assert blocks == [k * N + 1 for k in range(world * STEPS)]
+
+
+def test_strong_scaling_split_gathers_to_one_run_in_case_order():
+    """bench.py --scaling strong: a step is ONE run of N cases, rank r takes shard.case_range(N, r, W) of it; the ranks' outputs
+    concatenated in rank order are the single-process oracle run of that step, case by case (erlamsa_main.erl:95-108)."""
+    import torch.multiprocessing as mp
+    import build_emu
+    emu_lib = build_emu.build()
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, emu_lib, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    arena, gathered, (dt_all, out_all, cases_all) = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    offs = (np.arange(N + 1, dtype=np.uint64) * SIZE)
+    assert cases_all == float(N * STEPS)
+    by_rank = {r: got for r, got, _, _ in gathered}
+    for step in range(STEPS):
+        want, wst, _, _ = po.fuzz_batch(arena, offs, seed=SEED, mutations=MUTS, patterns=PATS, first_case=step * N + 1)
+        outs = [o for r in range(world) for o in by_rank[r][step][0]]
+        sts = [x for r in range(world) for x in by_rank[r][step][1]]
+        assert len(outs) == N and sts == wst.tolist() and outs == want, "step %d" % step

@@ -65,3 +65,11 @@ def test_emulated_chunked_work_areas_default_tables(emu_lib):
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_chunks.py"), "24"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "chunks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_emulated_fuse2_table_modes(emu_lib):
+    """eh_fuse2.h on periodic, textual, random and short-alphabet blocks of 6 KB: two-level next-byte tables, compact lookups,
+    bitmap rows, the special node — bytes, statuses and draw counts are the oracle's"""
+    env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_fuse2.py"), "24", "6000"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "fuse2 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
