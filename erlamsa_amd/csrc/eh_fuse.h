@@ -30,7 +30,7 @@ namespace eh {
 struct FNode { uint32_t fo, fc, to, tc; };
 // big-node path: [0,256) source count -> cursor, [256,512) target, [512,768) child index of the bin, [768,1024) flags
 #ifndef EH_FUSE_LDS_WORDS
-#define EH_FUSE_LDS_WORDS 2048
+#define EH_FUSE_LDS_WORDS 4096
 #endif
 EH_LDS_ARRAY(uint32_t, g_fuse_lds, EH_FUSE_LDS_WORDS);     // (eh_fuse2.h: bitmaps of <= EH_FUSE_LDS_WORDS / 8 nodes)
 

@@ -29,7 +29,10 @@
 namespace eh {
 
 constexpr uint32_t FB_DEAD = 0xFFFFFFFFu;
-constexpr uint32_t FB_LDS_WORDS = EH_FUSE_LDS_WORDS;          // g_fuse_lds: bitmaps of <= 256 nodes (every first round) are built in LDS
+// g_fuse_lds (16 KiB): words [0, 2048) hold the compact lookup entries of the current generation when it has <= 1024 nodes;
+// words [2048, 4096) hold the next generation's table while a pass fills it: bitmap rows of <= 256 nodes (every first
+// round), or N1 entries of <= 2048 nodes.  A pass whose tables are both in LDS moves ids and bytes only.
+constexpr uint32_t FB_LDS_SC_NODES = 1024, FB_LDS_NEXT = 2048, FB_LDS_WORDS = 2048, FB_LDS_N1_NODES = 2048;
 constexpr uint32_t FB_TEST_WORDS = 65536;        // bitmaps up to this size are hot: many members per bit, test (a load at L2) before the atomic
 struct RkWord { uint32_t mask, prefix; };
 
@@ -188,8 +191,8 @@ EH_DEV uint64_t fb_ld8(const uint8_t* S, uint32_t q, uint32_t len) {
 // A lone wavefront is bound by memory round trips, not by bytes: 1024 positions per step (16 per lane), the ids and
 // bytes of the NEXT step are requested before this step's 16 lookups, and every kind of access of a step (lookups,
 // tests of the next table) is issued as one batch, so a step costs a few round trips.
-template <int INS>   // how the next table is written: 0 bitmap, global atomics; 1 bitmap in LDS; 2 bitmap, test (at L2) before the atomic; 3 N1 + bitmap rows
-__device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_t* ids, uint32_t g, const RkWord* RK, const ScEnt* SC, uint32_t kill, uint32_t e_pos, bool e_kill, uint32_t* Mn, uint32_t* N1n) {
+template <int INS>   // how the next table is written: 0 bitmap, global atomics; 1 bitmap in LDS; 2 bitmap, test (at L2) before the atomic; 3 N1 + bitmap rows; 4 N1 in LDS + bitmap rows
+__device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_t* ids, uint32_t g, const RkWord* RK, const ScEnt* SC, bool sc_lds, uint32_t kill, uint32_t e_pos, bool e_kill, uint32_t* Mn, uint32_t* N1n) {
   const uint32_t l = (uint32_t)EH_LANE;
   constexpr int U = 4;
   uint32_t alive = 0;
@@ -219,7 +222,7 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
         for (uint32_t k = 0; k < 4; k++) {
           const bool ok = p + k + g < len && o[k] != FB_DEAD;
           ScEnt e; e.mask = 0; e.meta = 0;
-          if (ok) e = SC[o[k]];
+          if (ok) { if (sc_lds) { e.mask = g_fuse_lds[2u * o[k]]; e.meta = g_fuse_lds[2u * o[k] + 1u]; } else e = SC[o[k]]; }
           sc[u][k] = e;
         }
       }
@@ -280,28 +283,46 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
       if (p < len) { uint4 v; v.x = nw[0]; v.y = nw[1]; v.z = nw[2]; v.w = nw[3]; *reinterpret_cast<uint4*>(ids + p) = v; }
     }
     if (Mn) {
-      if (INS == 3) {
+      if (INS == 3 || INS == 4) {
+        // first level: N1 (global, tests batched; or LDS).  A member whose byte is not the node's single recorded byte
+        // has to be in the node's bitmap row: those bits are tested as one batch of loads and set only where missing —
+        // under a node with several continuations every member comes this way, and an atomic per member on the same few
+        // words serialises at the L2.
         uint32_t have[U][4];
+        if (INS == 3) {
 #pragma unroll
-        for (int u = 0; u < U; u++)
+          for (int u = 0; u < U; u++)
 #pragma unroll
-          for (uint32_t k = 0; k < 4; k++) have[u][k] = fb_ld(&N1n[nidn[u][k]]);     // (entry 0 for the lanes with nothing to set)
+            for (uint32_t k = 0; k < 4; k++) have[u][k] = fb_ld(&N1n[nidn[u][k]]);     // (entry 0 for the lanes with nothing to record)
+        }
+        bool row[U][4];
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
           for (uint32_t k = 0; k < 4; k++) {
+            row[u][k] = false;
             if (!bit2v[u][k]) continue;
             const uint32_t key = ((w2v[u][k] & 7u) << 5) + (uint32_t)__builtin_ctz(bit2v[u][k]) + 1u;     // byte' + 1
-            uint32_t old = have[u][k];
+            uint32_t* e = INS == 4 ? &g_fuse_lds[FB_LDS_NEXT + nidn[u][k]] : &N1n[nidn[u][k]];
+            uint32_t old = INS == 4 ? *e : have[u][k];
             if (old == key) continue;
-            if (old == 0) old = atomicCAS(&N1n[nidn[u][k]], 0u, key);
+            if (old == 0) old = atomicCAS(e, 0u, key);
             if (old == 0 || old == key) continue;
             if (old != FB_MULTI) {                                 // a second byte under this node: both go to its bitmap row
               atomicOr(&Mn[nidn[u][k] * 8u + ((old - 1u) >> 5)], 1u << ((old - 1u) & 31u));
-              atomicExch(&N1n[nidn[u][k]], FB_MULTI);
+              atomicExch(e, FB_MULTI);
             }
-            atomicOr(&Mn[w2v[u][k]], bit2v[u][k]);
+            row[u][k] = true;
           }
+        uint32_t bits[U][4];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (uint32_t k = 0; k < 4; k++) bits[u][k] = row[u][k] ? fb_ld(&Mn[w2v[u][k]]) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (uint32_t k = 0; k < 4; k++) if (bit2v[u][k] & ~bits[u][k]) atomicOr(&Mn[w2v[u][k]], bit2v[u][k]);
       } else if (INS == 2) {
         uint32_t have[U][4];
 #pragma unroll
@@ -316,7 +337,7 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
-          for (uint32_t k = 0; k < 4; k++) if (bit2v[u][k]) { if (INS == 1) atomicOr(&g_fuse_lds[w2v[u][k]], bit2v[u][k]); else atomicOr(&Mn[w2v[u][k]], bit2v[u][k]); }
+          for (uint32_t k = 0; k < 4; k++) if (bit2v[u][k]) { if (INS == 1) atomicOr(&g_fuse_lds[FB_LDS_NEXT + w2v[u][k]], bit2v[u][k]); else atomicOr(&Mn[w2v[u][k]], bit2v[u][k]); }
       }
     }
 #pragma unroll
@@ -465,7 +486,10 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t l
     // two-level tables when the nodes of this round had two children on average at most: low-entropy data, where the node
     // counts stay small over many rounds; lookups through the compact entries when few nodes spread over several words
     const bool n1 = next && !lds && nchild <= 2u * nn;
+    const bool n1_lds = n1 && nchild <= FB_LDS_N1_NODES;
     const ScEnt* look = nfull * 4u <= nn ? SC : nullptr;
+    const bool sc_lds = look && nn <= FB_LDS_SC_NODES;
+    if (sc_lds) { const uint32_t* scw = (const uint32_t*)SC; lanes_sync(); for (uint32_t i = l; i < 2u * nn; i += 64) g_fuse_lds[i] = scw[i]; lanes_sync(); }
     if (next && nchild > m_rows) {                                 // the next generation's tables (this one's are in RK now)
       m_rows = nchild;
       for (int s = 0; s < nside; s++) {
@@ -477,19 +501,22 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t l
     }
     uint64_t entries = 0;
     for (int s = 0; s < nside; s++) {
-      if (lds) { for (uint32_t i = l; i < nchild * 8u; i += 64) g_fuse_lds[i] = 0; lanes_sync(); }
+      if (lds) { for (uint32_t i = l; i < nchild * 8u; i += 64) g_fuse_lds[FB_LDS_NEXT + i] = 0; lanes_sync(); }
+      if (n1_lds) { for (uint32_t i = l; i < nchild; i += 64) g_fuse_lds[FB_LDS_NEXT + i] = 0; lanes_sync(); }
       EH_PT(c, 104);
       // the member at len-1: leaves when it was inserted first (alone, or an odd generation).  One list on both sides:
       // alone = the special node = the member itself, now empty, so it stays.
       bool ek = sym ? (!e_alone[0] && (g & 1u)) : (e_alone[s] || (g & 1u));
       uint32_t kill = (s == 1 && forced) ? sp : FB_DEAD;
-      uint32_t alive = lds ? fb_pass<1>(S[s], len[s], ids[s], g, RK, look, kill, e_pos[s], ek, M[s], nullptr)
-                     : n1 ? fb_pass<3>(S[s], len[s], ids[s], g, RK, look, kill, e_pos[s], ek, M[s], N1[s])
-                     : (next && nchild * 8u <= FB_TEST_WORDS) ? fb_pass<2>(S[s], len[s], ids[s], g, RK, look, kill, e_pos[s], ek, M[s], nullptr)
-                     : fb_pass<0>(S[s], len[s], ids[s], g, RK, look, kill, e_pos[s], ek, next ? M[s] : nullptr, nullptr);
+      uint32_t alive = lds ? fb_pass<1>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, e_pos[s], ek, M[s], nullptr)
+                     : n1_lds ? fb_pass<4>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, e_pos[s], ek, M[s], N1[s])
+                     : n1 ? fb_pass<3>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, e_pos[s], ek, M[s], N1[s])
+                     : (next && nchild * 8u <= FB_TEST_WORDS) ? fb_pass<2>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, e_pos[s], ek, M[s], nullptr)
+                     : fb_pass<0>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, e_pos[s], ek, next ? M[s] : nullptr, nullptr);
       entries += alive;
-      EH_PT(c, lds ? 105 : (n1 ? 111 : (next ? (nchild * 8u <= FB_TEST_WORDS ? 110 : 106) : 107)));
-      if (lds) { lanes_sync(); for (uint32_t i = l; i < nchild * 8u; i += 64) M[s][i] = g_fuse_lds[i]; wave_sync(); }
+      EH_PT(c, lds ? 105 : (n1_lds ? 96 : (n1 ? 111 : (next ? (nchild * 8u <= FB_TEST_WORDS ? 110 : 106) : 107))));
+      if (lds) { lanes_sync(); for (uint32_t i = l; i < nchild * 8u; i += 64) M[s][i] = g_fuse_lds[FB_LDS_NEXT + i]; wave_sync(); }
+      if (n1_lds) { lanes_sync(); for (uint32_t i = l; i < nchild; i += 64) N1[s][i] = g_fuse_lds[FB_LDS_NEXT + i]; wave_sync(); }
     }
     if (sym) entries *= 2; else if (forced) entries += 2;
     gen_entries = entries;
