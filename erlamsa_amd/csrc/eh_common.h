@@ -22,6 +22,7 @@ constexpr int MAX_FS = 64;          // mux_fuzzers list entries (one per lane of
 constexpr int MAX_BLOCKS = 2048;    // block-list entries per case
 constexpr int MAX_EMITS = 4096;     // deferred output pieces per case
 constexpr int MAX_FRAMES = 16;      // nested sizer/csum wrappers
+constexpr uint32_t TRACE_CAP = 32768; // meta-trace events kept per case (EH_FLAG_META_TRACE); the last byte is 0xFF when events were dropped
 constexpr int POOL_TIERS = 8;       // tiers of larger work areas a case can borrow from
 
 // erlamsa.hrl:44-58
@@ -99,6 +100,9 @@ struct KParams {
   int32_t* lastm;
   uint64_t* cycles;           // per-case shader-clock ticks (diagnostic)
   uint64_t* peak;             // per-case work-memory high-water mark in bytes (diagnostic)
+  uint64_t* trace_off;        // EH_FLAG_META_TRACE: where the case's trace sits in `out` ...
+  uint32_t* trace_len;        // ... and its length in events (one byte each, see TR_* in eh_device.h)
+  uint32_t flags;             // EH_FLAG_*
   unsigned long long* prof;   // EH_PROF builds: [2*k] cycles, [2*k+1] calls; k < 64 mutator fn, 64.. phases
   unsigned long long* ticket;
   unsigned long long* in_bytes;

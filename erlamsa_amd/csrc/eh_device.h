@@ -245,6 +245,8 @@ struct Ctx {
   uint64_t ws_lo;      // its virtual start
   uint64_t ch_vstart[MAX_CHUNKS], ch_vend[MAX_CHUNKS]; uint8_t* ch_base[MAX_CHUNKS]; uint32_t ch_area[MAX_CHUNKS]; int32_t ch_tier[MAX_CHUNKS];
   uint64_t lex_ptr[LEX_LEVELS];   // block the lex cache of nesting level d holds a table for (mirror of LexCache::ptr; 0: none)
+  uint8_t* trace;      // EH_FLAG_META_TRACE: the case's event bytes (slot memory), nullptr = off
+  uint32_t ntrace;
   uint64_t ws_peak, ws_top;   // diagnostics: highest ws_used, bytes taken from the top of chunks (eh_result_peak)
   int status;
   int lastm;
@@ -298,6 +300,17 @@ enum { R_SAME = 0, R_NEW = 1 };
 #define EH_PT(c, k) do {} while (0)
 #endif
 
+// ---- meta trace (erlamsa_main.erl:58-70 prints the Meta list a case has built: erlamsa_patterns.erl puts {pattern, P} on it,
+// mux_fuzzers {used, Name} / {failed, Name}, erlamsa_mutations.erl:1269-1279).  One byte per event, in the order the reference
+// conses them: kind << 6 | id, id = index in the mutator / pattern table.
+enum { TR_FAILED = 0, TR_USED = 1, TR_PATTERN = 2, TR_SKIPPED_BIG = 3 };
+EH_DEV void trace_event(Ctx& c, uint32_t kind, uint32_t id) {
+  if (!c.trace) return;
+  if (c.ntrace < TRACE_CAP) { if (EH_LANE == 0) c.trace[c.ntrace] = (uint8_t)((kind << 6) | (id & 63u)); }
+  else if (EH_LANE == 0) c.trace[TRACE_CAP - 1] = 0xFF;
+  if (c.ntrace < TRACE_CAP) c.ntrace++;
+}
+
 // ---- work-area pool (see KParams): lane 0 talks to the rings, the wave takes the result.  A popper owns ring entry
 // (ticket mod count) and waits until a pusher has filled it; a pusher waits until the entry's previous value has been
 // taken.  A wavefront only ever waits for an area of a HIGHER tier than any it holds, so the waits end.
@@ -344,6 +357,8 @@ struct LexChunk;
 struct LexCache { uint64_t ptr; uint32_t len; int32_t n; LexChunk* tab; uint32_t tcap; uint32_t pad; };
 constexpr uint32_t AUX_LEXCACHE = 2048;                              // offset in Ctx::aux of LexCache[LEX_LEVELS]
 constexpr uint64_t AUX_BYTES = 4096;
+// a slot: block list, scratch list, emit list, aux, meta-trace bytes, then the work area
+constexpr uint64_t SLOT_TABLE_BYTES = (uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + TRACE_CAP;
 EH_DEV LexCache& lex_slot(Ctx& c) { return ((LexCache*)(c.aux + AUX_LEXCACHE))[c.depth]; }
 // Work memory at virtual offsets >= v0 is about to be reused: a lexed block that lives there (a decoded base64 chunk, an
 // inner text — temporaries of a mutator attempt) is gone, and the cache is keyed by address.  Only this level's key can
@@ -800,7 +815,7 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
   int tried = 0; bool used = false; bool dropped = false;
   Blk h0 = blk_load(c.bl, c.cur);
   for (int r = 0; r < nfs; r++) {
-    if (h0.len > ABSMAX_BINARY_BLOCK) { dropped = true; break; }                 // :1269-1270
+    if (h0.len > ABSMAX_BINARY_BLOCK) { dropped = true; trace_event(c, TR_SKIPPED_BIG, 0); break; }   // :1269-1270
     unsigned long long who = __ballot(l < nfs && rank == (uint32_t)r);
     int j = (int)__builtin_ctzll(who);
     uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)lt.e_meta, j);
@@ -818,7 +833,7 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
 #endif
     // An attempt that runs out of work memory is repeated — that attempt only, from the same PRNG state — after the case
     // has borrowed a larger area (ws_regrow).  lis / lrs update their store before they allocate: it is put back as well.
-    const Rng rng0 = c.rng; const uint64_t work0 = c.work;
+    const Rng rng0 = c.rng; const uint64_t work0 = c.work; const uint32_t ntrace0 = c.ntrace;
     const bool stateful = fn == M_LIS || fn == M_LRS;
     if (stateful) { const uint32_t* ax = (const uint32_t*)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) g_st_save[i] = ax[i]; }
     int delta, last_tier = 0;
@@ -828,7 +843,7 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
       wave_sync();
       if (!ws_regrow(c, mark, &last_tier)) break;
       lex_forget_from(c, mark);
-      c.rng = rng0; c.work = work0;
+      c.rng = rng0; c.work = work0; c.ntrace = ntrace0;
       c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
       if (stateful) { lanes_sync(); uint32_t* ax = (uint32_t*)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) ax[i] = g_st_save[i]; }
       wave_sync();
@@ -849,6 +864,7 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
       uint32_t hd_len = c.r_flush && c.r_len >= AVG_BLOCK_SIZE ? AVG_BLOCK_SIZE : c.r_len;
       changed = c.r_changed || hd_len != h0.len || !wave_equal(c.r_ptr, (const uint8_t*)h0.ptr, hd_len);
     }
+    trace_event(c, changed ? TR_USED : TR_FAILED, name);                           // {used, Name} / {failed, Name} :1278-1279
     if (changed) {
       c.lastm = (int)name;
       // Reclaim work memory before committing: everything between `mark` and the candidate is a

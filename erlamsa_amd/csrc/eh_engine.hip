@@ -305,6 +305,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
     if (++guard > 1000000) { EH_SET_OVERFLOW(c, 305); break; }
     switch (act) {
       case A_RUN_PAT:
+        trace_event(c, TR_PATTERN, (uint32_t)pat);                                   // [{pattern, P} | Meta]
         switch (pat) {
           case P_OD: cont = C_EMIT; act = A_MUTATE_ONCE; break;                       // :306-309
           case P_ND: cont = C_ND; act = A_MUTATE_ONCE; break;                         // :323-326
@@ -415,7 +416,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
         switch (cont) {
           case C_EMIT: emit_all(c); act = A_TERMINAL; break;
           case C_ND:                                                                  // pat_many_dec_cont :313-321
-            if (rng_occurs(c.rng, 4, 5)) act = A_MUTATE_ONCE; else { emit_all(c); act = A_TERMINAL; }
+            if (rng_occurs(c.rng, 4, 5)) { trace_event(c, TR_PATTERN, P_ND); act = A_MUTATE_ONCE; } else { emit_all(c); act = A_TERMINAL; }
             break;
           case C_BU: {                                                                // pat_burst_cont :331-344
             int n = 1;
@@ -532,7 +533,8 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
   c.bl2 = c.bl + MAX_BLOCKS;
   c.em = c.bl2 + MAX_BLOCKS;
   c.aux = (uint8_t*)(c.em + MAX_EMITS);
-  uint8_t* const ws0 = c.aux + AUX_BYTES;
+  uint8_t* const trace0 = c.aux + AUX_BYTES;
+  uint8_t* const ws0 = trace0 + TRACE_CAP;
 
   // mode 0: the run state is shared by all cases
   Rng parent; int gen0 = 0; uint32_t pri0 = 0, meta0 = 0; int nfs0 = 0;
@@ -559,6 +561,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     if (i >= p.n) break;
     uint64_t tick0 = __builtin_readcyclecounter();
     c.nchunk = 0; c.ws_peak = 0; c.ws_top = 0;
+    c.trace = (p.flags & EH_FLAG_META_TRACE) ? trace0 : nullptr; c.ntrace = 0;
     c.ch_vstart[0] = 0; c.ch_vend[0] = p.work_cap; c.ch_base[0] = ws0; c.ch_tier[0] = 0; c.ch_area[0] = slot_id;
     ws_set_view(c, 0);
     for (int d = 0; d < LEX_LEVELS; d++) c.lex_ptr[d] = 0;
@@ -619,6 +622,15 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
       uint64_t pos = base;
       for (int k = 0; k < c.nem; k++) { Blk b = blk_load(c.em, k); wave_copy(p.out + pos, (const uint8_t*)b.ptr, b.len); pos += b.len; }
     }
+    // the case's meta trace goes behind its output in the arena
+    unsigned long long tbase = 0;
+    if (c.trace && c.ntrace > 0) {
+      wave_sync();
+      if (l == 0) tbase = atomicAdd(p.out_cursor, (unsigned long long)((c.ntrace + 15u) & ~15u));
+      tbase = uni64(tbase);
+      if (tbase + c.ntrace > p.out_cap) { c.ntrace = 0; if (c.status == CASE_OK) { c.status = CASE_ARENA_FULL; total = 0; } }
+      else wave_copy(p.out + tbase, c.trace, c.ntrace);
+    }
     EH_PH(3);
     // larger areas the case borrowed go back to the pool (the output has been copied out of them)
     wave_sync();
@@ -627,6 +639,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
       p.out_off[i] = base; p.out_len[i] = total; p.status[i] = c.status;
       p.draws[i] = c.rng.draws; p.lastm[i] = c.status == CASE_OVERFLOW ? -c.ovf_line : c.lastm; p.cycles[i] = __builtin_readcyclecounter() - tick0;
       p.peak[i] = c.ws_peak + c.ws_top;
+      if (p.flags & EH_FLAG_META_TRACE) { p.trace_off[i] = tbase; p.trace_len[i] = c.trace ? c.ntrace : 0u; }
     }
     wave_sync();
   }
@@ -741,7 +754,7 @@ struct eh_ctx {
   uint64_t big_case_bytes = 0;
   // outputs
   uint8_t* d_out = nullptr; uint64_t out_cap = 0;
-  uint64_t* d_off = nullptr; uint64_t* d_len = nullptr; int32_t* d_status = nullptr; uint64_t* d_draws = nullptr; int32_t* d_lastm = nullptr; uint64_t* d_cycles = nullptr; uint64_t* d_peak = nullptr;
+  uint64_t* d_off = nullptr; uint64_t* d_len = nullptr; int32_t* d_status = nullptr; uint64_t* d_draws = nullptr; int32_t* d_lastm = nullptr; uint64_t* d_cycles = nullptr; uint64_t* d_peak = nullptr; uint64_t* d_toff = nullptr; uint32_t* d_tlen = nullptr;
   uint64_t res_cap = 0;
   unsigned long long* d_counters = nullptr;  // [0] ticket, [1] out cursor
   RunState* d_run = nullptr;
@@ -850,9 +863,11 @@ static int build_funny(uint8_t (*out)[5]) {
 
 static int ensure_results(eh_ctx* ctx, uint64_t n) {
   if (n <= ctx->res_cap) return EH_OK;
-  if (ctx->d_off) { (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len); (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_peak); }
+  if (ctx->d_off) { (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len); (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_peak); (void)hipFree(ctx->d_toff); (void)hipFree(ctx->d_tlen); }
   HIPCHK(ctx, hipMalloc(&ctx->d_cycles, n * 8));
   HIPCHK(ctx, hipMalloc(&ctx->d_peak, n * 8));
+  HIPCHK(ctx, hipMalloc(&ctx->d_toff, n * 8));
+  HIPCHK(ctx, hipMalloc(&ctx->d_tlen, n * 4));
   HIPCHK(ctx, hipMalloc(&ctx->d_off, n * 8));
   HIPCHK(ctx, hipMalloc(&ctx->d_len, n * 8));
   HIPCHK(ctx, hipMalloc(&ctx->d_status, n * 4));
@@ -952,7 +967,7 @@ static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
   // a slot per workgroup of a batch: one workgroup per wavefront the device holds (EH_WAVES_PER_SIMD), or max_slots
   uint32_t want_slots = ctx->max_slots_opt ? ctx->max_slots_opt : (uint32_t)ctx->cus * 4u * EH_WAVES_PER_SIMD;
   if (want_slots > n) want_slots = (uint32_t)(n ? n : 1);
-  uint64_t stride = ((uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + work_cap + 255) & ~255ull;
+  uint64_t stride = (SLOT_TABLE_BYTES + work_cap + 255) & ~255ull;
   if (!ctx->d_slots || ctx->nslots < want_slots || ctx->slot_cap != work_cap) {
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     ctx->d_slots = nullptr;
@@ -992,7 +1007,7 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.work_budget = ctx->work_budget;                                            // 0 = no budget (the default)
   p.fuse_stream_min = ctx->fuse_stream_min;
   p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
-  p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles; p.peak = ctx->d_peak;
+  p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles; p.peak = ctx->d_peak; p.trace_off = ctx->d_toff; p.trace_len = ctx->d_tlen; p.flags = ctx->flags;
   p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;   // counters [8, 264) = prof
   p.slot_base = ctx->d_slots; p.slot_stride = ctx->slot_stride;
   p.ntiers = pl->ntiers; p.pool_ctr = pl->d_ctr; p.pool_cap[0] = pl->work_cap;
@@ -1111,7 +1126,7 @@ void eh_destroy(eh_ctx* ctx) {
   if (ctx->own_corpus) { (void)hipFree(ctx->d_corpus); (void)hipFree(ctx->d_coff); }
   pool_release(ctx);
   (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
-  (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_peak); (void)hipFree(ctx->d_counters);
+  (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_peak); (void)hipFree(ctx->d_toff); (void)hipFree(ctx->d_tlen); (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_run); (void)hipFree(ctx->d_seeds);
   for (int k = 0; k < 2; k++) { if (ctx->d_bounce[k]) (void)hipFree(ctx->d_bounce[k]); if (ctx->ev_g[k]) (void)hipEventDestroy(ctx->ev_g[k]); if (ctx->ev_c[k]) (void)hipEventDestroy(ctx->ev_c[k]); }
   if (ctx->dl_gather) (void)hipStreamDestroy(ctx->dl_gather);
@@ -1489,6 +1504,22 @@ int eh_result_cycles(eh_ctx* ctx, uint64_t* cycles) {
   if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
   int rc = eh_sync(ctx); if (rc) return rc;
   if (ctx->last_n) HIPCHK(ctx, hipMemcpy(cycles, ctx->d_cycles, ctx->last_n * 8, hipMemcpyDeviceToHost));
+  return EH_OK;
+}
+int eh_result_meta(eh_ctx* ctx, uint64_t i, uint8_t* buf, uint64_t cap, uint64_t* n_events) {
+  if (!ctx || !n_events) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  if (!(ctx->flags & EH_FLAG_META_TRACE)) { ctx->err = "eh_result_meta: configure with EH_FLAG_META_TRACE"; return EH_E_STATE; }
+  int rc = eh_sync(ctx); if (rc) return rc;
+  if (i >= ctx->last_n) { ctx->err = "eh_result_meta: case index outside the last batch"; return EH_E_INVALID; }
+  uint64_t off = 0; uint32_t len = 0;
+  HIPCHK(ctx, hipMemcpy(&off, ctx->d_toff + i, 8, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(&len, ctx->d_tlen + i, 4, hipMemcpyDeviceToHost));
+  *n_events = len;
+  if (len > cap || (!buf && len)) { ctx->err = "eh_result_meta: buffer too small"; return EH_E_INVALID; }
+  // (with EH_FLAG_ORDERED_OUTPUT the traces stay in the completion-ordered arena, which is d_out2 after the swap)
+  const uint8_t* src = (ctx->ordered ? ctx->d_out2 : ctx->d_out) + off;
+  if (len) HIPCHK(ctx, hipMemcpy(buf, src, len, hipMemcpyDeviceToHost));
   return EH_OK;
 }
 int eh_result_peak(eh_ctx* ctx, uint64_t* peak) {

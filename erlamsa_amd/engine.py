@@ -14,13 +14,14 @@ LIB_PATH = os.environ.get("ERLAMSA_HIP_LIB") or os.path.join(_HERE, "liberlamsa_
 
 EH_ABI_VERSION = 5
 EH_FLAG_ORDERED_OUTPUT = 1
+EH_FLAG_META_TRACE = 2
 
 CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BUDGET = 0, 1, 2, 3, 4, 5
 
 # every symbol include/erlamsa_hip.h declares
 ABI_SYMBOLS = [
     "eh_create", "eh_destroy", "eh_configure", "eh_corpus_upload", "eh_corpus_attach", "eh_fuzz_batch",
-    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_fetch", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_peak", "eh_result_prof", "eh_selftest_movers",
+    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_fetch", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_peak", "eh_result_meta", "eh_result_prof", "eh_selftest_movers",
     "eh_last_kernel_ms", "eh_pool_stats", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
@@ -78,6 +79,7 @@ def load_library():
     lib.eh_result_diag.argtypes = [vp, vp, vp]
     lib.eh_result_cycles.argtypes = [vp, vp]
     lib.eh_result_peak.argtypes = [vp, vp]
+    lib.eh_result_meta.argtypes = [vp, C.c_uint64, vp, C.c_uint64, u64p]
     lib.eh_result_prof.argtypes = [vp, vp]
     lib.eh_selftest_movers.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
     lib.eh_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -275,6 +277,27 @@ class Engine:
         cyc = np.zeros(max(n, 1), dtype=np.uint64)
         self._chk(self.lib.eh_result_cycles(self.h, cyc.ctypes.data))
         return cyc[:n]
+
+    def meta(self, i):
+        """Meta trace of case i (configure with flags=EH_FLAG_META_TRACE): list of (kind, name), kind in 'failed', 'used',
+        'pattern', 'skipped_big', in the order the reference makes the entries."""
+        buf = (C.c_uint8 * 32768)()
+        n = C.c_uint64()
+        self._chk(self.lib.eh_result_meta(self.h, i, buf, 32768, C.byref(n)))
+        mn = [self.lib.eh_mutator_name(k).decode() for k in range(self.lib.eh_mutator_count())]
+        pn = [self.lib.eh_pattern_name(k).decode() for k in range(self.lib.eh_pattern_count())]
+        out = []
+        for v in bytes(buf[:n.value]):
+            kind, idx = v >> 6, v & 63
+            if v == 0xFF:
+                out.append(("truncated", ""))
+            elif kind == 2:
+                out.append(("pattern", pn[idx]))
+            elif kind == 3:
+                out.append(("skipped_big", ""))
+            else:
+                out.append((("failed", "used")[kind], mn[idx]))
+        return out
 
     def peak(self):
         """Per-case high-water mark of work memory (bytes)."""

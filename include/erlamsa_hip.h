@@ -102,6 +102,7 @@ typedef struct eh_options {
 } eh_options;
 
 #define EH_FLAG_ORDERED_OUTPUT 1u /* compact the output arena into case order after the batch */
+#define EH_FLAG_META_TRACE 2u     /* keep every case's meta trace (eh_result_meta) */
 
 int eh_create(int device, eh_ctx** out);
 void eh_destroy(eh_ctx* ctx);
@@ -172,6 +173,14 @@ int eh_result_diag(eh_ctx* ctx, uint64_t* draws, int32_t* last_mutator);
 
 /* Per-case shader-clock ticks spent by the wavefront that ran the case (diagnostic). */
 int eh_result_cycles(eh_ctx* ctx, uint64_t* cycles);
+
+/* Meta trace of case i of the last batch (EH_FLAG_META_TRACE): what erlamsa's -M / meta logger prints for a case
+ * (erlamsa_main.erl:58-70) — the list erlamsa_patterns.erl and mux_fuzzers (erlamsa_mutations.erl:1269-1279) build:
+ * {pattern, P}, {used, Name}, {failed, Name}, nested scheduler calls included — in the order the entries are made (the
+ * reference's list is the reverse: it conses).  One byte per event: kind << 6 | id, kind 0 failed, 1 used, 2 pattern,
+ * 3 the mutator dropped because the block is larger than ABSMAX_BINARY_BLOCK (:1269-1270); id = index of eh_mutator_name /
+ * eh_pattern_name.  At most 32768 events per case are kept; the last byte is 0xFF when events were dropped. */
+int eh_result_meta(eh_ctx* ctx, uint64_t i, uint8_t* buf, uint64_t cap, uint64_t* n_events);
 
 /* Per-case high-water mark of work memory in bytes (diagnostic; what sizes max_case_bytes and the pool's tiers). */
 int eh_result_peak(eh_ctx* ctx, uint64_t* peak);

@@ -73,3 +73,10 @@ def test_emulated_fuse2_table_modes(emu_lib):
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_fuse2.py"), "24", "6000"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "fuse2 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_emulated_meta_trace(emu_lib):
+    """eh_result_meta = the oracle's meta trace ({pattern,P} / {used,Name} / {failed,Name}, nested calls included), default tables"""
+    env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_meta.py"), "18"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "meta ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -524,3 +524,16 @@ def test_full_size_bench_workload_is_independent_of_tiers_and_slots():
     assert (a[0][ok] == b[0][ok]).all() and (a[2][ok] == b[2][ok]).all()
     assert a[4] == b[4] and a[3] == b[3]
     assert ok.mean() > 0.995 and int(a[0].sum()) > 15 << 30          # the workload really is the heavy one
+
+
+def test_meta_trace_equals_the_oracles():
+    """the per-case meta trace (erlamsa_main.erl:58-70 prints it: {pattern, P}, {used, Name}, {failed, Name} as
+    erlamsa_patterns.erl and mux_fuzzers make them, nested scheduler calls included) through eh_result_meta, entry by entry
+    against the oracle's trace of the same run — default mutator and pattern tables, mixed / SGML / JSON inputs."""
+    if util.priming():
+        pytest.skip("the trace is not part of the digest cache")
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    import emu_meta
+    assert emu_meta.run(n=96, size=900, seed=(5, 3, 8)) >= 100
