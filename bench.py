@@ -31,8 +31,8 @@ def cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref=None):
     Every case runs under a wall-clock watchdog of `--cpu-case-seconds` — the reference's own maxrunningtime semantics
     (erlamsa_main.erl:197-204: the worker is killed and the case yields <<>>; its CLI default is 30 s): the time of such a
     case counts, its output does not.  Reported: the aggregate rate over all threads and the threads actually used.
-    The same outputs are the CHECKER of the run that was timed: gpu_ref holds status / length / draw count / SHA-1 of the
-    engine's results for the same case numbers (taken from the device before the timed steps); every case the oracle
+    The same outputs are the CHECKER of the engine build that was timed: gpu_ref holds status / length / draw count / SHA-1 of
+    the engine's results for the same case numbers (taken from the device right before this leg); every case the oracle
     finished must agree, or the bench fails.  Engine-only statuses (2, 3) and cases cut by the watchdog are counted, not
     compared."""
     import hashlib
@@ -100,6 +100,11 @@ def cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref=None):
                       % (state["cases"], threads, ct, args.cpu_case_seconds)}
 
 
+def log(msg):
+    sys.stderr.write("[bench %.1f] %s\n" % (time.time() % 100000, msg))
+    sys.stderr.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,9 +120,11 @@ def main():
     ap.add_argument("--cpu-case-seconds", type=float, default=10.0, help="per-case wall-clock watchdog of the CPU oracle leg "
                     "(the reference's maxrunningtime; its CLI default is 30 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle leg (0 = all host cores, at most 64)")
-    ap.add_argument("--max-slots", type=int, default=2048, help="slots = persistent workgroups of one pass (0 = one per wavefront the device holds: "
-                    "8 per CU); passes in flight oversubscribe the device")
-    ap.add_argument("--pool-gib", type=int, default=56, help="device memory of the work-area pool all contexts share (GiB), eh_options.pool_bytes; "
+    ap.add_argument("--max-slots", type=int, default=1024, help="slots = persistent workgroups of one pass (0 = one per wavefront the device holds: "
+                    "8 per CU = 2048); passes in flight oversubscribe the device.  1024 x 6 passes keeps ~45 GiB of the device free: with 2048 "
+                    "(5 percent faster, profiles/r03_bench.json) the free memory fell below what the runtime wants for the queues' scratch and "
+                    "two of six runs never left the set-up passes")
+    ap.add_argument("--pool-gib", type=int, default=48, help="device memory of the work-area pool all contexts share (GiB), eh_options.pool_bytes; "
                     "0 = the library's own rule (a quarter of the free memory, at most 64 GiB)")
     ap.add_argument("--out-gib", type=int, default=27, help="output arena capacity per context (GiB)")
     ap.add_argument("--case-mib", type=int, default=4, help="work area of a slot (MiB), eh_options.max_case_bytes; every workgroup of a pass owns a slot, a case that "
@@ -132,10 +139,63 @@ def main():
                     "(reported as 'pcie'); 0: skip")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak (default): every rank runs its own 64 K case numbers per step; "
                     "strong: a step is ONE run of --cases cases split over the ranks by shard.case_range (erlamsa_main.erl:95-108)")
+    ap.add_argument("--extras-seconds", type=int, default=240, help="watchdog of the legs that run after the headline result exists (CPU oracle leg, "
+                    "work-budget leg, PCIe leg): the JSON line is printed without a leg that has not come back by then")
     ap.add_argument("--inflight", type=int, default=6, help="passes in flight (engine contexts / HIP streams): the tail of a pass — a few "
                     "long single-wavefront cases — overlaps with the bulk of the next ones.  Every context owns its output arena (--out-gib) and its slots "
                     "(--max-slots x --case-mib); larger work areas come from one pool shared by all contexts (--pool-gib)")
+    ap.add_argument("--setup-seconds", type=int, default=150, help="single-GPU runs execute in a child process; a child whose set-up passes (the first "
+                    "dispatch on every HIP stream) have not finished after this many seconds is killed and the run repeated once with "
+                    "--inflight 3 (0 = no supervision)")
     args = ap.parse_args()
+
+    # ---- supervision (single GPU only): the run proper happens in a child process.  Twice in this round's development a run
+    # never came back from its set-up passes when device memory was nearly exhausted (the runtime could not place the queues'
+    # scratch); a benchmark that hangs reports nothing, so a stuck child is replaced by a more frugal one.
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.setup_seconds > 0 and not os.environ.get("EH_BENCH_CHILD"):
+        import subprocess
+        import threading
+        for attempt, extra in enumerate(([], ["--inflight", "3"])):
+            env = dict(os.environ, EH_BENCH_CHILD="1")
+            proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            marks = {"setup": None, "past": False}
+
+            def pump(proc=proc, marks=marks):
+                for ln in proc.stderr:
+                    sys.stderr.write(ln)
+                    sys.stderr.flush()
+                    if "reserve + set-up passes" in ln:
+                        marks["setup"] = time.time()
+                    if "warm-up steps" in ln:
+                        marks["past"] = True
+            th = threading.Thread(target=pump, daemon=True)
+            th.start()
+            stuck = False
+            while proc.poll() is None:
+                time.sleep(1.0)
+                if marks["setup"] is not None and not marks["past"] and time.time() - marks["setup"] > args.setup_seconds:
+                    stuck = True
+                    proc.kill()
+                    break
+            out = proc.stdout.read()
+            proc.wait()
+            lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+            if lines and not stuck:
+                print(lines[-1], flush=True)
+                sys.exit(0)
+            if not stuck:
+                sys.stderr.write(out[-2000:])
+                sys.exit(proc.returncode or 1)
+            log("set-up passes did not finish within %d s: child killed%s" % (args.setup_seconds, ", repeating with --inflight 3" if attempt == 0 else ""))
+        sys.exit(1)
+
+    if os.environ.get("EH_BENCH_SIMULATE"):                  # tests/test_bench_supervisor.py: a child that hangs in its set-up passes, or not
+        log("reserve + set-up passes (simulated)")
+        if os.environ["EH_BENCH_SIMULATE"] == "hang" or (os.environ["EH_BENCH_SIMULATE"] == "hang_once" and args.inflight != 3):
+            time.sleep(3600)
+        log("warm-up steps")
+        print(json.dumps({"metric": "simulated", "inflight": args.inflight}), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -185,24 +245,19 @@ def main():
     seed = (1, 2, 3)
     # Context set-up, not a step: every context reserves its device memory for a full batch (eh_reserve) and
     # runs one untimed full-size pass on its own HIP stream, which makes the runtime allocate that queue's
-    # scratch for the full grid.  Otherwise the first pass of a context (32 GiB of hipMalloc plus the
-    # queue's scratch) would land inside the timed region whenever W is smaller than the number of contexts.
+    # scratch.  Otherwise the first pass of a context (its hipMallocs plus the queue's scratch) would land
+    # inside the timed region whenever W is smaller than the number of contexts.
+    log("reserve + set-up passes (%d contexts)" % nctx)
     for e in engines:
         e.reserve(n)
+    # one context at a time: the first dispatch on a HIP stream makes the runtime allocate that hardware queue's scratch
+    # (the kernel recurses: 6 KiB of stack per lane for every wavefront slot of the device), which must not have to wait
+    # for memory or wavefront slots that the persistent workgroups of five other passes are holding
     for e, st in zip(engines, streams):
         e.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=n, stream=st.cuda_stream)
-    for e in engines:
         e.sync()
-    # The set-up pass ran cases 1 .. n: keep what the engine produced for the cases the CPU oracle leg will run (status,
-    # length, draw count, SHA-1 of the bytes), so that leg doubles as the parity check of this very run.
-    gpu_ref = None
-    if args.cpu_sample > 0 and world == 1:
-        import hashlib
-        e0, m = engines[0], min(args.cpu_sample, n)
-        st0, ln0, dr0 = e0.status()[:m].copy(), e0.lens()[:m].copy(), e0.diag()[0][:m].copy()
-        gpu_ref = (st0, ln0, dr0, [hashlib.sha1(e0.fetch(i, int(ln0[i]))).digest() for i in range(m)])
-
     raw = [st.cuda_stream for st in streams]
+    log("warm-up steps")
     # rank r, step k -> case numbers ((k*world + r) * n) + 1 ... (shard.run_steps, the loop tests/test_dist_gloo.py drives too)
     strong = args.scaling == "strong"
     overflow_sites = {}
@@ -220,6 +275,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    log("timed steps")
     t0 = time.perf_counter()
     timed = shard.run_steps(engines, raw, args.warmup, args.steps, rank, world, n, seed, on_result=on_result, strong=strong)
     torch.cuda.synchronize()
@@ -227,54 +283,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    log("timed steps done: %.3f s per step" % (dt / max(args.steps, 1)))
     out_bytes, kern_ms, status_counts = timed["out_bytes"], timed["kernel_ms"], timed["status_counts"]
-
-    # ---- PCIe-inclusive leg (rank 0, N=1): one more pass whose outputs are also brought to host memory, case-ordered,
-    # through the boundary call a host-side consumer uses (eh_result_download into pinned memory)
-    pcie = None
-    if args.pcie and world == 1 and args.steps > 0:
-        cap = int(out_bytes / args.steps * 1.5) + (1 << 30)
-        try:
-            hbuf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
-            kind = "pinned"
-        except RuntimeError:
-            hbuf = torch.empty(cap, dtype=torch.uint8)
-            kind = "pageable"
-        e = engines[0]
-        kx = args.warmup + args.steps + 100
-        torch.cuda.synchronize()
-        tp = time.perf_counter()
-        e.fuzz_batch(seed=seed, first_case=shard.weak_first_case(kx, rank, world, n), corpus_first=0, n=n, stream=raw[0])
-        e.sync()
-        tk = time.perf_counter()
-        try:
-            off, _ = e.download_into(hbuf.data_ptr(), cap)
-            td = time.perf_counter()
-            ob = int(off[-1])
-            pcie = {"pcie_inclusive_MBps": round(ob / (td - tp) / 1e6, 1), "download_GBps": round(ob / (td - tk) / 1e9, 2), "out_bytes": ob,
-                    "host_buffer": kind, "pass_s": round(tk - tp, 3), "download_s": round(td - tk, 3),
-                    "note": "one pass + eh_result_download (device gather into case order, 2 bounce buffers, D2H overlapped), not overlapped with the next pass"}
-        except ea.EngineError as ex:
-            pcie = {"error": str(ex)}
-        del hbuf
-
-    # ---- second, labelled figure: the same steps under a per-case work budget (the round-1 configuration)
-    budgeted = None
-    if args.budget_mib > 0 and args.work_mib == 0 and world == 1:
-        for e in engines:
-            e.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
-                        max_case_bytes=args.case_mib << 20, max_case_work=args.budget_mib << 20, big_case_bytes=args.big_mib << 20,
-                        pool_bytes=args.pool_gib << 30)
-        bsteps = min(3, args.steps)
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        br = shard.run_steps(engines, raw, args.warmup + args.steps, bsteps, rank, world, n, seed)
-        torch.cuda.synchronize()
-        bdt = time.perf_counter() - tb
-        bbytes, bstat = br["out_bytes"], br["status_counts"]
-        budgeted = {"max_case_work": args.budget_mib << 20, "steps": bsteps, "value": round(bbytes / bdt / 1e6, 1), "unit": "MB/s",
-                    "cases_per_s": round(n * bsteps / bdt, 1), "ms_per_step": round(bdt / bsteps * 1e3, 3),
-                    "case_status_budget": int(bstat[5]), "case_status_overflow": int(bstat[2])}
 
     my_cases = (shard.case_range(n, rank, world)[1] if strong else n) * args.steps
     dt_all, out_all, cases_all = shard.reduce_over_ranks(dt, out_bytes, my_cases, dist, dev)
@@ -291,13 +301,13 @@ def main():
         # when the configuration matches, else null.
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_summary.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r03_summary.json")) as fh:
                 ps = json.load(fh)
             wk = ps["workload_key"]
             if (wk["cases"], wk["size"], wk["max_case_work"], wk["max_case_bytes"], wk["mutators"], wk["patterns"]) == \
                     (n, size, args.work_mib << 20, args.case_mib << 20, muts, pats):       # per launch: independent of how many overlap
                 traffic = int(ps["traffic_bytes_per_launch"]["total_fetch_x2_plus_write"])
-                traffic_src = "profiles/r02_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch)"
+                traffic_src = "profiles/r03_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch; a committed counter run of this workload, not measured in this process)"
         except (OSError, KeyError, ValueError):
             pass
         res = {
@@ -315,7 +325,7 @@ def main():
                                "10% length/CRC-framed)" if args.corpus == "mixed" else "uniform random bytes",
                                pats, muts, len(muts.split(",")), nmut_total,
                                ",".join(m for m, _, _ in ea.mutator_table() if m not in [x.split("=")[0] for x in muts.split(",")]) or "none"),
-                "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream before the W warm-up steps",
+                "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream, one after the other, before the W warm-up steps",
                 "max_case_bytes": args.case_mib << 20, "big_case_bytes": args.big_mib << 20, "max_case_work": args.work_mib << 20,
                 "workgroups_per_pass": args.max_slots or "one per wavefront the device holds (8 per CU)", "pool_gib": args.pool_gib,
                 "work_area_pool": engines[0].pool_stats(),
@@ -338,19 +348,102 @@ def main():
                                    "about 1/%d of the device's" % (nctx, nctx),
                          "achieved_all_in_flight": round(alg_bytes / (dt_all / args.steps) / 1e9, 2)},
         }
-        if budgeted is not None:
-            res["with_work_budget"] = budgeted
-        if pcie is not None:
-            res["pcie"] = pcie
-        # ---- CPU baseline: the oracle (C++ restatement of the reference) on the host cores, N=1 only
-        if args.cpu_sample > 0 and world == 1:
-            cb = cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref)
-            res["parity_checked"] = cb.pop("parity_checked")
-            res["parity"] = {"checked_bit_exact": res["parity_checked"], "not_compared": cb.pop("parity_skipped"),
-                             "what": "cases 1..%d of this run (set-up pass of context 0): status, length, PRNG draw count and SHA-1 of every "
-                                     "output vs the oracle's; not compared = engine-only status (2, 3) or cut by the oracle leg's watchdog" % min(args.cpu_sample, n)}
-            res["cpu_baseline"] = cb
-        print(json.dumps(res))
+        # ---- legs that are not the headline: they run AFTER the result exists, under a watchdog that prints the line without them
+        # if one of them does not come back (a hung leg must not cost the measured result)
+        def leg_pcie():
+            # PCIe-inclusive leg: one more pass whose outputs are also brought to host memory, case-ordered, through the
+            # boundary call a host-side consumer uses (eh_result_download into pinned memory)
+            cap = int(out_bytes / args.steps * 1.5) + (1 << 30)
+            try:
+                hbuf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+                kind = "pinned"
+            except RuntimeError:
+                hbuf = torch.empty(cap, dtype=torch.uint8)
+                kind = "pageable"
+            e = engines[0]
+            kx = args.warmup + args.steps + 100
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            e.fuzz_batch(seed=seed, first_case=shard.weak_first_case(kx, rank, world, n), corpus_first=0, n=n, stream=raw[0])
+            e.sync()
+            tk = time.perf_counter()
+            try:
+                off, _ = e.download_into(hbuf.data_ptr(), cap)
+                td = time.perf_counter()
+                ob = int(off[-1])
+                return {"pcie_inclusive_MBps": round(ob / (td - tp) / 1e6, 1), "download_GBps": round(ob / (td - tk) / 1e9, 2), "out_bytes": ob,
+                        "host_buffer": kind, "pass_s": round(tk - tp, 3), "download_s": round(td - tk, 3),
+                        "note": "one pass + eh_result_download (device gather into case order, 2 bounce buffers, D2H overlapped), not overlapped with the next pass"}
+            except ea.EngineError as ex:
+                return {"error": str(ex)}
+
+        def leg_budget():
+            # second, labelled figure: the same steps under a per-case work budget (the round-1 configuration)
+            for e in engines:
+                e.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
+                            max_case_bytes=args.case_mib << 20, max_case_work=args.budget_mib << 20, big_case_bytes=args.big_mib << 20,
+                            pool_bytes=args.pool_gib << 30)
+            bsteps = min(2 * nctx, args.steps)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            br = shard.run_steps(engines, raw, args.warmup + args.steps, bsteps, rank, world, n, seed)
+            torch.cuda.synchronize()
+            bdt = time.perf_counter() - tb
+            bbytes, bstat = br["out_bytes"], br["status_counts"]
+            return {"max_case_work": args.budget_mib << 20, "steps": bsteps, "value": round(bbytes / bdt / 1e6, 1), "unit": "MB/s",
+                    "cases_per_s": round(n * bsteps / bdt, 1), "ms_per_step": round(bdt / bsteps * 1e3, 3),
+                    "case_status_budget": int(bstat[5]), "case_status_overflow": int(bstat[2])}
+
+        import threading
+        state = {"leg": "", "done": False}
+        lock = threading.Lock()
+
+        def emit():
+            with lock:
+                if not state["done"]:
+                    state["done"] = True
+                    print(json.dumps(res), flush=True)
+
+        def watchdog():
+            deadline = time.time() + args.extras_seconds
+            while time.time() < deadline:
+                time.sleep(0.5)
+                if state["done"]:
+                    return
+            res["extras_timed_out"] = "leg '%s' did not finish within %d s; the result above does not depend on it" % (state["leg"], args.extras_seconds)
+            emit()
+            os._exit(0)
+
+        if world == 1:
+            threading.Thread(target=watchdog, daemon=True).start()
+            # the CPU oracle leg first: it is also the parity check of this very run
+            if args.cpu_sample > 0:
+                state["leg"] = "cpu_baseline"
+                log("parity sample: cases 1..%d once more on context 0, alone on the device" % min(args.cpu_sample, n))
+                import hashlib
+                e0, m = engines[0], min(args.cpu_sample, n)
+                e0.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=m, stream=raw[0])
+                e0.sync()
+                st0, ln0, dr0 = e0.status()[:m].copy(), e0.lens()[:m].copy(), e0.diag()[0][:m].copy()
+                gpu_ref = (st0, ln0, dr0, [hashlib.sha1(e0.fetch(i, int(ln0[i]))).digest() for i in range(m)])
+                log("CPU oracle leg + parity check")
+                cb = cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref)
+                res["parity_checked"] = cb.pop("parity_checked")
+                res["parity"] = {"checked_bit_exact": res["parity_checked"], "not_compared": cb.pop("parity_skipped"),
+                                 "what": "cases 1..%d of this run (the case numbers of the set-up passes, run once more on context 0 after the timed steps): status, length, PRNG draw count and SHA-1 of every "
+                                         "output vs the oracle's; not compared = engine-only status (2, 3) or cut by the oracle leg's watchdog" % min(args.cpu_sample, n)}
+                res["cpu_baseline"] = cb
+            if args.pcie and args.steps > 0:
+                state["leg"] = "pcie"
+                log("PCIe leg")
+                res["pcie"] = leg_pcie()
+            if args.budget_mib > 0 and args.work_mib == 0:
+                state["leg"] = "with_work_budget"
+                log("work-budget leg")
+                res["with_work_budget"] = leg_budget()
+        emit()
+        sys.stdout.flush()
+        os._exit(0) if world == 1 else None
     if dist is not None:
         dist.destroy_process_group()
 

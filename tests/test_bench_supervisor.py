@@ -1,0 +1,37 @@
+"""bench.py runs a single-GPU benchmark in a child process and replaces a child that never leaves its set-up passes (seen twice
+when device memory was nearly exhausted) by a more frugal one: the driver must always get its JSON line.  The child is simulated
+here (EH_BENCH_SIMULATE); no GPU, no engine."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(sim, *args):
+    env = dict(os.environ, EH_BENCH_SIMULATE=sim)
+    env.pop("EH_BENCH_CHILD", None)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--setup-seconds", "3"] + list(args), env=env, capture_output=True, text=True, timeout=120)
+    return r, time.time() - t0
+
+
+def test_healthy_child_prints_one_line():
+    r, _ = _run("ok")
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1 and json.loads(lines[0])["inflight"] == 6
+
+
+def test_child_stuck_in_setup_is_replaced_by_a_frugal_one():
+    r, dt = _run("hang_once")
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1 and json.loads(lines[0])["inflight"] == 3
+    assert "repeating with --inflight 3" in r.stderr and dt < 60
+
+
+def test_two_stuck_children_fail_instead_of_hanging():
+    r, dt = _run("hang")
+    assert r.returncode != 0 and dt < 60 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

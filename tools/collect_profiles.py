@@ -2,15 +2,14 @@
 """Condense the rocprofv3 outputs of one profiling call (gpurun_out/prof_<tag>: --kernel-trace --stats; pmc_fetch,
 pmc_write, pmc_sq: one --pmc pass each) into the tracked summaries under profiles/.
 
-One eh_fuzz_batch ("launch") is one dispatch of eh_mutate_kernel (tier 0 and the overflow tiers are workgroup ranges
-of the same grid).
+One eh_fuzz_batch ("launch") is one dispatch of eh_mutate_kernel.
 
 Usage: tools/collect_profiles.py <round-tag, e.g. r02>"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 KERNEL = "eh_mutate_kernel"
@@ -55,7 +54,9 @@ with open(os.path.join(P, tag + "_kernel_trace_mutate.csv"), "w", newline="") as
 
 # ---- counters: sum over the dispatches of a launch, mean over launches
 rows, hdr = [], None
-for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_icache"):
+    if not glob.glob(os.path.join(G, d + "/**/*counter_collection.csv"), recursive=True):
+        continue
     with open(one(d + "/**/*counter_collection.csv")) as fh:
         rd = csv.reader(fh)
         h = next(rd)
@@ -84,8 +85,8 @@ if bl:
 k = [r for r in csv.DictReader(open(os.path.join(P, tag + "_kernel_stats.csv"))) if KERNEL in r["Name"]][0]
 out = {
     "round": tag,
-    "command": "rocprofv3 --kernel-trace --stats -f csv -- python bench.py --steps 6 --warmup 3 --cpu-sample 0 --budget-mib 0   (defaults otherwise: 65536 x 4096 B, full default mutator table, no work budget, 3 passes in flight)",
-    "pmc_command": "rocprofv3 --pmc <COUNTERS> -f csv -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 --budget-mib 0   (separate runs for FETCH_SIZE, WRITE_SIZE and the SQ set)",
+    "command": "rocprofv3 --kernel-trace --stats -f csv -- python bench.py --steps 12 --warmup 3 --cpu-sample 0 --budget-mib 0 --pcie 0   (defaults otherwise: 65536 x 4096 B, full default mutator table, no work budget, %d passes in flight)" % bench["config"]["passes_in_flight"],
+    "pmc_command": "rocprofv3 --pmc <COUNTERS> -f csv -- python bench.py --inflight 1 --steps 1 --warmup 0 --cpu-sample 0 --budget-mib 0 --pcie 0   (separate runs for FETCH_SIZE, WRITE_SIZE, the SQ set and the instruction-cache set; one pass at a time: the counters serialise dispatches)",
     "kernel": k["Name"], "dispatches": int(k["Calls"]), "dispatches_per_launch": group, "launches": len(launches),
     "avg_ms_per_dispatch_rocprof_stats": float(k["AverageNs"]) / 1e6,
     "all_dispatches_ms": [round(x, 3) for x in spans],
@@ -93,8 +94,8 @@ out = {
     "timed_span_ms_per_step_rocprof": (max(int(r[0]["End_Timestamp"]) for r in launches[-bench["steps"]:]) -
                                        min(int(r[0]["Start_Timestamp"]) for r in launches[-bench["steps"]:])) / 1e6 / bench["steps"],
     "note": "the first (contexts + warmup) dispatches are the per-context set-up passes and the warm-up steps; the last `steps` dispatches are the timed ones "
-            "bench.py's HIP events cover.  Every pass runs different case numbers: its duration follows its slowest cases (a few "
-            "multi-second single-wavefront cases per 65536)",
+            "bench.py's HIP events cover.  The passes in flight share the device: a dispatch lasts as long as its slowest cases (a few "
+            "single-wavefront cases of seconds per 65536) while its workgroups give way to those of the following passes",
     "avg_ms_bench_hip_events_same_run": bench["roofline"]["kernel_ms_avg"],
     "share_of_gpu_time_pct": float(k["Percentage"]),
     "per_launch_counters_mean": mean,
@@ -104,6 +105,8 @@ out = {
                                  "write": mean["WRITE_SIZE"] * 1024,
                                  "total_fetch_x2_plus_write": (2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024},
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+    "instruction_cache": ({"requests": mean["SQC_ICACHE_REQ"], "misses": mean["SQC_ICACHE_MISSES"], "miss_rate": mean["SQC_ICACHE_MISSES"] / max(mean["SQC_ICACHE_REQ"], 1.0)}
+                          if "SQC_ICACHE_REQ" in mean else None),
     "sq_breakdown_of_wave_cycles": {"wait_any(s_waitcnt)": mean["SQ_WAIT_ANY"] / mean["SQ_WAVE_CYCLES"],
                                     "active_inst": mean["SQ_ACTIVE_INST_ANY"] / mean["SQ_WAVE_CYCLES"],
                                     "wait_inst(issue stall)": mean["SQ_WAIT_INST_ANY"] / mean["SQ_WAVE_CYCLES"]},
@@ -111,6 +114,9 @@ out = {
                      "max_case_work": bench["config"]["max_case_work"], "max_case_bytes": bench["config"]["max_case_bytes"],
                      "mutators": bench["config"]["workload"].split("mutators ")[1].split(" (")[0], "patterns": "od,nd,bu",
                      "inflight": bench["config"]["passes_in_flight"]},
+    "traffic_note": "FETCH_SIZE counts 64 B per L2-to-fabric read request (Infinity-Cache hits included): the x2 correction of the guide holds for "
+                    "wide streaming reads; this kernel's reads are dominated by 4-8 byte gathers into per-case tables (fuse2 lookups), for which a "
+                    "request IS 64 B, so the true read traffic lies between fetch_raw and fetch_x2",
 }
 with open(os.path.join(P, tag + "_summary.json"), "w") as fh:
     json.dump(out, fh, indent=1)
