@@ -145,8 +145,8 @@ def main():
                     "long single-wavefront cases — overlaps with the bulk of the next ones.  Every context owns its output arena (--out-gib) and its slots "
                     "(--max-slots x --case-mib); larger work areas come from one pool shared by all contexts (--pool-gib)")
     ap.add_argument("--setup-seconds", type=int, default=150, help="single-GPU runs execute in a child process; a child whose set-up passes (the first "
-                    "dispatch on every HIP stream) have not finished after this many seconds is killed and the run repeated once with "
-                    "--inflight 3 (0 = no supervision)")
+                    "dispatch on every HIP stream) have not finished after this many seconds is killed and the run repeated with "
+                    "--inflight 3, then 1 (0 = no supervision)")
     args = ap.parse_args()
 
     # ---- supervision (single GPU only): the run proper happens in a child process.  Twice in this round's development a run
@@ -155,7 +155,7 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.setup_seconds > 0 and not os.environ.get("EH_BENCH_CHILD"):
         import subprocess
         import threading
-        for attempt, extra in enumerate(([], ["--inflight", "3"])):
+        for attempt, extra in enumerate(([], ["--inflight", "3"], ["--inflight", "1"])):
             env = dict(os.environ, EH_BENCH_CHILD="1")
             proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             marks = {"setup": None, "past": False}
@@ -186,7 +186,7 @@ def main():
             if not stuck:
                 sys.stderr.write(out[-2000:])
                 sys.exit(proc.returncode or 1)
-            log("set-up passes did not finish within %d s: child killed%s" % (args.setup_seconds, ", repeating with --inflight 3" if attempt == 0 else ""))
+            log("set-up passes did not finish within %d s: child killed%s" % (args.setup_seconds, ", repeating with --inflight %d" % (3, 1)[attempt] if attempt < 2 else ""))
         sys.exit(1)
 
     if os.environ.get("EH_BENCH_SIMULATE"):                  # tests/test_bench_supervisor.py: a child that hangs in its set-up passes, or not
