@@ -16,8 +16,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -1475,6 +1477,65 @@ int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, 
     HIPCHK(ctx, hipStreamSynchronize(ctx->dl_copy));
     HIPCHK(ctx, hipGetLastError());
   }
+  return EH_OK;
+}
+// erlamsa_out:file_writer/1 (erlamsa_out.erl:103-123): Tokens = re:split(Str, "%n"), Filename = the tokens joined by
+// integer_to_list(N) (build_name/3) — every "%n" of the template becomes the case number.
+static std::string build_name(const std::string& tmpl, uint64_t n) {
+  const std::string num = std::to_string(n);
+  std::string out; size_t pos = 0;
+  for (;;) {
+    size_t e = tmpl.find("%n", pos);
+    if (e == std::string::npos) { out.append(tmpl, pos, std::string::npos); break; }
+    out.append(tmpl, pos, e - pos); out += num; pos = e + 2;
+  }
+  return out;
+}
+int eh_result_write_files(eh_ctx* ctx, const char* name_template, uint64_t first_number, uint32_t threads, uint64_t* files_written, uint64_t* bytes_written, uint64_t* not_written) {
+  if (!ctx || !name_template) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  uint64_t in_b = 0, total = 0, n = 0;
+  int rc = eh_result_totals(ctx, &in_b, &total, &n);
+  if (rc) return rc;
+  // one case-ordered download (device gather + overlapped copies), then the files are written by a few host threads
+  std::vector<uint64_t> off(n + 1); std::vector<int32_t> st(n ? n : 1);
+  uint8_t* host = nullptr;
+  bool pinned = total > 0 && hipHostMalloc((void**)&host, total, 0) == hipSuccess;
+  if (total > 0 && !pinned) { host = (uint8_t*)malloc(total); if (!host) { ctx->err = "eh_result_write_files: out of host memory"; return EH_E_NOMEM; } }
+  rc = eh_result_download(ctx, host, total, off.data(), st.data());
+  std::atomic<uint64_t> next{0}, files{0}, bytes{0}, skipped{0}; std::atomic<int> failed{0};
+  std::string first_error;
+  std::mutex err_lock;
+  if (!rc) {
+    const std::string tmpl(name_template);
+    auto work = [&]() {
+      for (;;) {
+        uint64_t i = next.fetch_add(1);
+        if (i >= n || failed.load()) return;
+        // the reference opens the file inside the worker, after the mutation: a case whose worker died or was killed
+        // (statuses 1, 5) or that stopped at an engine limit (2, 3, 4) leaves no file
+        if (st[i] != EH_CASE_OK) { skipped++; continue; }
+        const std::string name = build_name(tmpl, first_number + i);
+        FILE* f = fopen(name.c_str(), "wb");
+        if (!f) { failed = 1; std::lock_guard<std::mutex> g(err_lock); if (first_error.empty()) first_error = "Error opening file '" + name + "'"; return; }
+        const uint64_t len = off[i + 1] - off[i];
+        if (len && fwrite(host + off[i], 1, len, f) != len) { failed = 1; std::lock_guard<std::mutex> g(err_lock); if (first_error.empty()) first_error = "short write to '" + name + "'"; }
+        fclose(f);
+        files++; bytes += len;
+      }
+    };
+    uint32_t nt = threads ? threads : 8; if (nt > 64) nt = 64; if (nt > n) nt = (uint32_t)(n ? n : 1);
+    std::vector<std::thread> ts;
+    for (uint32_t t = 1; t < nt; t++) ts.emplace_back(work);
+    work();
+    for (auto& t : ts) t.join();
+  }
+  if (pinned) (void)hipHostFree(host); else free(host);
+  if (files_written) *files_written = files.load();
+  if (bytes_written) *bytes_written = bytes.load();
+  if (not_written) *not_written = skipped.load();
+  if (rc) return rc;
+  if (failed.load()) { ctx->err = first_error; return EH_E_INVALID; }
   return EH_OK;
 }
 int eh_result_fetch(eh_ctx* ctx, uint64_t i, uint8_t* buf, uint64_t cap, uint64_t* out_len) {

@@ -21,7 +21,7 @@ CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BU
 # every symbol include/erlamsa_hip.h declares
 ABI_SYMBOLS = [
     "eh_create", "eh_destroy", "eh_configure", "eh_corpus_upload", "eh_corpus_attach", "eh_fuzz_batch",
-    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_fetch", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_peak", "eh_result_meta", "eh_result_prof", "eh_selftest_movers",
+    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_fetch", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_peak", "eh_result_meta", "eh_result_write_files", "eh_result_prof", "eh_selftest_movers",
     "eh_last_kernel_ms", "eh_pool_stats", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
@@ -79,6 +79,7 @@ def load_library():
     lib.eh_result_diag.argtypes = [vp, vp, vp]
     lib.eh_result_cycles.argtypes = [vp, vp]
     lib.eh_result_peak.argtypes = [vp, vp]
+    lib.eh_result_write_files.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_uint32, u64p, u64p, u64p]
     lib.eh_result_meta.argtypes = [vp, C.c_uint64, vp, C.c_uint64, u64p]
     lib.eh_result_prof.argtypes = [vp, vp]
     lib.eh_selftest_movers.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
@@ -277,6 +278,13 @@ class Engine:
         cyc = np.zeros(max(n, 1), dtype=np.uint64)
         self._chk(self.lib.eh_result_cycles(self.h, cyc.ctypes.data))
         return cyc[:n]
+
+    def write_files(self, template, first_number=1, threads=0):
+        """erlamsa_out's file sink: every EH_CASE_OK case of the last batch -> template with "%n" = case number.
+        -> (files written, bytes written, cases without a file)"""
+        f, b, s = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.eh_result_write_files(self.h, template.encode(), first_number, threads, C.byref(f), C.byref(b), C.byref(s)))
+        return f.value, b.value, s.value
 
     def meta(self, i):
         """Meta trace of case i (configure with flags=EH_FLAG_META_TRACE): list of (kind, name), kind in 'failed', 'used',

@@ -208,6 +208,21 @@ static ERL_NIF_TERM nif_flush(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[
   enif_mutex_unlock(r->lock);
   return ret;
 }
+/* write_files_nif(Ctx, Template :: string(), FirstN) -> {ok, Files, Bytes, NotWritten} | {error, _}
+ * erlamsa_out:file_writer/1 for a whole batch: every case of the context's last batch that ended ok goes to the file named
+ * by Template with "%n" = case number (erlamsa_out.erl:103-123), written by host threads straight from one download. */
+static ERL_NIF_TERM nif_write_files(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  (void)argc; ctx_res* r; char tmpl[1024]; ErlNifUInt64 first;
+  if (!enif_get_resource(env, argv[0], ctx_type, (void**)&r) || enif_get_string(env, argv[1], tmpl, sizeof(tmpl), ERL_NIF_LATIN1) <= 0 ||
+      !enif_get_uint64(env, argv[2], &first)) return enif_make_badarg(env);
+  uint64_t files = 0, bytes = 0, skipped = 0;
+  enif_mutex_lock(r->lock);
+  int rc = eh_result_write_files(r->ctx, tmpl, (uint64_t)first, 0, &files, &bytes, &skipped);
+  ERL_NIF_TERM ret = rc ? mk_error(env, r->ctx, rc)
+                        : enif_make_tuple4(env, enif_make_atom(env, "ok"), enif_make_uint64(env, files), enif_make_uint64(env, bytes), enif_make_uint64(env, skipped));
+  enif_mutex_unlock(r->lock);
+  return ret;
+}
 static ERL_NIF_TERM nif_poll(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   (void)argc; ctx_res* r; ErlNifUInt64 ticket;
   if (!enif_get_resource(env, argv[0], ctx_type, (void**)&r) || !enif_get_uint64(env, argv[1], &ticket)) return enif_make_badarg(env);
@@ -239,5 +254,6 @@ static ErlNifFunc funcs[] = {
   {"submit_nif", 4, nif_submit, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"flush_nif", 1, nif_flush, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"poll_nif", 2, nif_poll, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"write_files_nif", 3, nif_write_files, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 ERL_NIF_INIT(erlamsa_hip, funcs, load, NULL, NULL, NULL)

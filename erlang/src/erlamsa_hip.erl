@@ -16,6 +16,7 @@
 -module(erlamsa_hip).
 -export([init/0, open/1, fuzz_batch/2, fuzz_calls/2, fuzz_batch_nif/5, fuzz_calls_nif/4, capabilities/0, fuzzer/3]).
 -export([submit/3, flush/1, poll/2, submit_nif/4, flush_nif/1, poll_nif/2]).
+-export([write_files/3, write_files_nif/3]).
 -on_load(init/0).
 
 init() ->
@@ -28,6 +29,7 @@ fuzz_calls_nif(_Ctx, _Opts, _Seeds, _Bins) -> erlang:nif_error(nif_not_loaded).
 submit_nif(_Ctx, _Opts, _Seed, _Bin) -> erlang:nif_error(nif_not_loaded).
 flush_nif(_Ctx) -> erlang:nif_error(nif_not_loaded).
 poll_nif(_Ctx, _Ticket) -> erlang:nif_error(nif_not_loaded).
+write_files_nif(_Ctx, _Template, _FirstN) -> erlang:nif_error(nif_not_loaded).
 
 %% Dict: the options map of erlamsa_main:fuzzer/1 (seed, mutations, patterns, blockscale) plus first_case / device
 fuzz_batch(Bins, Dict) ->
@@ -41,6 +43,10 @@ fuzz_calls(Calls, Dict) ->
 
 %% Request coalescing for erlamsa_fsupervisor-style services: every request process submits and then polls; a timer
 %% process calls flush/1 every ~200 us (a full batch launches itself).  poll/2 -> {ok, Status, Bin} | again.
+%% `-o "out-%n.bin"` for a batch: the files of the cases fuzz_batch/2 has just produced on this node's context, named like
+%% erlamsa_out:file_writer/1 names them (erlamsa_out.erl:103-123) -> {ok, Files, Bytes, NotWritten}.
+write_files(Template, FirstN, Dict) -> write_files_nif(ctx(Dict), Template, FirstN).
+
 %% The coalescer has a context of its own: the engine refuses batches, corpora and configurations on a context with
 %% requests pending ({error, wrong_call_order}), because they would overwrite what those requests run with.
 submit(Bin, Seed, Dict) -> submit_nif(co_ctx(Dict), opts(Dict), Seed, Bin).

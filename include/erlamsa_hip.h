@@ -174,6 +174,14 @@ int eh_result_diag(eh_ctx* ctx, uint64_t* draws, int32_t* last_mutator);
 /* Per-case shader-clock ticks spent by the wavefront that ran the case (diagnostic). */
 int eh_result_cycles(eh_ctx* ctx, uint64_t* cycles);
 
+/* The file sink of erlamsa_out (erlamsa_out.erl:103-123, `-o "name-%n.ext"`): writes every case of the last batch that
+ * ended EH_CASE_OK to the file named by the template with each "%n" replaced by the case number (first_number + i), as
+ * build_name/3 does.  The results come to the host in one case-ordered download; `threads` host threads write the files
+ * (0 => 8).  Cases with another status leave no file (the reference opens the file inside the worker, after the mutation)
+ * and are counted in *not_written.  Any of the three counters may be NULL. */
+int eh_result_write_files(eh_ctx* ctx, const char* name_template, uint64_t first_number, uint32_t threads,
+                          uint64_t* files_written, uint64_t* bytes_written, uint64_t* not_written);
+
 /* Meta trace of case i of the last batch (EH_FLAG_META_TRACE): what erlamsa's -M / meta logger prints for a case
  * (erlamsa_main.erl:58-70) — the list erlamsa_patterns.erl and mux_fuzzers (erlamsa_mutations.erl:1269-1279) build:
  * {pattern, P}, {used, Name}, {failed, Name}, nested scheduler calls included — in the order the entries are made (the

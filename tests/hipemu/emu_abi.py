@@ -93,6 +93,23 @@ for rep in range(2):                                              # twice: the a
     flat = bytes(np.ctypeslib.as_array(C.cast(dptr, C.POINTER(C.c_uint8)), shape=(max(tot, 1),))[:tot])
     assert flat == b"".join(w3)
 e3.close()
+# ---- erlamsa_out's file sink (erlamsa_out.erl:103-123): "%n" -> case number, one file per EH_CASE_OK case, bytes = the case's output
+import tempfile
+with tempfile.TemporaryDirectory() as td:
+    ef = ea.Engine(0)
+    ef.configure(mutations="bd,bf,sr,num,ld", patterns="od,nd,bu")
+    ef.upload_corpus(data, off)
+    ef.fuzz_batch(seed=(4, 4, 4), first_case=11)
+    gotf, stf = ef.download()
+    nf, nb, ns = ef.write_files(os.path.join(td, "case-%n-of-%n.bin"), first_number=11, threads=3)
+    okc = [i for i in range(len(gotf)) if stf[i] == 0]
+    assert nf == len(okc) and ns == len(gotf) - len(okc) and nb == sum(len(gotf[i]) for i in okc)
+    for i in okc:
+        with open(os.path.join(td, "case-%d-of-%d.bin" % (11 + i, 11 + i)), "rb") as fh:
+            assert fh.read() == gotf[i], i
+    assert len(os.listdir(td)) == nf
+    assert code(ef.write_files, os.path.join(td, "no-such-dir", "x-%n")) == -1          # "Error opening file ..."
+    ef.close()
 # introspection tables mirror the reference's tables
 names = [m[0] for m in ea.mutator_table()]
 assert names[0] == "sgm" and names[-1] == "nil" and len(names) == 41

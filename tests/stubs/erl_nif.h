@@ -45,6 +45,7 @@ ERL_NIF_TERM enif_make_list_cell(ErlNifEnv*, ERL_NIF_TERM, ERL_NIF_TERM);
 ERL_NIF_TERM enif_make_tuple(ErlNifEnv*, unsigned cnt, ...);
 #define enif_make_tuple2(env, a, b) enif_make_tuple(env, 2, a, b)
 #define enif_make_tuple3(env, a, b, c) enif_make_tuple(env, 3, a, b, c)
+#define enif_make_tuple4(env, a, b, c, d) enif_make_tuple(env, 4, a, b, c, d)
 #define ERL_NIF_INIT(MOD, FUNCS, LOAD, RELOAD, UPGRADE, UNLOAD) \
   const ErlNifFunc* erl_nif_stub_funcs_##MOD(void) { (void)(LOAD); return FUNCS; }
 /* erl_nif.h: thread API */
