@@ -1,7 +1,7 @@
 """Oracle pinning, part 3: two independent models agree.
 
-tests/pymodel.py is a Python model of erlamsa_main:fuzzer/1 (set-up, direct/random generators, patterns od/nd/bu,
-28 mutators) transcribed from the reference's .erl sources without consulting oracle/oracle.cpp.  Here it is diffed
+tests/pymodel.py is a Python model of erlamsa_main:fuzzer/1 (set-up, direct/random generators, 8 of the 10 patterns — od nd bu
+sk sz cs co nu — and 37 of the 41 mutators: all but sgm, js, b64, zip) transcribed from the reference's .erl sources without consulting oracle/oracle.cpp.  Here it is diffed
 against the C++ oracle on 15 000 cases.  What both share is the author's reading of OTP's `random` and lists:sort/2 —
 the part only a BEAM run can pin (tests/golden/capture.escript)."""
 import os
