@@ -537,3 +537,28 @@ def test_meta_trace_equals_the_oracles():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
     import emu_meta
     assert emu_meta.run(n=96, size=900, seed=(5, 3, 8)) >= 100
+
+
+def test_two_rank_nccl_bench_smoke():
+    """bench.py over RCCL with 2 ranks on one node (arena broadcast, case-range sharding, MAX-over-ranks timing), weak and
+    strong: skipped on boxes with fewer than 2 GPUs (the builder's and the driver's test boxes have one; the 8-GPU runs are
+    the driver's)."""
+    if util.priming():
+        pytest.skip("no oracle involved")
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for scaling in ("weak", "strong"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
+               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--cases", "4096", "--inflight", "2", "--scaling", scaling,
+               "--out-gib", "4", "--pool-gib", "8", "--cpu-sample", "0", "--budget-mib", "0", "--pcie", "0"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-1500:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
