@@ -549,8 +549,9 @@ def test_two_rank_nccl_bench_smoke():
     import os
     import subprocess
     import sys
-    import torch
-    if torch.cuda.device_count() < 2:
+    # (asked in a child: this process may have loaded the engine's HIP runtime already, and torch must initialise first)
+    q = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+    if q.returncode != 0 or int((q.stdout.strip().splitlines() or ["0"])[-1]) < 2:
         pytest.skip("needs 2 GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for scaling in ("weak", "strong"):
