@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -764,6 +765,7 @@ struct eh_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // request coalescing (eh_submit / eh_flush / eh_poll)
   std::recursive_mutex co_lock;
+  std::condition_variable_any co_cv; bool co_collecting = false;   // a thread is waiting for / downloading the in-flight batch (lock released)
   bool co_internal = false;                             // co_launch / co_collect are calling the batch entry points themselves
   uint64_t co_next_ticket = 1, co_flush_cases = 4096, co_flush_bytes = 64ull << 20;
   std::vector<uint8_t> co_data; std::vector<uint64_t> co_off{0}; std::vector<int64_t> co_seeds; std::vector<uint64_t> co_tickets;   // pending batch
@@ -1268,33 +1270,43 @@ int eh_fuzz_calls(eh_ctx* ctx, const int64_t* seeds, uint64_t corpus_first, uint
   return launch(ctx, 1, dummy, 1, corpus_first, n, (hipStream_t)stream);
 }
 // ---- request coalescing -------------------------------------------------------------------------------------
-// co_lock held.  Brings the launched batch's results to the host (one download) and files them under their tickets.
+// Brings the launched batch's results to the host (one download) and files them under their tickets.
 static int co_collect(eh_ctx* ctx) {
+  // (the caller holds co_lock exactly once.)  The wait for the batch and the download happen WITHOUT the lock, so that
+  // other threads keep submitting to the next batch meanwhile; a second collector waits for the first.
+  while (ctx->co_collecting) ctx->co_cv.wait(ctx->co_lock);
   if (!ctx->co_inflight) return EH_OK;
+  ctx->co_collecting = true;
+  const std::vector<uint64_t> tickets = ctx->co_inflight_tickets;
+  const uint64_t n = tickets.size();
+  ctx->co_lock.unlock();
   uint64_t in_b = 0, out_b = 0, nc = 0;
+  std::vector<uint8_t> data; std::vector<uint64_t> off(n + 1); std::vector<int32_t> st(n ? n : 1);
   int rc = eh_result_totals(ctx, &in_b, &out_b, &nc);
-  if (rc) return rc;
-  const uint64_t n = ctx->co_inflight_tickets.size();
-  if (nc != n) { ctx->err = "coalescer: the context's last batch is not the one that was flushed"; return EH_E_STATE; }
-  std::vector<uint8_t> data(out_b ? out_b : 1); std::vector<uint64_t> off(n + 1); std::vector<int32_t> st(n ? n : 1);
-  rc = eh_result_download(ctx, data.data(), data.size(), off.data(), st.data());
-  if (rc) return rc;
-  for (uint64_t i = 0; i < n; i++) {
-    bool dropped = false;
-    for (uint64_t t : ctx->co_cancelled) if (t == ctx->co_inflight_tickets[i]) dropped = true;
-    if (dropped) continue;
-    eh_ctx::CoResult r; r.out.assign(data.begin() + off[i], data.begin() + off[i + 1]); r.status = st[i];
-    ctx->co_done.emplace(ctx->co_inflight_tickets[i], std::move(r));
+  if (!rc && nc != n) { ctx->err = "coalescer: the context's last batch is not the one that was flushed"; rc = EH_E_STATE; }
+  if (!rc) { data.resize(out_b ? out_b : 1); rc = eh_result_download(ctx, data.data(), data.size(), off.data(), st.data()); }
+  ctx->co_lock.lock();
+  if (!rc) {
+    for (uint64_t i = 0; i < n; i++) {
+      bool dropped = false;
+      for (uint64_t t : ctx->co_cancelled) if (t == tickets[i]) dropped = true;
+      if (dropped) continue;
+      eh_ctx::CoResult r; r.out.assign(data.begin() + off[i], data.begin() + off[i + 1]); r.status = st[i];
+      ctx->co_done.emplace(tickets[i], std::move(r));
+    }
+    ctx->co_cancelled.clear();
+    ctx->co_inflight = false; ctx->co_inflight_tickets.clear();
   }
-  ctx->co_cancelled.clear();
-  ctx->co_inflight = false; ctx->co_inflight_tickets.clear();
-  return EH_OK;
+  ctx->co_collecting = false;
+  ctx->co_cv.notify_all();
+  return rc;
 }
 // co_lock held.  Launches the pending batch (after collecting the previous one: one result buffer per context).
 static int co_launch(eh_ctx* ctx) {
   if (ctx->co_tickets.empty()) return EH_OK;
   int rc = co_collect(ctx);
   if (rc) return rc;
+  if (ctx->co_tickets.empty()) return EH_OK;                        // (co_collect lets other threads in: one of them has launched the batch)
   const uint64_t n = ctx->co_tickets.size();
   ctx->co_internal = true;
   rc = eh_corpus_upload(ctx, ctx->co_data.data(), ctx->co_off.data(), n);
@@ -1316,19 +1328,20 @@ int eh_submit(eh_ctx* ctx, const uint8_t* data, uint64_t len, const int64_t seed
   if (!ctx->configured) { ctx->err = "configure first"; return EH_E_STATE; }
   std::lock_guard<std::recursive_mutex> g(ctx->co_lock);
   const size_t d0 = ctx->co_data.size(), o0 = ctx->co_off.size(), s0 = ctx->co_seeds.size(), t0 = ctx->co_tickets.size();
-  auto rollback = [&]() { ctx->co_data.resize(d0); ctx->co_off.resize(o0); ctx->co_seeds.resize(s0); ctx->co_tickets.resize(t0); };
+  const uint64_t mine = ctx->co_next_ticket;
   try {
     ctx->co_data.insert(ctx->co_data.end(), data, data + len);
     ctx->co_off.push_back(ctx->co_data.size());
     ctx->co_seeds.insert(ctx->co_seeds.end(), seed, seed + 3);
-    ctx->co_tickets.push_back(ctx->co_next_ticket);
-  } catch (const std::bad_alloc&) { rollback(); return EH_E_NOMEM; }
+    ctx->co_tickets.push_back(mine);
+  } catch (const std::bad_alloc&) { ctx->co_data.resize(d0); ctx->co_off.resize(o0); ctx->co_seeds.resize(s0); ctx->co_tickets.resize(t0); return EH_E_NOMEM; }
+  ctx->co_next_ticket++;                                  // (before any launch: co_collect lets other submitters in)
   if (ctx->co_tickets.size() >= ctx->co_flush_cases || ctx->co_data.size() >= ctx->co_flush_bytes) {
     int rc = co_launch(ctx);
     // a launch that fails takes this request back out (the caller gets no ticket for it); the others stay queued for the next flush
-    if (rc) { if (!ctx->co_tickets.empty()) rollback(); return rc; }
+    if (rc) { std::string why = ctx->err; (void)eh_cancel(ctx, mine); ctx->err = why; return rc; }
   }
-  *ticket = ctx->co_next_ticket++;
+  *ticket = mine;
   return EH_OK;
 }
 int eh_cancel(eh_ctx* ctx, uint64_t ticket) {

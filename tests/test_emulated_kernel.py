@@ -80,3 +80,10 @@ def test_emulated_meta_trace(emu_lib):
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_meta.py"), "18"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "meta ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_emulated_coalescing_from_threads(emu_lib):
+    """submitters, pollers and a flusher on one context at once: every ticket gets its request's own result"""
+    env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_coalesce_threads.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "threads ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
