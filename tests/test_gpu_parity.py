@@ -550,8 +550,12 @@ def test_two_rank_nccl_bench_smoke():
     import subprocess
     import sys
     # (asked in a child: this process may have loaded the engine's HIP runtime already, and torch must initialise first)
-    q = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
-    if q.returncode != 0 or int((q.stdout.strip().splitlines() or ["0"])[-1]) < 2:
+    try:
+        q = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=240)
+        ngpu = int((q.stdout.strip().splitlines() or ["0"])[-1]) if q.returncode == 0 else 0
+    except Exception:                                     # noqa: BLE001 - a slow or broken torch import only means "cannot tell": skip
+        ngpu = 0
+    if ngpu < 2:
         pytest.skip("needs 2 GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for scaling in ("weak", "strong"):
