@@ -14,7 +14,7 @@ enum MutaId : int {
 };
 // Pattern ids in the table order of erlamsa_patterns:patterns/0 (erlamsa_patterns.erl:395-405).
 enum PatId : int { P_OD, P_ND, P_BU, P_SK, P_SZ, P_CS, P_AR, P_CP, P_CO, P_NU, P_COUNT };
-enum GenId : int { G_DIRECT = 0, G_RANDOM = 1 };
+enum GenId : int { G_DIRECT = 0, G_RANDOM = 1, G_FILE = 2, G_JUMP = 3, G_COUNT = 4 };   // erlamsa_gen:generators/0 (stdin, genfuz: host I/O, not here)
 
 enum CaseStatus : int { CASE_OK = 0, CASE_CRASHED = 1, CASE_OVERFLOW = 2, CASE_UNSUPPORTED = 3, CASE_ARENA_FULL = 4, CASE_BUDGET = 5 };
 
@@ -67,8 +67,8 @@ struct DevConfig {
   // generators after sort_by_priority
   int32_t ngen;
   int32_t gen_total;
-  uint8_t gen_id[2];
-  uint32_t gen_pri[2];
+  uint8_t gen_id[G_COUNT];
+  uint32_t gen_pri[G_COUNT];
   uint32_t max_block_scaled;  // round(MAX_BLOCK_SIZE * blockscale)
   uint32_t min_block_scaled;  // round(MIN_BLOCK_SIZE * blockscale)
   // SSRF endpoint strings pre-rendered on the host
@@ -80,6 +80,7 @@ struct KParams {
   const uint8_t* corpus;
   const uint64_t* coff;
   uint64_t corpus_first;
+  uint64_t n_paths;           // entries of the whole corpus: the Paths of the file / jump generators
   uint64_t n;
   uint64_t first_case;        // 1-based case number of case 0 (mode 0)
   int32_t mode;               // 0 batch (one parent seed), 1 per-call seeds

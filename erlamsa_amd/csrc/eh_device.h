@@ -264,6 +264,8 @@ struct Ctx {
   uint64_t ovf_need, ovf_req;   // work area the case had asked for in total / in the request that failed (0: unknown): picks the tier that runs it again
   int ovf_line;        // site id that set CASE_OVERFLOW (diagnostic: reported as -line in the last-mutator array)
   int depth;           // nesting depth of mux_fuzzers (b64 / sgm / js inner mutations re-enter the scheduler)
+  int gen_pending;     // G_FILE / G_JUMP: the generator's fun has not been called yet (gen_force, eh_engine.hip); 0 = Ll is a list
+  uint32_t gen_e1, gen_e2;   // the corpus entries (paths) it was made for
 };
 // The per-case context lives in LDS.  One workgroup is one wavefront, so there is exactly one Ctx per
 // workgroup and no synchronisation is needed.  As a stack object it was reached through generic

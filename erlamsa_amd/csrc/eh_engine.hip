@@ -171,6 +171,7 @@ EH_DEV void split_head(Ctx& c) {
   wave_sync();
 }
 
+__device__ __noinline__ void gen_force(Ctx&);   // the file / jump generators' fun, called by the pattern's first uncons (below)
 enum Act { A_RUN_PAT, A_MUTATE_ONCE, A_LOOP, A_CONT, A_TERMINAL, A_DONE };
 enum ContKind { C_EMIT, C_ND, C_BU, C_PAT };
 
@@ -314,12 +315,13 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
           case P_ND: cont = C_ND; act = A_MUTATE_ONCE; break;                         // :323-326
           case P_BU: cont = C_BU; act = A_MUTATE_ONCE; break;                         // :346-349
           case P_CO: pat = rng_erand(c.rng, 2) == 1 ? P_NU : P_OD; break;             // :378-384
-          case P_NU: split_head(c); emit_all(c); act = A_TERMINAL; break;             // :386-390
+          case P_NU: if (c.gen_pending) gen_force(c); split_head(c); emit_all(c); act = A_TERMINAL; break;   // :386-390
           default: {
             // make_complex_pat :351-357: the continuation pattern is drawn first, then Ip
             contpat = (int)rng_rand(c.rng, P_COUNT);                                  // rand_elem(patterns())
             cont = C_PAT;
             ip = rng_rand(c.rng, INITIAL_IP);
+            if (c.gen_pending) { gen_force(c); if (c.status != CASE_OK) break; }      // uncons(Ll, false) calls a fun Ll
             if (c.cur >= c.nb) { c.status = CASE_CRASHED; break; }                    // uncons(Ll, false) -> false -> badarg
             Blk b = blk_load(c.bl, c.cur);
             const uint8_t* H = (const uint8_t*)b.ptr;
@@ -403,8 +405,9 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
         }
         break;
       case A_MUTATE_ONCE:                                                             // mutate_once/4 :265-278
-        if (c.nb - c.cur == 1 && blk_load(c.bl, c.cur).len == 0) { c.cur = c.nb; act = A_TERMINAL; break; }
+        if (!c.gen_pending && c.nb - c.cur == 1 && blk_load(c.bl, c.cur).len == 0) { c.cur = c.nb; act = A_TERMINAL; break; }   // (a fun does not match [<<>>])
         ip = rng_rand(c.rng, INITIAL_IP);
+        if (c.gen_pending) { gen_force(c); if (c.status != CASE_OK) break; }          // uncons(Ll, false) calls a fun Ll
         if (c.cur >= c.nb) { act = A_CONT; break; }                                   // Cont([], ...)
         split_head(c);
         act = A_LOOP;
@@ -472,23 +475,80 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
 // =============================================================================================
 // device: generators
 // =============================================================================================
-EH_DEV void gen_direct(Ctx& c, const uint8_t* in, uint32_t L) {       // erlamsa_gen.erl:152-164 (split_binary guard never holds)
-  const DevConfig& cfg = c.p->cfg;
-  (void)rng_rand(c.rng, cfg.max_block_scaled);                         // rand_block_size :55-56
-  blk_store(c.bl, 0, (uint64_t)in, L);
-  c.nb = 1;
-  uint32_t n = rng_rand(c.rng, L + 1);                                 // finish/1 :43-51
-  if (n == L) {
+// finish/1 (erlamsa_gen.erl:43-51): with probability 1/(Len+1) a block of random bytes behind the stream, at bl[c.nb]
+EH_DEV void gen_finish(Ctx& c, uint32_t len) {
+  uint32_t n = rng_rand(c.rng, len + 1);
+  if (n == len) {
     uint32_t bits = rng_range(c.rng, 1, 16);
     uint32_t nlen = rng_rand(c.rng, 1u << bits);
     if (nlen > 0) {                                                    // check_empty
       uint8_t* dst = ws_alloc_grow(c, nlen);
       if (!dst) return;
       random_block_rev(c, dst, nlen);
-      blk_store(c.bl, 1, (uint64_t)dst, nlen);
-      c.nb = 2;
+      if (c.nb >= MAX_BLOCKS) { EH_SET_OVERFLOW(c, 312); return; }
+      blk_store(c.bl, c.nb, (uint64_t)dst, nlen);
+      c.nb++;
     }
   }
+}
+EH_DEV uint32_t rand_block_size(Ctx& c) {                              // :55-56
+  const DevConfig& cfg = c.p->cfg;
+  uint32_t r = rng_rand(c.rng, cfg.max_block_scaled);
+  return r > cfg.min_block_scaled ? r : cfg.min_block_scaled;
+}
+EH_DEV void gen_direct(Ctx& c, const uint8_t* in, uint32_t L) {       // erlamsa_gen.erl:152-164 (split_binary guard never holds)
+  (void)rand_block_size(c);
+  blk_store(c.bl, 0, (uint64_t)in, L);
+  c.nb = 1;
+  gen_finish(c, L);
+  wave_sync();
+}
+// port_stream/2 forced (erlamsa_gen.erl:59-90) over corpus entry e: the blocks point into the arena (nothing is copied), the
+// next block size is drawn after every full block, a short read is followed by eof and finish(Len).  Fills bl[0..nb).
+EH_DEV void gen_stream(Ctx& c, uint32_t e) {
+  const KParams& p = *c.p;
+  uint64_t o0 = uni64(p.coff[e]), o1 = uni64(p.coff[e + 1]);
+  const uint8_t* in = p.corpus + o0;
+  uint32_t L = (uint32_t)(o1 - o0), pos = 0;
+  c.nb = 0;
+  uint32_t wanted = rand_block_size(c);
+  while (pos < L) {
+    if (c.nb >= MAX_BLOCKS - 1) { EH_SET_OVERFLOW(c, 313); return; }
+    uint32_t avail = L - pos;
+    if (avail >= wanted) { blk_store(c.bl, c.nb++, (uint64_t)(in + pos), wanted); pos += wanted; wanted = rand_block_size(c); }
+    else { blk_store(c.bl, c.nb++, (uint64_t)(in + pos), avail); pos = L; }
+  }
+  gen_finish(c, L);
+  wave_sync();
+}
+// The file and jump generators hand the pattern a FUN (file_streamer :106-121, jump_streamer :136-150): only the paths are
+// drawn when DataGen() runs; the streams are read, and their block sizes drawn, when the pattern's first uncons/2 calls the
+// fun (erlamsa_utils.erl:93) - after the pattern's own first draws.  gen_force is that call.
+__device__ __noinline__ void gen_force(Ctx&) {
+  EH_CTX;
+  const int kind = c.gen_pending;
+  c.gen_pending = 0;
+  if (kind == G_FILE) { gen_stream(c, c.gen_e1); return; }
+  // jump_somewhere/2 :124-133
+  uint64_t dptr[2]; uint32_t dlen[2];
+  for (int k = 0; k < 2; k++) {
+    gen_stream(c, k == 0 ? c.gen_e1 : c.gen_e2);
+    if (c.status != CASE_OK) return;
+    if (c.nb == 0) { c.status = CASE_CRASHED; return; }                // rand_elem([]) = [] ; size([]) -> badarg
+    uint32_t i = rng_erand(c.rng, (uint32_t)c.nb) - 1;                 // rand_elem/1 (erlamsa_rnd.erl:128-132)
+    Blk b = blk_load(c.bl, (int)i);
+    dptr[k] = b.ptr; dlen[k] = b.len;
+    wave_sync();
+  }
+  uint32_t s1 = rng_rand(c.rng, dlen[0]), s2 = rng_rand(c.rng, dlen[1]);
+  uint32_t l1 = rng_erand(c.rng, dlen[0] - s1), l2 = rng_erand(c.rng, dlen[1] - s2);
+  uint8_t* dst = ws_alloc_grow(c, (uint64_t)l1 + l2);
+  if (!dst) return;
+  wave_copy(dst, (const uint8_t*)dptr[0] + s1, l1);
+  wave_copy(dst + l1, (const uint8_t*)dptr[1] + s2, l2);
+  wave_sync();
+  blk_store(c.bl, 0, (uint64_t)dst, l1 + l2);                          // uncons(B) when is_binary(B) -> {B, []}
+  c.nb = 1;
   wave_sync();
 }
 EH_DEV void gen_random(Ctx& c) {                                       // random_stream/1 :167-178
@@ -598,7 +658,11 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     uint64_t o0 = p.coff[p.corpus_first + i], o1 = p.coff[p.corpus_first + i + 1];
     o0 = uni64(o0); o1 = uni64(o1);
     EH_PH(0);
-    if (gen == G_DIRECT) gen_direct(c, p.corpus + o0, (uint32_t)(o1 - o0)); else gen_random(c);   // DataGen() :185
+    c.gen_pending = 0;                                                                               // DataGen() :185
+    if (gen == G_DIRECT) gen_direct(c, p.corpus + o0, (uint32_t)(o1 - o0));
+    else if (gen == G_RANDOM) gen_random(c);
+    else if (gen == G_FILE) { c.gen_e1 = rng_erand(c.rng, (uint32_t)p.n_paths) - 1; c.gen_pending = G_FILE; }          // file_streamer :108-110
+    else { c.gen_e1 = rng_erand(c.rng, (uint32_t)p.n_paths) - 1; c.gen_e2 = rng_erand(c.rng, (uint32_t)p.n_paths) - 1; c.gen_pending = G_JUMP; }   // jump_streamer :138
     EH_PH(1);
 
     if (c.status == CASE_OK) {
@@ -738,6 +802,7 @@ struct eh_ctx {
   uint64_t max_case_bytes = 0, out_capacity_opt = 0, work_budget = 0;
   uint64_t fuse_stream_min = 16384, pool_bytes_opt = 0, dl_chunk = 256ull << 20;   // eh_options (ABI 4)
   uint32_t max_slots_opt = 0, flags = 0;
+  int needs_paths = 0;                                  // corpus entries the configured generators need (file: 1, jump: 2)
   KParams* d_params = nullptr;                          // argument block of eh_mutate_kernel
   // eh_result_download: case-ordered chunks are gathered on the device into two bounce buffers; chunk k goes over PCIe
   // while chunk k+1 is gathered
@@ -991,6 +1056,8 @@ static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
 static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_case, uint64_t corpus_first, uint64_t n, hipStream_t st) {
   if (!ctx->configured || !ctx->d_corpus) { ctx->err = "configure and load a corpus first"; return EH_E_STATE; }
   if (corpus_first + n > ctx->n_corpus || (mode == 0 && first_case < 1)) { ctx->err = "case range outside the corpus"; return EH_E_INVALID; }
+  // make_generator_fun (erlamsa_gen.erl:215-224) drops `file` without paths and `jump` with fewer than two: said aloud here
+  if (ctx->n_corpus < (uint64_t)ctx->needs_paths || ctx->n_corpus > 0xFFFFFFFFull) { ctx->err = "generator file needs one corpus entry (path), jump two"; return EH_E_INVALID; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   uint64_t in_bytes = 0;
   if (!ctx->h_coff.empty()) in_bytes = ctx->h_coff[corpus_first + n] - ctx->h_coff[corpus_first];
@@ -1004,7 +1071,7 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
 
   KParams p;
   memset(&p, 0, sizeof(p));
-  p.corpus = ctx->d_corpus; p.coff = ctx->d_coff; p.corpus_first = corpus_first; p.n = n; p.first_case = first_case;
+  p.corpus = ctx->d_corpus; p.coff = ctx->d_coff; p.corpus_first = corpus_first; p.n_paths = ctx->n_corpus; p.n = n; p.first_case = first_case;
   p.mode = mode; p.run = ctx->d_run; p.seeds = ctx->d_seeds; p.cfg = ctx->cfg;
   const DevPool* pl = ctx->pool;
   p.work_cap = pl->work_cap;
@@ -1167,7 +1234,7 @@ int eh_configure(eh_ctx* ctx, const eh_options* o) {
   for (size_t i = 0; i < sp.size(); i++) { cfg.pat_id[i] = (uint8_t)sp[i].id; cfg.pat_pri[i] = sp[i].pri; cfg.pat_total += (int)sp[i].pri; }
   if (cfg.npat == 0) { ctx->err = "no patterns selected"; return EH_E_INVALID; }
   // generators: table order of erlamsa_gen:generators/0 is random(1) ... direct(500)
-  long gr = 1, gd = 500;
+  long gr = 1, gd = 500, gf = -1, gj = -1;
   if (o->generators) {
     gr = -1; gd = -1;
     std::string str(o->generators); size_t pos = 0;
@@ -1179,12 +1246,16 @@ int eh_configure(eh_ctx* ctx, const eh_options* o) {
       std::string name = eq == std::string::npos ? tok : tok.substr(0, eq);
       long p = -1; if (eq != std::string::npos) p = strtol(tok.c_str() + eq + 1, nullptr, 10);
       if (name == "random") gr = p < 0 ? 1 : p; else if (name == "direct") gd = p < 0 ? 500 : p;
+      else if (name == "file") gf = p < 0 ? 1000 : p; else if (name == "jump") gj = p < 0 ? 100 : p;      // Paths = the corpus entries
       else { ctx->err = "generator '" + name + "' is host-side I/O and not part of the GPU path"; return EH_E_UNSUPPORTED; }
     }
   }
   PL gl;
-  if (gr >= 0) gl.push_back({(uint32_t)gr, G_RANDOM});
+  if (gr >= 0) gl.push_back({(uint32_t)gr, G_RANDOM});                  // table order of erlamsa_gen:generators/0 :250-257
+  if (gj >= 0) gl.push_back({(uint32_t)gj, G_JUMP});
   if (gd >= 0) gl.push_back({(uint32_t)gd, G_DIRECT});
+  if (gf >= 0) gl.push_back({(uint32_t)gf, G_FILE});
+  ctx->needs_paths = gj >= 0 ? 2 : (gf >= 0 ? 1 : 0);
   if (gl.empty()) { ctx->err = "No generators!"; return EH_E_INVALID; }
   PL sg = otp_sort_desc_strict(gl);
   cfg.ngen = (int)sg.size();

@@ -71,7 +71,13 @@ typedef struct eh_options {
                                 (erlamsa_mutations.erl:1291-1331) */
   const char* patterns;      /* "od,nd,bu" (-p syntax); NULL = default (erlamsa_patterns.erl:395-405) */
   const char* generators;    /* "direct=500,random=1"; NULL = what paths=[direct] yields
-                                (erlamsa_gen.erl:204-241,250-257) */
+                                (erlamsa_gen.erl:204-241,250-257).  Also "file" (file_streamer :106-121) and "jump"
+                                (jump_streamer :136-150, jump_somewhere :124-133): their Paths are the entries of the
+                                corpus (all of them, whatever sub-range a batch runs); a case draws its path(s), the
+                                stream is cut into rand_block_size blocks on the device, and - like the reference's
+                                fun - only when the pattern first looks at the list.  A launch with `file` needs one
+                                corpus entry, with `jump` two (make_generator_fun would drop them: EH_E_INVALID here).
+                                stdin / genfuz are host I/O and not part of the GPU path (EH_E_UNSUPPORTED) */
   double blockscale;         /* 0 => 1.0 (erlamsa_gen.erl:206) */
   const char* ssrf_host;     /* NULL => "localhost" */
   int32_t ssrf_port;         /* 0 => 51234 */

@@ -212,6 +212,7 @@ struct Config {
   uint64_t max_case_bytes = 0;
   uint64_t max_case_work = 0;
   double max_case_seconds = 0;
+  const uint8_t* paths_data = nullptr; const uint64_t* paths_off = nullptr; uint64_t paths_n = 0;   // the file / jump generators' Paths
 };
 
 struct Case;  // fwd
@@ -242,6 +243,7 @@ struct Ctx {
   std::string* trace = nullptr;
   Bytes out;             // blocks already written by blocks_port
   EngineGuard* guard = nullptr;   // engine caps (not reference behaviour); nullptr = pure reference semantics
+  std::function<BList()> lazy_ll; // file / jump generators hand the pattern a fun: forced by its first uncons (erlamsa_utils.erl:93)
   void t(const char* tag, const char* name) { if (trace) { trace->append(tag); trace->push_back(':'); trace->append(name); trace->push_back(' '); } }
   void check_cap(size_t n) { if (guard) guard->size(n); }
 };
@@ -2150,9 +2152,13 @@ struct PatEngine {
     }
   }
   // mutate_once/4 :265-278
+  // uncons(Ll, false) on a fun Ll calls it (erlamsa_utils.erl:93): the port_stream / jump_somewhere closures of the file and
+  // jump generators draw their block sizes only now, AFTER the pattern's own first draws
+  void force(BList& ll) { if (c.lazy_ll) { auto f = c.lazy_ll; c.lazy_ll = nullptr; ll = f(); } }
   void mutate_once(BList ll, const Cont& cont, Bytes& sink) {
-    if (ll.size() == 1 && ll[0].empty()) return;                              // {Mutator, Meta}: nothing more is written
+    if (!c.lazy_ll && ll.size() == 1 && ll[0].empty()) return;                // {Mutator, Meta}: nothing more is written (a fun does not match [<<>>])
     int ip = (int)c.rnd.rand(INITIAL_IP);
+    force(ll);
     if (ll.empty()) { BList e; cont(e, sink); return; }
     split(ll);
     mutate_once_loop(ip, ll, cont, sink);
@@ -2164,7 +2170,7 @@ struct PatEngine {
       case P_ND: mutate_once(ll, [this](BList& l, Bytes& s) { many_dec_cont(l, s); }, sink); return;             // :323-326
       case P_BU: mutate_once(ll, [this](BList& l, Bytes& s) { burst_cont(l, s); }, sink); return;                // :346-349
       case P_CO: if (c.rnd.erand(2) == 1) run(P_NU, ll, sink); else run(P_OD, ll, sink); return;                 // :378-384
-      case P_NU: { split(ll); emit_all(ll, sink); return; }                                                     // :386-390
+      case P_NU: { force(ll); split(ll); emit_all(ll, sink); return; }                                          // :386-390
       default: break;
     }
     // make_complex_pat :351-357 : the continuation pattern is drawn first
@@ -2191,6 +2197,7 @@ struct PatEngine {
   }
   void skipper(BList ll, const Cont& next, Bytes& sink) {                     // mutate_once_skipper :146-161
     int ip = (int)c.rnd.rand(INITIAL_IP);
+    force(ll);
     if (ll.empty()) throw ErlCrash("badarg: size(false)");
     Bytes bin = ll[0];
     size_t len = c.rnd.rand((uint64_t)std::trunc((double)bin.size() / 2.0));
@@ -2201,6 +2208,7 @@ struct PatEngine {
   }
   void sizer(BList ll, const Cont& next, Bytes& sink) {                       // mutate_once_sizer :81-111
     int ip = (int)c.rnd.rand(INITIAL_IP);
+    force(ll);
     if (ll.empty()) throw ErlCrash("function_clause: get_possible_simple_lens(false)");
     Bytes bin = ll[0]; BList rest(ll.begin() + 1, ll.end());
     std::vector<Sizer> cands = get_possible_simple_lens(c, bin);
@@ -2219,6 +2227,7 @@ struct PatEngine {
   }
   void csum(BList ll, const Cont& next, Bytes& sink) {                        // mutate_once_csum :115-144
     int ip = (int)c.rnd.rand(INITIAL_IP);
+    force(ll);
     if (ll.empty()) throw ErlCrash("function_clause: get_possible_csum_locations(false)");
     Bytes bin = ll[0]; BList rest(ll.begin() + 1, ll.end());
     std::vector<Csum> cands = get_possible_csum_locations(bin);
@@ -2238,6 +2247,7 @@ struct PatEngine {
   }
   void archiver(BList ll, const Cont& next, Bytes& sink) {                    // mutate_once_archiver :165-214
     int ip = (int)c.rnd.rand(INITIAL_IP);
+    force(ll);
     if (ll.empty()) throw ErlCrash("badarg");
     Bytes all; for (auto& b : ll) all.insert(all.end(), b.begin(), b.end());  // list_to_binary([Bin|Rest])
     if (has_zip_eocd(all)) throw Unsupported();
@@ -2247,6 +2257,7 @@ struct PatEngine {
   }
   void compressed(BList ll, const Cont& next, Bytes& sink) {                  // mutate_once_compressed :216-260
     int ip = (int)c.rnd.rand(INITIAL_IP);
+    force(ll);
     if (ll.empty()) throw ErlCrash("badarg");
     const Bytes& bin = ll[0];
     // zlib:gunzip needs the 1f 8b magic; zlib:inflate needs a valid 2-byte zlib header.
@@ -2292,8 +2303,38 @@ BList random_stream(Rnd& rnd, double bs) {                                    //
   }
 }
 
+// port_stream/2 forced (:59-90): blocks of rand_block_size bytes; a short read is followed by eof, which ends the list
+// with what was read and finish(Len); the next block size is drawn only after a full block
+BList stream_port(Rnd& rnd, const Bytes& file, double bs) {
+  BList out; size_t pos = 0;
+  uint64_t wanted = rand_block_size(rnd, bs);
+  while (true) {
+    size_t avail = file.size() - pos;
+    if (avail == 0) break;                                                     // eof with Last = false
+    if (avail >= wanted) { out.emplace_back(file.begin() + pos, file.begin() + pos + wanted); pos += wanted; wanted = rand_block_size(rnd, bs); continue; }
+    out.emplace_back(file.begin() + pos, file.end()); pos = file.size(); break; // DataLen < Wanted, then eof: [Last | finish(..)]
+  }
+  BList f = finish(rnd, pos);
+  out.insert(out.end(), f.begin(), f.end());
+  return out;
+}
+// jump_somewhere/2 :124-133
+BList jump_somewhere(Rnd& rnd, const Bytes& f1, const Bytes& f2, double bs) {
+  BList l1 = stream_port(rnd, f1, bs);
+  int64_t i1 = rnd.rand_elem_idx(l1.size());
+  BList l2 = stream_port(rnd, f2, bs);
+  int64_t i2 = rnd.rand_elem_idx(l2.size());
+  if (i1 < 0 || i2 < 0) throw ErlCrash("badarg: size([])");                    // rand_elem([]) = []
+  const Bytes& d1 = l1[i1]; const Bytes& d2 = l2[i2];
+  uint64_t s1 = rnd.rand(d1.size()), s2 = rnd.rand(d2.size());
+  uint64_t n1 = rnd.erand(d1.size() - s1), n2 = rnd.erand(d2.size() - s2);
+  Bytes b(d1.begin() + s1, d1.begin() + s1 + n1);
+  b.insert(b.end(), d2.begin() + s2, d2.begin() + s2 + n2);
+  return {b};                                                                  // uncons(B) when is_binary(B) -> {B, []}
+}
+
 struct Run {                     // state of one erlamsa_main:fuzzer/1 invocation
-  Rnd parent; std::vector<Muta> muta; int gen; /*0 direct,1 random*/ std::vector<PriItem> pats; int pat_total;
+  Rnd parent; std::vector<Muta> muta; int gen; /*0 direct,1 random,2 file,3 jump*/ std::vector<PriItem> pats; int pat_total;
 };
 int lookup_muta(const std::string& n) { for (int i = 0; i < M_COUNT; i++) if (n == MUTA_TABLE[i].name) return i; return -1; }
 int lookup_pat(const std::string& n) { for (int i = 0; i < P_COUNT; i++) if (n == PAT_TABLE[i].name) return i; return -1; }
@@ -2304,7 +2345,7 @@ void setup_run(Run& run, const Config& cfg, int64_t s1, int64_t s2, int64_t s3) 
   run.muta = make_mutator(run.parent, cfg.mutations);                         // :149
   // make_generator :244-248 + mux_generators :194-199
   std::vector<PriItem> gs;
-  for (auto& g : cfg.generators) { int id = g.first == "direct" ? 0 : (g.first == "random" ? 1 : -1); if (id >= 0) gs.push_back({g.second, id}); }
+  for (auto& g : cfg.generators) { int id = g.first == "direct" ? 0 : g.first == "random" ? 1 : g.first == "file" ? 2 : g.first == "jump" ? 3 : -1; if (id >= 0) gs.push_back({g.second, id}); }
   if (gs.empty()) throw std::runtime_error("No generators!");
   int total; std::vector<PriItem> sg = sort_by_priority(gs, &total);
   run.gen = choose_pri(sg, (int64_t)run.parent.rand((uint64_t)total));
@@ -2326,7 +2367,21 @@ void run_case(Run& run, const Config& cfg, const Bytes& input, Bytes* out, int* 
   c.fs = run.muta;                                                            // CurMuta (not advanced between cases, :229-230)
   *status = EO_OK;
   try {
-    BList ll = run.gen == 0 ? direct_generator(c.rnd, input, cfg.blockscale) : random_stream(c.rnd, cfg.blockscale);   // :185
+    BList ll;                                                                 // {Ll, GenMeta} = DataGen() :185
+    auto path = [&cfg](uint64_t k) { return Bytes(cfg.paths_data + cfg.paths_off[k], cfg.paths_data + cfg.paths_off[k + 1]); };
+    if (run.gen == 0) ll = direct_generator(c.rnd, input, cfg.blockscale);
+    else if (run.gen == 1) ll = random_stream(c.rnd, cfg.blockscale);
+    else if (run.gen == 2) {                                                  // file_streamer :106-121: the path is drawn now, the stream is a fun
+      uint64_t p = c.rnd.erand(cfg.paths_n);
+      if (p == 0) throw ErlCrash("function_clause: lists:nth(0, [])");
+      Bytes f = path(p - 1); double bs = cfg.blockscale; Rnd* r = &c.rnd;
+      c.lazy_ll = [f, bs, r]() { return stream_port(*r, f, bs); };
+    } else {                                                                  // jump_streamer :136-150
+      int64_t p1 = c.rnd.rand_elem_idx(cfg.paths_n), p2 = c.rnd.rand_elem_idx(cfg.paths_n);
+      if (p1 < 0 || p2 < 0) throw ErlCrash("file:open([])");
+      Bytes f1 = path(p1), f2 = path(p2); double bs = cfg.blockscale; Rnd* r = &c.rnd;
+      c.lazy_ll = [f1, f2, bs, r]() { return jump_somewhere(*r, f1, f2, bs); };
+    }
     if (run.pats.empty()) throw ErlCrash("no patterns");
     int pat = choose_pri(run.pats, (int64_t)c.rnd.rand((uint64_t)run.pat_total));       // choose_pattern_fun :431-434
     PatEngine pe(c);
@@ -2371,14 +2426,18 @@ bool build_config(const eo_config* ec, Config* cfg) {
   cfg->generators = {{"random", 1}, {"direct", 500}};   // erlamsa_gen:default/0 filtered by make_generator_fun for paths=[direct]
   if (ec->generators) {
     cfg->generators.clear();
-    // keep erlamsa_gen:generators/0 table order (random before direct)
-    std::stringstream ss(ec->generators); std::string tok; int pr = -1, pd = -1;
+    // keep erlamsa_gen:generators/0 table order :250-257 (random, jump, direct, file)
+    std::stringstream ss(ec->generators); std::string tok; int pr = -1, pd = -1, pf = -1, pj = -1;
     while (std::getline(ss, tok, ',')) {
       std::string name = tok; int pri = -1; size_t eq = tok.find('='); if (eq != std::string::npos) { name = tok.substr(0, eq); pri = atoi(tok.c_str() + eq + 1); }
-      if (name == "random") pr = pri < 0 ? 1 : pri; else if (name == "direct") pd = pri < 0 ? 500 : pri; else { g_err = "unsupported generator " + name; return false; }
+      if (name == "random") pr = pri < 0 ? 1 : pri; else if (name == "direct") pd = pri < 0 ? 500 : pri;
+      else if (name == "file") pf = pri < 0 ? 1000 : pri; else if (name == "jump") pj = pri < 0 ? 100 : pri;
+      else { g_err = "unsupported generator " + name; return false; }
     }
     if (pr >= 0) cfg->generators.push_back({"random", pr});
+    if (pj >= 0) cfg->generators.push_back({"jump", pj});
     if (pd >= 0) cfg->generators.push_back({"direct", pd});
+    if (pf >= 0) cfg->generators.push_back({"file", pf});
   }
   cfg->blockscale = ec->blockscale == 0 ? 1.0 : ec->blockscale;
   if (ec->ssrf_host) cfg->ssrf_host = ec->ssrf_host;
@@ -2404,6 +2463,10 @@ static int eo_fuzz_batch_impl(const eo_config* ec, const uint8_t* data, const ui
   try {
     Config cfg;
     if (!build_config(ec, &cfg)) return 1;
+    // Paths of the file / jump generators: the corpus the cases' inputs were cut from, or the batch itself
+    if (ec->paths_off) { cfg.paths_data = ec->paths_data; cfg.paths_off = ec->paths_off; cfg.paths_n = ec->paths_n; }
+    else { cfg.paths_data = data; cfg.paths_off = off; cfg.paths_n = n; }
+    for (auto& g : cfg.generators) if (g.first == "jump" && cfg.paths_n < 2) { g_err = "generator jump needs at least two paths (make_generator_fun :220-224)"; return 1; }
     std::vector<Bytes> outs(n); std::vector<int> st(n); std::vector<uint64_t> dr(n); std::string trace;
     Run run;
     if (ec->mode == 0) {

@@ -17,7 +17,7 @@ typedef struct eo_config {
   // Dict keys of erlamsa_main:fuzzer/1 (erlamsa_main.erl:127-163)
   const char* mutations;   // "-m" syntax: "bd,bf=2,bi" ; NULL = default table
   const char* patterns;    // "-p" syntax: "od,nd,bu"   ; NULL = default table
-  const char* generators;  // "direct=500,random=1"     ; NULL = direct mode default
+  const char* generators;  // "direct=500,random=1" (also file, jump); NULL = direct mode default
   double blockscale;       // 1.0
   const char* ssrf_host;   // NULL = "localhost" (erlamsa_mutations.erl:698-703)
   int32_t ssrf_port;       // 0 = 51234
@@ -34,6 +34,11 @@ typedef struct eo_config {
   uint64_t max_case_work;  // engine work budget mirrored here; 0 = unlimited
   double max_case_seconds; // wall-clock watchdog per case (the reference's maxrunningtime: the case's output is <<>>); 0 = none.
                            // Only bench.py's cpu_baseline leg sets it: parity tests never depend on time.
+  // Paths of the `file` and `jump` generators (erlamsa_gen.erl:106-150): entry k = paths_data[paths_off[k] .. paths_off[k+1]).
+  // NULL paths_off = the batch's own inputs.
+  const uint8_t* paths_data;
+  const uint64_t* paths_off;
+  uint64_t paths_n;
 } eo_config;
 
 enum { EO_OK = 0, EO_CRASHED = 1, EO_OVERFLOW = 2, EO_UNSUPPORTED = 3, EO_BUDGET = 5, EO_TIMEOUT = 6 };

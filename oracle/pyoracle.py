@@ -25,7 +25,8 @@ class _Cfg(C.Structure):
     _fields_ = [("mutations", C.c_char_p), ("patterns", C.c_char_p), ("generators", C.c_char_p),
                 ("blockscale", C.c_double), ("ssrf_host", C.c_char_p), ("ssrf_port", C.c_int32),
                 ("mode", C.c_int32), ("seed", C.c_int64 * 3), ("first_case", C.c_uint64),
-                ("seeds", C.POINTER(C.c_int64)), ("max_case_bytes", C.c_uint64), ("max_case_work", C.c_uint64), ("max_case_seconds", C.c_double)]
+                ("seeds", C.POINTER(C.c_int64)), ("max_case_bytes", C.c_uint64), ("max_case_work", C.c_uint64), ("max_case_seconds", C.c_double),
+                ("paths_data", C.c_void_p), ("paths_off", C.c_void_p), ("paths_n", C.c_uint64)]
 
 
 class _Res(C.Structure):
@@ -73,8 +74,9 @@ def pack(inputs):
 
 
 def fuzz_batch(data, off, seed=(1, 2, 3), mutations=None, patterns=None, generators=None, blockscale=1.0,
-               first_case=1, seeds=None, max_case_bytes=0, ssrf_host=None, ssrf_port=0, trace=False, max_case_work=0, max_case_seconds=0.0):
-    """Returns (list[bytes] outputs, status int32[n], draws uint64[n], trace str|None)."""
+               first_case=1, seeds=None, max_case_bytes=0, ssrf_host=None, ssrf_port=0, trace=False, max_case_work=0, max_case_seconds=0.0, paths=None):
+    """Returns (list[bytes] outputs, status int32[n], draws uint64[n], trace str|None).
+    paths = (data, off) of the corpus the `file` / `jump` generators draw from (default: the batch itself)."""
     n = len(off) - 1
     cfg = _Cfg()
     cfg.mutations = mutations.encode() if mutations is not None else None
@@ -88,6 +90,10 @@ def fuzz_batch(data, off, seed=(1, 2, 3), mutations=None, patterns=None, generat
     cfg.max_case_work = max_case_work
     cfg.max_case_seconds = max_case_seconds
     keep = None
+    pkeep = None
+    if paths is not None:
+        pkeep = (np.ascontiguousarray(paths[0], dtype=np.uint8), np.ascontiguousarray(paths[1], dtype=np.uint64))
+        cfg.paths_data, cfg.paths_off, cfg.paths_n = pkeep[0].ctypes.data, pkeep[1].ctypes.data, len(pkeep[1]) - 1
     if seeds is not None:
         keep = np.ascontiguousarray(seeds, dtype=np.int64).reshape(-1)
         assert keep.size == 3 * n

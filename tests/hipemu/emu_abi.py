@@ -34,7 +34,7 @@ assert code(eng.configure, mutations="bd,nosuch") == -1                      # E
 assert code(eng.configure, patterns="xx") == -1
 assert code(eng.configure, mutations="sgm,js,b64") == 0                      # every mutator of the default table runs on the device
 assert code(eng.configure, mutations=None, patterns=None) == 0               # NULL = the reference's default tables
-assert code(eng.configure, generators="file=1") == -6                       # EH_E_UNSUPPORTED: host-side I/O generators
+assert code(eng.configure, generators="stdin=1") == -6                      # EH_E_UNSUPPORTED: host-side I/O generators
 eng.configure(mutations="bd=3,bf,bi=7", patterns="od,nd=2", generators="direct=500,random=1")
 inputs = util.corpus_uniform(40, 200)
 data, off = po.pack(inputs)

@@ -539,6 +539,20 @@ def test_meta_trace_equals_the_oracles():
     assert emu_meta.run(n=96, size=900, seed=(5, 3, 8)) >= 100
 
 
+def test_file_and_jump_generators_vs_oracle():
+    """SURVEY §8(f)-2, erlamsa_gen.erl:59-150: the `file` generator (multi-block streams cut by rand_block_size, finish/1) and
+    the `jump` generator (jump_somewhere/2 splices across corpus entries) on the device; their streams are forced by the
+    pattern's first uncons, so the draw order differs from `direct`.  Batches that are sub-ranges of the corpus, batch and
+    per-call seeding, all patterns: bytes, statuses and draw counts against the oracle."""
+    if util.priming():
+        pytest.skip("live oracle (small)")
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    import emu_gens
+    assert emu_gens.run(n=96) >= 700
+
+
 def test_two_rank_nccl_bench_smoke():
     """bench.py over RCCL with 2 ranks on one node (arena broadcast, case-range sharding, MAX-over-ranks timing), weak and
     strong: skipped on boxes with fewer than 2 GPUs (the builder's and the driver's test boxes have one; the 8-GPU runs are
