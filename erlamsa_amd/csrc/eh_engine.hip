@@ -36,6 +36,7 @@
 #include "eh_doc.h"
 #include "eh_sgml.h"
 #include "eh_json.h"
+#include "eh_zlib.h"
 
 namespace eh {
 
@@ -174,49 +175,6 @@ EH_DEV void split_head(Ctx& c) {
 __device__ __noinline__ void gen_force(Ctx&);   // the file / jump generators' fun, called by the pattern's first uncons (below)
 enum Act { A_RUN_PAT, A_MUTATE_ONCE, A_LOOP, A_CONT, A_TERMINAL, A_DONE };
 enum ContKind { C_EMIT, C_ND, C_BU, C_PAT };
-
-// CRC-32 (zlib polynomial, reflected) helpers for the csum pattern
-__constant__ uint32_t c_crc_table[256];
-EH_DEV uint32_t gf2_multmodp(uint32_t a, uint32_t b) {            // a(x)*b(x) mod p(x), reflected representation (x^0 = bit 31)
-  uint32_t m = 1u << 31, p = 0;
-  for (;;) {
-    if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
-    m >>= 1;
-    b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
-  }
-  return p;
-}
-EH_DEV uint32_t gf2_xpow8n(uint64_t nbytes) {                      // x^(8*nbytes) mod p
-  uint32_t r = 1u << 31, sq = 1u << 23;                            // sq = x^8
-  while (nbytes) { if (nbytes & 1) r = gf2_multmodp(r, sq); sq = gf2_multmodp(sq, sq); nbytes >>= 1; }
-  return r;
-}
-// erlang:crc32/1 of a contiguous buffer: 64 lane-local chunk CRCs combined with x^(8*len) shifts
-EH_DEV uint32_t wave_crc32(const uint8_t* p, uint32_t n) {
-  const int l = EH_LANE;
-  uint32_t chunk = (n + 63) / 64;
-  uint32_t a = (uint32_t)l * chunk, b = a + chunk; if (a > n) a = n; if (b > n) b = n;
-  uint32_t crc = 0xFFFFFFFFu;
-  for (uint32_t i = a; i < b; i++) crc = c_crc_table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
-  crc ^= 0xFFFFFFFFu;                                              // crc32 of my chunk (0 for an empty chunk)
-  uint32_t total = 0; uint32_t done = 0;
-  for (int k = 0; k < 64; k++) {                                   // crc32_combine left to right
-    uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)crc, k);
-    uint32_t ak = (uint32_t)k * chunk, bk = ak + chunk; if (ak > n) ak = n; if (bk > n) bk = n;
-    uint32_t lk = bk - ak;
-    if (lk == 0) continue;
-    total = done == 0 ? ck : (gf2_multmodp(gf2_xpow8n(lk), total) ^ ck);
-    done += lk;
-  }
-  return total;
-}
-EH_DEV uint32_t wave_xor8(const uint8_t* p, uint32_t n) {
-  uint32_t x = 0;
-  for (uint32_t i = EH_LANE; i < n; i += 64) x ^= p[i];
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) x ^= (uint32_t)__shfl_xor((int)x, d);
-  return uni(x) & 255u;
-}
 
 struct PatFrame {           // a sizer/csum wrapper waiting for its inner evaluation (prepare4sizer)
   int kind;                 // P_SZ or P_CS
@@ -765,6 +723,20 @@ __global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf, const ui
     }
     wave_sync();
   }
+}
+
+// Self test of eh_zlib.h: op 0..2 compress in[0..n) as ZF_RAW / ZF_GZIP / ZF_ZLIB, op 4 / 5 = zlib:gunzip / zlib:inflate semantics
+// (z_uncompress_size + z_uncompress_write); res[0] = bytes written, res[1] = 1 ok / 0 "raises".
+__global__ void __launch_bounds__(64) eh_test_zlib_kernel(int op, const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint8_t* scratch, uint64_t* res) {
+  uint64_t len = 0; int ok = 1;
+  if (op <= 2) { len = z_compress((ZDef*)scratch, op, in, n, out, cap); ok = len != 0; }
+  else {
+    ZInf* zi = (ZInf*)scratch; uint64_t off = 0;
+    ok = z_uncompress_size(zi, op - 3, in, n, &len, &off);
+    if (ok && len > cap) ok = 0;
+    if (ok) ok = z_uncompress_write(zi, op - 3, in, n, off, out, len);
+  }
+  if (EH_LANE == 0) { res[0] = len; res[1] = (uint64_t)ok; }
 }
 
 // =============================================================================================
@@ -1703,6 +1675,32 @@ int eh_selftest_movers(eh_ctx* ctx, uint8_t* buf, uint64_t buf_len, const uint32
   if (dj) (void)hipFree(dj);
   if (de) (void)hipFree(de);
   HIPCHK(ctx, e);
+  return EH_OK;
+}
+// Self test hook for the device deflate / inflate (eh_zlib.h): op 0 raw deflate, 1 zlib:gzip/1, 2 zlib:deflate(default), 4 zlib:gunzip/1,
+// 5 zlib:inflate/2 as mutate_once_compressed/6 uses it.  *ok = 0 where the reference's call raises.
+int eh_selftest_zlib(eh_ctx* ctx, int op, const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len, int32_t* ok) {
+  if (!ctx || (!in && n) || !out || !out_len || !ok || op < 0 || op > 5 || op == 3) return EH_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  uint8_t* di = nullptr; uint8_t* dout = nullptr; uint8_t* ds = nullptr; uint64_t* dr = nullptr;
+  hipError_t e = hipMalloc(&di, n + 16);
+  if (e == hipSuccess) e = hipMalloc(&dout, cap + 16);
+  if (e == hipSuccess) e = hipMalloc(&ds, sizeof(ZDef) > sizeof(ZInf) ? sizeof(ZDef) : sizeof(ZInf));
+  if (e == hipSuccess) e = hipMalloc(&dr, 16);
+  if (e == hipSuccess && n) e = hipMemcpy(di, in, n, hipMemcpyHostToDevice);
+  uint64_t r[2] = {0, 0};
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(eh_test_zlib_kernel, dim3(1), dim3(64), 0, 0, op, (const uint8_t*)di, n, dout, cap, ds, dr);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(r, dr, 16, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && r[1] && r[0] <= cap && r[0]) e = hipMemcpy(out, dout, r[0], hipMemcpyDeviceToHost);
+  if (di) (void)hipFree(di);
+  if (dout) (void)hipFree(dout);
+  if (ds) (void)hipFree(ds);
+  if (dr) (void)hipFree(dr);
+  HIPCHK(ctx, e);
+  *out_len = r[0]; *ok = (int32_t)r[1];
   return EH_OK;
 }
 int eh_pool_stats(eh_ctx* ctx, uint64_t* out /* 64 values */) {

@@ -21,7 +21,7 @@ CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BU
 # every symbol include/erlamsa_hip.h declares
 ABI_SYMBOLS = [
     "eh_create", "eh_destroy", "eh_configure", "eh_corpus_upload", "eh_corpus_attach", "eh_fuzz_batch",
-    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_fetch", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_peak", "eh_result_meta", "eh_result_write_files", "eh_result_prof", "eh_selftest_movers",
+    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_fetch", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_peak", "eh_result_meta", "eh_result_write_files", "eh_result_prof", "eh_selftest_movers", "eh_selftest_zlib",
     "eh_last_kernel_ms", "eh_pool_stats", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
@@ -83,6 +83,7 @@ def load_library():
     lib.eh_result_meta.argtypes = [vp, C.c_uint64, vp, C.c_uint64, u64p]
     lib.eh_result_prof.argtypes = [vp, vp]
     lib.eh_selftest_movers.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
+    lib.eh_selftest_zlib.argtypes = [vp, C.c_int, vp, C.c_uint64, vp, C.c_uint64, vp, vp]
     lib.eh_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.eh_pool_stats.argtypes = [vp, vp]
     lib.eh_coalesce_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
@@ -318,6 +319,17 @@ class Engine:
         pr = np.zeros(256, dtype=np.uint64)
         self._chk(self.lib.eh_result_prof(self.h, pr.ctypes.data))
         return pr
+
+    def selftest_zlib(self, op, data, cap=None):
+        """device deflate / inflate (csrc/eh_zlib.h): op 0 raw deflate, 1 gzip, 2 zlib, 4 gunzip, 5 zlib inflate -> bytes or None where the reference raises"""
+        src = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+        if cap is None:
+            cap = len(data) + len(data) // 8 + 1024 if op <= 2 else max(64 * len(data), 1 << 20)
+        out = np.zeros(cap + 16, dtype=np.uint8)
+        n = C.c_uint64(0)
+        ok = C.c_int32(0)
+        self._chk(self.lib.eh_selftest_zlib(self.h, op, src.ctypes.data, len(data), out.ctypes.data, cap, C.byref(n), C.byref(ok)))
+        return bytes(out[:n.value]) if ok.value else None
 
     def selftest_movers(self, buf, jobs):
         buf = np.ascontiguousarray(buf, dtype=np.uint8).copy()

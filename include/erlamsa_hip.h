@@ -206,6 +206,11 @@ int eh_result_prof(eh_ctx* ctx, uint64_t* prof);
 /* Kernel self-test hook for the wave-level byte movers (tests only): jobs = njobs x
  * {kind (0 copy, 1 periodic fill, 2 equal), dst_off, src_off, n, plen} over the buffer image. */
 int eh_selftest_movers(eh_ctx* ctx, uint8_t* buf, uint64_t buf_len, const uint32_t* jobs, uint32_t njobs, uint32_t* eq_out);
+/* Self test of the device deflate / inflate behind the cp / ar patterns and the zip mutator (csrc/eh_zlib.h; replaces OTP's zlib
+ * binding on this path: erlamsa_patterns.erl:216-246).  op 0 raw deflate stream, 1 zlib:gzip/1, 2 zlib:deflate(Z, Data, finish) after
+ * deflateInit(Z, default), 4 zlib:gunzip/1, 5 zlib:inflate/2 without inflateEnd (a stream that just stops yields what was decoded).
+ * *ok = 0 where the reference's call raises (data_error, need_dictionary) or `cap` is too small. */
+int eh_selftest_zlib(eh_ctx* ctx, int op, const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len, int32_t* ok);
 
 /* Work-area pool of this context's device (diagnostic), 64 values; t = tier 1 .. out[40]: out[2t] / out[2t+1] = areas
  * of tier t taken / returned since the pool was made (+ the tier's size for the latter), out[20+t] = shader-clock ticks
