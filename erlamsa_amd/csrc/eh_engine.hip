@@ -259,6 +259,120 @@ __device__ __noinline__ int pick_csum(Ctx&, const uint8_t* H, uint32_t L, uint32
   return 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The container patterns (cp: gzip / zlib, ar: zip).  Both evaluate the rest of the pattern chain on a decoded payload
+// (prepare4sizer(mutate_once_loop(Mutator, [], NextPat, Ip, Data, []))) and then keep using the Mutator they were GIVEN, not
+// the one that evaluation returns: the scheduler's list (LaneTab), the lis / lrs / fo states and, when the result is thrown
+// away, the meta trace are put back.  What is parked lives in the work area until the frame is popped.
+// ---------------------------------------------------------------------------------------------------------------------
+struct MutatorSave { uint32_t lt_pri[64], lt_meta[64]; uint32_t aux_save[180]; int32_t nfs; uint32_t ntrace; };   // aux + 0 .. 720: StState x 2 + FoState
+EH_DEV void mutator_save(Ctx& c, MutatorSave* m, uint32_t e_pri, uint32_t e_meta) {
+  const int l = EH_LANE;
+  m->lt_pri[l] = e_pri; m->lt_meta[l] = e_meta;
+  const uint32_t* ax = (const uint32_t*)c.aux;
+  for (int i = l; i < 180; i += 64) m->aux_save[i] = ax[i];
+  if (l == 0) { m->nfs = c.nfs; m->ntrace = c.ntrace; }
+  wave_sync();
+}
+EH_DEV uint64_t mutator_restore(Ctx& c, const MutatorSave* m, bool trace_too) {   // returns the lane's (e_pri, e_meta)
+  const int l = EH_LANE;
+  wave_sync();
+  uint32_t* ax = (uint32_t*)c.aux;
+  for (int i = l; i < 180; i += 64) ax[i] = m->aux_save[i];
+  c.nfs = (int)uni((uint32_t)m->nfs);
+  if (trace_too) c.ntrace = uni(m->ntrace);
+  wave_sync();
+  return ((uint64_t)m->lt_pri[l] << 32) | m->lt_meta[l];
+}
+// the pieces em[from..nem) as one binary (iolist_to_binary of prepare4sizer); a single piece is used where it is
+EH_DEV uint8_t* gather_emits(Ctx& c, int from, uint64_t* len) {
+  uint64_t tot = 0; for (int k = from; k < c.nem; k++) tot += blk_load(c.em, k).len;
+  *len = tot;
+  if (tot > 0xFFFFFF00ull) { EH_SET_OVERFLOW(c, 316); return nullptr; }
+  if (c.nem - from == 1) return (uint8_t*)blk_load(c.em, from).ptr;
+  uint8_t* blob = ws_alloc_grow(c, tot + 16);
+  if (!blob) return nullptr;
+  uint64_t o = 0;
+  for (int k = from; k < c.nem; k++) { Blk x = blk_load(c.em, k); wave_copy(blob + o, (const uint8_t*)x.ptr, x.len); o += x.len; }
+  wave_sync();
+  return blob;
+}
+
+struct CpSide { MutatorSave m; Blk orig; int32_t fmt, nrest, ip, contpat; };   // + Blk rest[nrest]
+// mutate_once_compressed/6 (erlamsa_patterns.erl:216-246) up to the inner evaluation: zlib:gunzip(Bin), on data_error
+// zlib:inflate(Bin).  1: bl[cur] is the decoded Data alone and a P_CP frame waits for the evaluation; 0: not compressed
+// ({Bin, Meta}); -1: the case stops (status set).
+__device__ __noinline__ int cp_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, PatFrame* frames, int nfr, uint32_t ip, int contpat) {
+  EH_CTX;
+  const int l = EH_LANE;
+  const Blk b = blk_load(c.bl, c.cur);
+  const uint8_t* H = (const uint8_t*)b.ptr;
+  ZInf* zi = (ZInf*)ws_alloc_grow(c, sizeof(ZInf));
+  if (!zi) return -1;
+  int fmt = 0; uint8_t* data = nullptr; uint64_t dlen = 0;
+  for (int f = ZF_GZIP; f <= ZF_ZLIB && fmt == 0; f++) {
+    uint64_t outn, off;
+    if (!z_uncompress_size(zi, f, H, b.len, &outn, &off)) continue;
+    if (outn > 0xFFFFFF00ull) { EH_SET_OVERFLOW(c, 314); return -1; }
+    uint8_t* d = ws_alloc_grow(c, outn + 16);
+    if (!d) return -1;
+    if (z_uncompress_write(zi, f, H, b.len, off, d, outn)) { fmt = f; data = d; dlen = outn; }
+  }
+  if (fmt == 0) return 0;
+  if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 315); return -1; }
+  const int nrest = c.nb - c.cur - 1;
+  CpSide* sd = (CpSide*)ws_alloc_grow(c, sizeof(CpSide) + (uint64_t)nrest * sizeof(Blk));
+  if (!sd) return -1;
+  mutator_save(c, &sd->m, e_pri, e_meta);
+  Blk* rest = (Blk*)(sd + 1);
+  for (int i = l; i < nrest; i += 64) rest[i] = c.bl[c.cur + 1 + i];
+  if (l == 0) {
+    sd->orig = b; sd->fmt = fmt; sd->nrest = nrest; sd->ip = (int32_t)ip; sd->contpat = contpat;
+    PatFrame& f = frames[nfr];
+    f.kind = P_CP; f.em_field = c.nem; f.field = (uint8_t*)sd; f.size_bits = 0; f.big = 0; f.tail_ptr = 0; f.tail_len = 0; f.crc = 0;
+  }
+  wave_sync();
+  blk_store(c.bl, c.cur, (uint64_t)data, (uint32_t)dlen);                   // mutate_once_loop(Mutator, [], NextPat, Ip, Data, [])
+  c.nb = c.cur + 1;
+  wave_sync();
+  return 1;
+}
+// ... and after it: NewBin = zlib:gzip(NewData) | deflate(default), split({NewBin, Rest}), NewBin =:= Bin ? (:222-224,236-244,
+// 252-260).  c.pat_ret 1: [NewBin | Rest] is the result (bl[cur..nb), to be written as it is); 0: unchanged - the list is
+// [Bin | Rest] again, the Mutator and the trace are the ones from before, c.pat_ip / c.pat_cont say how mutate_once_loop goes
+// on; -1: the case stops.  Returns the lane's scheduler entry (e_pri << 32 | e_meta) to go on with.
+__device__ __noinline__ uint64_t cp_end(Ctx&, uint32_t e_pri, uint32_t e_meta, int em_field, uint8_t* side) {
+  EH_CTX;
+  const int l = EH_LANE;
+  const uint64_t keep = ((uint64_t)e_pri << 32) | e_meta;
+  CpSide* sd = (CpSide*)side;
+  const int fmt = (int)uni((uint32_t)sd->fmt), nrest = (int)uni((uint32_t)sd->nrest);
+  Blk orig; orig.ptr = uni64(sd->orig.ptr); orig.len = uni(sd->orig.len); orig.aux = 0;
+  c.pat_ret = -1; c.pat_ip = uni((uint32_t)sd->ip); c.pat_cont = (int)uni((uint32_t)sd->contpat);
+  uint64_t tot;
+  const uint8_t* nd = gather_emits(c, em_field, &tot);
+  if (tot > 0 && !nd) return keep;
+  c.nem = em_field;
+  ZDef* zd = (ZDef*)ws_alloc_grow(c, sizeof(ZDef));
+  if (!zd) return keep;
+  const uint64_t cap = z_deflate_bound(tot) + z_wrap_bytes(fmt);
+  uint8_t* dst = ws_alloc_grow(c, cap);
+  if (!dst) return keep;
+  const uint64_t nlen = z_compress(zd, fmt, nd, tot, dst, cap);
+  if (nlen == 0 || nlen > 0xFFFFFF00ull) { EH_SET_OVERFLOW(c, 317); return keep; }
+  const bool changed = nlen != orig.len || !wave_equal(dst, (const uint8_t*)orig.ptr, (uint32_t)nlen);
+  if (c.cur + 1 + nrest > MAX_BLOCKS) { EH_SET_OVERFLOW(c, 318); return keep; }
+  const Blk* rest = (const Blk*)(sd + 1);
+  wave_sync();
+  for (int i = l; i < nrest; i += 64) c.bl[c.cur + 1 + i] = rest[i];
+  if (changed) blk_store(c.bl, c.cur, (uint64_t)dst, (uint32_t)nlen); else blk_store(c.bl, c.cur, orig.ptr, orig.len);
+  c.nb = c.cur + 1 + nrest;
+  wave_sync();
+  c.pat_ret = changed ? 1 : 0;
+  if (changed) return keep;
+  return mutator_restore(c, &sd->m, true);
+}
+
 EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
   int act = A_RUN_PAT, cont = C_EMIT, contpat = 0; uint32_t ip = 0;
   int guard = 0;
@@ -348,13 +462,9 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               }
               if (has_zip_eocd((const uint8_t*)b.ptr, b.len)) { c.status = CASE_UNSUPPORTED; break; }
             } else if (pat == P_CP) {                                                 // mutate_once_compressed :216-260
-              // zlib:gunzip needs the 1f 8b magic, zlib:inflate a valid 2-byte zlib header; data
-              // that passes those checks would need OTP's zlib bit for bit
-              bool small = b.len < 2;
-              uint32_t b0 = small ? 0 : uni(H[0]), b1 = small ? 0 : uni(H[1]);
-              bool gz = b0 == 0x1f && b1 == 0x8b;
-              bool zl = (b0 & 0x0f) == 8 && (b0 >> 4) <= 7 && ((b0 << 8) | b1) % 31 == 0 && !(b1 & 0x20);
-              if (small || gz || zl) { c.status = CASE_UNSUPPORTED; break; }
+              int r = cp_begin(c, lt.e_pri, lt.e_meta, frames, nfr, ip, contpat);
+              if (r < 0) break;
+              if (r == 1) { nfr++; act = A_LOOP; break; }                             // the inner evaluation: Data is not split/1
             }
             split_head(c);
             act = A_LOOP;
@@ -401,7 +511,14 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
         PatFrame f = frames[--nfr];
         f.kind = (int)uni((uint32_t)f.kind); f.em_field = (int)uni((uint32_t)f.em_field); f.field = (uint8_t*)uni64((uint64_t)f.field);
         f.size_bits = uni(f.size_bits); f.big = uni(f.big); f.tail_ptr = uni64(f.tail_ptr); f.tail_len = uni(f.tail_len); f.crc = uni(f.crc);
-        if (f.kind == P_SZ) {
+        if (f.kind == P_CP) {
+          uint64_t e = cp_end(c, lt.e_pri, lt.e_meta, f.em_field, f.field);
+          lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
+          if (c.pat_ret < 0) break;
+          split_head(c);                                                              // {This, LlN} = split({NewBin, Rest}) :254
+          if (c.pat_ret == 1) emit_all(c);                                            // [NewBin | Rest] ++ [..]: no continuation (the pieces of split/1 are NewBin)
+          else { ip = c.pat_ip; cont = C_PAT; contpat = c.pat_cont; act = A_LOOP; }   // mutate_once_loop(Mutator, [{compressed, failed} | Meta], NextPat, Ip, This, LlN)
+        } else if (f.kind == P_SZ) {
           // NewLen = size(NewBlob) = everything written after the length field  (:105-110)
           uint64_t tot = 0; for (int k = f.em_field + 1; k < c.nem; k++) tot += blk_load(c.em, k).len;
           // (the field piece itself is at em_field unless Size/8 was 0, which cannot happen)

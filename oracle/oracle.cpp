@@ -15,6 +15,7 @@
 // Engine limits (work-area cap, optional work budget, the cpu_baseline leg's wall
 // clock watchdog) are NOT part of the restated functions: they live in EngineGuard,
 // a null pointer unless a caller asks for caps.
+#include <zlib.h>   // the dependency OTP's zlib module binds (this image: 1.2.11, the version OTP 20 - 23 bundle); used for cp / ar / zip only
 #include "oracle.h"
 
 #include <chrono>
@@ -2120,6 +2121,63 @@ int sgml_mutate(Ctx& c, BList& ll) {                                          //
 // ===========================================================================
 // erlamsa_patterns.erl
 // ===========================================================================
+// OTP zlib calls of the container paths, on libz itself
+// ===========================================================================
+namespace otpz {
+// zlib:gunzip/1 (OTP lib/kernel zlib.erl): inflateInit(Z, 16 + MAX_WBITS), inflate, inflateEnd - which raises data_error unless the
+// end of the stream was reached.  false = the call raises error:data_error.
+bool gunzip(const Bytes& in, Bytes* out) {
+  z_stream z; memset(&z, 0, sizeof(z));
+  if (inflateInit2(&z, 16 + 15) != Z_OK) throw std::runtime_error("inflateInit2");
+  out->clear(); bool ok = false;
+  z.next_in = (Bytef*)in.data(); z.avail_in = (uInt)in.size();
+  std::vector<uint8_t> buf(1 << 16);
+  while (true) {
+    z.next_out = buf.data(); z.avail_out = (uInt)buf.size();
+    int rc = inflate(&z, Z_NO_FLUSH);
+    out->insert(out->end(), buf.data(), buf.data() + (buf.size() - z.avail_out));
+    if (rc == Z_STREAM_END) { ok = true; break; }
+    if (rc != Z_OK) break;                                                     // data_error, or Z_BUF_ERROR: the input ran out
+    if (z.avail_in == 0 && z.avail_out != 0) break;
+  }
+  inflateEnd(&z);
+  return ok;
+}
+// zlib:inflateInit(Z), zlib:inflate(Z, Bin) and no inflateEnd (erlamsa_patterns.erl:232-234): what was decoded when the input ran
+// out is the result; false = the call raises (data_error, {need_dictionary, _}).
+bool inflate_noend(const Bytes& in, Bytes* out) {
+  z_stream z; memset(&z, 0, sizeof(z));
+  if (inflateInit(&z) != Z_OK) throw std::runtime_error("inflateInit");
+  out->clear(); bool ok = true;
+  z.next_in = (Bytef*)in.data(); z.avail_in = (uInt)in.size();
+  std::vector<uint8_t> buf(1 << 16);
+  while (true) {
+    z.next_out = buf.data(); z.avail_out = (uInt)buf.size();
+    int rc = inflate(&z, Z_NO_FLUSH);
+    out->insert(out->end(), buf.data(), buf.data() + (buf.size() - z.avail_out));
+    if (rc == Z_STREAM_END) break;
+    if (rc == Z_DATA_ERROR || rc == Z_NEED_DICT || rc == Z_MEM_ERROR || rc == Z_STREAM_ERROR) { ok = false; break; }
+    if (z.avail_in == 0 && z.avail_out != 0) break;                            // Z_OK / Z_BUF_ERROR with nothing left to read
+  }
+  inflateEnd(&z);
+  return ok;
+}
+// deflateInit(Z, default, deflated, WindowBits, 8, default) + deflate(Z, Data, finish): 31 = zlib:gzip/1, 15 = deflateInit(Z, default),
+// -15 = the raw stream zip:create writes
+Bytes deflate_all(const Bytes& in, int window_bits) {
+  z_stream z; memset(&z, 0, sizeof(z));
+  if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, window_bits, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2");
+  Bytes out(deflateBound(&z, (uLong)in.size()) + 64);
+  z.next_in = (Bytef*)in.data(); z.avail_in = (uInt)in.size(); z.next_out = out.data(); z.avail_out = (uInt)out.size();
+  int rc = deflate(&z, Z_FINISH);
+  if (rc != Z_STREAM_END) { deflateEnd(&z); throw std::runtime_error("deflate"); }
+  out.resize(z.total_out);
+  deflateEnd(&z);
+  return out;
+}
+}  // namespace otpz
+
+// ===========================================================================
 enum PatId { P_OD, P_ND, P_BU, P_SK, P_SZ, P_CS, P_AR, P_CP, P_CO, P_NU, P_COUNT };
 struct PatDef { const char* name; int pri; };
 const PatDef PAT_TABLE[P_COUNT] = {{"od", 1}, {"nd", 2}, {"bu", 1}, {"sk", 2}, {"sz", 2}, {"cs", 1}, {"ar", 1}, {"cp", 1}, {"co", 0}, {"nu", 0}};   // :395-405
@@ -2255,18 +2313,33 @@ struct PatEngine {
     split(one);
     mutate_once_loop(ip, one, next, sink);
   }
-  void compressed(BList ll, const Cont& next, Bytes& sink) {                  // mutate_once_compressed :216-260
+  void compressed(BList ll, const Cont& next, Bytes& sink) {                  // mutate_once_compressed/4 :248-260 and /6 :216-246
     int ip = (int)c.rnd.rand(INITIAL_IP);
     force(ll);
-    if (ll.empty()) throw ErlCrash("badarg");
-    const Bytes& bin = ll[0];
-    // zlib:gunzip needs the 1f 8b magic; zlib:inflate needs a valid 2-byte zlib header.
-    // Anything that gets past the header checks would need OTP's zlib bit-for-bit.
-    bool gz = bin.size() >= 2 && bin[0] == 0x1f && bin[1] == 0x8b;
-    bool zl = bin.size() >= 2 && (bin[0] & 0x0f) == 8 && (bin[0] >> 4) <= 7 && ((bin[0] << 8) | bin[1]) % 31 == 0 && !(bin[1] & 0x20);
-    if (gz || zl || bin.size() < 2) throw Unsupported();
-    split(ll);
-    mutate_once_loop(ip, ll, next, sink);
+    if (ll.empty()) throw ErlCrash("badarg: zlib:gunzip(false)");
+    const Bytes bin = ll[0]; BList rest(ll.begin() + 1, ll.end());
+    Bytes data; int fmt = 0;                                                  // 1 gzip, 2 zlib
+    if (otpz::gunzip(bin, &data)) fmt = 1;                                    // try zlib:gunzip(Bin) ... catch error:data_error -> deflate
+    else if (otpz::inflate_noend(bin, &data)) fmt = 2;                        // catch _:_ -> {Bin, Meta}
+    Bytes newbin = bin;
+    const std::vector<Muta> mutator = c.fs;                                   // the closures keep using Mutator, not what the inner evaluation returns
+    const size_t trace_mark = c.trace ? c.trace->size() : 0;
+    if (fmt) {
+      Bytes newdata;                                                          // prepare4sizer(mutate_once_loop(Mutator, [], NextPat, Ip, Data, []))
+      BList one{data};
+      mutate_once_loop(ip, one, next, newdata);
+      newbin = otpz::deflate_all(newdata, fmt == 1 ? 31 : 15);                // zlib:gzip(NewData) | deflateInit(ZD, default), deflate(ZD, [NewData], finish)
+      c.check_cap(newbin.size());
+    }
+    BList l2{newbin}; l2.insert(l2.end(), rest.begin(), rest.end());
+    split(l2);                                                                // {This, LlN} = split({NewBin, Rest}) :254
+    if (newbin != bin) {                                                      // [NewBin | Rest] ++ [{fun .. end, NewMeta}]
+      emit_all(l2, sink);                                                     // (the pieces of split/1 are NewBin again)
+      return;
+    }
+    c.fs = mutator;                                                           // mutate_once_loop(Mutator, [{compressed, failed} | Meta], ..): the inner
+    if (c.trace) c.trace->resize(trace_mark);                                 // evaluation's mutator state and meta are dropped
+    mutate_once_loop(ip, l2, next, sink);
   }
 };
 

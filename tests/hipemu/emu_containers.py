@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""The container paths against the oracle (which calls libz itself): pattern cp on real gzip / zlib inputs - complete, with header
+fields, truncated, corrupted, nested, behind a length field - decoded on the device, mutated through the rest of the pattern chain
+and compressed again byte for byte (erlamsa_patterns.erl:216-260); pattern ar and mutator zip on real zip archives
+(erlamsa_patterns.erl:165-214, erlamsa_mutations.erl:1149-1163).
+
+  ERLAMSA_HIP_LIB=build/liberlamsa_hip_emu.so python tests/hipemu/emu_containers.py [cases per configuration]
+"""
+import io
+import os
+import sys
+import zlib
+import zipfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import pyoracle as po
+import util
+import erlamsa_amd as ea
+
+
+def _z(data, wbits, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, 8, strategy)
+    return c.compress(data) + c.flush()
+
+
+def compressed_corpus(n, seed):
+    """gzip / zlib streams of mixed payloads (any encoder settings), and the ways they go wrong"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    plain = util.corpus_mixed(n, 3000, seed=seed)
+    out = []
+    for i, p in enumerate(plain):
+        p = p[:int(rng.integers(0, len(p) + 1))]
+        kind = i % 12
+        lvl = int(rng.choice([0, 1, 6, 9]))
+        if kind in (0, 1, 2):
+            b = _z(p, 31, lvl)
+        elif kind in (3, 4):
+            b = _z(p, 15, lvl)
+        elif kind == 5:                                                  # header with a name and a comment, trailing bytes behind the member
+            raw = _z(p, -15, lvl)
+            b = b"\x1f\x8b\x08\x18" + bytes(6) + b"file.bin\x00a comment\x00" + raw + zlib.crc32(p).to_bytes(4, "little") + (len(p) & 0xffffffff).to_bytes(4, "little") + b"TAIL"
+        elif kind == 6:                                                  # a zlib stream that just stops: inflate/2 returns what it decoded
+            full = _z(p, 15, lvl); b = full[:int(rng.integers(0, len(full) + 1))]
+        elif kind == 7:                                                  # a gzip member that just stops: gunzip raises, the zlib attempt too
+            full = _z(p, 31, lvl); b = full[:int(rng.integers(0, len(full)))]
+        elif kind == 8:                                                  # one flipped bit
+            full = bytearray(_z(p, 31 if rng.random() < 0.5 else 15, lvl))
+            full[int(rng.integers(0, len(full)))] ^= 1 << int(rng.integers(0, 8)); b = bytes(full)
+        elif kind == 9:                                                  # gzip inside gzip
+            b = _z(_z(p, 31, lvl), 31, 6)
+        elif kind == 10:                                                 # a 16-bit big-endian length field in front of a gzip member (sz then cp)
+            g = _z(p[:1500], 31, lvl); b = b"HD" + len(g).to_bytes(2, "big") + g + b"trailer"
+        else:
+            b = p                                                        # not compressed at all
+        out.append(b)
+    return out
+
+
+CP_CONFIGS = [
+    # mutators, patterns
+    ("bd,bf,bi,sr,sd,num,ld,lr,ab,uw", "cp"),
+    ("bd,bf,bi,sr,lr,num,nil=3", "cp,sz,cs,od,nd"),
+    (None, "cp=3,sz,sk,od,nd,bu,cs,co,nu"),
+]
+
+
+def run_cp(n=24, big=1 << 25):
+    total = skipped = 0
+    for ci, (muts, pats) in enumerate(CP_CONFIGS):
+        inputs = compressed_corpus(n, seed=300 + ci)
+        data, off = po.pack(inputs)
+        seed = (21 + ci, 4, 9)
+        want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=muts, patterns=pats, max_case_bytes=big, trace=True)
+        eng = ea.Engine(0)
+        eng.configure(mutations=muts, patterns=pats, max_case_bytes=1 << 20, big_case_bytes=big, flags=ea.engine.EH_FLAG_META_TRACE)
+        eng.upload_corpus(data, off)
+        eng.fuzz_batch(seed=seed)
+        got, gst = eng.download()
+        gdr, _ = eng.diag()
+        lines = tr.split("\n")
+        bad = []
+        for i in range(len(inputs)):
+            if gst[i] in (2, 3) or wst[i] in (2, 3):
+                skipped += 1
+                continue
+            ok = got[i] == want[i] and gst[i] == wst[i] and (gst[i] != 0 or gdr[i] == wdr[i])
+            if ok and gst[i] == 0:
+                mine = " ".join("%s:%s" % kv for kv in eng.meta(i))
+                ok = "truncated" in mine or mine == " ".join(lines[i].split())
+            if not ok:
+                bad.append(i)
+        eng.close()
+        total += len(inputs)
+        print("cp config %d: cases %d bad %d, statuses %s" % (ci, len(inputs), len(bad), np.bincount(gst, minlength=4).tolist()), flush=True)
+        for i in bad[:3]:
+            print("  case %d (input kind %d, %d bytes): first diff %d, len %d vs %d, status %d vs %d, draws %d vs %d, %s" % (
+                i, i % 12, len(inputs[i]), util.first_diff(got[i], want[i]), len(got[i]), len(want[i]), gst[i], wst[i], gdr[i], wdr[i], lines[i][:160]))
+        assert not bad, "cp config %d: %d cases differ" % (ci, len(bad))
+    assert skipped <= total // 10, "%d of %d cases ended at an engine limit" % (skipped, total)
+    return total
+
+
+if __name__ == "__main__":
+    assert "emu" in os.environ.get("ERLAMSA_HIP_LIB", ""), "point ERLAMSA_HIP_LIB at the emulator build"
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    print("containers ok: cp %d cases" % run_cp(n))

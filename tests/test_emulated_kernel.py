@@ -95,3 +95,20 @@ def test_emulated_file_and_jump_generators(emu_lib):
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_gens.py"), "12"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "gens ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_emulated_device_zlib_against_libz(emu_lib):
+    """csrc/eh_zlib.h against zlib itself (Python's zlib module = libz 1.2.11): level-6 streams byte for byte (raw, gzip, zlib wrappers),
+    the decoders on complete / truncated / corrupted inputs with the semantics of zlib:gunzip/1 and zlib:inflate/2"""
+    env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_zlib.py"), "quick"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "zlib ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_emulated_container_patterns(emu_lib):
+    """pattern cp on real gzip / zlib inputs (complete, with header fields, truncated, corrupted, nested, behind a length field):
+    decoded, mutated through the rest of the pattern chain and compressed again - bytes, statuses, draw counts and the meta trace
+    are the oracle's, whose zlib calls are libz's"""
+    env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_containers.py"), "24"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "containers ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -553,6 +553,33 @@ def test_file_and_jump_generators_vs_oracle():
     assert emu_gens.run(n=96) >= 700
 
 
+def test_device_zlib_against_libz():
+    """csrc/eh_zlib.h on the GPU against zlib itself (Python's zlib module, the image's libz 1.2.11 - the library OTP's zlib module
+    binds): the level-6 deflate stream byte for byte with the raw / gzip / zlib wrappers, and the decoders on complete,
+    truncated and corrupted inputs with the semantics of zlib:gunzip/1 and zlib:inflate/2 (erlamsa_patterns.erl:216-246)."""
+    if util.priming():
+        pytest.skip("no oracle involved")
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    import emu_zlib
+    nc, nd = emu_zlib.run(quick=True)
+    assert nc >= 100 and nd >= 2000
+
+
+def test_container_patterns_vs_oracle():
+    """Pattern cp (erlamsa_patterns.erl:216-260) on real gzip / zlib inputs: zlib:gunzip / zlib:inflate on the device, the rest of the
+    pattern chain on the payload with the Mutator put back afterwards, zlib:gzip / zlib:deflate(default) byte for byte - bytes,
+    statuses, draw counts and the meta trace against the oracle, whose zlib calls are libz's."""
+    if util.priming():
+        pytest.skip("live oracle (small)")
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    import emu_containers
+    assert emu_containers.run_cp(n=60) >= 180
+
+
 def test_two_rank_nccl_bench_smoke():
     """bench.py over RCCL with 2 ranks on one node (arena broadcast, case-range sharding, MAX-over-ranks timing), weak and
     strong: skipped on boxes with fewer than 2 GPUs (the builder's and the driver's test boxes have one; the 8-GPU runs are
