@@ -37,6 +37,7 @@
 #include "eh_sgml.h"
 #include "eh_json.h"
 #include "eh_zlib.h"
+#include "eh_zip.h"
 
 namespace eh {
 
@@ -373,6 +374,99 @@ __device__ __noinline__ uint64_t cp_end(Ctx&, uint32_t e_pri, uint32_t e_meta, i
   return mutator_restore(c, &sd->m, true);
 }
 
+struct ArSide { MutatorSave m; Blk archive; int32_t n, idx, ip, contpat; ZipEntry* es; };
+// mutate_once_archiver/4 (erlamsa_patterns.erl:203-214): UnZip = zip:foldl(fun(N, I, B, Acc) -> [{N, B(), I()} | Acc] end, [], ..) over
+// bl[cur] (the whole list as one binary).  c.pat_ret 1: an archive - the side block (returned) holds its entries and the Mutator;
+// 0: {error, _}; -1: the case stops.
+__device__ __noinline__ uint8_t* ar_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, uint32_t ip, int contpat) {
+  EH_CTX;
+  const Blk b = blk_load(c.bl, c.cur);
+  c.pat_ret = -1;
+  ZipRd* rd = (ZipRd*)ws_alloc_grow(c, sizeof(ZipRd));
+  if (!rd) return nullptr;
+  int rc = zip_open(rd, (const uint8_t*)b.ptr, b.len);
+  if (rc == ZR_UNSUP) { c.status = CASE_UNSUPPORTED; return nullptr; }
+  if (rc != ZR_OK) { c.pat_ret = 0; return nullptr; }
+  const uint32_t n = uni(rd->entries);
+  ArSide* sd = (ArSide*)ws_alloc_grow(c, sizeof(ArSide));
+  if (!sd) return nullptr;
+  ZipEntry* es = (ZipEntry*)ws_alloc_grow(c, (uint64_t)(n ? n : 1) * sizeof(ZipEntry));
+  if (!es) return nullptr;
+  for (uint32_t i = 0; i < n; i++) {
+    rc = zip_next<true>(c, rd, &es[i]);
+    if (rc == ZR_STOP) return nullptr;
+    if (rc == ZR_UNSUP) { c.status = CASE_UNSUPPORTED; return nullptr; }
+    if (rc == ZR_CRASH) { c.status = CASE_CRASHED; return nullptr; }
+    if (rc != ZR_OK) { c.pat_ret = 0; return nullptr; }
+  }
+  mutator_save(c, &sd->m, e_pri, e_meta);
+  if (EH_LANE == 0) { sd->archive = b; sd->n = (int32_t)n; sd->idx = (int32_t)n - 1; sd->ip = (int32_t)ip; sd->contpat = contpat; sd->es = es; }
+  wave_sync();
+  c.pat_ret = 1;
+  return (uint8_t*)sd;
+}
+// The lists:mapfoldl of mutate_once_archiver/7 (:175-186) from entry sd->idx downwards (FileSpec is in reverse central-directory
+// order): R = rand(1000) per file, R > 750 runs the rest of the pattern chain on the file's bytes.  c.pat_ret 2: bl[cur] is such a
+// file and a P_AR frame waits for the evaluation; 1: all files done and zip:create gave bl[cur] = NewBin; 0: zip:create failed -
+// bl[cur] is the archive again, Mutator and trace are put back (the {error, _} clause, :165-174); -1: the case stops.
+// Returns the lane's scheduler entry to go on with.
+__device__ __noinline__ uint64_t ar_step(Ctx&, uint32_t e_pri, uint32_t e_meta, uint8_t* side, PatFrame* frames, int nfr) {
+  EH_CTX;
+  const uint64_t keep = ((uint64_t)e_pri << 32) | e_meta;
+  ArSide* sd = (ArSide*)side;
+  ZipEntry* es = (ZipEntry*)uni64((uint64_t)sd->es);
+  const int n = (int)uni((uint32_t)sd->n);
+  c.pat_ret = -1; c.pat_ip = uni((uint32_t)sd->ip); c.pat_cont = (int)uni((uint32_t)sd->contpat);
+  int idx = (int)uni((uint32_t)sd->idx);
+  while (idx >= 0) {
+    uint32_t r = rng_rand(c.rng, 1000);
+    if (r > 750) {                                                                      // 25 % of the files are mutated
+      if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 319); return keep; }
+      blk_store(c.bl, c.cur, uni64(es[idx].data), uni(es[idx].data_len));
+      c.nb = c.cur + 1;
+      if (EH_LANE == 0) {
+        sd->idx = idx;
+        PatFrame& f = frames[nfr];
+        f.kind = P_AR; f.em_field = c.nem; f.field = side; f.size_bits = 0; f.big = 0; f.tail_ptr = 0; f.tail_len = 0; f.crc = 0;
+      }
+      wave_sync();
+      c.pat_ret = 2;
+      return keep;
+    }
+    idx--;
+  }
+  uint8_t* out; uint64_t len;
+  int rc = zip_create<true>(c, es, (uint32_t)n, &out, &len);                            // zip:create(Name, lists:reverse(NewFileSpec), [memory])
+  if (rc == ZR_STOP) return keep;
+  if (rc == ZR_UNSUP) { c.status = CASE_UNSUPPORTED; return keep; }
+  if (rc == ZR_OK) {
+    blk_store(c.bl, c.cur, (uint64_t)out, (uint32_t)len); c.nb = c.cur + 1;
+    wave_sync();
+    c.pat_ret = 1;
+    return keep;
+  }
+  blk_store(c.bl, c.cur, uni64(sd->archive.ptr), uni(sd->archive.len)); c.nb = c.cur + 1;
+  wave_sync();
+  c.pat_ret = 0;
+  return mutator_restore(c, &sd->m, true);
+}
+// a file's evaluation ended: its pieces are the file's new bytes (prepare4sizer), the next file starts from the Mutator again
+__device__ __noinline__ uint64_t ar_file_done(Ctx&, int em_field, uint8_t* side) {
+  EH_CTX;
+  ArSide* sd = (ArSide*)side;
+  ZipEntry* es = (ZipEntry*)uni64((uint64_t)sd->es);
+  const int idx = (int)uni((uint32_t)sd->idx);
+  uint64_t tot;
+  uint8_t* nb = gather_emits(c, em_field, &tot);
+  c.pat_ret = -1;
+  if (!nb) return 0;
+  c.nem = em_field;
+  if (EH_LANE == 0) { es[idx].data = (uint64_t)nb; es[idx].data_len = (uint32_t)tot; sd->idx = idx - 1; }
+  wave_sync();
+  c.pat_ret = 0;
+  return mutator_restore(c, &sd->m, false);
+}
+
 EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
   int act = A_RUN_PAT, cont = C_EMIT, contpat = 0; uint32_t ip = 0;
   int guard = 0;
@@ -460,7 +554,15 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
                 wave_sync();
                 b = blk_load(c.bl, c.cur);
               }
-              if (has_zip_eocd((const uint8_t*)b.ptr, b.len)) { c.status = CASE_UNSUPPORTED; break; }
+              uint8_t* side = ar_begin(c, lt.e_pri, lt.e_meta, ip, contpat);
+              if (c.pat_ret < 0) break;
+              if (c.pat_ret == 1) {
+                uint64_t e = ar_step(c, lt.e_pri, lt.e_meta, side, frames, nfr);
+                lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
+                if (c.pat_ret < 0) break;
+                if (c.pat_ret == 2) { nfr++; act = A_LOOP; break; }                   // mutate_once_loop(Mutator, [], NextPat, Ip, B, [])
+                if (c.pat_ret == 1) { emit_all(c); act = A_TERMINAL; break; }         // [NewBin | {..}]
+              }
             } else if (pat == P_CP) {                                                 // mutate_once_compressed :216-260
               int r = cp_begin(c, lt.e_pri, lt.e_meta, frames, nfr, ip, contpat);
               if (r < 0) break;
@@ -511,7 +613,18 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
         PatFrame f = frames[--nfr];
         f.kind = (int)uni((uint32_t)f.kind); f.em_field = (int)uni((uint32_t)f.em_field); f.field = (uint8_t*)uni64((uint64_t)f.field);
         f.size_bits = uni(f.size_bits); f.big = uni(f.big); f.tail_ptr = uni64(f.tail_ptr); f.tail_len = uni(f.tail_len); f.crc = uni(f.crc);
-        if (f.kind == P_CP) {
+        if (f.kind == P_AR) {
+          uint64_t e = ar_file_done(c, f.em_field, f.field);
+          if (c.pat_ret < 0) break;
+          lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
+          e = ar_step(c, lt.e_pri, lt.e_meta, f.field, frames, nfr);
+          lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
+          if (c.pat_ret < 0) break;
+          ip = c.pat_ip; cont = C_PAT; contpat = c.pat_cont;
+          if (c.pat_ret == 2) { nfr++; act = A_LOOP; }                                // the next file's evaluation
+          else if (c.pat_ret == 1) emit_all(c);                                       // [NewBin | {..}]: terminal
+          else { split_head(c); act = A_LOOP; }                                       // zip:create failed: the {error, _} clause
+        } else if (f.kind == P_CP) {
           uint64_t e = cp_end(c, lt.e_pri, lt.e_meta, f.em_field, f.field);
           lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
           if (c.pat_ret < 0) break;

@@ -368,14 +368,6 @@ EH_DEV bool has_zip_eocd(const uint8_t* H, uint32_t L) {
   }
   return __ballot(found != 0) != 0;
 }
-__device__ __noinline__ int muta_zip(Ctx&) {
-  EH_CTX;                                   // zip_path_traversal :1149-1163
-  Blk hb = blk_load(c.bl, c.cur);
-  c.r_kind = R_SAME;
-  if (has_zip_eocd((const uint8_t*)hb.ptr, hb.len)) { c.status = CASE_UNSUPPORTED; return 0; }
-  return -1;
-}
-
 // base64:decode/1 acceptance (stdlib, restated in oracle/otp_compat.h): groups of four sextets, "xx==" / "xxx="
 // tails, white space skipped anywhere, only white space after the padding.  Returns the decoded length or -1;
 // with dst != nullptr lane 0 also writes the bytes.

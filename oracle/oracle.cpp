@@ -50,7 +50,7 @@ const size_t PREAMBLE_MAX_BYTES = 32;
 struct Overflow {};     // engine cap exceeded (not a reference behaviour)
 struct Timeout {};      // wall-clock watchdog of the cpu_baseline leg (maxrunningtime)
 struct Budget {};       // engine work budget exceeded (deterministic stand-in for maxrunningtime)
-struct Unsupported {};  // container success paths (zip/zlib re-encode) not restated
+struct Unsupported {};  // zip archives with features oracle's prim_zip / zip restatement does not pin (see otpzip)
 
 // ===========================================================================
 // erlamsa_rnd.erl
@@ -1085,20 +1085,220 @@ int length_predict(Ctx& c, BList& ll) {
   return +1;
 }
 
+// ===========================================================================
+// OTP zlib calls of the container paths, on libz itself
+// ===========================================================================
+namespace otpz {
+// zlib:gunzip/1 (OTP lib/kernel zlib.erl): inflateInit(Z, 16 + MAX_WBITS), inflate, inflateEnd - which raises data_error unless the
+// end of the stream was reached.  false = the call raises error:data_error.
+bool gunzip(const Bytes& in, Bytes* out) {
+  z_stream z; memset(&z, 0, sizeof(z));
+  if (inflateInit2(&z, 16 + 15) != Z_OK) throw std::runtime_error("inflateInit2");
+  out->clear(); bool ok = false;
+  z.next_in = (Bytef*)in.data(); z.avail_in = (uInt)in.size();
+  std::vector<uint8_t> buf(1 << 16);
+  while (true) {
+    z.next_out = buf.data(); z.avail_out = (uInt)buf.size();
+    int rc = inflate(&z, Z_NO_FLUSH);
+    out->insert(out->end(), buf.data(), buf.data() + (buf.size() - z.avail_out));
+    if (rc == Z_STREAM_END) { ok = true; break; }
+    if (rc != Z_OK) break;                                                     // data_error, or Z_BUF_ERROR: the input ran out
+    if (z.avail_in == 0 && z.avail_out != 0) break;
+  }
+  inflateEnd(&z);
+  return ok;
+}
+// zlib:inflateInit(Z), zlib:inflate(Z, Bin) and no inflateEnd (erlamsa_patterns.erl:232-234): what was decoded when the input ran
+// out is the result; false = the call raises (data_error, {need_dictionary, _}).
+bool inflate_noend(const Bytes& in, Bytes* out) {
+  z_stream z; memset(&z, 0, sizeof(z));
+  if (inflateInit(&z) != Z_OK) throw std::runtime_error("inflateInit");
+  out->clear(); bool ok = true;
+  z.next_in = (Bytef*)in.data(); z.avail_in = (uInt)in.size();
+  std::vector<uint8_t> buf(1 << 16);
+  while (true) {
+    z.next_out = buf.data(); z.avail_out = (uInt)buf.size();
+    int rc = inflate(&z, Z_NO_FLUSH);
+    out->insert(out->end(), buf.data(), buf.data() + (buf.size() - z.avail_out));
+    if (rc == Z_STREAM_END) break;
+    if (rc == Z_DATA_ERROR || rc == Z_NEED_DICT || rc == Z_MEM_ERROR || rc == Z_STREAM_ERROR) { ok = false; break; }
+    if (z.avail_in == 0 && z.avail_out != 0) break;                            // Z_OK / Z_BUF_ERROR with nothing left to read
+  }
+  inflateEnd(&z);
+  return ok;
+}
+// deflateInit(Z, default, deflated, WindowBits, 8, default) + deflate(Z, Data, finish): 31 = zlib:gzip/1, 15 = deflateInit(Z, default),
+// -15 = the raw stream zip:create writes
+Bytes deflate_all(const Bytes& in, int window_bits) {
+  z_stream z; memset(&z, 0, sizeof(z));
+  if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, window_bits, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2");
+  Bytes out(deflateBound(&z, (uLong)in.size()) + 64);
+  z.next_in = (Bytef*)in.data(); z.avail_in = (uInt)in.size(); z.next_out = out.data(); z.avail_out = (uInt)out.size();
+  int rc = deflate(&z, Z_FINISH);
+  if (rc != Z_STREAM_END) { deflateEnd(&z); throw std::runtime_error("deflate"); }
+  out.resize(z.total_out);
+  deflateEnd(&z);
+  return out;
+}
+}  // namespace otpz
+
+// ===========================================================================
+// OTP zip:foldl/3 (prim_zip) and zip:create/3 with [memory], as the ar pattern and the zip mutator use them
+// (erlamsa_patterns.erl:193-213, erlamsa_mutations.erl:1149-1163).  OTP's stdlib is not under /root/reference: this restates
+// prim_zip.erl / zip.erl of OTP 18 - 23 (the reference's CI range) for the archives they agree on, and says UNSUPPORTED
+// where the outcome depends on corners this restatement does not pin (ZIP64 markers, encrypted or data-descriptor entries,
+// directory entries, names that are empty or not ASCII, a local header outside the file).
+//   foldl:  the end-of-central-directory record is searched in the last 22, 44, 88, .. bytes (first signature in the
+//           window; no record within 64 K: {error, bad_eocd}); its comment length must match what follows; the central
+//           directory is walked entry by entry and the fun is called for each (so a later broken entry fails the call after
+//           earlier entries were handed out); a file's bytes come from its LOCAL header's method and compressed size
+//           (0 stored, 8 inflate with -MAX_WBITS, anything else throws); prim_zip checks no CRC; an inflate data_error is an
+//           error exception nobody catches (the worker dies); a deflate stream that just stops yields what it decoded.
+//   create: local header (version needed 20, flags 0, method, the entry's DOS time / date, CRC-32 and compressed size patched
+//           in afterwards, uncompressed size = the file_info's size - NOT the size of the new binary), name, data; central
+//           directory (version made by 20, attributes 0); end record without comment.  Method: stored below 10 bytes and for
+//           the extensions .Z .zip .zoo .arc .lzh .arj, deflated otherwise.  At most file_info.size bytes of the binary are
+//           read, in 8 K chunks; `finish` is passed with the chunk the counter ends on, so a binary that ends before that
+//           chunk leaves the stream unfinished and zip:create returns {error, _} (deflateEnd raises data_error).
+// ===========================================================================
+namespace otpzip {
+struct Entry { Bytes name; uint16_t time = 0, date = 0; uint32_t usize = 0; Bytes data; };
+enum { ZR_OK = 0, ZR_ERROR = 1, ZR_CRASH = 2, ZR_UNSUP = 3 };
+struct Reader { const Bytes* a; uint32_t entries = 0, idx = 0; uint64_t pos = 0; };
+inline uint32_t le16(const uint8_t* p) { return p[0] | (p[1] << 8); }
+inline uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+int open(const Bytes& a, Reader* r) {
+  const uint64_t n = a.size();
+  if (n < 22) return ZR_ERROR;
+  uint64_t at = UINT64_MAX;
+  for (uint64_t sz = 22; sz <= 0xffff && at == UINT64_MAX; sz += sz) {          // get_end_of_central_dir: Sz, Sz+Sz, ..
+    uint64_t start = n > sz ? n - sz : 0;
+    for (uint64_t i = start; i + 22 <= n; i++) if (a[i] == 0x50 && a[i + 1] == 0x4b && a[i + 2] == 0x05 && a[i + 3] == 0x06) { at = i; break; }
+    if (start == 0) break;
+  }
+  if (at == UINT64_MAX) return ZR_ERROR;                                         // bad_eocd
+  const uint8_t* e = a.data() + at + 4;
+  uint32_t entries = le16(e + 6), off = le32(e + 12), clen = le16(e + 16);
+  if (at + 22 + clen != n) return ZR_ERROR;                                      // eocd_and_comment_from_bin(_) -> throw(bad_eocd)
+  if (entries == 0xffff || off == 0xffffffffu) return ZR_UNSUP;                  // ZIP64
+  r->a = &a; r->entries = entries; r->idx = 0; r->pos = off;
+  return ZR_OK;
+}
+int next(Reader* r, Entry* out) {
+  const Bytes& a = *r->a; const uint64_t n = a.size();
+  if (r->pos + 46 > n) return ZR_ERROR;                                          // bad_central_directory
+  const uint8_t* h = a.data() + r->pos;
+  if (le32(h) != 0x02014b50u) return ZR_ERROR;
+  uint32_t gp = le16(h + 8), fnl = le16(h + 28), exl = le16(h + 30), cml = le16(h + 32), lho = le32(h + 42);
+  if (r->pos + 46 + fnl + exl + cml > n) return ZR_ERROR;
+  out->time = (uint16_t)le16(h + 12); out->date = (uint16_t)le16(h + 14); out->usize = le32(h + 24);
+  out->name.assign(h + 46, h + 46 + fnl);
+  r->pos += 46 + fnl + exl + cml; r->idx++;
+  if (fnl == 0 || out->name.back() == '/' || (gp & 9) || le32(h + 20) == 0xffffffffu || out->usize == 0xffffffffu || lho == 0xffffffffu) return ZR_UNSUP;
+  for (uint8_t ch : out->name) if (ch > 127) return ZR_UNSUP;
+  if ((uint64_t)lho + 30 > n) return ZR_UNSUP;
+  const uint8_t* l = a.data() + lho;
+  if (le32(l) != 0x04034b50u) return ZR_ERROR;                                   // bad_local_file_header
+  uint32_t lgp = le16(l + 6), method = le16(l + 8), csz = le32(l + 18), lfn = le16(l + 26), lex = le16(l + 28);
+  if (lgp & 9) return ZR_UNSUP;
+  uint64_t ds = (uint64_t)lho + 30 + lfn + lex;
+  if (ds > n) return ZR_UNSUP;
+  uint64_t de = ds + csz > n ? n : ds + csz;
+  if (method == 0) { out->data.assign(a.begin() + ds, a.begin() + de); return ZR_OK; }
+  if (method != 8) return ZR_ERROR;                                              // throw({bad_file_header, _})
+  z_stream z; memset(&z, 0, sizeof(z));
+  if (inflateInit2(&z, -15) != Z_OK) throw std::runtime_error("inflateInit2");
+  out->data.clear();
+  z.next_in = (Bytef*)a.data() + ds; z.avail_in = (uInt)(de - ds);
+  std::vector<uint8_t> buf(1 << 16); int res = ZR_OK;
+  while (true) {
+    z.next_out = buf.data(); z.avail_out = (uInt)buf.size();
+    int rc = inflate(&z, Z_NO_FLUSH);
+    out->data.insert(out->data.end(), buf.data(), buf.data() + (buf.size() - z.avail_out));
+    if (rc == Z_STREAM_END) break;
+    if (rc == Z_DATA_ERROR || rc == Z_NEED_DICT || rc == Z_MEM_ERROR || rc == Z_STREAM_ERROR) { res = ZR_CRASH; break; }
+    if (z.avail_in == 0 && z.avail_out != 0) break;
+  }
+  inflateEnd(&z);
+  return res;
+}
+bool stored_ext(const Bytes& name) {                                              // filename:extension/1 in [".Z", ".zip", ".zoo", ".arc", ".lzh", ".arj"]
+  size_t dot = std::string::npos;
+  for (size_t i = 0; i < name.size(); i++) { if (name[i] == '.') dot = i; else if (name[i] == '/') dot = std::string::npos; }
+  if (dot == std::string::npos) return false;
+  std::string e(name.begin() + dot, name.end());
+  return e == ".Z" || e == ".zip" || e == ".zoo" || e == ".arc" || e == ".lzh" || e == ".arj";
+}
+void put16(Bytes& o, uint32_t v) { o.push_back(v & 255); o.push_back((v >> 8) & 255); }
+void put32(Bytes& o, uint32_t v) { put16(o, v & 0xffff); put16(o, v >> 16); }
+int create(const std::vector<Entry>& es, Bytes* out) {
+  out->clear();
+  struct Rec { uint32_t method, crc, csz, pos; };
+  std::vector<Rec> recs;
+  for (auto& e : es) {
+    const uint64_t U = e.usize, S = e.data.size();
+    Rec rc; rc.pos = (uint32_t)out->size();
+    rc.method = (U < 10 || stored_ext(e.name)) ? 0 : 8;
+    uint64_t take = S < U ? S : U;
+    Bytes payload;
+    if (U == 0) { rc.crc = 0; }                                                   // put_z_file(_Method, 0, ..) -> {Out, Pos, 0}
+    else if (rc.method == 0) {
+      if (S == 0) return ZR_ERROR;                                                // {read, U} -> eof -> Output({write, eof}) exits
+      payload.assign(e.data.begin(), e.data.begin() + take); rc.crc = otp::crc32(payload.data(), payload.size());
+    } else {
+      uint64_t last_chunk_pos = 8192 * ((U + 8191) / 8192 - 1);
+      if (S == 0) { rc.crc = 0; }                                                 // the first read is eof: nothing was deflated, deflateEnd is fine
+      else if (S <= last_chunk_pos) return ZR_ERROR;                              // unfinished stream: deflateEnd -> data_error
+      else { Bytes in(e.data.begin(), e.data.begin() + take); payload = otpz::deflate_all(in, -15); rc.crc = otp::crc32(in.data(), in.size()); }
+    }
+    rc.csz = (uint32_t)payload.size();
+    put32(*out, 0x04034b50u); put16(*out, 20); put16(*out, 0); put16(*out, rc.method); put16(*out, e.time); put16(*out, e.date);
+    put32(*out, rc.crc); put32(*out, rc.csz); put32(*out, (uint32_t)U); put16(*out, (uint32_t)e.name.size()); put16(*out, 0);
+    out->insert(out->end(), e.name.begin(), e.name.end());
+    out->insert(out->end(), payload.begin(), payload.end());
+    recs.push_back(rc);
+  }
+  const uint32_t cd = (uint32_t)out->size();
+  for (size_t i = 0; i < es.size(); i++) {
+    const Entry& e = es[i]; const Rec& rc = recs[i];
+    put32(*out, 0x02014b50u); put16(*out, 20); put16(*out, 20); put16(*out, 0); put16(*out, rc.method); put16(*out, e.time); put16(*out, e.date);
+    put32(*out, rc.crc); put32(*out, rc.csz); put32(*out, e.usize); put16(*out, (uint32_t)e.name.size()); put16(*out, 0); put16(*out, 0);
+    put16(*out, 0); put16(*out, 0); put32(*out, 0); put32(*out, rc.pos);
+    out->insert(out->end(), e.name.begin(), e.name.end());
+  }
+  const uint32_t cdsz = (uint32_t)out->size() - cd;
+  put32(*out, 0x06054b50u); put16(*out, 0); put16(*out, 0); put16(*out, (uint32_t)es.size()); put16(*out, (uint32_t)es.size()); put32(*out, cdsz); put32(*out, cd); put16(*out, 0);
+  return ZR_OK;
+}
+}  // namespace otpzip
+
 int nomutation(Ctx&, BList&) { return -1; }                                   // :1104-1105
 
-// zip_path_traversal :1149-1163 — zip:foldl fails with {error, bad_eocd} unless an
-// end-of-central-directory record can be located; the success path needs OTP's
-// zip+zlib writers and is not restated (EO_UNSUPPORTED).
-bool has_zip_eocd(const Bytes& b) {
-  if (b.size() < 22) return false;
-  size_t lo = b.size() > 22 + 65535 ? b.size() - 22 - 65535 : 0;
-  for (size_t i = b.size() - 22 + 1; i-- > lo;) if (b[i] == 0x50 && b[i + 1] == 0x4b && b[i + 2] == 0x05 && b[i + 3] == 0x06) return true;
-  return false;
-}
-int zip_path_traversal(Ctx&, BList& ll) {
-  if (has_zip_eocd(ll[0])) throw Unsupported();
-  return -1;
+// zip_path_traversal :1149-1163: zip:foldl(fun mutate_zip_path/4, ..) draws rand(20) for every entry as the central directory is
+// walked and reads the entry; {ok, FileSpec} -> {ok, {_, Bin}} = zip:create(..) (a failing create is a badmatch); anything else: -1.
+int zip_path_traversal(Ctx& c, BList& ll) {
+  otpzip::Reader rd; std::vector<otpzip::Entry> es;
+  int rc = otpzip::open(ll[0], &rd);
+  if (rc == otpzip::ZR_UNSUP) throw Unsupported();
+  if (rc != otpzip::ZR_OK) return -1;
+  for (uint32_t i = 0; i < rd.entries; i++) {
+    uint64_t r = c.rnd.rand(20);                                               // mutate_zip_path/4 :1149-1152
+    otpzip::Entry e;
+    rc = otpzip::next(&rd, &e);
+    if (rc == otpzip::ZR_UNSUP) throw Unsupported();
+    if (rc == otpzip::ZR_CRASH) throw ErlCrash("data_error in zip:foldl");
+    if (rc != otpzip::ZR_OK) return -1;
+    Bytes nn; for (uint64_t k = 0; k < r; k++) { nn.push_back('.'); nn.push_back('.'); nn.push_back('/'); }
+    nn.insert(nn.end(), e.name.begin(), e.name.end()); e.name = nn;
+    if (e.name.size() > 0xffff) throw Unsupported();
+    es.push_back(e);
+  }
+  Bytes out;
+  rc = otpzip::create(es, &out);
+  if (rc != otpzip::ZR_OK) throw ErlCrash("badmatch: zip:create");
+  c.check_cap(out.size());
+  ll[0] = out;
+  return +1;
 }
 
 // fwd decls for mutators that recurse into the scheduler
@@ -2121,63 +2321,6 @@ int sgml_mutate(Ctx& c, BList& ll) {                                          //
 // ===========================================================================
 // erlamsa_patterns.erl
 // ===========================================================================
-// OTP zlib calls of the container paths, on libz itself
-// ===========================================================================
-namespace otpz {
-// zlib:gunzip/1 (OTP lib/kernel zlib.erl): inflateInit(Z, 16 + MAX_WBITS), inflate, inflateEnd - which raises data_error unless the
-// end of the stream was reached.  false = the call raises error:data_error.
-bool gunzip(const Bytes& in, Bytes* out) {
-  z_stream z; memset(&z, 0, sizeof(z));
-  if (inflateInit2(&z, 16 + 15) != Z_OK) throw std::runtime_error("inflateInit2");
-  out->clear(); bool ok = false;
-  z.next_in = (Bytef*)in.data(); z.avail_in = (uInt)in.size();
-  std::vector<uint8_t> buf(1 << 16);
-  while (true) {
-    z.next_out = buf.data(); z.avail_out = (uInt)buf.size();
-    int rc = inflate(&z, Z_NO_FLUSH);
-    out->insert(out->end(), buf.data(), buf.data() + (buf.size() - z.avail_out));
-    if (rc == Z_STREAM_END) { ok = true; break; }
-    if (rc != Z_OK) break;                                                     // data_error, or Z_BUF_ERROR: the input ran out
-    if (z.avail_in == 0 && z.avail_out != 0) break;
-  }
-  inflateEnd(&z);
-  return ok;
-}
-// zlib:inflateInit(Z), zlib:inflate(Z, Bin) and no inflateEnd (erlamsa_patterns.erl:232-234): what was decoded when the input ran
-// out is the result; false = the call raises (data_error, {need_dictionary, _}).
-bool inflate_noend(const Bytes& in, Bytes* out) {
-  z_stream z; memset(&z, 0, sizeof(z));
-  if (inflateInit(&z) != Z_OK) throw std::runtime_error("inflateInit");
-  out->clear(); bool ok = true;
-  z.next_in = (Bytef*)in.data(); z.avail_in = (uInt)in.size();
-  std::vector<uint8_t> buf(1 << 16);
-  while (true) {
-    z.next_out = buf.data(); z.avail_out = (uInt)buf.size();
-    int rc = inflate(&z, Z_NO_FLUSH);
-    out->insert(out->end(), buf.data(), buf.data() + (buf.size() - z.avail_out));
-    if (rc == Z_STREAM_END) break;
-    if (rc == Z_DATA_ERROR || rc == Z_NEED_DICT || rc == Z_MEM_ERROR || rc == Z_STREAM_ERROR) { ok = false; break; }
-    if (z.avail_in == 0 && z.avail_out != 0) break;                            // Z_OK / Z_BUF_ERROR with nothing left to read
-  }
-  inflateEnd(&z);
-  return ok;
-}
-// deflateInit(Z, default, deflated, WindowBits, 8, default) + deflate(Z, Data, finish): 31 = zlib:gzip/1, 15 = deflateInit(Z, default),
-// -15 = the raw stream zip:create writes
-Bytes deflate_all(const Bytes& in, int window_bits) {
-  z_stream z; memset(&z, 0, sizeof(z));
-  if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, window_bits, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2");
-  Bytes out(deflateBound(&z, (uLong)in.size()) + 64);
-  z.next_in = (Bytef*)in.data(); z.avail_in = (uInt)in.size(); z.next_out = out.data(); z.avail_out = (uInt)out.size();
-  int rc = deflate(&z, Z_FINISH);
-  if (rc != Z_STREAM_END) { deflateEnd(&z); throw std::runtime_error("deflate"); }
-  out.resize(z.total_out);
-  deflateEnd(&z);
-  return out;
-}
-}  // namespace otpz
-
-// ===========================================================================
 enum PatId { P_OD, P_ND, P_BU, P_SK, P_SZ, P_CS, P_AR, P_CP, P_CO, P_NU, P_COUNT };
 struct PatDef { const char* name; int pri; };
 const PatDef PAT_TABLE[P_COUNT] = {{"od", 1}, {"nd", 2}, {"bu", 1}, {"sk", 2}, {"sz", 2}, {"cs", 1}, {"ar", 1}, {"cp", 1}, {"co", 0}, {"nu", 0}};   // :395-405
@@ -2303,13 +2446,41 @@ struct PatEngine {
     sink.insert(sink.end(), nb2.begin(), nb2.end());
     c.check_cap(sink.size());
   }
-  void archiver(BList ll, const Cont& next, Bytes& sink) {                    // mutate_once_archiver :165-214
+  void archiver(BList ll, const Cont& next, Bytes& sink) {                    // mutate_once_archiver/4 :203-214 and /7 :165-200
     int ip = (int)c.rnd.rand(INITIAL_IP);
     force(ll);
     if (ll.empty()) throw ErlCrash("badarg");
-    Bytes all; for (auto& b : ll) all.insert(all.end(), b.begin(), b.end());  // list_to_binary([Bin|Rest])
-    if (has_zip_eocd(all)) throw Unsupported();
-    BList one{all};
+    Bytes all; for (auto& b : ll) all.insert(all.end(), b.begin(), b.end());  // list_to_binary([Bin|Rest]); NewRest = []
+    // UnZip = zip:foldl(fun(N, I, B, Acc) -> [{N, B(), I()} | Acc] end, [], {Name, ArchiveBin})
+    otpzip::Reader rd; std::vector<otpzip::Entry> es;
+    int rc = otpzip::open(all, &rd);
+    if (rc == otpzip::ZR_UNSUP) throw Unsupported();
+    for (uint32_t i = 0; rc == otpzip::ZR_OK && i < rd.entries; i++) {
+      otpzip::Entry e;
+      rc = otpzip::next(&rd, &e);
+      if (rc == otpzip::ZR_UNSUP) throw Unsupported();
+      if (rc == otpzip::ZR_CRASH) throw ErlCrash("data_error in zip:foldl");
+      if (rc == otpzip::ZR_OK) es.push_back(e);
+    }
+    const std::vector<Muta> mutator = c.fs;                                   // every inner evaluation starts from the Mutator the pattern was given
+    const size_t trace_mark = c.trace ? c.trace->size() : 0;
+    if (rc == otpzip::ZR_OK) {
+      // lists:mapfoldl over FileSpec, which foldl built by prepending: the LAST central-directory entry comes first
+      for (size_t k = es.size(); k-- > 0;) {
+        uint64_t r = c.rnd.rand(1000);
+        if (r > 750) {                                                        // :177-183
+          Bytes nb; BList one{es[k].data};
+          mutate_once_loop(ip, one, next, nb);                                // prepare4sizer(mutate_once_loop(Mutator, [], NextPat, Ip, B, []))
+          es[k].data = nb;
+          c.fs = mutator;
+        }
+      }
+      Bytes newbin;
+      rc = otpzip::create(es, &newbin);                                       // zip:create(Name, lists:reverse(NewFileSpec), [memory])
+      if (rc == otpzip::ZR_OK) { c.check_cap(newbin.size()); sink.insert(sink.end(), newbin.begin(), newbin.end()); return; }   // [NewBin | {fun .., ..}]
+      if (c.trace) c.trace->resize(trace_mark);                               // {error, Err}: the failed clause with the Meta the pattern was given
+    }
+    BList one{all};                                                           // mutate_once_archiver(Binary, {error, _}, Rest = [], ..) :165-174
     split(one);
     mutate_once_loop(ip, one, next, sink);
   }

@@ -102,7 +102,95 @@ def run_cp(n=24, big=1 << 25):
     return total
 
 
+def _mkzip(files, comment=b"", method=zipfile.ZIP_DEFLATED):
+    b = io.BytesIO()
+    with zipfile.ZipFile(b, "w", method) as z:
+        for name, data in files:
+            zi = zipfile.ZipInfo(name, date_time=(1980 + len(name) % 40, 1 + len(data) % 12, 1 + len(name) % 28, len(data) % 24, len(name) % 60, (2 * len(data)) % 60))
+            zi.compress_type = method
+            z.writestr(zi, data)
+        z.comment = comment
+    return b.getvalue()
+
+
+def zip_corpus(n, seed):
+    """zip archives as ordinary tools write them (several files, stored and deflated, small and empty files, extensions zip:create
+    stores, an archive comment) and the ways they go wrong"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    plain = util.corpus_mixed(4 * n, 2500, seed=seed)
+    names = ["a.txt", "dir/b.bin", "x/y/z.dat", "notes", "inner.zip", "old.arj", "pack.Z", "d.tar.gz", ".hidden", "UPPER.TXT", "q.zoo", "w.lzh", "e.arc"]
+    out = []
+    for i in range(n):
+        k = int(rng.integers(1, 6))
+        files = []
+        for j in range(k):
+            p = plain[4 * i + j % 4]
+            cut = int(rng.choice([0, 3, 9, 10, 11, 200, len(p)]))
+            files.append((names[int(rng.integers(0, len(names)))] if j else names[i % len(names)], p[:cut]))
+        kind = i % 10
+        if kind in (0, 1, 2, 3):
+            b = _mkzip(files)
+        elif kind == 4:
+            b = _mkzip(files, method=zipfile.ZIP_STORED)
+        elif kind == 5:
+            b = _mkzip(files, comment=b"an archive comment of some length " * int(rng.integers(1, 4)))
+        elif kind == 6:                                                  # cut somewhere: no end record, or a central directory that points outside
+            full = _mkzip(files); b = full[:int(rng.integers(0, len(full)))]
+        elif kind == 7:                                                  # a flipped bit anywhere (header fields, compressed data, names)
+            full = bytearray(_mkzip(files)); full[int(rng.integers(0, len(full)))] ^= 1 << int(rng.integers(0, 8)); b = bytes(full)
+        elif kind == 8:
+            b = _mkzip([])                                               # no entries: the end record alone
+        else:
+            b = plain[4 * i]                                             # not an archive
+        out.append(b)
+    return out
+
+
+ZIP_CONFIGS = [
+    ("bd,bf,bi,sr,sd,num,ld,lr,ab,uw", "ar"),
+    ("zip", "od,nd"),
+    ("zip=5,bd,bf,sr,lr,num", "ar=3,cp,sz,od,nd,bu"),
+    (None, "ar=4,cp,sz,sk,od,nd,bu,cs,co,nu"),
+]
+
+
+def run_zip(n=20, big=1 << 25):
+    total = skipped = 0
+    for ci, (muts, pats) in enumerate(ZIP_CONFIGS):
+        inputs = zip_corpus(n, seed=500 + ci)
+        data, off = po.pack(inputs)
+        seed = (31 + ci, 5, 2)
+        want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=muts, patterns=pats, max_case_bytes=big, trace=True)
+        eng = ea.Engine(0)
+        eng.configure(mutations=muts, patterns=pats, max_case_bytes=1 << 20, big_case_bytes=big, flags=ea.engine.EH_FLAG_META_TRACE)
+        eng.upload_corpus(data, off)
+        eng.fuzz_batch(seed=seed)
+        got, gst = eng.download()
+        gdr, _ = eng.diag()
+        lines = tr.split("\n")
+        bad = []
+        for i in range(len(inputs)):
+            if gst[i] == 2 or wst[i] == 2:
+                skipped += 1
+                continue
+            ok = got[i] == want[i] and gst[i] == wst[i] and (gst[i] != 0 or gdr[i] == wdr[i])
+            if ok and gst[i] == 0:
+                mine = " ".join("%s:%s" % kv for kv in eng.meta(i))
+                ok = "truncated" in mine or mine == " ".join(lines[i].split())
+            if not ok:
+                bad.append(i)
+        eng.close()
+        total += len(inputs)
+        print("zip config %d: cases %d bad %d, statuses engine %s oracle %s" % (ci, len(inputs), len(bad), np.bincount(gst, minlength=4).tolist(), np.bincount(wst, minlength=4).tolist()), flush=True)
+        for i in bad[:3]:
+            print("  case %d (input kind %d, %d bytes): first diff %d, len %d vs %d, status %d vs %d, draws %d vs %d, %s" % (
+                i, i % 10, len(inputs[i]), util.first_diff(got[i], want[i]), len(got[i]), len(want[i]), gst[i], wst[i], gdr[i], wdr[i], lines[i][:160]))
+        assert not bad, "zip config %d: %d cases differ" % (ci, len(bad))
+    assert skipped <= total // 10, "%d of %d cases ended at an engine limit" % (skipped, total)
+    return total
+
+
 if __name__ == "__main__":
     assert "emu" in os.environ.get("ERLAMSA_HIP_LIB", ""), "point ERLAMSA_HIP_LIB at the emulator build"
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-    print("containers ok: cp %d cases" % run_cp(n))
+    print("containers ok: cp %d cases, zip %d cases" % (run_cp(n), run_zip(n)))

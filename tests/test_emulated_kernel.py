@@ -107,8 +107,9 @@ def test_emulated_device_zlib_against_libz(emu_lib):
 
 def test_emulated_container_patterns(emu_lib):
     """pattern cp on real gzip / zlib inputs (complete, with header fields, truncated, corrupted, nested, behind a length field):
-    decoded, mutated through the rest of the pattern chain and compressed again - bytes, statuses, draw counts and the meta trace
-    are the oracle's, whose zlib calls are libz's"""
+    decoded, mutated through the rest of the pattern chain and compressed again; pattern ar and mutator zip on real zip archives
+    (stored / deflated / small / empty files, stored extensions, archive comment, cut and corrupted archives) - bytes, statuses,
+    draw counts and the meta trace are the oracle's, whose zlib calls are libz's"""
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_containers.py"), "24"], env=env, capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_containers.py"), "16"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "containers ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -580,6 +580,24 @@ def test_container_patterns_vs_oracle():
     assert emu_containers.run_cp(n=60) >= 180
 
 
+def test_zip_archives_vs_oracle():
+    """Pattern ar (erlamsa_patterns.erl:165-214) and mutator zip (erlamsa_mutations.erl:1149-1163) on real zip archives (several
+    files, stored and deflated, small and empty files, the extensions zip:create stores, an archive comment, cut and corrupted
+    archives, the empty archive): zip:foldl's walk and the files' inflate on the device, every file's evaluation from the Mutator
+    the pattern was given, zip:create's layout with raw deflate byte for byte - bytes, statuses, draw counts and the meta trace
+    against the oracle (prim_zip / zip restated there, its zlib calls are libz's)."""
+    if util.priming():
+        pytest.skip("live oracle (small)")
+    import os
+    import sys
+    import warnings
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    import emu_containers
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert emu_containers.run_zip(n=50) >= 200
+
+
 def test_two_rank_nccl_bench_smoke():
     """bench.py over RCCL with 2 ranks on one node (arena broadcast, case-range sharding, MAX-over-ranks timing), weak and
     strong: skipped on boxes with fewer than 2 GPUs (the builder's and the driver's test boxes have one; the 8-GPU runs are
