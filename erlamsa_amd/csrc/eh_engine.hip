@@ -467,6 +467,52 @@ __device__ __noinline__ uint64_t ar_file_done(Ctx&, int em_field, uint8_t* side)
   return mutator_restore(c, &sd->m, false);
 }
 
+// The two container patterns behind one call each, so that the pattern machine (inlined into the kernel) only carries two calls.
+// begin: c.pat_ret 2 = a payload is in bl[cur] and a frame was pushed; 1 = bl[cur..nb) is the pattern's result; 0 = not a
+// container (go on with split/1 and mutate_once_loop); -1 = the case stops.
+__device__ __noinline__ uint64_t pat_container_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, int pat, PatFrame* frames, int nfr, uint32_t ip, int contpat) {
+  EH_CTX;
+  const uint64_t keep = ((uint64_t)e_pri << 32) | e_meta;
+  if (pat == P_CP) {
+    int r = cp_begin(c, e_pri, e_meta, frames, nfr, ip, contpat);
+    c.pat_ret = r < 0 ? -1 : (r == 1 ? 2 : 0);
+    return keep;
+  }
+  // list_to_binary([Bin|Rest]) -> one block
+  c.pat_ret = -1;
+  uint64_t tot = 0; for (int i = c.cur; i < c.nb; i++) tot += blk_load(c.bl, i).len;
+  if (tot > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 308); return keep; }
+  if (c.nb - c.cur > 1) {
+    uint8_t* all = ws_alloc_grow(c, tot);
+    if (!all) return keep;
+    uint64_t o = 0;
+    for (int i = c.cur; i < c.nb; i++) { Blk x = blk_load(c.bl, i); wave_copy(all + o, (const uint8_t*)x.ptr, x.len); o += x.len; }
+    wave_sync();
+    blk_store(c.bl, c.cur, (uint64_t)all, (uint32_t)tot); c.nb = c.cur + 1;
+    wave_sync();
+  }
+  uint8_t* side = ar_begin(c, e_pri, e_meta, ip, contpat);
+  if (c.pat_ret != 1) return keep;
+  return ar_step(c, e_pri, e_meta, side, frames, nfr);
+}
+// end of a payload's evaluation (the frame has been popped): c.pat_ret 2 = the next payload (ar) with a new frame; 1 = bl[cur..nb)
+// is the result; 0 = go on with mutate_once_loop on bl[cur..nb) (split/1 done), c.pat_ip / c.pat_cont; -1 = the case stops.
+__device__ __noinline__ uint64_t pat_container_end(Ctx&, uint32_t e_pri, uint32_t e_meta, int kind, int em_field, uint8_t* side, PatFrame* frames, int nfr) {
+  EH_CTX;
+  uint64_t e;
+  if (kind == P_CP) {
+    e = cp_end(c, e_pri, e_meta, em_field, side);
+    if (c.pat_ret < 0) return e;
+    split_head(c);                                                                    // {This, LlN} = split({NewBin, Rest}) :254 (when changed, the pieces are NewBin again)
+    return e;
+  }
+  e = ar_file_done(c, em_field, side);
+  if (c.pat_ret < 0) return ((uint64_t)e_pri << 32) | e_meta;
+  e = ar_step(c, (uint32_t)(e >> 32), (uint32_t)e, side, frames, nfr);
+  if (c.pat_ret == 0) split_head(c);                                                  // the {error, _} clause :165-174
+  return e;
+}
+
 EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
   int act = A_RUN_PAT, cont = C_EMIT, contpat = 0; uint32_t ip = 0;
   int guard = 0;
@@ -540,33 +586,12 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
                 blk_store(c.bl, c.cur, b.ptr + plen, blen);
                 wave_sync();
               }
-            } else if (pat == P_AR) {                                                 // mutate_once_archiver :165-214
-              // list_to_binary([Bin|Rest]) -> one block; zip:foldl fails unless an EOCD record exists
-              uint64_t tot = 0; for (int i = c.cur; i < c.nb; i++) tot += blk_load(c.bl, i).len;
-              if (tot > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 308); break; }
-              if (c.nb - c.cur > 1) {
-                uint8_t* all = ws_alloc_grow(c, tot);
-                if (!all) break;
-                uint64_t o = 0;
-                for (int i = c.cur; i < c.nb; i++) { Blk x = blk_load(c.bl, i); wave_copy(all + o, (const uint8_t*)x.ptr, x.len); o += x.len; }
-                wave_sync();
-                blk_store(c.bl, c.cur, (uint64_t)all, (uint32_t)tot); c.nb = c.cur + 1;
-                wave_sync();
-                b = blk_load(c.bl, c.cur);
-              }
-              uint8_t* side = ar_begin(c, lt.e_pri, lt.e_meta, ip, contpat);
+            } else if (pat == P_AR || pat == P_CP) {                                  // mutate_once_archiver :165-214, mutate_once_compressed :216-260
+              uint64_t e = pat_container_begin(c, lt.e_pri, lt.e_meta, pat, frames, nfr, ip, contpat);
+              lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
               if (c.pat_ret < 0) break;
-              if (c.pat_ret == 1) {
-                uint64_t e = ar_step(c, lt.e_pri, lt.e_meta, side, frames, nfr);
-                lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
-                if (c.pat_ret < 0) break;
-                if (c.pat_ret == 2) { nfr++; act = A_LOOP; break; }                   // mutate_once_loop(Mutator, [], NextPat, Ip, B, [])
-                if (c.pat_ret == 1) { emit_all(c); act = A_TERMINAL; break; }         // [NewBin | {..}]
-              }
-            } else if (pat == P_CP) {                                                 // mutate_once_compressed :216-260
-              int r = cp_begin(c, lt.e_pri, lt.e_meta, frames, nfr, ip, contpat);
-              if (r < 0) break;
-              if (r == 1) { nfr++; act = A_LOOP; break; }                             // the inner evaluation: Data is not split/1
+              if (c.pat_ret == 2) { nfr++; act = A_LOOP; break; }                     // the rest of the chain on a payload: mutate_once_loop(Mutator, [], NextPat, Ip, Data, [])
+              if (c.pat_ret == 1) { emit_all(c); act = A_TERMINAL; break; }           // [NewBin | {..}]
             }
             split_head(c);
             act = A_LOOP;
@@ -613,24 +638,14 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
         PatFrame f = frames[--nfr];
         f.kind = (int)uni((uint32_t)f.kind); f.em_field = (int)uni((uint32_t)f.em_field); f.field = (uint8_t*)uni64((uint64_t)f.field);
         f.size_bits = uni(f.size_bits); f.big = uni(f.big); f.tail_ptr = uni64(f.tail_ptr); f.tail_len = uni(f.tail_len); f.crc = uni(f.crc);
-        if (f.kind == P_AR) {
-          uint64_t e = ar_file_done(c, f.em_field, f.field);
-          if (c.pat_ret < 0) break;
-          lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
-          e = ar_step(c, lt.e_pri, lt.e_meta, f.field, frames, nfr);
+        if (f.kind == P_AR || f.kind == P_CP) {
+          uint64_t e = pat_container_end(c, lt.e_pri, lt.e_meta, f.kind, f.em_field, f.field, frames, nfr);
           lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
           if (c.pat_ret < 0) break;
           ip = c.pat_ip; cont = C_PAT; contpat = c.pat_cont;
-          if (c.pat_ret == 2) { nfr++; act = A_LOOP; }                                // the next file's evaluation
-          else if (c.pat_ret == 1) emit_all(c);                                       // [NewBin | {..}]: terminal
-          else { split_head(c); act = A_LOOP; }                                       // zip:create failed: the {error, _} clause
-        } else if (f.kind == P_CP) {
-          uint64_t e = cp_end(c, lt.e_pri, lt.e_meta, f.em_field, f.field);
-          lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
-          if (c.pat_ret < 0) break;
-          split_head(c);                                                              // {This, LlN} = split({NewBin, Rest}) :254
-          if (c.pat_ret == 1) emit_all(c);                                            // [NewBin | Rest] ++ [..]: no continuation (the pieces of split/1 are NewBin)
-          else { ip = c.pat_ip; cont = C_PAT; contpat = c.pat_cont; act = A_LOOP; }   // mutate_once_loop(Mutator, [{compressed, failed} | Meta], NextPat, Ip, This, LlN)
+          if (c.pat_ret == 2) { nfr++; act = A_LOOP; }                                // ar: the next file's evaluation
+          else if (c.pat_ret == 1) emit_all(c);                                       // [NewBin | Rest] ++ [..]: no continuation
+          else act = A_LOOP;                                                          // unchanged / zip:create failed: mutate_once_loop(Mutator, .., NextPat, Ip, This, LlN)
         } else if (f.kind == P_SZ) {
           // NewLen = size(NewBlob) = everything written after the length field  (:105-110)
           uint64_t tot = 0; for (int k = f.em_field + 1; k < c.nem; k++) tot += blk_load(c.em, k).len;

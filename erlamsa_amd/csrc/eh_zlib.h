@@ -81,7 +81,7 @@ struct ZDef {
   uint16_t d_buf[Z_LIT_BUFSIZE]; uint8_t l_buf[Z_LIT_BUFSIZE];
   ZTree lt, dt, bt;            // dyn_ltree, dyn_dtree, bl_tree (dt and bt use the first 61 / 39 entries)
   uint16_t st_lcode[288]; uint8_t st_llen[288];                 // static_ltree (static_dtree: 5 bits, bit-reversed code number)
-  int32_t heap[Z_HEAP_SIZE]; uint8_t depth[Z_HEAP_SIZE]; uint16_t bl_count[16];
+  int32_t heap[Z_HEAP_SIZE]; uint8_t depth[Z_HEAP_SIZE]; uint16_t bl_count[16]; uint16_t next_code[16];
   int32_t heap_len, heap_max, l_max_code, d_max_code, bl_max_code;
   uint32_t last_lit; uint64_t opt_len, static_len;
   // bit writer
@@ -157,13 +157,13 @@ EH_DEV void z_gen_bitlen(ZDef& s, ZDesc& d) {
   }
 }
 // trees.c: gen_codes()
-EH_DEV void z_gen_codes(ZTree& t, int max_code, const uint16_t* bl_count) {
-  uint16_t next_code[16]; uint32_t code = 0;
+EH_DEV void z_gen_codes(ZTree& t, int max_code, const uint16_t* bl_count, uint16_t* next_code) {   // (next_code lives in the scratch block: no register arrays)
+  uint32_t code = 0;
   for (int bits = 1; bits <= 15; bits++) { code = (code + bl_count[bits - 1]) << 1; next_code[bits] = (uint16_t)code; }
   for (int n = 0; n <= max_code; n++) { int len = t.dl[n]; if (len == 0) continue; t.fc[n] = (uint16_t)z_bi_reverse(next_code[len]++, len); }
 }
 // trees.c: build_tree()
-EH_DEV void z_build_tree(ZDef& s, ZDesc& d) {
+__device__ __noinline__ void z_build_tree(ZDef& s, ZDesc& d) {
   ZTree& t = *d.tree; const int elems = d.elems;
   int n, m, max_code = -1, node;
   s.heap_len = 0; s.heap_max = Z_HEAP_SIZE;
@@ -191,10 +191,10 @@ EH_DEV void z_build_tree(ZDef& s, ZDesc& d) {
   } while (s.heap_len >= 2);
   s.heap[--s.heap_max] = s.heap[1];
   z_gen_bitlen(s, d);
-  z_gen_codes(t, max_code, s.bl_count);
+  z_gen_codes(t, max_code, s.bl_count, s.next_code);
 }
 // trees.c: scan_tree() (send == false) and send_tree() (send == true)
-EH_DEV void z_scan_send_tree(ZDef& s, ZTree& t, int max_code, bool send) {
+__device__ __noinline__ void z_scan_send_tree(ZDef& s, ZTree& t, int max_code, bool send) {
   int prevlen = -1, curlen, nextlen = t.dl[0], count = 0, max_count = 7, min_count = 4;
   if (nextlen == 0) { max_count = 138; min_count = 3; }
   if (!send) t.dl[max_code + 1] = 0xffff;                                              // guard
@@ -232,7 +232,7 @@ EH_DEV bool z_tally(ZDef& s, uint32_t dist, uint32_t lc) {
   return s.last_lit == Z_LIT_BUFSIZE - 1;
 }
 // trees.c: compress_block() with the static (stat == true) or the dynamic trees
-EH_DEV void z_compress_block(ZDef& s, bool stat) {
+__device__ __noinline__ void z_compress_block(ZDef& s, bool stat) {
   for (uint32_t lx = 0; lx < s.last_lit; lx++) {
     uint32_t dist = s.d_buf[lx], lc = s.l_buf[lx];
     if (dist == 0) { if (stat) z_send_bits(s, s.st_lcode[lc], s.st_llen[lc]); else z_send_bits(s, s.lt.fc[lc], s.lt.dl[lc]); continue; }
@@ -250,7 +250,7 @@ EH_DEV void z_compress_block(ZDef& s, bool stat) {
 }
 // trees.c: _tr_flush_block() (zlib 1.2.11; level 6, Z_DEFAULT_STRATEGY).  buf = nullptr when the block's start has slid out of
 // zlib's window (block_start < 0): no stored block then.
-EH_DEV void z_flush_block(ZDef& s, const uint8_t* buf, uint64_t stored_len, int last) {
+__device__ __noinline__ void z_flush_block(ZDef& s, const uint8_t* buf, uint64_t stored_len, int last) {
   ZDesc ld{&s.lt, Z_L_CODES, 257, 15, 0, 0}, dd{&s.dt, Z_D_CODES, 0, 15, 1, 0}, bd{&s.bt, Z_BL_CODES, 0, 7, 2, 0};
   z_build_tree(s, ld); z_build_tree(s, dd);
   z_scan_send_tree(s, s.lt, ld.max_code, false); z_scan_send_tree(s, s.dt, dd.max_code, false);     // build_bl_tree()
@@ -290,13 +290,14 @@ EH_DEV void z_flush_block(ZDef& s, const uint8_t* buf, uint64_t stored_len, int 
 __device__ __noinline__ void z_deflate_raw(ZDef& s, const uint8_t* src, uint64_t n) {
   for (int i = 0; i < Z_WSIZE; i++) s.head[i] = 0;
   {                                                                                      // tr_static_init(): static_ltree
-    uint16_t blc[16]; for (int i = 0; i < 16; i++) blc[i] = 0;
+    uint16_t* blc = s.bl_count; uint16_t* next_code = s.next_code;
+    for (int i = 0; i < 16; i++) blc[i] = 0;
     int k = 0;
     while (k <= 143) { s.st_llen[k++] = 8; blc[8]++; }
     while (k <= 255) { s.st_llen[k++] = 9; blc[9]++; }
     while (k <= 279) { s.st_llen[k++] = 7; blc[7]++; }
     while (k <= 287) { s.st_llen[k++] = 8; blc[8]++; }
-    uint16_t next_code[16]; uint32_t code = 0;
+    uint32_t code = 0;
     for (int bits = 1; bits <= 15; bits++) { code = (code + blc[bits - 1]) << 1; next_code[bits] = (uint16_t)code; }
     for (int m = 0; m <= 287; m++) { int len = s.st_llen[m]; s.st_lcode[m] = (uint16_t)z_bi_reverse(next_code[len]++, len); }
   }
