@@ -207,6 +207,7 @@ __device__ __noinline__ int muta_zip(Ctx&) {
   EH_CTX;
   const Blk hb = blk_load(c.bl, c.cur);
   c.r_kind = R_SAME;
+  if (!has_zip_eocd((const uint8_t*)hb.ptr, hb.len)) return -1;                                   // no end record anywhere: {error, bad_eocd} (the common case, nothing allocated)
   ZipRd* rd = (ZipRd*)ws_alloc(c, sizeof(ZipRd));
   if (!rd) return 0;
   int rc = zip_open(rd, (const uint8_t*)hb.ptr, hb.len);

@@ -56,8 +56,10 @@ enum eh_case_status {
   EH_CASE_CRASHED = 1,     /* the reference worker would have died (badmatch/badarith...):
                               output is <<>> (erlamsa_main.erl:211-220) */
   EH_CASE_OVERFLOW = 2,    /* exceeded max_case_bytes / block-table / arena capacity: output empty */
-  EH_CASE_UNSUPPORTED = 3, /* reached a container success path (zip/zlib re-encode) that is not
-                              implemented; output empty, caller should route the case to BEAM */
+  EH_CASE_UNSUPPORTED = 3, /* a zip archive (pattern ar, mutator zip) with a feature whose outcome in OTP's prim_zip / zip this
+                              build does not pin: ZIP64 markers, encrypted or data-descriptor entries, directory entries, an
+                              empty or non-ASCII name, a local header outside the file (csrc/eh_zip.h).  Output empty; route the
+                              case to BEAM.  gzip / zlib inputs (pattern cp) and ordinary zip archives run on the GPU */
   EH_CASE_ARENA_FULL = 4,  /* the output arena (eh_options.out_capacity) was exhausted; re-run the
                               case with a larger arena */
   EH_CASE_BUDGET = 5       /* exceeded max_case_work: the engine's deterministic stand-in for the

@@ -136,8 +136,12 @@ def zip_corpus(n, seed):
             b = _mkzip(files, comment=b"an archive comment of some length " * int(rng.integers(1, 4)))
         elif kind == 6:                                                  # cut somewhere: no end record, or a central directory that points outside
             full = _mkzip(files); b = full[:int(rng.integers(0, len(full)))]
-        elif kind == 7:                                                  # a flipped bit anywhere (header fields, compressed data, names)
-            full = bytearray(_mkzip(files)); full[int(rng.integers(0, len(full)))] ^= 1 << int(rng.integers(0, 8)); b = bytes(full)
+        elif kind == 7:                                                  # a flipped bit anywhere (header fields, names), or inside the first file's compressed data
+            full = bytearray(_mkzip(files))
+            lo, hi = 0, len(full)
+            if rng.random() < 0.6:
+                lo = 30 + len(files[0][0]); hi = max(lo + 1, min(len(full), lo + int.from_bytes(full[18:22], "little")))
+            full[int(rng.integers(lo, hi))] ^= 1 << int(rng.integers(0, 8)); b = bytes(full)
         elif kind == 8:
             b = _mkzip([])                                               # no entries: the end record alone
         else:

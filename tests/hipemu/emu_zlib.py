@@ -45,9 +45,9 @@ def want_inflate(data):
         return None
 
 
-def samples(rng, quick):
+def samples(rng, quick, small=False):
     out = [b"", b"a", b"ab", b"abc", b"aaaa", b"abcabcabcabc", bytes(1000), bytes(range(256)) * 3]
-    sizes = [5, 17, 100, 257, 1000, 4096, 20000] + ([] if quick else [70000, 140000, 300000])
+    sizes = [5, 17, 100, 257, 1000, 4096] + ([] if small else [20000]) + ([] if quick else [70000, 140000, 300000])
     for n in sizes:
         out.append(rng.integers(0, 256, size=n, dtype=np.uint8).tobytes())                       # incompressible: stored blocks
         out.append(rng.integers(0, 4, size=n, dtype=np.uint8).tobytes())                         # short alphabet
@@ -70,11 +70,12 @@ def samples(rng, quick):
     return out
 
 
-def run(quick=False):
+def run(quick=False, small=False):
+    """small: the GPU test's set (one lane walks level 6's hash chains: seconds per 20 KB of short-alphabet data)"""
     rng = np.random.Generator(np.random.PCG64(77))
     eng = ea.Engine(0)
     n_c = n_d = 0
-    for data in samples(rng, quick):
+    for data in samples(rng, quick, small):
         for op in (0, 1, 2):
             got = eng.selftest_zlib(op, data)
             want = want_compress(op, data)
@@ -90,7 +91,7 @@ def run(quick=False):
             c = zlib.compressobj(lvl, zlib.DEFLATED, 15, 8, strat); variants.append((5, c.compress(data) + c.flush()))
         named = b"\x1f\x8b\x08\x08" + bytes(6) + b"name.txt\x00" + want_compress(0, data) + zlib.crc32(data).to_bytes(4, "little") + (len(data) & 0xffffffff).to_bytes(4, "little")
         variants.append((4, named))
-        for k in range(10 if quick else 24):                                             # truncations and corruptions of both formats
+        for k in range(6 if small else 10 if quick else 24):                                             # truncations and corruptions of both formats
             for op, full in ((4, gz), (5, zl)):
                 cut = int(rng.integers(0, len(full) + 1))
                 variants.append((op, full[:cut]))
