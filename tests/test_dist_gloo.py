@@ -16,7 +16,8 @@ MUTS, PATS, SEED = "bd,bf,bi,sr,num,ld,ab", "od,nd,bu", (1, 2, 3)
 N, SIZE, STEPS = 24, 160, 2
 
 
-def _worker(rank, world, port, emu_lib, q, strong=False):
+def _worker(rank, world, port, emu_lib, q, strong=False, cfg=None):
+    muts, pats, gens = cfg or (MUTS, PATS, None)
     os.environ["ERLAMSA_HIP_LIB"] = emu_lib
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
@@ -35,7 +36,7 @@ def _worker(rank, world, port, emu_lib, q, strong=False):
     engines = []
     for _ in range(2):                                    # two contexts in flight, like bench.py --inflight 2
         e = ea.Engine(0)
-        e.configure(mutations=MUTS, patterns=PATS, max_case_bytes=1 << 20)
+        e.configure(mutations=muts, patterns=pats, generators=gens, max_case_bytes=1 << 20)
         e.attach_corpus(arena.data_ptr(), offs.data_ptr(), N, N * SIZE)
         engines.append(e)
     got = {}
@@ -122,3 +123,35 @@ def test_strong_scaling_split_gathers_to_one_run_in_case_order():
         outs = [o for r in range(world) for o in by_rank[r][step][0]]
         sts = [x for r in range(world) for x in by_rank[r][step][1]]
         assert len(outs) == N and sts == wst.tolist() and outs == want, "step %d" % step
+
+
+def test_c5_shape_jump_generator_over_the_whole_arena_on_every_rank():
+    """BASELINE configs[4] in small: generator `jump` (cross-seed splices, erlamsa_gen.erl:124-150), the fuse family + num + len,
+    pattern sz, one run split over 3 ranks (strong scaling).  A rank runs only its case range but draws its Paths from the WHOLE
+    broadcast arena (the full arena on every GPU); the ranks' outputs in rank order are the single-process oracle run."""
+    import torch.multiprocessing as mp
+    import build_emu
+    emu_lib = build_emu.build()
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    world = 3
+    cfg = ("ft,fn,fo,num,len", "sz", "jump")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, emu_lib, q, True, cfg)) for r in range(world)]
+    for p in procs:
+        p.start()
+    arena, gathered, (dt_all, out_all, cases_all) = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    offs = (np.arange(N + 1, dtype=np.uint64) * SIZE)
+    by_rank = {r: got for r, got, _, _ in gathered}
+    for step in range(STEPS):
+        want, wst, _, _ = po.fuzz_batch(arena, offs, seed=SEED, mutations=cfg[0], patterns=cfg[1], generators=cfg[2], first_case=step * N + 1)
+        outs = [o for r in range(world) for o in by_rank[r][step][0]]
+        sts = [x for r in range(world) for x in by_rank[r][step][1]]
+        assert len(outs) == N and sts == wst.tolist() and outs == want, "step %d" % step
+        assert any(o not in arena.tobytes() for o in outs if o)           # splices of two entries, not copies of one
