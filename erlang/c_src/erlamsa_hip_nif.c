@@ -23,8 +23,8 @@
 
 #define OPT_STR 1024
 typedef struct {
-  char muts[OPT_STR], pats[256], host[64];
-  int has_muts, has_pats, has_host, port;
+  char muts[OPT_STR], pats[256], gens[128], host[64];
+  int has_muts, has_pats, has_gens, has_host, port;
   double blockscale;
   uint64_t max_case_bytes, big_case_bytes, max_case_work;
 } opt_key;
@@ -87,6 +87,8 @@ static int read_opts(ErlNifEnv* env, ERL_NIF_TERM map, opt_key* k) {
   k->has_muts = rc;
   if ((rc = get_str(env, map, "patterns", k->pats, sizeof(k->pats))) < 0) return 0;
   k->has_pats = rc;
+  if ((rc = get_str(env, map, "generators", k->gens, sizeof(k->gens))) < 0) return 0;   /* "direct=500,random=1", also file / jump: Paths = Bins */
+  k->has_gens = rc;
   if ((rc = get_str(env, map, "ssrf_host", k->host, sizeof(k->host))) < 0) return 0;
   k->has_host = rc;
   if (enif_get_map_value(env, map, enif_make_atom(env, "ssrf_port"), &v) && !enif_get_int(env, v, &k->port)) return 0;
@@ -102,6 +104,7 @@ static int configure_if_changed(ctx_res* r, const opt_key* k) {
   eh_options o; memset(&o, 0, sizeof(o)); o.abi_version = EH_ABI_VERSION;
   o.mutations = k->has_muts ? k->muts : NULL;        /* NULL = the reference's default table */
   o.patterns = k->has_pats ? k->pats : NULL;
+  o.generators = k->has_gens ? k->gens : NULL;       /* NULL = what paths => [direct] leaves: direct=500, random=1 */
   o.ssrf_host = k->has_host ? k->host : NULL;
   o.ssrf_port = k->port; o.blockscale = k->blockscale;
   o.max_case_bytes = k->max_case_bytes; o.big_case_bytes = k->big_case_bytes; o.max_case_work = k->max_case_work;

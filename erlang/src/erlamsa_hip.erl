@@ -31,7 +31,7 @@ flush_nif(_Ctx) -> erlang:nif_error(nif_not_loaded).
 poll_nif(_Ctx, _Ticket) -> erlang:nif_error(nif_not_loaded).
 write_files_nif(_Ctx, _Template, _FirstN) -> erlang:nif_error(nif_not_loaded).
 
-%% Dict: the options map of erlamsa_main:fuzzer/1 (seed, mutations, patterns, blockscale) plus first_case / device
+%% Dict: the options map of erlamsa_main:fuzzer/1 (seed, mutations, patterns, generators, blockscale) plus first_case / device
 fuzz_batch(Bins, Dict) ->
     Seed = maps:get(seed, Dict, erlamsa_rnd:gen_urandom_seed()),
     split(fuzz_batch_nif(ctx(Dict), opts(Dict), Seed, maps:get(first_case, Dict, 1), Bins)).
@@ -76,7 +76,13 @@ opts(Dict) ->
     Base = #{mutations => actions(Mutas), patterns => actions(Pats),
              blockscale => float(maps:get(blockscale, Dict, 1.0)),
              ssrf_host => SsrfHost, ssrf_port => SsrfPort},
-    maps:merge(Base, maps:with([max_case_bytes, big_case_bytes, max_case_work], Dict)).
+    %% generators => [{Name, Pri}] as erlamsa_main:fuzzer/1 takes them (erlamsa_gen:default/0); `file` and `jump` stream the
+    %% Bins of the batch as their Paths on the device (erlamsa_gen.erl:106-150), stdin / genfuz stay on BEAM
+    Gens = case maps:find(generators, Dict) of
+               {ok, G} -> #{generators => actions([{N, P} || {N, P} <- G, lists:member(N, [direct, random, file, jump])])};
+               error -> #{}
+           end,
+    maps:merge(maps:merge(Base, Gens), maps:with([max_case_bytes, big_case_bytes, max_case_work], Dict)).
 
 split({error, Why}) -> {error, Why};                             %% caller falls back to erlamsa_main:fuzzer/1
 split({ok, Res}) ->
