@@ -45,6 +45,7 @@ def cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref=None):
     limit = min(args.cpu_sample, n)
     threads = max(1, args.cpu_threads or min(os.cpu_count() or 1, 64))
     CH = 8
+    whole = synth.as_arena(mat) if args.generators else None      # the Paths of file / jump: the whole corpus, whatever chunk a call runs
     lock = threading.Lock()
     state = {"next": 0, "cases": 0, "bytes": 0, "timeouts": 0, "checked": 0, "skipped": 0, "bad": []}
     t0 = time.perf_counter()
@@ -58,7 +59,7 @@ def cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref=None):
                 state["next"] = a + CH
             b = min(a + CH, limit)
             d, o = synth.as_arena(mat[a:b])
-            outs, st, dr, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, first_case=a + 1,
+            outs, st, dr, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, generators=args.generators, paths=whole, first_case=a + 1,
                                            max_case_bytes=args.big_mib << 20, max_case_work=args.work_mib << 20,
                                            max_case_seconds=args.cpu_case_seconds)
             with lock:
@@ -114,8 +115,14 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--mutations", default=None, help="-m syntax; default: the reference's full default table (erlamsa_mutations.erl:1291-1331)")
     ap.add_argument("--patterns", default="od,nd,bu")
-    ap.add_argument("--corpus", default="mixed", choices=["mixed", "uniform"],
-                    help="mixed = BASELINE configs[2] (default); uniform = random bytes (configs[1] with --cases 1024 --size 256)")
+    ap.add_argument("--corpus", default="mixed", choices=["mixed", "uniform", "counter"],
+                    help="mixed = BASELINE configs[2] (default); uniform = random bytes (configs[1] with --cases 1024 --size 256); counter = the "
+                    "counter-hash corpus of synth.counter, written into the HBM arena by every rank for itself (no host staging, no broadcast)")
+    ap.add_argument("--generators", default=None, help="-g syntax (direct, random, file, jump); default: what paths=[direct] leaves (direct=500,random=1). "
+                    "file / jump stream the corpus entries as their Paths on the device (erlamsa_gen.erl:106-150)")
+    ap.add_argument("--config", type=int, default=3, choices=[3, 5], help="3 = BASELINE configs[2] (the default, what the driver times); 5 = the shape of "
+                    "configs[4]: 131072 x world seeds of 64 KiB from the counter-hash corpus, generator jump (cross-seed splices), mutators "
+                    "ft,fn,fo,num,len, pattern sz, strong scaling (every rank holds the whole arena and runs its share of the cases); other flags override")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="cases timed on the CPU oracle: the first N of the run (0 = skip)")
     ap.add_argument("--cpu-case-seconds", type=float, default=10.0, help="per-case wall-clock watchdog of the CPU oracle leg "
                     "(the reference's maxrunningtime; its CLI default is 30 s)")
@@ -147,6 +154,11 @@ def main():
     ap.add_argument("--setup-seconds", type=int, default=150, help="single-GPU runs execute in a child process; a child whose set-up passes (the first "
                     "dispatch on every HIP stream) have not finished after this many seconds is killed and the run repeated with "
                     "--inflight 3, then 1 (0 = no supervision)")
+    pre, _ = ap.parse_known_args()
+    if pre.config == 5:
+        w5 = int(os.environ.get("WORLD_SIZE", "1"))
+        ap.set_defaults(cases=131072 * w5, size=65536, corpus="counter", generators="jump", mutations="ft,fn,fo,num,len", patterns="sz", scaling="strong",
+                        out_gib=8, cpu_sample=0, budget_mib=0)
     args = ap.parse_args()
 
     # ---- supervision (single GPU only): the run proper happens in a child process.  Twice in this round's development a run
@@ -222,11 +234,16 @@ def main():
     arena = torch.empty(n * size, dtype=torch.uint8, device=dev)
     offs = torch.arange(n + 1, dtype=torch.int64, device=dev) * size
     mat = None
-    if rank == 0:
-        mat = synth.mixed(n, size) if args.corpus == "mixed" else synth.uniform(n, size)
-        arena.copy_(torch.from_numpy(mat.reshape(-1)))
-    if dist is not None:
-        shard.broadcast_corpus(arena, offs, src=0)
+    if args.corpus == "counter":                               # every rank writes the same arena itself (closed form of seed, row, byte)
+        synth.counter_torch(arena, 0, n, size)
+        if rank == 0 and n * size <= (1 << 30):
+            mat = synth.counter(range(n), size)                # host copy for the CPU oracle leg (small runs only)
+    else:
+        if rank == 0:
+            mat = synth.mixed(n, size) if args.corpus == "mixed" else synth.uniform(n, size)
+            arena.copy_(torch.from_numpy(mat.reshape(-1)))
+        if dist is not None:
+            shard.broadcast_corpus(arena, offs, src=0)
     torch.cuda.synchronize()
 
     # `--inflight` engine contexts, each on its own HIP stream: step k runs on context k % inflight, so
@@ -236,7 +253,7 @@ def main():
     engines, streams = [], []
     for _ in range(nctx):
         e = ea.Engine(local)
-        e.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
+        e.configure(mutations=muts, patterns=pats, generators=args.generators, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
                     max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20, big_case_bytes=args.big_mib << 20,
                     pool_bytes=args.pool_gib << 30)
         e.attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
@@ -318,12 +335,14 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8 (byte edits) + f64 (AS183 draws)", "data": "synthetic",
             "config": {
-                "workload": "%s: %d seeds x %d B %s, generator direct=500/random=1, patterns %s, "
+                "workload": "%s: %d seeds x %d B %s, generator %s, patterns %s, "
                             "mutators %s (%d of the %d of the default table; not measured: %s)"
-                            % ("BASELINE configs[2]" if (args.corpus, n, size) == ("mixed", 65536, 4096) else "custom",
+                            % ("BASELINE configs[2]" if (args.corpus, n, size, args.generators) == ("mixed", 65536, 4096, None) else
+                               "the shape of BASELINE configs[4]" if args.config == 5 else "custom",
                                n, size, "mixed-binary corpus (50% random, 25% ASCII lines+numbers, 15% bracketed text, "
-                               "10% length/CRC-framed)" if args.corpus == "mixed" else "uniform random bytes",
-                               pats, muts, len(muts.split(",")), nmut_total,
+                               "10% length/CRC-framed)" if args.corpus == "mixed" else "uniform random bytes" if args.corpus == "uniform" else
+                               "counter-hash corpus (uniform / text with numbers / length-framed / low-entropy rows, written on the device)",
+                               args.generators or "direct=500/random=1", pats, muts, len(muts.split(",")), nmut_total,
                                ",".join(m for m, _, _ in ea.mutator_table() if m not in [x.split("=")[0] for x in muts.split(",")]) or "none"),
                 "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream, one after the other, before the W warm-up steps",
                 "max_case_bytes": args.case_mib << 20, "big_case_bytes": args.big_mib << 20, "max_case_work": args.work_mib << 20,
@@ -380,7 +399,7 @@ def main():
         def leg_budget():
             # second, labelled figure: the same steps under a per-case work budget (the round-1 configuration)
             for e in engines:
-                e.configure(mutations=muts, patterns=pats, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
+                e.configure(mutations=muts, patterns=pats, generators=args.generators, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
                             max_case_bytes=args.case_mib << 20, max_case_work=args.budget_mib << 20, big_case_bytes=args.big_mib << 20,
                             pool_bytes=args.pool_gib << 30)
             bsteps = min(2 * nctx, args.steps)
@@ -417,7 +436,7 @@ def main():
         if world == 1:
             threading.Thread(target=watchdog, daemon=True).start()
             # the CPU oracle leg first: it is also the parity check of this very run
-            if args.cpu_sample > 0:
+            if args.cpu_sample > 0 and mat is not None:
                 state["leg"] = "cpu_baseline"
                 log("parity sample: cases 1..%d once more on context 0, alone on the device" % min(args.cpu_sample, n))
                 import hashlib

@@ -133,6 +133,77 @@ def sgml_docs(n, seed=DEFAULT_SEED):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Counter-hash corpus (BASELINE configs[4]: 1 M x 64 KiB is 64 GiB - generated where it is used, never staged through the
+# host).  Byte i of row r is a closed form of (seed, r, i): word j = i >> 3 of the row is splitmix64's finaliser of
+# seed + r * G1 + (j + 1) * G2, the row's kind (0 uniform bytes, 1 text of letters / digit runs / newlines for sed_num,
+# 2 a big-endian 32-bit length field in front of uniform bytes for the size-field detector, 3 an 8-letter alphabet with long
+# repeats for fuse) comes from the same hash.  counter() is the numpy form (tests, oracle side), counter_torch() the same
+# arithmetic on a torch device (bench.py fills the HBM arena with it, every rank for itself: no broadcast).
+# ---------------------------------------------------------------------------------------------------------------------
+_G1, _G2, _M1, _M2 = 0x9E3779B97F4A7C15, 0xD1B54A32D192ED03, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB
+
+
+def _mix_np(x):
+    x = x.astype(np.uint64)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(_M1)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(_M2)
+    return x ^ (x >> np.uint64(31))
+
+
+def counter(rows, size, seed=DEFAULT_SEED):
+    """rows: iterable of row numbers -> uint8[len(rows), size] of the counter-hash corpus"""
+    assert size % 8 == 0 and size >= 8
+    r = np.asarray(list(rows), dtype=np.uint64)[:, None]
+    j = np.arange(size // 8, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        w = _mix_np(np.uint64(seed) + r * np.uint64(_G1) + (j + np.uint64(1)) * np.uint64(_G2))
+        kind = (_mix_np(np.uint64(seed ^ 0x5851F42D4C957F2D) + r[:, 0] * np.uint64(_G1)) & np.uint64(3)).astype(np.int64)
+    b = w.view(np.uint8).reshape(len(r), size) if w.dtype.byteorder in ("=", "<", "|") else None
+    out = b.copy()
+    c = b & 63
+    text = np.where(c < 10, 48 + c, np.where(c < 36, 97 + c - 10, np.where(c < 62, 65 + c - 36, np.where(c == 62, 32, 10)))).astype(np.uint8)
+    out[kind == 1] = text[kind == 1]
+    out[kind == 3] = (97 + (b[kind == 3] & 7)).astype(np.uint8)
+    fr = kind == 2
+    out[fr, 0:4] = np.frombuffer(int(size - 4).to_bytes(4, "big"), dtype=np.uint8)
+    return out
+
+
+def counter_torch(arena, first_row, nrows, size, seed=DEFAULT_SEED, chunk_rows=512):
+    """fills arena[first_row * size .. (first_row + nrows) * size) (a flat uint8 torch tensor on any device) with rows
+    first_row .. of the counter-hash corpus; int64 arithmetic wraps like uint64, the logical shifts are masked"""
+    import torch
+    dev = arena.device
+
+    def s64(v):
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def mix(x):
+        x = (x ^ lsr(x, 30)) * s64(_M1)
+        x = (x ^ lsr(x, 27)) * s64(_M2)
+        return x ^ lsr(x, 31)
+    j = torch.arange(1, size // 8 + 1, dtype=torch.int64, device=dev)[None, :] * s64(_G2)
+    sh = (torch.arange(8, dtype=torch.int64, device=dev) * 8)[None, None, :]
+    hdr = torch.tensor(list(int(size - 4).to_bytes(4, "big")), dtype=torch.uint8, device=dev)
+    for r0 in range(first_row, first_row + nrows, chunk_rows):
+        m = min(chunk_rows, first_row + nrows - r0)
+        r = torch.arange(r0, r0 + m, dtype=torch.int64, device=dev)
+        w = mix(s64(seed) + r[:, None] * s64(_G1) + j)
+        kind = mix(s64(seed ^ 0x5851F42D4C957F2D) + r * s64(_G1)) & 3
+        b = ((w[:, :, None] >> sh) & 255).reshape(m, size)
+        c = b & 63
+        text = torch.where(c < 10, 48 + c, torch.where(c < 36, 87 + c, torch.where(c < 62, 29 + c, torch.where(c == 62, torch.full_like(c, 32), torch.full_like(c, 10)))))
+        out = torch.where((kind == 1)[:, None], text, torch.where((kind == 3)[:, None], 97 + (b & 7), b)).to(torch.uint8)
+        out[kind == 2, 0:4] = hdr
+        arena[r0 * size:(r0 + m) * size] = out.reshape(-1)
+    return arena
+
+
 def as_arena(mat):
     """uint8[n, size] -> (flat data, uint64 off[n+1])"""
     n, size = mat.shape

@@ -22,6 +22,8 @@ CONFIGS = [
     ("file,jump", None, "od,nd,bu,sk,sz,cs,ar,cp,co,nu", "mixed", 3000),
     ("file=3,jump=2,direct=2,random=1", "bd,sr,lr,tr2,num,fo", "od,nd,bu,sk,sz,cs,co,nu", "ragged", 20000),
     ("jump", "bd,br,sp", "nu,co,od", "ragged", 700),
+    # the shape of BASELINE configs[4]: counter-hash corpus, cross-seed splices, fuse family + sed_num + length fields, pattern sz
+    ("jump", "ft,fn,fo,num,len", "sz", "counter", 16384),
 ]
 
 
@@ -31,6 +33,9 @@ def run(n=16):
     for ci, (gens, muts, pats, kind, size) in enumerate(CONFIGS):
         rng = np.random.Generator(np.random.PCG64(100 + ci))
         inputs = util.corpus_mixed(n, size, seed=20 + ci)
+        if kind == "counter":
+            from erlamsa_amd import synth
+            inputs = [bytes(r) for r in synth.counter(range(n), size)]
         if kind == "ragged":
             inputs = [b[:int(rng.integers(0, size + 1))] for b in inputs]
             inputs[0] = b""                                   # an empty file: finish(0) alone

@@ -205,3 +205,18 @@ def test_sgml_mutator_properties():
     assert len(outs) > 100
     assert any(o.count(b"<r ") > 1 for o in outs)            # pump / dup / repeat
     assert any(b"xmlns:xsi" in o or b"u http://" in o or b"'http://localhost:51234/'" in o for o in outs)   # xmlns features
+
+
+def test_counter_corpus_numpy_and_torch_forms_agree():
+    """synth.counter (numpy: tests, oracle side) and synth.counter_torch (what bench.py --corpus counter writes into the HBM arena)
+    are the same closed form of (seed, row, byte); rows are independent of how they are batched; all four row kinds occur."""
+    import torch
+    from erlamsa_amd import synth
+    a = synth.counter(range(40, 340), 1024, seed=11)
+    t = torch.zeros(400 * 1024, dtype=torch.uint8)
+    synth.counter_torch(t, 40, 300, 1024, seed=11, chunk_rows=37)
+    assert (t.numpy().reshape(400, 1024)[40:340] == a).all() and not t.numpy()[:40 * 1024].any()
+    assert (synth.counter([77], 1024, seed=11)[0] == a[37]).all()
+    framed = (a[:, :4] == np.frombuffer((1020).to_bytes(4, "big"), dtype=np.uint8)).all(axis=1)
+    texty = ((a >= 32) & (a < 127) | (a == 10)).all(axis=1)
+    assert framed.sum() > 30 and texty.sum() > 60 and (~framed & ~texty).sum() > 30
