@@ -24,6 +24,8 @@ def main():
         doc = json.load(f)
     changed = 0
     for v in doc["vectors"]:
+        if "generators" in v:                            # file / jump sets are not part of the capture (see make_golden.py)
+            continue
         for i in range(len(v["inputs_hex"])):
             if v["status"][i] in (2, 3):
                 continue

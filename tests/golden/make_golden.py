@@ -33,13 +33,32 @@ SETS = [
     ("default_json", (16, 17, 18), None, None, 32, 0, "json"),
     ("default_sgml", (19, 20, 21), None, None, 32, 0, "sgml"),
     ("sgm_js_only", (22, 23, 24), "sgm,js", "od,nd,bu", 48, 0, "docs"),
+    # containers (round 3): real gzip / zlib inputs through pattern cp, real zip archives through pattern ar and mutator zip.
+    # A BEAM capture of these two sets also pins the restated corners of OTP's zlib / prim_zip / zip ("Oracle").
+    ("containers_cp", (25, 26, 27), "bd,bf,bi,sr,num,lr,uw", "cp,od", 24, 0, "gz"),
+    ("containers_zip", (28, 29, 30), "zip=3,bd,bf,sr,num", "ar=3,od", 20, 0, "zip"),
+    # the file / jump generators (erlamsa_gen.erl:59-150): the inputs are the Paths.  Not in vectors.eterm: with paths other than
+    # [direct] erlamsa_main:fuzzer/1 records nothing (erlamsa_main.erl:139-146), a capture would have to go through -o files
+    ("gen_file", (31, 32, 33), "bd,bf,sr,num,lr,ft", "od,nd,bu,sz", 16, 6000, "mixed", "file"),
+    ("gen_jump", (34, 35, 36), "bd,bf,sr,num,lr,fo", "od,nd,bu,sz", 16, 6000, "mixed", "jump"),
 ]
 
 
 def main():
     vecs = []
-    for name, seed, muts, pats, n, size, kind in SETS:
-        if kind == "uniform":
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    import warnings
+    import emu_containers as ec                      # the container corpora of the emulator / GPU tests
+    for entry in SETS:
+        name, seed, muts, pats, n, size, kind = entry[:7]
+        gens = entry[7] if len(entry) > 7 else None
+        if kind == "gz":
+            inputs = ec.compressed_corpus(n, seed[0])
+        elif kind == "zip":
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                inputs = ec.zip_corpus(n, seed[0])
+        elif kind == "uniform":
             inputs = [bytes(r) for r in synth.uniform(n, size, seed=seed[0])]
         elif kind == "mixed":
             inputs = [bytes(r) for r in synth.mixed(n, size, seed=seed[0])]
@@ -52,9 +71,11 @@ def main():
         else:
             inputs = [b"Hello erlamsa!\n"]          # BASELINE configs[0] input; default mutators and patterns
         data, off = po.pack(inputs)
-        outs, st, _, _ = po.fuzz_batch(data, off, seed=seed, mutations=muts, patterns=pats, max_case_bytes=256 << 10)
+        outs, st, _, _ = po.fuzz_batch(data, off, seed=seed, mutations=muts, patterns=pats, generators=gens, max_case_bytes=256 << 10)
         vecs.append({"name": name, "seed": list(seed), "first_case": 1, "mutations": muts, "patterns": pats,
                      "inputs_hex": [b.hex() for b in inputs], "outputs_hex": [o.hex() for o in outs], "status": [int(x) for x in st]})
+        if gens:
+            vecs[-1]["generators"] = gens
     with open(os.path.join(HERE, "vectors.json"), "w") as f:
         json.dump({"generator": "oracle (C++ restatement) — NOT a BEAM run", "vectors": vecs}, f, indent=0)
     # the same inputs as Erlang terms for tests/golden/capture.escript (file:consult/1)
@@ -63,7 +84,7 @@ def main():
         return '{"%s", {%d,%d,%d}, %d, %s, %s, [%s]}' % (v["name"], *v["seed"], v["first_case"], q(v["mutations"]), q(v["patterns"]),
                                                          ", ".join('"%s"' % h for h in v["inputs_hex"]))
     with open(os.path.join(HERE, "vectors.eterm"), "w") as f:
-        f.write("[\n" + ",\n".join(term(v) for v in vecs) + "\n].\n")
+        f.write("[\n" + ",\n".join(term(v) for v in vecs if "generators" not in v) + "\n].\n")
     print("wrote", len(vecs), "vector sets")
 
 
