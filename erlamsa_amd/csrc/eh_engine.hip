@@ -1925,7 +1925,7 @@ int eh_selftest_movers(eh_ctx* ctx, uint8_t* buf, uint64_t buf_len, const uint32
 // Self test hook for the device deflate / inflate (eh_zlib.h): op 0 raw deflate, 1 zlib:gzip/1, 2 zlib:deflate(default), 4 zlib:gunzip/1,
 // 5 zlib:inflate/2 as mutate_once_compressed/6 uses it.  *ok = 0 where the reference's call raises.
 int eh_selftest_zlib(eh_ctx* ctx, int op, const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len, int32_t* ok) {
-  if (!ctx || (!in && n) || !out || !out_len || !ok || op < 0 || op > 5 || op == 3) return EH_E_INVALID;
+  if (!ctx || (!in && n) || !out || !out_len || !ok || op < 0 || op > 5 || op == 3 || (op <= 2 && cap < 64)) return EH_E_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   uint8_t* di = nullptr; uint8_t* dout = nullptr; uint8_t* ds = nullptr; uint64_t* dr = nullptr;
   hipError_t e = hipMalloc(&di, n + 16);

@@ -112,6 +112,9 @@ typedef struct eh_options {
 #define EH_FLAG_ORDERED_OUTPUT 1u /* compact the output arena into case order after the batch */
 #define EH_FLAG_META_TRACE 2u     /* keep every case's meta trace (eh_result_meta) */
 
+/* One context = one HIP device, its result buffers and slots.  eh_create sets the DEVICE's stack limit (hipLimitStackSize, 6 KiB per
+ * lane: the kernel recurses for nested scheduler calls) - a process-wide setting other HIP users of the same device (e.g. a
+ * co-resident torch) inherit; the runtime sizes every hardware queue's scratch from it. */
 int eh_create(int device, eh_ctx** out);
 void eh_destroy(eh_ctx* ctx);
 int eh_configure(eh_ctx* ctx, const eh_options* opts);

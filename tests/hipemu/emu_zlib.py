@@ -91,6 +91,9 @@ def run(quick=False, small=False):
             c = zlib.compressobj(lvl, zlib.DEFLATED, 15, 8, strat); variants.append((5, c.compress(data) + c.flush()))
         named = b"\x1f\x8b\x08\x08" + bytes(6) + b"name.txt\x00" + want_compress(0, data) + zlib.crc32(data).to_bytes(4, "little") + (len(data) & 0xffffffff).to_bytes(4, "little")
         variants.append((4, named))
+        cd = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_DEFAULT_STRATEGY, zdict=b"a preset dictionary")     # FDICT: {need_dictionary, _} once the id is there
+        withdict = cd.compress(data) + cd.flush()
+        variants += [(5, withdict), (5, withdict[:5]), (5, withdict[:2]), (5, withdict[:1])]
         for k in range(6 if small else 10 if quick else 24):                                             # truncations and corruptions of both formats
             for op, full in ((4, gz), (5, zl)):
                 cut = int(rng.integers(0, len(full) + 1))
