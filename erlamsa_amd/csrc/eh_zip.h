@@ -62,9 +62,9 @@ EH_DEV int zip_open(ZipRd* r, const uint8_t* a, uint64_t n) {
   wave_sync();
   return (int)uni((uint32_t)r->rc);
 }
-// get_cd_loop's next entry + the entry's GetBin() (get_z_file / get_z_all).  The entry's bytes are the archive's own for a stored
-// file and a fresh work-area block for a deflated one.
-template <bool GROW> EH_DEV int zip_next(Ctx& c, ZipRd* r, ZipEntry* out) {
+// get_cd_loop's next entry: the central-directory header and its name (what exists before the fun is called: a broken
+// header fails the fold without the fun having run for this entry)
+EH_DEV int zip_next_header(ZipRd* r) {
   if (EH_LANE == 0) {
     const uint8_t* a = r->a; const uint64_t n = r->n;
     int rc = ZR_OK;
@@ -76,23 +76,33 @@ template <bool GROW> EH_DEV int zip_next(Ctx& c, ZipRd* r, ZipEntry* out) {
       else {
         ZipEntry& e = r->cur;
         e.name = (uint64_t)(h + 46); e.name_len = fnl; e.up = 0; e.time = (uint16_t)zle16(h + 12); e.date = (uint16_t)zle16(h + 14); e.usize = zle32(h + 24);
-        e.data = 0; e.data_len = 0; e.method = 0; e.crc = 0; e.csz = 0; e.lpos = 0; e.pad = 0;
+        e.data = 0; e.data_len = 0; e.method = 0; e.crc = 0; e.csz = 0; e.lpos = lho; e.pad = 0;
         r->pos += 46 + fnl + exl + cml; r->idx++;
         bool ascii = true; for (uint32_t i = 0; i < fnl; i++) if (h[46 + i] > 127) ascii = false;
         if (fnl == 0 || h[46 + fnl - 1] == '/' || (gp & 9) || zle32(h + 20) == 0xffffffffu || e.usize == 0xffffffffu || lho == 0xffffffffu || !ascii || (uint64_t)lho + 30 > n) rc = ZR_UNSUP;
-        else {
-          const uint8_t* l = a + lho;
-          if (zle32(l) != 0x04034b50u) rc = ZR_ERROR;                                             // bad_local_file_header
-          else {
-            uint32_t lgp = zle16(l + 6), method = zle16(l + 8), csz = zle32(l + 18), lfn = zle16(l + 26), lex = zle16(l + 28);
-            uint64_t ds = (uint64_t)lho + 30 + lfn + lex;
-            if ((lgp & 9) || ds > n) rc = ZR_UNSUP;
-            else if (method != 0 && method != 8) rc = ZR_ERROR;                                   // throw({bad_file_header, _})
-            else { uint64_t de = ds + csz > n ? n : ds + csz; r->method = method; r->comp = (uint64_t)(a + ds); r->comp_len = (uint32_t)(de - ds); }
-          }
-        }
       }
     }
+    r->rc = rc;
+  }
+  wave_sync();
+  return (int)uni((uint32_t)r->rc);
+}
+// ... and the entry's GetBin() (get_z_file / get_z_all), called from inside the fun.  The entry's bytes are the archive's own for
+// a stored file and a fresh work-area block for a deflated one.
+template <bool GROW> EH_DEV int zip_next_file(Ctx& c, ZipRd* r, ZipEntry* out) {
+  if (EH_LANE == 0) {
+    const uint8_t* a = r->a; const uint64_t n = r->n;
+    int rc = ZR_OK;
+    const uint8_t* l = a + r->cur.lpos;
+    if (zle32(l) != 0x04034b50u) rc = ZR_ERROR;                                                   // bad_local_file_header
+    else {
+      uint32_t lgp = zle16(l + 6), method = zle16(l + 8), csz = zle32(l + 18), lfn = zle16(l + 26), lex = zle16(l + 28);
+      uint64_t ds = (uint64_t)r->cur.lpos + 30 + lfn + lex;
+      if ((lgp & 9) || ds > n) rc = ZR_UNSUP;
+      else if (method != 0 && method != 8) rc = ZR_ERROR;                                         // throw({bad_file_header, _})
+      else { uint64_t de = ds + csz > n ? n : ds + csz; r->method = method; r->comp = (uint64_t)(a + ds); r->comp_len = (uint32_t)(de - ds); }
+    }
+    r->cur.lpos = 0;
     r->rc = rc;
   }
   wave_sync();
@@ -116,6 +126,10 @@ template <bool GROW> EH_DEV int zip_next(Ctx& c, ZipRd* r, ZipEntry* out) {
   if (EH_LANE == 0) { *out = r->cur; out->data = dptr; out->data_len = (uint32_t)dlen; }
   wave_sync();
   return ZR_OK;
+}
+template <bool GROW> EH_DEV int zip_next(Ctx& c, ZipRd* r, ZipEntry* out) {
+  int rc = zip_next_header(r);
+  return rc != ZR_OK ? rc : zip_next_file<GROW>(c, r, out);
 }
 // zip:create(Name, Files, [memory]) over es[0..n) in order; *out / *len: the archive.
 template <bool GROW> EH_DEV int zip_create(Ctx& c, ZipEntry* es, uint32_t n, uint8_t** out, uint64_t* len) {
@@ -217,8 +231,11 @@ __device__ __noinline__ int muta_zip(Ctx&) {
   ZipEntry* es = (ZipEntry*)ws_alloc(c, (uint64_t)(n ? n : 1) * sizeof(ZipEntry));
   if (!es) return 0;
   for (uint32_t i = 0; i < n; i++) {
-    uint32_t up = rng_rand(c.rng, 20);                                                            // mutate_zip_path/4
-    rc = zip_next<false>(c, rd, &es[i]);
+    rc = zip_next_header(rd);                                                                     // (a broken directory entry ends the fold before the fun runs)
+    if (rc == ZR_UNSUP) { c.status = CASE_UNSUPPORTED; return 0; }
+    if (rc != ZR_OK) return -1;
+    uint32_t up = rng_rand(c.rng, 20);                                                            // mutate_zip_path/4: R first, then B()
+    rc = zip_next_file<false>(c, rd, &es[i]);
     if (rc == ZR_STOP) return 0;
     if (rc == ZR_UNSUP) { c.status = CASE_UNSUPPORTED; return 0; }
     if (rc == ZR_CRASH) { c.status = CASE_CRASHED; return 0; }

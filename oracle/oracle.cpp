@@ -1184,7 +1184,8 @@ int open(const Bytes& a, Reader* r) {
   r->a = &a; r->entries = entries; r->idx = 0; r->pos = off;
   return ZR_OK;
 }
-int next(Reader* r, Entry* out) {
+// the next central-directory entry (get_cd_loop up to the call of the fun): *lho = its local header's offset
+int next_header(Reader* r, Entry* out, uint32_t* lho_out) {
   const Bytes& a = *r->a; const uint64_t n = a.size();
   if (r->pos + 46 > n) return ZR_ERROR;                                          // bad_central_directory
   const uint8_t* h = a.data() + r->pos;
@@ -1197,6 +1198,12 @@ int next(Reader* r, Entry* out) {
   if (fnl == 0 || out->name.back() == '/' || (gp & 9) || le32(h + 20) == 0xffffffffu || out->usize == 0xffffffffu || lho == 0xffffffffu) return ZR_UNSUP;
   for (uint8_t ch : out->name) if (ch > 127) return ZR_UNSUP;
   if ((uint64_t)lho + 30 > n) return ZR_UNSUP;
+  *lho_out = lho;
+  return ZR_OK;
+}
+// the entry's GetBin(): get_z_file / get_z_all, called from inside the fun
+int next_file(Reader* r, Entry* out, uint32_t lho) {
+  const Bytes& a = *r->a; const uint64_t n = a.size();
   const uint8_t* l = a.data() + lho;
   if (le32(l) != 0x04034b50u) return ZR_ERROR;                                   // bad_local_file_header
   uint32_t lgp = le16(l + 6), method = le16(l + 8), csz = le32(l + 18), lfn = le16(l + 26), lex = le16(l + 28);
@@ -1221,6 +1228,11 @@ int next(Reader* r, Entry* out) {
   }
   inflateEnd(&z);
   return res;
+}
+int next(Reader* r, Entry* out) {
+  uint32_t lho = 0;
+  int rc = next_header(r, out, &lho);
+  return rc != ZR_OK ? rc : next_file(r, out, lho);
 }
 bool stored_ext(const Bytes& name) {                                              // filename:extension/1 in [".Z", ".zip", ".zoo", ".arc", ".lzh", ".arj"]
   size_t dot = std::string::npos;
@@ -1282,9 +1294,12 @@ int zip_path_traversal(Ctx& c, BList& ll) {
   if (rc == otpzip::ZR_UNSUP) throw Unsupported();
   if (rc != otpzip::ZR_OK) return -1;
   for (uint32_t i = 0; i < rd.entries; i++) {
-    uint64_t r = c.rnd.rand(20);                                               // mutate_zip_path/4 :1149-1152
-    otpzip::Entry e;
-    rc = otpzip::next(&rd, &e);
+    otpzip::Entry e; uint32_t lho = 0;
+    rc = otpzip::next_header(&rd, &e, &lho);                                   // a broken directory entry ends the fold before the fun runs
+    if (rc == otpzip::ZR_UNSUP) throw Unsupported();
+    if (rc != otpzip::ZR_OK) return -1;
+    uint64_t r = c.rnd.rand(20);                                               // mutate_zip_path/4 :1149-1152: R first, then B()
+    rc = otpzip::next_file(&rd, &e, lho);
     if (rc == otpzip::ZR_UNSUP) throw Unsupported();
     if (rc == otpzip::ZR_CRASH) throw ErlCrash("data_error in zip:foldl");
     if (rc != otpzip::ZR_OK) return -1;

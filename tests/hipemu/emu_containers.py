@@ -139,8 +139,11 @@ def zip_corpus(n, seed):
         elif kind == 7:                                                  # a flipped bit anywhere (header fields, names), or inside the first file's compressed data
             full = bytearray(_mkzip(files))
             lo, hi = 0, len(full)
-            if rng.random() < 0.6:
+            u = rng.random()
+            if u < 0.4:
                 lo = 30 + len(files[0][0]); hi = max(lo + 1, min(len(full), lo + int.from_bytes(full[18:22], "little")))
+            elif u < 0.7:                                                # the LAST central-directory entry's signature: the fold fails after the
+                lo = bytes(full).rfind(b"PK\x01\x02"); hi = lo + 4       # fun has run (and drawn) for the entries before it
             full[int(rng.integers(lo, hi))] ^= 1 << int(rng.integers(0, 8)); b = bytes(full)
         elif kind == 8:
             b = _mkzip([])                                               # no entries: the end record alone
