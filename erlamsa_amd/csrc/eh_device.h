@@ -887,7 +887,14 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
         const uint64_t need = ((uint64_t)c.r_len + 15) & ~(uint64_t)15;
         if (mark + need <= c.ch_vend[j]) {
           uint8_t* dst = c.ch_base[j] + mark;
-          wave_sync(); wave_copy(dst, c.r_ptr, c.r_len); wave_sync();
+          // (the candidate is not always up in a borrowed area: a chunk the PATTERN borrowed for its scans - pick_csum,
+          // pick_simple_len - and gave back by resetting ws_used starts exactly at mark, and the attempt then ran in the chunk
+          // below it, a few bytes above dst: overlapping ranges, which wave_copy must not be given)
+          if (dst != c.r_ptr) {
+            wave_sync();
+            if (c.r_ptr > dst && c.r_ptr < dst + need) wave_move_down(dst, c.r_ptr, c.r_len); else wave_copy(dst, c.r_ptr, c.r_len);
+            wave_sync();
+          }
           c.r_ptr = dst;
           ws_release_to(c, mark);
           c.ws_used = mark + need;

@@ -43,4 +43,29 @@ print("cases %d, needed more than the slot's %d bytes: %d, areas taken per tier 
 assert bad == 0
 assert grown > len(inputs) // 4 and sum(ps["taken"]) >= grown
 eng.close()
+
+# A slot that is ALMOST full when the pattern starts: the random generator's stream (up to ~30 KB of blocks in the work area) in a
+# 32 KiB slot, patterns whose own scans borrow an area and give it back (cs, sz) or that mutate the tail of a block (sk), and
+# mutators whose result goes through flush_bvecs (num).  The chunk borrowed by the pattern starts exactly where the mutator
+# attempt begins; the candidate, made a few bytes above that point in the chunk BELOW, is moved down onto an overlapping range
+# (a plain wave_copy there corrupted 11 - 48 bytes of such cases until round 3).
+bad2 = total2 = 0
+data2, off2 = po.pack(util.corpus_uniform(24, 64, seed=3))
+for spec, pats in (("num", "cs"), ("num", "sz"), ("num", "sk"), ("num,bd,sr,lr", "cs,sz,sk,od,nd")):
+    for s in range(6 if n >= 24 else 2):
+        seed = (s + 1, 77, 5)
+        want2, wst2, wdr2, _ = po.fuzz_batch(data2, off2, seed=seed, mutations=spec, patterns=pats, generators="random=1", max_case_bytes=32 << 20)
+        eng = ea.Engine(0)
+        eng.configure(mutations=spec, patterns=pats, generators="random=1", max_case_bytes=32768, big_case_bytes=32 << 20)
+        eng.upload_corpus(data2, off2); eng.fuzz_batch(seed=seed); got2, gst2 = eng.download(); gdr2, _ = eng.diag()
+        eng.close()
+        for i in range(24):
+            if gst2[i] in (2, 3) or wst2[i] in (2, 3):
+                continue
+            total2 += 1
+            if got2[i] != want2[i] or gst2[i] != wst2[i] or gdr2[i] != wdr2[i]:
+                bad2 += 1
+                print("MISMATCH (nearly full slot)", spec, pats, seed, "case", i, "len", len(got2[i]), len(want2[i]), "first diff", util.first_diff(got2[i], want2[i]))
+print("nearly full slots: %d cases, mismatches %d" % (total2, bad2))
+assert bad2 == 0 and total2 > 100
 print("chunks ok")
