@@ -9,7 +9,7 @@
 // (max_lazy 16, nice 128, too-far rule for length-3 matches), block boundaries (16 383 symbols), the heap-built Huffman trees with
 // zlib's tie breaking, its length-limiting fix-up, its run-length coding of the code lengths and its stored / static / dynamic
 // choice.  What follows restates deflate.c's deflate_slow / longest_match / fill_window and trees.c in that sense (function by
-// function, named in the comments); tests compare it with the image's libz 1.2.11 on the oracle side (tests/test_zlib_device.py,
+// function, named in the comments); tests compare it with the image's libz 1.2.11 on the oracle side (tests/test_gpu_round3.py: test_device_zlib_against_libz,
 // tests/hipemu/emu_zlib.py).
 //
 // Execution: ONE lane.  Match finding with lazy evaluation is a chain of data-dependent decisions and the container paths are rare
