@@ -18,6 +18,7 @@ def _compare(inputs, mutations, patterns, seed=(1, 2, 3), generators=None, first
     okw = dict(seed=seed, mutations=mutations, patterns=patterns, generators=generators, first_case=first_case,
                max_case_bytes=oracle_cap, max_case_work=work)
     ora = util.oracle_batch(data, off, **okw)
+    assert not (ora.status == 3).any(), "the oracle says UNSUPPORTED for an input that is not a zip archive"
     if util.priming():
         pytest.skip("oracle cache primed")
     import erlamsa_amd as ea
@@ -49,6 +50,9 @@ def _compare(inputs, mutations, patterns, seed=(1, 2, 3), generators=None, first
                     % (i, util.first_diff(got[i], ora.outs[i]), len(got[i]), len(ora.outs[i]), int(gst[i]), int(wst[i]), int(gdr[i]), int(wdr[i]),
                        ora.trace[i] if i < len(ora.trace) else "") for i in bad[:max_report])
     assert not bad, "%d/%d cases differ\n%s" % (len(bad), len(inputs), msg)
+    # EH_CASE_UNSUPPORTED is what is left for zip archives with features outside the restated prim_zip: none of these corpora holds
+    # an archive, and gzip / zlib look-alikes (a random two-byte header passes zlib's check once in ~2 000 inputs) are decoded now
+    assert not (gst == 3).any() and not (wst == 3).any(), "EH_CASE_UNSUPPORTED on an input that is not a zip archive"
     assert skipped <= max_skipped * len(inputs), "%d cases skipped as overflow/unsupported" % skipped
     ok = (wst == 0) & (gst == 0)
     assert (gdr[ok] == wdr[ok]).all(), "draw counts differ"
