@@ -67,6 +67,15 @@ def samples(rng, quick, small=False):
         # more than 16 383 symbols per block, distances beyond the first window slide, a far length-3 match
         out.append(rng.integers(0, 16, size=200000, dtype=np.uint8).tobytes())
         out.append(bytes(rng.integers(0, 256, size=40000, dtype=np.uint8)) * 4)
+        # the edges of zlib's window: sizes around wsize, wsize + MAX_DIST and 2 * wsize, matches at the largest distances
+        for n in (32506, 32768, 65274, 65275, 65536, 65537, 98042, 131077):
+            out.append(rng.integers(0, 3, size=n, dtype=np.uint8).tobytes())
+        for per in (32505, 32506, 32507, 32768, 258, 3, 1):
+            base = rng.integers(0, 256, size=per, dtype=np.uint8).tobytes()
+            b = bytearray((base * (140000 // per + 2))[:140000])
+            for _ in range(5):
+                b[int(rng.integers(0, len(b)))] ^= 0x55
+            out.append(bytes(b))
     return out
 
 
