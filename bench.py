@@ -221,8 +221,27 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    # EH_BENCH_DRY=1 (tests/test_bench_dry.py): this very script on the CPU wavefront emulator - device pointers are host
+    # pointers there, so the arena is a CPU tensor, streams are the null stream and there is nothing to synchronise
+    dry = os.environ.get("EH_BENCH_DRY") == "1" and world == 1
+    if dry:
+        dev = torch.device("cpu")
+
+        class _NullStream:
+            cuda_stream = 0
+
+        def sync():
+            return None
+
+        def new_stream():
+            return _NullStream()
+    else:
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+        sync = torch.cuda.synchronize
+
+        def new_stream():
+            return torch.cuda.Stream(device=dev)
 
     n, size = args.cases, args.size
     # Measured set = the reference's full default mutator table (41 entries, default priorities) unless overridden.
@@ -244,7 +263,7 @@ def main():
             arena.copy_(torch.from_numpy(mat.reshape(-1)))
         if dist is not None:
             shard.broadcast_corpus(arena, offs, src=0)
-    torch.cuda.synchronize()
+    sync()
 
     # `--inflight` engine contexts, each on its own HIP stream: step k runs on context k % inflight, so
     # the long tail of one pass (a few MB-sized cases handled by single wavefronts) overlaps with
@@ -258,7 +277,7 @@ def main():
                     pool_bytes=args.pool_gib << 30)
         e.attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
         engines.append(e)
-        streams.append(torch.cuda.Stream(device=dev))
+        streams.append(new_stream())
     seed = (1, 2, 3)
     # Context set-up, not a step: every context reserves its device memory for a full batch (eh_reserve) and
     # runs one untimed full-size pass on its own HIP stream, which makes the runtime allocate that queue's
@@ -288,17 +307,17 @@ def main():
                 overflow_sites[site] = overflow_sites.get(site, 0) + 1
 
     shard.run_steps(engines, raw, 0, args.warmup, rank, world, n, seed, strong=strong)
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     log("timed steps")
     t0 = time.perf_counter()
     timed = shard.run_steps(engines, raw, args.warmup, args.steps, rank, world, n, seed, on_result=on_result, strong=strong)
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     log("timed steps done: %.3f s per step" % (dt / max(args.steps, 1)))
     out_bytes, kern_ms, status_counts = timed["out_bytes"], timed["kernel_ms"], timed["status_counts"]
@@ -381,7 +400,7 @@ def main():
                 kind = "pageable"
             e = engines[0]
             kx = args.warmup + args.steps + 100
-            torch.cuda.synchronize()
+            sync()
             tp = time.perf_counter()
             e.fuzz_batch(seed=seed, first_case=shard.weak_first_case(kx, rank, world, n), corpus_first=0, n=n, stream=raw[0])
             e.sync()
@@ -403,10 +422,10 @@ def main():
                             max_case_bytes=args.case_mib << 20, max_case_work=args.budget_mib << 20, big_case_bytes=args.big_mib << 20,
                             pool_bytes=args.pool_gib << 30)
             bsteps = min(2 * nctx, args.steps)
-            torch.cuda.synchronize()
+            sync()
             tb = time.perf_counter()
             br = shard.run_steps(engines, raw, args.warmup + args.steps, bsteps, rank, world, n, seed)
-            torch.cuda.synchronize()
+            sync()
             bdt = time.perf_counter() - tb
             bbytes, bstat = br["out_bytes"], br["status_counts"]
             return {"max_case_work": args.budget_mib << 20, "steps": bsteps, "value": round(bbytes / bdt / 1e6, 1), "unit": "MB/s",

@@ -1,0 +1,41 @@
+"""bench.py itself, end to end, on the CPU wavefront emulator (EH_BENCH_DRY=1: the arena is a CPU tensor, streams are the null
+stream): the step loop, the roofline arithmetic, the parity leg against the oracle (the bench fails unless its sample agrees), the
+PCIe and work-budget legs, the JSON line - for the driver's configuration shape and for `--config 5` (counter-hash corpus written
+by torch, generator jump over the whole arena, strong scaling).  Sizes are tiny; the numbers mean nothing, the code paths do."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+SMALL = ["--steps", "2", "--warmup", "1", "--inflight", "2", "--max-slots", "4", "--out-gib", "1", "--pool-gib", "1", "--case-mib", "1", "--big-mib", "32",
+         "--cpu-sample", "8", "--cpu-threads", "2", "--setup-seconds", "0"]
+
+
+def _run(extra):
+    import build_emu
+    env = dict(os.environ, EH_BENCH_DRY="1", ERLAMSA_HIP_LIB=build_emu.build())
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-1500:]
+    return json.loads(lines[0])
+
+
+def test_bench_script_runs_end_to_end_on_the_emulator():
+    d = _run(["--cases", "16", "--size", "256", "--mutations", "bd,bf,bi,sr,num,lr,ab", "--budget-mib", "1", "--pcie", "1"])
+    assert d["metric"] == "mutated_MB_per_s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["config"]["cases_per_step_per_gpu"] == 16
+    assert d["case_status"]["ok"] == 32 and d["parity_checked"] + d["parity"]["not_compared"] == 8 and d["parity_checked"] >= 7
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["algorithmic_bytes_per_launch"] > 16 * 256
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 2 and "pcie" in d and "with_work_budget" in d
+
+
+def test_bench_config_5_shape_runs_on_the_emulator():
+    d = _run(["--config", "5", "--cases", "12", "--size", "4096", "--budget-mib", "0", "--pcie", "0", "--steps", "1", "--warmup", "0", "--inflight", "1", "--cpu-sample", "6"])
+    assert "configs[4]" in d["config"]["workload"] and "generator jump" in d["config"]["workload"] and d["scaling"] == "strong"
+    assert d["case_status"]["ok"] == 12 and d["parity_checked"] == 6        # the oracle's Paths are the whole counter-hash arena
