@@ -82,7 +82,7 @@ struct ZDef {
   ZTree lt, dt, bt;            // dyn_ltree, dyn_dtree, bl_tree (dt and bt use the first 61 / 39 entries)
   uint16_t st_lcode[288]; uint8_t st_llen[288];                 // static_ltree (static_dtree: 5 bits, bit-reversed code number)
   int32_t heap[Z_HEAP_SIZE]; uint8_t depth[Z_HEAP_SIZE]; uint16_t bl_count[16]; uint16_t next_code[16];
-  int32_t heap_len, heap_max, l_max_code, d_max_code, bl_max_code;
+  int32_t heap_len, heap_max;
   uint32_t last_lit; uint64_t opt_len, static_len;
   // bit writer
   uint8_t* out; uint64_t out_pos, out_cap; uint64_t bi_buf; int32_t bi_valid; int32_t overflow;

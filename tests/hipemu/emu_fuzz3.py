@@ -37,14 +37,16 @@ while time.time() < t_end:
     n = len(inputs)
     gens = rnd.choice([None, None, "file", "jump", "file=3,jump=2,direct=2,random=1"])
     slot = rnd.choice([32, 64, 256, 1024]) << 10
+    bs = rnd.choice([1.0, 1.0, 0.25, 2.0, 0.0625])                 # blockscale: block sizes of the file / jump / random streams
+    first = rnd.choice([1, 1, 7, 1000])
     data, off = po.pack(inputs)
     try:
-        want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=spec, patterns=pats, generators=gens, max_case_bytes=32 << 20, trace=True, max_case_seconds=20.0)
+        want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=spec, patterns=pats, generators=gens, blockscale=bs, first_case=first, max_case_bytes=32 << 20, trace=True, max_case_seconds=20.0)
     except RuntimeError as e:
         print("oracle error", e, spec, pats); continue
     eng = ea.Engine(0)
-    eng.configure(mutations=spec, patterns=pats, generators=gens, max_case_bytes=slot, big_case_bytes=32 << 20, flags=ea.engine.EH_FLAG_META_TRACE)
-    eng.upload_corpus(data, off); eng.fuzz_batch(seed=seed); got, gst = eng.download(); gdr, _ = eng.diag()
+    eng.configure(mutations=spec, patterns=pats, generators=gens, blockscale=bs, max_case_bytes=slot, big_case_bytes=32 << 20, flags=ea.engine.EH_FLAG_META_TRACE)
+    eng.upload_corpus(data, off); eng.fuzz_batch(seed=seed, first_case=first); got, gst = eng.download(); gdr, _ = eng.diag()
     lines = tr.split("\n")
     for i in range(n):
         total += 1
@@ -58,7 +60,7 @@ while time.time() < t_end:
                 bad = True
                 print("   TRACE differs: engine", mine[:200], "| oracle", " ".join(lines[i].split())[:200], flush=True)
         if bad:
-            print("MISMATCH trial", trial, "case", i, "spec", spec, "pats", pats, "gens", gens, "seed", seed, "kind", kind, "n", n, "slot", slot,
+            print("MISMATCH trial", trial, "case", i, "spec", spec, "pats", pats, "gens", gens, "seed", seed, "kind", kind, "n", n, "slot", slot, "blockscale", bs, "first_case", first,
                   "len", len(got[i]), len(want[i]), "status", gst[i], wst[i], "draws", gdr[i], wdr[i], "firstdiff", util.first_diff(got[i], want[i]), flush=True)
             print("   trace:", lines[i][:300], flush=True)
             break
