@@ -93,7 +93,7 @@ def test_emulated_file_and_jump_generators(emu_lib):
     """erlamsa_gen.erl:59-150 on the device: multi-block `file` streams, `jump` splices across corpus entries, the stream forced by
     the pattern's first uncons (its draws come after the pattern's), sub-range batches with the whole corpus as Paths"""
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_gens.py"), "12"], env=env, capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_gens.py"), "8"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "gens ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
