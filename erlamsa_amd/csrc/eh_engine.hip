@@ -881,6 +881,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
 
     EH_PH(2);
     // ---- erlamsa_out:output/4: concatenate the written blocks into the output arena
+    wave_sync();                                                        // (the last pieces were written by lane 0 just now)
     total = 0; base = 0;
     if (c.status == CASE_OK) for (int k = 0; k < c.nem; k++) total += blk_load(c.em, k).len;
     if (total > 0) {

@@ -49,6 +49,15 @@ struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c 
 struct hipemu_idx { unsigned x, y, z; };
 inline hipemu_idx threadIdx{0, 0, 0}, blockIdx{0, 0, 0}, blockDim{64, 1, 1}, gridDim{1, 1, 1};
 
+// ---- race detector hooks (build_emu.py --race links tests/hipemu/race_hooks.cpp; otherwise nothing) -------------------------
+#ifdef HIPEMU_RACE
+extern "C" { void hipemu_race_init(void); void hipemu_race_exclude(const void* lo, const void* hi); void hipemu_race_clear_excludes(void);
+             void hipemu_race_lane(int lane); void hipemu_race_epoch(void); unsigned long hipemu_race_count(void); void hipemu_race_atomic(int on); }
+#define HIPEMU_RACE_CALL(x) x
+#else
+#define HIPEMU_RACE_CALL(x) ((void)0)
+#endif
+
 // ---- the wavefront emulator --------------------------------------------------------------------
 namespace hipemu {
 constexpr int W = 64;
@@ -99,6 +108,12 @@ inline void run_block(const std::function<void()>& body) {
   w.lds_size = (size_t)(__stop_hipemu_shared - __start_hipemu_shared);
   if (!w.lds_save) w.lds_save = (char*)malloc(w.lds_size * W + 1);
   memset(w.lds_save, 0, w.lds_size * W);
+  HIPEMU_RACE_CALL(hipemu_race_init());
+  HIPEMU_RACE_CALL(hipemu_race_clear_excludes());
+  HIPEMU_RACE_CALL(hipemu_race_exclude(w.stacks, w.stacks + STACK * W));                   // private: the fibers' stacks
+  HIPEMU_RACE_CALL(hipemu_race_exclude(__start_hipemu_shared, __stop_hipemu_shared));      // LDS: one image per lane, compared at every rendezvous
+  HIPEMU_RACE_CALL(hipemu_race_exclude(&w, &w + 1));                                       // the emulator's own exchange buffers
+  HIPEMU_RACE_CALL(hipemu_race_epoch());
   for (int l = 0; l < W; l++) {
     getcontext(&w.ctx[l]);
     w.ctx[l].uc_stack.ss_sp = w.stacks + STACK * l;
@@ -112,7 +127,9 @@ inline void run_block(const std::function<void()>& body) {
       if (w.state[l] != RUN) continue;
       w.cur = l; threadIdx.x = (unsigned)l;
       memcpy(__start_hipemu_shared, w.lds_save + w.lds_size * l, w.lds_size);
+      HIPEMU_RACE_CALL(hipemu_race_lane(l));
       swapcontext(&w.sched, &w.ctx[l]);
+      HIPEMU_RACE_CALL(hipemu_race_lane(-1));
       memcpy(w.lds_save + w.lds_size * l, __start_hipemu_shared, w.lds_size);
     }
     int waiting = 0, op = OP_NONE; unsigned cnt = 0; bool mixed = false;
@@ -150,6 +167,7 @@ inline void run_block(const std::function<void()>& body) {
     unsigned par = cnt & 1u;
     for (int l = 0; l < W; l++) w.present[par ^ 1u][l] = 0;   // the other buffer has been read by everybody
     for (int l = 0; l < W; l++) if (w.state[l] == WAIT) w.state[l] = RUN;
+    HIPEMU_RACE_CALL(hipemu_race_epoch());                   // a rendezvous orders what came before it against what comes after
   }
 }
 
@@ -207,10 +225,10 @@ inline double __longlong_as_double(long long v) { double r; memcpy(&r, &v, 8); r
 inline unsigned long long __builtin_readcyclecounter() {
   return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-template <class T, class U> inline T atomicAdd(T* p, U v) { T old = *p; *p = (T)(old + (T)v); return old; }
-template <class T, class U> inline T atomicExch(T* p, U v) { T old = *p; *p = (T)v; return old; }
-template <class T, class U> inline T atomicOr(T* p, U v) { T old = *p; *p = (T)(old | (T)v); return old; }
-template <class T, class U, class V> inline T atomicCAS(T* p, U cmp, V v) { T old = *p; if (old == (T)cmp) *p = (T)v; return old; }
+template <class T, class U> inline T atomicAdd(T* p, U v) { HIPEMU_RACE_CALL(hipemu_race_atomic(1)); T old = *p; *p = (T)(old + (T)v); HIPEMU_RACE_CALL(hipemu_race_atomic(0)); return old; }
+template <class T, class U> inline T atomicExch(T* p, U v) { HIPEMU_RACE_CALL(hipemu_race_atomic(1)); T old = *p; *p = (T)v; HIPEMU_RACE_CALL(hipemu_race_atomic(0)); return old; }
+template <class T, class U> inline T atomicOr(T* p, U v) { HIPEMU_RACE_CALL(hipemu_race_atomic(1)); T old = *p; *p = (T)(old | (T)v); HIPEMU_RACE_CALL(hipemu_race_atomic(0)); return old; }
+template <class T, class U, class V> inline T atomicCAS(T* p, U cmp, V v) { HIPEMU_RACE_CALL(hipemu_race_atomic(1)); T old = *p; if (old == (T)cmp) *p = (T)v; HIPEMU_RACE_CALL(hipemu_race_atomic(0)); return old; }
 
 // ---- the slice of the HIP runtime API the engine's host side uses -----------------------------------
 typedef int hipError_t;
