@@ -72,3 +72,9 @@ while time.time() < t_end:
     eng.close()
     if trial % 10 == 0: print("trials", trial, "cases", total, "skipped", skipped, "grew beyond the slot", grown, "traces compared", traced, flush=True)
 print("done trials", trial, "cases", total, "skipped", skipped, "grew beyond the slot", grown, "traces compared", traced)
+try:                                                   # with the race build (build_emu.py --race): cross-lane accesses without a rendezvous in between
+    import ctypes
+    _l = ctypes.CDLL(os.environ["ERLAMSA_HIP_LIB"]); _l.hipemu_race_count.restype = ctypes.c_ulong
+    print("races", _l.hipemu_race_count())
+except (AttributeError, OSError, KeyError):
+    pass

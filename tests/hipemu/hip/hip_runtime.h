@@ -11,7 +11,8 @@
 // yields; when every live lane has arrived at the same operation the exchange is resolved and all lanes
 // continue.  Memory is ordinary host memory; lanes run one after another between rendezvous points, so
 // code that relies on lockstep execution without a wave_sync()/cross-lane operation between a store and
-// another lane's load of it fails here (it would be a race on the GPU as well).
+// another lane's load of it fails here (it would be a race on the GPU as well).  The converse - a load that only works because
+// a LOWER lane stored first - is what build_emu.py --race + race_hooks.cpp catch (every load / store instrumented).
 #pragma once
 #include <math.h>
 #include <ucontext.h>
