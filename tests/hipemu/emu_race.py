@@ -4,7 +4,8 @@ kernel code is checked against the rule that, between two rendezvous points of t
 wrote or overwrites a byte another lane read.  The plain emulator cannot see such a bug (lane 0 runs first, so the others do see
 what it wrote); a real wavefront promises nothing without the wave_sync().  Workloads: the file / jump / random generators, gzip /
 zlib / zip containers (their codecs run on lane 0 and hand results to the wavefront), nearly full and tiny slots with the default
-tables (nested scheduler calls, areas borrowed and returned), the streaming fuse with the meta trace.
+tables (nested scheduler calls, areas borrowed and returned), the streaming fuse with the meta trace.  The same hooks check
+BOUNDS: in this build every device allocation has a guard zone on either side, and an access that lands in one is reported.
 
   ERLAMSA_HIP_LIB=build/liberlamsa_hip_emu_race.so python tests/hipemu/emu_race.py [cases per workload]
 """
@@ -27,6 +28,14 @@ warnings.simplefilter("ignore")
 assert "race" in os.environ.get("ERLAMSA_HIP_LIB", ""), "point ERLAMSA_HIP_LIB at the race build (build_emu.py --race)"
 lib = ctypes.CDLL(os.environ["ERLAMSA_HIP_LIB"])
 lib.hipemu_race_count.restype = ctypes.c_ulong
+lib.hipemu_oob_count.restype = ctypes.c_ulong
+
+# the bounds check is alive: a byte-mover job that reads 104 bytes past its 4 096-byte device buffer lands in the guard zone
+_e = ea.Engine(0)
+_e.selftest_movers(np.zeros(4096, dtype=np.uint8), np.array([[0, 0, 4000, 200, 0]], dtype=np.uint32))
+_e.close()
+OOB0 = lib.hipemu_oob_count()
+assert OOB0 > 0, "the seeded overrun was not reported"
 
 
 def run(tag, inputs, generators=None, slot=1 << 20, flags=0, fsm=0, **kw):
@@ -58,4 +67,7 @@ if races:
         o = subprocess.run(["addr2line", "-f", "-C", "-i", "-e", os.environ["ERLAMSA_HIP_LIB"], "0x%x" % (pcs[i] - base - 1)], capture_output=True, text=True).stdout.split("\n")
         print("%8d  %s" % (cnt[i], " <- ".join("%s@%s" % (o[j].split("(")[0], os.path.basename(o[j + 1]).split(" ")[0]) for j in range(0, min(len(o) - 1, 8), 2))))
     sys.exit("%d cross-lane accesses without a rendezvous in between" % races)
+oob = lib.hipemu_oob_count() - OOB0
+if oob:
+    sys.exit("%d accesses outside a device allocation (guard zones)" % oob)
 print("race ok")

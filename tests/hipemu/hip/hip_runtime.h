@@ -53,7 +53,7 @@ inline hipemu_idx threadIdx{0, 0, 0}, blockIdx{0, 0, 0}, blockDim{64, 1, 1}, gri
 // ---- race detector hooks (build_emu.py --race links tests/hipemu/race_hooks.cpp; otherwise nothing) -------------------------
 #ifdef HIPEMU_RACE
 extern "C" { void hipemu_race_init(void); void hipemu_race_exclude(const void* lo, const void* hi); void hipemu_race_clear_excludes(void);
-             void hipemu_race_lane(int lane); void hipemu_race_epoch(void); unsigned long hipemu_race_count(void); void hipemu_race_atomic(int on); }
+             void hipemu_race_lane(int lane); void hipemu_race_epoch(void); unsigned long hipemu_race_count(void); void hipemu_race_atomic(int on); void hipemu_race_region(const void* p, size_t n, int add); }
 #define HIPEMU_RACE_CALL(x) x
 #else
 #define HIPEMU_RACE_CALL(x) ((void)0)
@@ -252,12 +252,17 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   p->multiProcessorCount = 1; p->totalGlobalMem = (size_t)8 << 30;
   return hipSuccess;
 }
+#ifdef HIPEMU_RACE
+constexpr size_t HIPEMU_GUARD = 256;   // race build: a guard zone on either side of every device allocation (race_hooks.cpp reports accesses to it)
+#else
+constexpr size_t HIPEMU_GUARD = 0;
+#endif
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) {
   void* q = nullptr;
-  if (posix_memalign(&q, 256, n ? n : 256) != 0) { *p = nullptr; return hipErrorOutOfMemory; }
-  *p = (T*)q; return hipSuccess;
+  if (posix_memalign(&q, 256, (n ? n : 256) + 2 * HIPEMU_GUARD) != 0) { *p = nullptr; return hipErrorOutOfMemory; }
+  *p = (T*)((char*)q + HIPEMU_GUARD); HIPEMU_RACE_CALL(hipemu_race_region((char*)q + HIPEMU_GUARD, n ? n : 256, 1)); return hipSuccess;
 }
-inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipFree(void* p) { if (!p) return hipSuccess; HIPEMU_RACE_CALL(hipemu_race_region(p, 0, 0)); free((char*)p - HIPEMU_GUARD); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
