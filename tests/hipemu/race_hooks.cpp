@@ -54,6 +54,7 @@ __attribute__((noinline)) void report_oob(uintptr_t a, size_t n, bool store, con
   static void* seen[64]; static int nseen = 0;
   for (int i = 0; i < nseen; i++) if (seen[i] == pc) return;
   if (nseen < 64) seen[nseen++] = pc;
+  if (getenv("HIPEMU_RACE_QUIET")) return;
   fprintf(stderr, "hipemu out of bounds: lane %d %s %zu byte(s) at %p, %ld bytes %s the device allocation [%p, %p)\n", g_lane, store ? "stores" : "loads", n, (void*)a,
           (long)(a >= r.hi ? a - r.hi : r.lo - a), a >= r.hi ? "behind" : "in front of", (void*)r.lo, (void*)r.hi);
   backtrace_symbols_fd(bt + 2, k > 2 ? (k - 2 < 5 ? k - 2 : 5) : 0, 2);
