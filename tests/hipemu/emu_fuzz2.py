@@ -13,6 +13,16 @@ import numpy as np, pyoracle as po, util, erlamsa_amd as ea
 from erlamsa_amd import synth
 ALL = list(ea.gpu_mutators())
 PATS = ["od", "nd", "bu", "sk", "sz", "cs", "ar", "cp", "co", "nu"]
+def _races():
+    """with the race build (build_emu.py --race): cross-lane accesses without a rendezvous + out-of-bounds accesses so far"""
+    try:
+        import ctypes
+        l = ctypes.CDLL(os.environ["ERLAMSA_HIP_LIB"]); l.hipemu_race_count.restype = ctypes.c_ulong; l.hipemu_oob_count.restype = ctypes.c_ulong
+        return "races %d oob %d" % (l.hipemu_race_count(), l.hipemu_oob_count())
+    except (AttributeError, OSError, KeyError):
+        return ""
+
+
 rnd = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 600)
 trial = total = skipped = grown = traced = 0
@@ -70,11 +80,5 @@ while time.time() < t_end:
             print("   trace:", lines[i][:300], flush=True)
             break
     eng.close()
-    if trial % 10 == 0: print("trials", trial, "cases", total, "skipped", skipped, "grew beyond the slot", grown, "traces compared", traced, flush=True)
+    if trial % 10 == 0: print("trials", trial, "cases", total, "skipped", skipped, "grew beyond the slot", grown, "traces compared", traced, _races(), flush=True)
 print("done trials", trial, "cases", total, "skipped", skipped, "grew beyond the slot", grown, "traces compared", traced)
-try:                                                   # with the race build (build_emu.py --race): cross-lane accesses without a rendezvous in between
-    import ctypes
-    _l = ctypes.CDLL(os.environ["ERLAMSA_HIP_LIB"]); _l.hipemu_race_count.restype = ctypes.c_ulong
-    print("races", _l.hipemu_race_count())
-except (AttributeError, OSError, KeyError):
-    pass

@@ -14,6 +14,16 @@ import emu_containers as ec
 warnings.simplefilter("ignore")
 ALL = list(ea.gpu_mutators())
 PATS = ["od", "nd", "bu", "sk", "sz", "cs", "ar", "cp", "co", "nu"]
+def _races():
+    """with the race build (build_emu.py --race): cross-lane accesses without a rendezvous + out-of-bounds accesses so far"""
+    try:
+        import ctypes
+        l = ctypes.CDLL(os.environ["ERLAMSA_HIP_LIB"]); l.hipemu_race_count.restype = ctypes.c_ulong; l.hipemu_oob_count.restype = ctypes.c_ulong
+        return "races %d oob %d" % (l.hipemu_race_count(), l.hipemu_oob_count())
+    except (AttributeError, OSError, KeyError):
+        return ""
+
+
 rnd = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 600)
 trial = total = skipped = traced = 0
@@ -65,11 +75,5 @@ while time.time() < t_end:
             print("   trace:", lines[i][:300], flush=True)
             break
     eng.close()
-    if trial % 10 == 0: print("trials", trial, "cases", total, "skipped", skipped, "traces compared", traced, "statuses", stat.tolist(), flush=True)
+    if trial % 10 == 0: print("trials", trial, "cases", total, "skipped", skipped, "traces compared", traced, "statuses", stat.tolist(), _races(), flush=True)
 print("done trials", trial, "cases", total, "skipped", skipped, "traces compared", traced, "statuses", stat.tolist())
-try:                                                   # with the race build (build_emu.py --race): cross-lane accesses without a rendezvous in between
-    import ctypes
-    _l = ctypes.CDLL(os.environ["ERLAMSA_HIP_LIB"]); _l.hipemu_race_count.restype = ctypes.c_ulong
-    print("races", _l.hipemu_race_count())
-except (AttributeError, OSError, KeyError):
-    pass
