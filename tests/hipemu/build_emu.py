@@ -34,6 +34,8 @@ def build(force=False, race=False):
                                   "--param", "asan-globals=0", "--param", "asan-stack=0", "-x", "c++", "-c", os.path.join(src, "eh_engine.hip"), "-o", obj[0]])
     subprocess.check_call(base + ["-c", hooks, "-o", obj[1]])
     subprocess.check_call(["g++", "-shared", "-rdynamic"] + obj + ["-o", out])
+    for o in obj:                                   # (11 MB of objects would travel with every gpurun snapshot)
+        os.remove(o)
     return out
 
 
