@@ -161,21 +161,24 @@ def main():
                         out_gib=8, cpu_sample=0, budget_mib=0)
     args = ap.parse_args()
 
-    # ---- supervision (single GPU only): the run proper happens in a child process.  Twice in this round's development a run
-    # never came back from its set-up passes when device memory was nearly exhausted (the runtime could not place the queues'
-    # scratch); a benchmark that hangs reports nothing, so a stuck child is replaced by a more frugal one.
+    # ---- supervision (single GPU only): the run proper happens in a child process, and the driver must get its JSON line.
+    # A child that dies (round 3's driver run: "Memory access fault by GPU node-2" 3.6 s in, once, never reproduced) or that never
+    # leaves its set-up passes is replaced: first by an identical one, then by more frugal ones (fewer passes in flight).
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.setup_seconds > 0 and not os.environ.get("EH_BENCH_CHILD"):
         import subprocess
         import threading
-        for attempt, extra in enumerate(([], ["--inflight", "3"], ["--inflight", "1"])):
+        ladder = ([], [], ["--inflight", "3"], ["--inflight", "1"])
+        for attempt, extra in enumerate(ladder):
             env = dict(os.environ, EH_BENCH_CHILD="1")
             proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-            marks = {"setup": None, "past": False}
+            marks = {"setup": None, "past": False, "stage": "start"}
 
             def pump(proc=proc, marks=marks):
                 for ln in proc.stderr:
                     sys.stderr.write(ln)
                     sys.stderr.flush()
+                    if ln.startswith("[bench "):
+                        marks["stage"] = ln.split("]", 1)[1].strip()[:80]
                     if "reserve + set-up passes" in ln:
                         marks["setup"] = time.time()
                     if "warm-up steps" in ln:
@@ -184,64 +187,58 @@ def main():
             th.start()
             stuck = False
             while proc.poll() is None:
-                time.sleep(1.0)
+                time.sleep(0.5)
                 if marks["setup"] is not None and not marks["past"] and time.time() - marks["setup"] > args.setup_seconds:
                     stuck = True
                     proc.kill()
                     break
             out = proc.stdout.read()
             proc.wait()
+            th.join(timeout=5)
             lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-            if lines and not stuck:
+            if lines and not stuck:                                     # a result is a result, whatever the child's exit code
                 print(lines[-1], flush=True)
                 sys.exit(0)
-            if not stuck:
+            nxt = ", repeating%s" % (" with " + " ".join(ladder[attempt + 1]) if ladder[attempt + 1] else " as configured") if attempt + 1 < len(ladder) else ""
+            if stuck:
+                log("set-up passes did not finish within %d s: child killed%s" % (args.setup_seconds, nxt))
+            else:
                 sys.stderr.write(out[-2000:])
-                sys.exit(proc.returncode or 1)
-            log("set-up passes did not finish within %d s: child killed%s" % (args.setup_seconds, ", repeating with --inflight %d" % (3, 1)[attempt] if attempt < 2 else ""))
+                log("child ended without a result (exit code %s, last stage: %s)%s" % (proc.returncode, marks["stage"], nxt))
         sys.exit(1)
 
     if os.environ.get("EH_BENCH_SIMULATE"):                  # tests/test_bench_supervisor.py: a child that hangs in its set-up passes, or not
+        sim = os.environ["EH_BENCH_SIMULATE"]
+        if sim == "crash" or (sim == "crash_once" and not os.path.exists(os.environ["EH_BENCH_SIMULATE_FLAG"])):
+            if sim == "crash_once":
+                open(os.environ["EH_BENCH_SIMULATE_FLAG"], "w").close()
+            log("corpus (simulated)")
+            os.abort()                                           # what a GPU memory access fault does to the process
         log("reserve + set-up passes (simulated)")
-        if os.environ["EH_BENCH_SIMULATE"] == "hang" or (os.environ["EH_BENCH_SIMULATE"] == "hang_once" and args.inflight != 3):
+        if sim == "hang" or (sim == "hang_once" and args.inflight != 3):
             time.sleep(3600)
         log("warm-up steps")
         print(json.dumps({"metric": "simulated", "inflight": args.inflight}), flush=True)
         return
 
     import numpy as np
-    import torch
-    import erlamsa_amd as ea
     from erlamsa_amd import shard, synth
-
     rank, world, local = shard.rank_env()
-    dist = None
+    # A single-GPU run needs no torch at all: the corpus goes up through eh_corpus_upload, every context runs on its own HIP
+    # stream (eh_stream), pinned host memory comes from eh_host_alloc.  torch is imported only for N > 1 - it is the RCCL binding
+    # (broadcast of the arena, barrier, reduction of the result) - and then BEFORE the engine's library, so that both share one
+    # HIP runtime.
+    dist = torch = None
     if world > 1:
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        log("rank %d: process group (nccl = RCCL)" % rank)
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    # EH_BENCH_DRY=1 (tests/test_bench_dry.py): this very script on the CPU wavefront emulator - device pointers are host
-    # pointers there, so the arena is a CPU tensor, streams are the null stream and there is nothing to synchronise
-    dry = os.environ.get("EH_BENCH_DRY") == "1" and world == 1
-    if dry:
-        dev = torch.device("cpu")
-
-        class _NullStream:
-            cuda_stream = 0
-
-        def sync():
-            return None
-
-        def new_stream():
-            return _NullStream()
-    else:
-        dev = torch.device("cuda", local)
-        torch.cuda.set_device(dev)
-        sync = torch.cuda.synchronize
-
-        def new_stream():
-            return torch.cuda.Stream(device=dev)
+    import erlamsa_amd as ea
+    from erlamsa_amd.engine import HostBuffer
+    dev = torch.device("cuda", local) if torch is not None else None
 
     n, size = args.cases, args.size
     # Measured set = the reference's full default mutator table (41 entries, default priorities) unless overridden.
@@ -249,35 +246,51 @@ def main():
     pats = args.patterns
     nmut_total = len(ea.mutator_table())
 
-    # ---- corpus: generated on rank 0, RCCL-broadcast to the other GPUs over xGMI
-    arena = torch.empty(n * size, dtype=torch.uint8, device=dev)
-    offs = torch.arange(n + 1, dtype=torch.int64, device=dev) * size
-    mat = None
-    if args.corpus == "counter":                               # every rank writes the same arena itself (closed form of seed, row, byte)
-        synth.counter_torch(arena, 0, n, size)
-        if rank == 0 and n * size <= (1 << 30):
-            mat = synth.counter(range(n), size)                # host copy for the CPU oracle leg (small runs only)
-    else:
-        if rank == 0:
-            mat = synth.mixed(n, size) if args.corpus == "mixed" else synth.uniform(n, size)
-            arena.copy_(torch.from_numpy(mat.reshape(-1)))
-        if dist is not None:
-            shard.broadcast_corpus(arena, offs, src=0)
-    sync()
-
     # `--inflight` engine contexts, each on its own HIP stream: step k runs on context k % inflight, so
     # the long tail of one pass (a few MB-sized cases handled by single wavefronts) overlaps with
     # the next pass instead of idling the GPU.  Every step is still a complete, separate pass.
     nctx = max(1, min(args.inflight, args.steps))
-    engines, streams = [], []
+    log("engine contexts (%d)" % nctx)
+    engines = []
     for _ in range(nctx):
         e = ea.Engine(local)
         e.configure(mutations=muts, patterns=pats, generators=args.generators, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
                     max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20, big_case_bytes=args.big_mib << 20,
                     pool_bytes=args.pool_gib << 30)
-        e.attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
         engines.append(e)
-        streams.append(new_stream())
+
+    def sync():
+        for e in engines:
+            e.sync()
+        if torch is not None:
+            torch.cuda.synchronize()
+
+    # ---- corpus: one arena in HBM, shared by all contexts of the device
+    log("corpus")
+    mat = None
+    if world == 1:
+        if args.corpus == "counter":
+            mat = np.concatenate([synth.counter(range(r0, min(r0 + 4096, n)), size) for r0 in range(0, n, 4096)])
+        else:
+            mat = synth.mixed(n, size) if args.corpus == "mixed" else synth.uniform(n, size)
+        engines[0].upload_corpus(*synth.as_arena(mat))
+        if n * size > (1 << 30):
+            mat = None                                              # (the CPU oracle leg wants a host copy: small runs only)
+    else:                                                           # generated on rank 0, RCCL-broadcast to the other GPUs over xGMI
+        arena = torch.empty(n * size, dtype=torch.uint8, device=dev)
+        offs = torch.arange(n + 1, dtype=torch.int64, device=dev) * size
+        if args.corpus == "counter":                               # every rank writes the same arena itself (closed form of seed, row, byte)
+            synth.counter_torch(arena, 0, n, size)
+        else:
+            if rank == 0:
+                mat = synth.mixed(n, size) if args.corpus == "mixed" else synth.uniform(n, size)
+                arena.copy_(torch.from_numpy(mat.reshape(-1)))
+            shard.broadcast_corpus(arena, offs, src=0)
+        torch.cuda.synchronize()
+        engines[0].attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
+    for e in engines[1:]:
+        e.share_corpus(engines[0])
+    raw = [e.own_stream() for e in engines]
     seed = (1, 2, 3)
     # Context set-up, not a step: every context reserves its device memory for a full batch (eh_reserve) and
     # runs one untimed full-size pass on its own HIP stream, which makes the runtime allocate that queue's
@@ -289,10 +302,10 @@ def main():
     # one context at a time: the first dispatch on a HIP stream makes the runtime allocate that hardware queue's scratch
     # (the kernel recurses: 6 KiB of stack per lane for every wavefront slot of the device), which must not have to wait
     # for memory or wavefront slots that the persistent workgroups of five other passes are holding
-    for e, st in zip(engines, streams):
-        e.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=n, stream=st.cuda_stream)
+    for k, (e, st) in enumerate(zip(engines, raw)):
+        e.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=n, stream=st)
         e.sync()
-    raw = [st.cuda_stream for st in streams]
+        log("set-up pass %d of %d done" % (k + 1, nctx))
     log("warm-up steps")
     # rank r, step k -> case numbers ((k*world + r) * n) + 1 ... (shard.run_steps, the loop tests/test_dist_gloo.py drives too)
     strong = args.scaling == "strong"
@@ -393,10 +406,10 @@ def main():
             # boundary call a host-side consumer uses (eh_result_download into pinned memory)
             cap = int(out_bytes / args.steps * 1.5) + (1 << 30)
             try:
-                hbuf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+                hbuf = HostBuffer(cap)
                 kind = "pinned"
-            except RuntimeError:
-                hbuf = torch.empty(cap, dtype=torch.uint8)
+            except ea.EngineError:
+                hbuf = np.empty(cap, dtype=np.uint8)
                 kind = "pageable"
             e = engines[0]
             kx = args.warmup + args.steps + 100
@@ -406,7 +419,7 @@ def main():
             e.sync()
             tk = time.perf_counter()
             try:
-                off, _ = e.download_into(hbuf.data_ptr(), cap)
+                off, _ = e.download_into(hbuf.ptr if kind == "pinned" else hbuf.ctypes.data, cap)
                 td = time.perf_counter()
                 ob = int(off[-1])
                 return {"pcie_inclusive_MBps": round(ob / (td - tp) / 1e6, 1), "download_GBps": round(ob / (td - tk) / 1e9, 2), "out_bytes": ob,

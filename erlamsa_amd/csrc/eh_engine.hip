@@ -1057,6 +1057,7 @@ struct eh_ctx {
   std::vector<uint64_t> co_cancelled;                                                   // in-flight tickets nobody will poll
   std::map<uint64_t, CoResult> co_done;                                                 // downloaded, not polled yet
   hipStream_t last_stream = nullptr;
+  hipStream_t own_stream = nullptr;                     // eh_stream: a stream of the context's own (non-blocking), made on first request
   uint64_t last_n = 0, last_in_bytes = 0;
   bool have_result = false;
 };
@@ -1387,8 +1388,11 @@ int eh_create(int device, eh_ctx** out) {
   // worst chain (per-function frames from the assembler's private_seg_size expressions): kernel 192 + (MAX_NEST + 1) x
   // (muta_sgml 272 + nested_fuzz 288) = 4.1 KiB.  The runtime sizes every hardware queue's scratch for all wavefront
   // slots of the device at this size (16 KiB meant ~8 GiB per queue).
-  size_t stack_bytes = 6144;
-  if (hipDeviceSetLimit(hipLimitStackSize, stack_bytes) != hipSuccess) { delete ctx; return EH_E_HIP; }
+  size_t stack_bytes = 6144, have = 0;
+  // only ever raised, and only when it has to be: changing the limit makes the runtime re-size the scratch of queues that
+  // may already exist (another context of this process, a co-resident torch)
+  if (hipDeviceGetLimit(&have, hipLimitStackSize) != hipSuccess) have = 0;
+  if (have < stack_bytes && hipDeviceSetLimit(hipLimitStackSize, stack_bytes) != hipSuccess) { delete ctx; return EH_E_HIP; }
   uint16_t t1[65], t2[65], t3[65];
   init_tables(t1, t2, t3);
   uint32_t crct[256];
@@ -1420,6 +1424,7 @@ void eh_destroy(eh_ctx* ctx) {
   for (int k = 0; k < 2; k++) { if (ctx->d_bounce[k]) (void)hipFree(ctx->d_bounce[k]); if (ctx->ev_g[k]) (void)hipEventDestroy(ctx->ev_g[k]); if (ctx->ev_c[k]) (void)hipEventDestroy(ctx->ev_c[k]); }
   if (ctx->dl_gather) (void)hipStreamDestroy(ctx->dl_gather);
   if (ctx->dl_copy) (void)hipStreamDestroy(ctx->dl_copy);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
   if (ctx->d_out2) (void)hipFree(ctx->d_out2);
   if (ctx->d_ord) (void)hipFree(ctx->d_ord);
@@ -1681,6 +1686,31 @@ int eh_sync(eh_ctx* ctx) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->last_stream));
   return EH_OK;
 }
+
+int eh_stream(eh_ctx* ctx, void** stream) {
+  if (!ctx || !stream) return EH_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->own_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+  *stream = (void*)ctx->own_stream;
+  return EH_OK;
+}
+
+int eh_corpus_device(eh_ctx* ctx, const void** d_data, const void** d_off, uint64_t* n, uint64_t* nbytes) {
+  if (!ctx) return EH_E_INVALID;
+  if (!ctx->d_corpus) { ctx->err = "no corpus loaded"; return EH_E_STATE; }
+  if (d_data) *d_data = ctx->d_corpus;
+  if (d_off) *d_off = ctx->d_coff;
+  if (n) *n = ctx->n_corpus;
+  if (nbytes) *nbytes = ctx->corpus_bytes;
+  return EH_OK;
+}
+
+int eh_host_alloc(void** p, uint64_t bytes) {
+  if (!p) return EH_E_INVALID;
+  *p = nullptr;
+  return hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? EH_OK : EH_E_NOMEM;
+}
+void eh_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int eh_result_device(eh_ctx* ctx, const uint8_t** d_data, const uint64_t** d_off, const uint64_t** d_len, const int32_t** d_status, uint64_t* total) {
   if (!ctx) return EH_E_INVALID;

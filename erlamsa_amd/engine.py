@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ERLAMSA_HIP_LIB") or os.path.join(_HERE, "liberlamsa_hip.so")
 
-EH_ABI_VERSION = 5
+EH_ABI_VERSION = 6
 EH_FLAG_ORDERED_OUTPUT = 1
 EH_FLAG_META_TRACE = 2
 
@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
     "eh_coalesce_limits", "eh_submit", "eh_flush", "eh_poll", "eh_cancel",
+    "eh_corpus_device", "eh_stream", "eh_host_alloc", "eh_host_free",
 ]
 
 
@@ -91,6 +92,11 @@ def load_library():
     lib.eh_flush.argtypes = [vp]
     lib.eh_cancel.argtypes = [vp, C.c_uint64]
     lib.eh_poll.argtypes = [vp, C.c_uint64, vp, C.c_uint64, u64p, C.POINTER(C.c_int32)]
+    lib.eh_corpus_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), u64p, u64p]
+    lib.eh_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.eh_host_alloc.argtypes = [C.POINTER(vp), C.c_uint64]
+    lib.eh_host_free.argtypes = [vp]
+    lib.eh_host_free.restype = None
     lib.eh_kernel_name.restype = C.c_char_p
     lib.eh_abi_version.restype = C.c_uint32
     for f in ("eh_mutator_name", "eh_pattern_name", "eh_strerror"):
@@ -181,6 +187,24 @@ class Engine:
         """d_*_ptr: raw device addresses (e.g. torch tensor .data_ptr())."""
         self._chk(self.lib.eh_corpus_attach(self.h, C.c_void_p(d_data_ptr), C.c_void_p(d_off_ptr), n, nbytes))
         self.n_corpus = n
+
+    def corpus_device(self):
+        """-> (d_data address, d_off address, n, nbytes) of the loaded corpus (eh_corpus_device)"""
+        d, o, n, nb = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.eh_corpus_device(self.h, C.byref(d), C.byref(o), C.byref(n), C.byref(nb)))
+        return d.value, o.value, n.value, nb.value
+
+    def share_corpus(self, other):
+        """this context reads the corpus `other` holds (same device); `other` must outlive it"""
+        d, o, n, nb = other.corpus_device()
+        self.attach_corpus(d, o, n, nb)
+        self._keep.append(other)
+
+    def own_stream(self):
+        """raw handle of the context's own HIP stream (eh_stream); 0 on the CPU emulator (the null stream)"""
+        s = C.c_void_p()
+        self._chk(self.lib.eh_stream(self.h, C.byref(s)))
+        return s.value or 0
 
     def fuzz_batch(self, seed=(1, 2, 3), first_case=1, corpus_first=0, n=None, stream=0):
         if n is None:
@@ -376,3 +400,28 @@ class Engine:
         tot = C.c_uint64()
         self._chk(self.lib.eh_result_device(self.h, C.byref(d), C.byref(o), C.byref(l), C.byref(s), C.byref(tot)))
         return d.value, o.value, l.value, s.value, tot.value
+
+
+class HostBuffer:
+    """page-locked host memory from the library (eh_host_alloc): .ptr, .size, .array (uint8 numpy view)"""
+
+    def __init__(self, size):
+        self.lib = load_library()
+        p = C.c_void_p()
+        rc = self.lib.eh_host_alloc(C.byref(p), size)
+        if rc != 0:
+            raise EngineError(rc, self.lib.eh_strerror(rc).decode())
+        self.ptr, self.size = p.value, size
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(size, 1),))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.lib.eh_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EH_ABI_VERSION 5
+#define EH_ABI_VERSION 6
 
 typedef struct eh_ctx eh_ctx;
 
@@ -124,6 +124,20 @@ int eh_corpus_upload(eh_ctx* ctx, const uint8_t* data, const uint64_t* off, uint
 /* Same, but both arrays already live in this device's memory (e.g. after an RCCL
  * broadcast); the engine does not take ownership. */
 int eh_corpus_attach(eh_ctx* ctx, const void* d_data, const void* d_off, uint64_t n, uint64_t nbytes);
+
+/* Device-side view of the loaded corpus (after eh_corpus_upload / eh_corpus_attach): lets further contexts of the same
+ * device share one arena (eh_corpus_attach on them) instead of holding a copy each.  Any pointer may be NULL. */
+int eh_corpus_device(eh_ctx* ctx, const void** d_data, const void** d_off, uint64_t* n, uint64_t* nbytes);
+
+/* A HIP stream owned by the context (non-blocking, made on first request, destroyed with the context): pass it as the
+ * `stream` of eh_fuzz_batch / eh_fuzz_calls to run the batches of several contexts side by side without the host
+ * needing a HIP binding of its own (the BEAM has none: erlang/c_src uses this; so does bench.py). */
+int eh_stream(eh_ctx* ctx, void** stream);
+
+/* Page-locked host memory for eh_result_download / eh_corpus_upload at the full PCIe rate (hipHostMalloc / hipHostFree);
+ * for hosts without a HIP binding. */
+int eh_host_alloc(void** p, uint64_t bytes);
+void eh_host_free(void* p);
 
 /* Allocates all device memory batches of up to `max_cases` cases will need (result arrays, per-slot work
  * areas, output arena sized from eh_options.out_capacity or 8 x corpus bytes + 2 GiB), so that later

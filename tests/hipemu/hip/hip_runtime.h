@@ -247,6 +247,7 @@ inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 enum hipLimit_t { hipLimitStackSize = 0 };
 inline hipError_t hipDeviceSetLimit(hipLimit_t, size_t) { return hipSuccess; }   // fibers have 1 MiB stacks
+inline hipError_t hipDeviceGetLimit(size_t* v, hipLimit_t) { *v = (size_t)1 << 20; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu (CPU wavefront emulator)"); strcpy(p->gcnArchName, "hipemu");
   p->multiProcessorCount = 1; p->totalGlobalMem = (size_t)8 << 30;
@@ -263,6 +264,7 @@ template <class T> inline hipError_t hipMalloc(T** p, size_t n) {
   *p = (T*)((char*)q + HIPEMU_GUARD); HIPEMU_RACE_CALL(hipemu_race_region((char*)q + HIPEMU_GUARD, n ? n : 256, 1)); return hipSuccess;
 }
 inline hipError_t hipFree(void* p) { if (!p) return hipSuccess; HIPEMU_RACE_CALL(hipemu_race_region(p, 0, 0)); free((char*)p - HIPEMU_GUARD); return hipSuccess; }
+#define hipHostMallocDefault 0
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }

@@ -1,7 +1,6 @@
-"""bench.py itself, end to end, on the CPU wavefront emulator (EH_BENCH_DRY=1: the arena is a CPU tensor, streams are the null
-stream): the step loop, the roofline arithmetic, the parity leg against the oracle (the bench fails unless its sample agrees), the
-PCIe and work-budget legs, the JSON line - for the driver's configuration shape and for `--config 5` (counter-hash corpus written
-by torch, generator jump over the whole arena, strong scaling).  Sizes are tiny; the numbers mean nothing, the code paths do."""
+"""bench.py itself, end to end, on the CPU wavefront emulator (ERLAMSA_HIP_LIB = the emulator build; a single-GPU run uses no torch:
+corpus through eh_corpus_upload, the contexts' own streams - the null stream on the emulator): the step loop, the roofline arithmetic, the parity leg against the oracle (the bench fails unless its sample agrees), the
+PCIe and work-budget legs, the JSON line - for the driver's configuration shape and for `--config 5` (counter-hash corpus, generator jump over the whole arena, strong scaling).  Sizes are tiny; the numbers mean nothing, the code paths do."""
 import json
 import os
 import subprocess

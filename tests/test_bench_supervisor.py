@@ -10,8 +10,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(sim, *args):
-    env = dict(os.environ, EH_BENCH_SIMULATE=sim)
+def _run(sim, *args, **envx):
+    env = dict(os.environ, EH_BENCH_SIMULATE=sim, **envx)
     env.pop("EH_BENCH_CHILD", None)
     env.pop("WORLD_SIZE", None)
     t0 = time.time()
@@ -35,3 +35,17 @@ def test_child_stuck_in_setup_is_replaced_by_a_frugal_one():
 def test_stuck_children_fail_instead_of_hanging():
     r, dt = _run("hang")
     assert r.returncode != 0 and dt < 60 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_crashed_child_is_repeated_as_configured(tmp_path):
+    """round 3's driver run: the child died of SIGABRT (GPU memory access fault) before its set-up passes and the bench printed nothing"""
+    r, dt = _run("crash_once", EH_BENCH_SIMULATE_FLAG=str(tmp_path / "crashed"))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1 and json.loads(lines[0])["inflight"] == 6
+    assert "child ended without a result" in r.stderr and "last stage: corpus (simulated)" in r.stderr and "repeating as configured" in r.stderr
+
+
+def test_children_that_always_crash_fail_with_the_stage_named():
+    r, dt = _run("crash")
+    assert r.returncode != 0 and dt < 60 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.stderr.count("child ended without a result") == 4 and "--inflight 1" in r.stderr

@@ -1,0 +1,148 @@
+"""GPU tests added in round 4 (they sort behind the earlier files): bench.py itself on the real device, the file sink, the ABI-6
+additions (context-owned streams, a corpus shared by several contexts, pinned host memory), the engine in a process where torch
+initialised the HIP runtime first, and the reference's eunit properties run against the ENGINE."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _engine_env():
+    env = dict(os.environ)
+    for k in ("EH_BENCH_CHILD", "EH_BENCH_SIMULATE", "EH_BENCH_DRY", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_script_on_the_device():
+    """The driver's command with fewer steps: `python bench.py --gpus 1 --steps 2 --warmup 1` as a subprocess on the real device
+    (round 3's driver run of it died before its set-up passes and printed nothing).  The line must be BASELINE configs[2] and
+    carry roofline, cpu_baseline and a parity count."""
+    if util.priming():
+        pytest.skip("no oracle cache involved")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--budget-mib", "0"],
+                       env=_engine_env(), capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["config"]["workload"].startswith("BASELINE configs[2]") and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["value"] > 1000 and d["unit"] == "MB/s" and d["vs_baseline"] is None
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["kernel"] == "eh_mutate_kernel" and rf["kernel_ms_avg"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert d["parity_checked"] > 1900                                   # cases 1..2048 against the oracle, bit for bit
+    assert "child ended without a result" not in r.stderr and "child killed" not in r.stderr
+
+
+def test_file_sink_on_the_device(tmp_path):
+    """SURVEY §8(f)-3, erlamsa_out.erl:103-123 (`-o "name-%n.ext"`): eh_result_write_files on the GPU - every "%n" of the template
+    is the case number (build_name/3), one file per EH_CASE_OK case holding exactly that case's output, other statuses leave
+    no file and are counted, an unopenable path is an error (not a crash)."""
+    if util.priming():
+        pytest.skip("no oracle involved")
+    import erlamsa_amd as ea
+    from erlamsa_amd import synth
+    mat = synth.mixed(300, 1024, seed=41)
+    e = ea.Engine(0)
+    e.configure(max_case_bytes=1 << 20, big_case_bytes=1 << 20)       # default tables; a small cap so that some cases end as EH_CASE_OVERFLOW
+    e.upload_corpus(*synth.as_arena(mat))
+    e.fuzz_batch(seed=(9, 8, 7), first_case=101)
+    got, st = e.download()
+    nf, nb, ns = e.write_files(str(tmp_path / "case-%n-of-%n.bin"), first_number=101, threads=4)
+    ok = [i for i in range(len(got)) if st[i] == 0]
+    assert len(ok) >= 250 and nf == len(ok) and ns == len(got) - len(ok) and nb == sum(len(got[i]) for i in ok)
+    for i in ok:
+        with open(tmp_path / ("case-%d-of-%d.bin" % (101 + i, 101 + i)), "rb") as fh:
+            assert fh.read() == got[i], i
+    assert len(os.listdir(tmp_path)) == nf
+    with pytest.raises(ea.EngineError) as ei:
+        e.write_files(str(tmp_path / "no-such-dir" / "x-%n"))
+    assert ei.value.code == -1
+    nf2, _, _ = e.write_files(str(tmp_path / "plain.bin"), threads=1)   # no "%n": every case writes the same name (the reference does too)
+    assert nf2 == len(ok) and (tmp_path / "plain.bin").exists()
+    e.close()
+
+
+def test_own_streams_shared_corpus_and_pinned_download():
+    """ABI 6: three contexts read ONE uploaded arena (eh_corpus_device + eh_corpus_attach), run different case ranges side by side
+    on their own streams (eh_stream) and download into eh_host_alloc memory; every result equals the one a lone context gives
+    on the null stream."""
+    if util.priming():
+        pytest.skip("no oracle involved")
+    import erlamsa_amd as ea
+    from erlamsa_amd import synth
+    from erlamsa_amd.engine import HostBuffer
+    mat = synth.mixed(1536, 512, seed=5)
+    data, off = synth.as_arena(mat)
+    ref = ea.Engine(0)
+    ref.configure()
+    ref.upload_corpus(data, off)
+    ref.fuzz_batch(seed=(3, 1, 4), first_case=1)
+    want, wst = ref.download()
+    es = [ea.Engine(0) for _ in range(3)]
+    for e in es:
+        e.configure()
+    es[0].upload_corpus(data, off)
+    for e in es[1:]:
+        e.share_corpus(es[0])
+    streams = [e.own_stream() for e in es]
+    assert all(streams) and len(set(streams)) == 3
+    for k, e in enumerate(es):                                         # all three in flight before the first is collected
+        e.fuzz_batch(seed=(3, 1, 4), first_case=512 * k + 1, corpus_first=512 * k, n=512, stream=streams[k])
+    for k, e in enumerate(es):
+        _, total, _ = e.totals()
+        hb = HostBuffer(max(total, 1))
+        offk, stk = e.download_into(hb.ptr, hb.size)
+        blob = hb.array[:total].tobytes()
+        for i in range(512):
+            assert int(stk[i]) == int(wst[512 * k + i]) and blob[int(offk[i]):int(offk[i + 1])] == want[512 * k + i], (k, i)
+        hb.free()
+    for e in es[::-1]:
+        e.close()
+    ref.close()
+
+
+def test_engine_in_a_process_where_torch_came_first():
+    """The multi-GPU bench imports torch (the RCCL binding) before the engine; no driver-run test did.  A child process: torch
+    initialises the HIP runtime and launches kernels, then the engine runs the smoke batch and must give the bytes a torch-free
+    process gives."""
+    if util.priming():
+        pytest.skip("no oracle involved")
+    code = r'''
+import hashlib, sys
+sys.path.insert(0, %r)
+if sys.argv[1] == "torch":
+    import torch
+    x = torch.arange(1 << 20, device="cuda") * 3
+    torch.cuda.synchronize()
+import erlamsa_amd as ea
+from erlamsa_amd import synth
+ins = [bytes(r) for r in synth.mixed(256, 1024, seed=77)]
+outs, st = ea.fuzz_batch(ins, {"seed": (5, 6, 7)}, return_status=True)
+if sys.argv[1] == "torch":
+    y = (x + 1).sum().item()
+    e = ea.Engine(0); e.configure(); e.upload_corpus(*synth.as_arena(synth.mixed(256, 1024, seed=77)))
+    s = torch.cuda.Stream()
+    e.fuzz_batch(seed=(5, 6, 7), stream=s.cuda_stream)               # on a torch stream, as INTEGRATION.md says a host may
+    o2, _ = e.download()
+    assert o2 == outs
+h = hashlib.sha1()
+for o in outs: h.update(len(o).to_bytes(8, "little")); h.update(o)
+print("DIGEST", h.hexdigest(), sum(map(int, st)))
+''' % ROOT
+    digs = []
+    for mode in ("plain", "torch"):
+        r = subprocess.run([sys.executable, "-c", code, mode], env=_engine_env(), capture_output=True, text=True, timeout=600)
+        ln = [x for x in r.stdout.splitlines() if x.startswith("DIGEST")]
+        assert r.returncode == 0 and ln, (mode, r.stdout[-800:], r.stderr[-2000:])
+        digs.append(ln[0])
+    assert digs[0] == digs[1]
