@@ -1979,6 +1979,15 @@ int eh_selftest_zlib(eh_ctx* ctx, int op, const uint8_t* in, uint64_t n, uint8_t
   *out_len = r[0]; *ok = (int32_t)r[1];
   return EH_OK;
 }
+int eh_selftest_sort_by_priority(const uint32_t* pri, uint32_t n, uint32_t* perm) {
+  if ((!pri || !perm) && n) return EH_E_INVALID;
+  PL in;
+  for (uint32_t i = 0; i < n; i++) in.push_back(PItem{pri[i], (int)i});
+  PL out = otp_sort_desc_strict(in);
+  for (uint32_t i = 0; i < n; i++) perm[i] = (uint32_t)out[i].id;
+  return EH_OK;
+}
+
 int eh_pool_stats(eh_ctx* ctx, uint64_t* out /* 64 values */) {
   if (!ctx || !out) return EH_E_INVALID;
   if (!ctx->pool) { ctx->err = "no work-area pool yet (eh_reserve or a first batch creates it)"; return EH_E_STATE; }

@@ -30,7 +30,7 @@ namespace eh {
 struct FNode { uint32_t fo, fc, to, tc; };
 // big-node path: [0,256) source count -> cursor, [256,512) target, [512,768) child index of the bin, [768,1024) flags
 #ifndef EH_FUSE_LDS_WORDS
-#define EH_FUSE_LDS_WORDS 4096
+#define EH_FUSE_LDS_WORDS 4800
 #endif
 EH_LDS_ARRAY(uint32_t, g_fuse_lds, EH_FUSE_LDS_WORDS);     // (eh_fuse2.h: bitmaps of <= EH_FUSE_LDS_WORDS / 8 nodes)
 
@@ -65,6 +65,9 @@ EH_DEV uint64_t wave_sum64(uint64_t v) {
   for (int d = 32; d > 0; d >>= 1) v += ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, d);
   return uni64(v);
 }
+}  // namespace eh
+#include "eh_fuse_lds.h"
+namespace eh {
 #define FUSE_UNROLL 4
 struct FuseGen { FNode* nd; uint32_t* F; uint32_t* T; };
 
@@ -344,7 +347,9 @@ __device__ __noinline__ bool fuse_lists(Ctx&, const uint8_t* A, uint32_t la, con
   EH_PT0;
   uint32_t from = la, tpos = lb;
   uint32_t prof_rounds = 0;
-  if ((uint64_t)la + lb >= c.p->fuse_stream_min) {                 // large lists: position-indexed refinement (eh_fuse2.h)
+  if ((sym ? (uint64_t)la : (uint64_t)la + lb) <= FL_NMAX && !(c.p->flags & EH_FLAG_FUSE_NO_LDS)) {     // small lists: sorted suffix entries in LDS (eh_fuse_lds.h)
+    if (!fuse_jump_lds(c, A, la, B, lb, sym, &from, &tpos, &prof_rounds)) { if (c.status == CASE_BUDGET) c.ws_used = mark; return false; }
+  } else if ((uint64_t)la + lb >= c.p->fuse_stream_min) {          // large lists: position-indexed refinement (eh_fuse2.h)
     if (!fuse_jump_stream(c, A, la, B, lb, sym, &from, &tpos, &prof_rounds)) { if (c.status == CASE_BUDGET) c.ws_used = mark; return false; }
   } else {
     FuseGen g[2];

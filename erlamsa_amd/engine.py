@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("ERLAMSA_HIP_LIB") or os.path.join(_HERE, "liberlamsa_
 EH_ABI_VERSION = 6
 EH_FLAG_ORDERED_OUTPUT = 1
 EH_FLAG_META_TRACE = 2
+EH_FLAG_FUSE_NO_LDS = 4
 
 CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BUDGET = 0, 1, 2, 3, 4, 5
 
@@ -26,7 +27,7 @@ ABI_SYMBOLS = [
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
     "eh_coalesce_limits", "eh_submit", "eh_flush", "eh_poll", "eh_cancel",
-    "eh_corpus_device", "eh_stream", "eh_host_alloc", "eh_host_free",
+    "eh_corpus_device", "eh_stream", "eh_host_alloc", "eh_host_free", "eh_selftest_sort_by_priority",
 ]
 
 
@@ -97,6 +98,7 @@ def load_library():
     lib.eh_host_alloc.argtypes = [C.POINTER(vp), C.c_uint64]
     lib.eh_host_free.argtypes = [vp]
     lib.eh_host_free.restype = None
+    lib.eh_selftest_sort_by_priority.argtypes = [vp, C.c_uint32, vp]
     lib.eh_kernel_name.restype = C.c_char_p
     lib.eh_abi_version.restype = C.c_uint32
     for f in ("eh_mutator_name", "eh_pattern_name", "eh_strerror"):
@@ -118,6 +120,16 @@ def pattern_table():
     lib = load_library()
     return [(lib.eh_pattern_name(i).decode(), lib.eh_pattern_default_pri(i), bool(lib.eh_pattern_on_gpu(i)))
             for i in range(lib.eh_pattern_count())]
+
+
+def sort_by_priority(pris):
+    """the engine's host-side erlamsa_utils:sort_by_priority/1 (a self-test hook): positions of `pris` in sorted order"""
+    p = np.ascontiguousarray(pris, dtype=np.uint32)
+    perm = np.zeros(max(len(p), 1), dtype=np.uint32)
+    rc = load_library().eh_selftest_sort_by_priority(p.ctypes.data, len(p), perm.ctypes.data)
+    if rc != 0:
+        raise EngineError(rc, "eh_selftest_sort_by_priority")
+    return [int(x) for x in perm[:len(p)]]
 
 
 def gpu_mutators():

@@ -111,6 +111,8 @@ typedef struct eh_options {
 
 #define EH_FLAG_ORDERED_OUTPUT 1u /* compact the output arena into case order after the batch */
 #define EH_FLAG_META_TRACE 2u     /* keep every case's meta trace (eh_result_meta) */
+#define EH_FLAG_FUSE_NO_LDS 4u    /* diagnostic: erlamsa_fuse:fuse/2 on small lists runs as the node-list refinement (csrc/eh_fuse.h)
+                                     instead of the LDS-resident one (csrc/eh_fuse_lds.h); results are identical */
 
 /* One context = one HIP device, its result buffers and slots.  eh_create sets the DEVICE's stack limit (hipLimitStackSize, 6 KiB per
  * lane: the kernel recurses for nested scheduler calls) - a process-wide setting other HIP users of the same device (e.g. a
@@ -230,6 +232,11 @@ int eh_selftest_movers(eh_ctx* ctx, uint8_t* buf, uint64_t buf_len, const uint32
  * deflateInit(Z, default), 4 zlib:gunzip/1, 5 zlib:inflate/2 without inflateEnd (a stream that just stops yields what was decoded).
  * *ok = 0 where the reference's call raises (data_error, need_dictionary) or `cap` is too small. */
 int eh_selftest_zlib(eh_ctx* ctx, int op, const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len, int32_t* ok);
+
+/* Host-side self test: erlamsa_utils:sort_by_priority/1 (erlamsa_utils.erl:113-117: lists:sort/2 with a strict '>') as the
+ * engine's set-up orders patterns, generators and mutators - perm[k] = index of the k-th entry of the sorted list.  The oracle
+ * and tests/pymodel.py carry their own restatements of OTP's merge sort; tests/test_oracle_otp.py diffs the three. */
+int eh_selftest_sort_by_priority(const uint32_t* pri, uint32_t n, uint32_t* perm);
 
 /* Work-area pool of this context's device (diagnostic), 64 values; t = tier 1 .. out[40]: out[2t] / out[2t+1] = areas
  * of tier t taken / returned since the pool was made (+ the tier's size for the latter), out[20+t] = shader-clock ticks

@@ -15,6 +15,8 @@
 // the reference's own tests (erlamsa_mutations_test.erl) pin no byte-exact
 // vectors (they seed from now()).  See DESIGN.md "Oracle".
 #pragma once
+#include <memory>
+#include <functional>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -63,11 +65,119 @@ struct Random {
   }
 };
 
-// lists:sort/2: the single implementation lives with the engine's host code (the engine may not include oracle/,
-// the oracle may include the engine's header).
-}  // namespace otp
-#include "../erlamsa_amd/csrc/eh_otp_sort.h"
-namespace otp {
+// ---------------------------------------------------------------------------
+// lists:sort/2 — stdlib lists.erl, the oracle's OWN restatement (the engine's host set-up has another one, written
+// independently over index cursors: erlamsa_amd/csrc/eh_otp_sort.h; tests/test_oracle_otp.py diffs the two and the third
+// one in tests/pymodel.py on every priority list of up to 7 entries and on random ones).  erlamsa_utils:sort_by_priority/1
+// (erlamsa_utils.erl:113-117) passes a strict '>' — not a total "=<" — so the order among equal priorities is whatever
+// this exact merge sort does with it.  Clause for clause over immutable cons lists, as the Erlang reads:
+//   sort/2, fsplit_1, fsplit_1_1, fsplit_2, fsplit_2_1, fmergel, rfmergel, fmerge2_1/_2, rfmerge2_1/_2.
+// ---------------------------------------------------------------------------
+template <class T>
+class ListsSort {
+  struct Cell; using P = std::shared_ptr<const Cell>;
+  struct Cell { T hd; P tl; };
+  struct LCell; using PL = std::shared_ptr<const LCell>;       // a list of lists
+  struct LCell { P hd; PL tl; };
+  using F = std::function<bool(const T&, const T&)>;
+  F fun;
+  static P cons(const T& h, P t) { return std::make_shared<const Cell>(Cell{h, std::move(t)}); }
+  static PL lcons(P h, PL t) { return std::make_shared<const LCell>(LCell{std::move(h), std::move(t)}); }
+  static P reverse(P l, P tail) { while (l) { tail = cons(l->hd, tail); l = l->tl; } return tail; }   // lists:reverse/2
+  enum Ord { asc, desc };
+
+  // fmerge2_1([H1|T1], H2, Fun, T2, M) / fmerge2_2(H1, T1, Fun, [H2|T2], M): elements of the first list are prioritised
+  P fmerge2_1(P l1, const T& h2, P t2, P m) {
+    for (;;) {
+      if (!l1) return reverse(t2, cons(h2, m));                                   // fmerge2_1([], H2, _, T2, M)
+      if (fun(l1->hd, h2)) { m = cons(l1->hd, m); l1 = l1->tl; continue; }        // true -> fmerge2_1(T1, H2, Fun, T2, [H1|M])
+      return fmerge2_2(l1->hd, l1->tl, t2, cons(h2, m));                          // false -> fmerge2_2(H1, T1, Fun, T2, [H2|M])
+    }
+  }
+  P fmerge2_2(const T& h1, P t1, P l2, P m) {
+    for (;;) {
+      if (!l2) return reverse(t1, cons(h1, m));                                   // fmerge2_2(H1, T1, _, [], M)
+      if (fun(h1, l2->hd)) return fmerge2_1(t1, l2->hd, l2->tl, cons(h1, m));     // true -> fmerge2_1(T1, H2, Fun, T2, [H1|M])
+      m = cons(l2->hd, m); l2 = l2->tl;                                           // false -> fmerge2_2(H1, T1, Fun, T2, [H2|M])
+    }
+  }
+  P rfmerge2_1(P l1, const T& h2, P t2, P m) {
+    for (;;) {
+      if (!l1) return reverse(t2, cons(h2, m));
+      if (fun(l1->hd, h2)) return rfmerge2_2(l1->hd, l1->tl, t2, cons(h2, m));    // true -> rfmerge2_2(H1, T1, Fun, T2, [H2|M])
+      m = cons(l1->hd, m); l1 = l1->tl;                                           // false -> rfmerge2_1(T1, H2, Fun, T2, [H1|M])
+    }
+  }
+  P rfmerge2_2(const T& h1, P t1, P l2, P m) {
+    for (;;) {
+      if (!l2) return reverse(t1, cons(h1, m));
+      if (fun(h1, l2->hd)) { m = cons(l2->hd, m); l2 = l2->tl; continue; }        // true -> rfmerge2_2(H1, T1, Fun, T2, [H2|M])
+      return rfmerge2_1(t1, l2->hd, l2->tl, cons(h1, m));                         // false -> rfmerge2_1(T1, H2, Fun, T2, [H1|M])
+    }
+  }
+  P fmergel(PL l, PL acc, Ord o) {
+    for (;;) {
+      if (l && l->tl) {
+        P a = l->hd, b = l->tl->hd; PL rest = l->tl->tl;
+        // asc: fmergel([T1, [H2|T2] | L]) ; desc: fmergel([[H2|T2], T1 | L])  -> [fmerge2_1(T1, H2, Fun, T2, []) | Acc]
+        P t1 = o == asc ? a : b, l2 = o == asc ? b : a;
+        acc = lcons(fmerge2_1(t1, l2->hd, l2->tl, nullptr), acc); l = rest; continue;
+      }
+      if (l && !acc) return l->hd;                                                 // fmergel([L], [], _, _) -> L
+      if (l) return rfmergel(lcons(reverse(l->hd, nullptr), acc), nullptr, o);     // fmergel([L], Acc, Fun, O)
+      return rfmergel(acc, nullptr, o);                                            // fmergel([], Acc, Fun, O)
+    }
+  }
+  P rfmergel(PL l, PL acc, Ord o) {
+    for (;;) {
+      if (l && l->tl) {
+        P a = l->hd, b = l->tl->hd; PL rest = l->tl->tl;
+        // asc: rfmergel([[H2|T2], T1 | L]) ; desc: rfmergel([T1, [H2|T2] | L]) -> [rfmerge2_1(T1, H2, Fun, T2, []) | Acc]
+        P t1 = o == asc ? b : a, l2 = o == asc ? a : b;
+        acc = lcons(rfmerge2_1(t1, l2->hd, l2->tl, nullptr), acc); l = rest; continue;
+      }
+      if (l) return fmergel(lcons(reverse(l->hd, nullptr), acc), nullptr, o);      // rfmergel([L], Acc, Fun, O)
+      return fmergel(acc, nullptr, o);                                             // rfmergel([], Acc, Fun, O)
+    }
+  }
+  // fsplit_1 / fsplit_1_1 (ascending runs; inv = false) and fsplit_2 / fsplit_2_1 (descending; every test negated)
+  P fsplit(bool inv, T y, T x, P l, P r, PL rs) {
+    auto t = [&](const T& a, const T& b) { return fun(a, b) != inv; };
+    for (;;) {
+      if (!l) { PL all = lcons(cons(y, cons(x, r)), rs); return inv ? fmergel(all, nullptr, desc) : rfmergel(all, nullptr, asc); }
+      const T z = l->hd; l = l->tl;
+      if (t(y, z)) { r = cons(x, r); x = y; y = z; continue; }                     // fsplit_1(Z, Y, Fun, L, [X|R], Rs)
+      if (t(x, z)) { r = cons(x, r); x = z; continue; }                            // fsplit_1(Y, Z, Fun, L, [X|R], Rs)
+      if (!r) { r = cons(z, nullptr); continue; }                                  // when R == [] -> fsplit_1(Y, X, Fun, L, [Z], Rs)
+      return fsplit_x_1(inv, y, x, l, r, rs, z);                                   // fsplit_1_1(Y, X, Fun, L, R, Rs, Z)
+    }
+  }
+  P fsplit_x_1(bool inv, T y, T x, P l, P r, PL rs, T s) {
+    auto t = [&](const T& a, const T& b) { return fun(a, b) != inv; };
+    for (;;) {
+      if (!l) { PL all = lcons(cons(s, nullptr), lcons(cons(y, cons(x, r)), rs)); return inv ? fmergel(all, nullptr, desc) : rfmergel(all, nullptr, asc); }
+      const T z = l->hd; l = l->tl;
+      if (t(y, z)) { r = cons(x, r); x = y; y = z; continue; }
+      if (t(x, z)) { r = cons(x, r); x = z; continue; }
+      PL rs2 = lcons(cons(y, cons(x, r)), rs);
+      if (t(s, z)) return fsplit(inv, z, s, l, nullptr, rs2);                      // fsplit_1(Z, S, Fun, L, [], [[Y, X | R] | Rs])
+      return fsplit(inv, s, z, l, nullptr, rs2);                                   // fsplit_1(S, Z, Fun, L, [], [[Y, X | R] | Rs])
+    }
+  }
+
+ public:
+  explicit ListsSort(F f) : fun(std::move(f)) {}
+  std::vector<T> sort(const std::vector<T>& in) {                                  // sort/2
+    if (in.size() < 2) return in;
+    P l = nullptr;
+    for (size_t i = in.size(); i-- > 2;) l = cons(in[i], l);
+    const T &x = in[0], &y = in[1];
+    P res = fun(x, y) ? fsplit(false, y, x, l, nullptr, nullptr) : fsplit(true, y, x, l, nullptr, nullptr);
+    std::vector<T> out;
+    for (; res; res = res->tl) out.push_back(res->hd);
+    return out;
+  }
+};
 
 // ---------------------------------------------------------------------------
 // erlang:crc32/1 — zlib CRC-32 (reflected 0xEDB88320, init/xorout 0xFFFFFFFF)

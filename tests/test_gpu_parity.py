@@ -12,12 +12,17 @@ SEQ = "sp,sr,sd,snand,srnd"
 
 
 def _compare(inputs, mutations, patterns, seed=(1, 2, 3), generators=None, first_case=1, max_report=5, max_skipped=0.015,
-             oracle_cap=8 << 20, engine_cap=0, work=0):
+             oracle_cap=8 << 20, engine_cap=0, work=0, live=False):
+    """live=True: the oracle runs here and now on the host's threads (util.oracle_live) instead of through the digest cache that
+    travels with the tree - the tests of the default tables and of the bench workload do, so that their green means "engine ==
+    the oracle as built on this box", not "engine == bytes hashed elsewhere"."""
     import pyoracle as po
     data, off = po.pack(inputs)
     okw = dict(seed=seed, mutations=mutations, patterns=patterns, generators=generators, first_case=first_case,
                max_case_bytes=oracle_cap, max_case_work=work)
-    ora = util.oracle_batch(data, off, **okw)
+    if live and util.priming():
+        pytest.skip("live oracle: nothing to prime")
+    ora = util.oracle_live(data, off, **okw) if live else util.oracle_batch(data, off, **okw)
     assert not (ora.status == 3).any(), "the oracle says UNSUPPORTED for an input that is not a zip archive"
     if util.priming():
         pytest.skip("oracle cache primed")
@@ -214,7 +219,7 @@ def test_b64_nested_default_table():
 def test_default_tables(kind):
     """eh_options.mutations = patterns = NULL: the reference's full default tables (41 mutators, 10 patterns)."""
     inputs = _docs(240, 3) if kind == "docs" else _texty(150, 1200, 6)
-    _compare(inputs, None, None, seed=(3, 4, 5), max_skipped=0.045, oracle_cap=4 << 20, engine_cap=4 << 20)
+    _compare(inputs, None, None, seed=(3, 4, 5), max_skipped=0.045, oracle_cap=4 << 20, engine_cap=4 << 20, live=True)
 
 
 TREES = "tr2,td,ts1,ts2,tr"
@@ -333,8 +338,20 @@ def test_bench_workload_full_table_vs_oracle():
             bad.append((i, "len %d vs %d, draws %d vs %d" % (lens[i], z["lens"][k], draws[i], z["draws"][k])))
         elif hashlib.sha1(eng.fetch(i, int(lens[i]))).digest() != z["sha1"][k].tobytes():
             bad.append((i, "bytes differ (len %d)" % lens[i]))
+    # ... and LIVE: rows 0..2047 through the oracle as built on this box, on the host's threads (no golden file, no digest cache)
+    m = 2048
+    ora = util.oracle_live(data[:m * 4096], off[:m + 1], seed=(1, 2, 3), patterns="od,nd,bu", max_case_bytes=1 << 30, max_case_seconds=20.0)
+    nlive = 0
+    for i in range(m):
+        if st[i] in (2, 3) or ora.status[i] in (2, 3, 6):
+            continue
+        nlive += 1
+        if int(st[i]) != int(ora.status[i]) or int(lens[i]) != len(ora.outs[i]) or (st[i] == 0 and int(draws[i]) != int(ora.draws[i])) \
+                or eng.fetch(i, int(lens[i])) != ora.outs[i]:
+            bad.append((i, "differs from the live oracle run"))
     eng.close()
-    assert not bad, "%d of %d cases differ from the oracle: %s" % (len(bad), len(z["idx"]), bad[:8])
+    assert nlive >= m - 16, "only %d of %d cases could be compared with the live oracle run" % (nlive, m)
+    assert not bad, "%d of %d cases differ from the oracle: %s" % (len(bad), len(z["idx"]) + m, bad[:8])
 
 
 def test_results_do_not_depend_on_slot_count_or_batch_cut():

@@ -59,3 +59,26 @@ def test_crc32_and_base64_match_python():
     data = b"aGVsbG8gd29ybGQh"   # "hello world!"
     assert base64.b64decode(data) == b"hello world!"
     assert zlib.crc32(b"123456789") == 0xCBF43926
+
+
+def test_three_restatements_of_lists_sort_agree():
+    """lists:sort/2 exists three times, written independently: the oracle's (oracle/otp_compat.h, cons lists, clause for clause),
+    the engine's host set-up (erlamsa_amd/csrc/eh_otp_sort.h, index cursors) and tests/pymodel.py's.  Every priority list of up to
+    7 entries over {0, 1, 2, 3} and 3 000 random ones of up to 45 entries (the mutator table has 41) must come out the same:
+    the order among equal priorities decides every weighted choice of pattern, generator and mutator."""
+    import itertools
+    import numpy as np
+    import pymodel
+    import erlamsa_amd.engine as eng
+
+    def three(pris):
+        a = po.sort_by_priority(list(pris))
+        b = eng.sort_by_priority(list(pris))
+        c = [i for _, i in pymodel.lists_sort(lambda x, y: x[0] > y[0], [(p, i) for i, p in enumerate(pris)])]
+        assert a == b == c, (pris, a, b, c)
+    for n in range(0, 8):
+        for pris in itertools.product([0, 1, 2, 3] if n < 7 else [0, 1, 2], repeat=n):
+            three(pris)
+    rng = np.random.Generator(np.random.PCG64(11))
+    for _ in range(3000):
+        three([int(x) for x in rng.integers(0, int(rng.integers(2, 12)), size=int(rng.integers(1, 46)))])

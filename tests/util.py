@@ -155,3 +155,52 @@ def oracle_batch(data, off, live=False, **kw):
 
 def priming():
     return os.environ.get("EH_PRIME_ORACLE") == "1"
+
+
+def oracle_live(data, off, threads=0, chunk=8, **kw):
+    """The oracle run LIVE (no digest cache), cases spread over host threads in chunks of `chunk` (the ctypes call releases the
+    GIL; a case is a pure function of the run's seed, its number and its input, so a chunk is a sub-range with first_case moved).
+    On the GPU box 64 idle host cores make this cheaper than shipping digests computed elsewhere.  -> OracleResult with outputs."""
+    import threading
+    import pyoracle as po
+    po.lib()
+    n = len(off) - 1
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    threads = threads or max(1, min(os.cpu_count() or 1, 64))
+    first = kw.pop("first_case", 1)
+    seeds = kw.pop("seeds", None)
+    if kw.get("generators") and ("file" in kw["generators"] or "jump" in kw["generators"]) and kw.get("paths") is None:
+        kw["paths"] = (data, off)                                  # the Paths of file / jump: the whole corpus, whatever chunk a call runs
+    outs, st, dr, tr = [None] * n, np.zeros(n, np.int32), np.zeros(n, np.uint64), [""] * n
+    lock, nxt, errs = threading.Lock(), [0], []
+
+    def work():
+        while True:
+            with lock:
+                a = nxt[0]
+                if a >= n:
+                    return
+                nxt[0] = a + chunk
+            b = min(a + chunk, n)
+            d = data[int(off[a]):int(off[b])] if int(off[b]) > int(off[a]) else np.zeros(1, np.uint8)
+            o = off[a:b + 1] - off[a]
+            try:
+                r = po.fuzz_batch(d, o, first_case=first + a, seeds=None if seeds is None else np.asarray(seeds).reshape(-1, 3)[a:b], trace=True, **kw)
+            except Exception as ex:                                # noqa: BLE001 - reported by the caller's thread
+                errs.append(ex)
+                return
+            outs[a:b] = r[0]; st[a:b] = r[1]; dr[a:b] = r[2]
+            tl = (r[3] or "").split("\n")
+            for j in range(b - a):
+                tr[a + j] = tl[j] if j < len(tl) else ""
+    ts = [threading.Thread(target=work) for _ in range(min(threads, (n + chunk - 1) // chunk or 1))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    lens = np.array([len(x) for x in outs], dtype=np.int64)
+    dig = np.frombuffer(b"".join(hashlib.sha1(x).digest() for x in outs), dtype=np.uint8).reshape(n, 20) if n else np.zeros((0, 20), np.uint8)
+    return OracleResult(outs, lens, dig, st, dr, tr)
