@@ -266,7 +266,8 @@ struct Ctx {
   int depth;           // nesting depth of mux_fuzzers (b64 / sgm / js inner mutations re-enter the scheduler)
   int gen_pending;     // G_FILE / G_JUMP: the generator's fun has not been called yet (gen_force, eh_engine.hip); 0 = Ll is a list
   uint32_t gen_e1, gen_e2;   // the corpus entries (paths) it was made for
-  int pat_ret; uint32_t pat_ip; int pat_cont;   // results of the container patterns' helpers (cp_end / ar_step, eh_engine.hip)
+  int pat_ret; uint32_t pat_ip; int pat_cont;   // results of the container patterns' helpers (cp_end / ar_step, eh_engine.hip)  // eh_fuse_red.h: the search runs on shortened lists and only names its node (fp_on); the members are found in the originals
+  uint32_t fp_on, fp_g, fp_special, fp_keypos, fp_bA, fp_bB;
 };
 // The per-case context lives in LDS.  One workgroup is one wavefront, so there is exactly one Ctx per
 // workgroup and no synchronisation is needed.  As a stack object it was reached through generic

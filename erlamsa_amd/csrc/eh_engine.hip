@@ -1370,6 +1370,14 @@ const char* eh_strerror(int code) {
   return "unknown error";
 }
 const char* eh_last_error(eh_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+uint64_t eh_last_error_copy(eh_ctx* ctx, char* buf, uint64_t cap) {
+  if (!buf || !cap) return 0;
+  if (!ctx) { buf[0] = 0; return 0; }
+  std::lock_guard<std::recursive_mutex> g(ctx->co_lock);            // the coalescer's calls set the text under this lock
+  uint64_t n = ctx->err.size() < cap - 1 ? ctx->err.size() : cap - 1;
+  memcpy(buf, ctx->err.data(), n); buf[n] = 0;
+  return n;
+}
 
 int eh_create(int device, eh_ctx** out) {
   if (!out) return EH_E_INVALID;
@@ -1433,10 +1441,19 @@ void eh_destroy(eh_ctx* ctx) {
   delete ctx;
 }
 
+static int co_collect(eh_ctx* ctx);
 int eh_configure(eh_ctx* ctx, const eh_options* o) {
   if (!ctx || !o) return EH_E_INVALID;
   if (o->abi_version != EH_ABI_VERSION) { ctx->err = "eh_options.abi_version mismatch"; return EH_E_INVALID; }
-  CO_GUARD(ctx);
+  // Requests that are still PENDING run with the configuration in force when they are launched, so a new one is refused
+  // (eh_flush them first).  A batch that is already in flight carries its configuration with it (launch() copies it into the
+  // kernel's argument block) but owns the context's result buffers, which the next launch may re-size: it is collected first.
+  std::lock_guard<std::recursive_mutex> co_guard_(ctx->co_lock);
+  if (!ctx->co_internal && !ctx->co_tickets.empty()) {
+    ctx->err = "coalesced requests are pending on this context: eh_flush them first, or use a context of its own";
+    return EH_E_STATE;
+  }
+  if (!ctx->co_internal && ctx->co_inflight) { int rcc = co_collect(ctx); if (rcc) return rcc; }
   DevConfig cfg;
   memset(&cfg, 0, sizeof(cfg));
   std::vector<long> mp, pp;

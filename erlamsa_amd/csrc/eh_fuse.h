@@ -331,6 +331,9 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
 }
 
 __device__ bool fuse_jump_stream(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, bool sym, uint32_t* from, uint32_t* tpos, uint32_t* rounds);   // eh_fuse2.h
+}  // namespace eh
+#include "eh_fuse_red.h"
+namespace eh {
 
 // fuse(Al, Bl) -> new byte list in the work area
 #ifdef EH_FUSE_INLINE
@@ -347,6 +350,45 @@ __device__ __noinline__ bool fuse_lists(Ctx&, const uint8_t* A, uint32_t la, con
   EH_PT0;
   uint32_t from = la, tpos = lb;
   uint32_t prof_rounds = 0;
+  c.fp_on = 0;
+  if ((sym ? (uint64_t)la : (uint64_t)la + lb) > FL_NMAX && !c.work_budget && !(c.p->flags & EH_FLAG_FUSE_NO_REDUCE)) {
+    // large lists: the same search on lists with the long periodic stretches cut short (eh_fuse_red.h)
+    const uint32_t rd = fr_peek_rounds(c.rng);
+    if (rd < 64) {
+      const uint32_t R = rd + 2u;
+      uint32_t la2 = la, lb2 = lb;
+      const uint8_t* A2 = fr_reduce(c, A, &la2, R);
+      if (!A2) return false;
+      const uint8_t* B2 = A2;
+      if (sym) lb2 = la2; else { B2 = fr_reduce(c, B, &lb2, R); if (!B2) return false; }
+      if ((uint64_t)la2 + lb2 <= ((uint64_t)la + lb) / 4u * 3u) {
+        EH_PT(c, 97);                                              // eh_result_prof 97: finding + making the cuts, calls that took them; 98: calls that found none
+        c.fp_on = 1;
+        bool ok;
+        if ((sym ? (uint64_t)la2 : (uint64_t)la2 + lb2) <= FL_NMAX && !(c.p->flags & EH_FLAG_FUSE_NO_LDS)) ok = fuse_jump_lds(c, A2, la2, B2, lb2, sym, &from, &tpos, &prof_rounds);
+        else ok = fuse_jump_stream(c, A2, la2, B2, lb2, sym, &from, &tpos, &prof_rounds);
+        c.fp_on = 0;
+        if (!ok) return false;
+        // any_position_pair/1 (:73-77) over the ORIGINAL lists: the members of the node are the occurrences of its g-gram
+        const uint32_t g = c.fp_g, par = g & 1u;
+        from = la; tpos = lb;
+        if (g == 0) { from = rng_rand(c.rng, la); tpos = rng_rand(c.rng, lb); }
+        else if (c.fp_special) { (void)rng_rand(c.rng, 1); (void)rng_rand(c.rng, 1); }      // {[[]], [[]]}
+        else {
+          const uint8_t* key = A2 + c.fp_keypos;
+          const uint32_t limA = la > g ? la - g : 0u, limB = lb > g ? lb - g : 0u;
+          const uint32_t fc0 = fr_occ(A, la, limA, key, g, FR_NONE, nullptr), fc = fc0 + c.fp_bA;
+          uint32_t pos = 0;
+          if (fc > 0) { uint32_t j = rng_rand(c.rng, fc); j = par ? fc - 1u - j : j; if (j < fc0) { (void)fr_occ(A, la, limA, key, g, j, &pos); from = uni(pos) + g; } }
+          const uint32_t tc0 = sym ? fc0 : fr_occ(B, lb, limB, key, g, FR_NONE, nullptr), tc = tc0 + c.fp_bB;
+          if (tc > 0) { uint32_t j = rng_rand(c.rng, tc); j = par ? tc - 1u - j : j; if (j < tc0) { (void)fr_occ(B, lb, limB, key, g, j, &pos); tpos = uni(pos) + g; } }
+        }
+        goto jump;
+      }
+    }
+    EH_PT(c, 98);
+    c.ws_used = mark;                                              // (no cut worth it: the copies go)
+  }
   if ((sym ? (uint64_t)la : (uint64_t)la + lb) <= FL_NMAX && !(c.p->flags & EH_FLAG_FUSE_NO_LDS)) {     // small lists: sorted suffix entries in LDS (eh_fuse_lds.h)
     if (!fuse_jump_lds(c, A, la, B, lb, sym, &from, &tpos, &prof_rounds)) { if (c.status == CASE_BUDGET) c.ws_used = mark; return false; }
   } else if ((uint64_t)la + lb >= c.p->fuse_stream_min) {          // large lists: position-indexed refinement (eh_fuse2.h)
@@ -387,6 +429,7 @@ __device__ __noinline__ bool fuse_lists(Ctx&, const uint8_t* A, uint32_t la, con
     if (fc > 0) { uint32_t j = rng_rand(c.rng, fc); from = fc == 1 ? fo : uni(g[par].F[fo + (par ? fc - 1 - j : j)]); }
     if (tc > 0) { uint32_t j = rng_rand(c.rng, tc); tpos = tc == 1 ? to : uni(g[par].T[to + (par ? tc - 1 - j : j)]); }
   }
+jump:
 #ifdef EH_PROF
   {                                                                // slots 112..125: fuse calls by log2(la + lb), 126: rounds
     uint32_t tot = la + lb, b = 0; while ((256u << b) < tot && b < 13) b++;

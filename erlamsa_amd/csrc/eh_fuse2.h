@@ -529,6 +529,20 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t l
   const uint32_t par = g & 1u;
   uint32_t ni = rng_rand(c.rng, nn);
   uint32_t node = par ? nn - 1 - ni : ni;
+  if (c.fp_on) {                                                   // eh_fuse_red.h: name the node, the members come from the original lists
+    c.fp_g = g; c.fp_special = 0; c.fp_keypos = 0; c.fp_bA = 0; c.fp_bB = 0;
+    if (g == 0) return true;
+    if (node == special_node) { c.fp_special = 1; return true; }
+    const uint32_t fcn = fb_count(ids[0], la, node);
+    const uint32_t m0 = fb_find(ids[0], la, node, 0), ml = fb_find(ids[0], la, node, fcn - 1u);
+    c.fp_keypos = m0;
+    c.fp_special = (fcn == 1u && m0 + g == la) ? 1u : 0u;
+    c.fp_bA = (ml + g == la) ? 1u : 0u;
+    if (sym) c.fp_bB = c.fp_bA;
+    else { const uint32_t tcn = fb_count(ids[1], lb, node); c.fp_bB = (tcn > 0 && fb_find(ids[1], lb, node, tcn - 1u) + g == lb) ? 1u : 0u; }
+    EH_PT(c, 109);
+    return true;
+  }
   if (g == 0) {                                                    // the one node of all suffixes
     *from = rng_rand(c.rng, la);
     *tpos = rng_rand(c.rng, lb);

@@ -442,6 +442,15 @@ __device__ __noinline__ bool fuse_jump_lds(Ctx&, const uint8_t* A, uint32_t la, 
     fc = cnt;
   }
   uint32_t tc = sym ? fc : (b - a) - fc;
+  if (c.fp_on) {                                                     // eh_fuse_red.h: name the node, the members come from the original lists
+    const uint32_t e0 = uni((uint32_t)E[a]), el = uni((uint32_t)E[a + fc - 1u]);          // (fc >= 1: a node has a source entry)
+    c.fp_g = st.g; c.fp_keypos = e0;
+    c.fp_special = (fc == 1u && e0 + st.g == la) ? 1u : 0u;
+    c.fp_bA = (el + st.g == la) ? 1u : 0u;
+    c.fp_bB = sym ? c.fp_bA : ((tc > 0 && uni((uint32_t)E[b - 1u]) - la + st.g == lb) ? 1u : 0u);
+    EH_PT(c, 103);
+    return true;
+  }
   bool special_t = false;
   if (!sym && tc == 0 && a != st.ghost) { tc = 1; special_t = true; }   // {[[]], [[]]}: Tos = [[]]
   *from = la; *tpos = lb;

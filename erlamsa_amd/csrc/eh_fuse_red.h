@@ -1,0 +1,180 @@
+// eh_fuse_red.h — erlamsa_fuse:fuse/2 on LARGE lists: run the search on a shorter list that has the same nodes.
+//
+// The large blocks fuse meets are pumped ones (sr, lr, tr, sgm repeat a piece of a 4 KiB seed hundreds of times).  The search
+// (find_jump_points/2, erlamsa_fuse.erl:102-128) never looks further than R bytes into a suffix, R - 1 = the rounds its own
+// rand(8) draws allow (they do not depend on the data and can be read ahead), and what it computes per generation g <= R is
+//   * which g-grams occur on both sides (the nodes, in key order) and how many there are (the fuel, NoDesp =:= []),
+//   * what happens to the member whose rest is [] (fix_empty_list/1: is it alone in its group?) - a question about the last
+//     bytes of the list and about whether their g-gram occurs anywhere else.
+// None of this depends on HOW OFTEN a g-gram occurs.  So a stretch S[a, b) with S[k] = S[k + P] can lose whole periods from
+// its middle: cutting [u, u + D) with u >= a + P, D a multiple of P and u + D + R <= b leaves every g-gram (g <= R) of the
+// list in place (a removed position has the g-gram of its counterpart in the period before u), creates none (the bytes after
+// the cut continue the bytes before it) and leaves the last R bytes alone.  The generations of the shortened lists therefore
+// have the same node counts, in the same order, and the search draws the same node - and the members of that node in the
+// ORIGINAL lists are simply the occurrences of its g-gram (ascending positions; plus, possibly, the member whose rest is [],
+// which the shortened run reports), found by one streaming compare pass instead of g refinement passes over every position.
+// Several cuts compose (each is valid on the list the previous one left).  A list without a long periodic stretch, a run
+// with a work budget (its accounting counts list members) and runs whose draws allow 64 rounds or more go the ordinary way.
+#pragma once
+
+namespace eh {
+
+constexpr uint32_t FR_NONE = 0xFFFFFFFFu;
+constexpr uint32_t FR_MAX_PERIOD = 1u << 17;        // how far the next occurrence of an anchor's 8 bytes is looked for
+constexpr int FR_LEVELS = 4;
+
+EH_DEV uint64_t fr_ld8(const uint8_t* S, uint32_t q, uint32_t len) {      // 8 bytes from q, zero filled past the end
+  uint64_t by = 0;
+  if (q + 8 <= len) __builtin_memcpy(&by, S + q, 8);
+  else { for (uint32_t k = 0; k < 8; k++) if (q + k < len) by |= (uint64_t)S[q + k] << (8 * k); }
+  return by;
+}
+// how many rand(8) draws from now come out non-zero before the first zero (= rounds the search may run); 64: none of the next 64 is zero
+EH_DEV uint32_t fr_peek_rounds(const Rng& r) {
+  const uint32_t l = (uint32_t)EH_LANE;
+  double x = rng_peek(r, l + 1u) * 8.0;
+  unsigned long long z = __ballot((uint32_t)x == 0u);
+  return z ? (uint32_t)__builtin_ctzll(z) : 64u;
+}
+// first i >= i0 with i + p >= n or S[i] != S[i + p]
+__device__ __noinline__ uint32_t fr_run_fwd(const uint8_t* S, uint32_t i0, uint32_t p, uint32_t n) {
+  const uint32_t l = (uint32_t)EH_LANE;
+  const uint32_t lim = n - p;
+  for (uint32_t base = i0;; base += 1024) {
+    const uint32_t q = base + 16u * l;
+    uint32_t mp = FR_NONE;
+    if (q + 16 <= lim) {
+      uint4 a, b;
+      __builtin_memcpy(&a, S + q, 16); __builtin_memcpy(&b, S + q + p, 16);
+      const uint32_t x[4] = {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w};
+#pragma unroll
+      for (int k = 3; k >= 0; k--) if (x[k]) mp = q + 4u * (uint32_t)k + ((uint32_t)__builtin_ctz(x[k]) >> 3);
+    } else {
+      for (uint32_t k = 0; k < 16; k++) { if (q + k >= lim || S[q + k] != S[q + k + p]) { mp = q + k; break; } }
+    }
+    unsigned long long hit = __ballot(mp != FR_NONE);
+    if (hit) return (uint32_t)__builtin_amdgcn_readlane((int)mp, (int)__builtin_ctzll(hit));
+  }
+}
+// smallest lo <= i0 with S[k] == S[k + p] for every k in [lo, i0)   (i0 + p <= n)
+__device__ __noinline__ uint32_t fr_run_bwd(const uint8_t* S, uint32_t i0, uint32_t p) {
+  const uint32_t l = (uint32_t)EH_LANE;
+  for (uint32_t hi = i0;; hi -= 1024) {                              // lane l looks at [hi - 16 (l + 1), hi - 16 l), lane 0 the highest
+    uint32_t mp = FR_NONE;                                           // highest mismatching position of this lane
+    const uint32_t top = 16u * l < hi ? hi - 16u * l : 0u, bot = 16u * (l + 1u) < hi ? hi - 16u * (l + 1u) : 0u;
+    if (top - bot == 16u) {
+      uint4 a, b;
+      __builtin_memcpy(&a, S + bot, 16); __builtin_memcpy(&b, S + bot + p, 16);
+      const uint32_t x[4] = {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (x[k]) mp = bot + 4u * (uint32_t)k + ((31u - (uint32_t)__builtin_clz(x[k])) >> 3);
+    } else {
+      for (uint32_t k = bot; k < top; k++) if (S[k] != S[k + p]) mp = k;
+    }
+    unsigned long long hit = __ballot(mp != FR_NONE);
+    if (hit) return (uint32_t)__builtin_amdgcn_readlane((int)mp, (int)__builtin_ctzll(hit)) + 1u;
+    if (hi <= 1024) return 0;
+  }
+}
+// first y in [from, lim) with y + 8 <= n and the 8 bytes at y equal to key, FR_NONE: none
+__device__ __noinline__ uint32_t fr_find8(const uint8_t* S, uint32_t from, uint32_t lim, uint32_t n, uint64_t key) {
+  const uint32_t l = (uint32_t)EH_LANE;
+  if (n < 8) return FR_NONE;
+  if (lim > n - 7) lim = n - 7;
+  for (uint32_t base = from; base < lim; base += 256) {
+    uint64_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { uint32_t y = base + 64u * (uint32_t)u + l; v[u] = 0; if (y < lim) __builtin_memcpy(&v[u], S + y, 8); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      uint32_t y = base + 64u * (uint32_t)u + l;
+      unsigned long long hit = __ballot(y < lim && v[u] == key);
+      if (hit) return base + 64u * (uint32_t)u + (uint32_t)__builtin_ctzll(hit);
+    }
+  }
+  return FR_NONE;
+}
+// The best cut of S[0, n) for searches of at most R bytes' depth: *u, *D (bytes [u, u + D) can go); false: nothing worth it.
+// Anchors at the eighths of the list: the 8 bytes there, their next occurrences as period candidates, the stretch each holds for.
+__device__ __noinline__ bool fr_find_cut(const uint8_t* S, uint32_t n, uint32_t R, uint32_t* cu, uint32_t* cD) {
+  uint32_t bestD = 0, bestU = 0, blo = 0, bhi = 0;
+  if (n < 4096) return false;
+  for (uint32_t a = 1; a <= 7; a++) {
+    const uint32_t x = (uint32_t)(((uint64_t)n * a) >> 3);
+    if (x + 8 > n) continue;
+    if (bestD && x >= blo && x < bhi) continue;                      // inside the stretch already found
+    const uint64_t key = fr_ld8(S, x, n);
+    uint32_t y = x + 1;
+    for (int tries = 0; tries < 4; tries++) {
+      const uint32_t far = x + 1u + FR_MAX_PERIOD < n ? x + 1u + FR_MAX_PERIOD : n;
+      y = fr_find8(S, y, far, n, key);
+      if (y == FR_NONE) break;
+      const uint32_t p = y - x;
+      const uint32_t hi = fr_run_fwd(S, x, p, n), lo = fr_run_bwd(S, x, p);
+      const uint32_t u = lo + p, b = hi + p;                          // S[k] == S[k + p] on [lo, hi)
+      if (b > u + R && b - u - R >= p) {
+        const uint32_t D = (b - R - u) / p * p;
+        if (D > bestD) { bestD = D; bestU = u; blo = lo; bhi = b; }
+      }
+      if (bestD >= n / 2) break;
+      y++;
+    }
+    if (bestD >= n / 2) break;
+  }
+  if (bestD < 2048 || bestD < n / 8) return false;
+  *cu = bestU; *cD = bestD;
+  return true;
+}
+// S[0, *n) -> a shortened copy in the work area (or S itself, untouched, when no cut is worth it); *n its length.  nullptr: work area exhausted.
+__device__ __noinline__ const uint8_t* fr_reduce(Ctx&, const uint8_t* S, uint32_t* n, uint32_t R) {
+  EH_CTX;
+  uint32_t u = 0, D = 0, len = *n;
+  if (!fr_find_cut(S, len, R, &u, &D)) return S;
+  uint8_t* C = ws_alloc(c, (uint64_t)len - D + 16);
+  if (!C) return nullptr;
+  wave_copy(C, S, u);
+  wave_copy(C + u, S + u + D, len - u - D);
+  len -= D;
+  wave_sync();
+  for (int lv = 1; lv < FR_LEVELS; lv++) {
+    if (!fr_find_cut(C, len, R, &u, &D)) break;
+    wave_sync();
+    wave_move_down(C + u, C + u + D, len - u - D);
+    len -= D;
+    wave_sync();
+  }
+  *n = len;
+  return C;
+}
+// Occurrences of key[0, g) in S at positions s < lim (s + g <= len): their number; with want != FR_NONE the position of the
+// want-th one (0-based, ascending) goes to *pos and the scan stops there.
+__device__ __noinline__ uint32_t fr_occ(const uint8_t* S, uint32_t len, uint32_t lim, const uint8_t* key, uint32_t g, uint32_t want, uint32_t* pos) {
+  const uint32_t l = (uint32_t)EH_LANE;
+  uint64_t k8 = 0;
+  for (uint32_t k = 0; k < 8 && k < g; k++) k8 |= (uint64_t)key[k] << (8 * k);
+  const uint64_t mask = g >= 8 ? ~0ull : ((1ull << (8 * g)) - 1ull);
+  uint32_t seen = 0;
+  for (uint32_t base = 0; base < lim; base += 256) {
+    uint64_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { uint32_t s = base + 64u * (uint32_t)u + l; v[u] = s < lim ? fr_ld8(S, s, len) : 0; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      uint32_t s = base + 64u * (uint32_t)u + l;
+      bool m = s < lim && (v[u] & mask) == k8;
+      if (m && g > 8) { for (uint32_t k = 8; k < g; k++) if (S[s + k] != key[k]) { m = false; break; } }
+      unsigned long long hit = __ballot(m);
+      uint32_t cnt = (uint32_t)__popcll(hit);
+      if (want != FR_NONE && want < seen + cnt) {
+        uint32_t r = want - seen;
+        for (uint32_t t = 0; t < r; t++) hit &= hit - 1ull;
+        *pos = base + 64u * (uint32_t)u + (uint32_t)__builtin_ctzll(hit);
+        return seen + cnt;
+      }
+      seen += cnt;
+    }
+  }
+  return seen;
+}
+
+}  // namespace eh

@@ -16,6 +16,7 @@ EH_ABI_VERSION = 6
 EH_FLAG_ORDERED_OUTPUT = 1
 EH_FLAG_META_TRACE = 2
 EH_FLAG_FUSE_NO_LDS = 4
+EH_FLAG_FUSE_NO_REDUCE = 8
 
 CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BUDGET = 0, 1, 2, 3, 4, 5
 
@@ -27,7 +28,7 @@ ABI_SYMBOLS = [
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
     "eh_coalesce_limits", "eh_submit", "eh_flush", "eh_poll", "eh_cancel",
-    "eh_corpus_device", "eh_stream", "eh_host_alloc", "eh_host_free", "eh_selftest_sort_by_priority",
+    "eh_corpus_device", "eh_stream", "eh_host_alloc", "eh_host_free", "eh_selftest_sort_by_priority", "eh_last_error_copy",
 ]
 
 

@@ -46,8 +46,9 @@ static int load(ErlNifEnv* env, void** priv, ERL_NIF_TERM info) {
 static ERL_NIF_TERM mk_err_atom(ErlNifEnv* env, const char* a) { return enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_atom(env, a)); }
 static ERL_NIF_TERM mk_error(ErlNifEnv* env, eh_ctx* c, int rc) {
   if (rc == EH_E_NOMEM) return mk_err_atom(env, "enomem");
-  const char* msg = c ? eh_last_error(c) : eh_strerror(rc);
-  return enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_string(env, msg && *msg ? msg : eh_strerror(rc), ERL_NIF_LATIN1));
+  char msg[512]; msg[0] = 0;
+  if (c) (void)eh_last_error_copy(c, msg, sizeof(msg));              /* copied under the engine's lock: pollers run beside submitters */
+  return enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_string(env, msg[0] ? msg : eh_strerror(rc), ERL_NIF_LATIN1));
 }
 
 /* open(Device) -> {ok, Ctx} */
@@ -195,7 +196,9 @@ static ERL_NIF_TERM nif_submit(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
   enif_mutex_lock(r->lock);
   uint64_t ticket = 0;
   int rc = EH_OK;
-  if (r->configured && memcmp(&r->key, &k, sizeof(k)) != 0) rc = eh_flush(r->ctx);   /* pending requests keep the options they came with */
+  /* other options than the previous request's: what is pending is launched with the options it came with; eh_configure then
+     collects that batch (its results wait for poll_nif) before the options change */
+  if (r->configured && memcmp(&r->key, &k, sizeof(k)) != 0) rc = eh_flush(r->ctx);
   if (!rc) rc = configure_if_changed(r, &k);
   if (!rc) rc = eh_submit(r->ctx, b.data, b.size, seed, &ticket);
   ERL_NIF_TERM ret = rc ? mk_error(env, r->ctx, rc) : enif_make_tuple2(env, enif_make_atom(env, "ok"), enif_make_uint64(env, ticket));
@@ -233,10 +236,10 @@ static ERL_NIF_TERM nif_poll(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]
   for (;;) {
     uint8_t* buf = malloc(cap);
     if (!buf) return mk_err_atom(env, "enomem");
-    enif_mutex_lock(r->lock);                    /* the error text of the context is read under the same lock */
+    /* NOT under r->lock: eh_poll may wait for the whole batch in flight and download it, and submit_nif / flush_nif of other
+       processes must go on filling the next batch meanwhile (the engine's coalescer calls are thread safe among themselves) */
     int rc = eh_poll(r->ctx, ticket, buf, cap, &len, &status);
-    if (rc && rc != EH_E_AGAIN && !(rc == EH_E_INVALID && len > cap)) { ERL_NIF_TERM e = mk_error(env, r->ctx, rc); enif_mutex_unlock(r->lock); free(buf); return e; }
-    enif_mutex_unlock(r->lock);
+    if (rc && rc != EH_E_AGAIN && !(rc == EH_E_INVALID && len > cap)) { ERL_NIF_TERM e = mk_error(env, r->ctx, rc); free(buf); return e; }
     if (rc == EH_E_AGAIN) { free(buf); return enif_make_atom(env, "again"); }
     if (rc == EH_E_INVALID && len > cap) { free(buf); cap = (size_t)len; continue; }   /* the ticket stays valid */
     ERL_NIF_TERM bin; unsigned char* p = enif_make_new_binary(env, (size_t)len, &bin);

@@ -54,18 +54,25 @@ flush(Dict) -> flush_nif(co_ctx(Dict)).
 poll(Ticket, Dict) -> poll_nif(co_ctx(Dict), Ticket).
 
 co_ctx(#{hip_co_ctx := C}) -> C;
-co_ctx(Dict) ->
-    case persistent_term:get(erlamsa_hip_co_ctx, undefined) of
-        undefined -> {ok, C} = open(maps:get(device, Dict, 0)), persistent_term:put(erlamsa_hip_co_ctx, C), C;
-        C -> C
-    end.
+co_ctx(Dict) -> shared_ctx(erlamsa_hip_co_ctx, Dict).
 
 %% One GPU context per node, shared by all processes (the NIF serialises batches on it; coalescing needs the
 %% requests of different processes in the same context).  #{hip_ctx => C} overrides it.
 ctx(#{hip_ctx := C}) -> C;
-ctx(Dict) ->
-    case persistent_term:get(erlamsa_hip_ctx, undefined) of
-        undefined -> {ok, C} = open(maps:get(device, Dict, 0)), persistent_term:put(erlamsa_hip_ctx, C), C;
+ctx(Dict) -> shared_ctx(erlamsa_hip_ctx, Dict).
+
+%% one context per key and node: two first callers must not open one each (check-then-put is not atomic), so the opening
+%% is serialised through a global lock; later callers only read the persistent term
+shared_ctx(Key, Dict) ->
+    case persistent_term:get(Key, undefined) of
+        undefined ->
+            global:trans({Key, self()},
+                         fun() ->
+                             case persistent_term:get(Key, undefined) of
+                                 undefined -> {ok, C} = open(maps:get(device, Dict, 0)), persistent_term:put(Key, C), C;
+                                 C -> C
+                             end
+                         end, [node()]);
         C -> C
     end.
 

@@ -66,7 +66,11 @@ run(S = #st{pending = []}) ->
 run(S = #st{pending = P, dict = Dict, timer = T}) ->
     case T of
         undefined -> ok;
-        _ -> erlang:cancel_timer(T)
+        _ ->
+            %% the timer may have fired while a batch was running: its `flush` is in the mailbox already and would launch
+            %% the NEXT batch early (and orphan that batch's own timer)
+            erlang:cancel_timer(T, [{async, false}, {info, false}]),
+            receive flush -> ok after 0 -> ok end
     end,
     Reqs = lists:reverse(P),                                   %% arrival order = case order of the batch
     Res = (catch erlamsa_hip:fuzz_calls([{B, Sd} || {_From, B, Sd} <- Reqs], Dict)),

@@ -111,6 +111,8 @@ typedef struct eh_options {
 
 #define EH_FLAG_ORDERED_OUTPUT 1u /* compact the output arena into case order after the batch */
 #define EH_FLAG_META_TRACE 2u     /* keep every case's meta trace (eh_result_meta) */
+#define EH_FLAG_FUSE_NO_REDUCE 8u /* diagnostic: erlamsa_fuse:fuse/2 on large lists searches the lists as they are instead of copies with the
+                                     long periodic stretches cut short (csrc/eh_fuse_red.h); results are identical */
 #define EH_FLAG_FUSE_NO_LDS 4u    /* diagnostic: erlamsa_fuse:fuse/2 on small lists runs as the node-list refinement (csrc/eh_fuse.h)
                                      instead of the LDS-resident one (csrc/eh_fuse_lds.h); results are identical */
 
@@ -172,7 +174,9 @@ int eh_sync(eh_ctx* ctx);
  *              `cap` is too small (out_len then says how much is needed and the ticket stays valid).  Waits for the
  *              batch the ticket was launched in.
  * The three calls are thread safe with respect to each other; they use the context's corpus slot and result buffers,
- * so a context used for coalescing is not used for eh_fuzz_batch at the same time. */
+ * so a context used for coalescing is not used for eh_fuzz_batch at the same time.
+ * eh_configure on such a context: refused (EH_E_STATE) while requests are pending - eh_flush them first, they keep the options they
+ * were submitted under; a batch already in flight is collected (its results wait for eh_poll), then the options change. */
 int eh_coalesce_limits(eh_ctx* ctx, uint64_t flush_cases, uint64_t flush_bytes);
 int eh_submit(eh_ctx* ctx, const uint8_t* data, uint64_t len, const int64_t seed[3], uint64_t* ticket);
 int eh_flush(eh_ctx* ctx);
@@ -262,6 +266,9 @@ int eh_pattern_default_pri(int id);
 int eh_pattern_on_gpu(int id);
 const char* eh_strerror(int code);
 const char* eh_last_error(eh_ctx* ctx);
+/* The same text copied into caller memory (NUL-terminated, at most cap - 1 bytes; returns its length): for hosts that call
+ * eh_submit / eh_flush / eh_poll from several threads, where the pointer eh_last_error returns may be rewritten meanwhile. */
+uint64_t eh_last_error_copy(eh_ctx* ctx, char* buf, uint64_t cap);
 
 #ifdef __cplusplus
 }

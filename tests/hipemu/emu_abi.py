@@ -146,4 +146,19 @@ ec.cancel(tk[4])                                      # finished, never polled
 assert code(ec.poll, tk[4]) == -1 and code(ec.cancel, tk[4]) == -1
 ec.fuzz_batch(seed=(1, 2, 3))                         # the coalescer is idle again: the context takes batches
 ec.close()
+# a request with OTHER options than the previous one (what erlang/c_src nif_submit does: eh_flush, eh_configure, eh_submit): the
+# pending request is launched with the options it came with, eh_configure collects that batch instead of refusing, both poll fine
+eo = ea.Engine(0)
+eo.configure(mutations="bd,bf,sr,num,ld", patterns="od,nd,bu")
+ta = eo.submit(reqs[0][0], reqs[0][1])
+assert code(eo.configure, mutations="bi,br", patterns="od") == -5      # still pending: refused
+eo.flush()                                             # launched: in flight, nobody has polled
+eo.configure(mutations="bi,br", patterns="od")         # collects the batch in flight, then the options change
+tb = eo.submit(reqs[1][0], reqs[1][1])
+eo.flush()
+d1, o1 = po.pack([reqs[1][0]])
+wb, wsb, _, _ = po.fuzz_batch(d1, o1, seeds=np.array([reqs[1][1]], dtype=np.int64), mutations="bi,br", patterns="od")
+assert eo.poll(tb) == (int(wsb[0]), wb[0])
+assert eo.poll(ta) == (int(wstq[0]), wantq[0])         # the first request kept the options it was submitted under
+eo.close()
 print("abi behaviour ok")

@@ -229,6 +229,9 @@ inline unsigned long long __builtin_readcyclecounter() {
 template <class T, class U> inline T atomicAdd(T* p, U v) { HIPEMU_RACE_CALL(hipemu_race_atomic(1)); T old = *p; *p = (T)(old + (T)v); HIPEMU_RACE_CALL(hipemu_race_atomic(0)); return old; }
 template <class T, class U> inline T atomicExch(T* p, U v) { HIPEMU_RACE_CALL(hipemu_race_atomic(1)); T old = *p; *p = (T)v; HIPEMU_RACE_CALL(hipemu_race_atomic(0)); return old; }
 template <class T, class U> inline T atomicOr(T* p, U v) { HIPEMU_RACE_CALL(hipemu_race_atomic(1)); T old = *p; *p = (T)(old | (T)v); HIPEMU_RACE_CALL(hipemu_race_atomic(0)); return old; }
+template <class T, class U> inline T atomicMin(T* p, U v) { HIPEMU_RACE_CALL(hipemu_race_atomic(1)); T old = *p; if ((T)v < old) *p = (T)v; HIPEMU_RACE_CALL(hipemu_race_atomic(0)); return old; }
+template <class T, class U> inline T atomicMax(T* p, U v) { HIPEMU_RACE_CALL(hipemu_race_atomic(1)); T old = *p; if ((T)v > old) *p = (T)v; HIPEMU_RACE_CALL(hipemu_race_atomic(0)); return old; }
+inline unsigned long long __builtin_amdgcn_s_memrealtime() { return __builtin_readcyclecounter() / 10; }
 template <class T, class U, class V> inline T atomicCAS(T* p, U cmp, V v) { HIPEMU_RACE_CALL(hipemu_race_atomic(1)); T old = *p; if (old == (T)cmp) *p = (T)v; HIPEMU_RACE_CALL(hipemu_race_atomic(0)); return old; }
 
 // ---- the slice of the HIP runtime API the engine's host side uses -----------------------------------

@@ -17,11 +17,11 @@ for i in range(n):
 kinds["periodic"] = per
 names = [m[0] for m in ea.mutator_table()]
 LAB_LDS = {100: "round1", 101: "rounds", 102: "rounds(single)", 103: "select"}
-LAB = {100: "alloc", 101: "bits0", 102: "etest", 103: "scan", 104: "clear", 105: "pass(lds)", 106: "pass(glob)", 107: "pass(last)", 108: "tail", 109: "select", 110: "pass(test)"}
+LAB = {97: "cuts", 98: "no-cut", 100: "alloc", 101: "bits0", 102: "etest", 103: "scan", 104: "clear", 105: "pass(lds)", 106: "pass(glob)", 107: "pass(last)", 108: "tail", 109: "select", 110: "pass(test)"}
 for kind, mat in kinds.items():
     data = np.ascontiguousarray(mat).reshape(-1); off = np.arange(n + 1, dtype=np.uint64) * np.uint64(size)
     eng = ea.Engine(0)
-    eng.configure(fuse_stream_min=int(os.environ.get("FUSE_STREAM_MIN", "0")), mutations=mut + ",nil=0", patterns="od", out_capacity=4 << 30, max_case_bytes=256 << 20, big_case_bytes=256 << 20, max_slots=n, flags=4 if os.environ.get("FUSE_NO_LDS") == "1" else 0)
+    eng.configure(fuse_stream_min=int(os.environ.get("FUSE_STREAM_MIN", "0")), mutations=mut + ",nil=0", patterns="od", out_capacity=4 << 30, max_case_bytes=256 << 20, big_case_bytes=256 << 20, max_slots=n, flags=(4 if os.environ.get("FUSE_NO_LDS") == "1" else 0) | (8 if os.environ.get("FUSE_NO_REDUCE") == "1" else 0))
     eng.upload_corpus(data, off)
     eng.fuzz_batch(seed=(1, 2, 3))
     eng.sync()
@@ -29,5 +29,5 @@ for kind, mat in kinds.items():
     m = names.index(mut)
     print("%-5s %-9s size %8d calls %5d mean %10.1f kcyc kernel %8.2f ms rounds/call %.2f" % (mut, kind, size, pr[2 * m + 1], pr[2 * m] / max(pr[2 * m + 1], 1) / 1e3, eng.kernel_ms(), pr[2 * 126] / max(pr[2 * 126 + 1], 1)))
     lab = LAB_LDS if (size <= 8192 and os.environ.get("FUSE_NO_LDS") != "1") else LAB
-    print("      " + "  ".join("%s %.0fk x%d" % (lab.get(k, str(k)), pr[2 * k] / max(pr[2 * k + 1], 1) / 1e3, pr[2 * k + 1]) for k in range(100, 111) if pr[2 * k + 1] > 0))
+    print("      " + "  ".join("%s %.0fk x%d" % (lab.get(k, str(k)), pr[2 * k] / max(pr[2 * k + 1], 1) / 1e3, pr[2 * k + 1]) for k in list(range(96, 99)) + list(range(100, 112)) if pr[2 * k + 1] > 0))
     eng.close()
