@@ -101,6 +101,17 @@ def cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref=None):
                       % (state["cases"], threads, ct, args.cpu_case_seconds)}
 
 
+def kernel_source_sha1():
+    """SHA-1 over the kernel's sources (erlamsa_amd/csrc/*, sorted by name): ties a profile under profiles/ to the build it is of"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "erlamsa_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def log(msg):
     sys.stderr.write("[bench %.1f] %s\n" % (time.time() % 100000, msg))
     sys.stderr.flush()
@@ -114,7 +125,7 @@ def main():
     ap.add_argument("--cases", type=int, default=65536)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--mutations", default=None, help="-m syntax; default: the reference's full default table (erlamsa_mutations.erl:1291-1331)")
-    ap.add_argument("--patterns", default="od,nd,bu")
+    ap.add_argument("--patterns", default="od,nd,bu", help="-p syntax; 'default' = the reference's default table (all ten patterns, BASELINE configs[3])")
     ap.add_argument("--corpus", default="mixed", choices=["mixed", "uniform", "counter"],
                     help="mixed = BASELINE configs[2] (default); uniform = random bytes (configs[1] with --cases 1024 --size 256); counter = the "
                     "counter-hash corpus of synth.counter, written into the HBM arena by every rank for itself (no host staging, no broadcast)")
@@ -131,9 +142,9 @@ def main():
                     "8 per CU = 2048); passes in flight oversubscribe the device.  1024 x 6 passes keeps ~45 GiB of the device free: with 2048 "
                     "(5 percent faster, profiles/r03_bench.json) the free memory fell below what the runtime wants for the queues' scratch and "
                     "two of six runs never left the set-up passes")
-    ap.add_argument("--pool-gib", type=int, default=48, help="device memory of the work-area pool all contexts share (GiB), eh_options.pool_bytes; "
+    ap.add_argument("--pool-gib", type=int, default=64, help="device memory of the work-area pool all contexts share (GiB), eh_options.pool_bytes; "
                     "0 = the library's own rule (a quarter of the free memory, at most 64 GiB)")
-    ap.add_argument("--out-gib", type=int, default=27, help="output arena capacity per context (GiB)")
+    ap.add_argument("--out-gib", type=int, default=25, help="output arena capacity per context (GiB)")
     ap.add_argument("--case-mib", type=int, default=4, help="work area of a slot (MiB), eh_options.max_case_bytes; every workgroup of a pass owns a slot, a case that "
                     "outgrows it borrows larger areas from the pool")
     ap.add_argument("--big-mib", type=int, default=1024, help="largest work area (MiB), eh_options.big_case_bytes: a case that outgrows its area "
@@ -229,21 +240,27 @@ def main():
     # (broadcast of the arena, barrier, reduction of the result) - and then BEFORE the engine's library, so that both share one
     # HIP runtime.
     dist = torch = None
+    # EH_BENCH_BACKEND=gloo: this very script's N > 1 path on CPU ranks with the emulator build of the engine (tests/test_bench_dry.py;
+    # device pointers are host pointers there) - everything but RCCL itself
+    on_gpu = os.environ.get("EH_BENCH_BACKEND", "nccl") == "nccl"
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        log("rank %d: process group (nccl = RCCL)" % rank)
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        log("rank %d: process group (%s)" % (rank, "nccl = RCCL" if on_gpu else "gloo"))
+        if on_gpu:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     import erlamsa_amd as ea
     from erlamsa_amd.engine import HostBuffer
-    dev = torch.device("cuda", local) if torch is not None else None
+    dev = None if torch is None else torch.device("cuda", local) if on_gpu else torch.device("cpu")
 
     n, size = args.cases, args.size
     # Measured set = the reference's full default mutator table (41 entries, default priorities) unless overridden.
     muts = args.mutations or ",".join("%s=%d" % (m, p) for m, p, _ in ea.mutator_table())
-    pats = args.patterns
+    pats = None if args.patterns == "default" else args.patterns     # "default": the reference's own table (erlamsa_patterns.erl:395-405), all ten at their priorities
     nmut_total = len(ea.mutator_table())
 
     # `--inflight` engine contexts, each on its own HIP stream: step k runs on context k % inflight, so
@@ -253,7 +270,7 @@ def main():
     log("engine contexts (%d)" % nctx)
     engines = []
     for _ in range(nctx):
-        e = ea.Engine(local)
+        e = ea.Engine(local if on_gpu else 0)
         e.configure(mutations=muts, patterns=pats, generators=args.generators, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
                     max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20, big_case_bytes=args.big_mib << 20,
                     pool_bytes=args.pool_gib << 30)
@@ -262,7 +279,7 @@ def main():
     def sync():
         for e in engines:
             e.sync()
-        if torch is not None:
+        if torch is not None and on_gpu:
             torch.cuda.synchronize()
 
     # ---- corpus: one arena in HBM, shared by all contexts of the device
@@ -286,7 +303,17 @@ def main():
                 mat = synth.mixed(n, size) if args.corpus == "mixed" else synth.uniform(n, size)
                 arena.copy_(torch.from_numpy(mat.reshape(-1)))
             shard.broadcast_corpus(arena, offs, src=0)
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
+        # every rank must hold the bytes rank 0 made: a wrapping 64-bit sum of the arena (as int64 words) and of the offsets,
+        # gathered over RCCL and compared on every rank (a broadcast that silently moved nothing would otherwise go unnoticed)
+        nw = (n * size) // 8
+        chk = torch.stack([arena[:nw * 8].view(torch.int64).sum(), arena[nw * 8:].to(torch.int64).sum(), offs.sum()])
+        allchk = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(allchk, chk)
+        arena_same = all(bool((c0 == allchk[0]).all()) for c0 in allchk)
+        if not arena_same:
+            raise RuntimeError("rank %d: the broadcast arena differs between ranks" % rank)
         engines[0].attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
     for e in engines[1:]:
         e.share_corpus(engines[0])
@@ -345,19 +372,27 @@ def main():
         avg_kern_s = float(np.mean(kern_ms)) / 1e3
         alg_bytes = in_bytes + out_bytes / args.steps + DESC_BYTES * nloc    # per launch (this rank)
         achieved = alg_bytes / avg_kern_s / 1e9
-        # HBM-side bytes per launch cannot be measured from inside this process (PMC counters need
-        # rocprofv3 around it); the figure of the committed counter run of this same workload is attached
-        # when the configuration matches, else null.
+        # HBM-side bytes per launch cannot be measured from inside this process (PMC counters need rocprofv3 around it): the figure
+        # of the newest committed counter run (profiles/rNN_summary.json, tools/profile_round.sh + collect_profiles.py) is attached
+        # when it is a run of THIS kernel (same sources) on THIS workload with THESE engine options; otherwise traffic is null
+        # and the file is only named.
         traffic, traffic_src = None, None
+        ksha = kernel_source_sha1()
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_summary.json")) as fh:
+            import glob
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_summary.json")))
+            with open(cand[-1]) as fh:
                 ps = json.load(fh)
             wk = ps["workload_key"]
-            if (wk["cases"], wk["size"], wk["max_case_work"], wk["max_case_bytes"], wk["mutators"], wk["patterns"]) == \
-                    (n, size, args.work_mib << 20, args.case_mib << 20, muts, pats):       # per launch: independent of how many overlap
+            mine = {"cases": n, "size": size, "max_case_work": args.work_mib << 20, "max_case_bytes": args.case_mib << 20, "mutators": muts, "patterns": pats,
+                    "max_slots": args.max_slots, "pool_gib": args.pool_gib, "big_case_bytes": args.big_mib << 20, "kernel_source_sha1": ksha}
+            if all(wk.get(k) == v for k, v in mine.items()):
                 traffic = int(ps["traffic_bytes_per_launch"]["total_fetch_x2_plus_write"])
-                traffic_src = "profiles/r03_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch; a committed counter run of this workload, not measured in this process)"
-        except (OSError, KeyError, ValueError):
+                traffic_src = "%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch; a committed counter run of this kernel and workload, not measured in this process)" % os.path.relpath(cand[-1], ROOT)
+            else:
+                traffic_src = "%s is a counter run of another kernel build or configuration (%s): not attached" % (
+                    os.path.relpath(cand[-1], ROOT), ", ".join(k for k, v in mine.items() if wk.get(k) != v))
+        except (OSError, KeyError, ValueError, IndexError):
             pass
         res = {
             "metric": "mutated_MB_per_s", "value": round(mbps, 1), "unit": "MB/s",
@@ -374,11 +409,15 @@ def main():
                                n, size, "mixed-binary corpus (50% random, 25% ASCII lines+numbers, 15% bracketed text, "
                                "10% length/CRC-framed)" if args.corpus == "mixed" else "uniform random bytes" if args.corpus == "uniform" else
                                "counter-hash corpus (uniform / text with numbers / length-framed / low-entropy rows, written on the device)",
-                               args.generators or "direct=500/random=1", pats, muts, len(muts.split(",")), nmut_total,
+                               args.generators or "direct=500/random=1", pats or "the default table (od,nd,bu,sk,sz,cs,ar,cp,co,nu at their default priorities)", muts, len(muts.split(",")), nmut_total,
                                ",".join(m for m, _, _ in ea.mutator_table() if m not in [x.split("=")[0] for x in muts.split(",")]) or "none"),
+                "world_size_seen_by_torch_distributed": (dist.get_world_size() if dist is not None else 1),
+                "arena_checksums_equal_on_all_ranks": (arena_same if world > 1 else None),
                 "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream, one after the other, before the W warm-up steps",
                 "max_case_bytes": args.case_mib << 20, "big_case_bytes": args.big_mib << 20, "max_case_work": args.work_mib << 20,
                 "workgroups_per_pass": args.max_slots or "one per wavefront the device holds (8 per CU)", "pool_gib": args.pool_gib,
+                "max_slots": args.max_slots, "kernel_source_sha1": ksha,
+                "host": "no torch in this process (corpus: eh_corpus_upload, streams: eh_stream, pinned memory: eh_host_alloc)" if world == 1 else "torch = the RCCL binding (arena broadcast, barrier, reduction)",
                 "work_area_pool": engines[0].pool_stats(),
             },
             "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(big_case_bytes)", "unsupported", "arena_full",

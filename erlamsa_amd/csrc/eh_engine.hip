@@ -1202,9 +1202,12 @@ static int pool_acquire(eh_ctx* ctx, uint64_t work_cap, uint64_t big, uint64_t p
   // twice the area per tier (most cases that outgrow what they hold need less than twice as much); the last tier has `big`.
   // The pool's memory (pool_bytes; default: a quarter of the free memory, at most 64 GiB) is split over the tiers in the
   // proportions the bench workload asks for them (BASELINE configs[2], 4 MiB slots: by far most borrowers are fuse calls on
-  // blocks of 0.1-1 MB, whose tables take 5-20 MB): 12 / 33 / 25 / 9 / 6 / 6 / 3 / 6 percent from the smallest tier up.
+  // blocks of 0.1-1 MB, whose tables take 5-20 MB): 12 / 23 / 17 / 7 / 10 / 10 / 9 / 12 percent from the smallest tier up.
   // Every tier holds at least one area, at most 4096; a tier that cannot be allocated at all ends the ladder.
-  static const uint32_t SHARE[POOL_TIERS] = {12, 33, 25, 9, 6, 6, 3, 6};
+  // Round 4: the large tiers get three times what they had.  With 2 areas of 1 GiB and 2 of 512 MiB for six passes in flight the
+  // heaviest cases of the passes queued for each other (eh_pool_stats of a bench run: ~130 waits of 1.8 G ticks each for the last
+  // tier alone, 1.8 - 3.2 T ticks of sleeping wavefronts per run), which stretched exactly the cases that decide how long a pass lasts.
+  static const uint32_t SHARE[POOL_TIERS] = {12, 23, 17, 7, 10, 10, 9, 12};
   size_t fr = 0, tot = 0;
   hipError_t e = hipSuccess;
   uint64_t pool_bytes = pool_bytes_opt;

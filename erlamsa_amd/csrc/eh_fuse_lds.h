@@ -47,6 +47,8 @@ struct FlState {
   uint32_t multi;           // nodes with more than one entry
   uint32_t dboff;           // byte offset in g_fuse_lds of the staged data (A then B), FL_NONE: read the lists where they are
   uint32_t* T;              // work-area parking space of a big node (n0 words)
+  // fuse(H, H) with single-member nodes only: a round retires one known member; it is marked, not removed (see fl_round)
+  uint32_t fast, tab_g0, ntomb;
 };
 struct FlRound { uint32_t w, nn, ghost, nsp, multi; };    // a round's output so far: entries written, nodes, ...
 
@@ -175,6 +177,15 @@ EH_DEV void fl_chunk(const FlState& st, uint32_t i, uint32_t m, uint64_t sb, FlR
   }
   if (!alive) { eqm = 0; lessm = 0; }
   unsigned long long amA = __ballot(alive && !side), amB = __ballot(alive && side);
+  // Nothing to do? Every member alive, none of them the one whose rest is [], every node's members agree on the next byte
+  // (and, two lists: have sources and targets) - then the nodes are their own children, in place.  The steady state of
+  // repetitive data, where nodes never split.
+  if (o.w == i && __ballot(in && (!alive || star || eqm != pgm || (!st.sym && ((amA & pgm) == 0 || (amB & pgm) == 0)))) == 0) {
+    const unsigned long long nxtb = (sb >> 1) | (1ull << (m - 1u));
+    const uint32_t groups = (uint32_t)__popcll(sb);
+    o.nn += groups; o.multi += groups - (uint32_t)__popcll(sb & nxtb); o.w += m;
+    return;
+  }
   unsigned long long smA = __ballot(star && !side), smB = __ballot(star && side);
   FlVerdict v = fl_verdict(st.sym, even, (uint32_t)__popcll(amA & eqm), (uint32_t)__popcll(amB & eqm), (smA & eqm) != 0, (smB & eqm) != 0);
   bool keep = alive && v.ch && (v.sp ? (star && !side) : !((star && !side && v.fdrop) || (star && side && v.tdrop)));
@@ -333,27 +344,40 @@ EH_DEV uint32_t fl_round(FlState& st) {
   FlRound o; o.w = 0; o.nn = 0; o.ghost = FL_NONE; o.nsp = 0; o.multi = 0;
   if (st.sym && st.multi == 0) {
     // every node is one member: it stays one (its next byte is its own), except the member whose rest WAS [] a round ago
-    // (position la now: the empty suffix is skipped, :66-67), which leaves; the member at la - 1 becomes {[[]], [[]]} and stays
+    // (position la now: the empty suffix is skipped, :66-67), which leaves; the member at la - 1 becomes {[[]], [[]]} and stays.
+    // The leaving member is suffix la - g: a table (H[0, 64): where the suffixes la - tab_g0 - j are in E, j < 64) finds it, and
+    // it is only MARKED dead (E = 0xFFFF, its index noted in H[64 ..)) - closing the gap would move half the array every round.
     uint16_t* E = fl_E();
-    const uint32_t target = st.la - st.g;                              // s + g == la
-    uint32_t at = FL_NONE;
-    if (st.g <= st.la) {
+    uint32_t* H = fl_H();
+    if (st.ntomb >= 190u) {                                          // (never in practice: a round for every mark) close the gaps
+      uint32_t w = 0;
       for (uint32_t base = 0; base < st.n; base += 64) {
-        unsigned long long hit = __ballot(base + l < st.n && (uint32_t)E[base + l] == target);
-        if (hit) { at = base + (uint32_t)__builtin_ctzll(hit); break; }
+        uint32_t e = base + l < st.n ? (uint32_t)E[base + l] : 0xFFFFu;
+        unsigned long long km = __ballot(e != 0xFFFFu);
+        lanes_sync();
+        if (e != 0xFFFFu) E[w + (uint32_t)__popcll(km & ((1ull << l) - 1ull))] = (uint16_t)e;
+        w += (uint32_t)__popcll(km);
+        lanes_sync();
       }
+      st.n = w; st.ntomb = 0; st.fast = 0;
     }
+    if (!st.fast || st.g - st.tab_g0 >= 64u) {
+      st.fast = 1; st.tab_g0 = st.g;
+      if (l < 64) H[l] = FL_NONE;
+      lanes_sync();
+      for (uint32_t base = 0; base < st.n; base += 64) {
+        uint32_t e = base + l < st.n ? (uint32_t)E[base + l] : 0xFFFFu;
+        uint32_t d = st.la - st.g - e;                               // (wraps for the others)
+        if (e != 0xFFFFu && d < 64u) H[d] = base + l;
+      }
+      lanes_sync();
+    }
+    const uint32_t at = st.g <= st.la ? H[st.g - st.tab_g0] : FL_NONE;
     if (at == FL_NONE) { st.g++; return st.nn; }
-    if (st.n == 1) return 0;
-    for (uint32_t base = at; base + 1 < st.n; base += 64) {          // close the gap (ascending: every step reads before it writes)
-      uint32_t idx = base + l;
-      uint32_t v = idx + 1 < st.n ? (uint32_t)E[idx + 1] : 0u;
-      lanes_sync();
-      if (idx + 1 < st.n) E[idx] = (uint16_t)v;
-      lanes_sync();
-    }
-    st.n--; st.nn--; st.g++;
-    // start bits: all ones below n, as before (bit n - 1 .. are never read beyond n)
+    if (st.nn == 1) return 0;
+    if (l == 0) { E[at] = 0xFFFFu; H[64u + st.ntomb] = at; }
+    lanes_sync();
+    st.ntomb++; st.nn--; st.g++;
     return st.nn;
   }
   uint32_t i = 0;
@@ -393,6 +417,7 @@ __device__ __noinline__ bool fuse_jump_lds(Ctx&, const uint8_t* A, uint32_t la, 
   st.A = A; st.B = B; st.la = la; st.lb = lb; st.sym = sym;
   const uint32_t n0 = sym ? la : la + lb;
   st.n = n0; st.g = 0; st.nn = 1; st.ghost = FL_NONE; st.nsp = 0; st.multi = n0 > 1 ? 1u : 0u; st.dboff = FL_NONE;
+  st.fast = 0; st.tab_g0 = 0; st.ntomb = 0;
   st.T = nullptr;
   if (n0 > 64) { st.T = (uint32_t*)ws_alloc(c, 4ull * n0); if (!st.T) return false; }
   uint16_t* E = fl_E();
@@ -426,15 +451,27 @@ __device__ __noinline__ bool fuse_jump_lds(Ctx&, const uint8_t* A, uint32_t la, 
     EH_PT(c, pslot);
     if (nchild == 0) break;                                          // NoDesp =:= [] -> any_position_pair(Nodes)
     fuel -= (int64_t)nchild;
-    gen_entries = sym ? 2ull * st.n : (uint64_t)st.n + st.nsp;
+    gen_entries = sym ? 2ull * (st.n - st.ntomb) : (uint64_t)st.n + st.nsp;
     (*rounds)++;
   }
   // any_position_pair/1 (:73-77); odd generations are stored reversed
   const uint32_t par = st.g & 1u;
   uint32_t ni = rng_rand(c.rng, st.nn);
   uint32_t k = par ? st.nn - 1u - ni : ni;
-  uint32_t a = (st.sym && st.multi == 0) ? k : fl_kth_start(k, st.n);
-  uint32_t b = (st.sym && st.multi == 0) ? k + 1u : fl_next_start(a + 1u, st.n);
+  uint32_t a, b;
+  if (st.sym && st.multi == 0) {                                    // single members: the k-th entry that is not marked dead
+    a = k;
+    if (st.ntomb) {
+      const uint32_t* H = fl_H();
+      for (;;) {
+        uint32_t cdead = 0;
+        for (uint32_t t0 = 0; t0 < st.ntomb; t0 += 64) cdead += (uint32_t)__popcll(__ballot(t0 + l < st.ntomb && H[64u + t0 + l] <= a));
+        if (k + cdead == a) break;
+        a = k + cdead;
+      }
+    }
+    b = a + 1u;
+  } else { a = fl_kth_start(k, st.n); b = fl_next_start(a + 1u, st.n); }
   uint32_t fc = b - a;
   if (!sym) {                                                        // sources come first
     uint32_t cnt = 0;

@@ -20,7 +20,7 @@
 namespace eh {
 
 constexpr uint32_t FR_NONE = 0xFFFFFFFFu;
-constexpr uint32_t FR_MAX_PERIOD = 1u << 17;        // how far the next occurrence of an anchor's 8 bytes is looked for
+constexpr uint32_t FR_MAX_PERIOD = 1u << 16;        // how far the next occurrence of an anchor's 8 bytes is looked for
 constexpr int FR_LEVELS = 4;
 
 EH_DEV uint64_t fr_ld8(const uint8_t* S, uint32_t q, uint32_t len) {      // 8 bytes from q, zero filled past the end
@@ -76,21 +76,27 @@ __device__ __noinline__ uint32_t fr_run_bwd(const uint8_t* S, uint32_t i0, uint3
     if (hi <= 1024) return 0;
   }
 }
-// first y in [from, lim) with y + 8 <= n and the 8 bytes at y equal to key, FR_NONE: none
+// first y in [from, lim) with y + 8 <= n and the 8 bytes at y equal to key, FR_NONE: none.  1024 positions per step: a lane
+// loads the 24 bytes at its 16 positions and slides an 8-byte window over them.
 __device__ __noinline__ uint32_t fr_find8(const uint8_t* S, uint32_t from, uint32_t lim, uint32_t n, uint64_t key) {
   const uint32_t l = (uint32_t)EH_LANE;
   if (n < 8) return FR_NONE;
   if (lim > n - 7) lim = n - 7;
-  for (uint32_t base = from; base < lim; base += 256) {
-    uint64_t v[4];
+  for (uint32_t base = from; base < lim; base += 1024) {
+    const uint32_t q = base + 16u * l;
+    uint64_t w0 = 0, w1 = 0, w2 = 0;
+    if (q + 24 <= n) { __builtin_memcpy(&w0, S + q, 8); __builtin_memcpy(&w1, S + q + 8, 8); __builtin_memcpy(&w2, S + q + 16, 8); }
+    else if (q < lim) { w0 = fr_ld8(S, q, n); w1 = fr_ld8(S, q + 8, n); w2 = fr_ld8(S, q + 16, n); }
+    uint32_t first = 16;
 #pragma unroll
-    for (int u = 0; u < 4; u++) { uint32_t y = base + 64u * (uint32_t)u + l; v[u] = 0; if (y < lim) __builtin_memcpy(&v[u], S + y, 8); }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      uint32_t y = base + 64u * (uint32_t)u + l;
-      unsigned long long hit = __ballot(y < lim && v[u] == key);
-      if (hit) return base + 64u * (uint32_t)u + (uint32_t)__builtin_ctzll(hit);
+    for (int k = 15; k >= 0; k--) {
+      const uint64_t lo = k < 8 ? w0 : w1, hi = k < 8 ? w1 : w2;
+      const int sh = 8 * (k & 7);
+      const uint64_t win = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+      if (win == key && q + (uint32_t)k < lim) first = (uint32_t)k;
     }
+    unsigned long long hit = __ballot(first < 16);
+    if (hit) { int src = (int)__builtin_ctzll(hit); return base + 16u * (uint32_t)src + (uint32_t)__builtin_amdgcn_readlane((int)first, src); }
   }
   return FR_NONE;
 }
@@ -99,7 +105,12 @@ __device__ __noinline__ uint32_t fr_find8(const uint8_t* S, uint32_t from, uint3
 __device__ __noinline__ bool fr_find_cut(const uint8_t* S, uint32_t n, uint32_t R, uint32_t* cu, uint32_t* cD) {
   uint32_t bestD = 0, bestU = 0, blo = 0, bhi = 0;
   if (n < 4096) return false;
-  for (uint32_t a = 1; a <= 7; a++) {
+  bool any = false;                                                  // some anchor's bytes came again at all
+  for (uint32_t ai = 0; ai < 7; ai++) {
+    // the middle and the quarters first: a list in which none of them sees its 8 bytes again within FR_MAX_PERIOD has no stretch
+    // worth cutting (it would have to miss all three), and the search must stay cheap for lists that are not periodic at all
+    const uint32_t a = ai == 0 ? 4u : ai == 1 ? 2u : ai == 2 ? 6u : ai == 3 ? 1u : ai == 4 ? 3u : ai == 5 ? 5u : 7u;
+    if (ai == 3 && !any) break;
     const uint32_t x = (uint32_t)(((uint64_t)n * a) >> 3);
     if (x + 8 > n) continue;
     if (bestD && x >= blo && x < bhi) continue;                      // inside the stretch already found
@@ -109,6 +120,7 @@ __device__ __noinline__ bool fr_find_cut(const uint8_t* S, uint32_t n, uint32_t 
       const uint32_t far = x + 1u + FR_MAX_PERIOD < n ? x + 1u + FR_MAX_PERIOD : n;
       y = fr_find8(S, y, far, n, key);
       if (y == FR_NONE) break;
+      any = true;
       const uint32_t p = y - x;
       const uint32_t hi = fr_run_fwd(S, x, p, n), lo = fr_run_bwd(S, x, p);
       const uint32_t u = lo + p, b = hi + p;                          // S[k] == S[k + p] on [lo, hi)

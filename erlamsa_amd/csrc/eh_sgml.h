@@ -102,8 +102,31 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   uint32_t ntok = 0, npar = 0, npc = 0;
 
   // ---- phase 2
+  // The events the state machine is walking through sit in LDS (g_fuse_lds is idle outside fuse): SG_EVC of them around the
+  // place of work, refilled in one batch of loads when it is left.  Read from the work area 64 at a time, every refill of
+  // the lane window was a global load that had to wait for all the piece / token stores issued before it (stores count in
+  // vmcnt on this ISA) - two memory round trips every few tokens, which is what the tokenizer of a megabyte block spent its
+  // hundreds of millions of cycles in (the heaviest cases of a pass are sgm on pumped documents).
+  constexpr uint32_t SG_EVC = 4096, SG_EVBACK = 512;
+  uint32_t cbase = 0xFFFFFFFFu;                                            // events [cbase, cbase + SG_EVC) are in g_fuse_lds
   uint32_t bev = 0, bbase = 0xFFFFFFFFu;                                   // lane k holds event bbase + k
-  auto need = [&](uint32_t i) { if (bbase == 0xFFFFFFFFu || i < bbase || i >= bbase + 64) { bbase = i & ~63u; uint32_t j = bbase + (uint32_t)l; bev = j < nev ? ev[j] : 0u; } };
+  auto need = [&](uint32_t i) {
+    if (bbase != 0xFFFFFFFFu && i >= bbase && i < bbase + 64) return;
+    bbase = i & ~63u;
+    if (cbase == 0xFFFFFFFFu || bbase < cbase || bbase + 64 > cbase + SG_EVC) {
+      cbase = bbase > SG_EVBACK ? bbase - SG_EVBACK : 0u;                 // (a failed tag is retried from its next '<': a little history stays)
+      lanes_sync();
+      for (uint32_t k0 = 0; k0 < SG_EVC; k0 += 256) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { uint32_t j = cbase + k0 + 64u * (uint32_t)u + (uint32_t)l; v[u] = j < nev ? ev[j] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) g_fuse_lds[k0 + 64u * (uint32_t)u + (uint32_t)l] = v[u];
+      }
+      lanes_sync();
+    }
+    bev = g_fuse_lds[bbase - cbase + (uint32_t)l];
+  };
   // index of the first event >= from whose class is in `set`; nev if there is none
   auto find = [&](uint32_t from, uint32_t set) -> uint32_t {
     while (from < nev) {

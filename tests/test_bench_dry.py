@@ -38,3 +38,25 @@ def test_bench_config_5_shape_runs_on_the_emulator():
     d = _run(["--config", "5", "--cases", "12", "--size", "4096", "--budget-mib", "0", "--pcie", "0", "--steps", "1", "--warmup", "0", "--inflight", "1", "--cpu-sample", "6"])
     assert "configs[4]" in d["config"]["workload"] and "generator jump" in d["config"]["workload"] and d["scaling"] == "strong"
     assert d["case_status"]["ok"] == 12 and d["parity_checked"] == 6        # the oracle's Paths are the whole counter-hash arena
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_script_two_ranks_over_gloo_on_the_emulator(scaling):
+    """bench.py's OWN N > 1 path (process group, arena generated on rank 0 and broadcast, the checksum agreement of all ranks, one
+    context attaching the broadcast tensors and the others sharing it, step loop per rank, barrier, MAX / SUM reduction, one JSON
+    line from rank 0) as two CPU ranks over gloo with the emulator build of the engine - everything of the driver's multi-GPU run
+    except RCCL itself.  Launched the way the driver launches it."""
+    import build_emu
+    env = dict(os.environ, EH_BENCH_BACKEND="gloo", ERLAMSA_HIP_LIB=build_emu.build())
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EH_BENCH_CHILD"):
+        env.pop(k, None)
+    port = 29700 + (os.getpid() % 200) + (0 if scaling == "weak" else 1)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", scaling, "--cases", "16", "--size", "256", "--mutations", "bd,bf,bi,sr,num,lr,ab"] + SMALL
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 2 and d["value"] > 0
+    assert d["config"]["world_size_seen_by_torch_distributed"] == 2 and d["config"]["arena_checksums_equal_on_all_ranks"] is True
+    assert d["case_status"]["ok"] == (32 if scaling == "weak" else 16)          # rank 0's share: weak = its own 16 cases per step, strong = half of one run's

@@ -146,3 +146,44 @@ print("DIGEST", h.hexdigest(), sum(map(int, st)))
         assert r.returncode == 0 and ln, (mode, r.stdout[-800:], r.stderr[-2000:])
         digs.append(ln[0])
     assert digs[0] == digs[1]
+
+
+def test_sgml_tokenizer_on_documents_of_many_thousand_events():
+    """The tokenizer keeps the 4 096 events around its place of work in LDS (csrc/eh_sgml.h).  Documents far larger than that window:
+    pumped ones (a run of elements repeated thousands of times: what the heaviest cases of the bench workload are), one whose first
+    tag runs through 12 000 events before it fails and is retried from its next '<' - a jump back across the whole window -, long
+    quoted values and comments spanning windows.  Bytes, statuses and draw counts against the oracle, run live."""
+    if util.priming():
+        pytest.skip("live oracle")
+    import erlamsa_amd as ea
+    import pyoracle as po
+    from erlamsa_amd import synth
+    rng = np.random.Generator(np.random.PCG64(44))
+    docs = []
+    small = synth.sgml_docs(24, seed=8)
+    for k in range(10):
+        unit = b"".join(small[(3 * k + j) % len(small)] for j in range(3))
+        docs.append(b"<doc>" + unit * int(rng.integers(40, 400)) + b"</doc>")
+    docs.append(b"<a " + b"x<y " * 4000)                                                   # no '>' anywhere
+    docs.append(b"<a " + b"x<y " * 3000 + b"> tail <b k='v'>text</b>")
+    docs.append(b"<r>" + b"<e a=\"" + b"v " * 6000 + b"\">t</e>" + b"<!-- " + b"- c " * 5000 + b"-->" + b"</r>")
+    docs.append(b"<p>" + b"<q w = 'z' />\n \t" * 5000 + b"</p>")
+    docs.append(b"text only < and > and = without a tag " * 3000)
+    data, off = po.pack(docs)
+    kw = dict(seed=(4, 2, 4), mutations="sgm", patterns="od,nd,bu", max_case_bytes=256 << 20)
+    ora = util.oracle_live(data, off, chunk=1, max_case_seconds=60.0, **kw)
+    eng = ea.Engine(0)
+    eng.configure(mutations="sgm", patterns="od,nd,bu", max_case_bytes=8 << 20, big_case_bytes=512 << 20)
+    eng.upload_corpus(data, off)
+    eng.fuzz_batch(seed=(4, 2, 4))
+    got, st = eng.download()
+    dr, _ = eng.diag()
+    eng.close()
+    compared = 0
+    for i in range(len(docs)):
+        if st[i] in (2, 3) or ora.status[i] in (2, 3, 6):
+            continue
+        compared += 1
+        assert int(st[i]) == int(ora.status[i]) and got[i] == ora.outs[i] and (st[i] != 0 or int(dr[i]) == int(ora.draws[i])), \
+            "document %d (%d bytes): first difference at %d" % (i, len(docs[i]), util.first_diff(got[i], ora.outs[i]))
+    assert compared >= len(docs) - 2

@@ -113,7 +113,8 @@ out = {
     "workload_key": {"cases": bench["config"]["cases_per_step_per_gpu"], "size": 4096,
                      "max_case_work": bench["config"]["max_case_work"], "max_case_bytes": bench["config"]["max_case_bytes"],
                      "mutators": bench["config"]["workload"].split("mutators ")[1].split(" (")[0], "patterns": "od,nd,bu",
-                     "inflight": bench["config"]["passes_in_flight"]},
+                     "inflight": bench["config"]["passes_in_flight"], "max_slots": bench["config"].get("max_slots"), "pool_gib": bench["config"].get("pool_gib"),
+                     "big_case_bytes": bench["config"].get("big_case_bytes"), "kernel_source_sha1": bench["config"].get("kernel_source_sha1")},
     "traffic_note": "FETCH_SIZE counts 64 B per L2-to-fabric read request (Infinity-Cache hits included): the x2 correction of the guide holds for "
                     "wide streaming reads; this kernel's reads are dominated by 4-8 byte gathers into per-case tables (fuse2 lookups), for which a "
                     "request IS 64 B, so the true read traffic lies between fetch_raw and fetch_x2",

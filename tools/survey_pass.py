@@ -65,3 +65,8 @@ if pr.sum() > 0:
     for k in range(64, 112):
         if pr[2 * k + 1] > 0:
             print("  slot %3d calls %9d mean %10.1f kcyc total %8.2f Gcyc" % (k, pr[2 * k + 1], pr[2 * k] / pr[2 * k + 1] / 1e3, pr[2 * k] / 1e9))
+
+    print("  large fuse calls that ran on shortened lists (eh_fuse_red.h): %d (finding + making the cuts: mean %.0f kcyc), that found no cut worth it: %d (mean %.0f kcyc)   # fuse_red" % (
+        pr[2 * 97 + 1], pr[2 * 97] / max(pr[2 * 97 + 1], 1) / 1e3, pr[2 * 98 + 1], pr[2 * 98] / max(pr[2 * 98 + 1], 1) / 1e3))
+    print("  sgm phases: tokenizer %d calls mean %.0f kcyc total %.1f Gcyc; pairing+flags total %.1f Gcyc; edit script total %.1f Gcyc; gather total %.1f Gcyc" % (
+        pr[2 * 90 + 1], pr[2 * 90] / max(pr[2 * 90 + 1], 1) / 1e3, pr[2 * 90] / 1e9, pr[2 * 91] / 1e9, pr[2 * 92] / 1e9, pr[2 * 93] / 1e9))
