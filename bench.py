@@ -165,12 +165,16 @@ def main():
     ap.add_argument("--setup-seconds", type=int, default=150, help="single-GPU runs execute in a child process; a child whose set-up passes (the first "
                     "dispatch on every HIP stream) have not finished after this many seconds is killed and the run repeated with "
                     "--inflight 3, then 1 (0 = no supervision)")
+    ap.add_argument("--profiled", type=int, default=0, help="1: the run is under rocprofv3 - no child process (--setup-seconds 0) and the process ends by "
+                    "returning from main() instead of os._exit, so that the profiler's tool gets to write its output")
     pre, _ = ap.parse_known_args()
     if pre.config == 5:
         w5 = int(os.environ.get("WORLD_SIZE", "1"))
         ap.set_defaults(cases=131072 * w5, size=65536, corpus="counter", generators="jump", mutations="ft,fn,fo,num,len", patterns="sz", scaling="strong",
                         out_gib=8, cpu_sample=0, budget_mib=0)
     args = ap.parse_args()
+    if args.profiled:
+        args.setup_seconds = 0
 
     # ---- supervision (single GPU only): the run proper happens in a child process, and the driver must get its JSON line.
     # A child that dies (round 3's driver run: "Memory access fault by GPU node-2" 3.6 s in, once, never reproduced) or that never
@@ -502,7 +506,8 @@ def main():
                     return
             res["extras_timed_out"] = "leg '%s' did not finish within %d s; the result above does not depend on it" % (state["leg"], args.extras_seconds)
             emit()
-            os._exit(0)
+            if not args.profiled:
+                os._exit(0)
 
         if world == 1:
             threading.Thread(target=watchdog, daemon=True).start()
@@ -533,7 +538,8 @@ def main():
                 res["with_work_budget"] = leg_budget()
         emit()
         sys.stdout.flush()
-        os._exit(0) if world == 1 else None
+        if world == 1 and not args.profiled:
+            os._exit(0)                                              # (tearing six contexts down takes seconds the driver's clock would count)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -100,10 +100,11 @@ __device__ __noinline__ uint32_t fr_find8(const uint8_t* S, uint32_t from, uint3
   }
   return FR_NONE;
 }
-// The best cut of S[0, n) for searches of at most R bytes' depth: *u, *D (bytes [u, u + D) can go); false: nothing worth it.
+// The best cut of S[0, n) for searches of at most R bytes' depth: *u, *D (bytes [u, u + D) can go; *cP: the period: S[k] == S[k + P]
+// for k in [u - P, u + D + R - P)); false: nothing worth it.
 // Anchors at the eighths of the list: the 8 bytes there, their next occurrences as period candidates, the stretch each holds for.
-__device__ __noinline__ bool fr_find_cut(const uint8_t* S, uint32_t n, uint32_t R, uint32_t* cu, uint32_t* cD) {
-  uint32_t bestD = 0, bestU = 0, blo = 0, bhi = 0;
+__device__ __noinline__ bool fr_find_cut(const uint8_t* S, uint32_t n, uint32_t R, uint32_t* cu, uint32_t* cD, uint32_t* cP = nullptr) {
+  uint32_t bestD = 0, bestU = 0, blo = 0, bhi = 0, bestP = 0;
   if (n < 4096) return false;
   bool any = false;                                                  // some anchor's bytes came again at all
   for (uint32_t ai = 0; ai < 7; ai++) {
@@ -126,7 +127,7 @@ __device__ __noinline__ bool fr_find_cut(const uint8_t* S, uint32_t n, uint32_t 
       const uint32_t u = lo + p, b = hi + p;                          // S[k] == S[k + p] on [lo, hi)
       if (b > u + R && b - u - R >= p) {
         const uint32_t D = (b - R - u) / p * p;
-        if (D > bestD) { bestD = D; bestU = u; blo = lo; bhi = b; }
+        if (D > bestD) { bestD = D; bestU = u; blo = lo; bhi = b; bestP = p; }
       }
       if (bestD >= n / 2) break;
       y++;
@@ -135,6 +136,7 @@ __device__ __noinline__ bool fr_find_cut(const uint8_t* S, uint32_t n, uint32_t 
   }
   if (bestD < 2048 || bestD < n / 8) return false;
   *cu = bestU; *cD = bestD;
+  if (cP) *cP = bestP;
   return true;
 }
 // S[0, *n) -> a shortened copy in the work area (or S itself, untouched, when no cut is worth it); *n its length.  nullptr: work area exhausted.

@@ -110,9 +110,11 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   constexpr uint32_t SG_EVC = 4096, SG_EVBACK = 512;
   uint32_t cbase = 0xFFFFFFFFu;                                            // events [cbase, cbase + SG_EVC) are in g_fuse_lds
   uint32_t bev = 0, bbase = 0xFFFFFFFFu;                                   // lane k holds event bbase + k
+  uint32_t reach_ev = 0;                                                  // events below this index may have been looked at (replay, below)
   auto need = [&](uint32_t i) {
     if (bbase != 0xFFFFFFFFu && i >= bbase && i < bbase + 64) return;
     bbase = i & ~63u;
+    if (bbase + 64 > reach_ev) reach_ev = bbase + 64;
     if (cbase == 0xFFFFFFFFu || bbase < cbase || bbase + 64 > cbase + SG_EVC) {
       cbase = bbase > SG_EVBACK ? bbase - SG_EVBACK : 0u;                 // (a failed tag is retried from its next '<': a little history stays)
       lanes_sync();
@@ -197,6 +199,49 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   };
   auto put = [&](const uint8_t* p, uint32_t len) { if (l == 0) { Piece q; q.ptr = (uint64_t)p; q.len = len; q.rep = 1; pc[npc] = q; } npc++; };
 
+  // ---- replay of periodic documents.  The heaviest cases of a pass are `sgm` on documents that sr / lr / sgm pumps have grown to
+  // megabytes: thousands of copies of one run of elements, ~3 000 cycles of this sequential machine per tag.  Right after an accepted
+  // tag the machine's state is a function of the position alone (text state, nothing pending), and what it does next depends only on
+  // the bytes it looks at.  So when the block is periodic around here (H[k] == H[k + P], found like eh_fuse_red.h finds its cuts) and
+  // the machine, started at s, is back in that state at exactly s + P, the tokens of [s, s + P) repeat - shifted by P - for every
+  // further period whose look-ahead stays inside the periodic stretch.  One period is tokenized as a template, the next one as a
+  // check (every token, piece and parameter must be the template's, shifted), the rest are written by the whole wave from the template.
+  uint32_t rp_P = 0, rp_lo = 0, rp_end = 0;                                // the stretch in hand: H[k] == H[k + P] for k in [rp_lo, rp_end - P)
+  int rp_state = 0, rp_tries = 0;                                          // 0 idle, 1 in the template period, 2 in the check period
+  // A document may hold several stretches (an element nested a thousand times: a run of open tags, a run of close tags; a block pumped
+  // twice).  Stretches are found best-first in what lies ahead (fr_find_cut: anchors at the eighths), then, when the best one starts far
+  // ahead, in the gap before it; they are replayed in the order the machine reaches them.  At most 8 searches per document.
+  uint32_t rq_lo[4], rq_end[4], rq_P[4]; int rq_n = 0, rp_budget = 8; uint32_t rp_scan_from = 0;
+  auto rp_detect = [&](uint32_t a, uint32_t b) -> bool {                   // the best stretch of H[a, b) goes onto the stack
+    if (rp_budget <= 0 || rq_n >= 4 || b <= a || b - a < 16384u) return false;
+    rp_budget--;
+    uint32_t u = 0, D = 0, P = 0;
+    const bool found = fr_find_cut(H + a, b - a, 0, &u, &D, &P) && P > 0;
+#ifdef EH_PROF
+    if (l == 0) { atomicAdd(&c.p->prof[2 * 95 + 1], 1ull); atomicAdd(&c.p->prof[2 * 95], found ? 1ull : 0ull); }      // searches, stretches found
+#endif
+    if (!found) return false;
+    rq_lo[rq_n] = a + u - P; rq_end[rq_n] = a + u + D; rq_P[rq_n] = P; rq_n++;
+    return true;
+  };
+  auto rp_load = [&](uint32_t at) {                                        // the next stretch the machine, now at byte `at`, will reach
+    rp_P = 0; rp_state = 0; rp_tries = 0;
+    for (;;) {
+      while (rq_n > 0 && (uint64_t)at + 4ull * rq_P[rq_n - 1] > rq_end[rq_n - 1]) rq_n--;        // behind us (or too little of it left)
+      if (rq_n == 0) {
+        const uint32_t from = at > rp_scan_from ? at : rp_scan_from;
+        if (!rp_detect(from, L)) return;
+        rp_scan_from = rq_end[rq_n - 1];
+        continue;
+      }
+      const int top = rq_n - 1;
+      if (rq_lo[top] > at && rq_lo[top] - at >= 32768u && rp_detect(at, rq_lo[top])) continue;   // something earlier in the gap
+      rp_P = rq_P[top]; rp_lo = rq_lo[top]; rp_end = rq_end[top]; rq_n--;
+      return;
+    }
+  };
+  if (L >= 16384 && nlt >= 64 && !(c.p->flags & EH_FLAG_SGML_NO_REPLAY)) rp_load(0);
+  uint32_t rp_s0 = 0, rp_tok0 = 0, rp_pc0 = 0, rp_par0 = 0, rp_e0 = 0, rp_dtok = 0, rp_dpc = 0, rp_dpar = 0, rp_de = 0, rp_reach1 = 0;
   // memo of attribute-loop entries of failed attempts (see above)
   uint8_t* bad = nullptr; uint32_t* chain = nullptr; uint32_t nchain = 0;
   int rc = 0;
@@ -334,6 +379,91 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
       ntok++;
       first = false;
       pos = next; ei = nexte; seg_start = next; text_p0 = npc; text_len = 0;
+      if (rp_P) {                                                          // ---- replay (see above): this is the state "right after an accepted tag"
+        if (rp_state == 1 && pos == rp_s0 + rp_P) {                        // the template period is complete
+          rp_dtok = ntok - rp_tok0; rp_dpc = npc - rp_pc0; rp_dpar = npar - rp_par0; rp_de = ei - rp_e0; rp_reach1 = reach_ev; rp_state = 2;
+          reach_ev = (bbase != 0xFFFFFFFFu && bbase + 64 > ei) ? bbase + 64 : ei;   // (the lane window that is loaded counts as looked at)
+        } else if (rp_state == 2 && pos == rp_s0 + 2u * rp_P) {            // the check period is complete
+          wave_sync();                                                     // (lane 0's stores of the two periods are read below)
+          bool same = ntok - rp_tok0 == 2u * rp_dtok && npc - rp_pc0 == 2u * rp_dpc && npar - rp_par0 == 2u * rp_dpar && ei - rp_e0 == 2u * rp_de && rp_dtok > 0;
+          const uint64_t h0 = (uint64_t)(uintptr_t)H, h1 = h0 + L;
+          if (same) {
+            bool ne = false;
+            for (uint32_t t = l; t < rp_dtok; t += 64) {
+              SgTok a = tok[rp_tok0 + t], b = tok[rp_tok0 + rp_dtok + t];
+              const bool text = (a.kind & TK_KIND) == TK_TEXT;
+              const uint32_t sh = text ? 0u : rp_P, shp = text ? 0u : rp_dpar;
+              ne |= b.kind != a.kind || b.p0 != a.p0 + rp_dpc || b.np != a.np || b.na != a.na + sh || b.nb != a.nb + sh || b.par0 != a.par0 + shp || b.npar != a.npar;
+            }
+            for (uint32_t t = l; t < rp_dpc; t += 64) {
+              Piece a = pc[rp_pc0 + t], b = pc[rp_pc0 + rp_dpc + t];
+              const bool inblk = a.ptr >= h0 && a.ptr < h1;
+              ne |= b.len != a.len || b.rep != a.rep || b.ptr != a.ptr + (inblk ? rp_P : 0u);
+            }
+            for (uint32_t t = l; t < rp_dpar; t += 64) {
+              SgParam a = par[rp_par0 + t], b = par[rp_par0 + rp_dpar + t];
+              ne |= b.na != a.na + rp_P || b.nb != a.nb + rp_P || b.va != a.va + rp_P || b.vb != a.vb + rp_P || b.delim != a.delim;
+            }
+            same = __ballot(ne) == 0;
+          }
+          // how far ahead of its start a period looked (events -> bytes; a search that ran to the end of the block leaves none to replay)
+          uint32_t r1 = rp_reach1 > rp_e0 ? rp_reach1 : rp_e0, r2 = reach_ev > rp_e0 + rp_de ? reach_ev : rp_e0 + rp_de;
+          uint32_t b1 = r1 >= nev ? L : (evget(r1) >> 4), b2 = r2 >= nev ? L : (evget(r2) >> 4);
+          uint32_t rel1 = b1 - rp_s0, rel2 = b2 - (rp_s0 + rp_P);
+          uint32_t rel = (rel1 > rel2 ? rel1 : rel2) + 4u;                 // (+ the bytes a class looks ahead: "/>", "?>", "-->")
+          uint32_t J = 0;
+          if (same && rp_end > rp_s0 + rel) J = (rp_end - rel - rp_s0) / rp_P;   // periods 0 .. J-1 see only bytes of the periodic stretch
+          if (J > 3) {
+            const uint32_t N = J - 2u;
+            if ((uint64_t)npc + (uint64_t)N * rp_dpc + 16 > cap_pc || (uint64_t)ntok + (uint64_t)N * rp_dtok + 2 > cap_tok || (uint64_t)npar + (uint64_t)N * rp_dpar + 1 > cap_par) { EH_SET_OVERFLOW(c, 603); return -3; }
+            for (uint64_t idx = l; idx < (uint64_t)N * rp_dtok; idx += 64) {
+              const uint32_t j = 2u + (uint32_t)(idx / rp_dtok), t = (uint32_t)(idx % rp_dtok);
+              SgTok a = tok[rp_tok0 + t];
+              const bool text = (a.kind & TK_KIND) == TK_TEXT;
+              a.p0 += j * rp_dpc;
+              if (!text) { a.na += j * rp_P; a.nb += j * rp_P; a.par0 += j * rp_dpar; }
+              tok[rp_tok0 + j * rp_dtok + t] = a;
+            }
+            for (uint64_t idx = l; idx < (uint64_t)N * rp_dpc; idx += 64) {
+              const uint32_t j = 2u + (uint32_t)(idx / rp_dpc), t = (uint32_t)(idx % rp_dpc);
+              Piece a = pc[rp_pc0 + t];
+              if (a.ptr >= h0 && a.ptr < h1) a.ptr += (uint64_t)j * rp_P;
+              pc[rp_pc0 + j * rp_dpc + t] = a;
+            }
+            for (uint64_t idx = l; idx < (uint64_t)N * rp_dpar; idx += 64) {
+              const uint32_t j = 2u + (uint32_t)(idx / rp_dpar), t = (uint32_t)(idx % rp_dpar);
+              SgParam a = par[rp_par0 + t];
+              a.na += j * rp_P; a.nb += j * rp_P; a.va += j * rp_P; a.vb += j * rp_P;
+              par[rp_par0 + j * rp_dpar + t] = a;
+            }
+            wave_sync();
+#ifdef EH_PROF
+            if (l == 0) { atomicAdd(&c.p->prof[2 * 94], (unsigned long long)N * rp_dtok); atomicAdd(&c.p->prof[2 * 94 + 1], 1ull); }   // tokens written by replay, replays
+#endif
+            ntok += N * rp_dtok; npc += N * rp_dpc; npar += N * rp_dpar;
+            pos = rp_s0 + J * rp_P; ei = rp_e0 + J * rp_de;
+            seg_start = pos; text_p0 = npc; text_len = 0;
+            bbase = 0xFFFFFFFFu;
+          }
+#ifdef EH_PROF
+          if (l == 0 && J <= 3) { atomicAdd(&c.p->prof[2 * 99 + 1], 1ull); atomicAdd(&c.p->prof[2 * 99], same ? 1ull : 0ull); }   // checked but not replayed; of them: look-ahead too long
+#endif
+          rp_load(pos);                                                    // this stretch is done; is there another one ahead?
+        } else if (rp_state != 0 && pos > rp_s0 + (uint32_t)rp_state * rp_P) {
+          rp_state = 0;                                                    // the machine was not back in this state a period later: try from here
+          if (++rp_tries >= 8) {
+            rp_load(rp_end);
+#ifdef EH_PROF
+            if (l == 0) atomicAdd(&c.p->prof[2 * 89 + 1], 1ull);        // gave up: never back in the state a period later
+#endif
+          }
+        }
+        if (rp_P && rp_state == 0 && (uint64_t)pos + 4ull * rp_P > rp_end) rp_load(pos);          // walked past it
+        if (rp_P && rp_state == 0 && pos >= rp_lo + rp_P && (uint64_t)pos + 4ull * rp_P <= rp_end) {
+          rp_state = 1; rp_s0 = pos; rp_tok0 = ntok; rp_pc0 = npc; rp_par0 = npar; rp_e0 = ei;
+          reach_ev = (bbase != 0xFFFFFFFFu && bbase + 64 > ei) ? bbase + 64 : ei;
+        }
+      }
     } else {
       if (first) { rc = other ? -2 : -1; break; }
       if (nchain > 0) {                                                    // remember where this attempt entered the attribute loop

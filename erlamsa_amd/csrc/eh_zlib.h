@@ -526,7 +526,12 @@ __device__ __noinline__ int zi_blocks(ZInf& z) {
 //  next call; the stream stops in both, with the same bytes written)
 
 // zlib:gunzip/1 = inflateInit2(16 + 15), inflate, inflateEnd: success only for a complete member with correct CRC-32 and ISIZE
-// (anything after it is ignored); everything else is error:data_error for the caller.  Parses the header, returns the offset of
+// (anything after it is ignored); everything else is error:data_error for the caller.
+// OTP VERSION: this is zlib:gunzip/1 of OTP 18 - 20.0 (the reference asks for "OTP 18.0+", its CI ran 18 - 23).  From OTP 20.1 on
+// gunzip/1 calls inflateInit(Z, 16 + MAX_WBITS, reset): concatenated members are ALL decoded and bytes that are not another
+// member raise data_error (the pattern then tries the zlib path and ends as {compressed, failed}).  Engine, oracle
+// (oracle.cpp otpz::gunzip) and tests/hipemu/emu_zlib.py implement the older rule alike, so parity tests cannot see the
+// difference; it only shows on inputs that are gz + gz or gz + trailing bytes.  Parses the header, returns the offset of
 // the deflate data or 0.
 EH_DEV uint64_t zi_gzip_header(const uint8_t* p, uint64_t n, const uint32_t* crc_table) {
   if (n < 10 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xe0)) return 0;

@@ -17,6 +17,7 @@ EH_FLAG_ORDERED_OUTPUT = 1
 EH_FLAG_META_TRACE = 2
 EH_FLAG_FUSE_NO_LDS = 4
 EH_FLAG_FUSE_NO_REDUCE = 8
+EH_FLAG_SGML_NO_REPLAY = 16
 
 CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BUDGET = 0, 1, 2, 3, 4, 5
 

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""erlamsa_sgml:sgml_mutate/2 on periodic documents three ways: the tokenizer replaying one period's tokens (csrc/eh_sgml.h, the
+default for blocks of 16 KiB and more), walking them tag by tag (EH_FLAG_SGML_NO_REPLAY) and the oracle.  Documents: a run of
+elements repeated many times - plain, with attributes in every quoting style, comments, processing instructions, failed tags whose
+white space is eaten, text between the tags -, a period that starts in the middle of a tag, a stretch followed by an unterminated
+quote or comment (look-ahead to the end of the block: nothing may be replayed), a stretch too short to replay.
+Bytes, statuses and PRNG draw counts must agree.
+
+  python tests/hipemu/build_emu.py && ERLAMSA_HIP_LIB=build/liberlamsa_hip_emu.so python tests/hipemu/emu_sgml_replay.py [n] [seed] [scale]
+(with the real library the same comparison runs on the GPU; scale multiplies the repeat counts)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import pyoracle as po
+import erlamsa_amd as ea
+from erlamsa_amd.engine import EH_FLAG_SGML_NO_REPLAY
+
+UNITS = [
+    b"<a>x</a>", b"<b k='v' j=\"w\" u=z>text <i/> more</b>\n", b"<c  x = 'q q' ><d/></c> ", b"<!-- note --><e>1</e>", b"<?pi data?><f g=h>t</f>",
+    b"< g>lost white space</g>", b"<h a b c>t</h>", b"plain text without tags ", b"<i j='k'>l<m n=\"o\"/>p</i>\r\n\t", b"<q =bad>r</q><s>t</s>",
+    b"<u v='w>x</u>' y>z</u>", b"</stray><t>u</t>", b"<x/><y /><z  />",
+]
+
+
+def corpus(n, seed, scale=1):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    for k in range(n):
+        def unit():
+            return b"".join(UNITS[int(j)] for j in rng.integers(0, len(UNITS), size=int(rng.integers(1, 5))))
+        u = unit()
+        reps = int(rng.integers(200, 900)) * scale
+        head = b"<doc>" + unit() * int(rng.integers(0, 4))
+        tail = unit() * int(rng.integers(0, 4)) + b"</doc>"
+        out.append(head + u * reps + tail)                                                 # plain pump
+        cut = int(rng.integers(1, max(2, len(u) - 1)))
+        out.append(head + u[cut:] + u * reps + u[:cut] + tail)                             # the period starts inside a tag / text
+        out.append(head + u * reps + b"<v w='unterminated " + unit() * 3)                  # a quote that never ends behind the stretch
+        out.append(head + u * reps + b"<!-- never closed " + unit() * 3)
+        out.append(head + u * (16384 // len(u) + 3) + tail)                                # barely long enough / too short to replay
+        out.append((head + u * reps + tail) * 2)                                           # two stretches of the same period
+    return out
+
+
+def run(n=1, seed=1, scale=1, pats="od,nd,bu", verbose=True):
+    inputs = corpus(n, seed, scale)
+    data, off = po.pack(inputs)
+    res = {}
+    for name, flags in (("replay", 0), ("walk", EH_FLAG_SGML_NO_REPLAY)):
+        t = time.time()
+        e = ea.Engine(0)
+        e.configure(mutations="sgm", patterns=pats, max_case_bytes=64 << 20, flags=flags)
+        e.upload_corpus(data, off)
+        e.fuzz_batch(seed=(seed, 6, 2))
+        got, st = e.download()
+        dr, _ = e.diag()
+        res[name] = (got, st, dr, time.time() - t)
+        e.close()
+    import util
+    t = time.time()
+    o = util.oracle_live(data, off, seed=(seed, 6, 2), mutations="sgm", patterns=pats, max_case_bytes=256 << 20, chunk=1)
+    to = time.time() - t
+    bad = 0
+    a, b = res["replay"], res["walk"]
+    for i in range(len(inputs)):
+        if a[1][i] in (2, 3) or o.status[i] in (2, 3):
+            continue
+        ok_o = a[0][i] == o.outs[i] and a[1][i] == o.status[i] and (a[1][i] != 0 or a[2][i] == o.draws[i])
+        ok_n = a[0][i] == b[0][i] and a[1][i] == b[1][i] and a[2][i] == b[2][i]
+        if not (ok_o and ok_n):
+            bad += 1
+            if verbose and bad <= 8:
+                print("case %d (kind %d, len %d): replay vs oracle %s, replay vs walk %s; status %d/%d/%d draws %d/%d/%d len %d/%d/%d" % (
+                    i, i % 6, len(inputs[i]), ok_o, ok_n, a[1][i], b[1][i], o.status[i], a[2][i], b[2][i], o.draws[i], len(a[0][i]), len(b[0][i]), len(o.outs[i])))
+    if verbose:
+        print("cases %d bad %d; replay %.1f s, walk %.1f s, oracle %.1f s; input bytes %d" % (len(inputs), bad, a[3], b[3], to, sum(map(len, inputs))))
+    return len(inputs), bad
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    total, bad = run(n, seed, scale)
+    sys.exit(1 if bad else 0)

@@ -187,3 +187,35 @@ def test_sgml_tokenizer_on_documents_of_many_thousand_events():
         assert int(st[i]) == int(ora.status[i]) and got[i] == ora.outs[i] and (st[i] != 0 or int(dr[i]) == int(ora.draws[i])), \
             "document %d (%d bytes): first difference at %d" % (i, len(docs[i]), util.first_diff(got[i], ora.outs[i]))
     assert compared >= len(docs) - 2
+
+
+def test_sgml_tokenizer_replay_of_periodic_documents():
+    """csrc/eh_sgml.h replays the tokens of one period of a pumped document instead of walking thousands of copies tag by tag (what
+    the heaviest cases of the bench workload spend their time in).  Three ways on pumped documents of 20 KB to a megabyte - period
+    starting inside a tag, white space eaten by failed tags, an unterminated quote or comment behind the stretch (nothing may be
+    replayed then), two stretches, stretches barely long enough: replay vs tag-by-tag (EH_FLAG_SGML_NO_REPLAY) vs the oracle, run live."""
+    if util.priming():
+        pytest.skip("live oracle")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    import emu_sgml_replay
+    total, bad = emu_sgml_replay.run(n=4, seed=5, scale=2, verbose=True)
+    assert total == 24 and bad == 0
+    total, bad = emu_sgml_replay.run(n=2, seed=9, scale=12, pats="od", verbose=True)
+    assert bad == 0
+
+
+def test_fuse_paths_agree_on_the_device():
+    """erlamsa_fuse:fuse/2 has four routes through the engine (csrc/eh_fuse_lds.h, eh_fuse_red.h in front of eh_fuse.h / eh_fuse2.h).
+    The differential scripts the routes were developed with, on the GPU: LDS-resident vs node lists vs oracle on the corner corpora,
+    shortened lists vs the lists as they are vs oracle on pumped blocks (and, larger, against each other)."""
+    if util.priming():
+        pytest.skip("live oracle")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    import emu_fuse_lds
+    import emu_fuse_red
+    total, bad = emu_fuse_lds.run(n=8, seed=23, verbose=True)
+    assert total == 64 and bad == 0
+    total, bad = emu_fuse_red.run(n=3, seed=29, verbose=True)
+    assert total == 24 and bad == 0
+    total, bad = emu_fuse_red.run(n=2, seed=31, big=8, with_oracle=False, verbose=True)
+    assert bad == 0

@@ -27,4 +27,6 @@ for i in cases:
     for k in range(64, 128):
         if pr[2 * k + 1] > 0 and pr[2 * k] > 10e6:
             print("    slot %3d calls %7d total %9.1f Mcyc mean %9.1f kcyc" % (k, pr[2 * k + 1], pr[2 * k] / 1e6, pr[2 * k] / pr[2 * k + 1] / 1e3))
+    print("    sgm replay: large documents %d, periodic %d, replays %d (tokens %d), checked but not replayed %d (look-ahead too long %d), gave up aligning %d" % (
+        pr[2 * 95 + 1], pr[2 * 95], pr[2 * 94 + 1], pr[2 * 94], pr[2 * 99 + 1], pr[2 * 99], pr[2 * 89 + 1]))
     sys.stdout.flush()

@@ -3,10 +3,10 @@
 # each for FETCH_SIZE, WRITE_SIZE, the SQ set and the instruction-cache set, on ONE pass at a time (--inflight 1: the
 # counters serialise dispatches anyway; never combined with trace domains).
 # usage: tools/profile_round.sh r03   -> gpurun_out/{prof_<tag>,pmc_*}
-tag=${1:-r03}
+tag=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --cpu-sample 0 --budget-mib 0 --pcie 0"
+B="python $R/bench.py --profiled 1 --cpu-sample 0 --budget-mib 0 --pcie 0"
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_$tag -o $tag -- $B --steps 12 --warmup 3 > $R/gpurun_out/prof_${tag}_bench.log 2>&1
 tail -1 $R/gpurun_out/prof_${tag}_bench.log | cut -c1-200
 P="$B --inflight 1 --steps 1 --warmup 0"

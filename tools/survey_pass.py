@@ -68,5 +68,7 @@ if pr.sum() > 0:
 
     print("  large fuse calls that ran on shortened lists (eh_fuse_red.h): %d (finding + making the cuts: mean %.0f kcyc), that found no cut worth it: %d (mean %.0f kcyc)   # fuse_red" % (
         pr[2 * 97 + 1], pr[2 * 97] / max(pr[2 * 97 + 1], 1) / 1e3, pr[2 * 98 + 1], pr[2 * 98] / max(pr[2 * 98 + 1], 1) / 1e3))
+    print("  sgm tokenizer replays of periodic documents: %d, tokens written by them: %d" % (pr[2 * 94 + 1], pr[2 * 94]))
+    print("  sgm replay: large documents %d, periodic %d; checked but not replayed %d (of them look-ahead too long %d); gave up aligning %d" % (pr[2 * 95 + 1], pr[2 * 95], pr[2 * 99 + 1], pr[2 * 99], pr[2 * 89 + 1]))
     print("  sgm phases: tokenizer %d calls mean %.0f kcyc total %.1f Gcyc; pairing+flags total %.1f Gcyc; edit script total %.1f Gcyc; gather total %.1f Gcyc" % (
         pr[2 * 90 + 1], pr[2 * 90] / max(pr[2 * 90 + 1], 1) / 1e3, pr[2 * 90] / 1e9, pr[2 * 91] / 1e9, pr[2 * 92] / 1e9, pr[2 * 93] / 1e9))
