@@ -90,6 +90,12 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
     nlt += lts; nstop += stops;
   }
   nlt = wave_sum(nlt); nstop = wave_sum(nstop);
+#ifdef EH_PROF
+  uint64_t tz_t0 = __builtin_readcyclecounter();
+#define SG_TZ(k) do { uint64_t n_ = __builtin_readcyclecounter(); if (l == 0) { atomicAdd(&c.p->prof[2 * (k)], (unsigned long long)(n_ - tz_t0)); atomicAdd(&c.p->prof[2 * (k) + 1], 1ull); } tz_t0 = n_; } while (0)
+#else
+#define SG_TZ(k) do {} while (0)
+#endif
   if (nlt == 0) return -1;                                                 // tz(nil, <<>>) :102
   // capacity: tokens <= 2 x '<' + 2; a parameter needs a byte of the stop set after its name
   uint32_t cap_tok = 2 * nlt + 8, cap_par = nstop + 8;
@@ -254,6 +260,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   }
   for (;;) {
     if (npc + 16 > cap_pc || ntok + 2 > cap_tok) { EH_SET_OVERFLOW(c, 601); return -3; }
+    SG_TZ(86);                                                             // eh_result_prof 86: text state + bookkeeping between attempts
     // ---- one tag attempt: '<' at lt, pos/ei just behind it
     skipws();
     const uint32_t tag0 = pos, ei0 = ei, tag_p0 = npc, par0 = npar;
@@ -367,6 +374,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
       }
     } while (false);
     if (c.status != CASE_OK) return -3;
+    if (ok) SG_TZ(88); else SG_TZ(87);                                     // 88: accepted tags, 87: failed attempts
     if (ok) {
       // the text before the tag (if any) and the tag itself
       if (!first) {

@@ -27,6 +27,8 @@ for i in cases:
     for k in range(64, 128):
         if pr[2 * k + 1] > 0 and pr[2 * k] > 10e6:
             print("    slot %3d calls %7d total %9.1f Mcyc mean %9.1f kcyc" % (k, pr[2 * k + 1], pr[2 * k] / 1e6, pr[2 * k] / pr[2 * k + 1] / 1e3))
+    print("    sgm tokenizer phase 2: between attempts %.1f Mcyc x%d, failed attempts %.1f Mcyc x%d (mean %.1f kcyc), accepted tags %.1f Mcyc x%d (mean %.1f kcyc)" % (
+        pr[2 * 86] / 1e6, pr[2 * 86 + 1], pr[2 * 87] / 1e6, pr[2 * 87 + 1], pr[2 * 87] / max(pr[2 * 87 + 1], 1) / 1e3, pr[2 * 88] / 1e6, pr[2 * 88 + 1], pr[2 * 88] / max(pr[2 * 88 + 1], 1) / 1e3))
     print("    sgm replay: large documents %d, periodic %d, replays %d (tokens %d), checked but not replayed %d (look-ahead too long %d), gave up aligning %d" % (
         pr[2 * 95 + 1], pr[2 * 95], pr[2 * 94 + 1], pr[2 * 94], pr[2 * 99 + 1], pr[2 * 99], pr[2 * 89 + 1]))
     sys.stdout.flush()
