@@ -115,6 +115,17 @@ def test_emulated_container_patterns(emu_lib):
     assert r.returncode == 0 and "containers ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_emulated_fuse_routes_agree(emu_lib):
+    """Round 4's fuse routes on the emulator: LDS-resident vs node lists vs oracle on the corner corpora (csrc/eh_fuse_lds.h), lists
+    with their periodic stretches cut short vs the lists as they are vs oracle (csrc/eh_fuse_red.h).  The GPU runs the same scripts
+    with more cases (tests/test_gpu_round4.py)."""
+    env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_fuse_lds.py"), "1", "3"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_fuse_red.py"), "1", "3"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout + r.stderr
+
+
 def test_emulated_race_detector_finds_no_cross_lane_access_without_a_rendezvous():
     """The engine built with every load / store of the kernel code instrumented (build_emu.py --race, tests/hipemu/race_hooks.cpp):
     between two rendezvous points no lane reads what another lane wrote or overwrites what another lane read - the class of bug
