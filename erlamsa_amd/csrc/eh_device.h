@@ -280,8 +280,13 @@ __shared__ Ctx g_ctx;
 // __shared__ as wave-uniform state, so there the array is plain memory (one wavefront runs at a time).
 #ifdef HIPEMU
 #define EH_LDS_ARRAY(type, name, n) static type name[n]
+#define EH_KEEP(v) do {} while (0)
 #else
 #define EH_LDS_ARRAY(type, name, n) __shared__ type name[n]
+// The value is used here, as far as the optimizer can tell: a load that produced it stays where it is.  (An LDS load and a global load in
+// the two arms of a condition are otherwise merged into ONE load through a generic pointer: slower, and it has sent this compiler's
+// back end into "Illegal instruction detected".)
+#define EH_KEEP(v) asm volatile("" : "+v"(v))
 #endif
 // orders LDS accesses of different lanes of the wavefront.  The hardware runs a wavefront's LDS instructions in
 // program order, so nothing is emitted; on the emulator the ballot is a rendezvous of the lane fibers.

@@ -182,8 +182,10 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
   const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
   LexChunk* tab;
+  EH_PT0;
   int n = lex_cached(c, lc, H, L, &tab);
   if (n < 0) return 0;
+  EH_PT(c, 48);                                                  // eh_result_prof 48..53: lexing, candidates refused, decode, nested call, encode, gather
   uint32_t snand_mask = rng_rand(c.rng, 3); (void)rng_rand(c.rng, 1);   // mutations([]) :661 -> :1313-1314
   Piece* out = nullptr; uint32_t nout = 0, cap = 0, done_to = 0;
   int dacc = -1;
@@ -197,17 +199,21 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
     int cj = (int)__builtin_ctzll(cand); cand &= cand - 1;
     int i = base + cj;
     uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)ca, cj), b = (uint32_t)__builtin_amdgcn_readlane((int)cb, cj);
-    if (!b64_accepts(H + a, b - a)) continue;                    // error:badarg / function_clause :677-684
-    int dl = b64_decode(H + a, b - a, nullptr);
+    uint32_t nalpha, span;
+    if (!b64_accepts(H + a, b - a, &nalpha, &span)) continue;    // error:badarg / function_clause :677-684
+    uint32_t dl = b64_decoded_len(nalpha);
     if (!out) {                                                  // first hit: the piece list of unlex(Ms)
       cap = 2 * (uint32_t)(n - i) + 4;
       out = (Piece*)ws_alloc(c, (uint64_t)cap * sizeof(Piece));
       if (!out) return 0;
     }
     uint8_t* dec = ws_alloc(c, (uint64_t)dl + 16);
-    if (!dec) return 0;
-    (void)b64_decode(H + a, b - a, dec);
+    uint8_t* pack = nalpha != span ? ws_alloc(c, (uint64_t)nalpha + 16) : nullptr;
+    if (!dec || (nalpha != span && !pack)) return 0;
+    EH_PT(c, 49);
+    b64_decode_wave(H + a, span, nalpha, dec, pack);
     wave_sync();
+    EH_PT(c, 50);
     int d = rng_delta(c.rng);                                    // :666
     // mutators_mutator(MutasList, []) :667: rand(10) per table entry in table order, each prepended
     uint32_t name = l < (int)M_COUNT ? (uint32_t)((int)M_COUNT - 1 - l) : 0;
@@ -216,8 +222,9 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
     rng_skip(c.rng, (uint64_t)M_COUNT);
     uint32_t e_pri = l < (int)M_COUNT ? (uint32_t)c_def_pri[name] : 0;
     uint32_t e_meta = em_pack(score, name, name, name == M_SNAND ? snand_mask : 3u);
-    int nres = nested_fuzz(c, e_pri, e_meta, (int)M_COUNT, dec, (uint32_t)dl);   // Muta([Bin], []) :668
+    int nres = nested_fuzz(c, e_pri, e_meta, (int)M_COUNT, dec, dl);   // Muta([Bin], []) :668
     if (nres < 0) return 0;
+    EH_PT(c, 51);
     // NewBin = iolist_to_binary(NewLl) :669
     uint64_t tot = 0;
     for (int k = 0; k < nres; k++) tot += blk_load(c.bl, c.nb + k).len;
@@ -234,8 +241,10 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
     piece_put(out, nout, enc, (uint32_t)((tot + 2) / 3 * 4)); nout++;
     done_to = b;
     dacc += d;
+    EH_PT(c, 52);
    }
   }
+  EH_PT(c, 49);
   if (!out) return -1;                                           // nothing decoded: unlex(lex(H)) =:= H
   piece_put(out, nout, H + done_to, L - done_to); nout++;
   wave_sync();
@@ -245,6 +254,7 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
   if (!dst) return 0;
   wave_gather(dst, out, nout);
   wave_sync();
+  EH_PT(c, 53);
   c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)total;
   return dacc;
 }

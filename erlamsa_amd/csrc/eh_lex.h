@@ -369,46 +369,13 @@ EH_DEV bool has_zip_eocd(const uint8_t* H, uint32_t L) {
   return __ballot(found != 0) != 0;
 }
 // base64:decode/1 acceptance (stdlib, restated in oracle/otp_compat.h): groups of four sextets, "xx==" / "xxx="
-// tails, white space skipped anywhere, only white space after the padding.  Returns the decoded length or -1;
-// with dst != nullptr lane 0 also writes the bytes.
-EH_DEV int b64_decode(const uint8_t* t, uint32_t n, uint8_t* dst) {
-  int res = -1;
-  if (EH_LANE == 0) {
-    uint32_t i = 0, o = 0; bool good = true, done = false;
-    while (!done) {
-      uint32_t q = 0, acc = 0; bool eq = false;
-      while (i < n && q < 4) {
-        uint32_t ch = t[i];
-        if (ch == 9 || ch == 10 || ch == 13 || ch == 32) { i++; continue; }
-        if (ch == '=') { eq = true; break; }
-        uint32_t v;
-        if (ch >= 'A' && ch <= 'Z') v = ch - 'A'; else if (ch >= 'a' && ch <= 'z') v = ch - 'a' + 26; else if (ch >= '0' && ch <= '9') v = ch - '0' + 52;
-        else if (ch == '+') v = 62; else if (ch == '/') v = 63; else { good = false; break; }
-        acc = (acc << 6) | v; q++; i++;
-      }
-      if (!good) break;
-      if (q == 4) { if (dst) { dst[o] = (uint8_t)(acc >> 16); dst[o + 1] = (uint8_t)(acc >> 8); dst[o + 2] = (uint8_t)acc; } o += 3; continue; }
-      if (!eq) { good = (q == 0); break; }                       // input exhausted
-      if (q == 2) {
-        i++; while (i < n && (t[i] == 9 || t[i] == 10 || t[i] == 13 || t[i] == 32)) i++;
-        if (i >= n || t[i] != '=') { good = false; break; }
-        i++;
-        if (dst) dst[o] = (uint8_t)(acc >> 4);
-        o += 1;
-      } else if (q == 3) { i++; if (dst) { dst[o] = (uint8_t)(acc >> 10); dst[o + 1] = (uint8_t)(acc >> 2); } o += 2; }
-      else { good = false; break; }
-      while (i < n) { uint32_t ch = t[i]; if (!(ch == 9 || ch == 10 || ch == 13 || ch == 32)) { good = false; break; } i++; }
-      done = true;
-    }
-    res = good ? (int)o : -1;
-  }
-  return (int)uni((uint32_t)__shfl(res, 0));
-}
-// The same acceptance test, wave-parallel and without decoding: 64 bytes per step are classified (alphabet, white
-// space, '=', other) with ballots; everything before the first '=' must be alphabet or white space, the number of
-// alphabet characters there decides which padding is legal.  Almost every text chunk fails within its first step,
-// which is what keeps b64 cheap as a failing probe.
-EH_DEV bool b64_accepts(const uint8_t* t, uint32_t n) {
+// tails, white space skipped anywhere, only white space after the padding.  Wave-parallel and without decoding:
+// 64 bytes per step are classified (alphabet, white space, '=', other) with ballots; everything before the first
+// '=' must be alphabet or white space, the number of alphabet characters there decides which padding is legal.
+// Almost every text chunk fails within its first step, which is what keeps b64 cheap as a failing probe.
+// On acceptance *nalpha = alphabet characters before the padding and *span = the bytes they sit in (offset of the
+// first '=' or n): the decoded length is nalpha / 4 * 3 + {0, -, 1, 2}[nalpha % 4].
+EH_DEV bool b64_accepts(const uint8_t* t, uint32_t n, uint32_t* nalpha_out, uint32_t* span_out) {
   const int l = EH_LANE;
   uint32_t nalpha = 0, eqpos = 0xFFFFFFFFu;
   for (uint32_t base = 0; base < n && eqpos == 0xFFFFFFFFu; base += 64) {
@@ -423,6 +390,7 @@ EH_DEV bool b64_accepts(const uint8_t* t, uint32_t n) {
     if (em) eqpos = base + (uint32_t)__builtin_ctzll(em);
   }
   uint32_t q = nalpha & 3u;
+  *nalpha_out = nalpha; *span_out = eqpos == 0xFFFFFFFFu ? n : eqpos;
   if (eqpos == 0xFFFFFFFFu) return q == 0;
   if (q != 2 && q != 3) return false;
   // after the first '=': q == 2 needs one more '=' (white space may sit in between), then only white space
@@ -439,6 +407,42 @@ EH_DEV bool b64_accepts(const uint8_t* t, uint32_t n) {
     }
   }
   return ok && need == 0;
+}
+EH_DEV uint32_t b64_decoded_len(uint32_t nalpha) { uint32_t q = nalpha & 3u; return nalpha / 4 * 3 + (q == 2 ? 1u : (q == 3 ? 2u : 0u)); }
+EH_DEV uint32_t b64_sextet(uint32_t ch) {
+  return ch >= 'a' ? ch - 'a' + 26 : (ch >= 'A' ? ch - 'A' : (ch >= '0' ? ch - '0' + 52 : (ch == '+' ? 62u : 63u)));
+}
+// The bytes of an accepted chunk (b64_accepts: nalpha alphabet characters within t[0, span), the rest of the span white
+// space).  A chunk with white space inside is first packed into pack[0, nalpha) (ballot ranks, 64 bytes per step); then
+// lane g turns the g-th group of four characters into three bytes, the last lane the "xx" / "xxx" tail.  dst holds
+// b64_decoded_len(nalpha) bytes.  (Round 3 decoded on lane 0, byte by byte: the longest case of the bench workload
+// spent 9 of its 9.2 Gcyc there, on megabytes of repeated base64 lines - profiles/r04_heaviest_cases.txt.)
+EH_DEV void b64_decode_wave(const uint8_t* t, uint32_t span, uint32_t nalpha, uint8_t* dst, uint8_t* pack) {
+  const int l = EH_LANE;
+  const uint8_t* src = t;
+  if (nalpha != span) {
+    uint32_t cnt = 0;
+    for (uint32_t base = 0; base < span; base += 64) {
+      uint32_t i = base + (uint32_t)l; bool in = i < span;
+      uint32_t ch = in ? t[i] : 32u;
+      bool al = in && !(ch == 9 || ch == 10 || ch == 13 || ch == 32);
+      unsigned long long am = __ballot(al);
+      if (al) pack[cnt + (uint32_t)__popcll(am & ((1ull << l) - 1))] = (uint8_t)ch;
+      cnt += (uint32_t)__popcll(am);
+    }
+    wave_sync();
+    src = pack;
+  }
+  uint32_t ng = nalpha / 4, q = nalpha & 3u;
+  for (uint32_t g = (uint32_t)l; g < ng; g += 64) {
+    uint32_t v = (b64_sextet(src[4 * g]) << 18) | (b64_sextet(src[4 * g + 1]) << 12) | (b64_sextet(src[4 * g + 2]) << 6) | b64_sextet(src[4 * g + 3]);
+    dst[3 * g] = (uint8_t)(v >> 16); dst[3 * g + 1] = (uint8_t)(v >> 8); dst[3 * g + 2] = (uint8_t)v;
+  }
+  if (l == 63 && q >= 2) {
+    uint32_t v = (b64_sextet(src[4 * ng]) << 6) | b64_sextet(src[4 * ng + 1]);        // 12 bits
+    if (q == 2) dst[3 * ng] = (uint8_t)(v >> 4);
+    else { v = (v << 6) | b64_sextet(src[4 * ng + 2]); dst[3 * ng] = (uint8_t)(v >> 10); dst[3 * ng + 1] = (uint8_t)(v >> 2); }
+  }
 }
 // base64:encode_to_string/1: lane g encodes the g-th 3-byte group
 EH_DEV void b64_encode(const uint8_t* src, uint32_t n, uint8_t* dst) {

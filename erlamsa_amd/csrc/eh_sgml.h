@@ -49,6 +49,183 @@ constexpr uint32_t SG_TAGHEAD = 3, SG_PARPCS = 6;
 
 struct SgDoc { SgTok* tok; SgParam* par; Piece* pc; uint32_t ntok, npar, npc; };
 
+// ---- one tag attempt PER LANE (round 4) ------------------------------------------------------------------------------------------
+// An attempt of tz/2 from a '<' depends on nothing before that '<' (the machine is in its text state there), so the attempts at
+// the next 64 '<' of the block can be made at once, one per lane, as plain per-lane loops over the events (LDS window, the event
+// list in the work area outside it); which of them the machine really makes is decided afterwards (an accepted tag swallows the
+// '<' inside it).  This is sgml_tokenize's attempt (below) statement for statement.  It pays while the events are in LDS: outside
+// the window every event is a dependent global load, and a tag of thousands of attributes walked that way by one lane (tried: a
+// batch of one for such tags) took twice the time of the wave-wide machine - so a lane gives up (bail) once it has left the
+// window for more than a few events or looked at more than its budget, and the wave-wide machine, which also searches 64 events
+// per ballot, takes that '<'.
+// MODE 0 sizes the tag, MODE 1 writes its pieces and parameters, MODE 2 marks the attribute-loop entries of a failed attempt.
+// The memos of the wave-wide machine are read here and fed from here: ff (a search for one class that found nothing from event f
+// finds nothing from a later event) and bad (the attribute loop entered at byte p fails) - both facts about the block, whichever
+// attempt establishes them.
+struct SgLaneTag { uint32_t ok, bail, kind, next, nexte, tag0, lt, npc, npar, na, nb, reach, ffc, fff, unmarked; };
+struct SgLaneMemo { uint32_t gt, qgt, cmt, sq, dq; const uint8_t* bad; const uint32_t* nstop; };
+constexpr uint32_t SG_LANE_BUDGET = 8192;           // events a lane may look at in all,
+constexpr uint32_t SG_LANE_FAR = 64;                // ... of them outside the LDS window (the event list in the work area: a dependent global load each),
+constexpr uint32_t SG_LANE_SEARCH = 2048;           // ... and in one search for a single class ('>', a quote, "-->", "?>"): the wave-wide machine looks at 64 per step
+// (a function of its own: inlined three times into sgml_tokenize it cost the wave-wide machine there its registers)
+template <int MODE>
+__device__ __noinline__ SgLaneTag sg_lane_attempt(const uint8_t* H, uint32_t L, const uint32_t* ev, uint32_t nev, uint32_t cbase, uint32_t e, const SgLaneMemo& mm, Piece* pc, SgParam* par, uint8_t* mark) {
+  SgLaneTag R; R.ok = 0; R.bail = 0; R.kind = 0; R.next = 0; R.nexte = 0; R.npc = 0; R.npar = 0; R.ffc = 0; R.fff = 0; R.unmarked = 0;
+  bool bail = false; uint32_t budget = SG_LANE_BUDGET, reach = e + 1, far = 0;
+  auto EV = [&](uint32_t i) -> uint32_t {                                  // (an unconditional LDS read, kept apart from the global one: EH_KEEP)
+    const uint32_t o = i - cbase; const bool in = o < 4096u;
+    uint32_t v = g_fuse_lds[in ? o : 0u];
+    EH_KEEP(v);
+    if (!in) { v = ev[i]; if (++far > SG_LANE_FAR) bail = true; }
+    return v;
+  };
+  auto have = [&](uint32_t i) -> bool {                                    // is there an event i?
+    if (i >= nev) return false;
+    if (budget == 0) { bail = true; return false; }
+    budget--;
+    if (i >= reach) reach = i + 1;
+    return true;
+  };
+  const uint32_t lt = EV(e) >> 4;
+  uint32_t pos = lt + 1, ei = e + 1, np = 0, nq = 0;
+  bool ws_sp = false;
+  auto cls_here = [&]() -> uint32_t { if (!have(ei)) return 0u; uint32_t v = EV(ei); return (v >> 4) == pos ? (v & 15u) : 0u; };
+  auto step1 = [&]() { if (have(ei) && (EV(ei) >> 4) == pos) ei++; pos++; };
+  auto skipws = [&]() {                                                    // ws/1 :176-177
+    ws_sp = false;
+    while (have(ei)) { uint32_t v = EV(ei); if (!((ES_WS >> (v & 15u)) & 1u) || (v >> 4) != pos) break; ws_sp = (v & 15u) == E_SPACE; pos++; ei++; }
+  };
+  auto find_set = [&](uint32_t from, uint32_t set) -> uint32_t {           // find_stop of the wave-wide machine: set is ES_STOP or ES_EV
+    uint32_t i = from;
+    for (int k = 0; k < 8; k++) { if (!have(i)) return nev; if ((set >> (EV(i) & 15u)) & 1u) return i; i++; }
+    for (;;) {                                                             // a name that runs over many events: the next-stop table
+      if (!have(i)) return nev;
+      const uint32_t j = mm.nstop[i];
+      if (j >= nev) return nev;
+      if (j >= reach) reach = j + 1;
+      if (set == ES_STOP || ((set >> (EV(j) & 15u)) & 1u)) return j;       // ES_EV: a "/>" does not end the name
+      i = j + 1;
+    }
+  };
+  auto find_one = [&](uint32_t from, uint32_t cls, uint32_t ff) -> uint32_t {      // find1 of the wave-wide machine
+    if (from >= ff) return nev;
+    uint32_t i = from;
+    while (have(i)) { if ((EV(i) & 15u) == cls) return i; i++; if (i - from > SG_LANE_SEARCH) { bail = true; return nev; } }
+    if (!bail) { R.ffc = cls; R.fff = from; reach = nev; }                // ran to the end of the block
+    return nev;
+  };
+  auto put = [&](const uint8_t* p, uint32_t len) { if (MODE == 1) { Piece q; q.ptr = (uint64_t)p; q.len = len; q.rep = 1; pc[np] = q; } np++; };
+  skipws();
+  const uint32_t tag0 = pos;
+  const bool tight = tag0 == lt + 1;
+  uint32_t kind = 0, na = pos, nb = pos, next = 0, nexte = 0;
+  bool ok = false;
+  do {
+    if (pos >= L) break;
+    uint32_t c0 = cls_here();
+    if (c0 == E_BANG) {                                                    // :104-105
+      bool d1 = false, d2 = false;
+      if (ei + 2 < nev) {
+        if (!have(ei + 2)) break;
+        uint32_t e1 = EV(ei + 1), e2 = EV(ei + 2);
+        d1 = (e1 >> 4) == pos + 1 && ((ES_DASH >> (e1 & 15u)) & 1u); d2 = (e2 >> 4) == pos + 2 && ((ES_DASH >> (e2 & 15u)) & 1u);
+      }
+      if (d1 && d2) {                                                      // {'!--',DT} :117-118
+        uint32_t dta = pos + 3;
+        uint32_t j = find_one(ei + 3, E_CMTEND, mm.cmt);
+        if (j >= nev) break;
+        uint32_t en = EV(j) >> 4;
+        put(tight ? H + lt : sglit(SL_CMT), 4); put(H + dta, en - dta); put(H + en, 3);
+        kind = TK_COMMENT; next = en + 3; nexte = j + 3; ok = true; break;
+      }
+      step1(); skipws();                                                   // {'!',DT} :113-115
+      uint32_t dta = pos;
+      uint32_t j = find_one(ei, E_GT, mm.gt);
+      if (j >= nev) break;
+      uint32_t en = EV(j) >> 4;
+      put(tight ? H + lt : sglit(SL_LTBANG), 2); put(H + dta, en - dta); put(H + en, 1);
+      kind = TK_BANG; next = en + 1; nexte = j + 1; ok = true; break;
+    }
+    if (c0 == E_QM || c0 == E_QGT) {                                       // {que,DT} :106,:120-122
+      step1(); skipws();
+      uint32_t dta = pos;
+      uint32_t j = find_one(ei, E_QGT, mm.qgt);
+      if (j >= nev) break;
+      uint32_t en = EV(j) >> 4;
+      put(tight ? H + lt : sglit(SL_LTQ), 2); put(H + dta, en - dta); put(H + en, 2);
+      kind = TK_QUE; next = en + 2; nexte = j + 2; ok = true; break;
+    }
+    if (c0 == E_SL || c0 == E_SLGT) {                                      // {end_tag,Tag} :107,:128-132
+      step1(); skipws();
+      na = pos;
+      uint32_t j = find_set(ei, ES_EV);
+      if (j >= nev) break;
+      nb = EV(j) >> 4; pos = nb; ei = j;
+      skipws();
+      if (cls_here() != E_GT) break;
+      put(tight ? H + lt : sglit(SL_LTSL), 2); put(H + na, nb - na); put(H + pos, 1);
+      kind = TK_CLOSE; next = pos + 1; nexte = ei + 1; ok = true; break;
+    }
+    // {tag,Tag} :108-111
+    uint32_t j = find_set(ei, ES_STOP);
+    if (j >= nev) break;
+    uint32_t ej = EV(j);
+    nb = ej >> 4;
+    put(H + lt, 1); put(H + na, nb - na); put(sglit(SL_SP), 0);
+    if ((ej & 15u) == E_SLGT) { put(sglit(SL_SPSLGT), 3); kind = TK_SC; next = nb + 2; nexte = j + 2; ok = true; break; }
+    pos = nb; ei = j;
+    skipws();
+    for (;;) {                                                             // attribute loop :134-160
+      if (pos >= L || bail) break;
+      if (nq >= 16) {                                                      // the memo of failed attribute-loop entries
+        if (mm.bad && mm.bad[pos]) break;
+        if (MODE == 2) mark[pos] = 1;
+        R.unmarked++;
+      }
+      uint32_t ca = cls_here();
+      if (ca == E_SLGT) { put(ws_sp ? H + pos - 1 : sglit(SL_SPSLGT), 3); kind = TK_SC; next = pos + 2; nexte = ei + 2; ok = true; break; }
+      if (ca == E_GT) { put(H + pos, 1); kind = TK_OPEN; next = pos + 1; nexte = ei + 1; ok = true; break; }
+      const bool sp_before = ws_sp;
+      if (ca == E_EQ) break;
+      uint32_t an = pos;
+      step1();
+      uint32_t ja = find_set(ei, ES_STOP);
+      if (ja >= nev) break;
+      uint32_t ae = EV(ja) >> 4; pos = ae; ei = ja;
+      skipws();
+      uint32_t va = pos, vb = pos, delim = 0, eqpos = 0xFFFFFFFFu;
+      if (pos < L && cls_here() == E_EQ) {
+        eqpos = pos;
+        step1(); skipws();
+        if (pos >= L) break;
+        uint32_t cv = cls_here();
+        if (cv == E_SQ || cv == E_DQ) {
+          uint32_t jq = find_one(ei + 1, cv, cv == E_SQ ? mm.sq : mm.dq);
+          if (jq >= nev) break;
+          va = pos + 1; vb = EV(jq) >> 4; delim = cv == E_SQ ? 1u : 2u;
+          pos = vb + 1; ei = jq + 1;
+        } else {
+          uint32_t ju = find_set(ei, ES_STOP);
+          if (ju >= nev) break;
+          va = pos; vb = EV(ju) >> 4; pos = vb; ei = ju;
+        }
+        skipws();
+      }
+      if (MODE == 1) { SgParam q; q.na = an; q.nb = ae; q.va = va; q.vb = vb; q.delim = delim; q.pad = 0; par[nq] = q; }
+      nq++;
+      const bool has = vb > va;
+      const uint8_t* qp = sglit(delim == 1 ? SL_SQ : SL_DQ);
+      put(sp_before ? H + an - 1 : sglit(SL_SP), 1); put(H + an, ae - an);
+      put(has ? H + eqpos : sglit(SL_EQ), has ? 1u : 0u); put(has && delim ? H + va - 1 : qp, has && delim ? 1u : 0u);
+      put(H + va, has ? vb - va : 0u); put(has && delim ? H + vb : qp, has && delim ? 1u : 0u);
+    }
+  } while (false);
+  R.ok = (ok && !bail) ? 1u : 0u; R.bail = bail ? 1u : 0u; R.kind = kind; R.next = next; R.nexte = nexte; R.tag0 = tag0; R.lt = lt;
+  R.npc = np; R.npar = nq; R.na = na; R.nb = nb; R.reach = reach;
+  if (ok || bail) { R.unmarked = 0; R.ffc = 0; }
+  return R;
+}
+
 // tokenize/1 :66-98 + tz/2 :100-164.  0 ok; -1 incorrect_sgml; -2 an error other than incorrect_sgml in the
 // first tag (outside any try: the worker dies); -3 engine capacity (c.status set).
 //
@@ -157,6 +334,22 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   };
   // ... and a name that runs over many events ("<<<<<< ... ") is skipped through a next-stop table, built on first need
   uint32_t* nstop_tab = nullptr;
+  auto build_nstop = [&]() __attribute__((always_inline)) -> bool {                                       // nstop_tab[i] = the first event >= i of the stop set (nev: none)
+    EH_CTX;
+    nstop_tab = (uint32_t*)ws_alloc(c, ((uint64_t)nev + 64) * 4);
+    if (!nstop_tab) return false;
+    uint32_t carry = nev;
+    for (uint32_t base = (nev - 1) & ~63u;; base -= 64) {
+      uint32_t j = base + (uint32_t)l; uint32_t e = j < nev ? ev[j] : 0u;
+      unsigned long long ms = __ballot(j < nev && ((ES_STOP >> (e & 15u)) & 1u));
+      unsigned long long mm = ms & ~((1ull << l) - 1);
+      if (j < nev) nstop_tab[j] = mm ? base + (uint32_t)__builtin_ctzll(mm) : carry;
+      if (ms) carry = base + (uint32_t)__builtin_ctzll(ms);
+      if (base == 0) break;
+    }
+    wave_sync();
+    return true;
+  };
   auto find_stop = [&](uint32_t from, uint32_t set) -> uint32_t {          // set: ES_STOP or ES_EV
     if (from >= nev) return nev;
     need(from);
@@ -164,20 +357,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
     if (m) return bbase + (uint32_t)__builtin_ctzll(m);
     from = bbase + 64;
     if (from >= nev) return nev;
-    if (!nstop_tab) {
-      nstop_tab = (uint32_t*)ws_alloc(c, ((uint64_t)nev + 64) * 4);
-      if (!nstop_tab) return 0xFFFFFFFFu;
-      uint32_t carry = nev;
-      for (uint32_t base = (nev - 1) & ~63u;; base -= 64) {
-        uint32_t j = base + (uint32_t)l; uint32_t e = j < nev ? ev[j] : 0u;
-        unsigned long long ms = __ballot(j < nev && ((ES_STOP >> (e & 15u)) & 1u));
-        unsigned long long mm = ms & ~((1ull << l) - 1);
-        if (j < nev) nstop_tab[j] = mm ? base + (uint32_t)__builtin_ctzll(mm) : carry;
-        if (ms) carry = base + (uint32_t)__builtin_ctzll(ms);
-        if (base == 0) break;
-      }
-      wave_sync();
-    }
+    if (!nstop_tab && !build_nstop()) return 0xFFFFFFFFu;
     for (;;) {
       uint32_t j = uni(nstop_tab[from]);
       if (j >= nev) return nev;
@@ -212,13 +392,16 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   // the machine, started at s, is back in that state at exactly s + P, the tokens of [s, s + P) repeat - shifted by P - for every
   // further period whose look-ahead stays inside the periodic stretch.  One period is tokenized as a template, the next one as a
   // check (every token, piece and parameter must be the template's, shifted), the rest are written by the whole wave from the template.
+  const bool lanes_on = !(c.p->flags & EH_FLAG_SGML_NO_LANES);
+  static_assert(4096 + 64 <= EH_FUSE_LDS_WORDS, "g_fuse_lds: event window + the batch's '<' list");
   uint32_t rp_P = 0, rp_lo = 0, rp_end = 0;                                // the stretch in hand: H[k] == H[k + P] for k in [rp_lo, rp_end - P)
   int rp_state = 0, rp_tries = 0;                                          // 0 idle, 1 in the template period, 2 in the check period
   // A document may hold several stretches (an element nested a thousand times: a run of open tags, a run of close tags; a block pumped
   // twice).  Stretches are found best-first in what lies ahead (fr_find_cut: anchors at the eighths), then, when the best one starts far
   // ahead, in the gap before it; they are replayed in the order the machine reaches them.  At most 8 searches per document.
   uint32_t rq_lo[4], rq_end[4], rq_P[4]; int rq_n = 0, rp_budget = 8; uint32_t rp_scan_from = 0;
-  auto rp_detect = [&](uint32_t a, uint32_t b) -> bool {                   // the best stretch of H[a, b) goes onto the stack
+  auto rp_detect = [&](uint32_t a, uint32_t b) __attribute__((always_inline)) -> bool {                   // the best stretch of H[a, b) goes onto the stack
+    EH_CTX;
     if (rp_budget <= 0 || rq_n >= 4 || b <= a || b - a < 16384u) return false;
     rp_budget--;
     uint32_t u = 0, D = 0, P = 0;
@@ -230,7 +413,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
     rq_lo[rq_n] = a + u - P; rq_end[rq_n] = a + u + D; rq_P[rq_n] = P; rq_n++;
     return true;
   };
-  auto rp_load = [&](uint32_t at) {                                        // the next stretch the machine, now at byte `at`, will reach
+  auto rp_load = [&](uint32_t at) __attribute__((always_inline)) {                                        // the next stretch the machine, now at byte `at`, will reach
     rp_P = 0; rp_state = 0; rp_tries = 0;
     for (;;) {
       while (rq_n > 0 && (uint64_t)at + 4ull * rq_P[rq_n - 1] > rq_end[rq_n - 1]) rq_n--;        // behind us (or too little of it left)
@@ -253,6 +436,232 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   int rc = 0;
   bool first = true;
   uint32_t lt = 0, seg_start = 0, text_p0 = 0, text_len = 0, seg_slot = 0;
+  // ---- replay bookkeeping: the machine has just accepted a tag (text state, nothing pending)
+  // (always_inline, like lane_batches below: a [&] lambda that is called, not inlined, moves every local it captures - pos, ei, npc ... -
+  // from registers into stack memory, for the wave-wide machine as well: three times its time on tags of thousands of attributes)
+  auto after_accept = [&]() __attribute__((always_inline)) -> int {
+    EH_CTX;                                                                // (not the captured reference: a lambda that is not inlined would carry a generic pointer to the LDS context)
+      if (rp_P) {                                                          // ---- replay (see above): this is the state "right after an accepted tag"
+        if (rp_state == 1 && pos == rp_s0 + rp_P) {                        // the template period is complete
+          rp_dtok = ntok - rp_tok0; rp_dpc = npc - rp_pc0; rp_dpar = npar - rp_par0; rp_de = ei - rp_e0; rp_reach1 = reach_ev; rp_state = 2;
+          reach_ev = (bbase != 0xFFFFFFFFu && bbase + 64 > ei) ? bbase + 64 : ei;   // (the lane window that is loaded counts as looked at)
+        } else if (rp_state == 2 && pos == rp_s0 + 2u * rp_P) {            // the check period is complete
+          wave_sync();                                                     // (lane 0's stores of the two periods are read below)
+          bool same = ntok - rp_tok0 == 2u * rp_dtok && npc - rp_pc0 == 2u * rp_dpc && npar - rp_par0 == 2u * rp_dpar && ei - rp_e0 == 2u * rp_de && rp_dtok > 0;
+          const uint64_t h0 = (uint64_t)(uintptr_t)H, h1 = h0 + L;
+          if (same) {
+            bool ne = false;
+            for (uint32_t t = l; t < rp_dtok; t += 64) {
+              SgTok a = tok[rp_tok0 + t], b = tok[rp_tok0 + rp_dtok + t];
+              const bool text = (a.kind & TK_KIND) == TK_TEXT;
+              const uint32_t sh = text ? 0u : rp_P, shp = text ? 0u : rp_dpar;
+              ne |= b.kind != a.kind || b.p0 != a.p0 + rp_dpc || b.np != a.np || b.na != a.na + sh || b.nb != a.nb + sh || b.par0 != a.par0 + shp || b.npar != a.npar;
+            }
+            for (uint32_t t = l; t < rp_dpc; t += 64) {
+              Piece a = pc[rp_pc0 + t], b = pc[rp_pc0 + rp_dpc + t];
+              const bool inblk = a.ptr >= h0 && a.ptr < h1;
+              ne |= b.len != a.len || b.rep != a.rep || b.ptr != a.ptr + (inblk ? rp_P : 0u);
+            }
+            for (uint32_t t = l; t < rp_dpar; t += 64) {
+              SgParam a = par[rp_par0 + t], b = par[rp_par0 + rp_dpar + t];
+              ne |= b.na != a.na + rp_P || b.nb != a.nb + rp_P || b.va != a.va + rp_P || b.vb != a.vb + rp_P || b.delim != a.delim;
+            }
+            same = __ballot(ne) == 0;
+          }
+          // how far ahead of its start a period looked (events -> bytes; a search that ran to the end of the block leaves none to replay)
+          uint32_t r1 = rp_reach1 > rp_e0 ? rp_reach1 : rp_e0, r2 = reach_ev > rp_e0 + rp_de ? reach_ev : rp_e0 + rp_de;
+          uint32_t b1 = r1 >= nev ? L : (evget(r1) >> 4), b2 = r2 >= nev ? L : (evget(r2) >> 4);
+          uint32_t rel1 = b1 - rp_s0, rel2 = b2 - (rp_s0 + rp_P);
+          uint32_t rel = (rel1 > rel2 ? rel1 : rel2) + 4u;                 // (+ the bytes a class looks ahead: "/>", "?>", "-->")
+          uint32_t J = 0;
+          if (same && rp_end > rp_s0 + rel) J = (rp_end - rel - rp_s0) / rp_P;   // periods 0 .. J-1 see only bytes of the periodic stretch
+          if (J > 3) {
+            const uint32_t N = J - 2u;
+            if ((uint64_t)npc + (uint64_t)N * rp_dpc + 16 > cap_pc || (uint64_t)ntok + (uint64_t)N * rp_dtok + 2 > cap_tok || (uint64_t)npar + (uint64_t)N * rp_dpar + 1 > cap_par) { EH_SET_OVERFLOW(c, 603); return -3; }
+            for (uint64_t idx = l; idx < (uint64_t)N * rp_dtok; idx += 64) {
+              const uint32_t j = 2u + (uint32_t)(idx / rp_dtok), t = (uint32_t)(idx % rp_dtok);
+              SgTok a = tok[rp_tok0 + t];
+              const bool text = (a.kind & TK_KIND) == TK_TEXT;
+              a.p0 += j * rp_dpc;
+              if (!text) { a.na += j * rp_P; a.nb += j * rp_P; a.par0 += j * rp_dpar; }
+              tok[rp_tok0 + j * rp_dtok + t] = a;
+            }
+            for (uint64_t idx = l; idx < (uint64_t)N * rp_dpc; idx += 64) {
+              const uint32_t j = 2u + (uint32_t)(idx / rp_dpc), t = (uint32_t)(idx % rp_dpc);
+              Piece a = pc[rp_pc0 + t];
+              if (a.ptr >= h0 && a.ptr < h1) a.ptr += (uint64_t)j * rp_P;
+              pc[rp_pc0 + j * rp_dpc + t] = a;
+            }
+            for (uint64_t idx = l; idx < (uint64_t)N * rp_dpar; idx += 64) {
+              const uint32_t j = 2u + (uint32_t)(idx / rp_dpar), t = (uint32_t)(idx % rp_dpar);
+              SgParam a = par[rp_par0 + t];
+              a.na += j * rp_P; a.nb += j * rp_P; a.va += j * rp_P; a.vb += j * rp_P;
+              par[rp_par0 + j * rp_dpar + t] = a;
+            }
+            wave_sync();
+#ifdef EH_PROF
+            if (l == 0) { atomicAdd(&c.p->prof[2 * 94], (unsigned long long)N * rp_dtok); atomicAdd(&c.p->prof[2 * 94 + 1], 1ull); }   // tokens written by replay, replays
+#endif
+            ntok += N * rp_dtok; npc += N * rp_dpc; npar += N * rp_dpar;
+            pos = rp_s0 + J * rp_P; ei = rp_e0 + J * rp_de;
+            seg_start = pos; text_p0 = npc; text_len = 0;
+            bbase = 0xFFFFFFFFu;
+          }
+#ifdef EH_PROF
+          if (l == 0 && J <= 3) { atomicAdd(&c.p->prof[2 * 99 + 1], 1ull); atomicAdd(&c.p->prof[2 * 99], same ? 1ull : 0ull); }   // checked but not replayed; of them: look-ahead too long
+#endif
+          rp_load(pos);                                                    // this stretch is done; is there another one ahead?
+        } else if (rp_state != 0 && pos > rp_s0 + (uint32_t)rp_state * rp_P) {
+          rp_state = 0;                                                    // the machine was not back in this state a period later: try from here
+          if (++rp_tries >= 8) {
+            rp_load(rp_end);
+#ifdef EH_PROF
+            if (l == 0) atomicAdd(&c.p->prof[2 * 89 + 1], 1ull);        // gave up: never back in the state a period later
+#endif
+          }
+        }
+        if (rp_P && rp_state == 0 && (uint64_t)pos + 4ull * rp_P > rp_end) rp_load(pos);          // walked past it
+        if (rp_P && rp_state == 0 && pos >= rp_lo + rp_P && (uint64_t)pos + 4ull * rp_P <= rp_end) {
+          rp_state = 1; rp_s0 = pos; rp_tok0 = ntok; rp_pc0 = npc; rp_par0 = npar; rp_e0 = ei;
+          reach_ev = (bbase != 0xFFFFFFFFu && bbase + 64 > ei) ? bbase + 64 : ei;
+        }
+      }
+    return 0;
+  };
+  // ---- lane batches: the next '<' of the block attempted one per lane (sg_lane_attempt).  Called in the text state - behind an accepted
+  // tag or a failed attempt - where what the machine does next depends on the bytes ahead alone.  A batch commits exactly what the
+  // machine would have done tag by tag: the attempts it would make (an accepted tag hides the '<' inside it; a failed one hands over to
+  // the next '<'; failed ones that lost white space behind their '<' leave a text piece), up to the first lane that gave up.  While
+  // a periodic stretch is in hand a batch stops behind its first accepted tag, so that the replay's bookkeeping sees every one.
+  // Batches are made where they pay: four '<' or more within reach, runs of failing attempts ("<a <b <c ...").
+  // A batch whose first lane gave up has cost its time for nothing: the next ones are skipped, twice as many each time it happens.
+  uint32_t fail_run = 0, lb_skip = 0, lb_penalty = 1;
+  auto lane_batches = [&]() __attribute__((always_inline)) -> int {
+    EH_CTX;                                                                // (not the captured reference: a lambda that is not inlined would carry a generic pointer to the LDS context)
+    while (lanes_on && ei < nev) {
+      const bool single = rp_P != 0 && (rp_state != 0 || pos >= rp_lo);
+      if (single && fail_run < 3) break;
+      if (lb_skip > 0) { lb_skip--; break; }
+      if (cbase != 0xFFFFFFFFu && cbase + SG_EVC < nev && ei + 2048u > cbase + SG_EVC) { cbase = 0xFFFFFFFFu; bbase = 0xFFFFFFFFu; }   // little of the window left: move it
+      need(ei);
+      const uint32_t wend = cbase + SG_EVC < nev ? cbase + SG_EVC : nev;
+      const uint32_t send = ei + 1024u < wend ? ei + 1024u : wend;         // '<' further ahead than this are the text state's to find
+      const uint32_t bound = rp_P && !single ? rp_lo : 0xFFFFFFFFu;        // before a stretch: '<' at or beyond it are left to the batches made there
+      // (the list of '<' goes into the 64 words behind the window, g_fuse_lds[SG_EVC ..): indexed, not through a pointer - a generic
+      // pointer into LDS here sent this compiler into "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base")
+      uint32_t nl = 0;
+      lanes_sync();
+      for (uint32_t base = ei; base < send && nl < 64; base += 64) {
+        const uint32_t idx = base + (uint32_t)l;
+        const uint32_t v = idx < send ? g_fuse_lds[idx - cbase] : 0u;
+        const bool is = idx < send && (v & 15u) == E_LT && (v >> 4) < bound;
+        const unsigned long long m = __ballot(is);
+        const uint32_t rank = nl + (uint32_t)__popcll(m & ((1ull << l) - 1ull));
+        if (is && rank < 64) g_fuse_lds[SG_EVC + rank] = idx;
+        nl += (uint32_t)__popcll(m);
+      }
+      if (nl > 64) nl = 64;
+      lanes_sync();
+      if (nl == 0 || (nl < 4 && fail_run < 3)) break;                       // not worth a batch: tag by tag
+      const bool mine = (uint32_t)l < nl;
+      const uint32_t e = mine ? g_fuse_lds[SG_EVC + (uint32_t)l] : 0xFFFFFFFFu;
+      if (!nstop_tab && !build_nstop()) return -3;
+      SgLaneMemo mm; mm.gt = ff_gt; mm.qgt = ff_qgt; mm.cmt = ff_cmt; mm.sq = ff_sq; mm.dq = ff_dq; mm.bad = bad; mm.nstop = nstop_tab;
+      SgLaneTag R; R.ok = 0; R.bail = 1; R.kind = 0; R.next = 0; R.nexte = 0; R.tag0 = 0; R.lt = 0; R.npc = 0; R.npar = 0; R.na = 0; R.nb = 0; R.reach = 0; R.ffc = 0; R.fff = 0; R.unmarked = 0;
+      if (mine) R = sg_lane_attempt<0>(H, L, ev, nev, cbase, e, mm, nullptr, nullptr, nullptr);
+      // what the attempts found out about the block: searches that ran to its end, attribute loops that fail
+      if (__ballot(R.ffc != 0)) {
+        const uint32_t m1 = wave_min(R.ffc == E_GT ? R.fff : nev), m2 = wave_min(R.ffc == E_QGT ? R.fff : nev), m3 = wave_min(R.ffc == E_CMTEND ? R.fff : nev);
+        const uint32_t m4 = wave_min(R.ffc == E_SQ ? R.fff : nev), m5 = wave_min(R.ffc == E_DQ ? R.fff : nev);
+        if (m1 < ff_gt) ff_gt = m1;
+        if (m2 < ff_qgt) ff_qgt = m2;
+        if (m3 < ff_cmt) ff_cmt = m3;
+        if (m4 < ff_sq) ff_sq = m4;
+        if (m5 < ff_dq) ff_dq = m5;
+      }
+      if (__ballot(R.unmarked != 0)) {
+        if (!bad) {
+          bad = ws_alloc(c, (uint64_t)L + 16);
+          if (!bad) return -3;
+          for (uint32_t i = 16u * (uint32_t)l; i < L + 16; i += 1024) { uint4 z = {0, 0, 0, 0}; __builtin_memcpy(bad + i, &z, 16); }
+          wave_sync();
+        }
+        if (R.unmarked != 0) (void)sg_lane_attempt<2>(H, L, ev, nev, cbase, e, mm, nullptr, nullptr, bad);
+        wave_sync();
+      }
+      // which attempts does the machine make?
+      unsigned long long visited = 0; uint32_t k = 0; bool any_acc = false;
+      while (k < nl) {
+        if ((uint32_t)__builtin_amdgcn_readlane((int)R.bail, (int)k)) break;
+        visited |= 1ull << k;
+        if (!(uint32_t)__builtin_amdgcn_readlane((int)R.ok, (int)k)) { k++; continue; }
+        any_acc = true;
+        if (single) break;
+        const uint32_t ne = (uint32_t)__builtin_amdgcn_readlane((int)R.nexte, (int)k);
+        const unsigned long long m = __ballot(mine && e >= ne);
+        if (!m) break;
+        k = (uint32_t)__builtin_ctzll(m);
+      }
+      if (!visited) { lb_skip = lb_penalty; if (lb_penalty < 1024) lb_penalty *= 2; break; }   // the first lane gave up: the wave-wide machine takes this '<'
+      if (__popcll(visited) >= 4) lb_penalty = 1;
+      const uint32_t lastc = 63u - (uint32_t)__builtin_clzll(visited);
+      const bool cm = (visited >> l) & 1ull;
+      const bool acc = cm && R.ok, fw = cm && !R.ok && R.tag0 > R.lt + 1u;   // accepted; failed with white space eaten behind its '<' (:80,:92)
+      const uint32_t pcs = acc ? 1u + R.npc : (fw ? 1u : 0u), tks = acc ? 2u : 0u, prs = acc ? R.npar : 0u;
+      const uint32_t ipc = wave_incl_scan(pcs), itk = wave_incl_scan(tks), ipr = wave_incl_scan(prs);
+      const uint32_t tpc = (uint32_t)__builtin_amdgcn_readlane((int)ipc, 63), ttk = (uint32_t)__builtin_amdgcn_readlane((int)itk, 63), tpr = (uint32_t)__builtin_amdgcn_readlane((int)ipr, 63);
+      if ((uint64_t)npc + tpc + 16 > cap_pc || (uint64_t)ntok + ttk + 2 > cap_tok || (uint64_t)npar + tpr + 1 > cap_par) { EH_SET_OVERFLOW(c, 604); return -3; }
+      const uint32_t bpc = npc + ipc - pcs, btk = ntok + itk - tks, bpr = npar + ipr - prs;
+      // where the text in front of this '<' begins: behind the last accepted tag, or behind the white space the last failed '<' lost
+      const unsigned long long defm = __ballot(acc || fw), accm = __ballot(acc), fwm = __ballot(fw);
+      const unsigned long long below = (1ull << l) - 1ull;
+      const uint32_t defv = acc ? R.next : R.tag0;
+      const uint32_t pd = (defm & below) ? 63u - (uint32_t)__builtin_clzll(defm & below) : 0u;
+      const uint32_t pdv = (uint32_t)__shfl((int)defv, (int)pd);
+      const uint32_t segb = (defm & below) ? pdv : seg_start;
+      const uint32_t pa = (accm & below) ? 63u - (uint32_t)__builtin_clzll(accm & below) : 0u;
+      const uint32_t pav = (uint32_t)__shfl((int)(bpc + pcs), (int)pa);
+      const uint32_t tp0 = (accm & below) ? pav : text_p0;                 // first piece of the text token in front of this tag
+      if (fw) { Piece q; q.ptr = (uint64_t)(H + segb); q.len = R.lt + 1u - segb; q.rep = 1; pc[bpc] = q; }
+      if (acc) {
+        Piece q; q.ptr = (uint64_t)(H + segb); q.len = R.lt - segb; q.rep = 1; pc[bpc] = q;
+        const bool empty = bpc == tp0 && R.lt == segb;                     // (every earlier piece of the token holds a '<')
+        SgTok t; t.kind = TK_TEXT | (empty ? (uint32_t)TF_EMPTY : 0u); t.p0 = tp0; t.np = bpc + 1u - tp0; t.na = 0; t.nb = 0; t.par0 = 0; t.npar = 0; t.match = -1;
+        tok[btk] = t;
+        SgLaneTag W = sg_lane_attempt<1>(H, L, ev, nev, cbase, e, mm, pc + bpc + 1u, par + bpr, nullptr);
+        SgTok g; g.kind = W.kind; g.p0 = bpc + 1u; g.np = W.npc; g.na = W.na; g.nb = W.nb; g.par0 = bpr; g.npar = W.npar; g.match = -1;
+        tok[btk + 1u] = g;
+      }
+      if (rp_state != 0) { const uint32_t r = wave_max(cm ? R.reach : 0u); if (r > reach_ev) reach_ev = r; }
+      // the state behind the last committed attempt
+      const bool last_is_acc = (accm >> lastc) & 1ull;
+      if (last_is_acc) {
+        pos = (uint32_t)__builtin_amdgcn_readlane((int)R.next, (int)lastc); ei = (uint32_t)__builtin_amdgcn_readlane((int)R.nexte, (int)lastc);
+        seg_start = pos; text_p0 = npc + tpc; text_len = 0;
+        fail_run = 0;
+      } else {
+        const unsigned long long trail = accm ? fwm & ~((2ull << (63u - (uint32_t)__builtin_clzll(accm))) - 1ull) : fwm;   // lost white space behind the last accepted tag
+        const uint32_t add = wave_sum(((trail >> l) & 1ull) ? R.lt + 1u - segb : 0u);
+        if (accm) {
+          const uint32_t la = 63u - (uint32_t)__builtin_clzll(accm);
+          text_p0 = (uint32_t)__shfl((int)(bpc + pcs), (int)la); text_len = 0; seg_start = (uint32_t)__builtin_amdgcn_readlane((int)R.next, (int)la);
+        }
+        text_len += add;
+        if (trail) seg_start = (uint32_t)__builtin_amdgcn_readlane((int)R.tag0, (int)(63u - (uint32_t)__builtin_clzll(trail)));
+        pos = (uint32_t)__builtin_amdgcn_readlane((int)R.lt, (int)lastc) + 1u; ei = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)lastc) + 1u;
+        fail_run += (uint32_t)__popcll(visited & ~accm & (accm ? ~((2ull << (63u - (uint32_t)__builtin_clzll(accm))) - 1ull) : ~0ull));
+      }
+      ntok += ttk; npc += tpc; npar += tpr;
+      bbase = 0xFFFFFFFFu;
+      wave_sync();
+#ifdef EH_PROF
+      if (l == 0) { atomicAdd(&c.p->prof[2 * 85], (unsigned long long)(ttk / 2u)); atomicAdd(&c.p->prof[2 * 85 + 1], 1ull); }   // tags written by lane batches, batches
+      if (l == 0) { atomicAdd(&c.p->prof[2 * 68], (unsigned long long)__popcll(visited & ~accm)); atomicAdd(&c.p->prof[2 * 68 + 1], 1ull); }   // failed attempts committed by batches
+#endif
+      if (single && any_acc) { const int r = after_accept(); if (r) return r; }
+    }
+    return 0;
+  };
   // tz(nil, ..) :100-101: bytes before the first '<' are dropped
   {
     uint32_t j = find(0, 1u << E_LT);
@@ -387,91 +796,8 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
       ntok++;
       first = false;
       pos = next; ei = nexte; seg_start = next; text_p0 = npc; text_len = 0;
-      if (rp_P) {                                                          // ---- replay (see above): this is the state "right after an accepted tag"
-        if (rp_state == 1 && pos == rp_s0 + rp_P) {                        // the template period is complete
-          rp_dtok = ntok - rp_tok0; rp_dpc = npc - rp_pc0; rp_dpar = npar - rp_par0; rp_de = ei - rp_e0; rp_reach1 = reach_ev; rp_state = 2;
-          reach_ev = (bbase != 0xFFFFFFFFu && bbase + 64 > ei) ? bbase + 64 : ei;   // (the lane window that is loaded counts as looked at)
-        } else if (rp_state == 2 && pos == rp_s0 + 2u * rp_P) {            // the check period is complete
-          wave_sync();                                                     // (lane 0's stores of the two periods are read below)
-          bool same = ntok - rp_tok0 == 2u * rp_dtok && npc - rp_pc0 == 2u * rp_dpc && npar - rp_par0 == 2u * rp_dpar && ei - rp_e0 == 2u * rp_de && rp_dtok > 0;
-          const uint64_t h0 = (uint64_t)(uintptr_t)H, h1 = h0 + L;
-          if (same) {
-            bool ne = false;
-            for (uint32_t t = l; t < rp_dtok; t += 64) {
-              SgTok a = tok[rp_tok0 + t], b = tok[rp_tok0 + rp_dtok + t];
-              const bool text = (a.kind & TK_KIND) == TK_TEXT;
-              const uint32_t sh = text ? 0u : rp_P, shp = text ? 0u : rp_dpar;
-              ne |= b.kind != a.kind || b.p0 != a.p0 + rp_dpc || b.np != a.np || b.na != a.na + sh || b.nb != a.nb + sh || b.par0 != a.par0 + shp || b.npar != a.npar;
-            }
-            for (uint32_t t = l; t < rp_dpc; t += 64) {
-              Piece a = pc[rp_pc0 + t], b = pc[rp_pc0 + rp_dpc + t];
-              const bool inblk = a.ptr >= h0 && a.ptr < h1;
-              ne |= b.len != a.len || b.rep != a.rep || b.ptr != a.ptr + (inblk ? rp_P : 0u);
-            }
-            for (uint32_t t = l; t < rp_dpar; t += 64) {
-              SgParam a = par[rp_par0 + t], b = par[rp_par0 + rp_dpar + t];
-              ne |= b.na != a.na + rp_P || b.nb != a.nb + rp_P || b.va != a.va + rp_P || b.vb != a.vb + rp_P || b.delim != a.delim;
-            }
-            same = __ballot(ne) == 0;
-          }
-          // how far ahead of its start a period looked (events -> bytes; a search that ran to the end of the block leaves none to replay)
-          uint32_t r1 = rp_reach1 > rp_e0 ? rp_reach1 : rp_e0, r2 = reach_ev > rp_e0 + rp_de ? reach_ev : rp_e0 + rp_de;
-          uint32_t b1 = r1 >= nev ? L : (evget(r1) >> 4), b2 = r2 >= nev ? L : (evget(r2) >> 4);
-          uint32_t rel1 = b1 - rp_s0, rel2 = b2 - (rp_s0 + rp_P);
-          uint32_t rel = (rel1 > rel2 ? rel1 : rel2) + 4u;                 // (+ the bytes a class looks ahead: "/>", "?>", "-->")
-          uint32_t J = 0;
-          if (same && rp_end > rp_s0 + rel) J = (rp_end - rel - rp_s0) / rp_P;   // periods 0 .. J-1 see only bytes of the periodic stretch
-          if (J > 3) {
-            const uint32_t N = J - 2u;
-            if ((uint64_t)npc + (uint64_t)N * rp_dpc + 16 > cap_pc || (uint64_t)ntok + (uint64_t)N * rp_dtok + 2 > cap_tok || (uint64_t)npar + (uint64_t)N * rp_dpar + 1 > cap_par) { EH_SET_OVERFLOW(c, 603); return -3; }
-            for (uint64_t idx = l; idx < (uint64_t)N * rp_dtok; idx += 64) {
-              const uint32_t j = 2u + (uint32_t)(idx / rp_dtok), t = (uint32_t)(idx % rp_dtok);
-              SgTok a = tok[rp_tok0 + t];
-              const bool text = (a.kind & TK_KIND) == TK_TEXT;
-              a.p0 += j * rp_dpc;
-              if (!text) { a.na += j * rp_P; a.nb += j * rp_P; a.par0 += j * rp_dpar; }
-              tok[rp_tok0 + j * rp_dtok + t] = a;
-            }
-            for (uint64_t idx = l; idx < (uint64_t)N * rp_dpc; idx += 64) {
-              const uint32_t j = 2u + (uint32_t)(idx / rp_dpc), t = (uint32_t)(idx % rp_dpc);
-              Piece a = pc[rp_pc0 + t];
-              if (a.ptr >= h0 && a.ptr < h1) a.ptr += (uint64_t)j * rp_P;
-              pc[rp_pc0 + j * rp_dpc + t] = a;
-            }
-            for (uint64_t idx = l; idx < (uint64_t)N * rp_dpar; idx += 64) {
-              const uint32_t j = 2u + (uint32_t)(idx / rp_dpar), t = (uint32_t)(idx % rp_dpar);
-              SgParam a = par[rp_par0 + t];
-              a.na += j * rp_P; a.nb += j * rp_P; a.va += j * rp_P; a.vb += j * rp_P;
-              par[rp_par0 + j * rp_dpar + t] = a;
-            }
-            wave_sync();
-#ifdef EH_PROF
-            if (l == 0) { atomicAdd(&c.p->prof[2 * 94], (unsigned long long)N * rp_dtok); atomicAdd(&c.p->prof[2 * 94 + 1], 1ull); }   // tokens written by replay, replays
-#endif
-            ntok += N * rp_dtok; npc += N * rp_dpc; npar += N * rp_dpar;
-            pos = rp_s0 + J * rp_P; ei = rp_e0 + J * rp_de;
-            seg_start = pos; text_p0 = npc; text_len = 0;
-            bbase = 0xFFFFFFFFu;
-          }
-#ifdef EH_PROF
-          if (l == 0 && J <= 3) { atomicAdd(&c.p->prof[2 * 99 + 1], 1ull); atomicAdd(&c.p->prof[2 * 99], same ? 1ull : 0ull); }   // checked but not replayed; of them: look-ahead too long
-#endif
-          rp_load(pos);                                                    // this stretch is done; is there another one ahead?
-        } else if (rp_state != 0 && pos > rp_s0 + (uint32_t)rp_state * rp_P) {
-          rp_state = 0;                                                    // the machine was not back in this state a period later: try from here
-          if (++rp_tries >= 8) {
-            rp_load(rp_end);
-#ifdef EH_PROF
-            if (l == 0) atomicAdd(&c.p->prof[2 * 89 + 1], 1ull);        // gave up: never back in the state a period later
-#endif
-          }
-        }
-        if (rp_P && rp_state == 0 && (uint64_t)pos + 4ull * rp_P > rp_end) rp_load(pos);          // walked past it
-        if (rp_P && rp_state == 0 && pos >= rp_lo + rp_P && (uint64_t)pos + 4ull * rp_P <= rp_end) {
-          rp_state = 1; rp_s0 = pos; rp_tok0 = ntok; rp_pc0 = npc; rp_par0 = npar; rp_e0 = ei;
-          reach_ev = (bbase != 0xFFFFFFFFu && bbase + 64 > ei) ? bbase + 64 : ei;
-        }
-      }
+      fail_run = 0;
+      { const int r = after_accept(); if (r) return r; }
     } else {
       if (first) { rc = other ? -2 : -1; break; }
       if (nchain > 0) {                                                    // remember where this attempt entered the attribute loop
@@ -490,7 +816,9 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
         text_len += lt + 1 - seg_start; seg_start = tag0;
       }
       pos = tag0; ei = ei0;                                                // ff/4 goes on from EStr
+      fail_run++;
     }
+    { const int r = lane_batches(); if (r) return r; }
     // ---- text state: ff/4 :166-174
     uint32_t j = find(ei, 1u << E_LT);
     if (j >= nev) {                                                        // {{text,Str},"",eof} :82-83,:94-95

@@ -18,6 +18,7 @@ EH_FLAG_META_TRACE = 2
 EH_FLAG_FUSE_NO_LDS = 4
 EH_FLAG_FUSE_NO_REDUCE = 8
 EH_FLAG_SGML_NO_REPLAY = 16
+EH_FLAG_SGML_NO_LANES = 32
 
 CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BUDGET = 0, 1, 2, 3, 4, 5
 

@@ -111,6 +111,8 @@ typedef struct eh_options {
 
 #define EH_FLAG_ORDERED_OUTPUT 1u /* compact the output arena into case order after the batch */
 #define EH_FLAG_META_TRACE 2u     /* keep every case's meta trace (eh_result_meta) */
+#define EH_FLAG_SGML_NO_LANES 32u  /* diagnostic: the sgm tokenizer makes its tag attempts one after the other instead of 64 at a time, one per
+                                     lane (csrc/eh_sgml.h); results are identical */
 #define EH_FLAG_SGML_NO_REPLAY 16u /* diagnostic: the sgm tokenizer walks periodic documents tag by tag instead of replaying one period's
                                      tokens (csrc/eh_sgml.h); results are identical */
 #define EH_FLAG_FUSE_NO_REDUCE 8u /* diagnostic: erlamsa_fuse:fuse/2 on large lists searches the lists as they are instead of copies with the

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.
 import numpy as np
 import pyoracle as po
 import erlamsa_amd as ea
-from erlamsa_amd.engine import EH_FLAG_SGML_NO_REPLAY
+from erlamsa_amd.engine import EH_FLAG_SGML_NO_REPLAY, EH_FLAG_SGML_NO_LANES
 
 UNITS = [
     b"<a>x</a>", b"<b k='v' j=\"w\" u=z>text <i/> more</b>\n", b"<c  x = 'q q' ><d/></c> ", b"<!-- note --><e>1</e>", b"<?pi data?><f g=h>t</f>",
@@ -43,6 +43,19 @@ def corpus(n, seed, scale=1):
         out.append(head + u * reps + b"<!-- never closed " + unit() * 3)
         out.append(head + u * (16384 // len(u) + 3) + tail)                                # barely long enough / too short to replay
         out.append((head + u * reps + tail) * 2)                                           # two stretches of the same period
+        out.append(head + b"".join(UNITS[int(j)] for j in rng.integers(0, len(UNITS), size=int(rng.integers(300, 1500)) * scale)) + tail)   # no period: tag attempts 64 at a time
+        junk = [b"<", b"< ", b"<a ", b"<a b", b"<!", b"<!--", b"<?", b"</", b"</x ", b"='", b"\"", b" > ", b"/>", b"-->", b"?>", b"x", b" ", b"\n", b"=", b"y z"]
+        out.append(head + b"".join(junk[int(j)] for j in rng.integers(0, len(junk), size=int(rng.integers(2000, 6000)) * scale)) + tail)     # tag soup: failed attempts, quotes and comments that run far
+        w = lambda a, b: bytes(rng.choice(list(b"abcdefghijklmnopqrstuvwxyz0123456789{}[]()."), size=int(rng.integers(a, b))).astype(np.uint8))
+        run = b"<" + w(3, 9) + b" " + w(4, 12)                                              # "<name attr<name attr ..." without a '>': every attempt walks the attributes ahead and fails
+        out.append(head + (b"<t>x</t>" + w(20, 100)) * 20 + run * (int(rng.integers(1500, 5000)) * scale) + w(3, 9) + b"=" + tail)
+        words = lambda n: b" ".join(w(1, 9) + (b"=" + w(1, 5) if rng.random() < 0.1 else b"") for _ in range(n))
+        out.append(head + b"".join(b"<" + words(int(rng.integers(20, 3000)) * scale) + rng.choice([b">", b"/>", b" >", b"=>", b""]) + w(0, 30) for _ in range(int(rng.integers(2, 12)))) + tail)   # tags of thousands of attributes, few '<'
+        soup = b"".join(rng.choice([b"<", b" ", b"  ", b"='", b"=\"", b"=", b">", b"a", b"bc", b"\n"], p=[.2, .2, .05, .03, .03, .05, .04, .2, .15, .05]) for _ in range(int(rng.integers(3000, 9000)) * scale))
+        out.append(head + soup + tail)                                                     # failing runs without a period, quotes that never close
+        unit2 = b"<" + w(2, 6) + b"/" + w(5, 30)                                            # names that run over thousands of '<' and '/' (neither ends a name)
+        out.append(head + unit2 * (int(rng.integers(1500, 4000)) * scale) + rng.choice([b" x=1>", b">", b"/>", b"", b" "]) + words(30) + tail)
+        out.append(head + b"".join(b"<" + w(1, 12) + rng.choice([b"", b"/", b"<", b"'", b"\""]) for _ in range(int(rng.integers(2000, 5000)) * scale)) + rng.choice([b" y>", b"", b"=", b"/>"]) + tail)
     return out
 
 
@@ -50,7 +63,7 @@ def run(n=1, seed=1, scale=1, pats="od,nd,bu", verbose=True):
     inputs = corpus(n, seed, scale)
     data, off = po.pack(inputs)
     res = {}
-    for name, flags in (("replay", 0), ("walk", EH_FLAG_SGML_NO_REPLAY)):
+    for name, flags in (("replay", 0), ("walk", EH_FLAG_SGML_NO_REPLAY | EH_FLAG_SGML_NO_LANES), ("lanes", EH_FLAG_SGML_NO_REPLAY), ("nolanes", EH_FLAG_SGML_NO_LANES)):
         t = time.time()
         e = ea.Engine(0)
         e.configure(mutations="sgm", patterns=pats, max_case_bytes=64 << 20, flags=flags)
@@ -70,14 +83,15 @@ def run(n=1, seed=1, scale=1, pats="od,nd,bu", verbose=True):
         if a[1][i] in (2, 3) or o.status[i] in (2, 3):
             continue
         ok_o = a[0][i] == o.outs[i] and a[1][i] == o.status[i] and (a[1][i] != 0 or a[2][i] == o.draws[i])
-        ok_n = a[0][i] == b[0][i] and a[1][i] == b[1][i] and a[2][i] == b[2][i]
+        ok_n = all(a[0][i] == x[0][i] and a[1][i] == x[1][i] and a[2][i] == x[2][i] for x in (b, res["lanes"], res["nolanes"]))
         if not (ok_o and ok_n):
             bad += 1
             if verbose and bad <= 8:
                 print("case %d (kind %d, len %d): replay vs oracle %s, replay vs walk %s; status %d/%d/%d draws %d/%d/%d len %d/%d/%d" % (
-                    i, i % 6, len(inputs[i]), ok_o, ok_n, a[1][i], b[1][i], o.status[i], a[2][i], b[2][i], o.draws[i], len(a[0][i]), len(b[0][i]), len(o.outs[i])))
+                    i, i % 13, len(inputs[i]), ok_o, ok_n, a[1][i], b[1][i], o.status[i], a[2][i], b[2][i], o.draws[i], len(a[0][i]), len(b[0][i]), len(o.outs[i])))
     if verbose:
-        print("cases %d bad %d; replay %.1f s, walk %.1f s, oracle %.1f s; input bytes %d" % (len(inputs), bad, a[3], b[3], to, sum(map(len, inputs))))
+        print("cases %d bad %d; replay+lanes %.1f s, tag by tag %.1f s, lanes only %.1f s, replay only %.1f s, oracle %.1f s; input bytes %d" % (
+            len(inputs), bad, a[3], b[3], res["lanes"][3], res["nolanes"][3], to, sum(map(len, inputs))))
     return len(inputs), bad
 
 

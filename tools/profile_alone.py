@@ -24,7 +24,7 @@ for i in cases:
     for m in range(len(names)):
         if pr[2 * m + 1] > 0 and pr[2 * m] > 10e6:
             print("    %-6s calls %6d  total %9.1f Mcyc  mean %9.1f kcyc" % (names[m], pr[2 * m + 1], pr[2 * m] / 1e6, pr[2 * m] / pr[2 * m + 1] / 1e3))
-    for k in range(64, 128):
+    for k in range(len(names), 128):
         if pr[2 * k + 1] > 0 and pr[2 * k] > 10e6:
             print("    slot %3d calls %7d total %9.1f Mcyc mean %9.1f kcyc" % (k, pr[2 * k + 1], pr[2 * k] / 1e6, pr[2 * k] / pr[2 * k + 1] / 1e3))
     print("    sgm tokenizer phase 2: between attempts %.1f Mcyc x%d, failed attempts %.1f Mcyc x%d (mean %.1f kcyc), accepted tags %.1f Mcyc x%d (mean %.1f kcyc)" % (
