@@ -193,7 +193,10 @@ def test_sgml_tokenizer_replay_of_periodic_documents():
     """csrc/eh_sgml.h replays the tokens of one period of a pumped document instead of walking thousands of copies tag by tag (what
     the heaviest cases of the bench workload spend their time in).  Three ways on pumped documents of 20 KB to a megabyte - period
     starting inside a tag, white space eaten by failed tags, an unterminated quote or comment behind the stretch (nothing may be
-    replayed then), two stretches, stretches barely long enough: replay vs tag-by-tag (EH_FLAG_SGML_NO_REPLAY) vs the oracle, run live."""
+    replayed then), two stretches, stretches barely long enough - and, for the tag attempts made one per lane (sg_lane_attempt), documents
+    without a period: tag soup, runs of failing attempts, tags of thousands of attributes, names over thousands of '<'.  Four ways:
+    replay + lane batches (the default), lane batches only, replay only, the wave-wide machine tag by tag
+    (EH_FLAG_SGML_NO_REPLAY | EH_FLAG_SGML_NO_LANES) vs the oracle, run live."""
     if util.priming():
         pytest.skip("live oracle")
     sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
@@ -202,6 +205,18 @@ def test_sgml_tokenizer_replay_of_periodic_documents():
     assert total == 52 and bad == 0
     total, bad = emu_sgml_replay.run(n=2, seed=9, scale=12, pats="od", verbose=True)
     assert bad == 0
+
+
+def test_base64_chunks_decoded_by_the_wave():
+    """base64_mutator/2 on text full of base64 (csrc/eh_lex.h b64_decode_wave: one group of four per lane, chunks with white space
+    inside packed first): every padding, white space inside groups, between and behind the padding characters, blobs of hundreds of
+    kilobytes, hundreds of chunks per block, chunks base64:decode/1 refuses - bytes, statuses and draw counts against the oracle, live."""
+    if util.priming():
+        pytest.skip("live oracle")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    import emu_b64
+    total, bad = emu_b64.run(n=40, seed=3, scale=20, verbose=True)
+    assert total == 160 and bad == 0
 
 
 def test_fuse_paths_agree_on_the_device():
