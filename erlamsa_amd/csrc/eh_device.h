@@ -26,14 +26,52 @@ EH_DEV uint64_t uni64(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) <
 EH_DEV void wave_sync() { __syncthreads(); }  // workgroup == one wavefront
 
 // ---------------------------------------------------------------------------------------------
-// AS183 jump tables: T?[k] = mult^k mod prime, k = 0..64  (filled by the host at load time)
+// Tables in constant memory, computed by the compiler.  (Until round 4 eh_create filled them with hipMemcpyToSymbol: the only
+// GPU write between process start and the first launch, into the code object's read-only segment - and the place where, on
+// two boxes of round 4 and on the driver's box of round 3, every process died with "Memory access fault by GPU".  Whether
+// those boxes were sick or that write was the cause never showed on a healthy box; now there is no such write.)
+// AS183 jump tables: T?[k] = mult^k mod prime, k = 0..64
 // ---------------------------------------------------------------------------------------------
-__constant__ uint16_t c_T1[65];
-__constant__ uint16_t c_T2[65];
-__constant__ uint16_t c_T3[65];
-// funny_unicode/0 table (erlamsa_mutations.erl:1053-1078): [len, b0..b3] per entry
-__constant__ uint8_t c_funny[192][5];
-__constant__ int c_nfunny;
+struct alignas(16) TabU16x65 { uint16_t v[65]; };   // (16-byte aligned like the arrays they replace: at the struct's natural alignment of 2 the 16-bit reads become vector loads instead of scalar ones)
+constexpr TabU16x65 as183_powers(uint32_t mult, uint32_t prime) {
+  TabU16x65 t{};
+  uint32_t a = 1;
+  for (int k = 0; k <= 64; k++) { t.v[k] = (uint16_t)a; a = a * mult % prime; }
+  return t;
+}
+__constant__ TabU16x65 c_T1 = as183_powers(171, 30269);
+__constant__ TabU16x65 c_T2 = as183_powers(172, 30307);
+__constant__ TabU16x65 c_T3 = as183_powers(170, 30323);
+// funny_unicode/0 (erlamsa_mutations.erl:1053-1078): 17 hand-written sequences, then the UTF-8 encodings of the code points
+// produced by folding (with prepend) over the Codes list.  [len, b0..b3] per entry.
+struct alignas(16) FunnyTab { uint8_t v[192][5]; int n; };
+constexpr FunnyTab funny_unicode() {
+  constexpr uint8_t manual[17][5] = {{3, 239, 191, 191}, {4, 240, 144, 128, 128}, {3, 0xef, 0xbb, 0xbf}, {2, 0xfe, 0xff}, {2, 0xff, 0xfe},
+                                     {4, 0, 0, 0xff, 0xff}, {4, 0xff, 0xff, 0, 0}, {4, 43, 47, 118, 56}, {4, 43, 47, 118, 57},
+                                     {4, 43, 47, 118, 43}, {4, 43, 47, 118, 47}, {3, 247, 100, 76}, {4, 221, 115, 102, 115},
+                                     {3, 14, 254, 255}, {3, 251, 238, 40}, {4, 251, 238, 40, 255}, {4, 132, 49, 149, 51}};
+  constexpr uint32_t codes[29][2] = {{0x0009, 0x000d}, {0x008D, 0x008D}, {0x00a0, 0x00a0}, {0x1680, 0x1680}, {0x180e, 0x180e},
+                                     {0x2000, 0x200a}, {0x2028, 0x2028}, {0x2029, 0x2029}, {0x202f, 0x202f}, {0x205f, 0x205f},
+                                     {0x3000, 0x3000}, {0x200e, 0x200f}, {0x202a, 0x202e}, {0x200c, 0x200d}, {0x0345, 0x0345},
+                                     {0x00b7, 0x00b7}, {0x02d0, 0x02d1}, {0xff70, 0xff70}, {0x02b0, 0x02b8}, {0xfdd0, 0xfdd0},
+                                     {0x034f, 0x034f}, {0x115f, 0x1160}, {0x2065, 0x2069}, {0x3164, 0x3164}, {0xffa0, 0xffa0},
+                                     {0xe0001, 0xe0001}, {0xe0020, 0xe007f}, {0x0e40, 0x0e44}, {0x1f4a9, 0x1f4a9}};
+  FunnyTab t{};
+  int n = 0;
+  for (int i = 0; i < 17; i++, n++) for (int k = 0; k < 5; k++) t.v[n][k] = manual[i][k];
+  for (int g = 28; g >= 0; g--)
+    for (uint32_t p = codes[g][0]; p <= codes[g][1]; p++, n++) {
+      uint8_t* e = t.v[n];
+      if (p < 0x80) { e[0] = 1; e[1] = (uint8_t)p; }
+      else if (p < 0x800) { e[0] = 2; e[1] = (uint8_t)(0xc0 | (0x1f & (p >> 6))); e[2] = (uint8_t)((p & 0x3f) | 0x80); }
+      else if (p < 0x10000) { e[0] = 3; e[1] = (uint8_t)(0xe0 | (0x0f & (p >> 12))); e[2] = (uint8_t)(((p >> 6) & 0x3f) | 0x80); e[3] = (uint8_t)((p & 0x3f) | 0x80); }
+      else { e[0] = 4; e[1] = (uint8_t)(0xf0 | (0x7 & (p >> 18))); e[2] = (uint8_t)(((p >> 12) & 0x3f) | 0x80); e[3] = (uint8_t)(((p >> 6) & 0x3f) | 0x80); e[4] = (uint8_t)((p & 0x3f) | 0x80); }
+    }
+  t.n = n;
+  return t;
+}
+__constant__ FunnyTab c_funny = funny_unicode();
+static_assert(funny_unicode().n == 179, "funny_unicode/0: 17 sequences + 162 code points");
 
 constexpr uint32_t P1 = 30269, P2 = 30307, P3 = 30323;
 
@@ -83,7 +121,7 @@ EH_DEV double rng_uniform(Rng& r) {
 // advance by k draws (k <= 64 via table, else modpow)
 EH_DEV void rng_skip(Rng& r, uint64_t k) {
   if (k <= 64) {
-    r.a1 = (r.a1 * (uint32_t)c_T1[k]) % P1; r.a2 = (r.a2 * (uint32_t)c_T2[k]) % P2; r.a3 = (r.a3 * (uint32_t)c_T3[k]) % P3;
+    r.a1 = (r.a1 * (uint32_t)c_T1.v[k]) % P1; r.a2 = (r.a2 * (uint32_t)c_T2.v[k]) % P2; r.a3 = (r.a3 * (uint32_t)c_T3.v[k]) % P3;
   } else {
     r.a1 = (r.a1 * modpow(171, k, P1)) % P1; r.a2 = (r.a2 * modpow(172, k, P2)) % P2; r.a3 = (r.a3 * modpow(170, k, P3)) % P3;
   }
@@ -91,7 +129,7 @@ EH_DEV void rng_skip(Rng& r, uint64_t k) {
 }
 // the j-th (1-based, j <= 64) NEXT uniform without advancing the state: per-lane j allowed
 EH_DEV double rng_peek(const Rng& r, uint32_t j) {
-  uint32_t b1 = (r.a1 * (uint32_t)c_T1[j]) % P1, b2 = (r.a2 * (uint32_t)c_T2[j]) % P2, b3 = (r.a3 * (uint32_t)c_T3[j]) % P3;
+  uint32_t b1 = (r.a1 * (uint32_t)c_T1.v[j]) % P1, b2 = (r.a2 * (uint32_t)c_T2.v[j]) % P2, b3 = (r.a3 * (uint32_t)c_T3.v[j]) % P3;
   return u_of(b1, b2, b3);
 }
 // erlamsa_rnd:rand/1 (erlamsa_rnd.erl:77): rand(0) = 0 without a draw
@@ -512,7 +550,7 @@ __device__ __noinline__ int muta_byte(Ctx&, int fn) {
   uint32_t p = rng_rand(c.rng, L);
   int d = rng_delta(c.rng);
   uint32_t ins_idx = 0;
-  if (fn == M_UI) ins_idx = rng_rand(c.rng, (uint32_t)c_nfunny);  // rand_elem(funny_unicode()) is drawn even for <<>>
+  if (fn == M_UI) ins_idx = rng_rand(c.rng, (uint32_t)c_funny.n);  // rand_elem(funny_unicode()) is drawn even for <<>>
   c.r_kind = R_SAME;
   if (L == 0) return d;  // edit_byte_vector(<<>>, _, _) -> <<>>
   uint32_t b = uni(src[p]);
@@ -532,11 +570,11 @@ __device__ __noinline__ int muta_byte(Ctx&, int fn) {
     case M_UI: break;
   }
   if (fn == M_UI) {
-    uint32_t il = c_funny[ins_idx][0];
+    uint32_t il = c_funny.v[ins_idx][0];
     uint8_t* dst = ws_alloc(c, (uint64_t)L + il);
     if (!dst) return d;
     wave_copy(dst, src, p + 1);
-    if ((uint32_t)EH_LANE < il) dst[p + 1 + EH_LANE] = c_funny[ins_idx][1 + EH_LANE];
+    if ((uint32_t)EH_LANE < il) dst[p + 1 + EH_LANE] = c_funny.v[ins_idx][1 + EH_LANE];
     wave_copy(dst + p + 1 + il, src + p + 1, L - p - 1);
     c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = L + il;
     return d;

@@ -230,7 +230,7 @@ __device__ __noinline__ int pick_csum(Ctx&, const uint8_t* H, uint32_t L, uint32
     ByteReader r; br_init(r, H, L);
     for (uint32_t A = 0; A < np; A++) {
       if (l == 0) pre[A] = run ^ 0xFFFFFFFFu;                       // crc32(bytes[0..A))
-      if (A < L) run = c_crc_table[(run ^ br_get(r, A, A)) & 0xFF] ^ (run >> 8);
+      if (A < L) run = c_crc_table.v[(run ^ br_get(r, A, A)) & 0xFF] ^ (run >> 8);
     }
     wave_sync();
     // ... then every lane tests its own preamble:
@@ -1117,38 +1117,6 @@ static int parse_actions(eh_ctx* ctx, const char* s, bool muta, std::vector<long
   return EH_OK;
 }
 
-static void init_tables(uint16_t* t1, uint16_t* t2, uint16_t* t3) {
-  uint32_t a = 1, b = 1, c = 1;
-  for (int k = 0; k <= 64; k++) { t1[k] = (uint16_t)a; t2[k] = (uint16_t)b; t3[k] = (uint16_t)c; a = a * 171 % 30269; b = b * 172 % 30307; c = c * 170 % 30323; }
-}
-// funny_unicode/0 (erlamsa_mutations.erl:1053-1078): 17 hand-written sequences, then the UTF-8
-// encodings of the code points produced by folding (with prepend) over the Codes list.
-static int build_funny(uint8_t (*out)[5]) {
-  static const uint8_t manual[17][5] = {{3, 239, 191, 191}, {4, 240, 144, 128, 128}, {3, 0xef, 0xbb, 0xbf}, {2, 0xfe, 0xff}, {2, 0xff, 0xfe},
-                                        {4, 0, 0, 0xff, 0xff}, {4, 0xff, 0xff, 0, 0}, {4, 43, 47, 118, 56}, {4, 43, 47, 118, 57},
-                                        {4, 43, 47, 118, 43}, {4, 43, 47, 118, 47}, {3, 247, 100, 76}, {4, 221, 115, 102, 115},
-                                        {3, 14, 254, 255}, {3, 251, 238, 40}, {4, 251, 238, 40, 255}, {4, 132, 49, 149, 51}};
-  static const uint32_t codes[][2] = {{0x0009, 0x000d}, {0x008D, 0x008D}, {0x00a0, 0x00a0}, {0x1680, 0x1680}, {0x180e, 0x180e},
-                                      {0x2000, 0x200a}, {0x2028, 0x2028}, {0x2029, 0x2029}, {0x202f, 0x202f}, {0x205f, 0x205f},
-                                      {0x3000, 0x3000}, {0x200e, 0x200f}, {0x202a, 0x202e}, {0x200c, 0x200d}, {0x0345, 0x0345},
-                                      {0x00b7, 0x00b7}, {0x02d0, 0x02d1}, {0xff70, 0xff70}, {0x02b0, 0x02b8}, {0xfdd0, 0xfdd0},
-                                      {0x034f, 0x034f}, {0x115f, 0x1160}, {0x2065, 0x2069}, {0x3164, 0x3164}, {0xffa0, 0xffa0},
-                                      {0xe0001, 0xe0001}, {0xe0020, 0xe007f}, {0x0e40, 0x0e44}, {0x1f4a9, 0x1f4a9}};
-  int n = 0;
-  for (int i = 0; i < 17; i++, n++) memcpy(out[n], manual[i], 5);
-  const int ng = (int)(sizeof(codes) / sizeof(codes[0]));
-  for (int g = ng - 1; g >= 0; g--)
-    for (uint32_t p = codes[g][0]; p <= codes[g][1]; p++, n++) {
-      uint8_t* e = out[n];
-      auto ext = [](uint32_t v) { return (uint8_t)((v & 0x3f) | 0x80); };
-      if (p < 0x80) { e[0] = 1; e[1] = (uint8_t)p; }
-      else if (p < 0x800) { e[0] = 2; e[1] = (uint8_t)(0xc0 | (0x1f & (p >> 6))); e[2] = ext(p); }
-      else if (p < 0x10000) { e[0] = 3; e[1] = (uint8_t)(0xe0 | (0x0f & (p >> 12))); e[2] = ext(p >> 6); e[3] = ext(p); }
-      else { e[0] = 4; e[1] = (uint8_t)(0xf0 | (0x7 & (p >> 18))); e[2] = ext(p >> 12); e[3] = ext(p >> 6); e[4] = ext(p); }
-    }
-  return n;
-}
-
 static int ensure_results(eh_ctx* ctx, uint64_t n) {
   if (n <= ctx->res_cap) return EH_OK;
   if (ctx->d_off) { (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len); (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_peak); (void)hipFree(ctx->d_toff); (void)hipFree(ctx->d_tlen); }
@@ -1404,18 +1372,8 @@ int eh_create(int device, eh_ctx** out) {
   // may already exist (another context of this process, a co-resident torch)
   if (hipDeviceGetLimit(&have, hipLimitStackSize) != hipSuccess) have = 0;
   if (have < stack_bytes && hipDeviceSetLimit(hipLimitStackSize, stack_bytes) != hipSuccess) { delete ctx; return EH_E_HIP; }
-  uint16_t t1[65], t2[65], t3[65];
-  init_tables(t1, t2, t3);
-  uint32_t crct[256];
-  for (uint32_t i = 0; i < 256; i++) { uint32_t cc = i; for (int k = 0; k < 8; k++) cc = (cc & 1) ? 0xEDB88320u ^ (cc >> 1) : cc >> 1; crct[i] = cc; }
-  if (hipMemcpyToSymbol(HIP_SYMBOL(c_crc_table), crct, sizeof(crct)) != hipSuccess) { delete ctx; return EH_E_HIP; }
-  static uint8_t funny[192][5];
-  memset(funny, 0, sizeof(funny));
-  int nf = build_funny(funny);
-  if (hipMemcpyToSymbol(HIP_SYMBOL(c_T1), t1, sizeof(t1)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_T2), t2, sizeof(t2)) != hipSuccess ||
-      hipMemcpyToSymbol(HIP_SYMBOL(c_T3), t3, sizeof(t3)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_funny), funny, sizeof(funny)) != hipSuccess ||
-      hipMemcpyToSymbol(HIP_SYMBOL(c_nfunny), &nf, sizeof(nf)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
-      hipEventCreate(&ctx->ev1) != hipSuccess) {
+  // (the constant tables - AS183 powers, CRC-32, funny_unicode/0 - are initialised in the code object: eh_device.h, eh_zlib.h)
+  if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
     eh_destroy(ctx);
     return EH_E_HIP;
   }

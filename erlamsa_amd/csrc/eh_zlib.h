@@ -31,7 +31,13 @@ constexpr int Z_L_CODES = 286, Z_D_CODES = 30, Z_BL_CODES = 19, Z_HEAP_SIZE = 2 
 constexpr int Z_GOOD_MATCH = 8, Z_MAX_LAZY = 16, Z_NICE_MATCH = 128, Z_MAX_CHAIN = 128;        // configuration_table[6]
 
 // CRC-32 (zlib polynomial, reflected) helpers (csum pattern, gzip and zip containers)
-__constant__ uint32_t c_crc_table[256];
+struct alignas(16) TabU32x256 { uint32_t v[256]; };
+constexpr TabU32x256 crc32_table() {
+  TabU32x256 t{};
+  for (uint32_t i = 0; i < 256; i++) { uint32_t cc = i; for (int k = 0; k < 8; k++) cc = (cc & 1) ? 0xEDB88320u ^ (cc >> 1) : cc >> 1; t.v[i] = cc; }
+  return t;
+}
+__constant__ TabU32x256 c_crc_table = crc32_table();       // (computed by the compiler, like the tables of eh_device.h)
 EH_DEV uint32_t gf2_multmodp(uint32_t a, uint32_t b) {            // a(x)*b(x) mod p(x), reflected representation (x^0 = bit 31)
   uint32_t m = 1u << 31, p = 0;
   for (;;) {
@@ -52,7 +58,7 @@ EH_DEV uint32_t wave_crc32(const uint8_t* p, uint32_t n) {
   uint32_t chunk = (n + 63) / 64;
   uint32_t a = (uint32_t)l * chunk, b = a + chunk; if (a > n) a = n; if (b > n) b = n;
   uint32_t crc = 0xFFFFFFFFu;
-  for (uint32_t i = a; i < b; i++) crc = c_crc_table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+  for (uint32_t i = a; i < b; i++) crc = c_crc_table.v[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
   crc ^= 0xFFFFFFFFu;                                              // crc32 of my chunk (0 for an empty chunk)
   uint32_t total = 0; uint32_t done = 0;
   for (int k = 0; k < 64; k++) {                                   // crc32_combine left to right
@@ -600,7 +606,7 @@ EH_DEV int z_inflate_pass(ZInf* zi, const uint8_t* in, uint64_t n, uint64_t off,
 EH_DEV int z_uncompress_size(ZInf* zi, int fmt, const uint8_t* in, uint64_t n, uint64_t* outn, uint64_t* data_off) {
   uint64_t off = 0; int early = -1;                                                      // early: 1 = empty result, 0 = raises
   if (EH_LANE == 0) {
-    if (fmt == ZF_GZIP) { off = zi_gzip_header(in, n, c_crc_table); if (off == 0) early = 0; }
+    if (fmt == ZF_GZIP) { off = zi_gzip_header(in, n, c_crc_table.v); if (off == 0) early = 0; }
     else {
       if (n < 2) early = 1;                                                              // HEAD needs 16 bits: nothing decoded, no error
       else {
