@@ -312,7 +312,7 @@ def test_bench_workload_full_table_vs_oracle():
     """THE WORKLOAD bench.py TIMES, against the oracle: BASELINE configs[2] — synth.mixed(65536, 4096), the reference's full
     default mutator table (41 entries), patterns od,nd,bu, no work budget, max_case_bytes 4 MiB / big_case_bytes 1 GiB —
     run as one pass of 65 536 cases; compared with tests/golden/bench_r03.npz (made by tests/golden/make_bench_golden.py
-    from the oracle with the same 1 GiB cap) on rows 0..4095 and on the 200 heaviest cases of the pass
+    from the oracle with the same 1 GiB cap) on rows 0..4095 and on the 214 heaviest cases of the pass (round 3's 200 and what round 4's last survey added)
     (tests/golden/bench_heavy_cases.json: multi-megabyte blocks under fuse / sgm / b64 / tree mutators, outputs up to
     1 GB): status, PRNG draw count, length and SHA-1 of every output.  A case may only end with an engine-only status when
     the capacity check that gave up is one of ENGINE_LIMIT_SITES — and then the oracle, under the same cap, must agree."""
