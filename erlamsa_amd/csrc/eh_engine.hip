@@ -1362,11 +1362,11 @@ int eh_create(int device, eh_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return EH_E_NODEVICE; }
   ctx->cus = prop.multiProcessorCount;
-  // eh_mutate_kernel recurses (nested scheduler calls of b64 / sgm / js, depth <= MAX_NEST): ~0.6 KiB of private stack
-  // per level on top of the kernel's fixed 1.2 KiB
-  // worst chain (per-function frames from the assembler's private_seg_size expressions): kernel 192 + (MAX_NEST + 1) x
-  // (muta_sgml 272 + nested_fuzz 288) = 4.1 KiB.  The runtime sizes every hardware queue's scratch for all wavefront
-  // slots of the device at this size (16 KiB meant ~8 GiB per queue).
+  // eh_mutate_kernel recurses (nested scheduler calls of b64 / sgm / js, depth <= MAX_NEST).  Deepest chain, from the
+  // assembler's private_seg_size expressions (tools/stack_chain.py evaluates them; end of round 4): kernel 448 + MAX_NEST x
+  // (muta_b64 304 + nested_fuzz 384) + the heaviest leaf (muta_sgml 288 + sgml_tokenize 792) = 5 656 bytes per lane, 488
+  // below the limit set here.  The runtime sizes every hardware queue's scratch for all wavefront slots of the device
+  // at this size (16 KiB meant ~8 GiB per queue).
   size_t stack_bytes = 6144, have = 0;
   // only ever raised, and only when it has to be: changing the limit makes the runtime re-size the scratch of queues that
   // may already exist (another context of this process, a co-resident torch)
