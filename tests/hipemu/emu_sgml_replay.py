@@ -19,6 +19,8 @@ import pyoracle as po
 import erlamsa_amd as ea
 from erlamsa_amd.engine import EH_FLAG_SGML_NO_REPLAY, EH_FLAG_SGML_NO_LANES
 
+FAILRUN_UNITS = [b"<a =1 <b =2 <c =3 <d>x</d>", b"< p =1< q =2 < r =3 <s t='u'>v</s> ", b"<a =1 <b =2 <c =3 <e =4 <f =5 <g h=i j>k</g>\n", b"<x y=\"1 <x y=\"2 <x y=\"3 <z>\"w</z>",
+                 b"<m<n =1 <o =2 <p =3 </m>text"]
 UNITS = [
     b"<a>x</a>", b"<b k='v' j=\"w\" u=z>text <i/> more</b>\n", b"<c  x = 'q q' ><d/></c> ", b"<!-- note --><e>1</e>", b"<?pi data?><f g=h>t</f>",
     b"< g>lost white space</g>", b"<h a b c>t</h>", b"plain text without tags ", b"<i j='k'>l<m n=\"o\"/>p</i>\r\n\t", b"<q =bad>r</q><s>t</s>",
@@ -64,8 +66,15 @@ def corpus(n, seed, scale=1, small=False):
         unit2 = b"<" + w(2, 6) + b"/" + w(5, 30)                                            # names that run over thousands of '<' and '/' (neither ends a name)
         out.append(head + unit2 * (int(rng.integers(1500, 4000)) * scale) + rng.choice([b" x=1>", b">", b"/>", b"", b" "]) + words(30) + tail)
         out.append(head + b"".join(b"<" + w(1, 12) + rng.choice([b"", b"/", b"<", b"'", b"\""]) for _ in range(int(rng.integers(2000, 5000)) * scale)) + rng.choice([b" y>", b"", b"=", b"/>"]) + tail)
+        # runs of three and more failing attempts INSIDE a periodic stretch: lane batches while the replay records its template / check
+        # period (one accepted tag per batch there).  Its own generator: the documents above stay what they were before this kind came.
+        rng2 = np.random.Generator(np.random.PCG64([seed, k, 77]))
+        fu = FAILRUN_UNITS[int(rng2.integers(0, len(FAILRUN_UNITS)))]
+        reps2 = max(4, int(rng2.integers(300, 900)) * scale // (10 if small else 1))
+        cut2 = int(rng2.integers(0, len(fu)))
+        out.append(b"<doc>" + fu[cut2:] + fu * reps2 + fu[:cut2] + (b"</doc>", b"<!-- ", b"<v w='")[int(rng2.integers(0, 3))])
     if small:
-        out = [d for k, d in enumerate(out) if k % 13 >= 6]                                  # the kinds without a period: what the lane batches are for (the periodic ones need their full length anyway)
+        out = [d for k, d in enumerate(out) if k % 14 >= 6]                                  # the kinds without a period: what the lane batches are for (the periodic ones need their full length anyway)
     return out
 
 
@@ -99,7 +108,7 @@ def run(n=1, seed=1, scale=1, pats="od,nd,bu", verbose=True, small=False):
             bad += 1
             if verbose and bad <= 8:
                 print("case %d (kind %d, len %d): replay vs oracle %s, replay vs walk %s; status %d/%d/%d draws %d/%d/%d len %d/%d/%d" % (
-                    i, i % 13, len(inputs[i]), ok_o, ok_n, a[1][i], b[1][i], o.status[i], a[2][i], b[2][i], o.draws[i], len(a[0][i]), len(b[0][i]), len(o.outs[i])))
+                    i, i % 14, len(inputs[i]), ok_o, ok_n, a[1][i], b[1][i], o.status[i], a[2][i], b[2][i], o.draws[i], len(a[0][i]), len(b[0][i]), len(o.outs[i])))
     if verbose:
         print("cases %d bad %d; %s, oracle %.1f s; input bytes %d" % (len(inputs), bad, ", ".join("%s %.1f s" % (
             {"replay": "replay+lanes", "walk": "tag by tag", "lanes": "lanes only", "nolanes": "replay only"}[k], v[3]) for k, v in res.items()), to, sum(map(len, inputs))))
