@@ -4,7 +4,8 @@ kernel code is checked against the rule that, between two rendezvous points of t
 wrote or overwrites a byte another lane read.  The plain emulator cannot see such a bug (lane 0 runs first, so the others do see
 what it wrote); a real wavefront promises nothing without the wave_sync().  Workloads: the file / jump / random generators, gzip /
 zlib / zip containers (their codecs run on lane 0 and hand results to the wavefront), nearly full and tiny slots with the default
-tables (nested scheduler calls, areas borrowed and returned), the streaming fuse with the meta trace.  The same hooks check
+tables (nested scheduler calls, areas borrowed and returned), the streaming fuse with the meta trace, the sgm tokenizer's lane
+batches and the base64 decode by the wave (round 4).  The same hooks check
 BOUNDS: in this build every device allocation has a guard zone on either side, and an access that lands in one is reported.
 
   ERLAMSA_HIP_LIB=build/liberlamsa_hip_emu_race.so python tests/hipemu/emu_race.py [cases per workload]
@@ -58,6 +59,12 @@ run("gzip / zlib through cp", ec.compressed_corpus(2 * n, 300), mutations="bd,bf
 run("zip through ar and zip", ec.zip_corpus(2 * n, 500), mutations="zip=3,bd,sr,num", patterns="ar=3,od,nd")
 run("default tables, 16 KiB slots", util.corpus_mixed(n, 700, seed=9) + synth.sgml_docs(2, seed=5) + synth.json_docs(2, seed=6), slot=16384)
 run("streaming fuse + meta trace", util.corpus_mixed(n, 3000, seed=4), mutations="ft,fn,fo,bd", patterns="od,nd,bu", fsm=64, flags=ea.engine.EH_FLAG_META_TRACE)
+import emu_sgml_replay
+import emu_b64
+# round 4: tag attempts one per lane (pieces, tokens and memo marks written by the lanes, read by the wave-wide machine), base64 chunks
+# packed and decoded by the wave
+run("sgm: lane batches", emu_sgml_replay.corpus(1, 21, 1, small=True)[:3], mutations="sgm", patterns="od", slot=8 << 20)
+run("b64: decode by the wave", emu_b64.corpus(1, 21)[1:3], mutations="b64", patterns="od", slot=8 << 20)
 races = lib.hipemu_race_count()
 if races:
     pcs = (ctypes.c_void_p * 256)(); cnt = (ctypes.c_ulong * 256)()
