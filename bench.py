@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--setup-seconds", type=int, default=150, help="single-GPU runs execute in a child process; a child whose set-up passes (the first "
                     "dispatch on every HIP stream) have not finished after this many seconds is killed and the run repeated with "
                     "--inflight 3, then 1 (0 = no supervision)")
+    ap.add_argument("--case-stats", type=int, default=1, help="1: collect per-case wave cycles and output lengths of the timed steps (one small D2H copy per "
+                    "collected pass, outside no kernel's way) and report them under 'case_stats': how the bytes and the cycles are distributed over the cases")
     ap.add_argument("--profiled", type=int, default=0, help="1: the run is under rocprofv3 - no child process (--setup-seconds 0) and the process ends by "
                     "returning from main() instead of os._exit, so that the profiler's tool gets to write its output")
     pre, _ = ap.parse_known_args()
@@ -343,8 +345,14 @@ def main():
     overflow_sites = {}
     names = [m for m, _, _ in ea.mutator_table()]
 
+    cyc_pass, len_hist = [], []
+
     def on_result(k, e):                                      # which capacity check gave up, for the cases that end as EH_CASE_OVERFLOW
         st = e.status()
+        if args.case_stats:
+            cy = e.cycles()
+            cyc_pass.append((int(cy.sum()), int(cy.max()), int(cy.argmax()) + 1 + k * n))
+            len_hist.append(np.sort(e.lens()))
         if (st == 2).any():
             _, lm = e.diag()
             for site in (-lm[st == 2]).tolist():
@@ -442,6 +450,28 @@ def main():
                                    "about 1/%d of the device's" % (nctx, nctx),
                          "achieved_all_in_flight": round(alg_bytes / (dt_all / args.steps) / 1e9, 2)},
         }
+        if args.case_stats and len_hist:
+            # How the headline is made: the default table pumps (sr, lr, tr, sgm, fuse repeat data), so a small share
+            # of the cases carries most of the bytes and of the wave cycles.
+            al = np.concatenate(len_hist).astype(np.float64)
+            al.sort()
+            tot = float(al.sum()) or 1.0
+            top1 = al[int(len(al) * 0.99):]
+            small = al[al <= 65536]
+            res["case_stats"] = {
+                "what": "all %d cases of the timed steps" % len(al),
+                "output_bytes_percentiles": {"p50": int(al[len(al) // 2]), "p90": int(al[int(len(al) * 0.9)]), "p99": int(al[int(len(al) * 0.99)]),
+                                             "p99.9": int(al[int(len(al) * 0.999)]), "max": int(al[-1]), "mean": round(tot / len(al), 1)},
+                "share_of_bytes_from_top_1pct_of_cases": round(float(top1.sum()) / tot, 4),
+                "share_of_bytes_from_top_10pct_of_cases": round(float(al[int(len(al) * 0.9):].sum()) / tot, 4),
+                "cases_with_output_le_64KiB": {"share_of_cases": round(len(small) / len(al), 4), "share_of_bytes": round(float(small.sum()) / tot, 4),
+                                               "cases_per_s": round(len(small) / dt_all, 1), "MB_per_s": round(float(small.sum()) / dt_all / 1e6, 1)},
+                "wave_cycles_per_pass": {"mean_sum_G": round(float(np.mean([c[0] for c in cyc_pass])) / 1e9, 1),
+                                         "heaviest_case_Mcyc_mean_over_passes": round(float(np.mean([c[1] for c in cyc_pass])) / 1e6, 1),
+                                         "heaviest_case_Mcyc_max": round(max(c[1] for c in cyc_pass) / 1e6, 1),
+                                         "heaviest_case_number": max(cyc_pass, key=lambda c: c[1])[2],
+                                         "note": "s_memtime cycles of the wavefront that ran the case, measured WITH the other passes in flight"},
+            }
         if int(status_counts[4]) > 0:                             # EH_CASE_ARENA_FULL inside the timed steps: those cases' outputs are missing from `value`
             res["warning"] = "%d cases of the timed steps did not fit their pass's output arena (%d GiB): raise --out-gib; value counts the bytes that were produced" % (int(status_counts[4]), args.out_gib)
             log(res["warning"])

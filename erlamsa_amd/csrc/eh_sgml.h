@@ -240,6 +240,9 @@ __device__ __noinline__ SgLaneTag sg_lane_attempt(const uint8_t* H, uint32_t L, 
 __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, SgDoc* out) {
   EH_CTX;
   const int l = EH_LANE;
+#ifdef EH_PROF
+  const uint64_t ph1_t0 = __builtin_readcyclecounter();
+#endif
   // ---- phase 1: events
   uint32_t* ev = (uint32_t*)ws_alloc(c, ((uint64_t)L + 80) * 4);
   if (!ev) return -3;
@@ -268,10 +271,18 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   }
   nlt = wave_sum(nlt); nstop = wave_sum(nstop);
 #ifdef EH_PROF
+  uint64_t sub_t0 = __builtin_readcyclecounter();
+#define SG_SUB0() do { sub_t0 = __builtin_readcyclecounter(); } while (0)
+#define SG_SUB(k) do { uint64_t n_ = __builtin_readcyclecounter(); if (l == 0) { atomicAdd(&c.p->prof[2 * (k)], (unsigned long long)(n_ - sub_t0)); atomicAdd(&c.p->prof[2 * (k) + 1], 1ull); } sub_t0 = n_; } while (0)
+#define SG_CNT(k, v) do { if (l == 0) { atomicAdd(&c.p->prof[2 * (k)], (unsigned long long)(v)); atomicAdd(&c.p->prof[2 * (k) + 1], 1ull); } } while (0)
+  if (l == 0) { atomicAdd(&c.p->prof[2 * 117], (unsigned long long)(sub_t0 - ph1_t0)); atomicAdd(&c.p->prof[2 * 117 + 1], 1ull); atomicAdd(&c.p->prof[2 * 119], (unsigned long long)nev); atomicAdd(&c.p->prof[2 * 119 + 1], (unsigned long long)L); }
   uint64_t tz_t0 = __builtin_readcyclecounter();
 #define SG_TZ(k) do { uint64_t n_ = __builtin_readcyclecounter(); if (l == 0) { atomicAdd(&c.p->prof[2 * (k)], (unsigned long long)(n_ - tz_t0)); atomicAdd(&c.p->prof[2 * (k) + 1], 1ull); } tz_t0 = n_; } while (0)
 #else
 #define SG_TZ(k) do {} while (0)
+#define SG_SUB0() do {} while (0)
+#define SG_SUB(k) do {} while (0)
+#define SG_CNT(k, v) do {} while (0)
 #endif
   if (nlt == 0) return -1;                                                 // tz(nil, <<>>) :102
   // capacity: tokens <= 2 x '<' + 2; a parameter needs a byte of the stop set after its name
@@ -338,6 +349,9 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
     EH_CTX;
     nstop_tab = (uint32_t*)ws_alloc(c, ((uint64_t)nev + 64) * 4);
     if (!nstop_tab) return false;
+#ifdef EH_PROF
+    const uint64_t bn_t0 = __builtin_readcyclecounter();
+#endif
     uint32_t carry = nev;
     for (uint32_t base = (nev - 1) & ~63u;; base -= 64) {
       uint32_t j = base + (uint32_t)l; uint32_t e = j < nev ? ev[j] : 0u;
@@ -348,6 +362,9 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
       if (base == 0) break;
     }
     wave_sync();
+#ifdef EH_PROF
+    if (l == 0) { atomicAdd(&c.p->prof[2 * 116], (unsigned long long)(__builtin_readcyclecounter() - bn_t0)); atomicAdd(&c.p->prof[2 * 116 + 1], 1ull); }
+#endif
     return true;
   };
   auto find_stop = [&](uint32_t from, uint32_t set) -> uint32_t {          // set: ES_STOP or ES_EV
@@ -667,6 +684,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
     uint32_t j = find(0, 1u << E_LT);
     lt = evget(j) >> 4; pos = lt + 1; ei = j + 1;
   }
+  SG_SUB(112);                                                             // set-up: tables, the first stretch search, the first '<'
   for (;;) {
     if (npc + 16 > cap_pc || ntok + 2 > cap_tok) { EH_SET_OVERFLOW(c, 601); return -3; }
     SG_TZ(86);                                                             // eh_result_prof 86: text state + bookkeeping between attempts
@@ -784,6 +802,8 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
     } while (false);
     if (c.status != CASE_OK) return -3;
     if (ok) SG_TZ(88); else SG_TZ(87);                                     // 88: accepted tags, 87: failed attempts
+    SG_CNT(118, npar - par0);                                              // attributes the attempt walked
+    SG_SUB0();
     if (ok) {
       // the text before the tag (if any) and the tag itself
       if (!first) {
@@ -798,6 +818,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
       pos = next; ei = nexte; seg_start = next; text_p0 = npc; text_len = 0;
       fail_run = 0;
       { const int r = after_accept(); if (r) return r; }
+      SG_SUB(113);
     } else {
       if (first) { rc = other ? -2 : -1; break; }
       if (nchain > 0) {                                                    // remember where this attempt entered the attribute loop
@@ -818,9 +839,12 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
       pos = tag0; ei = ei0;                                                // ff/4 goes on from EStr
       fail_run++;
     }
+    SG_SUB0();
     { const int r = lane_batches(); if (r) return r; }
+    SG_SUB(114);
     // ---- text state: ff/4 :166-174
     uint32_t j = find(ei, 1u << E_LT);
+    SG_SUB(115);
     if (j >= nev) {                                                        // {{text,Str},"",eof} :82-83,:94-95
       uint32_t n = L - seg_start;
       put(H + seg_start, n); text_len += n;

@@ -531,14 +531,14 @@ __device__ __noinline__ int zi_blocks(ZInf& z) {
 // (a length / distance pair whose bits run out half way has consumed its first part here while inflate.c would keep it for the
 //  next call; the stream stops in both, with the same bytes written)
 
-// zlib:gunzip/1 = inflateInit2(16 + 15), inflate, inflateEnd: success only for a complete member with correct CRC-32 and ISIZE
-// (anything after it is ignored); everything else is error:data_error for the caller.
-// OTP VERSION: this is zlib:gunzip/1 of OTP 18 - 20.0 (the reference asks for "OTP 18.0+", its CI ran 18 - 23).  From OTP 20.1 on
-// gunzip/1 calls inflateInit(Z, 16 + MAX_WBITS, reset): concatenated members are ALL decoded and bytes that are not another
-// member raise data_error (the pattern then tries the zlib path and ends as {compressed, failed}).  Engine, oracle
-// (oracle.cpp otpz::gunzip) and tests/hipemu/emu_zlib.py implement the older rule alike, so parity tests cannot see the
-// difference; it only shows on inputs that are gz + gz or gz + trailing bytes.  Parses the header, returns the offset of
-// the deflate data or 0.
+// zlib:gunzip/1 of OTP 20.1 - 23 (the OTP TARGET of this engine and of oracle/): inflateInit(Z, 16 + MAX_WBITS,
+// reset), inflate(Z, Data), inflateEnd(Z).  With the `reset` end-of-stream behaviour the NIF calls inflateReset when a member has
+// ended and input is left, so CONCATENATED MEMBERS ARE ALL DECODED (their data concatenated); bytes that are not another complete
+// member are a data_error (a bad header at once, an unfinished one at inflateEnd, which raises data_error unless the last call
+// saw the end of a stream).  So: success only for one or more complete members, each with correct CRC-32 and ISIZE, and nothing
+// else; everything else is error:data_error for the caller (mutate_once_compressed then tries the zlib path, which fails on the
+// gzip magic, and the block ends as {compressed, failed}).  Until round 4 this was the rule of OTP 18 - 20.0 (first member only,
+// trailing bytes ignored).  Parses one member header at p, returns the offset of its deflate data or 0.
 EH_DEV uint64_t zi_gzip_header(const uint8_t* p, uint64_t n, const uint32_t* crc_table) {
   if (n < 10 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xe0)) return 0;
   uint32_t flags = p[3]; uint64_t pos = 10;
@@ -604,42 +604,68 @@ EH_DEV int z_inflate_pass(ZInf* zi, const uint8_t* in, uint64_t n, uint64_t off,
 // nobody calls inflateEnd), 0 when the call raises (data_error, need_dictionary).  Phase 2: z_uncompress_write into a buffer of *outn
 // bytes; checks the trailer (CRC-32 + ISIZE / Adler-32) and returns 0 when it is wrong.
 EH_DEV int z_uncompress_size(ZInf* zi, int fmt, const uint8_t* in, uint64_t n, uint64_t* outn, uint64_t* data_off) {
+  *data_off = 0; *outn = 0;
+  if (fmt == ZF_GZIP) {                                                                  // every member in turn (inflateReset): count
+    uint64_t pos = 0, total = 0;
+    do {
+      if (EH_LANE == 0) zi->pos = zi_gzip_header(in + pos, n - pos, c_crc_table.v);
+      wave_sync();
+      const uint64_t off = uni64(zi->pos);
+      if (off == 0) return 0;                                                            // not a member (or its header stops): data_error
+      uint64_t end;
+      const int st = z_inflate_pass(zi, in + pos, n - pos, off, nullptr, &end);
+      if (st != ZS_END || end + 8 > n - pos) return 0;                                   // data error / an unfinished member: inflateEnd raises
+      total += uni64(zi->outn);
+      if (total > 0xFFFFFF00ull) { *outn = total; return 1; }                            // (the caller gives up on the size)
+      pos += end + 8;
+    } while (pos < n);
+    *outn = total;
+    return 1;
+  }
   uint64_t off = 0; int early = -1;                                                      // early: 1 = empty result, 0 = raises
   if (EH_LANE == 0) {
-    if (fmt == ZF_GZIP) { off = zi_gzip_header(in, n, c_crc_table.v); if (off == 0) early = 0; }
+    if (n < 2) early = 1;                                                                // HEAD needs 16 bits: nothing decoded, no error
     else {
-      if (n < 2) early = 1;                                                              // HEAD needs 16 bits: nothing decoded, no error
-      else {
-        uint32_t b0 = in[0], b1 = in[1];
-        if (((b0 << 8) + b1) % 31 != 0 || (b0 & 0x0f) != 8 || (b0 >> 4) + 8 > 15) early = 0;   // incorrect header check / unknown compression method / invalid window size
-        else if (b1 & 0x20) early = n >= 6 ? 0 : 1;                                      // FDICT: {need_dictionary, Adler} once the id is there
-        off = 2;
-      }
+      uint32_t b0 = in[0], b1 = in[1];
+      if (((b0 << 8) + b1) % 31 != 0 || (b0 & 0x0f) != 8 || (b0 >> 4) + 8 > 15) early = 0;   // incorrect header check / unknown compression method / invalid window size
+      else if (b1 & 0x20) early = n >= 6 ? 0 : 1;                                        // FDICT: {need_dictionary, Adler} once the id is there
+      off = 2;
     }
     zi->early = early; zi->pos = off;
   }
   wave_sync();
   early = (int)uni((uint32_t)zi->early); off = uni64(zi->pos);
-  *data_off = off; *outn = 0;
+  *data_off = off;
   if (early >= 0) return early;
   uint64_t end;
   int st = z_inflate_pass(zi, in, n, off, nullptr, &end);
   *outn = uni64(zi->outn);
   if (st == ZS_ERROR) return 0;
-  if (st == ZS_TRUNC) return fmt == ZF_ZLIB ? 1 : 0;                                     // gunzip's inflateEnd raises data_error for an unfinished stream
-  return 1;
+  return 1;                                                                              // ZS_TRUNC: inflate/2 returns what it decoded, nobody calls inflateEnd
 }
 EH_DEV int z_uncompress_write(ZInf* zi, int fmt, const uint8_t* in, uint64_t n, uint64_t data_off, uint8_t* out, uint64_t outn) {
-  if (outn == 0 && (fmt == ZF_ZLIB && (n < 2 || (in[1] & 0x20)))) return 1;
   uint64_t end;
-  int st = z_inflate_pass(zi, in, n, data_off, out, &end);
-  if (st != ZS_END) return st == ZS_TRUNC && fmt == ZF_ZLIB ? 1 : 0;
-  if (fmt == ZF_GZIP) {
-    if (end + 8 > n) return 0;                                                           // CHECK / LENGTH states starve: inflateEnd -> data_error
-    uint32_t crc = wave_crc32(out, (uint32_t)outn);
-    uint32_t c0 = 0, l0 = 0; for (int i = 0; i < 4; i++) { c0 |= (uint32_t)uni(in[end + i]) << (8 * i); l0 |= (uint32_t)uni(in[end + 4 + i]) << (8 * i); }
-    return c0 == crc && l0 == (uint32_t)outn ? 1 : 0;
+  if (fmt == ZF_GZIP) {                                                                  // the members again, written one behind the other
+    uint64_t pos = 0, total = 0;
+    do {
+      if (EH_LANE == 0) zi->pos = zi_gzip_header(in + pos, n - pos, c_crc_table.v);
+      wave_sync();
+      const uint64_t off = uni64(zi->pos);
+      if (off == 0) return 0;
+      const int st = z_inflate_pass(zi, in + pos, n - pos, off, out + total, &end);
+      const uint64_t mlen = uni64(zi->outn);
+      if (st != ZS_END || end + 8 > n - pos || total + mlen > outn) return 0;            // CHECK / LENGTH states starve: inflateEnd -> data_error
+      const uint32_t crc = wave_crc32(out + total, (uint32_t)mlen);
+      const uint8_t* t = in + pos + end;
+      uint32_t c0 = 0, l0 = 0; for (int i = 0; i < 4; i++) { c0 |= (uint32_t)uni(t[i]) << (8 * i); l0 |= (uint32_t)uni(t[4 + i]) << (8 * i); }
+      if (c0 != crc || l0 != (uint32_t)mlen) return 0;                                   // incorrect data check / incorrect length check
+      total += mlen; pos += end + 8;
+    } while (pos < n);
+    return total == outn ? 1 : 0;
   }
+  if (outn == 0 && (n < 2 || (in[1] & 0x20))) return 1;
+  int st = z_inflate_pass(zi, in, n, data_off, out, &end);
+  if (st != ZS_END) return st == ZS_TRUNC ? 1 : 0;
   if (end + 4 > n) return 1;                                                             // the check value never arrives: no error, everything was written
   uint32_t ad = wave_adler32(out, outn);
   uint32_t a0 = 0; for (int i = 0; i < 4; i++) a0 = (a0 << 8) | (uint32_t)uni(in[end + i]);

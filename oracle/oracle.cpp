@@ -1089,24 +1089,34 @@ int length_predict(Ctx& c, BList& ll) {
 // OTP zlib calls of the container paths, on libz itself
 // ===========================================================================
 namespace otpz {
-// zlib:gunzip/1 (OTP lib/kernel zlib.erl): inflateInit(Z, 16 + MAX_WBITS), inflate, inflateEnd - which raises data_error unless the
-// end of the stream was reached.  false = the call raises error:data_error.
+// zlib:gunzip/1 of OTP 20.1 - 23 (lib/kernel zlib.erl + erts zlib_nif.c; the OTP target):
+//   inflateInit(Z, 16 + ?MAX_WBITS, reset), inflate(Z, Data), inflateEnd(Z)
+// The NIF's inflate remembers that a stream has ended (eos_seen); called again with input left and the `reset` behaviour it calls
+// inflateReset and goes on: concatenated members are all decoded.  Bytes that are not another member raise data_error (incorrect
+// header check), and inflateEnd raises data_error unless the LAST inflate call ended a stream (eos_seen) - an unfinished member or
+// header.  false = the call raises error:data_error.  (OTP 18 - 20.0, the port driver: first member only, trailing bytes ignored -
+// what this function did until round 4.)
 bool gunzip(const Bytes& in, Bytes* out) {
   z_stream z; memset(&z, 0, sizeof(z));
   if (inflateInit2(&z, 16 + 15) != Z_OK) throw std::runtime_error("inflateInit2");
-  out->clear(); bool ok = false;
+  out->clear(); bool eos_seen = false, raised = false;
   z.next_in = (Bytef*)in.data(); z.avail_in = (uInt)in.size();
   std::vector<uint8_t> buf(1 << 16);
   while (true) {
+    if (eos_seen) {                                                            // zlib_nif.c: eos_seen && input left -> EOS_BEHAVIOR_RESET
+      if (z.avail_in == 0) break;
+      if (inflateReset(&z) != Z_OK) { raised = true; break; }
+      eos_seen = false;
+    }
     z.next_out = buf.data(); z.avail_out = (uInt)buf.size();
     int rc = inflate(&z, Z_NO_FLUSH);
     out->insert(out->end(), buf.data(), buf.data() + (buf.size() - z.avail_out));
-    if (rc == Z_STREAM_END) { ok = true; break; }
-    if (rc != Z_OK) break;                                                     // data_error, or Z_BUF_ERROR: the input ran out
-    if (z.avail_in == 0 && z.avail_out != 0) break;
+    if (rc == Z_STREAM_END) { eos_seen = true; continue; }
+    if (rc != Z_OK && rc != Z_BUF_ERROR) { raised = true; break; }             // data_error (need_dictionary cannot happen with a gzip wrapper)
+    if (z.avail_in == 0 && z.avail_out != 0) break;                            // the input ran out inside a member
   }
   inflateEnd(&z);
-  return ok;
+  return !raised && eos_seen;                                                  // inflateEnd: data_error unless the end of a stream was seen
 }
 // zlib:inflateInit(Z), zlib:inflate(Z, Bin) and no inflateEnd (erlamsa_patterns.erl:232-234): what was decoded when the input ran
 // out is the result; false = the call raises (data_error, {need_dictionary, _}).

@@ -35,7 +35,7 @@ SETS = [
     ("sgm_js_only", (22, 23, 24), "sgm,js", "od,nd,bu", 48, 0, "docs"),
     # containers (round 3): real gzip / zlib inputs through pattern cp, real zip archives through pattern ar and mutator zip.
     # A BEAM capture of these two sets also pins the restated corners of OTP's zlib / prim_zip / zip ("Oracle").
-    ("containers_cp", (25, 26, 27), "bd,bf,bi,sr,num,lr,uw", "cp,od", 24, 0, "gz"),
+    ("containers_cp", (25, 26, 27), "bd,bf,bi,sr,num,lr,uw", "cp,od", 30, 0, "gz"),
     ("containers_zip", (28, 29, 30), "zip=3,bd,bf,sr,num", "ar=3,od", 20, 0, "zip"),
     # the file / jump generators (erlamsa_gen.erl:59-150): the inputs are the Paths.  Not in vectors.eterm: with paths other than
     # [direct] erlamsa_main:fuzzer/1 records nothing (erlamsa_main.erl:139-146), a capture would have to go through -o files

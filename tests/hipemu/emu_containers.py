@@ -32,13 +32,22 @@ def compressed_corpus(n, seed):
     out = []
     for i, p in enumerate(plain):
         p = p[:int(rng.integers(0, len(p) + 1))]
-        kind = i % 12
+        kind = i % 15
         lvl = int(rng.choice([0, 1, 6, 9]))
         if kind in (0, 1, 2):
             b = _z(p, 31, lvl)
         elif kind in (3, 4):
             b = _z(p, 15, lvl)
-        elif kind == 5:                                                  # header with a name and a comment, trailing bytes behind the member
+        elif kind == 12:                                                 # OTP >= 20.1: two or three concatenated members are ALL decoded
+            q = plain[(i + 1) % len(plain)][:700]
+            b = _z(p, 31, lvl) + _z(q, 31, 6) + (_z(p[:50], 31, 1) if rng.random() < 0.5 else b"")
+        elif kind == 13:                                                 # ... a member and an unfinished one / stray bytes: data_error, then {compressed, failed}
+            g2 = _z(p[::-1], 31, lvl)
+            b = _z(p, 31, lvl) + [g2[:len(g2) // 2], b"\x1f", b"\x00\x00", g2[:-3]][int(rng.integers(0, 4))]
+        elif kind == 14:                                                 # ... members whose second one has a wrong CRC-32 / ISIZE
+            g2 = bytearray(_z(p[:900], 31, lvl)); g2[-1 - int(rng.integers(0, 8))] ^= 0x10
+            b = _z(p, 31, lvl) + bytes(g2)
+        elif kind == 5:                                                  # header with a name and a comment, trailing bytes behind the member (OTP >= 20.1: data_error)
             raw = _z(p, -15, lvl)
             b = b"\x1f\x8b\x08\x18" + bytes(6) + b"file.bin\x00a comment\x00" + raw + zlib.crc32(p).to_bytes(4, "little") + (len(p) & 0xffffffff).to_bytes(4, "little") + b"TAIL"
         elif kind == 6:                                                  # a zlib stream that just stops: inflate/2 returns what it decoded
@@ -96,7 +105,7 @@ def run_cp(n=24, big=1 << 25):
         print("cp config %d: cases %d bad %d, statuses %s" % (ci, len(inputs), len(bad), np.bincount(gst, minlength=4).tolist()), flush=True)
         for i in bad[:3]:
             print("  case %d (input kind %d, %d bytes): first diff %d, len %d vs %d, status %d vs %d, draws %d vs %d, %s" % (
-                i, i % 12, len(inputs[i]), util.first_diff(got[i], want[i]), len(got[i]), len(want[i]), gst[i], wst[i], gdr[i], wdr[i], lines[i][:160]))
+                i, i % 15, len(inputs[i]), util.first_diff(got[i], want[i]), len(got[i]), len(want[i]), gst[i], wst[i], gdr[i], wdr[i], lines[i][:160]))
         assert not bad, "cp config %d: %d cases differ" % (ci, len(bad))
     assert skipped <= total // 10, "%d of %d cases ended at an engine limit" % (skipped, total)
     return total

@@ -27,13 +27,20 @@ def want_compress(op, data):
 
 
 def want_gunzip(data):
-    """zlib:gunzip/1: inflateInit2(16 + 15), inflate, inflateEnd (raises unless the member is complete); trailing bytes ignored"""
-    d = zlib.decompressobj(31)
-    try:
-        out = d.decompress(data)
-    except zlib.error:
-        return None
-    return out if d.eof else None
+    """zlib:gunzip/1 of OTP 20.1 - 23: inflateInit(Z, 16 + 15, reset), inflate, inflateEnd - every concatenated member is decoded
+    (inflateReset at each end of stream with input left); anything that is not a sequence of complete members raises"""
+    out, rest = b"", data
+    while True:
+        d = zlib.decompressobj(31)
+        try:
+            out += d.decompress(rest)
+        except zlib.error:
+            return None
+        if not d.eof:
+            return None
+        rest = d.unused_data
+        if not rest:
+            return out
 
 
 def want_inflate(data):
@@ -94,6 +101,10 @@ def run(quick=False, small=False):
             continue
         gz, zl = want_compress(1, data), want_compress(2, data)
         variants = [(4, gz), (5, zl), (4, gz + b"trailing garbage"), (5, zl + b"xyz"), (4, zl), (5, gz), (4, data[:64]), (5, data[:64])]
+        # OTP >= 20.1: concatenated members (all decoded), a member + an unfinished member / a stray byte / a member with a wrong CRC
+        gz2 = want_compress(1, data[::-1][:777])
+        variants += [(4, gz + gz), (4, gz + gz2 + gz), (4, gz + gz2[:len(gz2) // 2]), (4, gz + b"\x1f"), (4, gz + b"\x1f\x8b"), (4, gz + gz2[:-5] + b"\x00" + gz2[-4:]),
+                     (4, gz + b"\x00"), (5, zl + zl)]
         # other encoders' streams: stored blocks, fixed trees, level 1 / 9, with a header name
         for lvl, strat in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY)):
             c = zlib.compressobj(lvl, zlib.DEFLATED, 31, 8, strat); variants.append((4, c.compress(data) + c.flush()))

@@ -111,7 +111,7 @@ def test_emulated_container_patterns(emu_lib):
     (stored / deflated / small / empty files, stored extensions, archive comment, cut and corrupted archives) - bytes, statuses,
     draw counts and the meta trace are the oracle's, whose zlib calls are libz's"""
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_containers.py"), "16"], env=env, capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_containers.py"), "30"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "containers ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 

@@ -7,20 +7,24 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import erlamsa_amd as ea
 from erlamsa_amd import synth
-base = int(sys.argv[1]); cases = [int(x) for x in sys.argv[2:]]
+# "@file": lines of "BASE ROW" (tools/r05_monsters.sh); otherwise BASE CASE [CASE ...]
+if sys.argv[1].startswith("@"):
+    jobs = [tuple(int(x) for x in ln.split()) for ln in open(sys.argv[1][1:]) if ln.strip()]
+else:
+    jobs = [(int(sys.argv[1]), int(x)) for x in sys.argv[2:]]
 mat = synth.mixed(65536, 4096)
 data, off = synth.as_arena(mat)
 names = [m[0] for m in ea.mutator_table()]
 eng = ea.Engine(0)
 eng.configure(fuse_stream_min=int(os.environ.get("FUSE_STREAM_MIN", "0")), patterns="od,nd,bu", out_capacity=4 << 30, max_case_bytes=16 << 20, big_case_bytes=1024 << 20, max_slots=8)
 eng.upload_corpus(data, off)
-for i in cases:
+for base, i in jobs:
     eng.fuzz_batch(seed=(1, 2, 3), first_case=base + 1 + i, corpus_first=i, n=1)
     eng.sync()
     pr = eng.prof().astype(np.float64)
     _, ob, _ = eng.totals()
     dr, lm = eng.diag()
-    print("case %d alone: %.0f Mcyc, out %d B, status %d, draws %d, kernel %.1f ms" % (i, eng.cycles()[0] / 1e6, ob, eng.status()[0], dr[0], eng.kernel_ms()))
+    print("case %d (base %d) alone: %.0f Mcyc, out %d B, status %d, draws %d, kernel %.1f ms" % (i, base, eng.cycles()[0] / 1e6, ob, eng.status()[0], dr[0], eng.kernel_ms()))
     for m in range(len(names)):
         if pr[2 * m + 1] > 0 and pr[2 * m] > 10e6:
             print("    %-6s calls %6d  total %9.1f Mcyc  mean %9.1f kcyc" % (names[m], pr[2 * m + 1], pr[2 * m] / 1e6, pr[2 * m] / pr[2 * m + 1] / 1e3))
