@@ -17,9 +17,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# passes in flight run on separate HIP streams; the runtime maps streams onto this many hardware queues (default 4), and
-# two batches on one hardware queue run one after the other.  Must be set before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (passes in flight run on separate HIP streams and want a hardware queue each: the library sets GPU_MAX_HW_QUEUES=8 itself when it is
+# loaded - csrc/eh_engine.hip eh_runtime_defaults; only the N > 1 path, where torch starts the HIP runtime first, sets it here)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DESC_BYTES = 24        # per-case descriptor: out_off, out_len, status/draws
@@ -250,6 +249,7 @@ def main():
     # device pointers are host pointers there) - everything but RCCL itself
     on_gpu = os.environ.get("EH_BENCH_BACKEND", "nccl") == "nccl"
     if world > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # torch initialises the HIP runtime before the engine's library is loaded
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

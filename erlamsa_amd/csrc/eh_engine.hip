@@ -1350,6 +1350,13 @@ uint64_t eh_last_error_copy(eh_ctx* ctx, char* buf, uint64_t cap) {
   return n;
 }
 
+// Batches in flight on several HIP streams (one context each) only run side by side when every stream gets a hardware queue of its
+// own; the runtime maps streams onto GPU_MAX_HW_QUEUES of them (default 4: with six passes in flight pairs of them serialise,
+// 21.7 instead of 33.7 GB/s, profiles/r04_bench_q4.json).  The variable is read when the HIP runtime initialises, i.e. at the first
+// HIP call of the process: set here, when the library is loaded, unless the host has chosen a value itself.  (A process that has
+// used HIP before it loads this library - a torch that came first - keeps what it started with: INTEGRATION.md section 3.)
+__attribute__((constructor)) static void eh_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 int eh_create(int device, eh_ctx** out) {
   if (!out) return EH_E_INVALID;
   *out = nullptr;

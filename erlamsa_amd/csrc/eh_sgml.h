@@ -66,6 +66,7 @@ struct SgLaneTag { uint32_t ok, bail, kind, next, nexte, tag0, lt, npc, npar, na
 struct SgLaneMemo { uint32_t gt, qgt, cmt, sq, dq; const uint8_t* bad; const uint32_t* nstop; };
 constexpr uint32_t SG_LANE_BUDGET = 8192;           // events a lane may look at in all,
 constexpr uint32_t SG_LANE_FAR = 64;                // ... of them outside the LDS window (the event list in the work area: a dependent global load each),
+constexpr uint32_t SG_LANE_ATTRS = 48;              // ... and attributes it walks: a longer tag is the wave-wide machine's, which takes its attributes one per lane (round 5)
 constexpr uint32_t SG_LANE_SEARCH = 2048;           // ... and in one search for a single class ('>', a quote, "-->", "?>"): the wave-wide machine looks at 64 per step
 // (a function of its own: inlined three times into sgml_tokenize it cost the wave-wide machine there its registers)
 template <int MODE>
@@ -177,6 +178,7 @@ __device__ __noinline__ SgLaneTag sg_lane_attempt(const uint8_t* H, uint32_t L, 
     skipws();
     for (;;) {                                                             // attribute loop :134-160
       if (pos >= L || bail) break;
+      if (nq >= SG_LANE_ATTRS) { bail = true; break; }
       if (nq >= 16) {                                                      // the memo of failed attribute-loop entries
         if (mm.bad && mm.bad[pos]) break;
         if (MODE == 2) mark[pos] = 1;
@@ -223,6 +225,90 @@ __device__ __noinline__ SgLaneTag sg_lane_attempt(const uint8_t* H, uint32_t L, 
   R.ok = (ok && !bail) ? 1u : 0u; R.bail = bail ? 1u : 0u; R.kind = kind; R.next = next; R.nexte = nexte; R.tag0 = tag0; R.lt = lt;
   R.npc = np; R.npar = nq; R.na = na; R.nb = nb; R.reach = reach;
   if (ok || bail) { R.unmarked = 0; R.ffc = 0; }
+  return R;
+}
+
+// ---- one ATTRIBUTE per lane (round 5) ---------------------------------------------------------------------------------------------
+// The heaviest cases of every pass are `sgm` on documents whose tags hold tens of thousands of attributes (a megabyte of words
+// between a '<' and the next '>': 100 000 iterations of the attribute loop :134-160 at ~4 000 cycles each in the wave-wide machine,
+// 1 600 in a lane of a batch - and nd / bu call sgm a dozen times per case).  One iteration of that loop depends on nothing but
+// the place it starts at (pos after ws/1, the first event there, whether the last blank skipped was 0x20), and nearly every
+// iteration starts right behind a run of white space or behind a closing quote.  So the wave-wide machine, once a tag has shown
+// to be long, takes the next 63 such places from the event window as CANDIDATES, lets every lane run ONE iteration from its
+// candidate (lane 0: from where the machine is), and then walks the chain - lane k's iteration ends where some later lane's began -
+// to find the iterations the machine would really have made; their parameters and pieces are written by all lanes at once.
+// A lane reports `term` for everything that is not a plain completed attribute (the tag's end, '=', a search that fails or runs
+// far, the end of the block): the chain stops in front of it and the wave-wide machine makes that iteration itself, statement for
+// statement as before - so this function only has to be right about the plain case.
+struct SgLaneAttr { uint32_t term, npos, nei, nws, an, ae, va, vb, delim, eqpos, reach; };
+constexpr uint32_t SG_ATTR_BUDGET = 512;            // events one lane may look at for its attribute
+__device__ __noinline__ SgLaneAttr sg_lane_attr(const uint8_t* H, uint32_t L, const uint32_t* ev, uint32_t nev, uint32_t cbase, uint32_t pos, uint32_t ei, uint32_t ws0, const SgLaneMemo& mm) {
+  (void)H;
+  SgLaneAttr R; R.term = 1; R.npos = pos; R.nei = ei; R.nws = ws0; R.an = pos; R.ae = pos; R.va = pos; R.vb = pos; R.delim = 0; R.eqpos = 0xFFFFFFFFu; R.reach = ei;
+  bool bail = false; uint32_t budget = SG_ATTR_BUDGET, reach = ei, far = 0;
+  auto EV = [&](uint32_t i) -> uint32_t {
+    const uint32_t o = i - cbase; const bool in = o < 4096u;
+    uint32_t v = g_fuse_lds[in ? o : 0u];
+    EH_KEEP(v);
+    if (!in) { v = ev[i]; if (++far > 8u) bail = true; }
+    return v;
+  };
+  auto have = [&](uint32_t i) -> bool {
+    if (i >= nev) return false;
+    if (budget == 0) { bail = true; return false; }
+    budget--;
+    if (i >= reach) reach = i + 1;
+    return true;
+  };
+  bool ws_sp = ws0 != 0;
+  auto cls_here = [&]() -> uint32_t { if (!have(ei)) return 0u; uint32_t v = EV(ei); return (v >> 4) == pos ? (v & 15u) : 0u; };
+  auto step1 = [&]() { if (have(ei) && (EV(ei) >> 4) == pos) ei++; pos++; };
+  auto skipws = [&]() {
+    ws_sp = false;
+    while (have(ei)) { uint32_t v = EV(ei); if (!((ES_WS >> (v & 15u)) & 1u) || (v >> 4) != pos) break; ws_sp = (v & 15u) == E_SPACE; pos++; ei++; }
+  };
+  auto find_stop = [&](uint32_t from) -> uint32_t {                        // ES_STOP
+    uint32_t i = from;
+    for (int k = 0; k < 8; k++) { if (!have(i)) return nev; if ((ES_STOP >> (EV(i) & 15u)) & 1u) return i; i++; }
+    if (!have(i)) return nev;
+    const uint32_t j = mm.nstop[i];                                        // a name that runs over many events: the next-stop table
+    if (j < nev && j >= reach) reach = j + 1;
+    return j;
+  };
+  do {
+    if (pos >= L) break;
+    const uint32_t ca = cls_here();
+    if (ca == E_SLGT || ca == E_GT || ca == E_EQ) break;                   // the machine's: {etag,..}, the tag's end, the throw
+    R.an = pos;
+    step1();
+    const uint32_t ja = find_stop(ei);
+    if (ja >= nev || bail) break;
+    R.ae = EV(ja) >> 4; pos = R.ae; ei = ja;
+    skipws();
+    R.va = pos; R.vb = pos;
+    if (pos < L && cls_here() == E_EQ) {
+      R.eqpos = pos;
+      step1(); skipws();
+      if (pos >= L) break;
+      const uint32_t cv = cls_here();
+      if (cv == E_SQ || cv == E_DQ) {
+        const uint32_t ff = cv == E_SQ ? mm.sq : mm.dq;
+        uint32_t i = ei + 1, jq = nev;
+        if (i < ff) { while (have(i)) { if ((EV(i) & 15u) == cv) { jq = i; break; } i++; } }
+        if (jq >= nev) break;                                              // not found (or not within reach): the machine's
+        R.va = pos + 1; R.vb = EV(jq) >> 4; R.delim = cv == E_SQ ? 1u : 2u;
+        pos = R.vb + 1; ei = jq + 1;
+      } else {
+        const uint32_t ju = find_stop(ei);
+        if (ju >= nev || bail) break;
+        R.va = pos; R.vb = EV(ju) >> 4; pos = R.vb; ei = ju;
+      }
+      skipws();
+    }
+    if (bail) break;
+    R.term = 0; R.npos = pos; R.nei = ei; R.nws = ws_sp ? 1u : 0u;
+  } while (false);
+  R.reach = reach;
   return R;
 }
 
@@ -553,6 +639,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   // Batches are made where they pay: four '<' or more within reach, runs of failing attempts ("<a <b <c ...").
   // A batch whose first lane gave up has cost its time for nothing: the next ones are skipped, twice as many each time it happens.
   uint32_t fail_run = 0, lb_skip = 0, lb_penalty = 1;
+  uint32_t ab_skip = 0, ab_penalty = 1;                                    // attribute batches (in the attempt below) back off the same way
   auto lane_batches = [&]() __attribute__((always_inline)) -> int {
     EH_CTX;                                                                // (not the captured reference: a lambda that is not inlined would carry a generic pointer to the LDS context)
     while (lanes_on && ei < nev) {
@@ -753,6 +840,92 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
       for (;;) {
         if (npc + 16 > cap_pc || npar + 1 > cap_par) { EH_SET_OVERFLOW(c, 602); return -3; }
         if (pos >= L) break;
+        // ---- a long tag: the next iterations one per lane (sg_lane_attr, above).  The chain walk commits exactly the iterations this
+        // loop would make, in its order; what is not a plain attribute stays for the statements below.
+        if (nattr >= 16 && lanes_on && (uint64_t)npc + 6u * 64u + 16u <= cap_pc && (uint64_t)npar + 65u <= cap_par) {
+          if (ab_skip > 0) ab_skip--;
+          else {
+            if (!nstop_tab && !build_nstop()) return -3;
+            if (!chain) { chain = (uint32_t*)ws_alloc(c, ((uint64_t)nstop + 8) * 4); if (!chain) return -3; }
+            if (cbase != 0xFFFFFFFFu && cbase + SG_EVC < nev && ei + 1024u > cbase + SG_EVC) { cbase = 0xFFFFFFFFu; bbase = 0xFFFFFFFFu; }   // little of the window left: move it
+            need(ei);
+            const uint32_t wend = cbase + SG_EVC < nev ? cbase + SG_EVC : nev;
+            const uint32_t lim = wend < nev ? wend - 1u : wend;            // (a candidate's event is looked at together with the one behind it)
+            const uint32_t send = ei + 1024u < lim ? ei + 1024u : lim;
+            uint32_t nc = 1;                                               // lane 0: where the machine is
+            lanes_sync();
+            for (uint32_t base = ei; base < send && nc < 64; base += 64) {
+              const uint32_t idx = base + (uint32_t)l;
+              const bool in = idx < send;
+              const uint32_t v = in ? g_fuse_lds[idx - cbase] : 0u;
+              const uint32_t vn = (in && idx + 1u < nev) ? g_fuse_lds[idx + 1u - cbase] : 0u;
+              const uint32_t cl = v & 15u;
+              const bool adj = in && idx + 1u < nev && (vn >> 4) == (v >> 4) + 1u && ((ES_WS >> (vn & 15u)) & 1u);
+              const bool is = in && (((ES_WS >> cl) & 1u) || cl == E_SQ || cl == E_DQ) && !adj;   // the end of a run of white space, or a quote with none behind it
+              const unsigned long long m = __ballot(is);
+              const uint32_t rank = nc + (uint32_t)__popcll(m & ((1ull << l) - 1ull));
+              if (is && rank < 64) g_fuse_lds[SG_EVC + rank] = idx;
+              nc += (uint32_t)__popcll(m);
+            }
+            if (nc > 64) nc = 64;
+            lanes_sync();
+            const bool mine = (uint32_t)l < nc;
+            const uint32_t cj = (l > 0 && mine) ? g_fuse_lds[SG_EVC + (uint32_t)l] : cbase;
+            const uint32_t cv = g_fuse_lds[cj - cbase];
+            const uint32_t cpos = l == 0 ? pos : (cv >> 4) + 1u, cei = l == 0 ? ei : cj + 1u, cws = l == 0 ? (ws_sp ? 1u : 0u) : ((cv & 15u) == E_SPACE ? 1u : 0u);
+            SgLaneMemo mm; mm.gt = ff_gt; mm.qgt = ff_qgt; mm.cmt = ff_cmt; mm.sq = ff_sq; mm.dq = ff_dq; mm.bad = bad; mm.nstop = nstop_tab;
+            SgLaneAttr A; A.term = 1; A.npos = 0; A.nei = 0; A.nws = 0; A.an = 0; A.ae = 0; A.va = 0; A.vb = 0; A.delim = 0; A.eqpos = 0; A.reach = 0;
+            if (mine) A = sg_lane_attr(H, L, ev, nev, cbase, cpos, cei, cws, mm);
+            const uint32_t isbad = (mine && bad && cpos < L) ? (uint32_t)bad[cpos] : 0u;
+            // the chain: lane k's iteration is followed by the lane whose candidate is where it ended.  Mostly that is the next lane
+            // (a word, white space, the next word), so runs of such lanes are taken with bit operations, the rest by a search.
+            const uint32_t cpos_nx = (uint32_t)__shfl((int)cpos, (l + 1) & 63);
+            const unsigned long long termm = __ballot(!mine || A.term != 0 || isbad != 0);   // isbad: the memo of failed attribute-loop entries (nattr >= 16 here)
+            const unsigned long long linkm = __ballot(mine && (uint32_t)l + 1u < nc && A.npos == cpos_nx);
+            const unsigned long long chainable = linkm & ~termm & (~termm >> 1);              // lane k and its successor k + 1 both make a plain iteration
+            unsigned long long visited = 0; uint32_t k = 0, cnt = 0;
+            for (;;) {
+              if ((termm >> k) & 1ull) break;
+              const uint32_t r = (uint32_t)__builtin_ctzll(~(chainable >> k));                // (bit 63 is never chainable: the shift brings in zeros)
+              visited |= ((2ull << r) - 1ull) << k; cnt += r + 1u; k += r;
+              if ((linkm >> k) & 1ull) break;                                                  // ends at lane k + 1's candidate, which is not a plain iteration
+              const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)A.npos, (int)k);
+              const unsigned long long m = __ballot(mine && (uint32_t)l > k && cpos == np);
+              if (!m) break;
+              k = (uint32_t)__builtin_ctzll(m);
+            }
+            if (cnt == 0) { ab_skip = ab_penalty; if (ab_penalty < 64) ab_penalty *= 2; }
+            else {
+              const bool cm = (visited >> l) & 1ull;
+              const uint32_t rank = (uint32_t)__popcll(visited & ((1ull << l) - 1ull));
+              if (cm) {
+                SgParam q; q.na = A.an; q.nb = A.ae; q.va = A.va; q.vb = A.vb; q.delim = A.delim; q.pad = 0; par[npar + rank] = q;
+                const bool has = A.vb > A.va, hd = has && A.delim != 0;
+                const uint8_t* qp = sglit(A.delim == 1 ? SL_SQ : SL_DQ);
+                Piece* o = pc + npc + 6u * rank; Piece x; x.rep = 1;
+                x.ptr = (uint64_t)(cws ? H + A.an - 1 : sglit(SL_SP)); x.len = 1; o[0] = x;
+                x.ptr = (uint64_t)(H + A.an); x.len = A.ae - A.an; o[1] = x;
+                x.ptr = (uint64_t)(has ? H + A.eqpos : sglit(SL_EQ)); x.len = has ? 1u : 0u; o[2] = x;
+                x.ptr = (uint64_t)(hd ? H + A.va - 1 : qp); x.len = hd ? 1u : 0u; o[3] = x;
+                x.ptr = (uint64_t)(H + A.va); x.len = has ? A.vb - A.va : 0u; o[4] = x;
+                x.ptr = (uint64_t)(hd ? H + A.vb : qp); x.len = hd ? 1u : 0u; o[5] = x;
+                chain[nchain + rank] = cpos;
+              }
+              const uint32_t lastc = 63u - (uint32_t)__builtin_clzll(visited);
+              pos = (uint32_t)__builtin_amdgcn_readlane((int)A.npos, (int)lastc); ei = (uint32_t)__builtin_amdgcn_readlane((int)A.nei, (int)lastc);
+              ws_sp = (uint32_t)__builtin_amdgcn_readlane((int)A.nws, (int)lastc) != 0;
+              npar += cnt; npc += 6u * cnt; nattr += cnt; nchain += cnt;
+              if (rp_state != 0) { const uint32_t r = wave_max(cm ? A.reach : 0u); if (r > reach_ev) reach_ev = r; }
+              bbase = 0xFFFFFFFFu;
+              wave_sync();
+              ab_penalty = 1;
+#ifdef EH_PROF
+              if (l == 0) { atomicAdd(&c.p->prof[2 * 120], (unsigned long long)cnt); atomicAdd(&c.p->prof[2 * 120 + 1], 1ull); }   // attributes written by attribute batches, batches
+#endif
+              continue;
+            }
+          }
+        }
         if (nattr >= 16) {                                                 // quadratic-rescan guard
           if (bad && uni(bad[pos])) break;
           if (!chain) { chain = (uint32_t*)ws_alloc(c, ((uint64_t)nstop + 8) * 4); if (!chain) return -3; }

@@ -73,8 +73,31 @@ def corpus(n, seed, scale=1, small=False):
         reps2 = max(4, int(rng2.integers(300, 900)) * scale // (10 if small else 1))
         cut2 = int(rng2.integers(0, len(fu)))
         out.append(b"<doc>" + fu[cut2:] + fu * reps2 + fu[:cut2] + (b"</doc>", b"<!-- ", b"<v w='")[int(rng2.integers(0, 3))])
+        # round 5: tags of thousands of attributes in every syntax the attribute loop knows (erlamsa_sgml.erl:134-160) - the wave-wide machine
+        # takes them one attribute per lane (sg_lane_attr): values quoted with blanks, '<', '>', "/>" and '=' inside, unquoted values, blanks around
+        # '=', tabs / CR / LF runs, attributes glued to a closing quote, quotes inside names, an '=' where a name should start (the tag fails),
+        # tags that end in '>', '/>', ' />' or never, a quote that never closes far into the tag
+        rng3 = np.random.Generator(np.random.PCG64([seed, k, 78]))
+        w3 = lambda a, b: bytes(rng3.choice(list(b"abcdefghijklmnopqrstuvwxyz0123456789{}[]().-!?"), size=int(rng3.integers(a, b))).astype(np.uint8))
+        def attr():
+            r = rng3.random()
+            ws = [b" ", b"  ", b"\t", b"\n", b"\r\n", b" \t "][int(rng3.integers(0, 6))]
+            if r < 0.55: return w3(1, 9) + ws
+            if r < 0.65: return w3(1, 6) + b"=" + w3(0, 6) + ws
+            if r < 0.75: return w3(1, 6) + b"='" + [w3(0, 9), b"a b  c", b"<x y>", b"/>", b"=", b"\"", b""][int(rng3.integers(0, 7))] + b"'" + ws
+            if r < 0.85: return w3(1, 6) + b" = \"" + [w3(0, 9), b"p q", b"<<<", b" ", b"'"][int(rng3.integers(0, 5))] + b"\"" + (ws if rng3.random() < 0.7 else b"")
+            if r < 0.90: return w3(1, 4) + b"\"" + w3(0, 4) + ws
+            if r < 0.94: return w3(1, 5) + b"/" + w3(0, 3) + ws
+            if r < 0.97: return w3(1, 5) + b"<" + w3(0, 5) + ws
+            return w3(1, 4) + b"= " + w3(1, 4) + ws
+        def bigtag(n):
+            body = b"".join(attr() for _ in range(n))
+            end = [b">", b"/>", b" />", b"", b"=>", b"='never closed ", b" = ", b">"][int(rng3.integers(0, 8))]
+            return b"<" + w3(1, 6) + b" " + body + end
+        natt = max(40, int(rng3.integers(300, 6000)) * scale // (10 if small else 1))
+        out.append(b"<doc>" + b"".join(bigtag(int(rng3.integers(17, natt))) + w3(0, 40) + (b"</x>" if rng3.random() < 0.3 else b"") for _ in range(int(rng3.integers(1, 7)))) + b"</doc>")
     if small:
-        out = [d for k, d in enumerate(out) if k % 14 >= 6]                                  # the kinds without a period: what the lane batches are for (the periodic ones need their full length anyway)
+        out = [d for k, d in enumerate(out) if k % 15 >= 6]                                  # the kinds without a period: what the lane batches are for (the periodic ones need their full length anyway)
     return out
 
 
@@ -108,7 +131,7 @@ def run(n=1, seed=1, scale=1, pats="od,nd,bu", verbose=True, small=False):
             bad += 1
             if verbose and bad <= 8:
                 print("case %d (kind %d, len %d): replay vs oracle %s, replay vs walk %s; status %d/%d/%d draws %d/%d/%d len %d/%d/%d" % (
-                    i, i % 14, len(inputs[i]), ok_o, ok_n, a[1][i], b[1][i], o.status[i], a[2][i], b[2][i], o.draws[i], len(a[0][i]), len(b[0][i]), len(o.outs[i])))
+                    i, i % 15, len(inputs[i]), ok_o, ok_n, a[1][i], b[1][i], o.status[i], a[2][i], b[2][i], o.draws[i], len(a[0][i]), len(b[0][i]), len(o.outs[i])))
     if verbose:
         print("cases %d bad %d; %s, oracle %.1f s; input bytes %d" % (len(inputs), bad, ", ".join("%s %.1f s" % (
             {"replay": "replay+lanes", "walk": "tag by tag", "lanes": "lanes only", "nolanes": "replay only"}[k], v[3]) for k, v in res.items()), to, sum(map(len, inputs))))
