@@ -38,6 +38,7 @@
 #include "eh_json.h"
 #include "eh_zlib.h"
 #include "eh_zip.h"
+#include "eh_comm.h"
 
 namespace eh {
 
@@ -1056,6 +1057,7 @@ struct eh_ctx {
   struct CoResult { std::vector<uint8_t> out; int32_t status; };
   std::vector<uint64_t> co_cancelled;                                                   // in-flight tickets nobody will poll
   std::map<uint64_t, CoResult> co_done;                                                 // downloaded, not polled yet
+  void* comm = nullptr; int comm_rank = 0, comm_n = 1;   // RCCL communicator of this context's device (eh_comm_init / eh_comm_init_local)
   hipStream_t last_stream = nullptr;
   hipStream_t own_stream = nullptr;                     // eh_stream: a stream of the context's own (non-blocking), made on first request
   uint64_t last_n = 0, last_in_bytes = 0;
@@ -1392,6 +1394,7 @@ void eh_destroy(eh_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
+  if (ctx->comm) { ehcomm::Api* a = ehcomm::api(); if (a->h) (void)a->CommDestroy(ctx->comm); ctx->comm = nullptr; }
   if (ctx->own_corpus) { (void)hipFree(ctx->d_corpus); (void)hipFree(ctx->d_coff); }
   pool_release(ctx);
   (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
@@ -1422,6 +1425,10 @@ int eh_configure(eh_ctx* ctx, const eh_options* o) {
     return EH_E_STATE;
   }
   if (!ctx->co_internal && ctx->co_inflight) { int rcc = co_collect(ctx); if (rcc) return rcc; }
+  if (o->sequence_muta) {
+    ctx->err = "sequence_muta (--consequtive-mutators, erlamsa_main.erl:223-235) chains the mutator scores from case to case: a batch of independent cases cannot keep that order; route this run to the BEAM path";
+    return EH_E_UNSUPPORTED;
+  }
   DevConfig cfg;
   memset(&cfg, 0, sizeof(cfg));
   std::vector<long> mp, pp;
@@ -1520,6 +1527,180 @@ int eh_corpus_attach(eh_ctx* ctx, const void* d_data, const void* d_off, uint64_
   HIPCHK(ctx, hipMemcpy(ctx->h_coff.data(), d_off, (n + 1) * 8, hipMemcpyDeviceToHost));
   if (ctx->h_coff[n] != nbytes) { ctx->err = "off[n] != nbytes"; return EH_E_INVALID; }
   return set_corpus(ctx, (uint8_t*)d_data, (uint64_t*)d_off, false, n, nbytes);
+}
+
+// ---- multi-GPU: the arena over RCCL (eh_comm.h) ------------------------------------------------------------------------------
+#define NCCLCHK(ctx, a, call)                                                                                   \
+  do {                                                                                                          \
+    int r_ = (call);                                                                                            \
+    if (r_ != 0) { (ctx)->err = std::string(#call) + ": " + ((a)->GetErrorString ? (a)->GetErrorString(r_) : "RCCL error"); return EH_E_HIP; } \
+  } while (0)
+
+// an owned corpus buffer for n entries / nbytes bytes (contents undefined); keeps the one it has when that is large enough
+static int corpus_own_buffers(eh_ctx* ctx, uint64_t n, uint64_t nbytes) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());                       // no launch may still read the previous corpus
+  if (ctx->own_corpus && ctx->own_corpus_cap >= nbytes && ctx->own_coff_cap >= n + 1) { ctx->n_corpus = n; ctx->corpus_bytes = nbytes; return EH_OK; }
+  uint8_t* d = nullptr; uint64_t* doff = nullptr;
+  const uint64_t cap_b = nbytes + 4096, cap_o = n + 16;
+  hipError_t e = hipMalloc(&d, cap_b);
+  if (e == hipSuccess) e = hipMalloc(&doff, cap_o * 8);
+  if (e != hipSuccess) { if (d) (void)hipFree(d); if (doff) (void)hipFree(doff); HIPCHK(ctx, e); }
+  int rc = set_corpus(ctx, d, doff, true, n, nbytes);
+  ctx->own_corpus_cap = cap_b; ctx->own_coff_cap = cap_o;
+  return rc;
+}
+
+int eh_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0; }
+int eh_comm_unique_id(uint8_t id[128]) {
+  if (!id) return EH_E_INVALID;
+  ehcomm::Api* a = ehcomm::api();
+  if (!a->h) return EH_E_UNSUPPORTED;
+  ehcomm::UniqueId u;
+  if (a->GetUniqueId(&u) != 0) return EH_E_HIP;
+  memcpy(id, u.internal, 128);
+  return EH_OK;
+}
+int eh_comm_init(eh_ctx* ctx, const uint8_t id[128], int rank, int nranks) {
+  if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return EH_E_INVALID;
+  ehcomm::Api* a = ehcomm::api();
+  if (!a->h) { ctx->err = a->err; return EH_E_UNSUPPORTED; }
+  if (ctx->comm) { (void)a->CommDestroy(ctx->comm); ctx->comm = nullptr; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ehcomm::UniqueId u; memcpy(u.internal, id, 128);
+  NCCLCHK(ctx, a, a->CommInitRank(&ctx->comm, nranks, u, rank));
+  ctx->comm_rank = rank; ctx->comm_n = nranks;
+  return EH_OK;
+}
+int eh_comm_init_local(eh_ctx** ctxs, int nctx) {
+  if (!ctxs || nctx < 1 || nctx > 64) return EH_E_INVALID;
+  for (int i = 0; i < nctx; i++) if (!ctxs[i]) return EH_E_INVALID;
+  ehcomm::Api* a = ehcomm::api();
+  if (!a->h) { ctxs[0]->err = a->err; return EH_E_UNSUPPORTED; }
+  std::vector<int> devs(nctx); std::vector<ehcomm::Comm> comms(nctx, nullptr);
+  for (int i = 0; i < nctx; i++) {
+    devs[i] = ctxs[i]->device;
+    for (int j = 0; j < i; j++) if (devs[j] == devs[i]) { ctxs[0]->err = "eh_comm_init_local: one context per device (contexts of one device share the corpus with eh_corpus_device / eh_corpus_attach)"; return EH_E_INVALID; }
+    if (ctxs[i]->comm) { (void)a->CommDestroy(ctxs[i]->comm); ctxs[i]->comm = nullptr; }
+  }
+  NCCLCHK(ctxs[0], a, a->CommInitAll(comms.data(), nctx, devs.data()));
+  for (int i = 0; i < nctx; i++) { ctxs[i]->comm = comms[i]; ctxs[i]->comm_rank = i; ctxs[i]->comm_n = nctx; }
+  return EH_OK;
+}
+int eh_comm_destroy(eh_ctx* ctx) {
+  if (!ctx) return EH_E_INVALID;
+  if (ctx->comm) { ehcomm::Api* a = ehcomm::api(); if (a->h) (void)a->CommDestroy(ctx->comm); ctx->comm = nullptr; }
+  ctx->comm_rank = 0; ctx->comm_n = 1;
+  return EH_OK;
+}
+
+// One process per GPU.  Root hands over the arena (host pointers), the others pass NULL / 0; afterwards every rank's context holds
+// the corpus as after eh_corpus_upload.  Three collectives on the context's stream: the sizes, the bytes, the offsets.
+int eh_corpus_broadcast(eh_ctx* ctx, int root, const uint8_t* data, const uint64_t* off, uint64_t n) {
+  if (!ctx) return EH_E_INVALID;
+  CO_GUARD(ctx);
+  if (!ctx->comm) { ctx->err = "eh_comm_init first"; return EH_E_STATE; }
+  if (root < 0 || root >= ctx->comm_n) return EH_E_INVALID;
+  const bool is_root = ctx->comm_rank == root;
+  if (is_root && (!off || (!data && off[n] > 0))) return EH_E_INVALID;
+  ehcomm::Api* a = ehcomm::api();
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  void* stv = nullptr; int rc = eh_stream(ctx, &stv); if (rc) return rc;
+  hipStream_t st = (hipStream_t)stv;
+  uint64_t* d_hdr = nullptr;
+  HIPCHK(ctx, hipMalloc(&d_hdr, 16));
+  uint64_t hdr[2] = {is_root ? n : 0, is_root ? off[n] : 0};
+  if (is_root) HIPCHK(ctx, hipMemcpy(d_hdr, hdr, 16, hipMemcpyHostToDevice));
+  NCCLCHK(ctx, a, a->Broadcast(d_hdr, d_hdr, 2, ehcomm::kUint64, root, ctx->comm, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  HIPCHK(ctx, hipMemcpy(hdr, d_hdr, 16, hipMemcpyDeviceToHost));
+  (void)hipFree(d_hdr);
+  const uint64_t cn = hdr[0], nbytes = hdr[1];
+  rc = corpus_own_buffers(ctx, cn, nbytes); if (rc) return rc;
+  if (is_root) {
+    if (nbytes) HIPCHK(ctx, hipMemcpy(ctx->d_corpus, data, nbytes, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_coff, off, (cn + 1) * 8, hipMemcpyHostToDevice));
+  }
+  if (nbytes) NCCLCHK(ctx, a, a->Broadcast(ctx->d_corpus, ctx->d_corpus, nbytes, ehcomm::kUint8, root, ctx->comm, st));
+  NCCLCHK(ctx, a, a->Broadcast(ctx->d_coff, ctx->d_coff, cn + 1, ehcomm::kUint64, root, ctx->comm, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  ctx->h_coff.resize(cn + 1);
+  if (is_root) ctx->h_coff.assign(off, off + cn + 1);
+  else HIPCHK(ctx, hipMemcpy(ctx->h_coff.data(), ctx->d_coff, (cn + 1) * 8, hipMemcpyDeviceToHost));
+  if (ctx->h_coff[cn] != nbytes) { ctx->err = "eh_corpus_broadcast: the offsets that arrived do not end at the arena's size"; return EH_E_HIP; }
+  return EH_OK;
+}
+
+// Every rank gives ITS shard - the same number of entries and of bytes on every rank (BASELINE configs[4]: fixed-size seeds) -;
+// afterwards every context holds the shards in rank order as one corpus.  In place: the shard is uploaded where it belongs and
+// ncclAllGather fills in the others, so each xGMI link carries 1/nranks of the arena.
+int eh_corpus_allgather(eh_ctx* ctx, const uint8_t* data, const uint64_t* off, uint64_t n_local) {
+  if (!ctx || !off || (!data && off[n_local] > 0)) return EH_E_INVALID;
+  CO_GUARD(ctx);
+  if (!ctx->comm) { ctx->err = "eh_comm_init first"; return EH_E_STATE; }
+  ehcomm::Api* a = ehcomm::api();
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  void* stv = nullptr; int rc = eh_stream(ctx, &stv); if (rc) return rc;
+  hipStream_t st = (hipStream_t)stv;
+  const int R = ctx->comm_n, me = ctx->comm_rank;
+  const uint64_t B = off[n_local];
+  // do all ranks bring the same shape?
+  uint64_t* d_sz = nullptr;
+  HIPCHK(ctx, hipMalloc(&d_sz, 16 * (size_t)R));
+  uint64_t mine[2] = {n_local, B};
+  HIPCHK(ctx, hipMemcpy(d_sz + 2 * me, mine, 16, hipMemcpyHostToDevice));
+  NCCLCHK(ctx, a, a->AllGather(d_sz + 2 * me, d_sz, 2, ehcomm::kUint64, ctx->comm, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  std::vector<uint64_t> sz(2 * (size_t)R);
+  HIPCHK(ctx, hipMemcpy(sz.data(), d_sz, 16 * (size_t)R, hipMemcpyDeviceToHost));
+  (void)hipFree(d_sz);
+  for (int r = 0; r < R; r++) if (sz[2 * r] != n_local || sz[2 * r + 1] != B) { ctx->err = "eh_corpus_allgather: shards differ in entries or bytes between ranks (use eh_corpus_broadcast)"; return EH_E_INVALID; }
+  const uint64_t cn = n_local * (uint64_t)R, nbytes = B * (uint64_t)R;
+  rc = corpus_own_buffers(ctx, cn, nbytes); if (rc) return rc;
+  if (B) HIPCHK(ctx, hipMemcpy(ctx->d_corpus + B * me, data, B, hipMemcpyHostToDevice));
+  std::vector<uint64_t> lo(n_local ? n_local : 1);
+  for (uint64_t i = 0; i < n_local; i++) lo[i] = off[i] + B * me;
+  if (n_local) HIPCHK(ctx, hipMemcpy(ctx->d_coff + n_local * me, lo.data(), n_local * 8, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->d_coff + cn, &nbytes, 8, hipMemcpyHostToDevice));
+  if (B) NCCLCHK(ctx, a, a->AllGather(ctx->d_corpus + B * me, ctx->d_corpus, B, ehcomm::kUint8, ctx->comm, st));
+  if (n_local) NCCLCHK(ctx, a, a->AllGather(ctx->d_coff + n_local * me, ctx->d_coff, n_local, ehcomm::kUint64, ctx->comm, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  ctx->h_coff.resize(cn + 1);
+  HIPCHK(ctx, hipMemcpy(ctx->h_coff.data(), ctx->d_coff, (cn + 1) * 8, hipMemcpyDeviceToHost));
+  return EH_OK;
+}
+
+// One process, several GPUs (a BEAM node): the corpus loaded on ctxs[root] goes to the devices of all the others (grouped
+// ncclBroadcast over the communicators of eh_comm_init_local).
+int eh_corpus_broadcast_local(eh_ctx** ctxs, int nctx, int root) {
+  if (!ctxs || nctx < 1 || root < 0 || root >= nctx) return EH_E_INVALID;
+  for (int i = 0; i < nctx; i++) if (!ctxs[i] || !ctxs[i]->comm || ctxs[i]->comm_n != nctx || ctxs[i]->comm_rank != i) { if (ctxs[0]) ctxs[0]->err = "eh_comm_init_local on these contexts, in this order, first"; return EH_E_STATE; }
+  eh_ctx* r = ctxs[root];
+  if (!r->d_corpus) { r->err = "no corpus loaded on the root context"; return EH_E_STATE; }
+  ehcomm::Api* a = ehcomm::api();
+  const uint64_t cn = r->n_corpus, nbytes = r->corpus_bytes;
+  std::vector<hipStream_t> sts(nctx);
+  for (int i = 0; i < nctx; i++) {
+    eh_ctx* x = ctxs[i];
+    if (i != root) { int rc = corpus_own_buffers(x, cn, nbytes); if (rc) return rc; }
+    void* stv = nullptr; int rc = eh_stream(x, &stv); if (rc) return rc;
+    sts[i] = (hipStream_t)stv;
+  }
+  NCCLCHK(r, a, a->GroupStart());
+  for (int i = 0; i < nctx; i++) {
+    eh_ctx* x = ctxs[i];
+    HIPCHK(x, hipSetDevice(x->device));
+    if (nbytes) NCCLCHK(x, a, a->Broadcast(x->d_corpus, x->d_corpus, nbytes, ehcomm::kUint8, root, x->comm, sts[i]));
+    NCCLCHK(x, a, a->Broadcast(x->d_coff, x->d_coff, cn + 1, ehcomm::kUint64, root, x->comm, sts[i]));
+  }
+  NCCLCHK(r, a, a->GroupEnd());
+  for (int i = 0; i < nctx; i++) {
+    eh_ctx* x = ctxs[i];
+    HIPCHK(x, hipSetDevice(x->device));
+    HIPCHK(x, hipStreamSynchronize(sts[i]));
+    if (i != root) x->h_coff = r->h_coff;
+  }
+  return EH_OK;
 }
 
 int eh_reserve(eh_ctx* ctx, uint64_t max_cases) {

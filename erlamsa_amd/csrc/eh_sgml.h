@@ -62,16 +62,16 @@ struct SgDoc { SgTok* tok; SgParam* par; Piece* pc; uint32_t ntok, npar, npc; };
 // The memos of the wave-wide machine are read here and fed from here: ff (a search for one class that found nothing from event f
 // finds nothing from a later event) and bad (the attribute loop entered at byte p fails) - both facts about the block, whichever
 // attempt establishes them.
-struct SgLaneTag { uint32_t ok, bail, kind, next, nexte, tag0, lt, npc, npar, na, nb, reach, ffc, fff, unmarked; };
+struct SgLaneTag { uint32_t ok, bail, kind, next, nexte, tag0, lt, npc, npar, na, nb, reach, ffc, fff, unmarked, capped; };
 struct SgLaneMemo { uint32_t gt, qgt, cmt, sq, dq; const uint8_t* bad; const uint32_t* nstop; };
 constexpr uint32_t SG_LANE_BUDGET = 8192;           // events a lane may look at in all,
 constexpr uint32_t SG_LANE_FAR = 64;                // ... of them outside the LDS window (the event list in the work area: a dependent global load each),
-constexpr uint32_t SG_LANE_ATTRS = 48;              // ... and attributes it walks: a longer tag is the wave-wide machine's, which takes its attributes one per lane (round 5)
+constexpr uint32_t SG_LANE_ATTRS = 48, SG_LANE_ATTRS_MIN = 6;   // ... and attributes it walks (the cap adapts between these, lane_batches): a longer tag is the wave-wide machine's, which takes its attributes one per lane (round 5)
 constexpr uint32_t SG_LANE_SEARCH = 2048;           // ... and in one search for a single class ('>', a quote, "-->", "?>"): the wave-wide machine looks at 64 per step
 // (a function of its own: inlined three times into sgml_tokenize it cost the wave-wide machine there its registers)
 template <int MODE>
-__device__ __noinline__ SgLaneTag sg_lane_attempt(const uint8_t* H, uint32_t L, const uint32_t* ev, uint32_t nev, uint32_t cbase, uint32_t e, const SgLaneMemo& mm, Piece* pc, SgParam* par, uint8_t* mark) {
-  SgLaneTag R; R.ok = 0; R.bail = 0; R.kind = 0; R.next = 0; R.nexte = 0; R.npc = 0; R.npar = 0; R.ffc = 0; R.fff = 0; R.unmarked = 0;
+__device__ __noinline__ SgLaneTag sg_lane_attempt(const uint8_t* H, uint32_t L, const uint32_t* ev, uint32_t nev, uint32_t cbase, uint32_t e, const SgLaneMemo& mm, Piece* pc, SgParam* par, uint8_t* mark, uint32_t attr_cap) {
+  SgLaneTag R; R.ok = 0; R.bail = 0; R.kind = 0; R.next = 0; R.nexte = 0; R.npc = 0; R.npar = 0; R.ffc = 0; R.fff = 0; R.unmarked = 0; R.capped = 0;
   bool bail = false; uint32_t budget = SG_LANE_BUDGET, reach = e + 1, far = 0;
   auto EV = [&](uint32_t i) -> uint32_t {                                  // (an unconditional LDS read, kept apart from the global one: EH_KEEP)
     const uint32_t o = i - cbase; const bool in = o < 4096u;
@@ -178,7 +178,7 @@ __device__ __noinline__ SgLaneTag sg_lane_attempt(const uint8_t* H, uint32_t L, 
     skipws();
     for (;;) {                                                             // attribute loop :134-160
       if (pos >= L || bail) break;
-      if (nq >= SG_LANE_ATTRS) { bail = true; break; }
+      if (nq >= attr_cap) { bail = true; R.capped = 1; break; }
       if (nq >= 16) {                                                      // the memo of failed attribute-loop entries
         if (mm.bad && mm.bad[pos]) break;
         if (MODE == 2) mark[pos] = 1;
@@ -639,6 +639,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   // Batches are made where they pay: four '<' or more within reach, runs of failing attempts ("<a <b <c ...").
   // A batch whose first lane gave up has cost its time for nothing: the next ones are skipped, twice as many each time it happens.
   uint32_t fail_run = 0, lb_skip = 0, lb_penalty = 1;
+  uint32_t lb_attr_cap = SG_LANE_ATTRS;                                    // attributes a lane of a tag batch walks before it gives up (adapts, below)
   uint32_t ab_skip = 0, ab_penalty = 1;                                    // attribute batches (in the attempt below) back off the same way
   auto lane_batches = [&]() __attribute__((always_inline)) -> int {
     EH_CTX;                                                                // (not the captured reference: a lambda that is not inlined would carry a generic pointer to the LDS context)
@@ -671,8 +672,9 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
       const uint32_t e = mine ? g_fuse_lds[SG_EVC + (uint32_t)l] : 0xFFFFFFFFu;
       if (!nstop_tab && !build_nstop()) return -3;
       SgLaneMemo mm; mm.gt = ff_gt; mm.qgt = ff_qgt; mm.cmt = ff_cmt; mm.sq = ff_sq; mm.dq = ff_dq; mm.bad = bad; mm.nstop = nstop_tab;
-      SgLaneTag R; R.ok = 0; R.bail = 1; R.kind = 0; R.next = 0; R.nexte = 0; R.tag0 = 0; R.lt = 0; R.npc = 0; R.npar = 0; R.na = 0; R.nb = 0; R.reach = 0; R.ffc = 0; R.fff = 0; R.unmarked = 0;
-      if (mine) R = sg_lane_attempt<0>(H, L, ev, nev, cbase, e, mm, nullptr, nullptr, nullptr);
+      SgLaneTag R; R.ok = 0; R.bail = 1; R.kind = 0; R.next = 0; R.nexte = 0; R.tag0 = 0; R.lt = 0; R.npc = 0; R.npar = 0; R.na = 0; R.nb = 0; R.reach = 0; R.ffc = 0; R.fff = 0; R.unmarked = 0; R.capped = 0;
+      const uint32_t acap = lb_attr_cap;                                   // (the three passes of one batch walk with the same cap)
+      if (mine) R = sg_lane_attempt<0>(H, L, ev, nev, cbase, e, mm, nullptr, nullptr, nullptr, acap);
       // what the attempts found out about the block: searches that ran to its end, attribute loops that fail
       if (__ballot(R.ffc != 0)) {
         const uint32_t m1 = wave_min(R.ffc == E_GT ? R.fff : nev), m2 = wave_min(R.ffc == E_QGT ? R.fff : nev), m3 = wave_min(R.ffc == E_CMTEND ? R.fff : nev);
@@ -690,7 +692,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
           for (uint32_t i = 16u * (uint32_t)l; i < L + 16; i += 1024) { uint4 z = {0, 0, 0, 0}; __builtin_memcpy(bad + i, &z, 16); }
           wave_sync();
         }
-        if (R.unmarked != 0) (void)sg_lane_attempt<2>(H, L, ev, nev, cbase, e, mm, nullptr, nullptr, bad);
+        if (R.unmarked != 0) (void)sg_lane_attempt<2>(H, L, ev, nev, cbase, e, mm, nullptr, nullptr, bad, acap);
         wave_sync();
       }
       // which attempts does the machine make?
@@ -705,6 +707,15 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
         const unsigned long long m = __ballot(mine && e >= ne);
         if (!m) break;
         k = (uint32_t)__builtin_ctzll(m);
+      }
+      // Lanes that walk a long tag to the cap before they give up make the whole batch wait for nothing - and where tags hold '<'
+      // themselves most lanes' work is thrown away anyway: few tags committed with lanes at the cap -> the cap halves (long tags
+      // go to the wave-wide machine sooner, whose attribute batches are cheap); many committed -> it grows back.
+      {
+        const uint32_t ncom = (uint32_t)__popcll(visited);
+        const bool hitcap = __ballot(mine && R.capped != 0) != 0;
+        if (hitcap && ncom < 8 && lb_attr_cap > SG_LANE_ATTRS_MIN) lb_attr_cap = lb_attr_cap / 2 < SG_LANE_ATTRS_MIN ? SG_LANE_ATTRS_MIN : lb_attr_cap / 2;
+        else if (ncom >= 24 && lb_attr_cap < SG_LANE_ATTRS) lb_attr_cap = lb_attr_cap * 2 > SG_LANE_ATTRS ? SG_LANE_ATTRS : lb_attr_cap * 2;
       }
       if (!visited) { lb_skip = lb_penalty; if (lb_penalty < 1024) lb_penalty *= 2; break; }   // the first lane gave up: the wave-wide machine takes this '<'
       if (__popcll(visited) >= 4) lb_penalty = 1;
@@ -732,7 +743,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
         const bool empty = bpc == tp0 && R.lt == segb;                     // (every earlier piece of the token holds a '<')
         SgTok t; t.kind = TK_TEXT | (empty ? (uint32_t)TF_EMPTY : 0u); t.p0 = tp0; t.np = bpc + 1u - tp0; t.na = 0; t.nb = 0; t.par0 = 0; t.npar = 0; t.match = -1;
         tok[btk] = t;
-        SgLaneTag W = sg_lane_attempt<1>(H, L, ev, nev, cbase, e, mm, pc + bpc + 1u, par + bpr, nullptr);
+        SgLaneTag W = sg_lane_attempt<1>(H, L, ev, nev, cbase, e, mm, pc + bpc + 1u, par + bpr, nullptr, acap);
         SgTok g; g.kind = W.kind; g.p0 = bpc + 1u; g.np = W.npc; g.na = W.na; g.nb = W.nb; g.par0 = bpr; g.npar = W.npar; g.match = -1;
         tok[btk + 1u] = g;
       }
@@ -842,11 +853,14 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
         if (pos >= L) break;
         // ---- a long tag: the next iterations one per lane (sg_lane_attr, above).  The chain walk commits exactly the iterations this
         // loop would make, in its order; what is not a plain attribute stays for the statements below.
-        if (nattr >= 16 && lanes_on && (uint64_t)npc + 6u * 64u + 16u <= cap_pc && (uint64_t)npar + 65u <= cap_par) {
+        // (below the 16th attribute the memo of failed entries is neither asked nor fed: a batch there takes at most 16 - nattr iterations)
+        if (nattr >= 2 && lanes_on && (uint64_t)npc + 6u * 64u + 16u <= cap_pc && (uint64_t)npar + 65u <= cap_par) {
           if (ab_skip > 0) ab_skip--;
           else {
             if (!nstop_tab && !build_nstop()) return -3;
-            if (!chain) { chain = (uint32_t*)ws_alloc(c, ((uint64_t)nstop + 8) * 4); if (!chain) return -3; }
+            const bool memo = nattr >= 16;
+            const uint32_t maxc = memo ? 64u : 16u - nattr;
+            if (memo && !chain) { chain = (uint32_t*)ws_alloc(c, ((uint64_t)nstop + 8) * 4); if (!chain) return -3; }
             if (cbase != 0xFFFFFFFFu && cbase + SG_EVC < nev && ei + 1024u > cbase + SG_EVC) { cbase = 0xFFFFFFFFu; bbase = 0xFFFFFFFFu; }   // little of the window left: move it
             need(ei);
             const uint32_t wend = cbase + SG_EVC < nev ? cbase + SG_EVC : nev;
@@ -854,7 +868,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
             const uint32_t send = ei + 1024u < lim ? ei + 1024u : lim;
             uint32_t nc = 1;                                               // lane 0: where the machine is
             lanes_sync();
-            for (uint32_t base = ei; base < send && nc < 64; base += 64) {
+            for (uint32_t base = ei; base < send && nc < maxc; base += 64) {
               const uint32_t idx = base + (uint32_t)l;
               const bool in = idx < send;
               const uint32_t v = in ? g_fuse_lds[idx - cbase] : 0u;
@@ -867,7 +881,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
               if (is && rank < 64) g_fuse_lds[SG_EVC + rank] = idx;
               nc += (uint32_t)__popcll(m);
             }
-            if (nc > 64) nc = 64;
+            if (nc > maxc) nc = maxc;
             lanes_sync();
             const bool mine = (uint32_t)l < nc;
             const uint32_t cj = (l > 0 && mine) ? g_fuse_lds[SG_EVC + (uint32_t)l] : cbase;
@@ -876,7 +890,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
             SgLaneMemo mm; mm.gt = ff_gt; mm.qgt = ff_qgt; mm.cmt = ff_cmt; mm.sq = ff_sq; mm.dq = ff_dq; mm.bad = bad; mm.nstop = nstop_tab;
             SgLaneAttr A; A.term = 1; A.npos = 0; A.nei = 0; A.nws = 0; A.an = 0; A.ae = 0; A.va = 0; A.vb = 0; A.delim = 0; A.eqpos = 0; A.reach = 0;
             if (mine) A = sg_lane_attr(H, L, ev, nev, cbase, cpos, cei, cws, mm);
-            const uint32_t isbad = (mine && bad && cpos < L) ? (uint32_t)bad[cpos] : 0u;
+            const uint32_t isbad = (memo && mine && bad && cpos < L) ? (uint32_t)bad[cpos] : 0u;
             // the chain: lane k's iteration is followed by the lane whose candidate is where it ended.  Mostly that is the next lane
             // (a word, white space, the next word), so runs of such lanes are taken with bit operations, the rest by a search.
             const uint32_t cpos_nx = (uint32_t)__shfl((int)cpos, (l + 1) & 63);
@@ -909,12 +923,12 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
                 x.ptr = (uint64_t)(hd ? H + A.va - 1 : qp); x.len = hd ? 1u : 0u; o[3] = x;
                 x.ptr = (uint64_t)(H + A.va); x.len = has ? A.vb - A.va : 0u; o[4] = x;
                 x.ptr = (uint64_t)(hd ? H + A.vb : qp); x.len = hd ? 1u : 0u; o[5] = x;
-                chain[nchain + rank] = cpos;
+                if (memo) chain[nchain + rank] = cpos;
               }
               const uint32_t lastc = 63u - (uint32_t)__builtin_clzll(visited);
               pos = (uint32_t)__builtin_amdgcn_readlane((int)A.npos, (int)lastc); ei = (uint32_t)__builtin_amdgcn_readlane((int)A.nei, (int)lastc);
               ws_sp = (uint32_t)__builtin_amdgcn_readlane((int)A.nws, (int)lastc) != 0;
-              npar += cnt; npc += 6u * cnt; nattr += cnt; nchain += cnt;
+              npar += cnt; npc += 6u * cnt; nattr += cnt; if (memo) nchain += cnt;
               if (rp_state != 0) { const uint32_t r = wave_max(cm ? A.reach : 0u); if (r > reach_ev) reach_ev = r; }
               bbase = 0xFFFFFFFFu;
               wave_sync();

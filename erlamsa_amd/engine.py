@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ERLAMSA_HIP_LIB") or os.path.join(_HERE, "liberlamsa_hip.so")
 
-EH_ABI_VERSION = 6
+EH_ABI_VERSION = 7
 EH_FLAG_ORDERED_OUTPUT = 1
 EH_FLAG_META_TRACE = 2
 EH_FLAG_FUSE_NO_LDS = 4
@@ -31,6 +31,8 @@ ABI_SYMBOLS = [
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
     "eh_coalesce_limits", "eh_submit", "eh_flush", "eh_poll", "eh_cancel",
     "eh_corpus_device", "eh_stream", "eh_host_alloc", "eh_host_free", "eh_selftest_sort_by_priority", "eh_last_error_copy",
+    "eh_comm_unique_id", "eh_comm_init", "eh_comm_init_local", "eh_comm_destroy", "eh_corpus_broadcast", "eh_corpus_allgather",
+    "eh_corpus_broadcast_local", "eh_device_count",
 ]
 
 
@@ -39,7 +41,8 @@ class EhOptions(C.Structure):
                 ("generators", C.c_char_p), ("blockscale", C.c_double), ("ssrf_host", C.c_char_p),
                 ("ssrf_port", C.c_int32), ("max_case_bytes", C.c_uint64), ("out_capacity", C.c_uint64),
                 ("max_case_work", C.c_uint64), ("max_slots", C.c_uint32), ("flags", C.c_uint32), ("big_case_bytes", C.c_uint64),
-                ("pool_bytes", C.c_uint64), ("download_chunk_bytes", C.c_uint64), ("fuse_stream_min", C.c_uint64)]
+                ("pool_bytes", C.c_uint64), ("download_chunk_bytes", C.c_uint64), ("fuse_stream_min", C.c_uint64),
+                ("sequence_muta", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class EngineError(RuntimeError):
@@ -94,6 +97,13 @@ def load_library():
     lib.eh_coalesce_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
     lib.eh_submit.argtypes = [vp, vp, C.c_uint64, i64p, u64p]
     lib.eh_flush.argtypes = [vp]
+    lib.eh_comm_unique_id.argtypes = [vp]
+    lib.eh_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.eh_comm_init_local.argtypes = [vp, C.c_int]
+    lib.eh_comm_destroy.argtypes = [vp]
+    lib.eh_corpus_broadcast.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
+    lib.eh_corpus_allgather.argtypes = [vp, vp, vp, C.c_uint64]
+    lib.eh_corpus_broadcast_local.argtypes = [vp, C.c_int, C.c_int]
     lib.eh_cancel.argtypes = [vp, C.c_uint64]
     lib.eh_poll.argtypes = [vp, C.c_uint64, vp, C.c_uint64, u64p, C.POINTER(C.c_int32)]
     lib.eh_corpus_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), u64p, u64p]
@@ -173,8 +183,9 @@ class Engine:
 
     def configure(self, mutations=None, patterns=None, generators=None, blockscale=1.0, ssrf_host=None, ssrf_port=0,
                   max_case_bytes=0, out_capacity=0, max_slots=0, flags=0, max_case_work=0, big_case_bytes=0,
-                  pool_bytes=0, download_chunk_bytes=0, fuse_stream_min=0):
+                  pool_bytes=0, download_chunk_bytes=0, fuse_stream_min=0, sequence_muta=False):
         o = EhOptions()
+        o.sequence_muta = 1 if sequence_muta else 0
         o.abi_version = EH_ABI_VERSION
         o.mutations = mutations.encode() if mutations is not None else None
         o.patterns = patterns.encode() if patterns is not None else None
@@ -202,6 +213,58 @@ class Engine:
         """d_*_ptr: raw device addresses (e.g. torch tensor .data_ptr())."""
         self._chk(self.lib.eh_corpus_attach(self.h, C.c_void_p(d_data_ptr), C.c_void_p(d_off_ptr), n, nbytes))
         self.n_corpus = n
+
+    # ---- multi-GPU: the arena over RCCL, called from inside the library (include/erlamsa_hip.h, csrc/eh_comm.h)
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: the 128 bytes every rank hands to comm_init (eh_comm_unique_id = ncclGetUniqueId)"""
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.eh_comm_unique_id(buf)
+        if rc != 0:
+            raise EngineError(rc, lib.eh_strerror(rc).decode() + " (RCCL could not be loaded: EH_RCCL_LIB)")
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, nranks):
+        """collective over the nranks processes (one per GPU): ncclCommInitRank on this context's device"""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._chk(self.lib.eh_comm_init(self.h, buf, rank, nranks))
+
+    def comm_destroy(self):
+        self._chk(self.lib.eh_comm_destroy(self.h))
+
+    def corpus_broadcast(self, root, data=None, off=None):
+        """root passes the arena, the others nothing; afterwards every rank's context holds it (eh_corpus_broadcast)"""
+        if data is not None:
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            off = np.ascontiguousarray(off, dtype=np.uint64)
+            self._chk(self.lib.eh_corpus_broadcast(self.h, root, data.ctypes.data, off.ctypes.data, len(off) - 1))
+        else:
+            self._chk(self.lib.eh_corpus_broadcast(self.h, root, None, None, 0))
+        self.n_corpus = self.corpus_device()[2]
+
+    def corpus_allgather(self, data, off):
+        """every rank passes its shard (same entries and bytes on all ranks); afterwards every context holds all shards in rank order"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        self._chk(self.lib.eh_corpus_allgather(self.h, data.ctypes.data, off.ctypes.data, len(off) - 1))
+        self.n_corpus = self.corpus_device()[2]
+
+    @staticmethod
+    def comm_init_local(engines):
+        """one process, several devices (one context each): ncclCommInitAll"""
+        arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        rc = engines[0].lib.eh_comm_init_local(arr, len(engines))
+        engines[0]._chk(rc)
+
+    @staticmethod
+    def corpus_broadcast_local(engines, root=0):
+        """the corpus loaded on engines[root] goes to the devices of all the others (eh_corpus_broadcast_local)"""
+        arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        rc = engines[0].lib.eh_corpus_broadcast_local(arr, len(engines), root)
+        engines[root]._chk(rc)
+        for e in engines:
+            e.n_corpus = engines[root].n_corpus
 
     def corpus_device(self):
         """-> (d_data address, d_off address, n, nbytes) of the loaded corpus (eh_corpus_device)"""

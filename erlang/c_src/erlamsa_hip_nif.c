@@ -11,6 +11,10 @@
  *       case I is its own fuzzer/1 run with n = 1 and the I-th seed: erlamsa_app:fuzz/2      (eh_fuzz_calls)
  *   Status: enum eh_case_status.  Both run on a dirty I/O scheduler: one call = one GPU batch.
  *   submit_nif / flush_nif / poll_nif: request coalescing, see below.
+ *   Several GPUs (ABI 7, include/erlamsa_hip.h "multi-GPU"), see the end of this file:
+ *     device_count() / load_corpus_nif / fuzz_range_nif                       a corpus that stays loaded, case ranges of it
+ *     comm_init_local_nif([Ctx]) / broadcast_local_nif([Ctx], Root)           one BEAM node, one context per GPU
+ *     comm_unique_id_nif() / comm_init_nif(Ctx, Id, Rank, N) / corpus_broadcast_nif(Ctx, Root, Bins | none)   one node per GPU
  *
  * A context remembers the options it was last configured with: eh_configure runs again only when they change.
  */
@@ -27,6 +31,7 @@ typedef struct {
   int has_muts, has_pats, has_gens, has_host, port;
   double blockscale;
   uint64_t max_case_bytes, big_case_bytes, max_case_work;
+  int sequence_muta;
 } opt_key;
 
 static ErlNifResourceType* ctx_type;
@@ -97,6 +102,8 @@ static int read_opts(ErlNifEnv* env, ERL_NIF_TERM map, opt_key* k) {
   if (get_u64(env, map, "max_case_bytes", &k->max_case_bytes) < 0) return 0;
   if (get_u64(env, map, "big_case_bytes", &k->big_case_bytes) < 0) return 0;
   if (get_u64(env, map, "max_case_work", &k->max_case_work) < 0) return 0;
+  /* erlamsa_main.erl:223-235: the engine refuses it (EH_E_UNSUPPORTED) and the caller stays on the BEAM path */
+  if (enif_get_map_value(env, map, enif_make_atom(env, "sequence_muta"), &v)) k->sequence_muta = enif_compare(v, enif_make_atom(env, "true")) == 0;
   return 1;
 }
 
@@ -109,6 +116,7 @@ static int configure_if_changed(ctx_res* r, const opt_key* k) {
   o.ssrf_host = k->has_host ? k->host : NULL;
   o.ssrf_port = k->port; o.blockscale = k->blockscale;
   o.max_case_bytes = k->max_case_bytes; o.big_case_bytes = k->big_case_bytes; o.max_case_work = k->max_case_work;
+  o.sequence_muta = (uint32_t)k->sequence_muta;
   int rc = eh_configure(r->ctx, &o);
   r->configured = rc == EH_OK;
   if (rc == EH_OK) r->key = *k;
@@ -253,6 +261,115 @@ static ERL_NIF_TERM nif_poll(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]
 static ERL_NIF_TERM nif_fuzz_batch(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { (void)argc; return run(env, argv, 0); }
 static ERL_NIF_TERM nif_fuzz_calls(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { (void)argc; return run(env, argv, 1); }
 
+/* ---- several GPUs (ABI 7) -----------------------------------------------------------------------------------------------------
+ * The corpus stays loaded on the context(s); a process per device then runs its contiguous range of the case numbers
+ * (erlamsa_hip:fuzz_batch_multi/2 = the shape of erlamsa_main:get_threading_mode/3, erlamsa_main.erl:95-108).  The arena reaches
+ * the other GPUs over RCCL called from inside the library (csrc/eh_comm.h): the BEAM needs no HIP or RCCL binding. */
+static int pack_bins(ErlNifEnv* env, ERL_NIF_TERM bins, unsigned n, uint8_t** data, uint64_t** off) {   /* 0 ok, 1 badarg, 2 enomem */
+  *off = malloc(((size_t)n + 1) * sizeof(uint64_t)); *data = NULL;
+  if (!*off) return 2;
+  uint64_t total = 0; unsigned i = 0; ERL_NIF_TERM head; ErlNifBinary b;
+  for (ERL_NIF_TERM l = bins; enif_get_list_cell(env, l, &head, &l); i++) { if (!enif_inspect_binary(env, head, &b)) return 1; (*off)[i] = total; total += b.size; }
+  (*off)[n] = total;
+  *data = malloc(total ? total : 1);
+  if (!*data) return 2;
+  i = 0;
+  for (ERL_NIF_TERM l = bins; enif_get_list_cell(env, l, &head, &l); i++) { enif_inspect_binary(env, head, &b); memcpy(*data + (*off)[i], b.data, b.size); }
+  return 0;
+}
+static int get_ctx_list(ErlNifEnv* env, ERL_NIF_TERM list, ctx_res** rs, eh_ctx** cs, unsigned* n) {
+  if (!enif_get_list_length(env, list, n) || *n < 1 || *n > 64) return 0;
+  ERL_NIF_TERM head; unsigned i = 0;
+  for (ERL_NIF_TERM l = list; enif_get_list_cell(env, l, &head, &l); i++) { if (!enif_get_resource(env, head, ctx_type, (void**)&rs[i])) return 0; cs[i] = rs[i]->ctx; }
+  return 1;
+}
+static ERL_NIF_TERM nif_device_count(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { (void)argc; (void)argv; return enif_make_int(env, eh_device_count()); }
+/* load_corpus_nif(Ctx, Bins) -> ok */
+static ERL_NIF_TERM nif_load_corpus(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res* r; unsigned n = 0; uint8_t* data = NULL; uint64_t* off = NULL; (void)argc;
+  if (!enif_get_resource(env, argv[0], ctx_type, (void**)&r) || !enif_get_list_length(env, argv[1], &n)) return enif_make_badarg(env);
+  int pr = pack_bins(env, argv[1], n, &data, &off);
+  ERL_NIF_TERM ret = enif_make_atom(env, "ok");
+  if (pr) ret = pr == 1 ? enif_make_badarg(env) : mk_err_atom(env, "enomem");
+  else { enif_mutex_lock(r->lock); int rc = eh_corpus_upload(r->ctx, data, off, n); if (rc) ret = mk_error(env, r->ctx, rc); enif_mutex_unlock(r->lock); }
+  free(data); free(off);
+  return ret;
+}
+/* comm_init_local_nif([Ctx]) -> ok ;  broadcast_local_nif([Ctx], Root) -> ok */
+static ERL_NIF_TERM nif_comm_init_local(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res* rs[64]; eh_ctx* cs[64]; unsigned n; (void)argc;
+  if (!get_ctx_list(env, argv[0], rs, cs, &n)) return enif_make_badarg(env);
+  int rc = eh_comm_init_local(cs, (int)n);
+  return rc ? mk_error(env, cs[0], rc) : enif_make_atom(env, "ok");
+}
+static ERL_NIF_TERM nif_broadcast_local(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res* rs[64]; eh_ctx* cs[64]; unsigned n; int root; (void)argc;
+  if (!get_ctx_list(env, argv[0], rs, cs, &n) || !enif_get_int(env, argv[1], &root) || root < 0 || root >= (int)n) return enif_make_badarg(env);
+  int rc = eh_corpus_broadcast_local(cs, (int)n, root);
+  return rc ? mk_error(env, cs[root], rc) : enif_make_atom(env, "ok");
+}
+/* one node per GPU: comm_unique_id_nif() -> {ok, <<128 bytes>>} ; comm_init_nif(Ctx, Id, Rank, N) -> ok ; corpus_broadcast_nif(Ctx, Root, Bins | none) -> ok */
+static ERL_NIF_TERM nif_comm_unique_id(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ERL_NIF_TERM bin; (void)argc; (void)argv;
+  unsigned char* p = enif_make_new_binary(env, 128, &bin);
+  int rc = p ? eh_comm_unique_id(p) : EH_E_NOMEM;
+  return rc ? mk_error(env, NULL, rc) : enif_make_tuple2(env, enif_make_atom(env, "ok"), bin);
+}
+static ERL_NIF_TERM nif_comm_init(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res* r; ErlNifBinary id; int rank, n; (void)argc;
+  if (!enif_get_resource(env, argv[0], ctx_type, (void**)&r) || !enif_inspect_binary(env, argv[1], &id) || id.size != 128 || !enif_get_int(env, argv[2], &rank) || !enif_get_int(env, argv[3], &n)) return enif_make_badarg(env);
+  enif_mutex_lock(r->lock);
+  int rc = eh_comm_init(r->ctx, id.data, rank, n);
+  ERL_NIF_TERM ret = rc ? mk_error(env, r->ctx, rc) : enif_make_atom(env, "ok");
+  enif_mutex_unlock(r->lock);
+  return ret;
+}
+static ERL_NIF_TERM nif_corpus_broadcast(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res* r; int root; unsigned n = 0; uint8_t* data = NULL; uint64_t* off = NULL; (void)argc;
+  if (!enif_get_resource(env, argv[0], ctx_type, (void**)&r) || !enif_get_int(env, argv[1], &root)) return enif_make_badarg(env);
+  const int have = enif_is_list(env, argv[2]);
+  if (have) { if (!enif_get_list_length(env, argv[2], &n)) return enif_make_badarg(env); int pr = pack_bins(env, argv[2], n, &data, &off); if (pr) { free(data); free(off); return pr == 1 ? enif_make_badarg(env) : mk_err_atom(env, "enomem"); } }
+  enif_mutex_lock(r->lock);
+  int rc = eh_corpus_broadcast(r->ctx, root, data, off, n);
+  ERL_NIF_TERM ret = rc ? mk_error(env, r->ctx, rc) : enif_make_atom(env, "ok");
+  enif_mutex_unlock(r->lock);
+  free(data); free(off);
+  return ret;
+}
+/* fuzz_range_nif(Ctx, Opts, {A,B,C}, FirstCase, CorpusFirst, N) -> {ok, [{Status, binary()}]}: N cases of the LOADED corpus */
+static ERL_NIF_TERM nif_fuzz_range(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res* r; opt_key k; ErlNifUInt64 first, cfirst, n; const ERL_NIF_TERM* st; int arity; ErlNifSInt64 seed[3]; (void)argc;
+  if (!enif_get_resource(env, argv[0], ctx_type, (void**)&r) || !enif_is_map(env, argv[1]) || !read_opts(env, argv[1], &k) || !enif_get_tuple(env, argv[2], &arity, &st) || arity != 3 ||
+      !enif_get_uint64(env, argv[3], &first) || first < 1 || !enif_get_uint64(env, argv[4], &cfirst) || !enif_get_uint64(env, argv[5], &n)) return enif_make_badarg(env);
+  for (int i = 0; i < 3; i++) if (!enif_get_int64(env, st[i], &seed[i])) return enif_make_badarg(env);
+  uint64_t* off = malloc(((size_t)n + 1) * sizeof(uint64_t)); int32_t* status = malloc(((size_t)n + 1) * sizeof(int32_t)); uint8_t* out = NULL;
+  ERL_NIF_TERM ret;
+  if (!off || !status) { ret = mk_err_atom(env, "enomem"); goto done; }
+  enif_mutex_lock(r->lock);
+  {
+    int rc = configure_if_changed(r, &k);
+    if (!rc) rc = eh_fuzz_batch(r->ctx, (const int64_t*)seed, first, cfirst, n, NULL);
+    uint64_t in_b = 0, out_b = 0, nc = 0;
+    if (!rc) rc = eh_result_totals(r->ctx, &in_b, &out_b, &nc);
+    if (!rc) { out = malloc(out_b ? out_b : 1); if (!out) rc = EH_E_NOMEM; }
+    if (!rc) rc = eh_result_download(r->ctx, out, out_b, off, status);
+    if (rc) { ret = mk_error(env, r->ctx, rc); enif_mutex_unlock(r->lock); goto done; }
+  }
+  enif_mutex_unlock(r->lock);
+  ret = enif_make_list(env, 0);
+  for (uint64_t i = n; i-- > 0;) {
+    ERL_NIF_TERM bin; size_t len = (size_t)(off[i + 1] - off[i]);
+    unsigned char* p = enif_make_new_binary(env, len, &bin);
+    if (!p) { ret = mk_err_atom(env, "enomem"); goto done; }
+    memcpy(p, out + off[i], len);
+    ret = enif_make_list_cell(env, enif_make_tuple2(env, enif_make_int(env, status[i]), bin), ret);
+  }
+  ret = enif_make_tuple2(env, enif_make_atom(env, "ok"), ret);
+done:
+  free(off); free(status); free(out);
+  return ret;
+}
+
 static ErlNifFunc funcs[] = {
   {"open", 1, nif_open, 0},
   {"fuzz_batch_nif", 5, nif_fuzz_batch, ERL_NIF_DIRTY_JOB_IO_BOUND},
@@ -261,5 +378,13 @@ static ErlNifFunc funcs[] = {
   {"flush_nif", 1, nif_flush, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"poll_nif", 2, nif_poll, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"write_files_nif", 3, nif_write_files, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"device_count", 0, nif_device_count, 0},
+  {"load_corpus_nif", 2, nif_load_corpus, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"fuzz_range_nif", 6, nif_fuzz_range, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"comm_init_local_nif", 1, nif_comm_init_local, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"broadcast_local_nif", 2, nif_broadcast_local, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"comm_unique_id_nif", 0, nif_comm_unique_id, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"comm_init_nif", 4, nif_comm_init, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"corpus_broadcast_nif", 3, nif_corpus_broadcast, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 ERL_NIF_INIT(erlamsa_hip, funcs, load, NULL, NULL, NULL)

@@ -17,6 +17,8 @@
 -export([init/0, open/1, fuzz_batch/2, fuzz_calls/2, fuzz_batch_nif/5, fuzz_calls_nif/4, capabilities/0, fuzzer/3]).
 -export([submit/3, flush/1, poll/2, submit_nif/4, flush_nif/1, poll_nif/2]).
 -export([write_files/3, write_files_nif/3]).
+-export([fuzz_batch_multi/2, open_all/0, device_count/0, load_corpus_nif/2, fuzz_range_nif/6, comm_init_local_nif/1, broadcast_local_nif/2,
+         comm_unique_id_nif/0, comm_init_nif/4, corpus_broadcast_nif/3, case_range/3, join_ranks/3]).
 -on_load(init/0).
 
 init() ->
@@ -30,11 +32,78 @@ submit_nif(_Ctx, _Opts, _Seed, _Bin) -> erlang:nif_error(nif_not_loaded).
 flush_nif(_Ctx) -> erlang:nif_error(nif_not_loaded).
 poll_nif(_Ctx, _Ticket) -> erlang:nif_error(nif_not_loaded).
 write_files_nif(_Ctx, _Template, _FirstN) -> erlang:nif_error(nif_not_loaded).
+device_count() -> erlang:nif_error(nif_not_loaded).
+load_corpus_nif(_Ctx, _Bins) -> erlang:nif_error(nif_not_loaded).
+fuzz_range_nif(_Ctx, _Opts, _Seed, _FirstCase, _CorpusFirst, _N) -> erlang:nif_error(nif_not_loaded).
+comm_init_local_nif(_Ctxs) -> erlang:nif_error(nif_not_loaded).
+broadcast_local_nif(_Ctxs, _Root) -> erlang:nif_error(nif_not_loaded).
+comm_unique_id_nif() -> erlang:nif_error(nif_not_loaded).
+comm_init_nif(_Ctx, _Id, _Rank, _N) -> erlang:nif_error(nif_not_loaded).
+corpus_broadcast_nif(_Ctx, _Root, _BinsOrNone) -> erlang:nif_error(nif_not_loaded).
 
 %% Dict: the options map of erlamsa_main:fuzzer/1 (seed, mutations, patterns, generators, blockscale) plus first_case / device
 fuzz_batch(Bins, Dict) ->
     Seed = maps:get(seed, Dict, erlamsa_rnd:gen_urandom_seed()),
     split(fuzz_batch_nif(ctx(Dict), opts(Dict), Seed, maps:get(first_case, Dict, 1), Bins)).
+
+%% ---- several GPUs -------------------------------------------------------------------------------------------------------
+%% One BEAM node, every GPU of the machine: the arena is uploaded to the first device, RCCL-broadcast to the others from inside
+%% the library (no HIP binding needed here), and every device runs its contiguous range of the case numbers - the shape of
+%% erlamsa_main:get_threading_mode/3 (erlamsa_main.erl:95-108), except that results do NOT depend on the number of devices
+%% (case I is parent draws s0+3(I-1)+1.., whoever runs it).  Same return value as fuzz_batch/2.
+fuzz_batch_multi(Bins, Dict) ->
+    Ctxs = multi_ctxs(),
+    W = length(Ctxs), N = length(Bins),
+    Seed = maps:get(seed, Dict, erlamsa_rnd:gen_urandom_seed()),
+    First = maps:get(first_case, Dict, 1),
+    Opts = opts(Dict),
+    ok = load_corpus_nif(hd(Ctxs), Bins),
+    ok = case W of 1 -> ok; _ -> broadcast_local_nif(Ctxs, 0) end,
+    Parent = self(),
+    Pids = [spawn_link(fun() -> {A, Cnt} = case_range(N, R, W),
+                                Parent ! {self(), fuzz_range_nif(C, Opts, Seed, First + A, A, Cnt)} end)
+            || {R, C} <- lists:zip(lists:seq(0, W - 1), Ctxs)],
+    Parts = [receive {P, Res} -> Res end || P <- Pids],
+    case [E || {error, _} = E <- Parts] of
+        [E | _] -> E;                                             %% caller falls back to erlamsa_main:fuzzer/1
+        [] -> split({ok, lists:append([L || {ok, L} <- Parts])})
+    end.
+
+%% contiguous split of cases 0..N-1 over W ranks, the first N rem W ranks take one more (erlamsa_amd/shard.py case_range)
+case_range(N, Rank, W) ->
+    Base = N div W, Rem = N rem W,
+    {Rank * Base + min(Rank, Rem), Base + case Rank < Rem of true -> 1; false -> 0 end}.
+
+open_all() -> [begin {ok, C} = open(D), C end || D <- lists:seq(0, device_count() - 1)].
+multi_ctxs() ->
+    case persistent_term:get(erlamsa_hip_multi, undefined) of
+        undefined ->
+            global:trans({erlamsa_hip_multi, self()},
+                         fun() ->
+                             case persistent_term:get(erlamsa_hip_multi, undefined) of
+                                 undefined ->
+                                     Cs = open_all(),
+                                     ok = case Cs of [_] -> ok; _ -> comm_init_local_nif(Cs) end,
+                                     persistent_term:put(erlamsa_hip_multi, Cs), Cs;
+                                 Cs -> Cs
+                             end
+                         end, [node()]);
+        Cs -> Cs
+    end.
+
+%% One BEAM node PER GPU (a cluster of nodes on one machine, or `--workers` across nodes): rank 0 makes the unique id, Erlang
+%% distribution carries its 128 bytes, every node joins, the root's Bins reach all of them over xGMI.
+%%   Nodes :: [node()] in rank order, this node among them.  -> {ok, Ctx, Rank}
+join_ranks(Nodes, Bins, Dict) ->
+    Rank = length(lists:takewhile(fun(Nd) -> Nd =/= node() end, Nodes)),
+    C = ctx(Dict),
+    Id = case Rank of
+             0 -> {ok, I} = comm_unique_id_nif(), [{erlamsa_hip_uid, Nd} ! {uid, I} || Nd <- tl(Nodes)], I;
+             _ -> register(erlamsa_hip_uid, self()), receive {uid, I} -> unregister(erlamsa_hip_uid), I end
+         end,
+    ok = comm_init_nif(C, Id, Rank, length(Nodes)),
+    ok = corpus_broadcast_nif(C, 0, case Rank of 0 -> Bins; _ -> none end),
+    {ok, C, Rank}.
 
 %% Calls :: [{Bin, Seed}] — one erlamsa_app:fuzz(Bin, #{seed => Seed}) each
 fuzz_calls(Calls, Dict) ->
@@ -89,7 +158,9 @@ opts(Dict) ->
                {ok, G} -> #{generators => actions([{N, P} || {N, P} <- G, lists:member(N, [direct, random, file, jump])])};
                error -> #{}
            end,
-    maps:merge(maps:merge(Base, Gens), maps:with([max_case_bytes, big_case_bytes, max_case_work], Dict)).
+    %% sequence_muta (--consequtive-mutators, erlamsa_main.erl:223-235) goes along as it is: the engine refuses it
+    %% ({error, "sequence_muta ..."}) and the caller's fall-back to erlamsa_main:fuzzer/1 takes the run
+    maps:merge(maps:merge(Base, Gens), maps:with([max_case_bytes, big_case_bytes, max_case_work, sequence_muta], Dict)).
 
 split({error, Why}) -> {error, Why};                             %% caller falls back to erlamsa_main:fuzzer/1
 split({ok, Res}) ->

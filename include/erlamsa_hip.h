@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EH_ABI_VERSION 6
+#define EH_ABI_VERSION 7
 
 typedef struct eh_ctx eh_ctx;
 
@@ -107,6 +107,12 @@ typedef struct eh_options {
   uint64_t fuse_stream_min;  /* erlamsa_fuse:fuse/2 on la + lb >= this many bytes runs as the position-indexed class
                                 refinement (csrc/eh_fuse2.h) instead of the node-list refinement (csrc/eh_fuse.h);
                                 results are identical.  0 => 16384 */
+  /* ABI 7 */
+  uint32_t sequence_muta;    /* the reference's --consequtive-mutators / sequence_muta (erlamsa_main.erl:223-235): the mutator
+                                scores of case I are what case I-1 left behind - a serial chain over the cases of a run, which a
+                                batch of independent cases cannot keep.  Non-zero => eh_configure refuses with EH_E_UNSUPPORTED
+                                ("route this run to the BEAM path"); the shim (erlang/src/erlamsa_hip.erl) checks the same key */
+  uint32_t reserved0;
 } eh_options;
 
 #define EH_FLAG_ORDERED_OUTPUT 1u /* compact the output arena into case order after the batch */
@@ -132,6 +138,34 @@ int eh_corpus_upload(eh_ctx* ctx, const uint8_t* data, const uint64_t* off, uint
 /* Same, but both arrays already live in this device's memory (e.g. after an RCCL
  * broadcast); the engine does not take ownership. */
 int eh_corpus_attach(eh_ctx* ctx, const void* d_data, const void* d_off, uint64_t n, uint64_t nbytes);
+
+/* ---- multi-GPU: the seed arena on every GPU of the node, over RCCL called from inside the library (csrc/eh_comm.h, ABI 7) ----
+ * Cases are independent, so the mutation path never communicates; the one exchange is the arena at load time.
+ * The reference's counterpart: every `--workers` scheduler reads the same input files (erlamsa_main.erl:90-108).  RCCL is reached
+ * from here because the host north_star names - the BEAM - has no HIP or RCCL binding.  librccl.so is loaded on first use
+ * (environment EH_RCCL_LIB names another file); a single-GPU host never needs it.  EH_E_UNSUPPORTED when it cannot be loaded.
+ *
+ * One OS process per GPU (how bench.py is launched):
+ *   rank 0: eh_comm_unique_id(id); the 128 bytes reach the other processes over the host's own channel (Erlang distribution, a
+ *   file, torch.distributed's store).  Every rank: eh_comm_init(ctx, id, rank, nranks) - collective, returns when all have joined.
+ *   eh_corpus_broadcast(ctx, root, data, off, n)    root passes the arena (host pointers), the others NULL / 0; afterwards every
+ *                                                   context holds the corpus as after eh_corpus_upload (BASELINE configs[3]).
+ *   eh_corpus_allgather(ctx, data, off, n_local)    every rank passes ITS shard, the same number of entries and bytes on all ranks
+ *                                                   (configs[4]: fixed-size seeds); afterwards every context holds the shards in
+ *                                                   rank order - each xGMI link carries 1/nranks of the arena.
+ * One process, several GPUs (what one BEAM node is): eh_comm_init_local(ctxs, n) - one context per device, ncclCommInitAll - then
+ *   eh_corpus_broadcast_local(ctxs, n, root) copies the corpus loaded on ctxs[root] to the devices of all the others.
+ * Cases are then sharded by case number: rank r of W runs eh_fuzz_batch(first_case + a_r, corpus_first + a_r, n_r) for its
+ * contiguous range (erlamsa_amd/shard.py case_range = the shape of erlamsa_main:get_threading_mode/3, erlamsa_main.erl:95-108);
+ * results never depend on W. */
+int eh_device_count(void);   /* HIP devices this process sees (0 when there is none or the runtime fails) */
+int eh_comm_unique_id(uint8_t id[128]);
+int eh_comm_init(eh_ctx* ctx, const uint8_t id[128], int rank, int nranks);
+int eh_comm_init_local(eh_ctx** ctxs, int nctx);
+int eh_comm_destroy(eh_ctx* ctx);
+int eh_corpus_broadcast(eh_ctx* ctx, int root, const uint8_t* data, const uint64_t* off, uint64_t n);
+int eh_corpus_allgather(eh_ctx* ctx, const uint8_t* data, const uint64_t* off, uint64_t n_local);
+int eh_corpus_broadcast_local(eh_ctx** ctxs, int nctx, int root);
 
 /* Device-side view of the loaded corpus (after eh_corpus_upload / eh_corpus_attach): lets further contexts of the same
  * device share one arena (eh_corpus_attach on them) instead of holding a copy each.  Any pointer may be NULL. */

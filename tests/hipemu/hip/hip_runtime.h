@@ -246,7 +246,7 @@ struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGl
 
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "hipemu: out of memory"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { const char* e = getenv("HIPEMU_DEVICES"); *n = e && atoi(e) > 0 ? atoi(e) : 1; return hipSuccess; }   // (HIPEMU_DEVICES: several "devices", all of them this CPU - the multi-GPU entry points of the C ABI, tests/test_comm_abi.py)
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 enum hipLimit_t { hipLimitStackSize = 0 };
 inline hipError_t hipDeviceSetLimit(hipLimit_t, size_t) { return hipSuccess; }   // fibers have 1 MiB stacks

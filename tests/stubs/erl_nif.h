@@ -33,6 +33,8 @@ int enif_get_list_length(ErlNifEnv*, ERL_NIF_TERM, unsigned*);
 int enif_get_list_cell(ErlNifEnv*, ERL_NIF_TERM, ERL_NIF_TERM*, ERL_NIF_TERM*);
 int enif_get_map_value(ErlNifEnv*, ERL_NIF_TERM map, ERL_NIF_TERM key, ERL_NIF_TERM* value);
 int enif_is_map(ErlNifEnv*, ERL_NIF_TERM);
+int enif_is_list(ErlNifEnv*, ERL_NIF_TERM);
+int enif_compare(ERL_NIF_TERM lhs, ERL_NIF_TERM rhs);
 int enif_inspect_binary(ErlNifEnv*, ERL_NIF_TERM, ErlNifBinary*);
 unsigned char* enif_make_new_binary(ErlNifEnv*, size_t, ERL_NIF_TERM*);
 ERL_NIF_TERM enif_make_atom(ErlNifEnv*, const char*);

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "missing export " + n
     assert sorted(eng.ABI_SYMBOLS) == names, "engine.ABI_SYMBOLS out of date with the header"
-    assert lib.eh_abi_version() == 6
+    assert lib.eh_abi_version() == 7
 
 
 def test_tables_mirror_the_reference():

@@ -88,7 +88,9 @@ def test_gunzip_of_otp_20_1_concatenated_members_and_trailing_bytes():
     import emu_zlib
     eng = ea.Engine(0)
     a, b = b"first member " * 40, bytes(range(256)) * 5
-    gz = lambda x, lvl=6: emu_zlib.want_compress(1, x) if lvl == 6 else zlib.compress(x, lvl, 31)
+    def gz(x, lvl=6):
+        c = zlib.compressobj(lvl, zlib.DEFLATED, 31, 8, zlib.Z_DEFAULT_STRATEGY)
+        return c.compress(x) + c.flush()
     cases = [(gz(a) + gz(b), a + b), (gz(a) + gz(b, 1) + gz(a, 9), a + b + a), (gz(a) + b"tail", None), (gz(a) + gz(b)[:-1], None), (gz(a) + b"\x1f\x8b", None),
              (gz(a) + gz(b)[:-8] + bytes(8), None), (gz(b""), b""), (gz(b"") + gz(b""), b""), (b"", None)]
     for blob, want in cases:
@@ -96,3 +98,101 @@ def test_gunzip_of_otp_20_1_concatenated_members_and_trailing_bytes():
         assert got == want and emu_zlib.want_gunzip(blob) == want, "gunzip of %d bytes: %r vs %r" % (len(blob), None if got is None else len(got), None if want is None else len(want))
     eng.close()
     assert emu_containers.run_cp(n=45) >= 135
+
+
+def test_rccl_called_from_inside_the_library_on_this_gpu():
+    """ABI 7 (include/erlamsa_hip.h "multi-GPU"): librccl.so loaded by the library, a communicator of ONE rank on this GPU, and the
+    three ways an arena reaches a context - eh_corpus_broadcast, eh_corpus_allgather, eh_corpus_broadcast_local - each giving the
+    results of eh_corpus_upload.  (One rank is all a one-GPU box has; the W-rank logic runs in tests/test_comm_abi.py on CPU ranks,
+    two real ranks in test_two_ranks_rccl_strong_scaling_equals_one_rank below.)"""
+    import hashlib
+    import erlamsa_amd as ea
+    from erlamsa_amd import synth
+    mat = synth.mixed(512, 1500, seed=21)
+    data, off = synth.as_arena(mat)
+
+    def digests(e):
+        e.fuzz_batch(seed=(2, 7, 1))
+        outs, st = e.download()
+        return [hashlib.sha1(x).digest() for x in outs], [int(x) for x in st]
+
+    ref = ea.Engine(0); ref.configure(max_case_bytes=4 << 20); ref.upload_corpus(data, off)
+    want = digests(ref)
+    uid = ea.Engine.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    e = ea.Engine(0); e.configure(max_case_bytes=4 << 20)
+    e.comm_init(uid, 0, 1)
+    e.corpus_broadcast(0, data, off)
+    assert e.n_corpus == 512 and digests(e) == want, "eh_corpus_broadcast: other results than eh_corpus_upload"
+    e.corpus_allgather(data, off)
+    assert e.n_corpus == 512 and digests(e) == want, "eh_corpus_allgather: other results than eh_corpus_upload"
+    e.comm_destroy()
+    ea.Engine.comm_init_local([e])
+    e.upload_corpus(data[:int(off[100])], off[:101])
+    ea.Engine.corpus_broadcast_local([e], 0)
+    assert e.n_corpus == 100
+    with pytest.raises(ea.EngineError):
+        ea.Engine.comm_init_local([e, ref])                     # two contexts of one device
+    with pytest.raises(ea.EngineError):
+        ref.corpus_broadcast(0, data, off)                      # no communicator
+    with pytest.raises(ea.EngineError) as ex:
+        ref.configure(sequence_muta=True)
+    assert ex.value.code == -6
+    e.close(); ref.close()
+
+
+TWO_RANK = r'''
+import hashlib, json, os, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+import erlamsa_amd as ea
+from erlamsa_amd import shard, synth
+rank, world, idfile, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+n = 4096
+e = ea.Engine(rank)
+e.configure(max_case_bytes=4 << 20, out_capacity=4 << 30)
+if rank == 0:
+    open(idfile + ".tmp", "wb").write(ea.Engine.comm_unique_id()); os.rename(idfile + ".tmp", idfile)
+while not os.path.exists(idfile):
+    time.sleep(0.01)
+e.comm_init(open(idfile, "rb").read(), rank, world)
+if rank == 0:
+    e.corpus_broadcast(0, *synth.as_arena(synth.mixed(n, 4096, seed=3)))
+else:
+    e.corpus_broadcast(0)
+first, cnt = shard.case_range(n, rank, world)
+e.fuzz_batch(seed=(1, 2, 3), first_case=first + 1, corpus_first=first, n=cnt)
+outs, st = e.download()
+json.dump({"first": first, "sha1": [hashlib.sha1(x).hexdigest() for x in outs], "status": [int(x) for x in st]}, open(out, "w"))
+'''
+
+
+def test_two_ranks_rccl_strong_scaling_equals_one_rank(tmp_path):
+    """Two OS processes, one GPU each, the arena RCCL-broadcast over xGMI from inside the library, ONE run of 4096 cases split by
+    shard.case_range: byte for byte the results of a 1-rank run.  Skipped on a box with one GPU."""
+    import hashlib
+    import subprocess
+    import erlamsa_amd as ea
+    import ctypes
+    n_dev = ctypes.c_int(0)
+    hip = ctypes.CDLL("libamdhip64.so")
+    if hip.hipGetDeviceCount(ctypes.byref(n_dev)) != 0 or n_dev.value < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % n_dev.value)
+    from erlamsa_amd import synth
+    script = tmp_path / "rank.py"
+    script.write_text(TWO_RANK % {"root": ROOT})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(tmp_path / "uid"), str(tmp_path / ("r%d.json" % r))], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
+    import json
+    res = [json.load(open(tmp_path / ("r%d.json" % r))) for r in range(2)]
+    e = ea.Engine(0); e.configure(max_case_bytes=4 << 20, out_capacity=4 << 30)
+    e.upload_corpus(*synth.as_arena(synth.mixed(4096, 4096, seed=3)))
+    e.fuzz_batch(seed=(1, 2, 3))
+    outs, st = e.download()
+    want = [hashlib.sha1(x).hexdigest() for x in outs]
+    for r in res:
+        assert r["sha1"] == want[r["first"]:r["first"] + len(r["sha1"])] and r["status"] == [int(x) for x in st[r["first"]:r["first"] + len(r["sha1"])]]
+    assert sum(len(r["sha1"]) for r in res) == 4096
