@@ -202,7 +202,7 @@ def test_sgml_tokenizer_replay_of_periodic_documents():
     sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
     import emu_sgml_replay
     total, bad = emu_sgml_replay.run(n=4, seed=5, scale=2, verbose=True)
-    assert total == 56 and bad == 0
+    assert total == 60 and bad == 0
     total, bad = emu_sgml_replay.run(n=2, seed=9, scale=12, pats="od", verbose=True)
     assert bad == 0
 
