@@ -22,7 +22,41 @@ constexpr int MAX_FS = 64;          // mux_fuzzers list entries (one per lane of
 constexpr int MAX_BLOCKS = 2048;    // block-list entries per case
 constexpr int MAX_EMITS = 4096;     // deferred output pieces per case
 constexpr int MAX_FRAMES = 16;      // nested sizer/csum wrappers
-constexpr uint32_t TRACE_CAP = 32768; // meta-trace events kept per case (EH_FLAG_META_TRACE); the last byte is 0xFF when events were dropped
+constexpr uint32_t TRACE_CAP = 32768; // meta-trace bytes kept per case (EH_FLAG_META_TRACE); the last byte is 0xFF when events were dropped
+
+// ---- meta trace (ABI 7): the reference's Meta list of a case, element by element, in the order erlamsa_main.erl:58-70 prints it
+// (lists:reverse(lists:flatten(Meta)), every element with ~p on a line of its own).  An event is a kind byte and its operands;
+// atoms are ids into the table below (the 41 mutator codes first, in MutaId order), integers are LEB128 varints (zigzag where
+// they can be negative).  eh_result_meta hands the bytes over as they are; eh_meta_atom_name names the atoms; the renderers are
+// erlamsa_amd/meta.py and erlang/src/erlamsa_hip.erl meta_terms/1.
+enum TraceKind : int {
+  TRK_AA = 1,       // {Atom, Atom}            [a][b]                         {failed, sgm} {pattern, once_dec} {compressed, gzip}
+  TRK_AI = 2,       // {Atom, Integer}         [a][zigzag varint]             {byte_drop, -1} {seq_repeat, 4096} {skipped_big, N}
+  TRK_SIZER = 3,    // {sizer, {ok, Size, big | little, Len, A, B}}  [Size/8][big][varint Len][varint A][varint B]   erlamsa_patterns.erl:97
+  TRK_CSUM = 4,     // {csum, {xor8 | crc32, Size, PLen, BLen}}      [crc][varint PLen][varint BLen]                  :131
+  TRK_SKIPPED = 5,  // {skipped, Len/8}        [varint bytes]                 the float of a whole number :154
+  TRK_ARCHIVER = 6, // {archiver, Name}        [varint n][n bytes]            the file name :183
+};
+#define EH_ATOMS(X)                                                                                                              \
+  X(sgm) X(js) X(uw) X(ui) X(ab) X(ad) X(tr2) X(td) X(num) X(ts1) X(tr) X(ts2) X(bd) X(bei) X(bed) X(bf) X(bi) X(ber) X(br) X(sp)  \
+  X(sr) X(sd) X(snand) X(srnd) X(ld) X(lds) X(lr2) X(lri) X(lr) X(ls) X(lp) X(lis) X(lrs) X(ft) X(fn) X(fo) X(len) X(b64) X(uri)  \
+  X(zip) X(nil)                                                                                                                   \
+  X(failed) X(used) X(pattern) X(skipped_big) X(once_dec) X(many_dec) X(burst) X(skipper) X(sizer) X(csum) X(archiver)            \
+  X(compressed) X(no_muta) X(mutate_once) X(empty_stopped) X(decompressed) X(gzip) X(zlib) X(ok) X(success) X(json)               \
+  X(base64_mutator) X(sed_utf8_widen) X(sed_utf8_insert) X(ascii_bad) X(ascii_delimeter) X(tree_dup) X(tree_del) X(muta_num)      \
+  X(tree_swap_one) X(tree_stutter) X(tree_swap_two) X(byte_drop) X(byte_inc) X(byte_dec) X(byte_flip) X(byte_insert)              \
+  X(byte_swap_random) X(byte_repeat) X(seq_perm) X(seq_repeat) X(seq_drop) X(seq_randmask) X(line_del) X(line_del_seq)            \
+  X(line_dup) X(line_clone) X(line_repeat) X(line_swap) X(line_perm) X(list_ins) X(list_replace) X(fuse_this) X(fuse_next)        \
+  X(fuse_old) X(muta_len) X(muta_zippath) X(nomutation) X(json_swap) X(json_dup) X(json_pump) X(json_repeat) X(json_insert)       \
+  X(json_unserialize) X(json_innertext) X(null) X(bool) X(sgml_swap) X(sgml_dup) X(sgml_pump) X(sgml_repeat) X(sgml_insert2)      \
+  X(sgml_permparams) X(sgml_breaktag) X(sgml_insert) X(sgml_xmlfeatures) X(xmlns) X(sgml_innertext)
+enum AtomId : int {
+#define EH_ATOM_ENUM(n) AT_##n,
+  EH_ATOMS(EH_ATOM_ENUM)
+#undef EH_ATOM_ENUM
+  AT_COUNT
+};
+static_assert((int)AT_nil == (int)M_NIL && (int)AT_sgm == (int)M_SGM && (int)AT_b64 == (int)M_B64, "the mutator codes are the first atoms, in MutaId order");
 constexpr int POOL_TIERS = 8;       // tiers of larger work areas a case can borrow from
 
 // erlamsa.hrl:44-58
@@ -102,7 +136,7 @@ struct KParams {
   uint64_t* cycles;           // per-case shader-clock ticks (diagnostic)
   uint64_t* peak;             // per-case work-memory high-water mark in bytes (diagnostic)
   uint64_t* trace_off;        // EH_FLAG_META_TRACE: where the case's trace sits in `out` ...
-  uint32_t* trace_len;        // ... and its length in events (one byte each, see TR_* in eh_device.h)
+  uint32_t* trace_len;        // ... and its length in bytes (TraceKind events, above)
   uint32_t flags;             // EH_FLAG_*
   unsigned long long* prof;   // EH_PROF builds: [2*k] cycles, [2*k+1] calls; k < 64 mutator fn, 64.. phases
   unsigned long long* ticket;

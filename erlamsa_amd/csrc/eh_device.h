@@ -284,7 +284,8 @@ struct Ctx {
   uint64_t ch_vstart[MAX_CHUNKS], ch_vend[MAX_CHUNKS]; uint8_t* ch_base[MAX_CHUNKS]; uint32_t ch_area[MAX_CHUNKS]; int32_t ch_tier[MAX_CHUNKS];
   uint64_t lex_ptr[LEX_LEVELS];   // block the lex cache of nesting level d holds a table for (mirror of LexCache::ptr; 0: none)
   uint8_t* trace;      // EH_FLAG_META_TRACE: the case's event bytes (slot memory), nullptr = off
-  uint32_t ntrace;
+  uint32_t ntrace, tr_base;   // bytes written; where the Meta list in hand begins (tr_drop_before)
+  int32_t m_aux;       // set by the mutators whose own Meta entry does not follow from their result alone (num: a number found; ab / ad: stringy)
   uint64_t ws_peak, ws_top;   // diagnostics: highest ws_used, bytes taken from the top of chunks (eh_result_peak)
   int status;
   int lastm;
@@ -347,15 +348,27 @@ enum { R_SAME = 0, R_NEW = 1 };
 #define EH_PT(c, k) do {} while (0)
 #endif
 
-// ---- meta trace (erlamsa_main.erl:58-70 prints the Meta list a case has built: erlamsa_patterns.erl puts {pattern, P} on it,
-// mux_fuzzers {used, Name} / {failed, Name}, erlamsa_mutations.erl:1269-1279).  One byte per event, in the order the reference
-// conses them: kind << 6 | id, id = index in the mutator / pattern table.
-enum { TR_FAILED = 0, TR_USED = 1, TR_PATTERN = 2, TR_SKIPPED_BIG = 3 };
-EH_DEV void trace_event(Ctx& c, uint32_t kind, uint32_t id) {
-  if (!c.trace) return;
-  if (c.ntrace < TRACE_CAP) { if (EH_LANE == 0) c.trace[c.ntrace] = (uint8_t)((kind << 6) | (id & 63u)); }
-  else if (EH_LANE == 0) c.trace[TRACE_CAP - 1] = 0xFF;
-  if (c.ntrace < TRACE_CAP) c.ntrace++;
+// ---- meta trace (erlamsa_main.erl:58-70 prints the Meta list a case has built).  Events (eh_common.h TraceKind) are appended in the
+// order the reference PRINTS the elements: lists:reverse(lists:flatten(Meta)) - the order in time for everything that is consed as
+// it happens, which is nearly everything; the few literal lists ([A, B | Meta]) are written back to front at their sites.
+// tr_base = where the Meta list in hand begins: Muta([Bin], []) (b64 / sgm / js inner runs, nested_fuzz) and
+// mutate_once_loop(Mutator, [], ..) (cp, ar) start lists of their own, and sgml_mutate / json_mutate return NewMeta ALONE when the
+// block comes back unchanged (erlamsa_sgml.erl:748-749, erlamsa_json.erl:722-723), which drops what the list in hand held before.
+EH_DEV void tr_b(Ctx& c, uint32_t v) {
+  if (c.ntrace < TRACE_CAP - 1) { if (EH_LANE == 0) c.trace[c.ntrace] = (uint8_t)v; c.ntrace++; }
+  else { if (EH_LANE == 0) c.trace[TRACE_CAP - 1] = 0xFF; c.ntrace = TRACE_CAP; }
+}
+EH_DEV void tr_v(Ctx& c, uint64_t v) { while (v >= 128) { tr_b(c, (uint32_t)(v & 127u) | 128u); v >>= 7; } tr_b(c, (uint32_t)v); }
+EH_DEV void tr_aa(Ctx& c, int a, int b) { if (!c.trace) return; tr_b(c, TRK_AA); tr_b(c, (uint32_t)a); tr_b(c, (uint32_t)b); }
+EH_DEV void tr_ai(Ctx& c, int a, int64_t v) { if (!c.trace) return; tr_b(c, TRK_AI); tr_b(c, (uint32_t)a); tr_v(c, ((uint64_t)v << 1) ^ (uint64_t)(v >> 63)); }
+// drops the events [tr_base, start) of the list in hand (see above); what came after start moves down
+EH_DEV void tr_drop_before(Ctx& c, uint32_t start) {
+  if (!c.trace || start <= c.tr_base || c.ntrace >= TRACE_CAP) return;
+  const uint32_t n = c.ntrace - start;
+  wave_sync();
+  if (n) wave_move_down(c.trace + c.tr_base, c.trace + start, n);
+  wave_sync();
+  c.ntrace = c.tr_base + n;
 }
 
 // ---- work-area pool (see KParams): lane 0 talks to the rings, the wave takes the result.  A popper owns ring entry
@@ -838,6 +851,40 @@ EH_DEV void commit_result(Ctx& c) {
   wave_sync();
 }
 
+// The Meta entry a mutator conses itself (erlamsa_mutations.erl:162-168 muta_num, :180 {Name, D}, :235/:248 {Name, -1 | BSize}, :360/:376
+// {Name, 1} when the block is lines, :390/:402/:421 fuse, :598 ascii when stringy, :922/:968/:1021 tree when it ran, :1089/:1099 utf8,
+// :1105, :1143, :1160-1162); b64 / uri / sgm / js write theirs where they happen.  oracle.cpp own_meta is the same table.
+struct alignas(16) OwnTab { uint8_t v[M_COUNT]; };
+constexpr OwnTab own_atoms() {
+  OwnTab t{};
+  const int a[M_COUNT] = {0, 0, AT_sed_utf8_widen, AT_sed_utf8_insert, AT_ascii_bad, AT_ascii_delimeter, AT_tree_dup, AT_tree_del, AT_muta_num, AT_tree_swap_one,
+                          AT_tree_stutter, AT_tree_swap_two, AT_byte_drop, AT_byte_inc, AT_byte_dec, AT_byte_flip, AT_byte_insert, AT_byte_swap_random, AT_byte_repeat,
+                          AT_seq_perm, AT_seq_repeat, AT_seq_drop, AT_seq_randmask, AT_seq_randmask, AT_line_del, AT_line_del_seq, AT_line_dup, AT_line_clone,
+                          AT_line_repeat, AT_line_swap, AT_line_perm, AT_list_ins, AT_list_replace, AT_fuse_this, AT_fuse_next, AT_fuse_old, AT_muta_len, 0, 0,
+                          AT_muta_zippath, AT_nomutation};
+  for (int i = 0; i < M_COUNT; i++) t.v[i] = (uint8_t)a[i];
+  return t;
+}
+__constant__ OwnTab c_own_atom = own_atoms();
+EH_DEV void own_meta(Ctx& c, uint32_t fn, int delta, uint32_t hlen) {
+  if (!c.trace) return;
+  const int nm = (int)c_own_atom.v[fn];
+  switch (fn) {
+    case M_BD: case M_BEI: case M_BED: case M_BF: case M_BI: case M_BER: case M_BR: case M_UW: case M_UI:
+    case M_FT: case M_FN: case M_FO: case M_LEN: case M_ZIP: case M_NIL:
+      tr_ai(c, nm, delta); break;
+    case M_SP: case M_SR: case M_SD: case M_SNAND: case M_SRND:
+      tr_ai(c, nm, hlen == 0 ? -1 : (int64_t)hlen); break;
+    case M_NUM: tr_ai(c, nm, c.m_aux); break;
+    case M_AB: case M_AD: if (c.m_aux == 1) tr_ai(c, nm, delta); break;
+    case M_LD: case M_LDS: case M_LR2: case M_LRI: case M_LR: case M_LS: case M_LP: case M_LIS: case M_LRS:
+    case M_TR2: case M_TD: case M_TS1: case M_TS2: case M_TR:
+      if (delta == 1) tr_ai(c, nm, 1);
+      break;
+    default: break;
+  }
+}
+
 // One call of the mux_fuzzers closure on the list bl[cur..nb).
 EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
   const int l = EH_LANE;
@@ -862,7 +909,7 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
   int tried = 0; bool used = false; bool dropped = false;
   Blk h0 = blk_load(c.bl, c.cur);
   for (int r = 0; r < nfs; r++) {
-    if (h0.len > ABSMAX_BINARY_BLOCK) { dropped = true; trace_event(c, TR_SKIPPED_BIG, 0); break; }   // :1269-1270
+    if (h0.len > ABSMAX_BINARY_BLOCK) { dropped = true; tr_ai(c, AT_skipped_big, (int64_t)h0.len); break; }   // [{skipped_big, byte_size(H)} | Meta] :1269-1270
     unsigned long long who = __ballot(l < nfs && rank == (uint32_t)r);
     int j = (int)__builtin_ctzll(who);
     uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)lt.e_meta, j);
@@ -885,6 +932,7 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
     if (stateful) { const uint32_t* ax = (const uint32_t*)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) g_st_save[i] = ax[i]; }
     int delta, last_tier = 0;
     for (;;) {
+      c.m_aux = -1;
       delta = run_mutator(c, fn, em_mask(meta));
       if (c.status != CASE_OVERFLOW || c.ovf_need == 0) break;
       wave_sync();
@@ -911,7 +959,8 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
       uint32_t hd_len = c.r_flush && c.r_len >= AVG_BLOCK_SIZE ? AVG_BLOCK_SIZE : c.r_len;
       changed = c.r_changed || hd_len != h0.len || !wave_equal(c.r_ptr, (const uint8_t*)h0.ptr, hd_len);
     }
-    trace_event(c, changed ? TR_USED : TR_FAILED, name);                           // {used, Name} / {failed, Name} :1278-1279
+    own_meta(c, fn, delta, h0.len);                                                // the mutator's own entry is in the Meta it returns, used or failed
+    tr_aa(c, changed ? AT_used : AT_failed, (int)name);                            // {used, Name} / {failed, Name} :1278-1279
     if (changed) {
       c.lastm = (int)name;
       // Reclaim work memory before committing: everything between `mark` and the candidate is a

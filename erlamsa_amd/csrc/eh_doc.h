@@ -215,6 +215,7 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
     wave_sync();
     EH_PT(c, 50);
     int d = rng_delta(c.rng);                                    // :666
+    tr_ai(c, AT_base64_mutator, d);                              // [AddedMeta, {base64_mutator, D} | MAcc] :674: D's entry, then what the nested run adds
     // mutators_mutator(MutasList, []) :667: rand(10) per table entry in table order, each prepended
     uint32_t name = l < (int)M_COUNT ? (uint32_t)((int)M_COUNT - 1 - l) : 0;
     uint32_t score = 0;

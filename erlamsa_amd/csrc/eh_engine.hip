@@ -82,11 +82,13 @@ __device__ __noinline__ int nested_fuzz(Ctx&, uint32_t e_pri, uint32_t e_meta, i
   blk_store(c.bl, nb0, (uint64_t)bin, len);
   wave_sync();
   c.cur = nb0; c.nb = nb0 + 1; c.nfs = nfs; c.depth++;
+  const uint32_t tr_base0 = c.tr_base; c.tr_base = c.ntrace;                // Muta([Bin], []): a Meta list of its own
   c.lex_ptr[c.depth] = 0;                                                  // this level's last lexed block was a temporary of an earlier call
   if (l == 0) lex_slot(c).n = -1;
   LaneTab lt; lt.e_pri = e_pri; lt.e_meta = e_meta;
   mux_fuzzers(c, lt);
   c.depth--;
+  c.tr_base = tr_base0;
   int nres = c.nb - c.cur;
   wave_sync();
   for (uint32_t i = l; i < SAVE / 4; i += 64) ax[i] = save[i];
@@ -300,7 +302,7 @@ EH_DEV uint8_t* gather_emits(Ctx& c, int from, uint64_t* len) {
   return blob;
 }
 
-struct CpSide { MutatorSave m; Blk orig; int32_t fmt, nrest, ip, contpat; };   // + Blk rest[nrest]
+struct CpSide { MutatorSave m; Blk orig; int32_t fmt, nrest, ip, contpat; uint32_t tr_base0, pad; };   // + Blk rest[nrest]
 // mutate_once_compressed/6 (erlamsa_patterns.erl:216-246) up to the inner evaluation: zlib:gunzip(Bin), on data_error
 // zlib:inflate(Bin).  1: bl[cur] is the decoded Data alone and a P_CP frame waits for the evaluation; 0: not compressed
 // ({Bin, Meta}); -1: the case stops (status set).
@@ -326,9 +328,14 @@ __device__ __noinline__ int cp_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, PatF
   CpSide* sd = (CpSide*)ws_alloc_grow(c, sizeof(CpSide) + (uint64_t)nrest * sizeof(Blk));
   if (!sd) return -1;
   mutator_save(c, &sd->m, e_pri, e_meta);
+  // {NewBin, [{compressed, gzip}, NewMeta, {decompressed, gzip} | Meta]} :223 (zlib :241): printed as decompressed, what the payload's
+  // evaluation adds (a Meta list of its own, from []), compressed
+  tr_aa(c, AT_decompressed, fmt == ZF_GZIP ? AT_gzip : AT_zlib);
+  const uint32_t tr_base0 = c.tr_base; c.tr_base = c.ntrace;
   Blk* rest = (Blk*)(sd + 1);
   for (int i = l; i < nrest; i += 64) rest[i] = c.bl[c.cur + 1 + i];
   if (l == 0) {
+    sd->tr_base0 = tr_base0;
     sd->orig = b; sd->fmt = fmt; sd->nrest = nrest; sd->ip = (int32_t)ip; sd->contpat = contpat;
     PatFrame& f = frames[nfr];
     f.kind = P_CP; f.em_field = c.nem; f.field = (uint8_t*)sd; f.size_bits = 0; f.big = 0; f.tail_ptr = 0; f.tail_len = 0; f.crc = 0;
@@ -351,6 +358,8 @@ __device__ __noinline__ uint64_t cp_end(Ctx&, uint32_t e_pri, uint32_t e_meta, i
   const int fmt = (int)uni((uint32_t)sd->fmt), nrest = (int)uni((uint32_t)sd->nrest);
   Blk orig; orig.ptr = uni64(sd->orig.ptr); orig.len = uni(sd->orig.len); orig.aux = 0;
   c.pat_ret = -1; c.pat_ip = uni((uint32_t)sd->ip); c.pat_cont = (int)uni((uint32_t)sd->contpat);
+  c.tr_base = uni(sd->tr_base0);
+  tr_aa(c, AT_compressed, fmt == ZF_GZIP ? AT_gzip : AT_zlib);
   uint64_t tot;
   const uint8_t* nd = gather_emits(c, em_field, &tot);
   if (tot > 0 && !nd) return keep;
@@ -375,7 +384,7 @@ __device__ __noinline__ uint64_t cp_end(Ctx&, uint32_t e_pri, uint32_t e_meta, i
   return mutator_restore(c, &sd->m, true);
 }
 
-struct ArSide { MutatorSave m; Blk archive; int32_t n, idx, ip, contpat; ZipEntry* es; };
+struct ArSide { MutatorSave m; Blk archive; int32_t n, idx, ip, contpat; ZipEntry* es; uint32_t tr_base0, pad; };
 // mutate_once_archiver/4 (erlamsa_patterns.erl:203-214): UnZip = zip:foldl(fun(N, I, B, Acc) -> [{N, B(), I()} | Acc] end, [], ..) over
 // bl[cur] (the whole list as one binary).  c.pat_ret 1: an archive - the side block (returned) holds its entries and the Mutator;
 // 0: {error, _}; -1: the case stops.
@@ -425,6 +434,14 @@ __device__ __noinline__ uint64_t ar_step(Ctx&, uint32_t e_pri, uint32_t e_meta, 
       if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 319); return keep; }
       blk_store(c.bl, c.cur, uni64(es[idx].data), uni(es[idx].data_len));
       c.nb = c.cur + 1;
+      if (c.trace) {                                                                    // [NM, {archiver, N} | Acc] :183: the name, then what the file's evaluation adds (a list of its own)
+        const uint8_t* nm = (const uint8_t*)uni64(es[idx].name); const uint32_t nl = uni(es[idx].name_len), up = uni(es[idx].up);
+        tr_b(c, TRK_ARCHIVER); tr_v(c, nl + 3u * up);
+        for (uint32_t k = 0; k < up; k++) { tr_b(c, '.'); tr_b(c, '.'); tr_b(c, '/'); }
+        for (uint32_t k = 0; k < nl; k++) tr_b(c, uni(nm[k]));
+      }
+      if (EH_LANE == 0) sd->tr_base0 = c.tr_base;
+      c.tr_base = c.ntrace;
       if (EH_LANE == 0) {
         sd->idx = idx;
         PatFrame& f = frames[nfr];
@@ -442,6 +459,7 @@ __device__ __noinline__ uint64_t ar_step(Ctx&, uint32_t e_pri, uint32_t e_meta, 
   if (rc == ZR_UNSUP) { c.status = CASE_UNSUPPORTED; return keep; }
   if (rc == ZR_OK) {
     blk_store(c.bl, c.cur, (uint64_t)out, (uint32_t)len); c.nb = c.cur + 1;
+    tr_aa(c, AT_archiver, AT_ok);                                                        // [{archiver, ok}, flatten(NewMeta) | Meta] :196
     wave_sync();
     c.pat_ret = 1;
     return keep;
@@ -460,6 +478,7 @@ __device__ __noinline__ uint64_t ar_file_done(Ctx&, int em_field, uint8_t* side)
   uint64_t tot;
   uint8_t* nb = gather_emits(c, em_field, &tot);
   c.pat_ret = -1;
+  c.tr_base = uni(sd->tr_base0);
   if (!nb) return 0;
   c.nem = em_field;
   if (EH_LANE == 0) { es[idx].data = (uint64_t)nb; es[idx].data_len = (uint32_t)tot; sd->idx = idx - 1; }
@@ -522,7 +541,11 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
     if (++guard > 1000000) { EH_SET_OVERFLOW(c, 305); break; }
     switch (act) {
       case A_RUN_PAT:
-        trace_event(c, TR_PATTERN, (uint32_t)pat);                                   // [{pattern, P} | Meta]
+        {                                                                             // [{pattern, once_dec | many_dec | burst} | Meta] :309,:326,:349; make_complex_pat's {pattern, Type} :356; nu: {pattern, no_muta} :390; co adds none
+          const int pa = pat == P_OD ? AT_once_dec : pat == P_ND ? AT_many_dec : pat == P_BU ? AT_burst : pat == P_SK ? AT_skipper : pat == P_SZ ? AT_sizer : pat == P_CS ? AT_csum :
+                         pat == P_AR ? AT_archiver : pat == P_CP ? AT_compressed : pat == P_NU ? AT_no_muta : -1;
+          if (pa >= 0) tr_aa(c, AT_pattern, pa);
+        }
         switch (pat) {
           case P_OD: cont = C_EMIT; act = A_MUTATE_ONCE; break;                       // :306-309
           case P_ND: cont = C_ND; act = A_MUTATE_ONCE; break;                         // :323-326
@@ -540,6 +563,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
             const uint8_t* H = (const uint8_t*)b.ptr;
             if (pat == P_SK) {                                                        // mutate_once_skipper :146-161
               uint32_t len = rng_rand(c.rng, b.len / 2);
+              if (c.trace) { tr_b(c, TRK_SKIPPED); tr_v(c, len); }                     // [{skipped, Len/8} | Meta] :154
               emit_ref(c, b.ptr, len);
               blk_store(c.bl, c.cur, b.ptr + len, b.len - len);
               wave_sync();
@@ -555,7 +579,9 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
                 }
               }
               if (r < 0) break;
+              if (r == 0) tr_aa(c, AT_sizer, AT_failed);                              // [{sizer, failed} | Meta] :85
               if (r == 1) {
+                if (c.trace) { tr_b(c, TRK_SIZER); tr_b(c, e.size_bits / 8); tr_b(c, e.big ? 1u : 0u); tr_v(c, e.len); tr_v(c, e.a); tr_v(c, e.b); }   // [{sizer, Elem} | Meta] :97
                 uint32_t nbytes = e.size_bits / 8;
                 if ((uint64_t)e.a + nbytes + e.len > b.len) { c.status = CASE_CRASHED; break; }
                 if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 306); break; }
@@ -576,7 +602,9 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               uint32_t iscrc, plen, blen;
               int r = pick_csum(c, H, b.len, &iscrc, &plen, &blen);
               if (r < 0) break;
+              if (r == 0) tr_aa(c, AT_csum, AT_failed);                               // :119
               if (r == 1) {
+                if (c.trace) { tr_b(c, TRK_CSUM); tr_b(c, iscrc); tr_v(c, plen); tr_v(c, blen); }   // [{csum, Elem} | Meta] :131
                 if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 307); break; }
                 emit_ref(c, b.ptr, plen);                                             // P
                 if (EH_LANE == 0) {
@@ -593,6 +621,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               if (c.pat_ret < 0) break;
               if (c.pat_ret == 2) { nfr++; act = A_LOOP; break; }                     // the rest of the chain on a payload: mutate_once_loop(Mutator, [], NextPat, Ip, Data, [])
               if (c.pat_ret == 1) { emit_all(c); act = A_TERMINAL; break; }           // [NewBin | {..}]
+              tr_aa(c, pat == P_CP ? AT_compressed : AT_archiver, AT_failed);         // [{compressed, failed} | Meta] :259 / [{archiver, failed} | Meta] :169
             }
             split_head(c);
             act = A_LOOP;
@@ -601,7 +630,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
         }
         break;
       case A_MUTATE_ONCE:                                                             // mutate_once/4 :265-278
-        if (!c.gen_pending && c.nb - c.cur == 1 && blk_load(c.bl, c.cur).len == 0) { c.cur = c.nb; act = A_TERMINAL; break; }   // (a fun does not match [<<>>])
+        if (!c.gen_pending && c.nb - c.cur == 1 && blk_load(c.bl, c.cur).len == 0) { tr_aa(c, AT_mutate_once, AT_empty_stopped); c.cur = c.nb; act = A_TERMINAL; break; }   // {Mutator, [{mutate_once, empty_stopped} | Meta]} :268-269 (a fun does not match [<<>>])
         ip = rng_rand(c.rng, INITIAL_IP);
         if (c.gen_pending) { gen_force(c); if (c.status != CASE_OK) break; }          // uncons(Ll, false) calls a fun Ll
         if (c.cur >= c.nb) { act = A_CONT; break; }                                   // Cont([], ...)
@@ -618,7 +647,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
         switch (cont) {
           case C_EMIT: emit_all(c); act = A_TERMINAL; break;
           case C_ND:                                                                  // pat_many_dec_cont :313-321
-            if (rng_occurs(c.rng, 4, 5)) { trace_event(c, TR_PATTERN, P_ND); act = A_MUTATE_ONCE; } else { emit_all(c); act = A_TERMINAL; }
+            if (rng_occurs(c.rng, 4, 5)) { tr_aa(c, AT_pattern, AT_many_dec); act = A_MUTATE_ONCE; } else { emit_all(c); act = A_TERMINAL; }
             break;
           case C_BU: {                                                                // pat_burst_cont :331-344
             int n = 1;
@@ -646,7 +675,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
           ip = c.pat_ip; cont = C_PAT; contpat = c.pat_cont;
           if (c.pat_ret == 2) { nfr++; act = A_LOOP; }                                // ar: the next file's evaluation
           else if (c.pat_ret == 1) emit_all(c);                                       // [NewBin | Rest] ++ [..]: no continuation
-          else act = A_LOOP;                                                          // unchanged / zip:create failed: mutate_once_loop(Mutator, .., NextPat, Ip, This, LlN)
+          else { tr_aa(c, f.kind == P_CP ? AT_compressed : AT_archiver, AT_failed); act = A_LOOP; }   // unchanged / zip:create failed: mutate_once_loop(Mutator, [{compressed | archiver, failed} | Meta], NextPat, Ip, This, LlN) - the Meta from before the pattern (mutator_restore)
         } else if (f.kind == P_SZ) {
           // NewLen = size(NewBlob) = everything written after the length field  (:105-110)
           uint64_t tot = 0; for (int k = f.em_field + 1; k < c.nem; k++) tot += blk_load(c.em, k).len;
@@ -828,7 +857,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     if (i >= p.n) break;
     uint64_t tick0 = __builtin_readcyclecounter();
     c.nchunk = 0; c.ws_peak = 0; c.ws_top = 0;
-    c.trace = (p.flags & EH_FLAG_META_TRACE) ? trace0 : nullptr; c.ntrace = 0;
+    c.trace = (p.flags & EH_FLAG_META_TRACE) ? trace0 : nullptr; c.ntrace = 0; c.tr_base = 0; c.m_aux = -1;
     c.ch_vstart[0] = 0; c.ch_vend[0] = p.work_cap; c.ch_base[0] = ws0; c.ch_tier[0] = 0; c.ch_area[0] = slot_id;
     ws_set_view(c, 0);
     for (int d = 0; d < LEX_LEVELS; d++) c.lex_ptr[d] = 0;
@@ -1328,6 +1357,15 @@ const char* eh_pattern_name(int id) { return id >= 0 && id < P_COUNT ? PATS[id].
 int eh_pattern_default_pri(int id) { return id >= 0 && id < P_COUNT ? PATS[id].pri : -1; }
 int eh_pattern_on_gpu(int id) { return id >= 0 && id < P_COUNT ? PATS[id].on_gpu : 0; }
 const char* eh_kernel_name(void) { return "eh_mutate_kernel"; }
+int eh_meta_atom_count(void) { return AT_COUNT; }
+const char* eh_meta_atom_name(int id) {
+  static const char* const names[AT_COUNT] = {
+#define EH_ATOM_NAME(n) #n,
+      EH_ATOMS(EH_ATOM_NAME)
+#undef EH_ATOM_NAME
+  };
+  return id >= 0 && id < AT_COUNT ? names[id] : nullptr;
+}
 
 const char* eh_strerror(int code) {
   switch (code) {

@@ -284,7 +284,7 @@ __device__ __noinline__ int muta_json(Ctx&) {
     if (p0 < L) {
       uint32_t c0 = uni(H[p0]);
       if (c0 != '[' && c0 != '{' && c0 != '"' && c0 != 't' && c0 != 'f' && c0 != 'n') {
-        if (c0 == ',' || c0 == ']' || c0 == '}' || c0 == ':') return -1;  // number/3 throws at once
+        if (c0 == ',' || c0 == ']' || c0 == '}' || c0 == ':') { tr_aa(c, AT_failed, AT_json); return -1; }  // number/3 throws at once: [{failed, json} | Meta] :730
         bool more = false;
         for (uint32_t base = p0; base < L && !more; base += 64) {         // end of the number, then anything but blanks?
           uint32_t i = base + (uint32_t)l; uint32_t ch = i < L ? H[i] : 0u;
@@ -294,14 +294,14 @@ __device__ __noinline__ int muta_json(Ctx&) {
           unsigned long long nb = __ballot(i < L && i >= q0 && !blank);
           if (q0 != L && nb) more = true;
         }
-        if (more) return -1;
+        if (more) { tr_aa(c, AT_failed, AT_json); return -1; }
       }
     }
   }
   uint64_t mark0 = c.ws_used;
   int rc = json_tokenize(c, H, L, dh, false);                              // verdict first, tables only for real documents
   if (rc == 0 && uni(dh->have_top)) { c.ws_used = mark0; rc = json_tokenize(c, H, L, dh, true); }
-  if (rc == -1) return -1;                                                 // catch incorrect_json :729-730
+  if (rc == -1) { tr_aa(c, AT_failed, AT_json); return -1; }               // catch incorrect_json -> [{failed, json} | Meta] :729-730
   if (rc == -2) { c.status = CASE_CRASHED; return 0; }
   if (rc != 0) return 0;
   JNode* nd = (JNode*)uni64((uint64_t)dh->nd); Piece* pc = (Piece*)uni64((uint64_t)dh->pc);
@@ -325,10 +325,15 @@ __device__ __noinline__ int muta_json(Ctx&) {
   int D = 1;
   uint32_t r;
   bool failed = false;
+  const uint32_t meta0 = c.ntrace;                                         // NewMeta = what json_mutation/2 adds from here on
   if (NT == 0 && N < 2) {                                                  // json_mutation/2 :646-650
     uint32_t e7 = rng_erand(c.rng, 7);
-    if (e7 == 4 && N == 1) r = rng_rand(c.rng, 8); else { failed = true; r = 99; D = -1; }
+    if (e7 == 4 && N == 1) r = rng_rand(c.rng, 8); else { failed = true; r = 99; D = -1; tr_aa(c, AT_failed, AT_json); }   // {[{failed, json}], Ast, -1}
   } else r = rng_rand(c.rng, 21);
+  if (!failed) {                                                           // {[{json_swap, 1}], Res, 1} ... :655-670; the inner-text walk: [Meta, {json_innertext, 1}] :706
+    const int ja = r == 0 ? AT_json_swap : r == 1 ? AT_json_dup : r == 2 ? AT_json_pump : r == 3 ? AT_json_repeat : r == 4 ? AT_json_insert : r == 5 ? AT_json_unserialize : AT_json_innertext;
+    tr_ai(c, ja, 1);
+  }
   if (failed) all(0, npc);
   else switch (r) {
     case 0: {                                                              // json_swap :581-594
@@ -446,7 +451,9 @@ __device__ __noinline__ int muta_json(Ctx&) {
             for (int q = 0; q < 7; q++) if ((uint32_t)q == k) { lit_k = lk[q]; lit_l = ll[q]; }
             wave_sync();
             if (l == 0) { out[p0].ptr = (uint64_t)jslit(lit_k); out[p0].len = lit_l; }
+            tr_ai(c, AT_json_innertext, 1); tr_aa(c, AT_json_innertext, AT_null);      // [{json_innertext, null}, {json_innertext, 1} | InnerMeta] :686
           } else {                                                         // basic_type_mutation(Boolean, ..) :1212-1219
+            tr_ai(c, AT_json_innertext, 1); tr_aa(c, AT_json_innertext, AT_bool);      // :691
             wave_sync();
             if (l == 0) { out[p0].ptr = (uint64_t)jslit(a == 0 ? JL_FALSE : JL_TRUE); out[p0].len = a == 0 ? 5u : 4u; }
           }
@@ -478,6 +485,7 @@ __device__ __noinline__ int muta_json(Ctx&) {
             }
           }
           if (uni((uint32_t)__shfl((int)same, 0))) continue;
+          tr_ai(c, AT_json_innertext, 1); tr_aa(c, AT_json_innertext, AT_num);         // :698
           wave_sync();
           if (l == 0) { out[p0].ptr = (uint64_t)txt; out[p0].len = tlen; }
         }
@@ -499,7 +507,7 @@ __device__ __noinline__ int muta_json(Ctx&) {
     wave_gather(dst, out, nout);
     wave_sync();
   }
-  if ((uint32_t)total == L && wave_equal(dst, H, L)) return -1;            // NewBinStr =:= H :722-723
+  if ((uint32_t)total == L && wave_equal(dst, H, L)) { tr_drop_before(c, meta0); return -1; }   // NewBinStr =:= H: {fun json_mutate/2, Ll, NewMeta, -1} :722-723 - NewMeta ALONE
   c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)total; c.r_changed = 1;
   return D + (int)(total / (AVG_BLOCK_SIZE * 10));
 }

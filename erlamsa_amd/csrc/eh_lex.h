@@ -300,7 +300,9 @@ __device__ __noinline__ int muta_ascii(Ctx&, LexCache& lc, int fn) {
   // stringy/1 :438-442
   uint32_t nontext = 0;
   for (int i = EH_LANE; i < n; i += 64) if (tab[i].type != 1) nontext = 1;
-  if (__ballot(nontext != 0) == 0) return -1;
+  c.m_aux = 0;
+  if (__ballot(nontext != 0) == 0) return -1;                     // {Ascii_mutator, Ll, Meta, -1} :600-601
+  c.m_aux = 1;                                                    // [{Name, D} | Meta] :598
   // R > L/4 -> give up  (R starts at 0; compares R > n/4 as floats)
   for (uint32_t r = 0; !((double)r > (double)n / 4.0); r++) {
     uint32_t P = rng_erand(c.rng, (uint32_t)n);
@@ -533,6 +535,7 @@ __device__ __noinline__ int muta_uri(Ctx&, LexCache& lc) {
     }
     out = uni((uint32_t)__shfl((int)newout, 0));
     dacc += 1;
+    tr_aa(c, AT_uri, AT_success);                                 // [NewMeta | MAcc] :778: {uri, success} (a chunk without "://" adds [])
     wave_sync();
   }
   if (crashed) { c.status = CASE_CRASHED; return 0; }

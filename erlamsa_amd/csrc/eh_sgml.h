@@ -1198,7 +1198,12 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
   auto all = [&](uint32_t a, uint32_t b) { pieces_append(out, &nout, pc, a, b); };
   auto elem = [&](uint32_t R) -> SgRange { return sg_range_of(tok, sg_find(ef, ntok, 1, R - 1)); };   // select_elem/2 :435-443
   int D = 1;
+  const uint32_t meta0 = c.ntrace;                                         // NewMeta = what sgml_mutation/2 adds from here on
   uint32_t r = rng_rand(c.rng, 12);                                        // sgml_mutation/2 :696-698
+  if (r < 8) {                                                             // {[{sgml_swap, 1}], Res, 1} ... :700-723
+    const int sa = r == 0 ? AT_sgml_swap : r == 1 ? AT_sgml_dup : r == 2 ? AT_sgml_pump : r == 3 ? AT_sgml_repeat : r == 4 ? AT_sgml_insert2 : r == 5 ? AT_sgml_permparams : r == 6 ? AT_sgml_breaktag : AT_sgml_insert;
+    tr_ai(c, sa, 1);
+  } else if (r > 8) tr_ai(c, AT_sgml_innertext, 1);                        // {[Meta, {sgml_innertext, 1}], Res, 1} :737: in front of what the walk adds
   switch (r) {
     case 0: {                                                              // sgml_swap :530-543
       uint32_t R1 = rng_erand(c.rng, N), R2 = rng_erand(c.rng, N);
@@ -1324,7 +1329,8 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
       break;
     }
     case 8: {                                                              // sgml_xmlfeatures(Ast, NT, 1) :651-665
-      if (NT == 0) { D = -1; all(0, npc); break; }
+      if (NT == 0) { D = -1; all(0, npc); tr_ai(c, AT_sgml_xmlfeatures, -1); break; }   // sgml_xmlfeatures(Ast, _NT, _) :664-665
+      bool xm_changed = false;
       all(0, npc);
       wave_sync();
       const DevConfig& cfg = c.p->cfg;
@@ -1343,6 +1349,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
         uint32_t os = (uint32_t)uni((uint32_t)ct.match);
         uint32_t T = sg_count(ef, 0, os, 2);
         if (rng_erand(c.rng, (uint32_t)((double)T * 1.5)) != 1) continue;  // xmlns_modify/2 :618-625
+        xm_changed = true;                                                 // (a tag that is picked always comes out different)
         SgTok ot = tok[os];
         uint32_t p0 = uni(ot.p0), pa0 = uni(ot.par0), npa = uni(ot.npar);
         bool any = false;
@@ -1385,6 +1392,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
           if (l == 0) { out[p0 + 2].ptr = (uint64_t)b; out[p0 + 2].len = bl; }
         }
       }
+      tr_aa(c, AT_sgml_xmlfeatures, xm_changed ? AT_xmlns : AT_failed);     // Ast =:= NewAst -> failed :661-662
       wave_sync();
       break;
     }
@@ -1451,7 +1459,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
   wave_gather(dst, out, nout);
   wave_sync();
   EH_PT(c, 93);
-  if ((uint32_t)total == L && wave_equal(dst, H, L)) return -1;            // NewBinStr =:= H :748-749
+  if ((uint32_t)total == L && wave_equal(dst, H, L)) { tr_drop_before(c, meta0); return -1; }   // NewBinStr =:= H: {fun sgml_mutate/2, Ll, NewMeta, -1} :748-749 - NewMeta ALONE
   c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)total; c.r_changed = 1;
   return D + (int)(total / (AVG_BLOCK_SIZE * 10));
 }

@@ -629,6 +629,7 @@ __device__ __noinline__ int muta_num(Ctx&) {
   c.r_kind = R_SAME;
   // mutate_a_num/2: numbers = maximal digit runs, each extended left over the dashes before it
   uint32_t nfound = wave_count(H, L, IsDigitStart());
+  c.m_aux = nfound == 0 ? 0 : 1;                              // [{muta_num, 0 | 1} | Meta] :162-168
   uint32_t which = rng_rand(c.rng, nfound);
   if (nfound == 0) {
     // nothing to change; the data still goes through flush_bvecs (re-chunking counts as a change

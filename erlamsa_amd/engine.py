@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "eh_coalesce_limits", "eh_submit", "eh_flush", "eh_poll", "eh_cancel",
     "eh_corpus_device", "eh_stream", "eh_host_alloc", "eh_host_free", "eh_selftest_sort_by_priority", "eh_last_error_copy",
     "eh_comm_unique_id", "eh_comm_init", "eh_comm_init_local", "eh_comm_destroy", "eh_corpus_broadcast", "eh_corpus_allgather",
-    "eh_corpus_broadcast_local", "eh_device_count",
+    "eh_corpus_broadcast_local", "eh_device_count", "eh_meta_atom_count", "eh_meta_atom_name",
 ]
 
 
@@ -97,6 +97,8 @@ def load_library():
     lib.eh_coalesce_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
     lib.eh_submit.argtypes = [vp, vp, C.c_uint64, i64p, u64p]
     lib.eh_flush.argtypes = [vp]
+    lib.eh_meta_atom_name.restype = C.c_char_p
+    lib.eh_meta_atom_name.argtypes = [C.c_int]
     lib.eh_comm_unique_id.argtypes = [vp]
     lib.eh_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.eh_comm_init_local.argtypes = [vp, C.c_int]
@@ -389,26 +391,29 @@ class Engine:
         self._chk(self.lib.eh_result_write_files(self.h, template.encode(), first_number, threads, C.byref(f), C.byref(b), C.byref(s)))
         return f.value, b.value, s.value
 
-    def meta(self, i):
-        """Meta trace of case i (configure with flags=EH_FLAG_META_TRACE): list of (kind, name), kind in 'failed', 'used',
-        'pattern', 'skipped_big', in the order the reference makes the entries."""
+    def meta_raw(self, i):
+        """event bytes of case i's meta trace (eh_result_meta; configure with flags=EH_FLAG_META_TRACE)"""
         buf = (C.c_uint8 * 32768)()
         n = C.c_uint64()
         self._chk(self.lib.eh_result_meta(self.h, i, buf, 32768, C.byref(n)))
-        mn = [self.lib.eh_mutator_name(k).decode() for k in range(self.lib.eh_mutator_count())]
-        pn = [self.lib.eh_pattern_name(k).decode() for k in range(self.lib.eh_pattern_count())]
-        out = []
-        for v in bytes(buf[:n.value]):
-            kind, idx = v >> 6, v & 63
-            if v == 0xFF:
-                out.append(("truncated", ""))
-            elif kind == 2:
-                out.append(("pattern", pn[idx]))
-            elif kind == 3:
-                out.append(("skipped_big", ""))
-            else:
-                out.append((("failed", "used")[kind], mn[idx]))
-        return out
+        return bytes(buf[:min(n.value, 32768)])
+
+    def meta_atoms(self):
+        return [self.lib.eh_meta_atom_name(k).decode() for k in range(self.lib.eh_meta_atom_count())]
+
+    def meta_terms(self, i):
+        """-> (terms, truncated): the reference's Meta list of case i, element by element, in the order erlamsa_main.erl:58-70 prints it
+        (erlamsa_amd/meta.py: render / lines give the ~p text)"""
+        from . import meta as _meta
+        return _meta.decode(self.meta_raw(i), self.meta_atoms())
+
+    def meta(self, i):
+        """The short form: list of (kind, name), kind in 'failed', 'used', 'pattern', 'skipped_big' (mutator / pattern codes), in the
+        order the reference makes the entries."""
+        from . import meta as _meta
+        terms, cut = self.meta_terms(i)
+        out = _meta.legacy(terms, [self.lib.eh_mutator_name(k).decode() for k in range(self.lib.eh_mutator_count())])
+        return out + ([("truncated", "")] if cut else [])
 
     def peak(self):
         """Per-case high-water mark of work memory (bytes)."""

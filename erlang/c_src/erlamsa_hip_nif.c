@@ -31,7 +31,7 @@ typedef struct {
   int has_muts, has_pats, has_gens, has_host, port;
   double blockscale;
   uint64_t max_case_bytes, big_case_bytes, max_case_work;
-  int sequence_muta;
+  int sequence_muta, meta;
 } opt_key;
 
 static ErlNifResourceType* ctx_type;
@@ -104,6 +104,7 @@ static int read_opts(ErlNifEnv* env, ERL_NIF_TERM map, opt_key* k) {
   if (get_u64(env, map, "max_case_work", &k->max_case_work) < 0) return 0;
   /* erlamsa_main.erl:223-235: the engine refuses it (EH_E_UNSUPPORTED) and the caller stays on the BEAM path */
   if (enif_get_map_value(env, map, enif_make_atom(env, "sequence_muta"), &v)) k->sequence_muta = enif_compare(v, enif_make_atom(env, "true")) == 0;
+  if (enif_get_map_value(env, map, enif_make_atom(env, "meta"), &v)) k->meta = enif_compare(v, enif_make_atom(env, "true")) == 0;   /* -M: keep every case's Meta list */
   return 1;
 }
 
@@ -117,6 +118,7 @@ static int configure_if_changed(ctx_res* r, const opt_key* k) {
   o.ssrf_port = k->port; o.blockscale = k->blockscale;
   o.max_case_bytes = k->max_case_bytes; o.big_case_bytes = k->big_case_bytes; o.max_case_work = k->max_case_work;
   o.sequence_muta = (uint32_t)k->sequence_muta;
+  o.flags = k->meta ? EH_FLAG_META_TRACE : 0;
   int rc = eh_configure(r->ctx, &o);
   r->configured = rc == EH_OK;
   if (rc == EH_OK) r->key = *k;
@@ -370,8 +372,34 @@ done:
   return ret;
 }
 
+/* meta_nif(Ctx, I) -> {ok, <<EventBytes>>}: the meta trace of case I of the context's last batch (eh_result_meta; the options must
+ * carry meta => true, i.e. EH_FLAG_META_TRACE).  erlamsa_hip:meta_terms/1 decodes the bytes into the reference's own terms.
+ * meta_atoms_nif() -> [atom()]: the atom table the ids in the bytes refer to (eh_meta_atom_name). */
+static ERL_NIF_TERM nif_meta(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res* r; ErlNifUInt64 i; (void)argc;
+  if (!enif_get_resource(env, argv[0], ctx_type, (void**)&r) || !enif_get_uint64(env, argv[1], &i)) return enif_make_badarg(env);
+  ERL_NIF_TERM bin; uint64_t n = 0;
+  static uint8_t dummy;
+  enif_mutex_lock(r->lock);
+  int rc = eh_result_meta(r->ctx, i, &dummy, 0, &n);
+  unsigned char* p = rc ? NULL : enif_make_new_binary(env, (size_t)n, &bin);
+  if (!rc && !p) rc = EH_E_NOMEM;
+  if (!rc) rc = eh_result_meta(r->ctx, i, p, n, &n);
+  ERL_NIF_TERM ret = rc ? mk_error(env, r->ctx, rc) : enif_make_tuple2(env, enif_make_atom(env, "ok"), bin);
+  enif_mutex_unlock(r->lock);
+  return ret;
+}
+static ERL_NIF_TERM nif_meta_atoms(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  (void)argc; (void)argv;
+  ERL_NIF_TERM l = enif_make_list(env, 0);
+  for (int k = eh_meta_atom_count(); k-- > 0;) l = enif_make_list_cell(env, enif_make_atom(env, eh_meta_atom_name(k)), l);
+  return l;
+}
+
 static ErlNifFunc funcs[] = {
   {"open", 1, nif_open, 0},
+  {"meta_nif", 2, nif_meta, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"meta_atoms_nif", 0, nif_meta_atoms, 0},
   {"fuzz_batch_nif", 5, nif_fuzz_batch, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"fuzz_calls_nif", 4, nif_fuzz_calls, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"submit_nif", 4, nif_submit, ERL_NIF_DIRTY_JOB_IO_BOUND},

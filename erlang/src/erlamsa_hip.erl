@@ -17,6 +17,7 @@
 -export([init/0, open/1, fuzz_batch/2, fuzz_calls/2, fuzz_batch_nif/5, fuzz_calls_nif/4, capabilities/0, fuzzer/3]).
 -export([submit/3, flush/1, poll/2, submit_nif/4, flush_nif/1, poll_nif/2]).
 -export([write_files/3, write_files_nif/3]).
+-export([meta_terms/1, meta_terms/3, meta_print/2, meta_nif/2, meta_atoms_nif/0]).
 -export([fuzz_batch_multi/2, open_all/0, device_count/0, load_corpus_nif/2, fuzz_range_nif/6, comm_init_local_nif/1, broadcast_local_nif/2,
          comm_unique_id_nif/0, comm_init_nif/4, corpus_broadcast_nif/3, case_range/3, join_ranks/3]).
 -on_load(init/0).
@@ -32,6 +33,8 @@ submit_nif(_Ctx, _Opts, _Seed, _Bin) -> erlang:nif_error(nif_not_loaded).
 flush_nif(_Ctx) -> erlang:nif_error(nif_not_loaded).
 poll_nif(_Ctx, _Ticket) -> erlang:nif_error(nif_not_loaded).
 write_files_nif(_Ctx, _Template, _FirstN) -> erlang:nif_error(nif_not_loaded).
+meta_nif(_Ctx, _I) -> erlang:nif_error(nif_not_loaded).
+meta_atoms_nif() -> erlang:nif_error(nif_not_loaded).
 device_count() -> erlang:nif_error(nif_not_loaded).
 load_corpus_nif(_Ctx, _Bins) -> erlang:nif_error(nif_not_loaded).
 fuzz_range_nif(_Ctx, _Opts, _Seed, _FirstCase, _CorpusFirst, _N) -> erlang:nif_error(nif_not_loaded).
@@ -45,6 +48,44 @@ corpus_broadcast_nif(_Ctx, _Root, _BinsOrNone) -> erlang:nif_error(nif_not_loade
 fuzz_batch(Bins, Dict) ->
     Seed = maps:get(seed, Dict, erlamsa_rnd:gen_urandom_seed()),
     split(fuzz_batch_nif(ctx(Dict), opts(Dict), Seed, maps:get(first_case, Dict, 1), Bins)).
+
+%% ---- the meta trace (-M, erlamsa_main.erl:58-70) ---------------------------------------------------------------------
+%% With #{meta => true} in Dict the engine keeps every case's Meta list (EH_FLAG_META_TRACE).  meta_nif(Ctx, I) hands over case I's
+%% event bytes (0-based index into the last batch), meta_terms/1 turns them into the reference's OWN terms in the order its meta
+%% logger prints them - [{pattern,once_dec},{byte_drop,-1},{used,bd}] ... - and meta_terms/3 adds what the host side of fuzzer/1
+%% conses around Pat(Ll, Muta, Meta): {nth, I}, the generator's entry, the output's, {written, N}.  meta_print/2 is the logger:
+%% every element with ~p on a line of its own, exactly the text erlamsa -M writes.
+meta_terms(Bytes) -> meta_decode(Bytes, list_to_tuple(meta_atoms()), []).
+meta_terms(Bytes, {Nth, GenMeta, OutMeta}, Written) ->
+    %% [{nth, I}, GenMeta] ++ the output's entry (erlamsa_main.erl:185-186) in front, {written, N} (:195) behind; GenMeta may be a
+    %% list ([{generator, file}, {source, path}], erlamsa_gen.erl:115): lists:flatten keeps its order, the final reverse turns it round
+    [{nth, Nth}] ++ lists:reverse(lists:flatten([GenMeta])) ++ [OutMeta] ++ meta_terms(Bytes) ++ [{written, Written}].
+meta_print(Verb, Terms) -> lists:foreach(fun(X) -> Verb(io_lib:format("~p~n", [X])) end, Terms).
+
+meta_atoms() ->
+    case persistent_term:get(erlamsa_hip_meta_atoms, undefined) of
+        undefined -> A = meta_atoms_nif(), persistent_term:put(erlamsa_hip_meta_atoms, A), A;
+        A -> A
+    end.
+%% events: include/erlamsa_hip.h eh_result_meta (csrc/eh_common.h TraceKind)
+meta_decode(<<>>, _At, Acc) -> lists:reverse(Acc);
+meta_decode(<<16#FF>>, _At, Acc) -> lists:reverse([{meta, truncated} | Acc]);
+meta_decode(<<1, A, B, R/binary>>, At, Acc) -> meta_decode(R, At, [{element(A + 1, At), element(B + 1, At)} | Acc]);
+meta_decode(<<2, A, R0/binary>>, At, Acc) -> {Z, R} = varint(R0), meta_decode(R, At, [{element(A + 1, At), (Z bsr 1) bxor -(Z band 1)} | Acc]);
+meta_decode(<<3, S8, Big, R0/binary>>, At, Acc) ->
+    {Len, R1} = varint(R0), {A, R2} = varint(R1), {B, R} = varint(R2),
+    Endian = case Big of 1 -> big; 0 -> little end,
+    meta_decode(R, At, [{sizer, {ok, S8 * 8, Endian, Len, A, B}} | Acc]);
+meta_decode(<<4, Crc, R0/binary>>, At, Acc) ->
+    {PLen, R1} = varint(R0), {BLen, R} = varint(R1),
+    E = case Crc of 1 -> {crc32, 32, PLen, BLen}; 0 -> {xor8, 8, PLen, BLen} end,
+    meta_decode(R, At, [{csum, E} | Acc]);
+meta_decode(<<5, R0/binary>>, At, Acc) -> {N, R} = varint(R0), meta_decode(R, At, [{skipped, N * 8 / 8} | Acc]);   %% Len/8, Len in bits (erlamsa_patterns.erl:152-154)
+meta_decode(<<6, R0/binary>>, At, Acc) -> {N, R1} = varint(R0), <<Name:N/binary, R/binary>> = R1, meta_decode(R, At, [{archiver, binary_to_list(Name)} | Acc]);
+meta_decode(_Cut, _At, Acc) -> lists:reverse([{meta, truncated} | Acc]).     %% the engine keeps 32 KiB per case: an event cut by that limit
+varint(B) -> varint(B, 0, 0).
+varint(<<1:1, V:7, R/binary>>, S, Acc) -> varint(R, S + 7, Acc bor (V bsl S));
+varint(<<0:1, V:7, R/binary>>, S, Acc) -> {Acc bor (V bsl S), R}.
 
 %% ---- several GPUs -------------------------------------------------------------------------------------------------------
 %% One BEAM node, every GPU of the machine: the arena is uploaded to the first device, RCCL-broadcast to the others from inside
@@ -160,7 +201,7 @@ opts(Dict) ->
            end,
     %% sequence_muta (--consequtive-mutators, erlamsa_main.erl:223-235) goes along as it is: the engine refuses it
     %% ({error, "sequence_muta ..."}) and the caller's fall-back to erlamsa_main:fuzzer/1 takes the run
-    maps:merge(maps:merge(Base, Gens), maps:with([max_case_bytes, big_case_bytes, max_case_work, sequence_muta], Dict)).
+    maps:merge(maps:merge(Base, Gens), maps:with([max_case_bytes, big_case_bytes, max_case_work, sequence_muta, meta], Dict)).
 
 split({error, Why}) -> {error, Why};                             %% caller falls back to erlamsa_main:fuzzer/1
 split({ok, Res}) ->

@@ -251,12 +251,23 @@ int eh_result_cycles(eh_ctx* ctx, uint64_t* cycles);
 int eh_result_write_files(eh_ctx* ctx, const char* name_template, uint64_t first_number, uint32_t threads,
                           uint64_t* files_written, uint64_t* bytes_written, uint64_t* not_written);
 
-/* Meta trace of case i of the last batch (EH_FLAG_META_TRACE): what erlamsa's -M / meta logger prints for a case
- * (erlamsa_main.erl:58-70) — the list erlamsa_patterns.erl and mux_fuzzers (erlamsa_mutations.erl:1269-1279) build:
- * {pattern, P}, {used, Name}, {failed, Name}, nested scheduler calls included — in the order the entries are made (the
- * reference's list is the reverse: it conses).  One byte per event: kind << 6 | id, kind 0 failed, 1 used, 2 pattern,
- * 3 the mutator dropped because the block is larger than ABSMAX_BINARY_BLOCK (:1269-1270); id = index of eh_mutator_name /
- * eh_pattern_name.  At most 32768 events per case are kept; the last byte is 0xFF when events were dropped. */
+/* Meta trace of case i of the last batch (EH_FLAG_META_TRACE): the reference's Meta list of the case IN FULL - what erlamsa's -M /
+ * meta logger prints (erlamsa_main.erl:58-70: lists:reverse(lists:flatten(Meta)), every element with ~p on a line of its own),
+ * for the part of the list the batch path builds (from Pat(Ll, Muta, Meta) down; {nth, I}, the generator's, the output's and
+ * {written, N} are the host's: erlang/src/erlamsa_hip.erl meta_terms/3 adds them): {pattern, once_dec | many_dec | burst |
+ * skipper | sizer | csum | archiver | compressed | no_muta}, {sizer, Elem}, {csum, Elem}, {skipped, F}, {archiver, _},
+ * {decompressed | compressed, _}, {mutate_once, empty_stopped}, every mutator's own entry ({byte_drop, D}, {seq_repeat, BSize},
+ * {muta_num, 0 | 1}, {line_del, 1}, {fuse_this, D}, {tree_dup, 1}, {ascii_bad, D}, {muta_len, D}, {base64_mutator, D},
+ * {uri, success}, {sgml_swap, 1} .. {sgml_innertext, 1}, {json_swap, 1} .. {json_innertext, _}, {failed, json} ...), {used, Name},
+ * {failed, Name}, {skipped_big, Size} - nested scheduler calls included, in the order the reference prints them, with its quirk
+ * that sgml_mutate / json_mutate drop the list when the block comes back unchanged (erlamsa_sgml.erl:748-749).
+ * Encoding (csrc/eh_common.h TraceKind): a kind byte and its operands - 1 {Atom, Atom}: two atom ids; 2 {Atom, Int}: atom id,
+ * zigzag LEB128; 3 sizer: Size/8, big, then LEB128 Len, A, B; 4 csum: crc32?, LEB128 PLen, BLen; 5 skipped: LEB128 bytes (printed
+ * as a float); 6 {archiver, Name}: LEB128 n, n bytes.  Atom ids: eh_meta_atom_name (the mutator codes come first, in table order).
+ * *n_events = BYTES of the trace (copied up to cap).  At most 32768 bytes per case are kept; the last byte is 0xFF when events
+ * were dropped.  Renderers to ~p text: erlamsa_amd/meta.py, erlang/src/erlamsa_hip.erl. */
+int eh_meta_atom_count(void);
+const char* eh_meta_atom_name(int id);
 int eh_result_meta(eh_ctx* ctx, uint64_t i, uint8_t* buf, uint64_t cap, uint64_t* n_events);
 
 /* Per-case high-water mark of work memory in bytes (diagnostic; what sizes max_case_bytes and the pool's tiers). */

@@ -242,6 +242,20 @@ struct Ctx {
   const Config* cfg;
   std::vector<Muta> fs;  // the mux_fuzzers list, in list order
   std::string* trace = nullptr;
+  // The reference's Meta list in full (erlamsa_main.erl:58-70 prints it with ~p, one element per line): every line below is one
+  // element as io_lib:format("~p", [X]) writes it, in the order lists:reverse(lists:flatten(Meta)) gives them.  Elements are
+  // consed in time order nearly everywhere, so they are appended as they happen; the few literal lists ([A, B | Meta]) are
+  // appended back to front at their sites.
+  std::string* meta = nullptr;
+  size_t meta_base = 0;  // where the Meta list in hand begins: a nested run (Muta([Bin], []), mutate_once_loop(Mutator, [], ..)) starts a list of its own
+  size_t meta_size() const { return meta ? meta->size() : 0; }
+  // sgml_mutate / json_mutate return NewMeta ALONE when the block comes back unchanged (erlamsa_sgml.erl:748-749, erlamsa_json.erl:722-723:
+  // "{fun .., Ll, NewMeta, -1}", not [NewMeta | Meta]): everything the list in hand held before is gone from what gets printed
+  void meta_drop_before(size_t start) { if (meta && start > meta_base) meta->erase(meta_base, start - meta_base); }
+  int own_aux = -1;      // set by the mutators whose own Meta entry does not follow from their result alone (sed_num, ascii)
+  void m(const std::string& term) { if (meta) { meta->append(term); meta->push_back('\n'); } }
+  void m2(const char* a, long long v) { if (meta) m(std::string("{") + a + "," + std::to_string(v) + "}"); }
+  void m2(const char* a, const char* b) { if (meta) m(std::string("{") + a + "," + b + "}"); }
   Bytes out;             // blocks already written by blocks_port
   EngineGuard* guard = nullptr;   // engine caps (not reference behaviour); nullptr = pure reference semantics
   std::function<BList()> lazy_ll; // file / jump generators hand the pattern a fun: forced by its first uncons (erlamsa_utils.erl:93)
@@ -437,6 +451,7 @@ int sed_num(Ctx& c, BList& ll) {                                              //
   bool isbin = binarish(lst);
   BList tail(ll.begin() + 1, ll.end());
   ll = flush_bvecs(lst, tail);
+  c.own_aux = n_ret == 0 ? 0 : 1;                                             // [{muta_num, 0 | 1} | Meta] :162-168
   if (n_ret == 0) { uint64_t r = c.rnd.rand(10); return r == 0 ? -1 : 0; }
   return isbin ? -1 : +2;
 }
@@ -968,7 +983,9 @@ void string_delimeter_mutate(Ctx& c, std::vector<Chunk>& cs) {                //
 }
 int ascii_mutator(Ctx& c, BList& ll, int fn) {                                // construct_ascii_mutator :585-602
   std::vector<Chunk> cs = lex(ll[0]);
-  if (!stringy(cs)) return -1;
+  c.own_aux = 0;
+  if (!stringy(cs)) return -1;                                                // {Ascii_mutator, Ll, Meta, -1} :600-601
+  c.own_aux = 1;                                                              // [{Name, D} | Meta] :598
   if (fn == M_AB) string_generic_mutate(c, cs, {T_INSERT_BADNESS, T_REPLACE_BADNESS, T_INSERT_TRAVERSAL, T_INSERT_AAAS, T_INSERT_NULL});
   else string_delimeter_mutate(c, cs);
   int d = c.rnd.rand_delta();
@@ -1412,6 +1429,36 @@ void EngineGuard::round(uint64_t members) {
   work += 16ull * members;
   if (work > max_work) throw Budget();
 }
+// The Meta entry a mutator conses itself (it is part of the Meta it RETURNS, so it stands in front of {used, _} as well as of
+// {failed, _}).  Most follow from the mutator and its result: erlamsa_mutations.erl:162-168 (muta_num), :180 ({Name, D}, byte
+// level), :235/:248 ({Name, -1} for <<>>, {Name, BSize} otherwise), :360/:376 ({Name, 1} when the block is lines), :390/:402/:421
+// (fuse), :598 (ascii, when stringy), :922/:968/:1021 (tree, {Name, 1} when it ran), :1089/:1099 (utf8), :1105, :1143, :1160-1162.
+// b64 / uri / sgm / js write theirs where they happen.
+static const char* OWN_NAME[M_COUNT] = {
+    nullptr, nullptr, "sed_utf8_widen", "sed_utf8_insert", "ascii_bad", "ascii_delimeter", "tree_dup", "tree_del",
+    "muta_num", "tree_swap_one", "tree_stutter", "tree_swap_two", "byte_drop", "byte_inc", "byte_dec", "byte_flip",
+    "byte_insert", "byte_swap_random", "byte_repeat", "seq_perm", "seq_repeat", "seq_drop", "seq_randmask", "seq_randmask",
+    "line_del", "line_del_seq", "line_dup", "line_clone", "line_repeat", "line_swap", "line_perm", "list_ins",
+    "list_replace", "fuse_this", "fuse_next", "fuse_old", "muta_len", nullptr, nullptr, "muta_zippath",
+    "nomutation"};
+void own_meta(Ctx& c, int fn, int delta, const Bytes& h) {
+  if (!c.meta) return;
+  const char* nm = OWN_NAME[fn];
+  switch (fn) {
+    case M_BD: case M_BEI: case M_BED: case M_BF: case M_BI: case M_BER: case M_BR: case M_UW: case M_UI:
+    case M_FT: case M_FN: case M_FO: case M_LEN: case M_ZIP: case M_NIL:
+      c.m2(nm, (long long)delta); break;
+    case M_SP: case M_SR: case M_SD: case M_SNAND: case M_SRND:
+      c.m2(nm, h.empty() ? -1ll : (long long)h.size()); break;
+    case M_NUM: c.m2(nm, (long long)c.own_aux); break;
+    case M_AB: case M_AD: if (c.own_aux == 1) c.m2(nm, (long long)delta); break;
+    case M_LD: case M_LDS: case M_LR2: case M_LRI: case M_LR: case M_LS: case M_LP: case M_LIS: case M_LRS:
+    case M_TR2: case M_TD: case M_TS1: case M_TS2: case M_TR:
+      if (delta == 1) c.m2(nm, 1ll);
+      break;
+    default: break;
+  }
+}
 void mux_fuzzers(Ctx& c, std::vector<Muta>& fs, BList& ll) {
   if (ll.size() == 1 && ll[0].empty()) return;                                // L([<<>>], Meta)
   if (ll.empty()) throw ErlCrash("mux_fuzzers([]) -> <<>> (non-list result)");
@@ -1425,16 +1472,20 @@ void mux_fuzzers(Ctx& c, std::vector<Muta>& fs, BList& ll) {
   for (; i < sorted.size(); i++) {
     if (ll[0].size() > ABSMAX_BINARY_BLOCK) {                                 // :1269-1270 (drops sorted[i])
       if (c.trace) c.t("skipped_big", "");
+      c.m2("skipped_big", (long long)ll[0].size());                            // [{skipped_big, byte_size(H)} | Meta] :1270
       std::vector<Muta> nf = out; nf.insert(nf.end(), sorted.begin() + i + 1, sorted.end()); fs.swap(nf); return;
     }
     Muta node = sorted[i];
     if (c.guard) c.guard->attempt(node.fn, ll[0].size());
     BList mll = ll;
+    c.own_aux = -1;
+    const int fn0 = node.fn;
     int delta = run_muta_fn(c, mll, node);
+    own_meta(c, fn0, delta, ll[0]);                                           // the mutator's own entry: it is in the Meta it returns, used or failed
     node.score = adjust_priority(node.score, delta);
     out.insert(out.begin(), node);
-    if (!mll.empty() && mll[0] == ll[0]) { c.t("failed", MUTA_TABLE[node.name].name); continue; }   // :1278
-    c.t("used", MUTA_TABLE[node.name].name);
+    if (!mll.empty() && mll[0] == ll[0]) { c.t("failed", MUTA_TABLE[node.name].name); c.m2("failed", MUTA_TABLE[node.name].name); continue; }   // :1278
+    c.t("used", MUTA_TABLE[node.name].name); c.m2("used", MUTA_TABLE[node.name].name);
     std::vector<Muta> nf = out; nf.insert(nf.end(), sorted.begin() + i + 1, sorted.end());
     fs.swap(nf); ll.swap(mll);
     size_t tot = 0; for (auto& b : ll) tot += b.size(); c.check_cap(tot + c.out.size());
@@ -1457,10 +1508,13 @@ int base64_mutator(Ctx& c, BList& ll) {
     // `try base64:decode(A) of Bin -> Body catch ...`: only decode errors are caught;
     // a crash inside Body (the nested mutation) kills the worker.
     int d = c.rnd.rand_delta();
+    c.m2("base64_mutator", (long long)d);                                     // [AddedMeta, {base64_mutator, D} | MAcc] :674: D's entry, then what the nested run adds
     std::vector<Muta> muta = mutators_mutator(c.rnd, table);                  // :669 (table order => draws in table order)
     BList one{dec};
     size_t tr0 = c.trace ? c.trace->size() : 0;
+    const size_t base0 = c.meta_base; c.meta_base = c.meta_size();            // Muta([Bin], []) :670
     mux_fuzzers(c, muta, one);
+    c.meta_base = base0;
     Bytes nb; for (auto& b : one) nb.insert(nb.end(), b.begin(), b.end());
     if (getenv("EO_DUMP_B64")) {                                              // debugging aid (stderr): every nested call of base64_mutator
       fprintf(stderr, "B64 in=");  for (uint8_t x : dec) fprintf(stderr, "%02x", x);
@@ -1527,7 +1581,7 @@ bool try_uri_mutate(Ctx& c, Bytes& a) {                                       //
 int uri_mutator(Ctx& c, BList& ll, Muta& m) {                                 // :770-784
   std::vector<Chunk> cs = lex(ll[0]);
   int dacc = -1;
-  for (auto& ch : cs) if (ch.type == 0 && ch.bs.size() > 5) { if (try_uri_mutate(c, ch.bs)) dacc += 1; }
+  for (auto& ch : cs) if (ch.type == 0 && ch.bs.size() > 5) { if (try_uri_mutate(c, ch.bs)) { dacc += 1; c.m2("uri", "success"); } }   // [NewMeta | MAcc] :778: {uri, success} or []
   ll[0] = unlex(cs);
   m.fn = M_B64;                                                               // :784 returns fun base64_mutator/2 (sic)
   return dacc;
@@ -1791,7 +1845,7 @@ JMutRes json_mutation(Ctx& c, const std::vector<JTP>& ast, long n, long nt, long
   uint64_t r;
   if (nt == 0 && n < 2) {                                                     // :647-651 "prevent too much JSONish on non-JSON data"
     uint64_t e = c.rnd.erand(7);
-    if (!(e == 4 && n == 1)) { res.failed = true; res.d = -1; return res; }
+    if (!(e == 4 && n == 1)) { res.failed = true; res.d = -1; c.m2("failed", "json"); return res; }   // {[{failed, json}], Ast, -1} :649
     r = c.rnd.rand(8);
   } else r = c.rnd.rand(21);
   switch (r) {
@@ -1799,10 +1853,11 @@ JMutRes json_mutation(Ctx& c, const std::vector<JTP>& ast, long n, long nt, long
       long r1 = (long)c.rnd.erand(nv), r2 = (long)c.rnd.erand(nv);
       JTP e1 = json_select_elem_values(ast, r1), e2 = json_select_elem_values(ast, r2);
       res.ast = json_walk_top(false, ast, [&](const JTP& e, std::vector<JTP>& tree, long, long i) { tree.push_back(i == r1 ? e2 : (i == r2 ? e1 : e)); });
-      res.d = 1; return res;
+      c.m2("json_swap", 1ll); res.d = 1; return res;
     }
-    case 1: { long rr = (long)c.rnd.erand(nv); res.ast = json_repeat_elem(ast, rr, 1); res.d = 1; return res; }                 // json_dup :569-571
+    case 1: { long rr = (long)c.rnd.erand(nv); res.ast = json_repeat_elem(ast, rr, 1); c.m2("json_dup", 1ll); res.d = 1; return res; }                 // json_dup :569-571
     case 2: {                                                                 // json_pump :551-567
+      c.m2("json_pump", 1ll);
       if (nt == 0) { res.d = -2; return res; }                                // json_pump(Ast, 0) -> Ast
       long rr = (long)c.rnd.erand(nt);
       JSel st = json_select_top(true, ast, [&](const JTP& e, long ct, long) { return (e->k == JK_OBJECT || e->k == JK_ARRAY) && ct == rr; });
@@ -1813,22 +1868,23 @@ JMutRes json_mutation(Ctx& c, const std::vector<JTP>& ast, long n, long nt, long
       res.ast = json_replace_elem(ast, st.cnt, pumped);
       res.d = -2; return res;
     }
-    case 3: { long rr = (long)c.rnd.erand(nv); long times = (long)c.rnd.erand(100); res.ast = json_repeat_elem(ast, rr, times); res.d = 1; return res; }   // json_repeat :573-575
+    case 3: { long rr = (long)c.rnd.erand(nv); long times = (long)c.rnd.erand(100); res.ast = json_repeat_elem(ast, rr, times); c.m2("json_repeat", 1ll); res.d = 1; return res; }   // json_repeat :573-575
     case 4: {                                                                 // json_insert :592-596
       long r1 = (long)c.rnd.erand(nv), r2 = (long)c.rnd.erand(nv);
       JTP ne = json_select_elem_values(ast, r1);
       res.ast = json_walk_top(false, ast, [&](const JTP& e, std::vector<JTP>& tree, long, long i) { tree.push_back(e); if (i == r2) tree.push_back(ne); });
-      res.d = 1; return res;
+      c.m2("json_insert", 1ll); res.d = 1; return res;
     }
     case 5: {                                                                 // make_json_unserialize :624-627
       std::string uri = "://" + std::string(c.cfg->ssrf_host) + ":" + std::to_string(c.cfg->ssrf_port) + "/";
       const char* p = JSON_UNSERIALIZE[c.rnd.rand_elem_idx(6)];
       res.is_bin = true;
       for (const char* q = p; *q; q++) { if (q[0] == '~' && q[1] == 's') { res.bin.insert(res.bin.end(), uri.begin(), uri.end()); q++; } else res.bin.push_back((uint8_t)*q); }
-      res.d = -2; return res;
+      c.m2("json_unserialize", 1ll); res.d = -2; return res;
     }
     default: break;
   }
+  c.m2("json_innertext", 1ll);                                                // {[Meta, {json_innertext, 1}], Res, 1} :706: it stands in front of what the walk adds
   // inner text / basic type mutations :668-710 (walk2acc; the meta accumulators carry no draws)
   std::vector<Muta> muta = json_inner_muta(c);
   auto mutate_text = [&](const Bytes& str, double prob) -> Bytes {            // mutate_innertext_prob/4 :629-636
@@ -1836,7 +1892,9 @@ JMutRes json_mutation(Ctx& c, const std::vector<JTP>& ast, long n, long nt, long
     if (rnd > prob) return str;
     std::vector<Muta> m = muta;                                               // the updated mutator is dropped (_NewMuta)
     BList one{str};
+    const size_t base0 = c.meta_base; c.meta_base = c.meta_size();            // Muta([Binary], []) :637: a Meta list of its own
     mux_fuzzers(c, m, one);
+    c.meta_base = base0;
     if (one.empty()) throw ErlCrash("badarg: hd([])");
     return one[0];
   };
@@ -1858,6 +1916,7 @@ JMutRes json_mutation(Ctx& c, const std::vector<JTP>& ast, long n, long nt, long
         double rnd = c.rnd.rand_float();
         if (t->cval == 2) {                                                   // mutate_null/2 :638-640
           if (rnd >= 3.0 / N) { acc.push_back(t); break; }
+          c.m2("json_innertext", 1ll); c.m2("json_innertext", "null");        // [{json_innertext, null}, {json_innertext, 1} | InnerMeta] :686
           switch (c.rnd.rand_elem_idx(7)) {
             case 0: acc.push_back(j_text(JK_NUMBER, Bytes{'-', '1'})); break;
             case 1: { const char* z = "1000000000"; acc.push_back(j_text(JK_NUMBER, Bytes(z, z + 10))); break; }
@@ -1867,7 +1926,7 @@ JMutRes json_mutation(Ctx& c, const std::vector<JTP>& ast, long n, long nt, long
             case 5: acc.push_back(j_text(JK_NUMBER, Bytes{'0'})); break;
             default: { const char* z = "AAAAAAAAAAAA"; acc.push_back(j_text(JK_STRING, Bytes(z, z + 12))); break; }
           }
-        } else acc.push_back(rnd >= 3.0 / N ? t : j_const(t->cval == 0 ? 1 : 0));   // basic_type_mutation(Boolean, Prob) :1212-1221
+        } else { if (!(rnd >= 3.0 / N)) { c.m2("json_innertext", 1ll); c.m2("json_innertext", "bool"); } acc.push_back(rnd >= 3.0 / N ? t : j_const(t->cval == 0 ? 1 : 0)); }   // basic_type_mutation(Boolean, Prob) :1212-1221, :691
         break;
       }
       case JK_NUMBER: {
@@ -1877,6 +1936,7 @@ JMutRes json_mutation(Ctx& c, const std::vector<JTP>& ast, long n, long nt, long
         if (rnd >= 3.0 / N) { acc.push_back(t); break; }
         Big nv2 = mutate_num(c, v);
         if (nv2.neg == v.neg && Big::cmp_mag(nv2.mag, v.mag) == 0) { acc.push_back(t); break; }
+        c.m2("json_innertext", 1ll); c.m2("json_innertext", "num");           // :698
         std::string d = nv2.to_dec(); acc.push_back(j_text(JK_NUMBER, Bytes(d.begin(), d.end())));
         break;
       }
@@ -1890,12 +1950,13 @@ JMutRes json_mutation(Ctx& c, const std::vector<JTP>& ast, long n, long nt, long
 int json_mutate(Ctx& c, BList& ll) {                                          // json_mutate/2 :714-737
   const Bytes h = ll[0];
   std::vector<JTP> tokens;
-  try { tokens = json_tokenize(h); } catch (IncorrectJson&) { return -1; }
+  try { tokens = json_tokenize(h); } catch (IncorrectJson&) { c.m2("failed", "json"); return -1; }   // [{failed, json} | Meta] :730
   JCnt cc; long nv = json_count_walk(j_list(tokens), 0, cc);
+  const size_t meta0 = c.meta_size();
   JMutRes r = json_mutation(c, tokens, cc.cnt, cc.ct, nv);
   Bytes nb;
   if (r.is_bin) nb = r.bin; else json_fold(j_list(r.ast), nb);
-  if (nb == h) return -1;
+  if (nb == h) { c.meta_drop_before(meta0); return -1; }                      // {fun json_mutate/2, Ll, NewMeta, -1} :722-723
   int d = r.d + (int)(nb.size() / (AVG_BLOCK_SIZE * 10));
   ll[0] = nb;
   return d;
@@ -2213,6 +2274,8 @@ std::vector<Muta> inner_muta(Ctx& c, const std::vector<int>& names) {           
 std::vector<SN> sgml_mutation(Ctx& c, const std::vector<SN>& ast, long n, long nt, int* d) {
   uint64_t r = c.rnd.rand(12);
   *d = 1;
+  static const char* const SG_META[8] = {"sgml_swap", "sgml_dup", "sgml_pump", "sgml_repeat", "sgml_insert2", "sgml_permparams", "sgml_breaktag", "sgml_insert"};
+  if (r < 8) c.m2(SG_META[r], 1ll);                                           // {[{sgml_swap, 1}], Res, 1} ... :700-723
   switch (r) {
     case 0: {                                                                 // sgml_swap :530-543
       long r1 = (long)c.rnd.erand(n), r2 = (long)c.rnd.erand(n);
@@ -2267,7 +2330,7 @@ std::vector<SN> sgml_mutation(Ctx& c, const std::vector<SN>& ast, long n, long n
       });
     }
     case 8: {                                                                 // sgml_xmlfeatures(Ast, NT, 1) :651-665
-      if (nt <= 0) { *d = -1; return ast; }
+      if (nt <= 0) { *d = -1; c.m2("sgml_xmlfeatures", -1ll); return ast; }    // sgml_xmlfeatures(Ast, _NT, _) :664-665
       std::string uri = "http" + ssrf_uri(c);
       bool changed = false;
       std::vector<SN> res = sgml_walk_top(ast, [&](const SN& e, std::vector<SN>& tree, long t, long) {
@@ -2290,11 +2353,13 @@ std::vector<SN> sgml_mutation(Ctx& c, const std::vector<SN>& ast, long n, long n
         }
         auto x = std::make_shared<SNode>(*e); x->params = np; tree.push_back(x); changed = true;
       });
-      if (!changed) { *d = -1; return ast; }                                  // Ast =:= NewAst
+      if (!changed) { *d = -1; c.m2("sgml_xmlfeatures", "failed"); return ast; }   // Ast =:= NewAst :661
+      c.m2("sgml_xmlfeatures", "xmlns");
       return res;
     }
     default: break;
   }
+  c.m2("sgml_innertext", 1ll);                                                // {[Meta, {sgml_innertext, 1}], Res, 1} :737: in front of what the walk adds
   // inner text :727-737: walk2acc/3 :363-379 visits children before the tag itself
   static const std::vector<int> names = {M_AB, M_AD, M_BD, M_B64, M_LD, M_LP, M_LRI, M_LR, M_NUM, M_SD, M_URI};   // `json` names nothing (:1343)
   std::vector<Muta> muta = inner_muta(c, names);
@@ -2304,7 +2369,9 @@ std::vector<SN> sgml_mutation(Ctx& c, const std::vector<SN>& ast, long n, long n
     double rnd = c.rnd.rand_float();
     if (rnd > 3.0 / (double)nt2) return bin;
     std::vector<Muta> m = muta; BList one{bin};
+    const size_t base0 = c.meta_base; c.meta_base = c.meta_size();            // Muta([Binary], []) :670
     mux_fuzzers(c, m, one);
+    c.meta_base = base0;
     if (one.empty()) throw ErlCrash("badarg: hd([])");
     return one[0];
   };
@@ -2336,9 +2403,10 @@ int sgml_mutate(Ctx& c, BList& ll) {                                          //
   SBuild b = sgml_build(toks, 0, {});
   if (b.st != 0) throw ErlCrash("try_clause: parse/1");
   int d = 1;
+  const size_t meta0 = c.meta_size();
   std::vector<SN> res = sgml_mutation(c, b.ast, b.n, b.nt, &d);
   Bytes nb; sgml_fold(res, nb);
-  if (nb == h) return -1;
+  if (nb == h) { c.meta_drop_before(meta0); return -1; }                      // {fun sgml_mutate/2, Ll, NewMeta, -1} :748-749
   ll[0] = nb;
   return d + (int)(nb.size() / (AVG_BLOCK_SIZE * 10));
 }
@@ -2349,6 +2417,39 @@ int sgml_mutate(Ctx& c, BList& ll) {                                          //
 enum PatId { P_OD, P_ND, P_BU, P_SK, P_SZ, P_CS, P_AR, P_CP, P_CO, P_NU, P_COUNT };
 struct PatDef { const char* name; int pri; };
 const PatDef PAT_TABLE[P_COUNT] = {{"od", 1}, {"nd", 2}, {"bu", 1}, {"sk", 2}, {"sz", 2}, {"cs", 1}, {"ar", 1}, {"cp", 1}, {"co", 0}, {"nu", 0}};   // :395-405
+
+// io_lib:format("~p", [F]) for a float F of integral value k >= 0 (erlamsa_patterns.erl:154 {skipped, Len/8}): the shortest digits,
+// written plainly while that is not longer than the exponent form (io_lib_format:fwrite_g/1 -> insert_decimal/2): 17.0, 1000.0,
+// 1.0e5, 1.23e6, 123456.0
+std::string erl_float_of_int(uint64_t k) {
+  if (k == 0) return "0.0";
+  std::string digs = std::to_string(k);
+  const int place = (int)digs.size();
+  while (digs.size() > 1 && digs.back() == '0') digs.pop_back();
+  const int l = (int)digs.size(), exp = place - 1;
+  const int expcost = (int)std::to_string(exp).size() + 2;
+  if (place - l <= expcost) return digs + std::string((size_t)(place - l), '0') + ".0";
+  std::string m = digs.substr(0, 1) + "." + (l > 1 ? digs.substr(1) : std::string("0"));
+  return m + "e" + std::to_string(exp);
+}
+// io_lib:format("~p", [Str]) for a file name out of zip:foldl (a list of bytes; the restated prim_zip passes ASCII names only):
+// a printable list is written as a string with the usual escapes, anything else as a list of integers
+std::string erl_string_p(const Bytes& s) {
+  bool printable = true;
+  for (uint8_t ch : s) if (!((ch >= 32 && ch <= 126) || ch == 8 || ch == 9 || ch == 10 || ch == 11 || ch == 12 || ch == 13 || ch == 27 || ch >= 160)) printable = false;
+  std::string o;
+  if (!printable) { o = "["; for (size_t i = 0; i < s.size(); i++) { if (i) o += ","; o += std::to_string((int)s[i]); } return o + "]"; }
+  if (s.empty()) return "[]";
+  o = "\"";
+  for (uint8_t ch : s) {
+    switch (ch) {
+      case '"': o += "\\\""; break; case '\\': o += "\\\\"; break; case 10: o += "\\n"; break; case 13: o += "\\r"; break; case 9: o += "\\t"; break;
+      case 11: o += "\\v"; break; case 8: o += "\\b"; break; case 12: o += "\\f"; break; case 27: o += "\\e"; break;
+      default: o.push_back((char)ch);
+    }
+  }
+  return o + "\"";
+}
 
 struct PatEngine {
   Ctx& c;
@@ -2382,7 +2483,7 @@ struct PatEngine {
   // jump generators draw their block sizes only now, AFTER the pattern's own first draws
   void force(BList& ll) { if (c.lazy_ll) { auto f = c.lazy_ll; c.lazy_ll = nullptr; ll = f(); } }
   void mutate_once(BList ll, const Cont& cont, Bytes& sink) {
-    if (!c.lazy_ll && ll.size() == 1 && ll[0].empty()) return;                // {Mutator, Meta}: nothing more is written (a fun does not match [<<>>])
+    if (!c.lazy_ll && ll.size() == 1 && ll[0].empty()) { c.m2("mutate_once", "empty_stopped"); return; }   // {Mutator, [{mutate_once, empty_stopped} | Meta]} :268-269: nothing more is written (a fun does not match [<<>>])
     int ip = (int)c.rnd.rand(INITIAL_IP);
     force(ll);
     if (ll.empty()) { BList e; cont(e, sink); return; }
@@ -2391,6 +2492,10 @@ struct PatEngine {
   }
   void run(int pat, BList ll, Bytes& sink) {
     c.t("pattern", PAT_TABLE[pat].name);
+    // [{pattern, once_dec | many_dec | burst} | Meta] :309,:326,:349; make_complex_pat's [{pattern, Type} | Meta] :356; co adds nothing of
+    // its own (:380-384), nu conses {pattern, no_muta} (:390)
+    static const char* const PAT_META[P_COUNT] = {"once_dec", "many_dec", "burst", "skipper", "sizer", "csum", "archiver", "compressed", nullptr, "no_muta"};
+    if (PAT_META[pat]) c.m2("pattern", PAT_META[pat]);
     switch (pat) {
       case P_OD: mutate_once(ll, [this](BList& l, Bytes& s) { emit_all(l, s); }, sink); return;                  // :306-309
       case P_ND: mutate_once(ll, [this](BList& l, Bytes& s) { many_dec_cont(l, s); }, sink); return;             // :323-326
@@ -2413,7 +2518,7 @@ struct PatEngine {
   void many_dec_cont(BList& l, Bytes& sink) {                                 // :313-321
     if (c.rnd.rand_occurs_fixed(4, 5)) run_nd_again(l, sink); else emit_all(l, sink);
   }
-  void run_nd_again(BList& l, Bytes& sink) { c.t("pattern", "nd"); mutate_once(l, [this](BList& l2, Bytes& s) { many_dec_cont(l2, s); }, sink); }
+  void run_nd_again(BList& l, Bytes& sink) { c.t("pattern", "nd"); c.m2("pattern", "many_dec"); mutate_once(l, [this](BList& l2, Bytes& s) { many_dec_cont(l2, s); }, sink); }
   void burst_cont(BList& l, Bytes& sink) {                                    // :331-344
     int n = 1;
     while (true) {
@@ -2427,6 +2532,7 @@ struct PatEngine {
     if (ll.empty()) throw ErlCrash("badarg: size(false)");
     Bytes bin = ll[0];
     size_t len = c.rnd.rand((uint64_t)std::trunc((double)bin.size() / 2.0));
+    if (c.meta) c.m("{skipped," + erl_float_of_int(len) + "}");              // [{skipped, Len/8} | Meta] :154 (Len in bits: a float)
     sink.insert(sink.end(), bin.begin(), bin.begin() + len);
     ll[0] = Bytes(bin.begin() + len, bin.end());
     split(ll);
@@ -2439,8 +2545,9 @@ struct PatEngine {
     Bytes bin = ll[0]; BList rest(ll.begin() + 1, ll.end());
     std::vector<Sizer> cands = get_possible_simple_lens(c, bin);
     int64_t ei = c.rnd.rand_elem_idx(cands.size());
-    if (ei < 0) { split(ll); mutate_once_loop(ip, ll, next, sink); return; }
+    if (ei < 0) { c.m2("sizer", "failed"); split(ll); mutate_once_loop(ip, ll, next, sink); return; }   // :85
     const Sizer& e = cands[ei]; int nb = e.size / 8;
+    if (c.meta) c.m("{sizer,{ok," + std::to_string(e.size) + "," + (e.big ? "big" : "little") + "," + std::to_string(e.len) + "," + std::to_string(e.a) + "," + std::to_string(e.b) + "}}");   // :97
     if (bin.size() < e.a + nb + e.len) throw ErlCrash("badmatch: extract_blob");
     Bytes h(bin.begin(), bin.begin() + e.a), blob(bin.begin() + e.a + nb, bin.begin() + e.a + nb + e.len), tailbin(bin.begin() + e.a + nb + e.len, bin.end());
     BList sub; sub.push_back(blob); sub.insert(sub.end(), rest.begin(), rest.end());
@@ -2458,8 +2565,9 @@ struct PatEngine {
     Bytes bin = ll[0]; BList rest(ll.begin() + 1, ll.end());
     std::vector<Csum> cands = get_possible_csum_locations(bin);
     int64_t ei = c.rnd.rand_elem_idx(cands.size());
-    if (ei < 0) { split(ll); mutate_once_loop(ip, ll, next, sink); return; }
+    if (ei < 0) { c.m2("csum", "failed"); split(ll); mutate_once_loop(ip, ll, next, sink); return; }   // :119
     const Csum& e = cands[ei];
+    if (c.meta) c.m(std::string("{csum,{") + (e.crc ? "crc32,32," : "xor8,8,") + std::to_string(e.plen) + "," + std::to_string(e.blen) + "}}");   // :131
     Bytes p(bin.begin(), bin.begin() + e.plen), blob(bin.begin() + e.plen, bin.begin() + e.plen + e.blen);
     BList sub; sub.push_back(blob); sub.insert(sub.end(), rest.begin(), rest.end());
     split(sub);
@@ -2489,22 +2597,28 @@ struct PatEngine {
     }
     const std::vector<Muta> mutator = c.fs;                                   // every inner evaluation starts from the Mutator the pattern was given
     const size_t trace_mark = c.trace ? c.trace->size() : 0;
+    const size_t meta_mark = c.meta_size();
     if (rc == otpzip::ZR_OK) {
       // lists:mapfoldl over FileSpec, which foldl built by prepending: the LAST central-directory entry comes first
       for (size_t k = es.size(); k-- > 0;) {
         uint64_t r = c.rnd.rand(1000);
         if (r > 750) {                                                        // :177-183
           Bytes nb; BList one{es[k].data};
+          if (c.meta) c.m("{archiver," + erl_string_p(es[k].name) + "}");      // [NM, {archiver, N} | Acc] :183: the name, then what the file's evaluation adds
+          const size_t base0 = c.meta_base; c.meta_base = c.meta_size();
           mutate_once_loop(ip, one, next, nb);                                // prepare4sizer(mutate_once_loop(Mutator, [], NextPat, Ip, B, []))
+          c.meta_base = base0;
           es[k].data = nb;
           c.fs = mutator;
         }
       }
       Bytes newbin;
       rc = otpzip::create(es, &newbin);                                       // zip:create(Name, lists:reverse(NewFileSpec), [memory])
-      if (rc == otpzip::ZR_OK) { c.check_cap(newbin.size()); sink.insert(sink.end(), newbin.begin(), newbin.end()); return; }   // [NewBin | {fun .., ..}]
-      if (c.trace) c.trace->resize(trace_mark);                               // {error, Err}: the failed clause with the Meta the pattern was given
+      if (rc == otpzip::ZR_OK) { c.m2("archiver", "ok"); c.check_cap(newbin.size()); sink.insert(sink.end(), newbin.begin(), newbin.end()); return; }   // [NewBin | {fun .., [{archiver, ok}, flatten(NewMeta) | Meta]}] :196
+      if (c.trace) c.trace->resize(trace_mark);
+      if (c.meta) c.meta->resize(meta_mark);                               // {error, Err}: the failed clause with the Meta the pattern was given
     }
+    c.m2("archiver", "failed");                                               // SizerMeta = [{archiver, failed} | Meta] :169
     BList one{all};                                                           // mutate_once_archiver(Binary, {error, _}, Rest = [], ..) :165-174
     split(one);
     mutate_once_loop(ip, one, next, sink);
@@ -2520,10 +2634,17 @@ struct PatEngine {
     Bytes newbin = bin;
     const std::vector<Muta> mutator = c.fs;                                   // the closures keep using Mutator, not what the inner evaluation returns
     const size_t trace_mark = c.trace ? c.trace->size() : 0;
+    const size_t meta_mark = c.meta_size();
     if (fmt) {
       Bytes newdata;                                                          // prepare4sizer(mutate_once_loop(Mutator, [], NextPat, Ip, Data, []))
       BList one{data};
+      // {NewBin, [{compressed, gzip}, NewMeta, {decompressed, gzip} | Meta]} :223 (zlib :241): printed in the order decompressed,
+      // what the evaluation of the payload added (a Meta list of its own, started from []), compressed
+      c.m2("decompressed", fmt == 1 ? "gzip" : "zlib");
+      const size_t base0 = c.meta_base; c.meta_base = c.meta_size();
       mutate_once_loop(ip, one, next, newdata);
+      c.meta_base = base0;
+      c.m2("compressed", fmt == 1 ? "gzip" : "zlib");
       newbin = otpz::deflate_all(newdata, fmt == 1 ? 31 : 15);                // zlib:gzip(NewData) | deflateInit(ZD, default), deflate(ZD, [NewData], finish)
       c.check_cap(newbin.size());
     }
@@ -2535,6 +2656,8 @@ struct PatEngine {
     }
     c.fs = mutator;                                                           // mutate_once_loop(Mutator, [{compressed, failed} | Meta], ..): the inner
     if (c.trace) c.trace->resize(trace_mark);                                 // evaluation's mutator state and meta are dropped
+    if (c.meta) c.meta->resize(meta_mark);
+    c.m2("compressed", "failed");                                             // :259
     mutate_once_loop(ip, l2, next, sink);
   }
 };
@@ -2625,9 +2748,9 @@ void setup_run(Run& run, const Config& cfg, int64_t s1, int64_t s2, int64_t s3) 
 }
 
 // One FuzzingLoop iteration :176-221 (worker process body :182-210)
-void run_case(Run& run, const Config& cfg, const Bytes& input, Bytes* out, int* status, uint64_t* draws, std::string* trace) {
+void run_case(Run& run, const Config& cfg, const Bytes& input, Bytes* out, int* status, uint64_t* draws, std::string* trace, std::string* meta = nullptr) {
   int64_t t1 = (int64_t)run.parent.erand(99999), t2 = (int64_t)run.parent.erand(99999), t3 = (int64_t)run.parent.erand(99999);   // gen_predictable_seed :179
-  Ctx c; c.cfg = &cfg; c.trace = trace;
+  Ctx c; c.cfg = &cfg; c.trace = trace; c.meta = meta;
   EngineGuard guard; guard.max_bytes = cfg.max_case_bytes; guard.max_work = cfg.max_case_work;
   if (cfg.max_case_seconds > 0) { guard.timed = true; guard.deadline = std::chrono::steady_clock::now() + std::chrono::microseconds((int64_t)(cfg.max_case_seconds * 1e6)); }
   if (guard.max_bytes || guard.max_work || guard.timed) c.guard = &guard;     // engine caps requested by the test (not reference behaviour)
@@ -2747,8 +2870,11 @@ static int eo_fuzz_batch_impl(const eo_config* ec, const uint8_t* data, const ui
       Bytes input(data + off[i], data + off[i + 1]);
       if (ec->mode == 1) setup_run(run, cfg, ec->seeds[3 * i], ec->seeds[3 * i + 1], ec->seeds[3 * i + 2]);
       std::string tr;
-      run_case(run, cfg, input, &outs[i], &st[i], &dr[i], want_trace ? &tr : nullptr);
-      if (want_trace) { trace += tr; trace.push_back('\n'); }
+      // want_trace 1: the short form ("pattern:od failed:sgm used:bd "), one line per case; 2: the reference's Meta list in full, every
+      // element as ~p prints it on a line of its own, a line "\x1e" behind every case
+      run_case(run, cfg, input, &outs[i], &st[i], &dr[i], want_trace == 1 ? &tr : nullptr, want_trace == 2 ? &tr : nullptr);
+      if (want_trace == 1) { trace += tr; trace.push_back('\n'); }
+      if (want_trace == 2) { trace += tr; trace += "\x1e\n"; }
     }
     uint64_t total = 0; for (auto& o : outs) total += o.size();
     res->data = (uint8_t*)malloc(total ? total : 1);

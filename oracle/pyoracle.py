@@ -105,7 +105,7 @@ def fuzz_batch(data, off, seed=(1, 2, 3), mutations=None, patterns=None, generat
     data = np.ascontiguousarray(data, dtype=np.uint8)
     off = np.ascontiguousarray(off, dtype=np.uint64)
     res = _Res()
-    rc = lib().eo_fuzz_batch(C.byref(cfg), data.ctypes.data, off.ctypes.data, n, 1 if trace else 0, C.byref(res))
+    rc = lib().eo_fuzz_batch(C.byref(cfg), data.ctypes.data, off.ctypes.data, n, 2 if trace == "full" else 1 if trace else 0, C.byref(res))
     if rc != 0:
         raise RuntimeError("oracle: " + lib().eo_last_error().decode())
     o = np.ctypeslib.as_array(res.off, shape=(n + 1,)).copy()

@@ -81,14 +81,14 @@ def run_cp(n=24, big=1 << 25):
         inputs = compressed_corpus(n, seed=300 + ci)
         data, off = po.pack(inputs)
         seed = (21 + ci, 4, 9)
-        want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=muts, patterns=pats, max_case_bytes=big, trace=True)
+        want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=muts, patterns=pats, max_case_bytes=big, trace="full")
         eng = ea.Engine(0)
         eng.configure(mutations=muts, patterns=pats, max_case_bytes=1 << 20, big_case_bytes=big, flags=ea.engine.EH_FLAG_META_TRACE)
         eng.upload_corpus(data, off)
         eng.fuzz_batch(seed=seed)
         got, gst = eng.download()
         gdr, _ = eng.diag()
-        lines = tr.split("\n")
+        lines = tr.split("\x1e\n")
         bad = []
         for i in range(len(inputs)):
             if gst[i] in (2, 3) or wst[i] in (2, 3):
@@ -96,8 +96,7 @@ def run_cp(n=24, big=1 << 25):
                 continue
             ok = got[i] == want[i] and gst[i] == wst[i] and (gst[i] != 0 or gdr[i] == wdr[i])
             if ok and gst[i] == 0:
-                mine = " ".join("%s:%s" % kv for kv in eng.meta(i))
-                ok = "truncated" in mine or mine == " ".join(lines[i].split())
+                ok = util.meta_matches(eng, i, lines[i])
             if not ok:
                 bad.append(i)
         eng.close()
@@ -176,14 +175,14 @@ def run_zip(n=20, big=1 << 25):
         inputs = zip_corpus(n, seed=500 + ci)
         data, off = po.pack(inputs)
         seed = (31 + ci, 5, 2)
-        want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=muts, patterns=pats, max_case_bytes=big, trace=True)
+        want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=muts, patterns=pats, max_case_bytes=big, trace="full")
         eng = ea.Engine(0)
         eng.configure(mutations=muts, patterns=pats, max_case_bytes=1 << 20, big_case_bytes=big, flags=ea.engine.EH_FLAG_META_TRACE)
         eng.upload_corpus(data, off)
         eng.fuzz_batch(seed=seed)
         got, gst = eng.download()
         gdr, _ = eng.diag()
-        lines = tr.split("\n")
+        lines = tr.split("\x1e\n")
         bad = []
         for i in range(len(inputs)):
             if gst[i] == 2 or wst[i] == 2:
@@ -191,8 +190,7 @@ def run_zip(n=20, big=1 << 25):
                 continue
             ok = got[i] == want[i] and gst[i] == wst[i] and (gst[i] != 0 or gdr[i] == wdr[i])
             if ok and gst[i] == 0:
-                mine = " ".join("%s:%s" % kv for kv in eng.meta(i))
-                ok = "truncated" in mine or mine == " ".join(lines[i].split())
+                ok = util.meta_matches(eng, i, lines[i])
             if not ok:
                 bad.append(i)
         eng.close()

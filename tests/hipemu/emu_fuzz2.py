@@ -55,14 +55,14 @@ while time.time() < t_end:
     want_trace = rnd.random() < 0.5
     data, off = po.pack(inputs)
     try:
-        want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=spec, patterns=pats, generators=gens, max_case_bytes=32 << 20, trace=True, max_case_seconds=20.0)
+        want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=spec, patterns=pats, generators=gens, max_case_bytes=32 << 20, trace="full", max_case_seconds=20.0)
     except RuntimeError as e:
         print("oracle error", e, spec, pats); continue
     eng = ea.Engine(0)
     eng.configure(mutations=spec, patterns=pats, generators=gens, max_case_bytes=slot, big_case_bytes=32 << 20, fuse_stream_min=fsm,
                   flags=ea.engine.EH_FLAG_META_TRACE if want_trace else 0)
     eng.upload_corpus(data, off); eng.fuzz_batch(seed=seed); got, gst = eng.download(); gdr, _ = eng.diag(); pk = eng.peak()
-    lines = tr.split("\n")
+    lines = tr.split("\x1e\n")
     for i in range(n):
         total += 1
         if gst[i] in (2, 3) or wst[i] in (2, 3, 6): skipped += 1; continue
@@ -70,10 +70,10 @@ while time.time() < t_end:
         bad = got[i] != want[i] or gst[i] != wst[i] or (gst[i] == 0 and gdr[i] != wdr[i])
         if not bad and want_trace and gst[i] == 0:
             traced += 1
-            mine = " ".join("%s:%s" % kv for kv in eng.meta(i))
-            if "truncated" not in mine and mine != " ".join(lines[i].split()):
+            if not util.meta_matches(eng, i, lines[i]):
                 bad = True
-                print("   TRACE differs: engine", mine[:200], "| oracle", " ".join(lines[i].split())[:200], flush=True)
+                from erlamsa_amd import meta as _meta
+                print("   TRACE differs: engine", _meta.lines(eng.meta_terms(i)[0]).replace("\n", " ")[:300], "| oracle", lines[i].replace("\n", " ")[:300], flush=True)
         if bad:
             print("MISMATCH trial", trial, "case", i, "spec", spec, "pats", pats, "gens", gens, "seed", seed, "kind", kind, "n", n, "slot", slot, "fsm", fsm,
                   "len", len(got[i]), len(want[i]), "status", gst[i], wst[i], "draws", gdr[i], wdr[i], "firstdiff", util.first_diff(got[i], want[i]), flush=True)

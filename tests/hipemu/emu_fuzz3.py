@@ -51,13 +51,13 @@ while time.time() < t_end:
     first = rnd.choice([1, 1, 7, 1000])
     data, off = po.pack(inputs)
     try:
-        want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=spec, patterns=pats, generators=gens, blockscale=bs, first_case=first, max_case_bytes=32 << 20, trace=True, max_case_seconds=20.0)
+        want, wst, wdr, tr = po.fuzz_batch(data, off, seed=seed, mutations=spec, patterns=pats, generators=gens, blockscale=bs, first_case=first, max_case_bytes=32 << 20, trace="full", max_case_seconds=20.0)
     except RuntimeError as e:
         print("oracle error", e, spec, pats); continue
     eng = ea.Engine(0)
     eng.configure(mutations=spec, patterns=pats, generators=gens, blockscale=bs, max_case_bytes=slot, big_case_bytes=32 << 20, flags=ea.engine.EH_FLAG_META_TRACE)
     eng.upload_corpus(data, off); eng.fuzz_batch(seed=seed, first_case=first); got, gst = eng.download(); gdr, _ = eng.diag()
-    lines = tr.split("\n")
+    lines = tr.split("\x1e\n")
     for i in range(n):
         total += 1
         stat[min(int(gst[i]), 7)] += 1
@@ -65,10 +65,10 @@ while time.time() < t_end:
         bad = got[i] != want[i] or gst[i] != wst[i] or (gst[i] == 0 and gdr[i] != wdr[i])
         if not bad and gst[i] == 0:
             traced += 1
-            mine = " ".join("%s:%s" % kv for kv in eng.meta(i))
-            if "truncated" not in mine and mine != " ".join(lines[i].split()):
+            if not util.meta_matches(eng, i, lines[i]):
                 bad = True
-                print("   TRACE differs: engine", mine[:200], "| oracle", " ".join(lines[i].split())[:200], flush=True)
+                from erlamsa_amd import meta as _meta
+                print("   TRACE differs: engine", _meta.lines(eng.meta_terms(i)[0]).replace("\n", " ")[:300], "| oracle", lines[i].replace("\n", " ")[:300], flush=True)
         if bad:
             print("MISMATCH trial", trial, "case", i, "spec", spec, "pats", pats, "gens", gens, "seed", seed, "kind", kind, "n", n, "slot", slot, "blockscale", bs, "first_case", first,
                   "len", len(got[i]), len(want[i]), "status", gst[i], wst[i], "draws", gdr[i], wdr[i], "firstdiff", util.first_diff(got[i], want[i]), flush=True)

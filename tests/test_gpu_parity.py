@@ -558,9 +558,12 @@ def test_full_size_bench_workload_is_independent_of_tiers_and_slots():
 
 
 def test_meta_trace_equals_the_oracles():
-    """the per-case meta trace (erlamsa_main.erl:58-70 prints it: {pattern, P}, {used, Name}, {failed, Name} as
-    erlamsa_patterns.erl and mux_fuzzers make them, nested scheduler calls included) through eh_result_meta, entry by entry
-    against the oracle's trace of the same run — default mutator and pattern tables, mixed / SGML / JSON inputs."""
+    """the per-case meta trace in the reference's term format - the TEXT erlamsa's meta logger prints
+    (erlamsa_main.erl:58-70, ~p per element): {pattern, _}, the patterns' own entries ({sizer, Elem}, {csum, Elem}, {skipped, F},
+    {archiver, _}, {compressed | decompressed, _}), every mutator's own entry ({byte_drop, D}, {seq_repeat, BSize}, {muta_num, 0 | 1},
+    {sgml_swap, 1}, {json_innertext, _} ...), {used | failed, Name}, nested scheduler calls included - through eh_result_meta and
+    erlamsa_amd/meta.py, line by line against the oracle's full trace of the same run: default mutator and pattern tables on mixed /
+    SGML / JSON inputs, documents through js / sgm, the complex patterns, gzip / zlib inputs through cp, zip archives through ar."""
     if util.priming():
         pytest.skip("the trace is not part of the digest cache")
     import os
@@ -568,6 +571,7 @@ def test_meta_trace_equals_the_oracles():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
     import emu_meta
     assert emu_meta.run(n=96, size=900, seed=(5, 3, 8)) >= 100
+    assert emu_meta.run_sets(n=60) >= 250
 
 
 def test_two_rank_nccl_bench_smoke():

@@ -204,3 +204,11 @@ def oracle_live(data, off, threads=0, chunk=8, **kw):
     lens = np.array([len(x) for x in outs], dtype=np.int64)
     dig = np.frombuffer(b"".join(hashlib.sha1(x).digest() for x in outs), dtype=np.uint8).reshape(n, 20) if n else np.zeros((0, 20), np.uint8)
     return OracleResult(outs, lens, dig, st, dr, tr)
+
+
+def meta_matches(eng, i, oracle_case):
+    """case i's meta trace, rendered as erlamsa's meta logger prints it (erlamsa_amd/meta.py), against the oracle's full trace of the
+    same case (pyoracle.fuzz_batch(trace="full"), cases split at "\\x1e\\n"); a trace the engine had to cut short counts as equal"""
+    from erlamsa_amd import meta as _meta
+    terms, cut = eng.meta_terms(i)
+    return cut or _meta.lines(terms) == oracle_case
