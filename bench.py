@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--setup-seconds", type=int, default=150, help="single-GPU runs execute in a child process; a child whose set-up passes (the first "
                     "dispatch on every HIP stream) have not finished after this many seconds is killed and the run repeated with "
                     "--inflight 3, then 1 (0 = no supervision)")
+    ap.add_argument("--strong-leg", type=int, default=1, help="N > 1 with weak scaling: after the timed steps, a few steps of STRONG scaling (one run of --cases cases "
+                    "split over the ranks by shard.case_range, what north_star's corpus sharding is) reported under 'strong_scaling_leg'; 0 = skip")
     ap.add_argument("--case-stats", type=int, default=1, help="1: collect per-case wave cycles and output lengths of the timed steps (one small D2H copy per "
                     "collected pass, outside no kernel's way) and report them under 'case_stats': how the bytes and the cycles are distributed over the cases")
     ap.add_argument("--profiled", type=int, default=0, help="1: the run is under rocprofv3 - no child process (--setup-seconds 0) and the process ends by "
@@ -172,7 +174,7 @@ def main():
     if pre.config == 5:
         w5 = int(os.environ.get("WORLD_SIZE", "1"))
         ap.set_defaults(cases=131072 * w5, size=65536, corpus="counter", generators="jump", mutations="ft,fn,fo,num,len", patterns="sz", scaling="strong",
-                        out_gib=8, cpu_sample=0, budget_mib=0)
+                        out_gib=8, cpu_sample=1024, budget_mib=0)
     args = ap.parse_args()
     if args.profiled:
         args.setup_seconds = 0
@@ -299,28 +301,28 @@ def main():
         engines[0].upload_corpus(*synth.as_arena(mat))
         if n * size > (1 << 30):
             mat = None                                              # (the CPU oracle leg wants a host copy: small runs only)
-    else:                                                           # generated on rank 0, RCCL-broadcast to the other GPUs over xGMI
-        arena = torch.empty(n * size, dtype=torch.uint8, device=dev)
-        offs = torch.arange(n + 1, dtype=torch.int64, device=dev) * size
-        if args.corpus == "counter":                               # every rank writes the same arena itself (closed form of seed, row, byte)
-            synth.counter_torch(arena, 0, n, size)
+    else:
+        # The arena reaches every GPU through the LIBRARY's own RCCL calls (include/erlamsa_hip.h "multi-GPU", csrc/eh_comm.h) - the path a
+        # host without a HIP / RCCL binding (the BEAM) takes; torch.distributed only carries the 128 bytes of the unique id, the barriers
+        # and the reduction of the result.  EH_BENCH_BACKEND=gloo: the same calls with tests/hipemu/fake_rccl.cpp behind EH_RCCL_LIB.
+        uid = [ea.Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        engines[0].comm_init(uid[0], rank, world)
+        if args.corpus == "counter":
+            # BASELINE configs[4]: every rank brings ITS shard (closed form of seed, row, byte - no file to read), all-gathered in place:
+            # each xGMI link carries 1 / world of the arena instead of one root feeding everybody
+            per = n // world
+            assert per * world == n, "--cases must be a multiple of the number of ranks for the all-gathered counter corpus"
+            shard_rows = np.concatenate([synth.counter(range(r0, min(r0 + 4096, (rank + 1) * per)), size) for r0 in range(rank * per, (rank + 1) * per, 4096)])
+            engines[0].corpus_allgather(*synth.as_arena(shard_rows))
+            del shard_rows
         else:
             if rank == 0:
                 mat = synth.mixed(n, size) if args.corpus == "mixed" else synth.uniform(n, size)
-                arena.copy_(torch.from_numpy(mat.reshape(-1)))
-            shard.broadcast_corpus(arena, offs, src=0)
-        if on_gpu:
-            torch.cuda.synchronize()
-        # every rank must hold the bytes rank 0 made: a wrapping 64-bit sum of the arena (as int64 words) and of the offsets,
-        # gathered over RCCL and compared on every rank (a broadcast that silently moved nothing would otherwise go unnoticed)
-        nw = (n * size) // 8
-        chk = torch.stack([arena[:nw * 8].view(torch.int64).sum(), arena[nw * 8:].to(torch.int64).sum(), offs.sum()])
-        allchk = [torch.empty_like(chk) for _ in range(world)]
-        dist.all_gather(allchk, chk)
-        arena_same = all(bool((c0 == allchk[0]).all()) for c0 in allchk)
-        if not arena_same:
-            raise RuntimeError("rank %d: the broadcast arena differs between ranks" % rank)
-        engines[0].attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
+                engines[0].corpus_broadcast(0, *synth.as_arena(mat))
+            else:
+                engines[0].corpus_broadcast(0)
+        assert engines[0].n_corpus == n
     for e in engines[1:]:
         e.share_corpus(engines[0])
     raw = [e.own_stream() for e in engines]
@@ -339,6 +341,22 @@ def main():
         e.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=n, stream=st)
         e.sync()
         log("set-up pass %d of %d done" % (k + 1, nctx))
+    arena_same = None
+    if world > 1:
+        # every rank must hold the bytes the others hold: the first 512 case numbers, which mutate rows 0..511 and - with file / jump -
+        # rows anywhere in the arena, are run on EVERY rank and the digests compared (a collective that silently moved nothing, or
+        # shards in another order, would show here)
+        import hashlib
+        e0 = engines[0]
+        e0.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=min(512, n), stream=raw[0])
+        e0.sync()
+        ln0 = e0.lens()
+        dig = hashlib.sha1(b"".join(hashlib.sha1(e0.fetch(i, int(ln0[i]))).digest() for i in range(len(ln0)))).digest()
+        allv = [None] * world
+        dist.all_gather_object(allv, dig)
+        arena_same = all(v == allv[0] for v in allv)
+        if not arena_same:
+            raise RuntimeError("rank %d: the arena differs between ranks (results of the same case numbers differ)" % rank)
     log("warm-up steps")
     # rank r, step k -> case numbers ((k*world + r) * n) + 1 ... (shard.run_steps, the loop tests/test_dist_gloo.py drives too)
     strong = args.scaling == "strong"
@@ -376,6 +394,21 @@ def main():
 
     my_cases = (shard.case_range(n, rank, world)[1] if strong else n) * args.steps
     dt_all, out_all, cases_all = shard.reduce_over_ranks(dt, out_bytes, my_cases, dist, dev)
+    strong_leg = None
+    if world > 1 and not strong and args.strong_leg and args.steps > 0:
+        # the same corpus, strong scaling: ONE run of n cases per step, rank r takes case_range(n, r, world) of it (erlamsa_main.erl:95-108).
+        # A rank's pass is 1 / world of a weak one, so world x as many passes are in flight per GPU-second; with the driver's 20 steps the
+        # pipeline never fills at 8 ranks - which is why `value` stays the weak figure and this one is a labelled second.
+        ks = max(2, min(args.steps, 2 * nctx))
+        sync(); dist.barrier(); sync()
+        ts = time.perf_counter()
+        sr = shard.run_steps(engines, raw, args.warmup + args.steps + 1000, ks, rank, world, n, seed, strong=True)
+        sync(); dist.barrier(); sync()
+        sdt = time.perf_counter() - ts
+        sdt_all, sout_all, scases_all = shard.reduce_over_ranks(sdt, sr["out_bytes"], shard.case_range(n, rank, world)[1] * ks, dist, dev)
+        strong_leg = {"steps": ks, "value": round(sout_all / sdt_all / 1e6, 1), "unit": "MB/s", "cases_per_s": round(scases_all / sdt_all, 1),
+                      "ms_per_step": round(sdt_all / ks * 1e3, 3), "cases_per_step_all_ranks": n,
+                      "what": "one run of %d cases per step split over %d ranks by contiguous case ranges; results are those of a 1-rank run (tests/test_comm_abi.py, tests/test_dist_gloo.py)" % (n, world)}
 
     if rank == 0:
         mbps = out_all / dt_all / 1e6
@@ -424,8 +457,9 @@ def main():
                                args.generators or "direct=500/random=1", pats or "the default table (od,nd,bu,sk,sz,cs,ar,cp,co,nu at their default priorities)", muts, len(muts.split(",")), nmut_total,
                                ",".join(m for m, _, _ in ea.mutator_table() if m not in [x.split("=")[0] for x in muts.split(",")]) or "none"),
                 "world_size_seen_by_torch_distributed": (dist.get_world_size() if dist is not None else 1),
-                "arena_checksums_equal_on_all_ranks": (arena_same if world > 1 else None),
-                "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, arena RCCL-broadcast" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream, one after the other, before the W warm-up steps",
+                "arena_equal_on_all_ranks": arena_same,
+                "arena_transport": (None if world == 1 else "eh_corpus_allgather (RCCL inside the library, per-rank shards)" if args.corpus == "counter" else "eh_corpus_broadcast (RCCL inside the library, root = rank 0)"),
+                "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, no collective on the mutation path" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream, one after the other, before the W warm-up steps",
                 "max_case_bytes": args.case_mib << 20, "big_case_bytes": args.big_mib << 20, "max_case_work": args.work_mib << 20,
                 "workgroups_per_pass": args.max_slots or "one per wavefront the device holds (8 per CU)", "pool_gib": args.pool_gib,
                 "max_slots": args.max_slots, "kernel_source_sha1": ksha,
@@ -450,6 +484,8 @@ def main():
                                    "about 1/%d of the device's" % (nctx, nctx),
                          "achieved_all_in_flight": round(alg_bytes / (dt_all / args.steps) / 1e9, 2)},
         }
+        if strong_leg is not None:
+            res["strong_scaling_leg"] = strong_leg
         if args.case_stats and len_hist:
             # How the headline is made: the default table pumps (sr, lr, tr, sgm, fuse repeat data), so a small share
             # of the cases carries most of the bytes and of the wave cycles.
@@ -498,9 +534,27 @@ def main():
                 off, _ = e.download_into(hbuf.ptr if kind == "pinned" else hbuf.ctypes.data, cap)
                 td = time.perf_counter()
                 ob = int(off[-1])
-                return {"pcie_inclusive_MBps": round(ob / (td - tp) / 1e6, 1), "download_GBps": round(ob / (td - tk) / 1e9, 2), "out_bytes": ob,
-                        "host_buffer": kind, "pass_s": round(tk - tp, 3), "download_s": round(td - tk, 3),
-                        "note": "one pass + eh_result_download (device gather into case order, 2 bounce buffers, D2H overlapped), not overlapped with the next pass"}
+                r = {"pcie_inclusive_MBps": round(ob / (td - tp) / 1e6, 1), "download_GBps": round(ob / (td - tk) / 1e9, 2), "out_bytes": ob,
+                     "host_buffer": kind, "pass_s": round(tk - tp, 3), "download_s": round(td - tk, 3),
+                     "note": "one pass + eh_result_download (device gather into case order, 2 bounce buffers, D2H overlapped), not overlapped with the next pass"}
+                if nctx >= 2:
+                    # ... and pipelined, the way a consumer would run it: while pass k goes over PCIe, pass k+1 runs on the device (two contexts)
+                    hp = hbuf.ptr if kind == "pinned" else hbuf.ctypes.data
+                    sync()
+                    tq = time.perf_counter()
+                    npipe, tot = 4, 0
+                    engines[0].fuzz_batch(seed=seed, first_case=shard.weak_first_case(kx + 1, rank, world, n), corpus_first=0, n=n, stream=raw[0])
+                    for j in range(npipe):
+                        cur, nxt = engines[j % 2], engines[(j + 1) % 2]
+                        if j + 1 < npipe:
+                            nxt.fuzz_batch(seed=seed, first_case=shard.weak_first_case(kx + 2 + j, rank, world, n), corpus_first=0, n=n, stream=raw[(j + 1) % 2])
+                        cur.sync()
+                        o2, _ = cur.download_into(hp, cap)
+                        tot += int(o2[-1])
+                    tq = time.perf_counter() - tq
+                    r["pipelined"] = {"passes": npipe, "pcie_inclusive_MBps": round(tot / tq / 1e6, 1), "s_per_pass": round(tq / npipe, 3),
+                                      "note": "pass k+1 on the device while pass k is downloaded: bound by the slower of the two"}
+                return r
             except ea.EngineError as ex:
                 return {"error": str(ex)}
 
@@ -545,12 +599,23 @@ def main():
         if world == 1:
             threading.Thread(target=watchdog, daemon=True).start()
             # the CPU oracle leg first: it is also the parity check of this very run
+            reduced = None
+            if args.cpu_sample > 0 and mat is None and args.corpus == "counter":
+                # The arena is too large for a host copy (configs[4]: 8 GiB and more per GPU), and the oracle needs the Paths the cases draw
+                # from: the parity sample runs the SAME kernel and options over the first rows of the arena as a corpus of their own
+                # (the counter-hash rows are a closed form of their number) - same seed size, same generators, fewer paths.
+                reduced = min(n, 4096)
+                mat = np.concatenate([synth.counter(range(r0, min(r0 + 1024, reduced)), size) for r0 in range(0, reduced, 1024)])
+                ep = ea.Engine(local if on_gpu else 0)
+                ep.configure(mutations=muts, patterns=pats, generators=args.generators, max_slots=args.max_slots, out_capacity=2 << 30,
+                             max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20, big_case_bytes=args.big_mib << 20, pool_bytes=args.pool_gib << 30)
+                ep.upload_corpus(*synth.as_arena(mat))
             if args.cpu_sample > 0 and mat is not None:
                 state["leg"] = "cpu_baseline"
-                log("parity sample: cases 1..%d once more on context 0, alone on the device" % min(args.cpu_sample, n))
+                log("parity sample: cases 1..%d once more on context 0, alone on the device" % min(args.cpu_sample, mat.shape[0]))
                 import hashlib
-                e0, m = engines[0], min(args.cpu_sample, n)
-                e0.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=m, stream=raw[0])
+                e0, m = (engines[0] if reduced is None else ep), min(args.cpu_sample, mat.shape[0])
+                e0.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=m, stream=raw[0] if reduced is None else 0)
                 e0.sync()
                 st0, ln0, dr0 = e0.status()[:m].copy(), e0.lens()[:m].copy(), e0.diag()[0][:m].copy()
                 gpu_ref = (st0, ln0, dr0, [hashlib.sha1(e0.fetch(i, int(ln0[i]))).digest() for i in range(m)])
@@ -558,6 +623,7 @@ def main():
                 cb = cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref)
                 res["parity_checked"] = cb.pop("parity_checked")
                 res["parity"] = {"checked_bit_exact": res["parity_checked"], "not_compared": cb.pop("parity_skipped"),
+                                 "corpus": "the run's own arena" if reduced is None else "rows 0..%d of the arena as a corpus of their own (same kernel, options, seed size and generators; the oracle needs the Paths on the host)" % (reduced - 1),
                                  "what": "cases 1..%d of this run (the case numbers of the set-up passes, run once more on context 0 after the timed steps): status, length, PRNG draw count and SHA-1 of every "
                                          "output vs the oracle's; not compared = engine-only status (2, 3) or cut by the oracle leg's watchdog" % min(args.cpu_sample, n)}
                 res["cpu_baseline"] = cb

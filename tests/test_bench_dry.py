@@ -10,6 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 SMALL = ["--steps", "2", "--warmup", "1", "--inflight", "2", "--max-slots", "4", "--out-gib", "1", "--pool-gib", "1", "--case-mib", "1", "--big-mib", "32",
          "--cpu-sample", "8", "--cpu-threads", "2", "--setup-seconds", "0"]
 
@@ -47,7 +48,9 @@ def test_bench_script_two_ranks_over_gloo_on_the_emulator(scaling):
     line from rank 0) as two CPU ranks over gloo with the emulator build of the engine - everything of the driver's multi-GPU run
     except RCCL itself.  Launched the way the driver launches it."""
     import build_emu
-    env = dict(os.environ, EH_BENCH_BACKEND="gloo", ERLAMSA_HIP_LIB=build_emu.build())
+    import test_comm_abi
+    test_comm_abi._build()                                                  # build/libfake_rccl.so: the stand-in behind EH_RCCL_LIB
+    env = dict(os.environ, EH_BENCH_BACKEND="gloo", ERLAMSA_HIP_LIB=build_emu.build(), EH_RCCL_LIB=test_comm_abi.FAKE)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EH_BENCH_CHILD"):
         env.pop(k, None)
     port = 29700 + (os.getpid() % 200) + (0 if scaling == "weak" else 1)
@@ -58,5 +61,8 @@ def test_bench_script_two_ranks_over_gloo_on_the_emulator(scaling):
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 2 and d["value"] > 0
-    assert d["config"]["world_size_seen_by_torch_distributed"] == 2 and d["config"]["arena_checksums_equal_on_all_ranks"] is True
+    assert d["config"]["world_size_seen_by_torch_distributed"] == 2 and d["config"]["arena_equal_on_all_ranks"] is True
+    if scaling == "weak":
+        assert d["strong_scaling_leg"]["cases_per_step_all_ranks"] == 16 and d["strong_scaling_leg"]["value"] > 0
+    assert "RCCL inside the library" in d["config"]["arena_transport"]
     assert d["case_status"]["ok"] == (32 if scaling == "weak" else 16)          # rank 0's share: weak = its own 16 cases per step, strong = half of one run's

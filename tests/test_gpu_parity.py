@@ -602,4 +602,4 @@ def test_two_rank_nccl_bench_smoke():
         assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-1500:]
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
-        assert d["config"]["world_size_seen_by_torch_distributed"] == 2 and d["config"]["arena_checksums_equal_on_all_ranks"] is True
+        assert d["config"]["world_size_seen_by_torch_distributed"] == 2 and d["config"]["arena_equal_on_all_ranks"] is True
