@@ -3,7 +3,7 @@
 # each for FETCH_SIZE, WRITE_SIZE, the SQ set and the instruction-cache set, on ONE pass at a time (--inflight 1: the
 # counters serialise dispatches anyway; never combined with trace domains).
 # usage: tools/profile_round.sh r03   -> gpurun_out/{prof_<tag>,pmc_*}
-tag=${1:-r04}
+tag=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --profiled 1 --cpu-sample 0 --budget-mib 0 --pcie 0"
