@@ -354,13 +354,35 @@ enum { R_SAME = 0, R_NEW = 1 };
 // tr_base = where the Meta list in hand begins: Muta([Bin], []) (b64 / sgm / js inner runs, nested_fuzz) and
 // mutate_once_loop(Mutator, [], ..) (cp, ar) start lists of their own, and sgml_mutate / json_mutate return NewMeta ALONE when the
 // block comes back unchanged (erlamsa_sgml.erl:748-749, erlamsa_json.erl:722-723), which drops what the list in hand held before.
+// (The emitters are functions of their own, called only when a trace is kept: inlined into the scheduler loop they cost the
+// kernel 7 % of its wave cycles with tracing OFF - 18 % on cases that nest thousands of scheduler calls -, measured on the
+// build that first had them, profiles/r05_bench_after_tests_same_call.json against r05_bench_driver_command_mid_round.json.)
 EH_DEV void tr_b(Ctx& c, uint32_t v) {
   if (c.ntrace < TRACE_CAP - 1) { if (EH_LANE == 0) c.trace[c.ntrace] = (uint8_t)v; c.ntrace++; }
   else { if (EH_LANE == 0) c.trace[TRACE_CAP - 1] = 0xFF; c.ntrace = TRACE_CAP; }
 }
 EH_DEV void tr_v(Ctx& c, uint64_t v) { while (v >= 128) { tr_b(c, (uint32_t)(v & 127u) | 128u); v >>= 7; } tr_b(c, (uint32_t)v); }
-EH_DEV void tr_aa(Ctx& c, int a, int b) { if (!c.trace) return; tr_b(c, TRK_AA); tr_b(c, (uint32_t)a); tr_b(c, (uint32_t)b); }
-EH_DEV void tr_ai(Ctx& c, int a, int64_t v) { if (!c.trace) return; tr_b(c, TRK_AI); tr_b(c, (uint32_t)a); tr_v(c, ((uint64_t)v << 1) ^ (uint64_t)(v >> 63)); }
+__device__ __noinline__ void tr_aa_emit(int a, int b) { Ctx& c = g_ctx; tr_b(c, TRK_AA); tr_b(c, (uint32_t)a); tr_b(c, (uint32_t)b); }
+__device__ __noinline__ void tr_ai_emit(int a, int64_t v) { Ctx& c = g_ctx; tr_b(c, TRK_AI); tr_b(c, (uint32_t)a); tr_v(c, ((uint64_t)v << 1) ^ (uint64_t)(v >> 63)); }
+// kind byte + up to five LEB128 operands (sizer, csum, skipped)
+__device__ __noinline__ void tr_kv_emit(int kind, int nb, uint32_t b0, uint32_t b1, int nv, uint64_t v0, uint64_t v1, uint64_t v2) {
+  Ctx& c = g_ctx;
+  tr_b(c, (uint32_t)kind);
+  if (nb > 0) tr_b(c, b0);
+  if (nb > 1) tr_b(c, b1);
+  if (nv > 0) tr_v(c, v0);
+  if (nv > 1) tr_v(c, v1);
+  if (nv > 2) tr_v(c, v2);
+}
+// {archiver, Name}: `up` x "../" in front of the name
+__device__ __noinline__ void tr_name_emit(const uint8_t* nm, uint32_t nl, uint32_t up) {
+  Ctx& c = g_ctx;
+  tr_b(c, TRK_ARCHIVER); tr_v(c, nl + 3u * up);
+  for (uint32_t k = 0; k < up; k++) { tr_b(c, '.'); tr_b(c, '.'); tr_b(c, '/'); }
+  for (uint32_t k = 0; k < nl; k++) tr_b(c, uni(nm[k]));
+}
+EH_DEV void tr_aa(Ctx& c, int a, int b) { if (__builtin_expect(c.trace != nullptr, 0)) tr_aa_emit(a, b); }
+EH_DEV void tr_ai(Ctx& c, int a, int64_t v) { if (__builtin_expect(c.trace != nullptr, 0)) tr_ai_emit(a, v); }
 // drops the events [tr_base, start) of the list in hand (see above); what came after start moves down
 EH_DEV void tr_drop_before(Ctx& c, uint32_t start) {
   if (!c.trace || start <= c.tr_base || c.ntrace >= TRACE_CAP) return;
@@ -866,8 +888,8 @@ constexpr OwnTab own_atoms() {
   return t;
 }
 __constant__ OwnTab c_own_atom = own_atoms();
-EH_DEV void own_meta(Ctx& c, uint32_t fn, int delta, uint32_t hlen) {
-  if (!c.trace) return;
+__device__ __noinline__ void own_meta_emit(uint32_t fn, int delta, uint32_t hlen) {
+  Ctx& c = g_ctx;
   const int nm = (int)c_own_atom.v[fn];
   switch (fn) {
     case M_BD: case M_BEI: case M_BED: case M_BF: case M_BI: case M_BER: case M_BR: case M_UW: case M_UI:
@@ -884,6 +906,7 @@ EH_DEV void own_meta(Ctx& c, uint32_t fn, int delta, uint32_t hlen) {
     default: break;
   }
 }
+EH_DEV void own_meta(Ctx& c, uint32_t fn, int delta, uint32_t hlen) { if (__builtin_expect(c.trace != nullptr, 0)) own_meta_emit(fn, delta, hlen); }
 
 // One call of the mux_fuzzers closure on the list bl[cur..nb).
 EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
@@ -932,7 +955,6 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
     if (stateful) { const uint32_t* ax = (const uint32_t*)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) g_st_save[i] = ax[i]; }
     int delta, last_tier = 0;
     for (;;) {
-      c.m_aux = -1;
       delta = run_mutator(c, fn, em_mask(meta));
       if (c.status != CASE_OVERFLOW || c.ovf_need == 0) break;
       wave_sync();

@@ -434,12 +434,7 @@ __device__ __noinline__ uint64_t ar_step(Ctx&, uint32_t e_pri, uint32_t e_meta, 
       if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 319); return keep; }
       blk_store(c.bl, c.cur, uni64(es[idx].data), uni(es[idx].data_len));
       c.nb = c.cur + 1;
-      if (c.trace) {                                                                    // [NM, {archiver, N} | Acc] :183: the name, then what the file's evaluation adds (a list of its own)
-        const uint8_t* nm = (const uint8_t*)uni64(es[idx].name); const uint32_t nl = uni(es[idx].name_len), up = uni(es[idx].up);
-        tr_b(c, TRK_ARCHIVER); tr_v(c, nl + 3u * up);
-        for (uint32_t k = 0; k < up; k++) { tr_b(c, '.'); tr_b(c, '.'); tr_b(c, '/'); }
-        for (uint32_t k = 0; k < nl; k++) tr_b(c, uni(nm[k]));
-      }
+      if (c.trace) tr_name_emit((const uint8_t*)uni64(es[idx].name), uni(es[idx].name_len), uni(es[idx].up));   // [NM, {archiver, N} | Acc] :183: the name, then what the file's evaluation adds (a list of its own)
       if (EH_LANE == 0) sd->tr_base0 = c.tr_base;
       c.tr_base = c.ntrace;
       if (EH_LANE == 0) {
@@ -563,7 +558,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
             const uint8_t* H = (const uint8_t*)b.ptr;
             if (pat == P_SK) {                                                        // mutate_once_skipper :146-161
               uint32_t len = rng_rand(c.rng, b.len / 2);
-              if (c.trace) { tr_b(c, TRK_SKIPPED); tr_v(c, len); }                     // [{skipped, Len/8} | Meta] :154
+              if (c.trace) tr_kv_emit(TRK_SKIPPED, 0, 0, 0, 1, len, 0, 0);             // [{skipped, Len/8} | Meta] :154
               emit_ref(c, b.ptr, len);
               blk_store(c.bl, c.cur, b.ptr + len, b.len - len);
               wave_sync();
@@ -581,7 +576,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               if (r < 0) break;
               if (r == 0) tr_aa(c, AT_sizer, AT_failed);                              // [{sizer, failed} | Meta] :85
               if (r == 1) {
-                if (c.trace) { tr_b(c, TRK_SIZER); tr_b(c, e.size_bits / 8); tr_b(c, e.big ? 1u : 0u); tr_v(c, e.len); tr_v(c, e.a); tr_v(c, e.b); }   // [{sizer, Elem} | Meta] :97
+                if (c.trace) tr_kv_emit(TRK_SIZER, 2, e.size_bits / 8, e.big ? 1u : 0u, 3, e.len, e.a, e.b);   // [{sizer, Elem} | Meta] :97
                 uint32_t nbytes = e.size_bits / 8;
                 if ((uint64_t)e.a + nbytes + e.len > b.len) { c.status = CASE_CRASHED; break; }
                 if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 306); break; }
@@ -604,7 +599,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               if (r < 0) break;
               if (r == 0) tr_aa(c, AT_csum, AT_failed);                               // :119
               if (r == 1) {
-                if (c.trace) { tr_b(c, TRK_CSUM); tr_b(c, iscrc); tr_v(c, plen); tr_v(c, blen); }   // [{csum, Elem} | Meta] :131
+                if (c.trace) tr_kv_emit(TRK_CSUM, 1, iscrc, 0, 2, plen, blen, 0);      // [{csum, Elem} | Meta] :131
                 if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 307); break; }
                 emit_ref(c, b.ptr, plen);                                             // P
                 if (EH_LANE == 0) {

@@ -94,7 +94,7 @@ def corpus(n, seed, scale=1, small=False):
             body = b"".join(attr() for _ in range(n))
             end = [b">", b"/>", b" />", b"", b"=>", b"='never closed ", b" = ", b">"][int(rng3.integers(0, 8))]
             return b"<" + w3(1, 6) + b" " + body + end
-        natt = max(40, int(rng3.integers(300, 6000)) * scale // (10 if small else 1))
+        natt = max(40, int(rng3.integers(300, 6000)) * scale // (40 if small else 1))
         out.append(b"<doc>" + b"".join(bigtag(int(rng3.integers(17, natt))) + w3(0, 40) + (b"</x>" if rng3.random() < 0.3 else b"") for _ in range(int(rng3.integers(1, 7)))) + b"</doc>")
     if small:
         out = [d for k, d in enumerate(out) if k % 15 >= 6]                                  # the kinds without a period: what the lane batches are for (the periodic ones need their full length anyway)

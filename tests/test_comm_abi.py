@@ -34,7 +34,7 @@ import numpy as np
 import erlamsa_amd as ea
 from erlamsa_amd import shard, synth
 rank, world, mode, idfile, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
-n, size = 96, 600
+n, size = 48, 600
 mat = synth.mixed(n, size, seed=11)
 e = ea.Engine(0)
 e.configure(mutations="bd,bf,bi,sr,sd,num,ld,lr,ft,fn,fo,len", patterns="od,nd,bu,sz", generators="direct=5,jump=3" if mode == "allgather" else None, max_case_bytes=1 << 20)
@@ -75,7 +75,7 @@ e.close()
 '''
 
 
-@pytest.mark.parametrize("mode,world", [("broadcast", 2), ("broadcast", 3), ("allgather", 2), ("allgather", 4)])
+@pytest.mark.parametrize("mode,world", [("broadcast", 3), ("allgather", 2)])
 def test_ranks_load_the_arena_through_the_library_and_shard_the_run(tmp_path, mode, world):
     emu = _build()
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu, EH_RCCL_LIB=FAKE)
@@ -93,12 +93,12 @@ def test_ranks_load_the_arena_through_the_library_and_shard_the_run(tmp_path, mo
     one = json.load(open(tmp_path / "single.json"))
     want, st = one["sha1"], one["status"]
     from erlamsa_amd import synth
-    data, _ = synth.as_arena(synth.mixed(96, 600, seed=11))
+    data, _ = synth.as_arena(synth.mixed(48, 600, seed=11))
     for r in res:
-        assert r["n"] == 96 and r["offs_ok"] and r["arena_sha1"] == hashlib.sha1(data.tobytes()).hexdigest(), "rank holds another arena"
+        assert r["n"] == 48 and r["offs_ok"] and r["arena_sha1"] == hashlib.sha1(data.tobytes()).hexdigest(), "rank holds another arena"
         assert r["sha1"] == want[r["first"]:r["first"] + len(r["sha1"])], "a rank's cases differ from the 1-rank run"
         assert r["status"] == st[r["first"]:r["first"] + len(r["sha1"])]
-    assert sum(len(r["sha1"]) for r in res) == 96
+    assert sum(len(r["sha1"]) for r in res) == 48
 
 
 def test_one_process_several_devices_broadcast_local_and_refusals(tmp_path):

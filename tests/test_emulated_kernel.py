@@ -130,13 +130,13 @@ def test_emulated_sgml_lane_batches_and_base64_wave_decode(emu_lib):
     """Round 4's last two changes on the emulator.  csrc/eh_sgml.h: tag attempts one per lane from any text state (runs of failed
     attempts, the machine's memos read and fed by the lanes, names over thousands of events through the next-stop table, a batch per
     accepted tag inside periodic stretches) against the wave-wide machine alone (EH_FLAG_SGML_NO_REPLAY | EH_FLAG_SGML_NO_LANES) and the
-    oracle, on the 7 kinds of documents without a period and the one with failing runs inside its periods of tests/hipemu/emu_sgml_replay.py (tag soup, runs of failing attempts, tags of
+    oracle, on the 8 kinds of documents without a period (round 5: tags of thousands of attributes in every attribute syntax) and the one with failing runs inside its periods of tests/hipemu/emu_sgml_replay.py (tag soup, runs of failing attempts, tags of
     thousands of attributes, names over thousands of '<' ...) at a tenth of their length.  csrc/eh_lex.h
     b64_decode_wave: every padding, white space inside groups / the padding, long blobs, refused chunks (tests/hipemu/emu_b64.py).
     The GPU runs both scripts at full length (tests/test_gpu_round4.py)."""
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_sgml_replay.py"), "1", "5", "1", "small"], env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and "cases 8 bad 0" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "cases 9 bad 0" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_b64.py"), "1", "2"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout + r.stderr
 
