@@ -2197,6 +2197,18 @@ int eh_pool_stats(eh_ctx* ctx, uint64_t* out /* 64 values */) {
   out[61] = (uint64_t)ctx->pool->refs; out[62] = ctx->nslots; out[63] = 0;
   return EH_OK;
 }
+// Has the last batch of this context finished (results ready, the context free for the next batch)?  Never blocks: what a host
+// that keeps several contexts busy polls to give the next batch to WHICHEVER context is free, instead of waiting for the oldest.
+int eh_batch_done(eh_ctx* ctx, int* done) {
+  if (!ctx || !done) return EH_E_INVALID;
+  *done = 1;
+  if (!ctx->have_result) return EH_OK;
+  hipError_t e = hipEventQuery(ctx->ev1);
+  if (e == hipSuccess) return EH_OK;
+  if (e == hipErrorNotReady) { *done = 0; (void)hipGetLastError(); return EH_OK; }
+  ctx->err = std::string("hipEventQuery: ") + hipGetErrorString(e);
+  return EH_E_HIP;
+}
 int eh_last_kernel_ms(eh_ctx* ctx, float* ms) {
   if (!ctx || !ms) return EH_E_INVALID;
   if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "eh_coalesce_limits", "eh_submit", "eh_flush", "eh_poll", "eh_cancel",
     "eh_corpus_device", "eh_stream", "eh_host_alloc", "eh_host_free", "eh_selftest_sort_by_priority", "eh_last_error_copy",
     "eh_comm_unique_id", "eh_comm_init", "eh_comm_init_local", "eh_comm_destroy", "eh_corpus_broadcast", "eh_corpus_allgather",
-    "eh_corpus_broadcast_local", "eh_device_count", "eh_meta_atom_count", "eh_meta_atom_name",
+    "eh_corpus_broadcast_local", "eh_device_count", "eh_meta_atom_count", "eh_meta_atom_name", "eh_batch_done",
 ]
 
 
@@ -79,6 +79,7 @@ def load_library():
     lib.eh_fuzz_batch.argtypes = [vp, i64p, C.c_uint64, C.c_uint64, C.c_uint64, vp]
     lib.eh_fuzz_calls.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp]
     lib.eh_sync.argtypes = [vp]
+    lib.eh_batch_done.argtypes = [vp, C.POINTER(C.c_int)]
     lib.eh_reserve.argtypes = [vp, C.c_uint64]
     lib.eh_result_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u64p]
     lib.eh_result_download.argtypes = [vp, vp, C.c_uint64, vp, vp]
@@ -304,6 +305,12 @@ class Engine:
 
     def sync(self):
         self._chk(self.lib.eh_sync(self.h))
+
+    def done(self):
+        """has the last batch finished?  (eh_batch_done: never blocks)"""
+        d = C.c_int()
+        self._chk(self.lib.eh_batch_done(self.h, C.byref(d)))
+        return bool(d.value)
 
     def totals(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -38,7 +38,7 @@ def rank_env(env=None):
 
 def run_steps(engines, streams, first_step, steps, rank, world, n, seed, on_result=None, strong=False):
     """The step loop of bench.py (and of tests/test_dist_gloo.py): step k of this rank is one eh_fuzz_batch over the
-    whole attached corpus with case numbers weak_first_case(k, rank, world, n).., on context k % len(engines) and that
+    whole attached corpus with case numbers weak_first_case(k, rank, world, n).., on whichever context is free (eh_batch_done) and that
     context's stream (strong=True: step k is ONE run of n cases over all ranks — this rank takes case_range(n, rank, world)
     of it, the shape of erlamsa_main:get_threading_mode/3); a context's previous results are collected before it is reused.
     `streams` are raw stream handles (0 = the null stream).  Returns {"out_bytes", "kernel_ms": [...], "status_counts": int64[6]}; `on_result(step,
@@ -47,8 +47,8 @@ def run_steps(engines, streams, first_step, steps, rank, world, n, seed, on_resu
     nctx = len(engines)
     res = {"out_bytes": 0, "kernel_ms": [], "status_counts": np.zeros(6, dtype=np.int64)}
 
-    def collect(k):
-        e = engines[k % nctx]
+    def collect_ctx(ci, k):
+        e = engines[ci]
         _, ob, _ = e.totals()                         # waits for that context's batch
         res["out_bytes"] += ob
         res["kernel_ms"].append(e.kernel_ms())        # HIP events recorded on the launch stream inside the library
@@ -56,17 +56,28 @@ def run_steps(engines, streams, first_step, steps, rank, world, n, seed, on_resu
         if on_result is not None:
             on_result(k, e)
 
+    # A step goes to WHICHEVER context is free.  Passes do not end in the order they were launched (a pass lasts as long as its
+    # heaviest case, 0.75 - 2 s alone), and waiting for the oldest one leaves contexts - and, once their workgroups have left, the
+    # device - idle behind one long tail.
+    import time
+    busy = {}                                          # context index -> step it runs
+    free = list(range(nctx))
     for k in range(first_step, first_step + steps):
-        if k - first_step >= nctx:
-            collect(k - nctx)
+        while not free:
+            for ci in list(busy):
+                if engines[ci].done():
+                    collect_ctx(ci, busy.pop(ci)); free.append(ci)
+            if not free:
+                time.sleep(0.0005)
+        ci = free.pop(0)
         if strong:
             first, cnt = case_range(n, rank, world)
-            engines[k % nctx].fuzz_batch(seed=seed, first_case=k * n + first + 1, corpus_first=first, n=cnt, stream=streams[k % nctx])
+            engines[ci].fuzz_batch(seed=seed, first_case=k * n + first + 1, corpus_first=first, n=cnt, stream=streams[ci])
         else:
-            engines[k % nctx].fuzz_batch(seed=seed, first_case=weak_first_case(k, rank, world, n), corpus_first=0, n=n,
-                                         stream=streams[k % nctx])
-    for k in range(max(first_step, first_step + steps - nctx), first_step + steps):
-        collect(k)
+            engines[ci].fuzz_batch(seed=seed, first_case=weak_first_case(k, rank, world, n), corpus_first=0, n=n, stream=streams[ci])
+        busy[ci] = k
+    for ci in sorted(busy, key=lambda c: busy[c]):
+        collect_ctx(ci, busy[ci])
     return res
 
 

@@ -197,6 +197,10 @@ int eh_fuzz_batch(eh_ctx* ctx, const int64_t seed[3], uint64_t first_case, uint6
 /* Case i is its own fuzzer/1 run (n = 1) with seed seeds[3i..3i+2] (host pointer). */
 int eh_fuzz_calls(eh_ctx* ctx, const int64_t* seeds, uint64_t corpus_first, uint64_t n, void* stream);
 int eh_sync(eh_ctx* ctx);
+/* Non-blocking: *done = 1 when the context's last batch has finished (or none was launched).  A host that keeps several contexts
+ * busy polls this to hand the next batch to whichever context is free (bench.py / erlamsa_amd/shard.py run_steps); no reference
+ * counterpart (BEAM's receive ... after does the same for its worker processes, erlamsa_main.erl:211-220). */
+int eh_batch_done(eh_ctx* ctx, int* done);
 
 /* Request coalescing for services — what erlamsa_fsupervisor / erlamsa_esi do one request at a time
  * (erlamsa_esi.erl:86-95 call_fuzzer/3 -> erlamsa_fsupervisor:get_fuzzing_output/1, erlamsa_fsupervisor.erl:60-86: one

@@ -238,6 +238,7 @@ template <class T, class U, class V> inline T atomicCAS(T* p, U cmp, V v) { HIPE
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
 constexpr hipError_t hipErrorOutOfMemory = 2;
+constexpr hipError_t hipErrorNotReady = 600;
 typedef void* hipStream_t;
 struct hipemu_event { std::chrono::steady_clock::time_point t; };
 typedef hipemu_event* hipEvent_t;
@@ -286,6 +287,7 @@ inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = *tot = (size_t)
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event(); return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }   // (launches are synchronous here: whatever was recorded has happened)
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
 
