@@ -305,23 +305,65 @@ def main():
         # The arena reaches every GPU through the LIBRARY's own RCCL calls (include/erlamsa_hip.h "multi-GPU", csrc/eh_comm.h) - the path a
         # host without a HIP / RCCL binding (the BEAM) takes; torch.distributed only carries the 128 bytes of the unique id, the barriers
         # and the reduction of the result.  EH_BENCH_BACKEND=gloo: the same calls with tests/hipemu/fake_rccl.cpp behind EH_RCCL_LIB.
-        uid = [ea.Engine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        engines[0].comm_init(uid[0], rank, world)
-        if args.corpus == "counter":
-            # BASELINE configs[4]: every rank brings ITS shard (closed form of seed, row, byte - no file to read), all-gathered in place:
-            # each xGMI link carries 1 / world of the arena instead of one root feeding everybody
-            per = n // world
-            assert per * world == n, "--cases must be a multiple of the number of ranks for the all-gathered counter corpus"
-            shard_rows = np.concatenate([synth.counter(range(r0, min(r0 + 4096, (rank + 1) * per)), size) for r0 in range(rank * per, (rank + 1) * per, 4096)])
-            engines[0].corpus_allgather(*synth.as_arena(shard_rows))
-            del shard_rows
+        def agree(ok):                                             # every rank takes the same path: all succeeded, or all fall back
+            flags = [None] * world
+            dist.all_gather_object(flags, bool(ok))
+            return all(flags)
+        transport = "library"
+        try:
+            uid = [ea.Engine.comm_unique_id() if rank == 0 else None]
+            ok = True
+        except ea.EngineError as ex:
+            log("rank %d: %s" % (rank, ex)); uid, ok = [None], False
+        if agree(ok):
+            dist.broadcast_object_list(uid, src=0)
+            try:
+                engines[0].comm_init(uid[0], rank, world)
+                ok = True
+            except ea.EngineError as ex:
+                log("rank %d: eh_comm_init: %s" % (rank, ex)); ok = False
+            if not agree(ok):
+                transport = "torch"
         else:
-            if rank == 0:
-                mat = synth.mixed(n, size) if args.corpus == "mixed" else synth.uniform(n, size)
-                engines[0].corpus_broadcast(0, *synth.as_arena(mat))
+            transport = "torch"
+        if transport == "library":
+            try:
+                if args.corpus == "counter":
+                    # BASELINE configs[4]: every rank brings ITS shard (closed form of seed, row, byte - no file to read), all-gathered in place:
+                    # each xGMI link carries 1 / world of the arena instead of one root feeding everybody
+                    per = n // world
+                    assert per * world == n, "--cases must be a multiple of the number of ranks for the all-gathered counter corpus"
+                    shard_rows = np.concatenate([synth.counter(range(r0, min(r0 + 4096, (rank + 1) * per)), size) for r0 in range(rank * per, (rank + 1) * per, 4096)])
+                    engines[0].corpus_allgather(*synth.as_arena(shard_rows))
+                    del shard_rows
+                else:
+                    if rank == 0:
+                        mat = synth.mixed(n, size) if args.corpus == "mixed" else synth.uniform(n, size)
+                        engines[0].corpus_broadcast(0, *synth.as_arena(mat))
+                    else:
+                        engines[0].corpus_broadcast(0)
+                ok = engines[0].n_corpus == n
+            except ea.EngineError as ex:
+                log("rank %d: the library's collective failed: %s" % (rank, ex)); ok = False
+            if not agree(ok):
+                transport = "torch"
+        if transport == "torch":
+            # fall-back (never taken in the tests): the arena as a torch tensor, broadcast by torch.distributed, attached to the context
+            log("rank %d: the library's RCCL path is not available here - arena over torch.distributed" % rank)
+            import torch
+            arena = torch.empty(n * size, dtype=torch.uint8, device=dev)
+            offs = torch.arange(n + 1, dtype=torch.int64, device=dev) * size
+            if args.corpus == "counter":
+                synth.counter_torch(arena, 0, n, size)
             else:
-                engines[0].corpus_broadcast(0)
+                if rank == 0:
+                    mat = synth.mixed(n, size) if args.corpus == "mixed" else synth.uniform(n, size)
+                    arena.copy_(torch.from_numpy(mat.reshape(-1)))
+                shard.broadcast_corpus(arena, offs, src=0)
+            if on_gpu:
+                torch.cuda.synchronize()
+            engines[0].attach_corpus(arena.data_ptr(), offs.data_ptr(), n, n * size)
+            keep_alive = (arena, offs)
         assert engines[0].n_corpus == n
     for e in engines[1:]:
         e.share_corpus(engines[0])
@@ -459,7 +501,8 @@ def main():
                                ",".join(m for m, _, _ in ea.mutator_table() if m not in [x.split("=")[0] for x in muts.split(",")]) or "none"),
                 "world_size_seen_by_torch_distributed": (dist.get_world_size() if dist is not None else 1),
                 "arena_equal_on_all_ranks": arena_same,
-                "arena_transport": (None if world == 1 else "eh_corpus_allgather (RCCL inside the library, per-rank shards)" if args.corpus == "counter" else "eh_corpus_broadcast (RCCL inside the library, root = rank 0)"),
+                "arena_transport": (None if world == 1 else "torch.distributed broadcast + eh_corpus_attach (fall-back: the library's RCCL path failed here, see stderr)" if transport == "torch" else
+                                    "eh_corpus_allgather (RCCL inside the library, per-rank shards)" if args.corpus == "counter" else "eh_corpus_broadcast (RCCL inside the library, root = rank 0)"),
                 "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, no collective on the mutation path" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream, one after the other, before the W warm-up steps",
                 "max_case_bytes": args.case_mib << 20, "big_case_bytes": args.big_mib << 20, "max_case_work": args.work_mib << 20,
                 "workgroups_per_pass": args.max_slots or "one per wavefront the device holds (8 per CU)", "pool_gib": args.pool_gib,

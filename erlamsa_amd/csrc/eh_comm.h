@@ -37,9 +37,15 @@ inline Api* api() {
   std::lock_guard<std::mutex> g(m);
   if (a.h) return &a;
   const char* name = getenv("EH_RCCL_LIB");
-  if (!name || !*name) name = "librccl.so";
-  void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-  if (!h && !getenv("EH_RCCL_LIB")) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  void* h = nullptr;
+  if (!name || !*name) {
+    // a host that has RCCL in the process already (torch brings its own copy) shares that instance; otherwise the system's
+    name = "librccl.so";
+    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  } else h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
   if (!h) { a.err = std::string("cannot load RCCL (") + name + "): " + (dlerror() ? dlerror() : "?"); return &a; }
   bool ok = true;
   auto sym = [&](const char* s) -> void* { void* p = dlsym(h, s); if (!p) { ok = false; a.err = std::string("RCCL symbol missing: ") + s; } return p; };

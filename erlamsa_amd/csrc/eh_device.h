@@ -285,6 +285,7 @@ struct Ctx {
   uint64_t lex_ptr[LEX_LEVELS];   // block the lex cache of nesting level d holds a table for (mirror of LexCache::ptr; 0: none)
   uint8_t* trace;      // EH_FLAG_META_TRACE: the case's event bytes (slot memory), nullptr = off
   uint32_t ntrace, tr_base;   // bytes written; where the Meta list in hand begins (tr_drop_before)
+  uint64_t t_case;     // cycle stamp at which the case began (mux_fuzzers raises the wavefront's issue priority for cases that run long)
   int32_t m_aux;       // set by the mutators whose own Meta entry does not follow from their result alone (num: a number found; ab / ad: stringy)
   uint64_t ws_peak, ws_top;   // diagnostics: highest ws_used, bytes taken from the top of chunks (eh_result_peak)
   int status;
@@ -928,6 +929,11 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
     uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
     rank += (kj > key || (kj == key && j < l)) ? 1u : 0u;
   }
+  // A case that has been running for long decides when its pass ends (one wavefront, seconds): from 20 M cycles on its wavefront
+  // issues ahead of the other wavefront of its SIMD (s_setprio; the ticket loop puts it back when the case is done).
+#ifndef HIPEMU
+  if (__builtin_readcyclecounter() - c.t_case > 20000000ull) __builtin_amdgcn_s_setprio(3);
+#endif
   // --- mux_fuzzers_loop
   int tried = 0; bool used = false; bool dropped = false;
   Blk h0 = blk_load(c.bl, c.cur);

@@ -851,6 +851,11 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     uint64_t i = tk_next++;
     if (i >= p.n) break;
     uint64_t tick0 = __builtin_readcyclecounter();
+#ifndef HIPEMU
+    c.t_case = tick0;
+#else
+    c.t_case = 0;                                                          // the emulator's lanes read their own clocks
+#endif
     c.nchunk = 0; c.ws_peak = 0; c.ws_top = 0;
     c.trace = (p.flags & EH_FLAG_META_TRACE) ? trace0 : nullptr; c.ntrace = 0; c.tr_base = 0; c.m_aux = -1;
     c.ch_vstart[0] = 0; c.ch_vend[0] = p.work_cap; c.ch_base[0] = ws0; c.ch_tier[0] = 0; c.ch_area[0] = slot_id;
@@ -928,6 +933,9 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
       else wave_copy(p.out + tbase, c.trace, c.ntrace);
     }
     EH_PH(3);
+#ifndef HIPEMU
+    __builtin_amdgcn_s_setprio(0);                                      // (mux_fuzzers raises it for cases that run long)
+#endif
     // larger areas the case borrowed go back to the pool (the output has been copied out of them)
     wave_sync();
     if (c.nchunk > 0) ws_release_to(c, 0);
