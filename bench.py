@@ -530,6 +530,9 @@ def main():
         }
         if strong_leg is not None:
             res["strong_scaling_leg"] = strong_leg
+        # the host thread of the timed loop, per step: collecting a finished pass (totals, statuses: D2H copies), the case statistics,
+        # eh_fuzz_batch itself, and waiting with every context busy
+        res["host_loop_ms_per_step"] = {k: round(v * 1000.0 / (1 if k.endswith("_max") else max(args.steps, 1)), 2) for k, v in timed["host_loop_s"].items()}
         if args.case_stats and len_hist:
             # How the headline is made: the default table pumps (sr, lr, tr, sgm, fuse repeat data), so a small share
             # of the cases carries most of the bytes and of the wave cycles.

@@ -416,6 +416,11 @@ EH_DEV uint32_t pool_pop(const KParams& p, int t) {
       atomicAdd(&p.pool_ctr[20 + t], (unsigned long long)(__builtin_readcyclecounter() - w0));
       atomicAdd(&p.pool_ctr[30 + t], 1ull);
     }
+    // the most areas of the tier wanted at the same time (eh_pool_stats): what says how to split the pool's memory over the tiers
+    // (holders + wavefronts waiting for one, so it can exceed the tier's size)
+    unsigned long long back = atomicAdd(&p.pool_ctr[2 * t + 1], 0ull);
+    unsigned long long outn = h + 1 + p.pool_cnt[t] > back ? h + 1 + p.pool_cnt[t] - back : 0;
+    atomicMax(&p.pool_ctr[40 + t], outn);
   }
 #ifndef EH_NO_POOL_FENCE
   __threadfence();                                                   // the previous owner's stores (another XCD's L2) are behind us

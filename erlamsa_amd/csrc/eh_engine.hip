@@ -1,7 +1,7 @@
 // eh_engine.hip — kernels + C ABI of liberlamsa_hip.so (see include/erlamsa_hip.h).
 //
 // Kernels (gfx950 only):
-//   eh_setup_kernel   : per-run setup of erlamsa_main:fuzzer/1 (one wavefront)
+//   eh_prologue_kernel: counters + argument block of a batch, per-run setup of erlamsa_main:fuzzer/1 (one wavefront)
 //   eh_mutate_kernel  : persistent grid, one wavefront per case, cases pulled from a ticket
 //                       counter; runs generator -> pattern -> mux_fuzzers -> mutators and
 //                       writes each case's output into a bump-allocated arena.
@@ -132,10 +132,27 @@ EH_DEV void setup_run(const DevConfig& cfg, int64_t s1, int64_t s2, int64_t s3, 
   }
 }
 
-__global__ void __launch_bounds__(64) eh_setup_kernel(DevConfig cfg, int64_t s1, int64_t s2, int64_t s3, RunState* out) {
-  Rng rng; int gen, mask, nfs; uint32_t e_pri, e_meta;
-  setup_run(cfg, s1, s2, s3, rng, gen, mask, e_pri, e_meta, nfs);
+// One wavefront in front of every eh_mutate_kernel: the batch's counters back to zero, its argument block written to device memory,
+// and (mode 0) the run state of the parent seed.  The runtime's own fill and copy kernels (hipMemsetAsync, hipMemcpyAsync from
+// pageable memory) are workgroups of 256 work-items: four wavefronts that must find room on ONE compute unit at the same moment.
+// On a device whose every slot is held by the one-wavefront workgroups of the passes in flight, and whose freed slots go to the
+// next of those one at a time, they starve - 0.17 s on average and up to 0.8 s per launch with six passes in flight, seconds with
+// twelve (profiles/r05_kernel_stats_before_prologue.csv) - and the pass behind them with them.  A one-wavefront kernel takes the
+// next free slot like any other workgroup of the batch (the old eh_setup_kernel: 29 us on average in the same trace).
+__global__ void __launch_bounds__(64) eh_prologue_kernel(KParams p, int64_t s1, int64_t s2, int64_t s3, RunState* out, KParams* params_out,
+                                                         unsigned long long* counters) {
   const int l = EH_LANE;
+  for (int i = l; i < 512; i += 64) counters[i] = 0;             // ticket, output cursor, input bytes, prof slots: 4096 bytes
+#ifdef EH_PROF
+  if (l == 0) counters[8 + 2 * 127] = ~0ull;                     // earliest workgroup start: atomicMin
+#endif
+  static_assert(sizeof(KParams) % 4 == 0, "KParams is copied word by word");
+  const uint32_t* src = (const uint32_t*)&p;
+  uint32_t* dst = (uint32_t*)params_out;
+  for (int i = l; i < (int)(sizeof(KParams) / 4); i += 64) dst[i] = src[i];
+  if (p.mode != 0) return;
+  Rng rng; int gen, mask, nfs; uint32_t e_pri, e_meta;
+  setup_run(p.cfg, s1, s2, s3, rng, gen, mask, e_pri, e_meta, nfs);
   if (l == 0) { out->a1 = rng.a1; out->a2 = rng.a2; out->a3 = rng.a3; out->gen = gen; out->nfs = nfs; out->snand_mask = mask; }
   if (l < nfs) { out->fs_name[l] = (uint8_t)em_name(e_meta); out->fs_score[l] = (uint8_t)em_score(e_meta); out->fs_pri[l] = e_pri; }
 }
@@ -1209,7 +1226,12 @@ static int pool_acquire(eh_ctx* ctx, uint64_t work_cap, uint64_t big, uint64_t p
   // Round 4: the large tiers get three times what they had.  With 2 areas of 1 GiB and 2 of 512 MiB for six passes in flight the
   // heaviest cases of the passes queued for each other (eh_pool_stats of a bench run: ~130 waits of 1.8 G ticks each for the last
   // tier alone, 1.8 - 3.2 T ticks of sleeping wavefronts per run), which stretched exactly the cases that decide how long a pass lasts.
-  static const uint32_t SHARE[POOL_TIERS] = {12, 23, 17, 7, 10, 10, 9, 12};
+  uint32_t SHARE[POOL_TIERS] = {12, 23, 17, 7, 10, 10, 9, 12};
+  if (const char* ev = getenv("EH_POOL_SHARES")) {                                 // (measurement knob: eight numbers, smallest tier first)
+    uint32_t v[POOL_TIERS]; int k = 0;
+    for (const char* q = ev; *q && k < POOL_TIERS; ) { char* end = nullptr; unsigned long x = strtoul(q, &end, 10); if (end == q) break; v[k++] = (uint32_t)x; q = *end ? end + 1 : end; }
+    if (k == POOL_TIERS) { bool ok = true; for (int i = 0; i < k; i++) ok = ok && v[i] >= 1 && v[i] <= 1000; if (ok) memcpy(SHARE, v, sizeof(v)); }
+  }
   size_t fr = 0, tot = 0;
   hipError_t e = hipSuccess;
   uint64_t pool_bytes = pool_bytes_opt;
@@ -1288,10 +1310,6 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   int rc = reserve(ctx, n, in_bytes);
   if (rc) return rc;
   if (!ctx->d_counters) { HIPCHK(ctx, hipMalloc(&ctx->d_counters, 4096)); HIPCHK(ctx, hipMalloc(&ctx->d_run, sizeof(RunState))); HIPCHK(ctx, hipMalloc(&ctx->d_params, sizeof(KParams))); }
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 4096, st));
-#ifdef EH_PROF
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_counters + 8 + 2 * 127, 0xFF, 8, st));   // earliest workgroup start: atomicMin
-#endif
 
   KParams p;
   memset(&p, 0, sizeof(p));
@@ -1311,9 +1329,10 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   // oversubscribe the device: the dispatcher starts a batch's workgroups as those of earlier ones leave.
   uint32_t grid0 = ctx->nslots < n ? ctx->nslots : (uint32_t)n;
 
-  if (mode == 0) hipLaunchKernelGGL(eh_setup_kernel, dim3(1), dim3(64), 0, st, ctx->cfg, seed[0], seed[1], seed[2], ctx->d_run);
+  // counters, argument block and run state by ONE one-wavefront kernel (no fill / copy kernels of the runtime: see eh_prologue_kernel)
+  hipLaunchKernelGGL(eh_prologue_kernel, dim3(1), dim3(64), 0, st, p, mode == 0 ? seed[0] : 0, mode == 0 ? seed[1] : 0, mode == 0 ? seed[2] : 0,
+                     ctx->d_run, ctx->d_params, ctx->d_counters);
   HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, &p, sizeof(KParams), hipMemcpyHostToDevice, st));   // pageable source: staged before the call returns
   if (n > 0) hipLaunchKernelGGL(eh_mutate_kernel, dim3(grid0), dim3(64), 0, st, (const KParams*)ctx->d_params);
   HIPCHK(ctx, hipEventRecord(ctx->ev1, st));
   HIPCHK(ctx, hipGetLastError());
@@ -2199,9 +2218,14 @@ int eh_pool_stats(eh_ctx* ctx, uint64_t* out /* 64 values */) {
   if (!ctx || !out) return EH_E_INVALID;
   if (!ctx->pool) { ctx->err = "no work-area pool yet (eh_reserve or a first batch creates it)"; return EH_E_STATE; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipMemcpy(out, ctx->pool->d_ctr, 40 * 8, hipMemcpyDeviceToHost));   // (a plain copy: fine while batches run)
+  uint64_t raw[64];
+  HIPCHK(ctx, hipMemcpy(raw, ctx->pool->d_ctr, 64 * 8, hipMemcpyDeviceToHost));   // (a plain copy: fine while batches run)
+  memcpy(out, raw, 40 * 8);
   out[40] = (uint64_t)ctx->pool->ntiers;
-  for (int t = 0; t <= POOL_TIERS; t++) { out[41 + t] = t >= 1 && t <= ctx->pool->ntiers ? ctx->pool->cnt[t] : 0; out[51 + t] = t <= ctx->pool->ntiers ? ctx->pool->cap[t] : 0; }
+  for (int t = 0; t <= POOL_TIERS; t++) {
+    out[41 + t] = t >= 1 && t <= ctx->pool->ntiers ? (uint64_t)ctx->pool->cnt[t] | (raw[40 + t] << 32) : 0;   // areas | the most that were out at once
+    out[51 + t] = t <= ctx->pool->ntiers ? ctx->pool->cap[t] : 0;
+  }
   out[61] = (uint64_t)ctx->pool->refs; out[62] = ctx->nslots; out[63] = 0;
   return EH_OK;
 }

@@ -328,7 +328,8 @@ class Engine:
         self._chk(self.lib.eh_pool_stats(self.h, v.ctypes.data_as(C.c_void_p)))
         nt = int(v[40])
         ts = range(1, nt + 1)
-        return {"slot_bytes": int(v[51]), "slots": int(v[62]), "area_bytes": [int(v[51 + t]) for t in ts], "areas": [int(v[41 + t]) for t in ts],
+        return {"slot_bytes": int(v[51]), "slots": int(v[62]), "area_bytes": [int(v[51 + t]) for t in ts], "areas": [int(v[41 + t]) & 0xFFFFFFFF for t in ts],
+                "peak_wanted": [int(v[41 + t]) >> 32 for t in ts],
                 "taken": [int(v[2 * t]) for t in ts], "waits": [int(v[30 + t]) for t in ts], "wait_ticks": [int(v[20 + t]) for t in ts],
                 "contexts": int(v[61])}
 

@@ -45,24 +45,31 @@ def run_steps(engines, streams, first_step, steps, rank, world, n, seed, on_resu
     engine)` is called at collection time (the engine still holds that step's results)."""
     import numpy as np
     nctx = len(engines)
-    res = {"out_bytes": 0, "kernel_ms": [], "status_counts": np.zeros(6, dtype=np.int64)}
+    import time
+    res = {"out_bytes": 0, "kernel_ms": [], "status_counts": np.zeros(6, dtype=np.int64),
+           "host_loop_s": {"collect": 0.0, "collect_max": 0.0, "on_result": 0.0, "launch": 0.0, "launch_max": 0.0, "no_context_free": 0.0}}
+    hl = res["host_loop_s"]                           # where the host thread's time goes (bench.py reports it next to ms_per_step)
 
     def collect_ctx(ci, k):
+        t0 = time.perf_counter()
         e = engines[ci]
         _, ob, _ = e.totals()                         # waits for that context's batch
         res["out_bytes"] += ob
         res["kernel_ms"].append(e.kernel_ms())        # HIP events recorded on the launch stream inside the library
         res["status_counts"] += np.bincount(e.status(), minlength=6)[:6]
+        t1 = time.perf_counter()
         if on_result is not None:
             on_result(k, e)
+        t2 = time.perf_counter()
+        hl["collect"] += t1 - t0; hl["collect_max"] = max(hl["collect_max"], t1 - t0); hl["on_result"] += t2 - t1
 
     # A step goes to WHICHEVER context is free.  Passes do not end in the order they were launched (a pass lasts as long as its
     # heaviest case, 0.75 - 2 s alone), and waiting for the oldest one leaves contexts - and, once their workgroups have left, the
     # device - idle behind one long tail.
-    import time
     busy = {}                                          # context index -> step it runs
     free = list(range(nctx))
     for k in range(first_step, first_step + steps):
+        tw0, c0 = time.perf_counter(), hl["collect"] + hl["on_result"]
         while not free:
             for ci in list(busy):
                 if engines[ci].done():
@@ -70,11 +77,15 @@ def run_steps(engines, streams, first_step, steps, rank, world, n, seed, on_resu
             if not free:
                 time.sleep(0.0005)
         ci = free.pop(0)
+        t0 = time.perf_counter()
+        hl["no_context_free"] += (t0 - tw0) - (hl["collect"] + hl["on_result"] - c0)
         if strong:
             first, cnt = case_range(n, rank, world)
             engines[ci].fuzz_batch(seed=seed, first_case=k * n + first + 1, corpus_first=first, n=cnt, stream=streams[ci])
         else:
             engines[ci].fuzz_batch(seed=seed, first_case=weak_first_case(k, rank, world, n), corpus_first=0, n=n, stream=streams[ci])
+        dt = time.perf_counter() - t0
+        hl["launch"] += dt; hl["launch_max"] = max(hl["launch_max"], dt)
         busy[ci] = k
     for ci in sorted(busy, key=lambda c: busy[c]):
         collect_ctx(ci, busy[ci])

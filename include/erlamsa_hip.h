@@ -297,7 +297,8 @@ int eh_selftest_sort_by_priority(const uint32_t* pri, uint32_t n, uint32_t* perm
 
 /* Work-area pool of this context's device (diagnostic), 64 values; t = tier 1 .. out[40]: out[2t] / out[2t+1] = areas
  * of tier t taken / returned since the pool was made (+ the tier's size for the latter), out[20+t] = shader-clock ticks
- * wavefronts waited for an area of tier t, out[30+t] = how many had to wait, out[40] = tiers, out[41+t] = areas of tier t,
+ * wavefronts waited for an area of tier t, out[30+t] = how many had to wait, out[40] = tiers, out[41+t] = areas of tier t (low 32 bits) and the most of them that
+ * were wanted at the same time, taken or waited for (high 32 bits),
  * out[51+t] = bytes of an area of tier t (out[51] = the slots'), out[61] = contexts sharing the pool, out[62] = slots
  * (= workgroups of a batch) of this context. */
 int eh_pool_stats(eh_ctx* ctx, uint64_t* out);
