@@ -832,9 +832,19 @@ EH_DEV uint32_t work_weight(uint32_t fn) {
     case M_SGM: case M_JS: case M_AB: case M_AD: case M_TR2: case M_TD: case M_TS1: case M_TR: case M_TS2:
     case M_SNAND: case M_SRND: case M_B64: case M_URI: return 8;
     case M_NUM: return 4;
-    case M_FT: case M_FN: case M_FO: return 64;
+    case M_FT: case M_FN: case M_FO: case M_ZIP: return 64;       // (zip: every file of the archive is inflated and deflated again on one lane)
     default: return 1;
   }
+}
+// The device codecs of the container patterns (cp: gunzip / inflate and gzip / deflate; ar: zip:foldl and zip:create) run on one
+// lane at a few thousand cycles per byte (profiles/r05_zlib_rate.json): their bytes count towards the work budget at the weight of
+// the dearest mutators.  false: the budget is spent (status set).  oracle/oracle.cpp EngineGuard::codec mirrors the sites.
+constexpr uint32_t CODEC_WEIGHT = 64;
+EH_DEV bool codec_work(Ctx& c, uint64_t bytes) {
+  if (!c.work_budget) return true;
+  c.work += bytes * CODEC_WEIGHT;
+  if (c.work > c.work_budget) { c.status = CASE_BUDGET; return false; }
+  return true;
 }
 
 EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask);   // eh_engine.hip: text/tree/... mutators

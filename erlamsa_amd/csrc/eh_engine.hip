@@ -328,6 +328,7 @@ __device__ __noinline__ int cp_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, PatF
   const int l = EH_LANE;
   const Blk b = blk_load(c.bl, c.cur);
   const uint8_t* H = (const uint8_t*)b.ptr;
+  if (!codec_work(c, b.len)) return -1;                                      // the attempt to decode reads the block
   ZInf* zi = (ZInf*)ws_alloc_grow(c, sizeof(ZInf));
   if (!zi) return -1;
   int fmt = 0; uint8_t* data = nullptr; uint64_t dlen = 0;
@@ -340,6 +341,7 @@ __device__ __noinline__ int cp_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, PatF
     if (z_uncompress_write(zi, f, H, b.len, off, d, outn)) { fmt = f; data = d; dlen = outn; }
   }
   if (fmt == 0) return 0;
+  if (!codec_work(c, dlen)) return -1;                                       // ... and the payload was written
   if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 315); return -1; }
   const int nrest = c.nb - c.cur - 1;
   CpSide* sd = (CpSide*)ws_alloc_grow(c, sizeof(CpSide) + (uint64_t)nrest * sizeof(Blk));
@@ -381,6 +383,7 @@ __device__ __noinline__ uint64_t cp_end(Ctx&, uint32_t e_pri, uint32_t e_meta, i
   const uint8_t* nd = gather_emits(c, em_field, &tot);
   if (tot > 0 && !nd) return keep;
   c.nem = em_field;
+  if (!codec_work(c, tot)) return keep;                                      // zlib:gzip(NewData) | deflate
   ZDef* zd = (ZDef*)ws_alloc_grow(c, sizeof(ZDef));
   if (!zd) return keep;
   const uint64_t cap = z_deflate_bound(tot) + z_wrap_bytes(fmt);
@@ -409,6 +412,7 @@ __device__ __noinline__ uint8_t* ar_begin(Ctx&, uint32_t e_pri, uint32_t e_meta,
   EH_CTX;
   const Blk b = blk_load(c.bl, c.cur);
   c.pat_ret = -1;
+  if (!codec_work(c, b.len)) return nullptr;                                 // zip:foldl reads the archive
   ZipRd* rd = (ZipRd*)ws_alloc_grow(c, sizeof(ZipRd));
   if (!rd) return nullptr;
   int rc = zip_open(rd, (const uint8_t*)b.ptr, b.len);
@@ -425,6 +429,7 @@ __device__ __noinline__ uint8_t* ar_begin(Ctx&, uint32_t e_pri, uint32_t e_meta,
     if (rc == ZR_UNSUP) { c.status = CASE_UNSUPPORTED; return nullptr; }
     if (rc == ZR_CRASH) { c.status = CASE_CRASHED; return nullptr; }
     if (rc != ZR_OK) { c.pat_ret = 0; return nullptr; }
+    if (!codec_work(c, uni(es[i].data_len))) return nullptr;                 // ... and inflates every file
   }
   mutator_save(c, &sd->m, e_pri, e_meta);
   if (EH_LANE == 0) { sd->archive = b; sd->n = (int32_t)n; sd->idx = (int32_t)n - 1; sd->ip = (int32_t)ip; sd->contpat = contpat; sd->es = es; }
@@ -464,6 +469,11 @@ __device__ __noinline__ uint64_t ar_step(Ctx&, uint32_t e_pri, uint32_t e_meta, 
       return keep;
     }
     idx--;
+  }
+  if (c.work_budget) {                                                                  // zip:create deflates every file again
+    uint64_t sum = 0;
+    for (int i = EH_LANE; i < n; i += 64) sum += es[i].data_len;
+    if (!codec_work(c, wave_sum64(sum))) return keep;
   }
   uint8_t* out; uint64_t len;
   int rc = zip_create<true>(c, es, (uint32_t)n, &out, &len);                            // zip:create(Name, lists:reverse(NewFileSpec), [memory])

@@ -89,8 +89,9 @@ typedef struct eh_options {
   uint64_t out_capacity;     /* output arena bytes; 0 => 8 x batch input bytes + 2 GiB */
   uint64_t max_case_work;    /* OPTIONAL per-case work budget in bytes (sum over mutator attempts, failed ones
                                 included, of block size x cost weight of the mutator: 8 for parsers and
-                                per-byte-draw mutators, 64 for the fuse family, 4 for num, 1 otherwise; plus 16 x
-                                the list members of every fuse refinement round);
+                                per-byte-draw mutators, 64 for the fuse family and zip, 4 for num, 1 otherwise; plus 16 x
+                                the list members of every fuse refinement round; plus 64 x the bytes the container
+                                patterns cp / ar read, inflate and deflate);
                                 0 => no budget (default): every case runs to completion */
   uint32_t max_slots;        /* slots = persistent workgroups (wavefronts) of one batch; 0 => one per wavefront the device holds.
                                 Batches in flight on several streams may oversubscribe the device: a batch's workgroups

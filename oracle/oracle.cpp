@@ -229,6 +229,7 @@ struct EngineGuard {
   void clock() { if (timed && std::chrono::steady_clock::now() > deadline) throw Timeout(); }
   void attempt(int fn, size_t len);          // called once per mutator attempt of mux_fuzzers_loop
   void round(uint64_t members);              // called once per find_jump_points_loop round
+  void codec(uint64_t bytes);                // the container patterns' inflate / deflate (eh_device.h codec_work(): the same sites)
   void size(size_t n) const { if (max_bytes && n > max_bytes) throw Overflow(); }
 };
 
@@ -1417,10 +1418,16 @@ void EngineGuard::attempt(int fn, size_t len) {
     case M_SGM: case M_JS: case M_AB: case M_AD: case M_TR2: case M_TD: case M_TS1: case M_TR: case M_TS2:
     case M_SNAND: case M_SRND: case M_B64: case M_URI: w = 8; break;
     case M_NUM: w = 4; break;
-    case M_FT: case M_FN: case M_FO: w = 64; break;
+    case M_FT: case M_FN: case M_FO: case M_ZIP: w = 64; break;
     default: break;
   }
   work += (uint64_t)len * w;
+  if (work > max_work) throw Budget();
+}
+void EngineGuard::codec(uint64_t bytes) {
+  clock();
+  if (!max_work) return;
+  work += 64ull * bytes;
   if (work > max_work) throw Budget();
 }
 void EngineGuard::round(uint64_t members) {
@@ -2586,6 +2593,7 @@ struct PatEngine {
     Bytes all; for (auto& b : ll) all.insert(all.end(), b.begin(), b.end());  // list_to_binary([Bin|Rest]); NewRest = []
     // UnZip = zip:foldl(fun(N, I, B, Acc) -> [{N, B(), I()} | Acc] end, [], {Name, ArchiveBin})
     otpzip::Reader rd; std::vector<otpzip::Entry> es;
+    if (c.guard) c.guard->codec(all.size());
     int rc = otpzip::open(all, &rd);
     if (rc == otpzip::ZR_UNSUP) throw Unsupported();
     for (uint32_t i = 0; rc == otpzip::ZR_OK && i < rd.entries; i++) {
@@ -2593,7 +2601,7 @@ struct PatEngine {
       rc = otpzip::next(&rd, &e);
       if (rc == otpzip::ZR_UNSUP) throw Unsupported();
       if (rc == otpzip::ZR_CRASH) throw ErlCrash("data_error in zip:foldl");
-      if (rc == otpzip::ZR_OK) es.push_back(e);
+      if (rc == otpzip::ZR_OK) { es.push_back(e); if (c.guard) c.guard->codec(e.data.size()); }
     }
     const std::vector<Muta> mutator = c.fs;                                   // every inner evaluation starts from the Mutator the pattern was given
     const size_t trace_mark = c.trace ? c.trace->size() : 0;
@@ -2613,6 +2621,7 @@ struct PatEngine {
         }
       }
       Bytes newbin;
+      if (c.guard) { uint64_t sum = 0; for (auto& e : es) sum += e.data.size(); c.guard->codec(sum); }
       rc = otpzip::create(es, &newbin);                                       // zip:create(Name, lists:reverse(NewFileSpec), [memory])
       if (rc == otpzip::ZR_OK) { c.m2("archiver", "ok"); c.check_cap(newbin.size()); sink.insert(sink.end(), newbin.begin(), newbin.end()); return; }   // [NewBin | {fun .., [{archiver, ok}, flatten(NewMeta) | Meta]}] :196
       if (c.trace) c.trace->resize(trace_mark);
@@ -2629,8 +2638,10 @@ struct PatEngine {
     if (ll.empty()) throw ErlCrash("badarg: zlib:gunzip(false)");
     const Bytes bin = ll[0]; BList rest(ll.begin() + 1, ll.end());
     Bytes data; int fmt = 0;                                                  // 1 gzip, 2 zlib
+    if (c.guard) c.guard->codec(bin.size());
     if (otpz::gunzip(bin, &data)) fmt = 1;                                    // try zlib:gunzip(Bin) ... catch error:data_error -> deflate
     else if (otpz::inflate_noend(bin, &data)) fmt = 2;                        // catch _:_ -> {Bin, Meta}
+    if (fmt && c.guard) c.guard->codec(data.size());
     Bytes newbin = bin;
     const std::vector<Muta> mutator = c.fs;                                   // the closures keep using Mutator, not what the inner evaluation returns
     const size_t trace_mark = c.trace ? c.trace->size() : 0;
@@ -2645,6 +2656,7 @@ struct PatEngine {
       mutate_once_loop(ip, one, next, newdata);
       c.meta_base = base0;
       c.m2("compressed", fmt == 1 ? "gzip" : "zlib");
+      if (c.guard) c.guard->codec(newdata.size());
       newbin = otpz::deflate_all(newdata, fmt == 1 ? 31 : 15);                // zlib:gzip(NewData) | deflateInit(ZD, default), deflate(ZD, [NewData], finish)
       c.check_cap(newbin.size());
     }

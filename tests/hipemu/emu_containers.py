@@ -204,7 +204,35 @@ def run_zip(n=20, big=1 << 25):
     return total
 
 
+def run_budget(n=20, big=1 << 25):
+    """The optional work budget (eh_options.max_case_work) counts the codecs' bytes: the engine and the oracle's EngineGuard must stop the
+    same cases (status 3) - every other case is byte-identical as before."""
+    total = stopped = 0
+    for ci, (muts, pats, mk, work) in enumerate([("bd,bf,bi,sr,lr,num,nil=3", "cp,sz,cs,od,nd", compressed_corpus, 300000),
+                                                 ("zip=5,bd,bf,sr,lr,num", "ar=3,cp,sz,od,nd,bu", zip_corpus, 700000),
+                                                 ("zip", "od,nd", zip_corpus, 120000)]):
+        inputs = mk(n, seed=700 + ci)
+        data, off = po.pack(inputs)
+        seed = (41 + ci, 6, 3)
+        want, wst, wdr = po.fuzz_batch(data, off, seed=seed, mutations=muts, patterns=pats, max_case_bytes=big, max_case_work=work)[:3]
+        eng = ea.Engine(0)
+        eng.configure(mutations=muts, patterns=pats, max_case_bytes=1 << 20, big_case_bytes=big, max_case_work=work)
+        eng.upload_corpus(data, off)
+        eng.fuzz_batch(seed=seed)
+        got, gst = eng.download()
+        gdr, _ = eng.diag()
+        eng.close()
+        bad = [i for i in range(len(inputs)) if gst[i] != 2 and wst[i] != 2 and not (got[i] == want[i] and gst[i] == wst[i] and (gst[i] != 0 or gdr[i] == wdr[i]))]
+        total += len(inputs); stopped += int((gst == 3).sum())
+        print("budget config %d (max_case_work %d): cases %d bad %d, statuses engine %s oracle %s" % (ci, work, len(inputs), len(bad), np.bincount(gst, minlength=4).tolist(), np.bincount(wst, minlength=4).tolist()), flush=True)
+        for i in bad[:3]:
+            print("  case %d (%d bytes): len %d vs %d, status %d vs %d, draws %d vs %d" % (i, len(inputs[i]), len(got[i]), len(want[i]), gst[i], wst[i], gdr[i], wdr[i]))
+        assert not bad, "budget config %d: %d cases differ" % (ci, len(bad))
+    assert 0 < stopped < total, "the budgets of this test are meant to stop some cases and not all (%d of %d)" % (stopped, total)
+    return total
+
+
 if __name__ == "__main__":
     assert "emu" in os.environ.get("ERLAMSA_HIP_LIB", ""), "point ERLAMSA_HIP_LIB at the emulator build"
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-    print("containers ok: cp %d cases, zip %d cases" % (run_cp(n), run_zip(n)))
+    print("containers ok: cp %d cases, zip %d cases, with a work budget %d cases" % (run_cp(n), run_zip(n), run_budget(min(n, 20))))

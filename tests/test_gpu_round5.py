@@ -100,6 +100,14 @@ def test_gunzip_of_otp_20_1_concatenated_members_and_trailing_bytes():
     assert emu_containers.run_cp(n=45) >= 135
 
 
+def test_work_budget_counts_the_device_codecs():
+    """eh_options.max_case_work (the engine's deterministic stand-in for maxrunningtime) counts what pattern cp / ar and mutator zip
+    inflate and deflate on one lane: the engine and the oracle's EngineGuard stop the same cases (EH_CASE_BUDGET), the others are
+    byte-identical (csrc/eh_device.h codec_work)."""
+    import emu_containers
+    assert emu_containers.run_budget(n=40) == 120
+
+
 def test_rccl_called_from_inside_the_library_on_this_gpu():
     """ABI 7 (include/erlamsa_hip.h "multi-GPU"): librccl.so loaded by the library, a communicator of ONE rank on this GPU, and the
     three ways an arena reaches a context - eh_corpus_broadcast, eh_corpus_allgather, eh_corpus_broadcast_local - each giving the
