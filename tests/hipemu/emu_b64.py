@@ -4,7 +4,7 @@ groups of four per lane, chunks with white space inside packed first) against th
 white space inside groups, between the padding characters and behind them, long blobs, lines of them repeated many times, chunks
 base64:decode/1 refuses (bad length, padding in the wrong place, text behind the padding).  Bytes, statuses, draw counts must agree.
 
-  python tests/hipemu/build_emu.py && ERLAMSA_HIP_LIB=build/liberlamsa_hip_emu.so python tests/hipemu/emu_b64.py [n] [seed] [scale]
+  python tests/hipemu/build_emu.py && ERLAMSA_HIP_LIB=build/liberlamsa_hip_emu.so python tests/hipemu/emu_b64.py [n] [seed] [scale] [small]
 (with the real library the same comparison runs on the GPU; scale multiplies blob sizes and repeat counts)"""
 import base64
 import os
@@ -28,7 +28,7 @@ def sprinkle(rng, b, p):
     return bytes(out)
 
 
-def corpus(n, seed, scale=1):
+def corpus(n, seed, scale=1, small=False):
     rng = np.random.Generator(np.random.PCG64(seed))
     out = []
     for k in range(n):
@@ -49,14 +49,14 @@ def corpus(n, seed, scale=1):
             pieces.append(rng.choice([b"\x00", b"; ", b"\x01\x02", b"|", b"{", b"\xff"]))
         out.append(b"".join(pieces))
         line = base64.b64encode(blob(30, 90)) + b"\n"
-        out.append(b"-----BEGIN-----\x00" + line * (int(rng.integers(20, 200)) * scale) + b"\x00-----END-----")       # one chunk of many lines
-        out.append(b"\x00".join(base64.b64encode(blob(6, 40)) for _ in range(int(rng.integers(70, 300)))))             # more than 64 candidates
-        out.append(sprinkle(rng, base64.b64encode(blob(1000 * scale, 20000 * scale)), float(rng.choice([0.0, 0.0, 0.01, 0.3]))))
+        out.append(b"-----BEGIN-----\x00" + line * (int(rng.integers(10, 40) if small else rng.integers(20, 200)) * scale) + b"\x00-----END-----")       # one chunk of many lines
+        out.append(b"\x00".join(base64.b64encode(blob(6, 40)) for _ in range(int(rng.integers(70, 110) if small else rng.integers(70, 300)))))             # more than 64 candidates
+        out.append(sprinkle(rng, base64.b64encode(blob(400, 3000) if small else blob(1000 * scale, 20000 * scale)), float(rng.choice([0.0, 0.0, 0.01, 0.3]))))
     return out
 
 
-def run(n=4, seed=1, scale=1, pats="od,nd,bu", verbose=True):
-    inputs = corpus(n, seed, scale)
+def run(n=4, seed=1, scale=1, pats="od,nd,bu", verbose=True, small=False):
+    inputs = corpus(n, seed, scale, small)
     data, off = po.pack(inputs)
     t = time.time()
     e = ea.Engine(0)
@@ -89,5 +89,5 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    total, bad = run(n, seed, scale)
+    total, bad = run(n, seed, scale, small=len(sys.argv) > 4 and sys.argv[4] == "small")   # small: the CPU suite's run on the emulator
     sys.exit(1 if bad else 0)

@@ -63,7 +63,7 @@ def test_emulated_chunked_work_areas_default_tables(emu_lib):
     """16 KiB slots, the full default tables: attempts that run out of memory (also inside nested scheduler calls) are
     repeated after the case has borrowed a larger area; bytes, statuses and draw counts are the oracle's"""
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_chunks.py"), "24"], env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_chunks.py"), "16"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "chunks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -71,7 +71,7 @@ def test_emulated_fuse2_table_modes(emu_lib):
     """eh_fuse2.h on periodic, textual, random and short-alphabet blocks of 6 KB: two-level next-byte tables, compact lookups,
     bitmap rows, the special node — bytes, statuses and draw counts are the oracle's"""
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_fuse2.py"), "24", "6000"], env=env, capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_fuse2.py"), "16", "6000"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "fuse2 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -137,7 +137,7 @@ def test_emulated_sgml_lane_batches_and_base64_wave_decode(emu_lib):
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_sgml_replay.py"), "1", "5", "1", "small"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "cases 9 bad 0" in r.stdout, r.stdout + r.stderr
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_b64.py"), "1", "2"], env=env, capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_b64.py"), "3", "2", "1", "small"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout + r.stderr
 
 
@@ -151,5 +151,5 @@ def test_emulated_race_detector_finds_no_cross_lane_access_without_a_rendezvous(
     import build_emu
     lib = build_emu.build(race=True)
     env = dict(os.environ, ERLAMSA_HIP_LIB=lib, HIPEMU_RACE_QUIET="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_race.py"), "4"], env=env, capture_output=True, text=True, timeout=1800)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_race.py"), "3"], env=env, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0 and "race ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

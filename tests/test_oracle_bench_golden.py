@@ -18,14 +18,14 @@ def test_bench_golden_matches_the_live_oracle_on_a_sample():
     assert set(int(i) for i in z["idx"]) >= set(range(4096)) | set(heavy)
     pos = {int(i): k for k, i in enumerate(z["idx"])}
     mat = synth.mixed(65536, 4096)
-    # 96 consecutive rows in one call, plus three single heavy cases with outputs below 8 MB
-    d, o = synth.as_arena(mat[1000:1096])
+    # 64 consecutive rows in one call, plus two single heavy cases with outputs below 8 MB
+    d, o = synth.as_arena(mat[1000:1064])
     outs, st, dr, _ = po.fuzz_batch(d, o, seed=(1, 2, 3), patterns="od,nd,bu", first_case=1001, max_case_bytes=1 << 30)
-    for j in range(96):
+    for j in range(64):
         k = pos[1000 + j]
         assert int(st[j]) == int(z["status"][k]) and int(dr[j]) == int(z["draws"][k]) and len(outs[j]) == int(z["lens"][k])
         assert hashlib.sha1(outs[j]).digest() == z["sha1"][k].tobytes()
-    small = [i for i in heavy if int(z["lens"][pos[i]]) < (8 << 20)][:3]
+    small = [i for i in heavy if int(z["lens"][pos[i]]) < (8 << 20)][:2]
     for i in small:
         d, o = synth.as_arena(mat[i:i + 1])
         outs, st, dr, _ = po.fuzz_batch(d, o, seed=(1, 2, 3), patterns="od,nd,bu", first_case=i + 1, max_case_bytes=1 << 30)

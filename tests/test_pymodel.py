@@ -117,7 +117,7 @@ def _bracket_inputs(n, seed):
 def test_model_and_oracle_agree_on_the_tree_mutators(seed):
     """tr2 td ts1 ts2 tr: partial_parse / sublists / edit_sublist(s) compare nodes by VALUE, so equal subtrees in different
     places are all edited; tree stutter grows exponentially (cases beyond 8 MB are not compared)."""
-    ins = _bracket_inputs(240, seed[1])
+    ins = _bracket_inputs(160, seed[1])
     trees = [("tr2", 1), ("td", 1), ("ts1", 2), ("tr", 2), ("ts2", 2)]
     _diff(ins, seed, trees, PATS, oracle_cap=32 << 20)
     _diff(ins, seed, trees + [("bd", 1), ("sr", 1)], [("od", 1), ("nd", 1)], oracle_cap=32 << 20)
