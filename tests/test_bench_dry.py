@@ -33,6 +33,9 @@ def test_bench_script_runs_end_to_end_on_the_emulator():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["algorithmic_bytes_per_launch"] > 16 * 256
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 2 and "pcie" in d and "with_work_budget" in d
+    hl, pool = d["host_loop_ms_per_step"], d["config"]["work_area_pool"]
+    assert set(hl) == {"collect", "collect_max", "on_result", "launch", "launch_max", "no_context_free"} and all(v >= 0 for v in hl.values())
+    assert len(pool["peak_wanted"]) == len(pool["areas"]) and all(a >= 1 for a in pool["areas"])
 
 
 def test_bench_config_5_shape_runs_on_the_emulator():
