@@ -144,7 +144,8 @@ int eh_corpus_attach(eh_ctx* ctx, const void* d_data, const void* d_off, uint64_
  * Cases are independent, so the mutation path never communicates; the one exchange is the arena at load time.
  * The reference's counterpart: every `--workers` scheduler reads the same input files (erlamsa_main.erl:90-108).  RCCL is reached
  * from here because the host north_star names - the BEAM - has no HIP or RCCL binding.  librccl.so is loaded on first use
- * (environment EH_RCCL_LIB names another file); a single-GPU host never needs it.  EH_E_UNSUPPORTED when it cannot be loaded.
+ * (an RCCL the process has loaded already - a host that also uses torch.distributed - is shared, not loaded a second time;
+ * environment EH_RCCL_LIB names another file); a single-GPU host never needs it.  EH_E_UNSUPPORTED when it cannot be loaded.
  *
  * One OS process per GPU (how bench.py is launched):
  *   rank 0: eh_comm_unique_id(id); the 128 bytes reach the other processes over the host's own channel (Erlang distribution, a
