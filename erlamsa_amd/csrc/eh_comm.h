@@ -46,7 +46,7 @@ inline Api* api() {
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   } else h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-  if (!h) { a.err = std::string("cannot load RCCL (") + name + "): " + (dlerror() ? dlerror() : "?"); return &a; }
+  if (!h) { const char* de = dlerror(); a.err = std::string("cannot load RCCL (") + name + "): " + (de ? de : "?"); return &a; }   // (dlerror() hands its text out once)
   bool ok = true;
   auto sym = [&](const char* s) -> void* { void* p = dlsym(h, s); if (!p) { ok = false; a.err = std::string("RCCL symbol missing: ") + s; } return p; };
   a.GetUniqueId = (int (*)(UniqueId*))sym("ncclGetUniqueId");

@@ -44,7 +44,7 @@ def test_bench_config_5_shape_runs_on_the_emulator():
     assert d["case_status"]["ok"] == 12 and d["parity_checked"] == 6        # the oracle's Paths are the whole counter-hash arena
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
+@pytest.mark.parametrize("scaling", ["weak", "strong", "weak-without-rccl"])
 def test_bench_script_two_ranks_over_gloo_on_the_emulator(scaling):
     """bench.py's OWN N > 1 path (process group, arena generated on rank 0 and broadcast, the checksum agreement of all ranks, one
     context attaching the broadcast tensors and the others sharing it, step loop per rank, barrier, MAX / SUM reduction, one JSON
@@ -56,7 +56,11 @@ def test_bench_script_two_ranks_over_gloo_on_the_emulator(scaling):
     env = dict(os.environ, EH_BENCH_BACKEND="gloo", ERLAMSA_HIP_LIB=build_emu.build(), EH_RCCL_LIB=test_comm_abi.FAKE)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EH_BENCH_CHILD"):
         env.pop(k, None)
-    port = 29700 + (os.getpid() % 200) + (0 if scaling == "weak" else 1)
+    no_rccl = scaling == "weak-without-rccl"      # the library cannot load RCCL: every rank agrees to load the arena over torch.distributed instead
+    if no_rccl:
+        env["EH_RCCL_LIB"] = os.path.join(ROOT, "build", "no_such_rccl.so")
+        scaling = "weak"
+    port = 29700 + (os.getpid() % 200) + (2 if no_rccl else 0 if scaling == "weak" else 1)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", scaling, "--cases", "16", "--size", "256", "--mutations", "bd,bf,bi,sr,num,lr,ab"] + SMALL
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -67,5 +71,5 @@ def test_bench_script_two_ranks_over_gloo_on_the_emulator(scaling):
     assert d["config"]["world_size_seen_by_torch_distributed"] == 2 and d["config"]["arena_equal_on_all_ranks"] is True
     if scaling == "weak":
         assert d["strong_scaling_leg"]["cases_per_step_all_ranks"] == 16 and d["strong_scaling_leg"]["cases_per_s"] > 0     # (value is MB/s to one decimal: 16 cases of the emulator can round to 0.0)
-    assert "RCCL inside the library" in d["config"]["arena_transport"]
+    assert ("fall-back" if no_rccl else "RCCL inside the library") in d["config"]["arena_transport"]
     assert d["case_status"]["ok"] == (32 if scaling == "weak" else 16)          # rank 0's share: weak = its own 16 cases per step, strong = half of one run's

@@ -140,3 +140,33 @@ print("ok")
     env = dict(os.environ, ERLAMSA_HIP_LIB=emu, EH_RCCL_LIB=FAKE, HIPEMU_DEVICES="4")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_a_host_without_rccl_gets_an_error_code_not_a_crash():
+    """include/erlamsa_hip.h: EH_E_UNSUPPORTED when librccl cannot be loaded (a single-GPU host has no need of it) - from every entry
+    point that would call it, with the loader's text where there is a context to keep it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    import build_emu
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import erlamsa_amd as ea
+seen = []
+try:
+    ea.Engine.comm_unique_id()
+except ea.EngineError as e:
+    seen.append(e.code)
+e = ea.Engine(0)
+try:
+    e.comm_init(bytes(128), 0, 1)
+except ea.EngineError as x:
+    seen.append(x.code); assert "cannot load RCCL" in str(x) and "no_such_rccl" in str(x), str(x)
+try:
+    ea.Engine.comm_init_local([e])
+except ea.EngineError as x:
+    seen.append(x.code)
+print("codes", seen)
+''' % ROOT
+    env = dict(os.environ, ERLAMSA_HIP_LIB=build_emu.build(), EH_RCCL_LIB=os.path.join(ROOT, "build", "no_such_rccl.so"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "codes [-6, -6, -6]" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
