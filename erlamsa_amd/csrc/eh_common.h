@@ -3,7 +3,23 @@
 #pragma once
 #include <stdint.h>
 
+// Everything the kernels read and write besides their registers, the LDS and their stack is HBM (corpus arena, slots, pool areas,
+// output arena, result arrays).  Device code says so in the pointer TYPE: address space 1, so loads and stores are global_*
+// instructions.  A generic pointer makes them flat_*: an aperture check per access, and - what costs - a flat access counts in
+// vmcnt AND lgkmcnt, so every LDS read of the per-case context (g_ctx) waits for the HBM traffic in flight.  Global converts to
+// generic implicitly, never the other way round: a pointer into the LDS or the stack cannot end up in one of these types unseen.
+// The host pass and the CPU emulator (tests/hipemu) see plain pointers.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIPEMU)
+#define EH_G __attribute__((address_space(1)))
+#else
+#define EH_G
+#endif
+
 namespace eh {
+
+typedef EH_G uint8_t* bptr;   typedef const EH_G uint8_t* cbptr;
+typedef EH_G uint32_t* wptr;  typedef const EH_G uint32_t* cwptr;
+typedef EH_G uint64_t* qptr;  typedef const EH_G uint64_t* cqptr;
 
 // Mutator ids in the table order of erlamsa_mutations:mutations/1
 // (reference src/erlamsa_mutations.erl:1291-1331).
@@ -111,51 +127,51 @@ struct DevConfig {
 };
 
 struct KParams {
-  const uint8_t* corpus;
-  const uint64_t* coff;
+  cbptr corpus;
+  cqptr coff;
   uint64_t corpus_first;
   uint64_t n_paths;           // entries of the whole corpus: the Paths of the file / jump generators
   uint64_t n;
   uint64_t first_case;        // 1-based case number of case 0 (mode 0)
   int32_t mode;               // 0 batch (one parent seed), 1 per-call seeds
-  const RunState* run;        // mode 0
-  const int64_t* seeds;       // mode 1: 3n
+  const EH_G RunState* run;        // mode 0
+  const EH_G int64_t* seeds;       // mode 1: 3n
   DevConfig cfg;
   uint64_t work_cap;          // bytes of the linear work area of a tier-0 slot
   uint64_t work_budget;       // per-case byte budget (sum of block sizes handed to mutators)
   uint64_t fuse_stream_min;   // fuse/2 on la + lb >= this many bytes runs as the position-indexed refinement of eh_fuse2.h
   // outputs
-  uint8_t* out;
+  bptr out;
   uint64_t out_cap;
-  unsigned long long* out_cursor;
-  uint64_t* out_off;
-  uint64_t* out_len;
-  int32_t* status;
-  uint64_t* draws;
-  int32_t* lastm;
-  uint64_t* cycles;           // per-case shader-clock ticks (diagnostic)
-  uint64_t* peak;             // per-case work-memory high-water mark in bytes (diagnostic)
-  uint64_t* trace_off;        // EH_FLAG_META_TRACE: where the case's trace sits in `out` ...
-  uint32_t* trace_len;        // ... and its length in bytes (TraceKind events, above)
+  EH_G unsigned long long* out_cursor;
+  qptr out_off;
+  qptr out_len;
+  EH_G int32_t* status;
+  qptr draws;
+  EH_G int32_t* lastm;
+  qptr cycles;           // per-case shader-clock ticks (diagnostic)
+  qptr peak;             // per-case work-memory high-water mark in bytes (diagnostic)
+  qptr trace_off;        // EH_FLAG_META_TRACE: where the case's trace sits in `out` ...
+  wptr trace_len;        // ... and its length in bytes (TraceKind events, above)
   uint32_t flags;             // EH_FLAG_*
-  unsigned long long* prof;   // EH_PROF builds: [2*k] cycles, [2*k+1] calls; k < 64 mutator fn, 64.. phases
-  unsigned long long* ticket;
-  unsigned long long* in_bytes;
+  EH_G unsigned long long* prof;   // EH_PROF builds: [2*k] cycles, [2*k+1] calls; k < 64 mutator fn, 64.. phases
+  EH_G unsigned long long* ticket;
+  EH_G unsigned long long* in_bytes;
   // Work areas.  Workgroup w of a batch owns slot w of the context (block tables + work_cap bytes of work area): a slot per
   // launched workgroup, so no wavefront ever waits for one.  A case that outgrows what it holds borrows a larger area from
   // a POOL all contexts of the device share (eh_engine.hip, DevPool; tiers 1..ntiers, twice the area per tier up to
   // big_case_bytes) and goes on there; only the mutator attempt that ran out of memory is repeated (eh_device.h, ws_regrow).
   // Every tier is a ring of free area indices: pool_ctr[2t] = pop tickets, pool_ctr[2t+1] = push tickets,
   // pool_ctr[20+t] = ticks wavefronts waited for an area of tier t, pool_ctr[30+t] = how many had to wait.
-  uint8_t* slot_base;
+  bptr slot_base;
   uint64_t slot_stride;
   int32_t ntiers;                // tiers of the pool (1..ntiers)
-  uint8_t* pool_base[POOL_TIERS + 1];   // tier t: area k at pool_base[t] + k * pool_stride[t]
+  bptr pool_base[POOL_TIERS + 1];   // tier t: area k at pool_base[t] + k * pool_stride[t]
   uint64_t pool_stride[POOL_TIERS + 1];
   uint64_t pool_cap[POOL_TIERS + 1];    // work-area bytes of an area of tier t (pool_cap[0] == work_cap: the slot's own)
   uint32_t pool_cnt[POOL_TIERS + 1];
-  uint32_t* pool_ring[POOL_TIERS + 1];
-  unsigned long long* pool_ctr;
+  wptr pool_ring[POOL_TIERS + 1];
+  EH_G unsigned long long* pool_ctr;
 };
 
 struct MutaInfo { const char* name; int pri; int on_gpu; };

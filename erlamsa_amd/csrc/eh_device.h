@@ -165,9 +165,34 @@ EH_DEV uint32_t rng_log(Rng& r, uint32_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// wave-parallel byte movers (generic pointers: HBM arena or slot work memory)
+// 4 / 8 / 16 bytes of HBM in one instruction.  ldg* / stg*: any alignment (the device runs with unaligned access on: one
+// global_load_dwordx4 whatever the address), *a: the address is a multiple of the size.  (The vector types of the HIP headers are
+// classes, which cannot be copied out of an address-space qualified lvalue: the accesses go through the compiler's own vectors.)
 // ---------------------------------------------------------------------------------------------
-EH_DEV void wave_copy(uint8_t* dst, const uint8_t* src, uint32_t n) {
+#ifdef HIPEMU
+EH_DEV uint4 ldg16(const void* p) { uint4 v; memcpy(&v, p, 16); return v; }
+EH_DEV uint4 ldg16a(const void* p) { uint4 v; memcpy(&v, p, 16); return v; }
+EH_DEV void stg16(void* p, const uint4& v) { memcpy(p, &v, 16); }
+EH_DEV void stg16a(void* p, const uint4& v) { memcpy(p, &v, 16); }
+EH_DEV uint64_t ldg8(const void* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+EH_DEV uint32_t ldg4(const void* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+#else
+typedef uint32_t eh_v4 __attribute__((ext_vector_type(4)));
+typedef eh_v4 __attribute__((aligned(1))) eh_v4u;
+typedef uint64_t __attribute__((aligned(1))) eh_u64u;
+typedef uint32_t __attribute__((aligned(1))) eh_u32u;
+EH_DEV uint4 ldg16(const EH_G void* p) { eh_v4 v = *reinterpret_cast<const EH_G eh_v4u*>(p); uint4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+EH_DEV uint4 ldg16a(const EH_G void* p) { eh_v4 v = *reinterpret_cast<const EH_G eh_v4*>(p); uint4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+EH_DEV void stg16(EH_G void* p, const uint4& r) { eh_v4 v; v.x = r.x; v.y = r.y; v.z = r.z; v.w = r.w; *reinterpret_cast<EH_G eh_v4u*>(p) = v; }
+EH_DEV void stg16a(EH_G void* p, const uint4& r) { eh_v4 v; v.x = r.x; v.y = r.y; v.z = r.z; v.w = r.w; *reinterpret_cast<EH_G eh_v4*>(p) = v; }
+EH_DEV uint64_t ldg8(const EH_G void* p) { return *reinterpret_cast<const EH_G eh_u64u*>(p); }
+EH_DEV uint32_t ldg4(const EH_G void* p) { return *reinterpret_cast<const EH_G eh_u32u*>(p); }
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// wave-parallel byte movers (HBM to HBM: corpus arena, slot and pool work memory, output arena)
+// ---------------------------------------------------------------------------------------------
+EH_DEV void wave_copy(bptr dst, cbptr src, uint32_t n) {
   const int l = EH_LANE;
   // head: bring dst to 16-byte alignment
   uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
@@ -178,20 +203,16 @@ EH_DEV void wave_copy(uint8_t* dst, const uint8_t* src, uint32_t n) {
   uint32_t i = l;
   // 4 independent 16-byte loads in flight per lane (4 KiB per wave per round trip)
   for (; i + 192 < nv; i += 256) {
-    uint4 v0, v1, v2, v3;
-    __builtin_memcpy(&v0, src + 16 * (size_t)i, 16);
-    __builtin_memcpy(&v1, src + 16 * (size_t)(i + 64), 16);
-    __builtin_memcpy(&v2, src + 16 * (size_t)(i + 128), 16);
-    __builtin_memcpy(&v3, src + 16 * (size_t)(i + 192), 16);
-    *reinterpret_cast<uint4*>(dst + 16 * (size_t)i) = v0;
-    *reinterpret_cast<uint4*>(dst + 16 * (size_t)(i + 64)) = v1;
-    *reinterpret_cast<uint4*>(dst + 16 * (size_t)(i + 128)) = v2;
-    *reinterpret_cast<uint4*>(dst + 16 * (size_t)(i + 192)) = v3;
+    const uint4 v0 = ldg16(src + 16 * (size_t)i), v1 = ldg16(src + 16 * (size_t)(i + 64));
+    const uint4 v2 = ldg16(src + 16 * (size_t)(i + 128)), v3 = ldg16(src + 16 * (size_t)(i + 192));
+    stg16a(dst + 16 * (size_t)i, v0);
+    stg16a(dst + 16 * (size_t)(i + 64), v1);
+    stg16a(dst + 16 * (size_t)(i + 128), v2);
+    stg16a(dst + 16 * (size_t)(i + 192), v3);
   }
   for (; i < nv; i += 64) {
-    uint4 v;
-    __builtin_memcpy(&v, src + 16 * (size_t)i, 16);  // unaligned dwordx4 load
-    *reinterpret_cast<uint4*>(dst + 16 * (size_t)i) = v;
+    const uint4 v = ldg16(src + 16 * (size_t)i);      // unaligned dwordx4 load
+    stg16a(dst + 16 * (size_t)i, v);
   }
   uint32_t done = nv << 4;
   if (done + l < n) dst[done + l] = src[done + l];
@@ -200,16 +221,16 @@ EH_DEV void wave_copy(uint8_t* dst, const uint8_t* src, uint32_t n) {
 // the whole wave — all loads of a 4 KiB stripe are issued before its stores — so no lane can read
 // bytes that a lane running ahead has already overwritten (wave_copy's per-lane loop trip counts
 // differ, which is only safe for disjoint ranges).
-EH_DEV void wave_move_down(uint8_t* dst, const uint8_t* src, uint32_t n) {
+EH_DEV void wave_move_down(bptr dst, cbptr src, uint32_t n) {
   const int l = EH_LANE;
   uint32_t nv = n >> 4;
   for (uint32_t base = 0; base < nv; base += 256) {
     uint4 v[4]; bool ok[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { uint32_t i = base + 64u * u + (uint32_t)l; ok[u] = i < nv; if (ok[u]) __builtin_memcpy(&v[u], src + 16 * (size_t)i, 16); }
+    for (int u = 0; u < 4; u++) { uint32_t i = base + 64u * u + (uint32_t)l; ok[u] = i < nv; if (ok[u]) v[u] = ldg16(src + 16 * (size_t)i); }
     wave_sync();                                     // every lane has loaded its 4 chunks before any lane stores
 #pragma unroll
-    for (int u = 0; u < 4; u++) { uint32_t i = base + 64u * u + (uint32_t)l; if (ok[u]) __builtin_memcpy(dst + 16 * (size_t)i, &v[u], 16); }
+    for (int u = 0; u < 4; u++) { uint32_t i = base + 64u * u + (uint32_t)l; if (ok[u]) stg16(dst + 16 * (size_t)i, v[u]); }
   }
   uint32_t done = nv << 4;
   uint8_t t = 0; bool tk = done + (uint32_t)l < n;
@@ -219,7 +240,7 @@ EH_DEV void wave_move_down(uint8_t* dst, const uint8_t* src, uint32_t n) {
 }
 // dst[i] = pat[i % plen], i < total.  The first copy is written directly, the rest by doubling
 // (dst[0,k) -> dst[k,2k)) so that all but the first plen bytes move as 16-byte vectors.
-EH_DEV void wave_fill_periodic(uint8_t* dst, const uint8_t* pat, uint32_t plen, uint64_t total) {
+EH_DEV void wave_fill_periodic(bptr dst, cbptr pat, uint32_t plen, uint64_t total) {
   if (total == 0) return;
   uint64_t have = plen < total ? plen : total;
   wave_copy(dst, pat, (uint32_t)have);
@@ -233,7 +254,7 @@ EH_DEV void wave_fill_periodic(uint8_t* dst, const uint8_t* pat, uint32_t plen, 
   }
 }
 // returns true if the two byte ranges are equal
-EH_DEV bool wave_equal(const uint8_t* a, const uint8_t* b, uint32_t n) {
+EH_DEV bool wave_equal(cbptr a, cbptr b, uint32_t n) {
   const int l = EH_LANE;
   uint32_t nv = n >> 4;
   // uniform trip count (the early exit must be taken by the whole wave)
@@ -241,8 +262,8 @@ EH_DEV bool wave_equal(const uint8_t* a, const uint8_t* b, uint32_t n) {
     uint32_t i0 = base + l, i1 = base + 64 + l;
     bool ne = false;
     uint4 x0, y0, x1, y1;
-    if (i0 < nv) { __builtin_memcpy(&x0, a + 16 * (size_t)i0, 16); __builtin_memcpy(&y0, b + 16 * (size_t)i0, 16); }
-    if (i1 < nv) { __builtin_memcpy(&x1, a + 16 * (size_t)i1, 16); __builtin_memcpy(&y1, b + 16 * (size_t)i1, 16); }
+    if (i0 < nv) { x0 = ldg16(a + 16 * (size_t)i0); y0 = ldg16(b + 16 * (size_t)i0); }
+    if (i1 < nv) { x1 = ldg16(a + 16 * (size_t)i1); y1 = ldg16(b + 16 * (size_t)i1); }
     if (i0 < nv) ne |= (x0.x != y0.x) | (x0.y != y0.y) | (x0.z != y0.z) | (x0.w != y0.w);
     if (i1 < nv) ne |= (x1.x != y1.x) | (x1.y != y1.y) | (x1.z != y1.z) | (x1.w != y1.w);
     if (__ballot(ne) != 0) return false;
@@ -264,16 +285,16 @@ constexpr int ST_STATE_WORDS = 84;  // sizeof(StState) / 4 (eh_text.h; checked t
 #define EH_SET_OVERFLOW(c, site) ((c).ovf_line = (site), (c).ovf_need = 0, (c).ovf_req = 0, (c).status = CASE_OVERFLOW)
 struct Ctx {
   Rng rng;
-  const KParams* p;
+  const EH_G KParams* p;
   // block list: bl[cur..nb) is the list handed to the mutator; bl[0..cur) already emitted
-  Blk* bl;
-  Blk* bl2;
+  EH_G Blk* bl;
+  EH_G Blk* bl2;
   int nb, cur;
-  Blk* em;
+  EH_G Blk* em;
   int nem;
-  uint8_t* aux;        // per-slot mutator state (lis/lrs lines, fo block)
+  bptr aux;        // per-slot mutator state (lis/lrs lines, fo block)
   // linear work allocator
-  uint8_t* ws;
+  bptr ws;
   // ws + ws_used is the next free byte; ws_used and ws_cap are VIRTUAL offsets that run on across the chunks of the work
   // area (chunk 0 = the slot's own area, chunks 1.. = larger areas borrowed from the pool when the case outgrows what it has,
   // see ws_grow), and ws is the current chunk's base minus the chunk's virtual start, so the arithmetic is that of one area
@@ -281,9 +302,9 @@ struct Ctx {
   int nchunk;          // chunks above the slot's own
   int view;            // chunk ws / ws_lo / ws_cap describe (the one the last allocation came from)
   uint64_t ws_lo;      // its virtual start
-  uint64_t ch_vstart[MAX_CHUNKS], ch_vend[MAX_CHUNKS]; uint8_t* ch_base[MAX_CHUNKS]; uint32_t ch_area[MAX_CHUNKS]; int32_t ch_tier[MAX_CHUNKS];
+  uint64_t ch_vstart[MAX_CHUNKS], ch_vend[MAX_CHUNKS]; bptr ch_base[MAX_CHUNKS]; uint32_t ch_area[MAX_CHUNKS]; int32_t ch_tier[MAX_CHUNKS];
   uint64_t lex_ptr[LEX_LEVELS];   // block the lex cache of nesting level d holds a table for (mirror of LexCache::ptr; 0: none)
-  uint8_t* trace;      // EH_FLAG_META_TRACE: the case's event bytes (slot memory), nullptr = off
+  bptr trace;      // EH_FLAG_META_TRACE: the case's event bytes (slot memory), nullptr = off
   uint32_t ntrace, tr_base;   // bytes written; where the Meta list in hand begins (tr_drop_before)
   uint64_t t_case;     // cycle stamp at which the case began (mux_fuzzers raises the wavefront's issue priority for cases that run long)
   int32_t m_aux;       // set by the mutators whose own Meta entry does not follow from their result alone (num: a number found; ab / ad: stringy)
@@ -293,12 +314,12 @@ struct Ctx {
   uint64_t work;       // bytes handed to mutators so far (deterministic stand-in for maxrunningtime)
   // mutator result (candidate new head of the list)
   int r_kind;          // R_SAME: list unchanged ; R_NEW: r_ptr/r_len replace bl[cur]
-  uint8_t* r_ptr;
+  bptr r_ptr;
   uint32_t r_len;
   int r_flush;         // result goes through flush_bvecs/2
   int r_drop_next;     // fn consumed the following block
   int r_changed;       // mutator guarantees hd(result) != hd(input): skip the compare
-  int r2; uint8_t* r2_ptr; uint32_t r2_len;   // optional second flushed region (fo: flush_bvecs(A, flush_bvecs(B, T)))
+  int r2; bptr r2_ptr; uint32_t r2_len;   // optional second flushed region (fo: flush_bvecs(A, flush_bvecs(B, T)))
   int nfs;             // entries of the mux_fuzzers list (the entries themselves: LaneTab)
   uint64_t work_budget;
   uint64_t ovf_need, ovf_req;   // work area the case had asked for in total / in the request that failed (0: unknown): picks the tier that runs it again
@@ -376,7 +397,7 @@ __device__ __noinline__ void tr_kv_emit(int kind, int nb, uint32_t b0, uint32_t 
   if (nv > 2) tr_v(c, v2);
 }
 // {archiver, Name}: `up` x "../" in front of the name
-__device__ __noinline__ void tr_name_emit(const uint8_t* nm, uint32_t nl, uint32_t up) {
+__device__ __noinline__ void tr_name_emit(cbptr nm, uint32_t nl, uint32_t up) {
   Ctx& c = g_ctx;
   tr_b(c, TRK_ARCHIVER); tr_v(c, nl + 3u * up);
   for (uint32_t k = 0; k < up; k++) { tr_b(c, '.'); tr_b(c, '.'); tr_b(c, '/'); }
@@ -404,11 +425,11 @@ EH_DEV void pool_nap() {
   fprintf(stderr, "hipemu: a wait for a pool area can never end with one wavefront running (block %u)\n", blockIdx.x); abort();
 #endif
 }
-EH_DEV uint32_t pool_pop(const KParams& p, int t) {
+EH_DEV uint32_t pool_pop(const EH_G KParams& p, int t) {
   uint32_t v = 0xFFFFFFFFu;
   if (EH_LANE == 0) {
     unsigned long long h = atomicAdd(&p.pool_ctr[2 * t], 1ull);
-    uint32_t* e = p.pool_ring[t] + (h % p.pool_cnt[t]);
+    wptr e = p.pool_ring[t] + (h % p.pool_cnt[t]);
     v = atomicExch(e, 0xFFFFFFFFu);
     if (v == 0xFFFFFFFFu) {                                          // every area of the tier is out: wait for a push (eh_pool_stats counts the cycles)
       uint64_t w0 = __builtin_readcyclecounter();
@@ -427,13 +448,13 @@ EH_DEV uint32_t pool_pop(const KParams& p, int t) {
 #endif
   return uni(v);
 }
-EH_DEV void pool_push(const KParams& p, int t, uint32_t v) {
+EH_DEV void pool_push(const EH_G KParams& p, int t, uint32_t v) {
 #ifndef EH_NO_POOL_FENCE
   __threadfence();                                                   // our stores to the area are written back before it changes hands
 #endif
   if (EH_LANE == 0) {
     unsigned long long h = atomicAdd(&p.pool_ctr[2 * t + 1], 1ull);
-    uint32_t* e = p.pool_ring[t] + (h % p.pool_cnt[t]);
+    wptr e = p.pool_ring[t] + (h % p.pool_cnt[t]);
     while (atomicCAS(e, 0xFFFFFFFFu, v) != 0xFFFFFFFFu) pool_nap();
   }
 }
@@ -442,12 +463,12 @@ EH_DEV void pool_push(const KParams& p, int t, uint32_t v) {
 // scheduler on a piece of it (base64 chunks, inner texts), and the mutators down there lex their own blocks.  A table lives at
 // the top of a work-area chunk and survives candidate discards; tcap = entries it has room for (0: no table).
 struct LexChunk;
-struct LexCache { uint64_t ptr; uint32_t len; int32_t n; LexChunk* tab; uint32_t tcap; uint32_t pad; };
+struct LexCache { uint64_t ptr; uint32_t len; int32_t n; EH_G LexChunk* tab; uint32_t tcap; uint32_t pad; };
 constexpr uint32_t AUX_LEXCACHE = 2048;                              // offset in Ctx::aux of LexCache[LEX_LEVELS]
 constexpr uint64_t AUX_BYTES = 4096;
 // a slot: block list, scratch list, emit list, aux, meta-trace bytes, then the work area
 constexpr uint64_t SLOT_TABLE_BYTES = (uint64_t)(2 * MAX_BLOCKS + MAX_EMITS) * sizeof(Blk) + AUX_BYTES + TRACE_CAP;
-EH_DEV LexCache& lex_slot(Ctx& c) { return ((LexCache*)(c.aux + AUX_LEXCACHE))[c.depth]; }
+EH_DEV EH_G LexCache& lex_slot(Ctx& c) { return ((EH_G LexCache*)(c.aux + AUX_LEXCACHE))[c.depth]; }
 // Work memory at virtual offsets >= v0 is about to be reused: a lexed block that lives there (a decoded base64 chunk, an
 // inner text — temporaries of a mutator attempt) is gone, and the cache is keyed by address.  Only this level's key can
 // be up there: the blocks of the levels above are older than anything the running attempt allocated.
@@ -483,16 +504,16 @@ EH_DEV bool ws_slow(Ctx& c, uint64_t need, int site) {
   return false;
 }
 EH_DEV uint64_t ws_max_request(const Ctx& c) { return c.p->pool_cap[c.p->ntiers]; }   // the largest single allocation a case can get
-EH_DEV uint8_t* ws_alloc(Ctx& c, uint64_t n) {
+EH_DEV bptr ws_alloc(Ctx& c, uint64_t n) {
   uint64_t need = (n + 15) & ~(uint64_t)15;
   if ((c.ws_used < c.ws_lo || c.ws_used + need > c.ws_cap) && !ws_slow(c, need, 102)) return nullptr;
-  uint8_t* p = c.ws + c.ws_used;
+  bptr p = c.ws + c.ws_used;
   c.ws_used += need;
   if (c.ws_used > c.ws_peak) c.ws_peak = c.ws_used;
   return p;
 }
 // from the TOP of the chunk (tables that must survive candidate discards: the lex caches)
-EH_DEV uint8_t* ws_alloc_top(Ctx& c, uint64_t n) {
+EH_DEV bptr ws_alloc_top(Ctx& c, uint64_t n) {
   uint64_t need = (n + 15) & ~(uint64_t)15;
   if ((c.ws_used < c.ws_lo || c.ws_used + need > c.ws_cap) && !ws_slow(c, need, 501)) return nullptr;
   c.ws_cap -= need; c.ch_vend[c.view] = c.ws_cap; c.ws_top += need;
@@ -504,10 +525,10 @@ __device__ __noinline__ void ws_release_to(Ctx&, uint64_t mark) {
   c.ws_used = mark;
   while (c.nchunk > 0 && mark <= c.ch_vstart[c.nchunk]) {
     const int k = c.nchunk;
-    const KParams& p = *c.p;
-    uint8_t* lo = c.ch_base[k] + c.ch_vstart[k]; uint8_t* hi = lo + p.pool_cap[c.ch_tier[k]];
+    const EH_G KParams& p = *c.p;
+    bptr lo = c.ch_base[k] + c.ch_vstart[k]; bptr hi = lo + p.pool_cap[c.ch_tier[k]];
     for (int d = 0; d < LEX_LEVELS; d++) {                           // lex tables and lexed blocks inside the chunk: forget them
-      LexCache* lc = (LexCache*)(c.aux + AUX_LEXCACHE) + d;
+      EH_G LexCache* lc = (EH_G LexCache*)(c.aux + AUX_LEXCACHE) + d;
       uint64_t tab = uni64((uint64_t)lc->tab), key = c.lex_ptr[d];
       bool tin = uni(lc->tcap) != 0 && tab >= (uint64_t)lo && tab < (uint64_t)hi, kin = key >= (uint64_t)lo && key < (uint64_t)hi;
       if (tin || kin) { c.lex_ptr[d] = 0; if (EH_LANE == 0) { lc->n = -1; if (tin) lc->tcap = 0; } }
@@ -528,7 +549,7 @@ __device__ __noinline__ void ws_release_to(Ctx&, uint64_t mark) {
 // so that callers further out do not try again): request above the largest area, or the case is already there.
 __device__ __noinline__ bool ws_regrow(Ctx&, uint64_t mark, int* last_tier) {
   Ctx& c = g_ctx;
-  const KParams& p = *c.p;
+  const EH_G KParams& p = *c.p;
   const uint64_t asked = c.ovf_need > mark ? c.ovf_need - mark : c.ovf_req, req = c.ovf_req;
   const int site = c.ovf_line;
   ws_release_to(c, mark);
@@ -540,7 +561,7 @@ __device__ __noinline__ bool ws_regrow(Ctx&, uint64_t mark, int* last_tier) {
   const uint32_t area = pool_pop(p, tt);
   const int k = c.nchunk + 1;
   c.ch_vstart[k] = mark; c.ch_vend[k] = mark + p.pool_cap[tt]; c.ch_tier[k] = tt; c.ch_area[k] = area;
-  c.ch_base[k] = (uint8_t*)((uintptr_t)(p.pool_base[tt] + (uint64_t)area * p.pool_stride[tt]) - (uintptr_t)mark);
+  c.ch_base[k] = (bptr)((uintptr_t)(p.pool_base[tt] + (uint64_t)area * p.pool_stride[tt]) - (uintptr_t)mark);
   c.nchunk = k;
   ws_set_view(c, k);
   c.status = CASE_OK;
@@ -548,27 +569,27 @@ __device__ __noinline__ bool ws_regrow(Ctx&, uint64_t mark, int* last_tier) {
   return true;
 }
 // ws_alloc for code that is not inside a mutator attempt (patterns, generators): grows the work area on the spot
-__device__ __noinline__ uint8_t* ws_alloc_grow(Ctx&, uint64_t n) {
+__device__ __noinline__ bptr ws_alloc_grow(Ctx&, uint64_t n) {
   Ctx& c = g_ctx;
   int last_tier = 0;
   for (;;) {
-    uint8_t* q = ws_alloc(c, n);
+    bptr q = ws_alloc(c, n);
     if (q || c.status != CASE_OVERFLOW || c.ovf_need == 0) return q;
     if (!ws_regrow(c, c.ws_used, &last_tier)) return nullptr;
   }
 }
-EH_DEV Blk blk_load(const Blk* t, int i) {
+EH_DEV Blk blk_load(const EH_G Blk* t, int i) {
   Blk b = t[i];
   b.ptr = uni64(b.ptr); b.len = uni(b.len); b.aux = 0;
   return b;
 }
-EH_DEV void blk_store(Blk* t, int i, uint64_t ptr, uint32_t len) {
+EH_DEV void blk_store(EH_G Blk* t, int i, uint64_t ptr, uint32_t len) {
   if (EH_LANE == 0) { t[i].ptr = ptr; t[i].len = len; t[i].aux = 0; }
 }
 
 // random_block/1 (erlamsa_rnd.erl:165,173-174) / random_numbers(256, N) (:178-183): N draws of
 // rand(256), list built by prepending => draw j (0-based) lands at byte N-1-j.  Lane-parallel.
-EH_DEV void random_block_rev(Ctx& c, uint8_t* dst, uint32_t n) {
+EH_DEV void random_block_rev(Ctx& c, bptr dst, uint32_t n) {
   const int l = EH_LANE;
   for (uint32_t base = 0; base < n; base += 64) {
     uint32_t chunk = n - base < 64 ? n - base : 64;
@@ -586,7 +607,7 @@ EH_DEV void random_block_rev(Ctx& c, uint8_t* dst, uint32_t n) {
 __device__ __noinline__ int muta_byte(Ctx&, int fn) {
   EH_CTX;
   Blk h = blk_load(c.bl, c.cur);
-  const uint8_t* src = (const uint8_t*)h.ptr;
+  cbptr src = (cbptr)h.ptr;
   uint32_t L = h.len;
   uint32_t p = rng_rand(c.rng, L);
   int d = rng_delta(c.rng);
@@ -612,7 +633,7 @@ __device__ __noinline__ int muta_byte(Ctx&, int fn) {
   }
   if (fn == M_UI) {
     uint32_t il = c_funny.v[ins_idx][0];
-    uint8_t* dst = ws_alloc(c, (uint64_t)L + il);
+    bptr dst = ws_alloc(c, (uint64_t)L + il);
     if (!dst) return d;
     wave_copy(dst, src, p + 1);
     if ((uint32_t)EH_LANE < il) dst[p + 1 + EH_LANE] = c_funny.v[ins_idx][1 + EH_LANE];
@@ -622,7 +643,7 @@ __device__ __noinline__ int muta_byte(Ctx&, int fn) {
   }
   if (repl == 1 && nb0 == b) return d;  // same byte value: hd(Mll) == hd(Ll)
   uint32_t nl = L - 1 + repl;
-  uint8_t* dst = ws_alloc(c, nl);
+  bptr dst = ws_alloc(c, nl);
   if (!dst) return d;
   wave_copy(dst, src, p);
   if (EH_LANE == 0) { if (repl >= 1) dst[p] = (uint8_t)nb0; if (repl == 2) dst[p + 1] = (uint8_t)nb1; }
@@ -637,7 +658,7 @@ __device__ __noinline__ int muta_byte(Ctx&, int fn) {
 // ---------------------------------------------------------------------------------------------
 struct Key2 { uint64_t hi, lo; };
 EH_DEV bool key2_gt(const Key2& a, const Key2& b) { return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo); }
-EH_DEV void wave_sort_key2(Key2* k, uint32_t n_pow2) {
+EH_DEV void wave_sort_key2(EH_G Key2* k, uint32_t n_pow2) {
   const int l = EH_LANE;
   const uint32_t half = n_pow2 >> 1;
   for (uint32_t size = 2; size <= n_pow2; size <<= 1) {
@@ -672,25 +693,25 @@ EH_DEV void wave_sort_key2(Key2* k, uint32_t n_pow2) {
 __device__ __noinline__ int muta_seq(Ctx&, int fn, int mask_fun) {
   EH_CTX;
   Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* src = (const uint8_t*)hb.ptr;
+  cbptr src = (cbptr)hb.ptr;
   uint32_t B = hb.len;
   c.r_kind = R_SAME;
   if (B == 0) return -1;                                   // Self([<<>>|BTail], Meta)
   uint32_t S = rng_rand(c.rng, B);
   uint32_t Lp = rng_range(c.rng, 1, (int64_t)B - S + 1);
-  const uint8_t* P = src + S;
+  cbptr P = src + S;
   uint32_t tl = B - S - Lp;
   const int l = EH_LANE;
   switch (fn) {
     case M_SD: {                                           // :273-276
-      uint8_t* dst = ws_alloc(c, B - Lp);
+      bptr dst = ws_alloc(c, B - Lp);
       if (dst) { wave_copy(dst, src, S); wave_copy(dst + S, P + Lp, tl); c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = B - Lp; c.r_changed = 1; }
       break;
     }
     case M_SR: {                                           // :263-270
       uint32_t n = rng_log(c.rng, 10); if (n < 2) n = 2;
       uint64_t nl = (uint64_t)S + (uint64_t)Lp * n + tl;
-      uint8_t* dst = nl > 0xFFFFFFFFull ? (EH_SET_OVERFLOW(c, 103), c.ovf_req = ~0ull, nullptr) : ws_alloc(c, nl);
+      bptr dst = nl > 0xFFFFFFFFull ? (EH_SET_OVERFLOW(c, 103), c.ovf_req = ~0ull, nullptr) : ws_alloc(c, nl);
       if (dst) {
         wave_copy(dst, src, S);
         wave_fill_periodic(dst + S, P, Lp, (uint64_t)Lp * n);
@@ -700,7 +721,7 @@ __device__ __noinline__ int muta_seq(Ctx&, int fn, int mask_fun) {
       break;
     }
     case M_SP: {                                           // :253-260 + random_permutation erlamsa_rnd.erl:190-196
-      uint8_t* dst = ws_alloc(c, B);
+      bptr dst = ws_alloc(c, B);
       if (!dst) break;
       wave_copy(dst, src, S);
       wave_copy(dst + S + Lp, P + Lp, tl);
@@ -712,7 +733,7 @@ __device__ __noinline__ int muta_seq(Ctx&, int fn, int mask_fun) {
         // non-negative double order like the value.
         uint32_t np2 = 1; while (np2 < Lp) np2 <<= 1;
         uint64_t mark = c.ws_used;
-        Key2* keys = (Key2*)ws_alloc(c, (uint64_t)np2 * sizeof(Key2));
+        EH_G Key2* keys = (EH_G Key2*)ws_alloc(c, (uint64_t)np2 * sizeof(Key2));
         if (!keys) break;
         for (uint32_t base = 0; base < np2; base += 64) {
           uint32_t idx = base + l;
@@ -739,7 +760,7 @@ __device__ __noinline__ int muta_seq(Ctx&, int fn, int mask_fun) {
       // draw carrying the next flag), so 64 draws are resolved at once: every lane evaluates its
       // uniform by jump-ahead, the transition maps are composed with a shuffle prefix scan, and
       // ballots assign draws to bytes.
-      uint8_t* dst = ws_alloc(c, B);
+      bptr dst = ws_alloc(c, B);
       if (!dst) break;
       wave_copy(dst, src, B);
       uint32_t prob = rng_erand(c.rng, 100);
@@ -879,7 +900,7 @@ EH_DEV void commit_result(Ctx& c) {
   for (uint32_t k = EH_LANE; k < chunks; k += 64) {
     bool second = k >= chunks1;
     uint32_t kk = second ? k - chunks1 : k, nchk = second ? chunks2 : chunks1;
-    uint8_t* base = second ? c.r2_ptr : c.r_ptr; uint32_t blen = second ? c.r2_len : c.r_len;
+    bptr base = second ? c.r2_ptr : c.r_ptr; uint32_t blen = second ? c.r2_len : c.r_len;
     bool fl = second || c.r_flush;
     uint64_t off = (uint64_t)kk * AVG_BLOCK_SIZE;
     uint32_t len = fl ? (kk + 1 < nchk ? AVG_BLOCK_SIZE : blen - (uint32_t)off) : blen;
@@ -973,7 +994,7 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
     // has borrowed a larger area (ws_regrow).  lis / lrs update their store before they allocate: it is put back as well.
     const Rng rng0 = c.rng; const uint64_t work0 = c.work; const uint32_t ntrace0 = c.ntrace;
     const bool stateful = fn == M_LIS || fn == M_LRS;
-    if (stateful) { const uint32_t* ax = (const uint32_t*)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) g_st_save[i] = ax[i]; }
+    if (stateful) { cwptr ax = (cwptr)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) g_st_save[i] = ax[i]; }
     int delta, last_tier = 0;
     for (;;) {
       delta = run_mutator(c, fn, em_mask(meta));
@@ -983,7 +1004,7 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
       lex_forget_from(c, mark);
       c.rng = rng0; c.work = work0; c.ntrace = ntrace0;
       c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
-      if (stateful) { lanes_sync(); uint32_t* ax = (uint32_t*)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) ax[i] = g_st_save[i]; }
+      if (stateful) { lanes_sync(); wptr ax = (wptr)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) ax[i] = g_st_save[i]; }
       wave_sync();
     }
 #ifdef EH_PROF
@@ -1000,7 +1021,7 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
     if (c.r_kind == R_NEW) {
       wave_sync();                                                                  // candidate bytes were written by other lanes
       uint32_t hd_len = c.r_flush && c.r_len >= AVG_BLOCK_SIZE ? AVG_BLOCK_SIZE : c.r_len;
-      changed = c.r_changed || hd_len != h0.len || !wave_equal(c.r_ptr, (const uint8_t*)h0.ptr, hd_len);
+      changed = c.r_changed || hd_len != h0.len || !wave_equal(c.r_ptr, (cbptr)h0.ptr, hd_len);
     }
     own_meta(c, fn, delta, h0.len);                                                // the mutator's own entry is in the Meta it returns, used or failed
     tr_aa(c, changed ? AT_used : AT_failed, (int)name);                            // {used, Name} / {failed, Name} :1278-1279
@@ -1022,7 +1043,7 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
         while (j > 0 && mark <= c.ch_vstart[j]) j--;
         const uint64_t need = ((uint64_t)c.r_len + 15) & ~(uint64_t)15;
         if (mark + need <= c.ch_vend[j]) {
-          uint8_t* dst = c.ch_base[j] + mark;
+          bptr dst = c.ch_base[j] + mark;
           // (the candidate is not always up in a borrowed area: a chunk the PATTERN borrowed for its scans - pick_csum,
           // pick_simple_len - and gave back by resetting ws_used starts exactly at mark, and the attempt then ran in the chunk
           // below it, a few bytes above dst: overlapping ranges, which wave_copy must not be given)
@@ -1037,16 +1058,16 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
           if (c.ws_used > c.ws_peak) c.ws_peak = c.ws_used;
         }
       }
-      uint8_t* lo = c.ws + mark;
+      bptr lo = c.ws + mark;
       // A candidate of more than a few MiB stays where it is: mux_fuzzers never hands out a block above
       // ABSMAX_BINARY_BLOCK again (:1269, split_into_maxblocks), so nothing will copy it as a whole any more, and sliding
       // a 1 GiB tree-stutter result took a lone wavefront 0.7 s.  (mark below the chunk the candidate is in: the attempt
       // went on in the next area up; not worth a copy across areas.)
       const uint64_t vs = c.ws_lo;
       if (mark >= vs && c.ws_used - vs > (c.ws_cap - vs) / 8 && c.r_len <= (4u << 20) && !c.r2 && c.r_ptr >= lo && c.r_ptr + c.r_len <= c.ws + c.ws_used) {
-        uint8_t* dst = lo;
-        uint8_t* hp = (uint8_t*)h0.ptr;
-        bool state_refs = uni(((const uint32_t*)c.aux)[0]) != 0 || uni(((const uint32_t*)(c.aux + 336))[0]) != 0 || uni(((const uint32_t*)(c.aux + 704))[3]) != 0;
+        bptr dst = lo;
+        bptr hp = (bptr)h0.ptr;
+        bool state_refs = uni(((cwptr)c.aux)[0]) != 0 || uni(((cwptr)(c.aux + 336))[0]) != 0 || uni(((cwptr)(c.aux + 704))[3]) != 0;
         if (!state_refs && hp >= c.ws + vs && hp + ((h0.len + 15u) & ~15u) == lo && ((uintptr_t)hp & 15) == 0) dst = hp;
         if (dst != c.r_ptr) { wave_sync(); wave_move_down(dst, c.r_ptr, c.r_len); wave_sync(); c.r_ptr = dst; }   // candidate stores must have landed
         c.ws_used = (uint64_t)(dst - c.ws) + (((uint64_t)c.r_len + 15) & ~(uint64_t)15);

@@ -17,7 +17,7 @@ namespace eh {
 
 struct Piece { uint64_t ptr; uint32_t len; uint32_t rep; };
 
-EH_DEV void piece_put(Piece* t, uint32_t i, const void* p, uint32_t len, uint32_t rep = 1) {
+EH_DEV void piece_put(EH_G Piece* t, uint32_t i, const void* p, uint32_t len, uint32_t rep = 1) {
   if (EH_LANE == 0) { t[i].ptr = (uint64_t)p; t[i].len = len; t[i].rep = rep; }
 }
 // per-lane source lane (ds_bpermute); readlane64 needs a wave-uniform lane
@@ -27,7 +27,7 @@ EH_DEV uint32_t wave_max(uint32_t v) {
   for (int d = 32; d > 0; d >>= 1) { uint32_t t = (uint32_t)__shfl_xor((int)v, d); v = t > v ? t : v; }
   return uni(v);
 }
-EH_DEV uint64_t pieces_total(const Piece* t, uint32_t n) {
+EH_DEV uint64_t pieces_total(const EH_G Piece* t, uint32_t n) {
   uint64_t s = 0;
   for (uint32_t i = EH_LANE; i < n; i += 64) s += (uint64_t)t[i].len * t[i].rep;
   return wave_sum64(s);
@@ -36,7 +36,7 @@ EH_DEV uint64_t pieces_total(const Piece* t, uint32_t n) {
 // count.  Tokenizers point their "literal" pieces at the input bytes whenever the input spells the canonical form,
 // so an unedited stretch of a document collapses into one long piece and the gather below moves it with 16-byte
 // vectors instead of a lane per 1-byte piece.
-EH_DEV uint32_t pieces_coalesce(Piece* t, uint32_t n) {
+EH_DEV uint32_t pieces_coalesce(EH_G Piece* t, uint32_t n) {
   const int l = EH_LANE;
   uint32_t nout = 0;
   uint64_t carry_end = 0; bool have_carry = false;                  // end address of the last written piece (if mergeable)
@@ -83,7 +83,7 @@ EH_DEV uint32_t pieces_coalesce(Piece* t, uint32_t n) {
   return nout;
 }
 // dst[0, total) = concatenation of the pieces; the caller allocated `total` = pieces_total() bytes
-EH_DEV void wave_gather(uint8_t* dst, const Piece* t, uint32_t n) {
+EH_DEV void wave_gather(bptr dst, const EH_G Piece* t, uint32_t n) {
   const int l = EH_LANE;
   uint64_t pos = 0;
   for (uint32_t base = 0; base < n; base += 64) {
@@ -101,8 +101,8 @@ EH_DEV void wave_gather(uint8_t* dst, const Piece* t, uint32_t n) {
     uint64_t off = pos + inc - tl;
     bool big = len > 48 || rep > 1;
     uint32_t maxs = wave_max(big ? 0u : len);
-    const uint8_t* sp = (const uint8_t*)ptr;
-    uint8_t* dp = dst + off;
+    cbptr sp = (cbptr)ptr;
+    bptr dp = dst + off;
     for (uint32_t i0 = 0; i0 < maxs; i0 += 8) {
       uint8_t b[8];
 #pragma unroll
@@ -115,25 +115,25 @@ EH_DEV void wave_gather(uint8_t* dst, const Piece* t, uint32_t n) {
       int j = (int)__builtin_ctzll(bm); bm &= bm - 1;
       uint64_t pj = readlane64(ptr, (uint32_t)j), oj = readlane64(off, (uint32_t)j);
       uint32_t lj = (uint32_t)__builtin_amdgcn_readlane((int)len, j), rj = (uint32_t)__builtin_amdgcn_readlane((int)rep, j);
-      if (rj == 1) wave_copy(dst + oj, (const uint8_t*)pj, lj);
-      else wave_fill_periodic(dst + oj, (const uint8_t*)pj, lj, (uint64_t)lj * rj);
+      if (rj == 1) wave_copy(dst + oj, (cbptr)pj, lj);
+      else wave_fill_periodic(dst + oj, (cbptr)pj, lj, (uint64_t)lj * rj);
     }
     pos += readlane64(inc, 63);
   }
 }
 // entries [a, b) of src appended to dst[*n ..)
-EH_DEV void pieces_append(Piece* dst, uint32_t* n, const Piece* src, uint32_t a, uint32_t b) {
+EH_DEV void pieces_append(EH_G Piece* dst, uint32_t* n, const EH_G Piece* src, uint32_t a, uint32_t b) {
   if (b <= a) return;
   uint32_t cnt = b - a, at = *n;
   for (uint32_t i = EH_LANE; i < cnt; i += 64) dst[at + i] = src[a + i];
   *n = at + cnt;
 }
 // gathers pieces [a, b) into a fresh temporary of the work area; returns it as one piece (ptr, len)
-EH_DEV bool pieces_materialize(Ctx& c, const Piece* t, uint32_t a, uint32_t b, uint8_t** out, uint32_t* outlen) {
+EH_DEV bool pieces_materialize(Ctx& c, const EH_G Piece* t, uint32_t a, uint32_t b, bptr* out, uint32_t* outlen) {
   wave_sync();
   uint64_t tot = pieces_total(t + a, b - a);
   if (tot > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 201); return false; }
-  uint8_t* d = ws_alloc(c, tot ? tot : 16);
+  bptr d = ws_alloc(c, tot ? tot : 16);
   if (!d) return false;
   wave_gather(d, t + a, b - a);
   wave_sync();
@@ -148,7 +148,7 @@ struct IsInk { EH_DEV bool operator()(uint32_t b, uint32_t) const { return b != 
 // erlamsa_json:mutate_innertext_prob/4 (:633-639).  Lane i holds entry i of the list.  Returns the number
 // of blocks of the resulting list, which sit at c.bl[c.nb .. c.nb + n) until the next nested call, or -1
 // with c.status set.  Defined in eh_engine.hip (it re-enters mux_fuzzers; real device recursion).
-__device__ int nested_fuzz(Ctx&, uint32_t e_pri, uint32_t e_meta, int nfs, const uint8_t* bin, uint32_t len);
+__device__ int nested_fuzz(Ctx&, uint32_t e_pri, uint32_t e_meta, int nfs, cbptr bin, uint32_t len);
 
 __constant__ uint8_t c_def_pri[M_COUNT] = {10, 3, 1, 2, 1, 1, 1, 1, 3, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 2, 2, 7, 1, 1, 0};
 
@@ -175,19 +175,19 @@ EH_DEV void inner_table(Ctx& c, bool json, uint32_t* e_pri, uint32_t* e_meta, in
 // base64_mutator/2 (erlamsa_mutations.erl:658-690): every text chunk longer than 6 that base64:decode/1 accepts
 // is decoded, mutated once by a FRESH mutators_mutator over the whole default table (mutas_list(mutations([])):
 // 2 draws for the table itself, then 41 score draws per chunk, list in REVERSE table order) and encoded again.
-__device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
+__device__ __noinline__ int muta_b64(Ctx&, EH_G LexCache& lc) {
   EH_CTX;
   const int l = EH_LANE;
   Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
-  LexChunk* tab;
+  EH_G LexChunk* tab;
   EH_PT0;
   int n = lex_cached(c, lc, H, L, &tab);
   if (n < 0) return 0;
   EH_PT(c, 48);                                                  // eh_result_prof 48..53: lexing, candidates refused, decode, nested call, encode, gather
   uint32_t snand_mask = rng_rand(c.rng, 3); (void)rng_rand(c.rng, 1);   // mutations([]) :661 -> :1313-1314
-  Piece* out = nullptr; uint32_t nout = 0, cap = 0, done_to = 0;
+  EH_G Piece* out = nullptr; uint32_t nout = 0, cap = 0, done_to = 0;
   int dacc = -1;
   // candidate chunks ({text, A} when length(A) > 6, :664) are picked 64 table entries at a time
   for (int base = 0; base < n; base += 64) {
@@ -204,11 +204,11 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
     uint32_t dl = b64_decoded_len(nalpha);
     if (!out) {                                                  // first hit: the piece list of unlex(Ms)
       cap = 2 * (uint32_t)(n - i) + 4;
-      out = (Piece*)ws_alloc(c, (uint64_t)cap * sizeof(Piece));
+      out = (EH_G Piece*)ws_alloc(c, (uint64_t)cap * sizeof(Piece));
       if (!out) return 0;
     }
-    uint8_t* dec = ws_alloc(c, (uint64_t)dl + 16);
-    uint8_t* pack = nalpha != span ? ws_alloc(c, (uint64_t)nalpha + 16) : nullptr;
+    bptr dec = ws_alloc(c, (uint64_t)dl + 16);
+    bptr pack = nalpha != span ? ws_alloc(c, (uint64_t)nalpha + 16) : nullptr;
     if (!dec || (nalpha != span && !pack)) return 0;
     EH_PT(c, 49);
     b64_decode_wave(H + a, span, nalpha, dec, pack);
@@ -230,11 +230,11 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
     uint64_t tot = 0;
     for (int k = 0; k < nres; k++) tot += blk_load(c.bl, c.nb + k).len;
     if (tot > 0xBFFFFFF0ull) { EH_SET_OVERFLOW(c, 202); return 0; }
-    uint8_t* nb = ws_alloc(c, tot + 16);
-    uint8_t* enc = ws_alloc(c, (tot + 2) / 3 * 4 + 16);
+    bptr nb = ws_alloc(c, tot + 16);
+    bptr enc = ws_alloc(c, (tot + 2) / 3 * 4 + 16);
     if (!nb || !enc) return 0;
     uint64_t o = 0;
-    for (int k = 0; k < nres; k++) { Blk x = blk_load(c.bl, c.nb + k); wave_copy(nb + o, (const uint8_t*)x.ptr, x.len); o += x.len; }
+    for (int k = 0; k < nres; k++) { Blk x = blk_load(c.bl, c.nb + k); wave_copy(nb + o, (cbptr)x.ptr, x.len); o += x.len; }
     wave_sync();
     b64_encode(nb, (uint32_t)tot, enc);
     wave_sync();
@@ -251,7 +251,7 @@ __device__ __noinline__ int muta_b64(Ctx&, LexCache& lc) {
   wave_sync();
   uint64_t total = pieces_total(out, nout);
   if (total > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 203); return 0; }
-  uint8_t* dst = ws_alloc(c, total ? total : 16);
+  bptr dst = ws_alloc(c, total ? total : 16);
   if (!dst) return 0;
   wave_gather(dst, out, nout);
   wave_sync();

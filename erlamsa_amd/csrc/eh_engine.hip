@@ -45,7 +45,7 @@ namespace eh {
 
 EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
   (void)mask;
-  StState* st = (StState*)c.aux;
+  EH_G StState* st = (EH_G StState*)c.aux;
   switch (fn) {
     case M_LD: case M_LDS: case M_LR2: case M_LRI: case M_LR: case M_LS: case M_LP: return muta_line(c, (int)fn);
     case M_LIS: return muta_st_line(c, (int)fn, st);
@@ -56,7 +56,7 @@ EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
     case M_B64: return muta_b64(c, lex_slot(c));
     case M_ZIP: return muta_zip(c);
     case M_LEN: return muta_len(c);
-    case M_FT: case M_FN: case M_FO: return muta_fuse(c, (int)fn, (FoState*)(c.aux + 704));
+    case M_FT: case M_FN: case M_FO: return muta_fuse(c, (int)fn, (EH_G FoState*)(c.aux + 704));
     case M_TR2: case M_TD: case M_TS1: case M_TS2: case M_TR: return muta_tree(c, (int)fn);
     case M_SGM: return muta_sgml(c);
     case M_JS: return muta_json(c);
@@ -67,17 +67,17 @@ EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
 // Nested scheduler call (see eh_doc.h).  The inner list [Bin] lives above the outer block list; the stateful
 // mutators of the inner table (lis, lrs, fo) start from their initial state, as the closures of a fresh
 // mutators_mutator/1 do, so the outer states are parked in the work area for the duration of the call.
-__device__ __noinline__ int nested_fuzz(Ctx&, uint32_t e_pri, uint32_t e_meta, int nfs, const uint8_t* bin, uint32_t len) {
+__device__ __noinline__ int nested_fuzz(Ctx&, uint32_t e_pri, uint32_t e_meta, int nfs, cbptr bin, uint32_t len) {
   EH_CTX;
   const int l = EH_LANE;
   if (c.depth >= MAX_NEST || c.nb + 2 > MAX_BLOCKS) { EH_SET_OVERFLOW(c, 301); return -1; }
   constexpr uint32_t SAVE = 720;                                            // StState x 2 + FoState (aux + 0 .. 720)
-  uint32_t* save = (uint32_t*)ws_alloc(c, SAVE);
+  wptr save = (wptr)ws_alloc(c, SAVE);
   if (!save) return -1;
-  uint32_t* ax = (uint32_t*)c.aux;
+  wptr ax = (wptr)c.aux;
   for (uint32_t i = l; i < SAVE / 4; i += 64) save[i] = ax[i];
   wave_sync();
-  if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; ((FoState*)(c.aux + 704))->has = 0; }
+  if (l == 0) { ((EH_G StState*)c.aux)[0].count = 0; ((EH_G StState*)c.aux)[1].count = 0; ((EH_G FoState*)(c.aux + 704))->has = 0; }
   const int cur0 = c.cur, nb0 = c.nb, nfs0 = c.nfs, lastm0 = c.lastm;
   blk_store(c.bl, nb0, (uint64_t)bin, len);
   wave_sync();
@@ -139,16 +139,18 @@ EH_DEV void setup_run(const DevConfig& cfg, int64_t s1, int64_t s2, int64_t s3, 
 // next of those one at a time, they starve - 0.17 s on average and up to 0.8 s per launch with six passes in flight, seconds with
 // twelve (profiles/r05_kernel_stats_before_prologue.csv) - and the pass behind them with them.  A one-wavefront kernel takes the
 // next free slot like any other workgroup of the batch (the old eh_setup_kernel: 29 us on average in the same trace).
-__global__ void __launch_bounds__(64) eh_prologue_kernel(KParams p, int64_t s1, int64_t s2, int64_t s3, RunState* out, KParams* params_out,
-                                                         unsigned long long* counters) {
+__global__ void __launch_bounds__(64) eh_prologue_kernel(KParams p, int64_t s1, int64_t s2, int64_t s3, RunState* out_, KParams* params_out_,
+                                                         unsigned long long* counters_) {
+  // (kernel arguments are what the host passes: generic pointers)
+  EH_G RunState* out = (EH_G RunState*)out_; EH_G KParams* params_out = (EH_G KParams*)params_out_; EH_G unsigned long long* counters = (EH_G unsigned long long*)counters_;
   const int l = EH_LANE;
   for (int i = l; i < 512; i += 64) counters[i] = 0;             // ticket, output cursor, input bytes, prof slots: 4096 bytes
 #ifdef EH_PROF
   if (l == 0) counters[8 + 2 * 127] = ~0ull;                     // earliest workgroup start: atomicMin
 #endif
   static_assert(sizeof(KParams) % 4 == 0, "KParams is copied word by word");
-  const uint32_t* src = (const uint32_t*)&p;
-  uint32_t* dst = (uint32_t*)params_out;
+  cwptr src = (cwptr)&p;
+  wptr dst = (wptr)params_out;
   for (int i = l; i < (int)(sizeof(KParams) / 4); i += 64) dst[i] = src[i];
   if (p.mode != 0) return;
   Rng rng; int gen, mask, nfs; uint32_t e_pri, e_meta;
@@ -200,7 +202,7 @@ enum ContKind { C_EMIT, C_ND, C_BU, C_PAT };
 struct PatFrame {           // a sizer/csum wrapper waiting for its inner evaluation (prepare4sizer)
   int kind;                 // P_SZ or P_CS
   int em_field;             // sz: index of the length-field piece in the emit list; cs: first inner piece
-  uint8_t* field;           // sz: the Size/8 bytes to fill in
+  bptr field;           // sz: the Size/8 bytes to fill in
   uint32_t size_bits, big;  // sz
   uint64_t tail_ptr; uint32_t tail_len;   // sz: TailBin
   uint32_t crc;             // cs: 1 crc32, 0 xor8
@@ -208,7 +210,7 @@ struct PatFrame {           // a sizer/csum wrapper waiting for its inner evalua
 
 // get_possible_csum_locations/1 + rand_elem (erlamsa_field_predict.erl:131-161).
 // Returns 1 with (*crc,*plen,*blen), 0 for no candidate, -1 on failure.
-__device__ __noinline__ int pick_csum(Ctx&, const uint8_t* H, uint32_t L, uint32_t* crc, uint32_t* plen, uint32_t* blen) {
+__device__ __noinline__ int pick_csum(Ctx&, cbptr H, uint32_t L, uint32_t* crc, uint32_t* plen, uint32_t* blen) {
   EH_CTX;
   const int l = EH_LANE;
   if (L == 0) return 0;
@@ -220,7 +222,7 @@ __device__ __noinline__ int pick_csum(Ctx&, const uint8_t* H, uint32_t L, uint32
   uint32_t tot = wave_xor8(H, L - 1);
   uint32_t target = tot ^ last;
   uint64_t mark = c.ws_used;
-  uint8_t* flags = ws_alloc_grow(c, (uint64_t)np * 2);                  // [0,np): xor8 hit, [np,2np): crc32 hit
+  bptr flags = ws_alloc_grow(c, (uint64_t)np * 2);                  // [0,np): xor8 hit, [np,2np): crc32 hit
   if (!flags) return -1;
   uint32_t carry = 0, nx = 0;
   for (uint32_t base = 0; base < np; base += 64) {
@@ -244,7 +246,7 @@ __device__ __noinline__ int pick_csum(Ctx&, const uint8_t* H, uint32_t L, uint32
     uint32_t E = L - 4;
     uint32_t whole = wave_crc32(H, E);                             // crc(0..E)
     // prefix CRCs crc(0..A) for A <= maxp: one sequential table walk shared by the wave ...
-    uint32_t* pre = (uint32_t*)ws_alloc_grow(c, (uint64_t)np * 4);
+    wptr pre = (wptr)ws_alloc_grow(c, (uint64_t)np * 4);
     if (!pre) return -1;
     uint32_t run = 0xFFFFFFFFu;
     ByteReader r; br_init(r, H, L);
@@ -287,18 +289,18 @@ __device__ __noinline__ int pick_csum(Ctx&, const uint8_t* H, uint32_t L, uint32
 // away, the meta trace are put back.  What is parked lives in the work area until the frame is popped.
 // ---------------------------------------------------------------------------------------------------------------------
 struct MutatorSave { uint32_t lt_pri[64], lt_meta[64]; uint32_t aux_save[180]; int32_t nfs; uint32_t ntrace; };   // aux + 0 .. 720: StState x 2 + FoState
-EH_DEV void mutator_save(Ctx& c, MutatorSave* m, uint32_t e_pri, uint32_t e_meta) {
+EH_DEV void mutator_save(Ctx& c, EH_G MutatorSave* m, uint32_t e_pri, uint32_t e_meta) {
   const int l = EH_LANE;
   m->lt_pri[l] = e_pri; m->lt_meta[l] = e_meta;
-  const uint32_t* ax = (const uint32_t*)c.aux;
+  cwptr ax = (cwptr)c.aux;
   for (int i = l; i < 180; i += 64) m->aux_save[i] = ax[i];
   if (l == 0) { m->nfs = c.nfs; m->ntrace = c.ntrace; }
   wave_sync();
 }
-EH_DEV uint64_t mutator_restore(Ctx& c, const MutatorSave* m, bool trace_too) {   // returns the lane's (e_pri, e_meta)
+EH_DEV uint64_t mutator_restore(Ctx& c, const EH_G MutatorSave* m, bool trace_too) {   // returns the lane's (e_pri, e_meta)
   const int l = EH_LANE;
   wave_sync();
-  uint32_t* ax = (uint32_t*)c.aux;
+  wptr ax = (wptr)c.aux;
   for (int i = l; i < 180; i += 64) ax[i] = m->aux_save[i];
   c.nfs = (int)uni((uint32_t)m->nfs);
   if (trace_too) c.ntrace = uni(m->ntrace);
@@ -306,15 +308,15 @@ EH_DEV uint64_t mutator_restore(Ctx& c, const MutatorSave* m, bool trace_too) { 
   return ((uint64_t)m->lt_pri[l] << 32) | m->lt_meta[l];
 }
 // the pieces em[from..nem) as one binary (iolist_to_binary of prepare4sizer); a single piece is used where it is
-EH_DEV uint8_t* gather_emits(Ctx& c, int from, uint64_t* len) {
+EH_DEV bptr gather_emits(Ctx& c, int from, uint64_t* len) {
   uint64_t tot = 0; for (int k = from; k < c.nem; k++) tot += blk_load(c.em, k).len;
   *len = tot;
   if (tot > 0xFFFFFF00ull) { EH_SET_OVERFLOW(c, 316); return nullptr; }
-  if (c.nem - from == 1) return (uint8_t*)blk_load(c.em, from).ptr;
-  uint8_t* blob = ws_alloc_grow(c, tot + 16);
+  if (c.nem - from == 1) return (bptr)blk_load(c.em, from).ptr;
+  bptr blob = ws_alloc_grow(c, tot + 16);
   if (!blob) return nullptr;
   uint64_t o = 0;
-  for (int k = from; k < c.nem; k++) { Blk x = blk_load(c.em, k); wave_copy(blob + o, (const uint8_t*)x.ptr, x.len); o += x.len; }
+  for (int k = from; k < c.nem; k++) { Blk x = blk_load(c.em, k); wave_copy(blob + o, (cbptr)x.ptr, x.len); o += x.len; }
   wave_sync();
   return blob;
 }
@@ -323,20 +325,20 @@ struct CpSide { MutatorSave m; Blk orig; int32_t fmt, nrest, ip, contpat; uint32
 // mutate_once_compressed/6 (erlamsa_patterns.erl:216-246) up to the inner evaluation: zlib:gunzip(Bin), on data_error
 // zlib:inflate(Bin).  1: bl[cur] is the decoded Data alone and a P_CP frame waits for the evaluation; 0: not compressed
 // ({Bin, Meta}); -1: the case stops (status set).
-__device__ __noinline__ int cp_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, PatFrame* frames, int nfr, uint32_t ip, int contpat) {
+__device__ __noinline__ int cp_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, EH_G PatFrame* frames, int nfr, uint32_t ip, int contpat) {
   EH_CTX;
   const int l = EH_LANE;
   const Blk b = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)b.ptr;
+  cbptr H = (cbptr)b.ptr;
   if (!codec_work(c, b.len)) return -1;                                      // the attempt to decode reads the block
-  ZInf* zi = (ZInf*)ws_alloc_grow(c, sizeof(ZInf));
+  EH_G ZInf* zi = (EH_G ZInf*)ws_alloc_grow(c, sizeof(ZInf));
   if (!zi) return -1;
-  int fmt = 0; uint8_t* data = nullptr; uint64_t dlen = 0;
+  int fmt = 0; bptr data = nullptr; uint64_t dlen = 0;
   for (int f = ZF_GZIP; f <= ZF_ZLIB && fmt == 0; f++) {
     uint64_t outn, off;
     if (!z_uncompress_size(zi, f, H, b.len, &outn, &off)) continue;
     if (outn > 0xFFFFFF00ull) { EH_SET_OVERFLOW(c, 314); return -1; }
-    uint8_t* d = ws_alloc_grow(c, outn + 16);
+    bptr d = ws_alloc_grow(c, outn + 16);
     if (!d) return -1;
     if (z_uncompress_write(zi, f, H, b.len, off, d, outn)) { fmt = f; data = d; dlen = outn; }
   }
@@ -344,20 +346,20 @@ __device__ __noinline__ int cp_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, PatF
   if (!codec_work(c, dlen)) return -1;                                       // ... and the payload was written
   if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 315); return -1; }
   const int nrest = c.nb - c.cur - 1;
-  CpSide* sd = (CpSide*)ws_alloc_grow(c, sizeof(CpSide) + (uint64_t)nrest * sizeof(Blk));
+  EH_G CpSide* sd = (EH_G CpSide*)ws_alloc_grow(c, sizeof(CpSide) + (uint64_t)nrest * sizeof(Blk));
   if (!sd) return -1;
   mutator_save(c, &sd->m, e_pri, e_meta);
   // {NewBin, [{compressed, gzip}, NewMeta, {decompressed, gzip} | Meta]} :223 (zlib :241): printed as decompressed, what the payload's
   // evaluation adds (a Meta list of its own, from []), compressed
   tr_aa(c, AT_decompressed, fmt == ZF_GZIP ? AT_gzip : AT_zlib);
   const uint32_t tr_base0 = c.tr_base; c.tr_base = c.ntrace;
-  Blk* rest = (Blk*)(sd + 1);
+  EH_G Blk* rest = (EH_G Blk*)(sd + 1);
   for (int i = l; i < nrest; i += 64) rest[i] = c.bl[c.cur + 1 + i];
   if (l == 0) {
     sd->tr_base0 = tr_base0;
     sd->orig = b; sd->fmt = fmt; sd->nrest = nrest; sd->ip = (int32_t)ip; sd->contpat = contpat;
-    PatFrame& f = frames[nfr];
-    f.kind = P_CP; f.em_field = c.nem; f.field = (uint8_t*)sd; f.size_bits = 0; f.big = 0; f.tail_ptr = 0; f.tail_len = 0; f.crc = 0;
+    EH_G PatFrame& f = frames[nfr];
+    f.kind = P_CP; f.em_field = c.nem; f.field = (bptr)sd; f.size_bits = 0; f.big = 0; f.tail_ptr = 0; f.tail_len = 0; f.crc = 0;
   }
   wave_sync();
   blk_store(c.bl, c.cur, (uint64_t)data, (uint32_t)dlen);                   // mutate_once_loop(Mutator, [], NextPat, Ip, Data, [])
@@ -369,31 +371,31 @@ __device__ __noinline__ int cp_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, PatF
 // 252-260).  c.pat_ret 1: [NewBin | Rest] is the result (bl[cur..nb), to be written as it is); 0: unchanged - the list is
 // [Bin | Rest] again, the Mutator and the trace are the ones from before, c.pat_ip / c.pat_cont say how mutate_once_loop goes
 // on; -1: the case stops.  Returns the lane's scheduler entry (e_pri << 32 | e_meta) to go on with.
-__device__ __noinline__ uint64_t cp_end(Ctx&, uint32_t e_pri, uint32_t e_meta, int em_field, uint8_t* side) {
+__device__ __noinline__ uint64_t cp_end(Ctx&, uint32_t e_pri, uint32_t e_meta, int em_field, bptr side) {
   EH_CTX;
   const int l = EH_LANE;
   const uint64_t keep = ((uint64_t)e_pri << 32) | e_meta;
-  CpSide* sd = (CpSide*)side;
+  EH_G CpSide* sd = (EH_G CpSide*)side;
   const int fmt = (int)uni((uint32_t)sd->fmt), nrest = (int)uni((uint32_t)sd->nrest);
   Blk orig; orig.ptr = uni64(sd->orig.ptr); orig.len = uni(sd->orig.len); orig.aux = 0;
   c.pat_ret = -1; c.pat_ip = uni((uint32_t)sd->ip); c.pat_cont = (int)uni((uint32_t)sd->contpat);
   c.tr_base = uni(sd->tr_base0);
   tr_aa(c, AT_compressed, fmt == ZF_GZIP ? AT_gzip : AT_zlib);
   uint64_t tot;
-  const uint8_t* nd = gather_emits(c, em_field, &tot);
+  cbptr nd = gather_emits(c, em_field, &tot);
   if (tot > 0 && !nd) return keep;
   c.nem = em_field;
   if (!codec_work(c, tot)) return keep;                                      // zlib:gzip(NewData) | deflate
-  ZDef* zd = (ZDef*)ws_alloc_grow(c, sizeof(ZDef));
+  EH_G ZDef* zd = (EH_G ZDef*)ws_alloc_grow(c, sizeof(ZDef));
   if (!zd) return keep;
   const uint64_t cap = z_deflate_bound(tot) + z_wrap_bytes(fmt);
-  uint8_t* dst = ws_alloc_grow(c, cap);
+  bptr dst = ws_alloc_grow(c, cap);
   if (!dst) return keep;
   const uint64_t nlen = z_compress(zd, fmt, nd, tot, dst, cap);
   if (nlen == 0 || nlen > 0xFFFFFF00ull) { EH_SET_OVERFLOW(c, 317); return keep; }
-  const bool changed = nlen != orig.len || !wave_equal(dst, (const uint8_t*)orig.ptr, (uint32_t)nlen);
+  const bool changed = nlen != orig.len || !wave_equal(dst, (cbptr)orig.ptr, (uint32_t)nlen);
   if (c.cur + 1 + nrest > MAX_BLOCKS) { EH_SET_OVERFLOW(c, 318); return keep; }
-  const Blk* rest = (const Blk*)(sd + 1);
+  const EH_G Blk* rest = (const EH_G Blk*)(sd + 1);
   wave_sync();
   for (int i = l; i < nrest; i += 64) c.bl[c.cur + 1 + i] = rest[i];
   if (changed) blk_store(c.bl, c.cur, (uint64_t)dst, (uint32_t)nlen); else blk_store(c.bl, c.cur, orig.ptr, orig.len);
@@ -404,24 +406,24 @@ __device__ __noinline__ uint64_t cp_end(Ctx&, uint32_t e_pri, uint32_t e_meta, i
   return mutator_restore(c, &sd->m, true);
 }
 
-struct ArSide { MutatorSave m; Blk archive; int32_t n, idx, ip, contpat; ZipEntry* es; uint32_t tr_base0, pad; };
+struct ArSide { MutatorSave m; Blk archive; int32_t n, idx, ip, contpat; EH_G ZipEntry* es; uint32_t tr_base0, pad; };
 // mutate_once_archiver/4 (erlamsa_patterns.erl:203-214): UnZip = zip:foldl(fun(N, I, B, Acc) -> [{N, B(), I()} | Acc] end, [], ..) over
 // bl[cur] (the whole list as one binary).  c.pat_ret 1: an archive - the side block (returned) holds its entries and the Mutator;
 // 0: {error, _}; -1: the case stops.
-__device__ __noinline__ uint8_t* ar_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, uint32_t ip, int contpat) {
+__device__ __noinline__ bptr ar_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, uint32_t ip, int contpat) {
   EH_CTX;
   const Blk b = blk_load(c.bl, c.cur);
   c.pat_ret = -1;
   if (!codec_work(c, b.len)) return nullptr;                                 // zip:foldl reads the archive
-  ZipRd* rd = (ZipRd*)ws_alloc_grow(c, sizeof(ZipRd));
+  EH_G ZipRd* rd = (EH_G ZipRd*)ws_alloc_grow(c, sizeof(ZipRd));
   if (!rd) return nullptr;
-  int rc = zip_open(rd, (const uint8_t*)b.ptr, b.len);
+  int rc = zip_open(rd, (cbptr)b.ptr, b.len);
   if (rc == ZR_UNSUP) { c.status = CASE_UNSUPPORTED; return nullptr; }
   if (rc != ZR_OK) { c.pat_ret = 0; return nullptr; }
   const uint32_t n = uni(rd->entries);
-  ArSide* sd = (ArSide*)ws_alloc_grow(c, sizeof(ArSide));
+  EH_G ArSide* sd = (EH_G ArSide*)ws_alloc_grow(c, sizeof(ArSide));
   if (!sd) return nullptr;
-  ZipEntry* es = (ZipEntry*)ws_alloc_grow(c, (uint64_t)(n ? n : 1) * sizeof(ZipEntry));
+  EH_G ZipEntry* es = (EH_G ZipEntry*)ws_alloc_grow(c, (uint64_t)(n ? n : 1) * sizeof(ZipEntry));
   if (!es) return nullptr;
   for (uint32_t i = 0; i < n; i++) {
     rc = zip_next<true>(c, rd, &es[i]);
@@ -435,18 +437,18 @@ __device__ __noinline__ uint8_t* ar_begin(Ctx&, uint32_t e_pri, uint32_t e_meta,
   if (EH_LANE == 0) { sd->archive = b; sd->n = (int32_t)n; sd->idx = (int32_t)n - 1; sd->ip = (int32_t)ip; sd->contpat = contpat; sd->es = es; }
   wave_sync();
   c.pat_ret = 1;
-  return (uint8_t*)sd;
+  return (bptr)sd;
 }
 // The lists:mapfoldl of mutate_once_archiver/7 (:175-186) from entry sd->idx downwards (FileSpec is in reverse central-directory
 // order): R = rand(1000) per file, R > 750 runs the rest of the pattern chain on the file's bytes.  c.pat_ret 2: bl[cur] is such a
 // file and a P_AR frame waits for the evaluation; 1: all files done and zip:create gave bl[cur] = NewBin; 0: zip:create failed -
 // bl[cur] is the archive again, Mutator and trace are put back (the {error, _} clause, :165-174); -1: the case stops.
 // Returns the lane's scheduler entry to go on with.
-__device__ __noinline__ uint64_t ar_step(Ctx&, uint32_t e_pri, uint32_t e_meta, uint8_t* side, PatFrame* frames, int nfr) {
+__device__ __noinline__ uint64_t ar_step(Ctx&, uint32_t e_pri, uint32_t e_meta, bptr side, EH_G PatFrame* frames, int nfr) {
   EH_CTX;
   const uint64_t keep = ((uint64_t)e_pri << 32) | e_meta;
-  ArSide* sd = (ArSide*)side;
-  ZipEntry* es = (ZipEntry*)uni64((uint64_t)sd->es);
+  EH_G ArSide* sd = (EH_G ArSide*)side;
+  EH_G ZipEntry* es = (EH_G ZipEntry*)uni64((uint64_t)sd->es);
   const int n = (int)uni((uint32_t)sd->n);
   c.pat_ret = -1; c.pat_ip = uni((uint32_t)sd->ip); c.pat_cont = (int)uni((uint32_t)sd->contpat);
   int idx = (int)uni((uint32_t)sd->idx);
@@ -456,12 +458,12 @@ __device__ __noinline__ uint64_t ar_step(Ctx&, uint32_t e_pri, uint32_t e_meta, 
       if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 319); return keep; }
       blk_store(c.bl, c.cur, uni64(es[idx].data), uni(es[idx].data_len));
       c.nb = c.cur + 1;
-      if (c.trace) tr_name_emit((const uint8_t*)uni64(es[idx].name), uni(es[idx].name_len), uni(es[idx].up));   // [NM, {archiver, N} | Acc] :183: the name, then what the file's evaluation adds (a list of its own)
+      if (c.trace) tr_name_emit((cbptr)uni64(es[idx].name), uni(es[idx].name_len), uni(es[idx].up));   // [NM, {archiver, N} | Acc] :183: the name, then what the file's evaluation adds (a list of its own)
       if (EH_LANE == 0) sd->tr_base0 = c.tr_base;
       c.tr_base = c.ntrace;
       if (EH_LANE == 0) {
         sd->idx = idx;
-        PatFrame& f = frames[nfr];
+        EH_G PatFrame& f = frames[nfr];
         f.kind = P_AR; f.em_field = c.nem; f.field = side; f.size_bits = 0; f.big = 0; f.tail_ptr = 0; f.tail_len = 0; f.crc = 0;
       }
       wave_sync();
@@ -475,7 +477,7 @@ __device__ __noinline__ uint64_t ar_step(Ctx&, uint32_t e_pri, uint32_t e_meta, 
     for (int i = EH_LANE; i < n; i += 64) sum += es[i].data_len;
     if (!codec_work(c, wave_sum64(sum))) return keep;
   }
-  uint8_t* out; uint64_t len;
+  bptr out; uint64_t len;
   int rc = zip_create<true>(c, es, (uint32_t)n, &out, &len);                            // zip:create(Name, lists:reverse(NewFileSpec), [memory])
   if (rc == ZR_STOP) return keep;
   if (rc == ZR_UNSUP) { c.status = CASE_UNSUPPORTED; return keep; }
@@ -492,13 +494,13 @@ __device__ __noinline__ uint64_t ar_step(Ctx&, uint32_t e_pri, uint32_t e_meta, 
   return mutator_restore(c, &sd->m, true);
 }
 // a file's evaluation ended: its pieces are the file's new bytes (prepare4sizer), the next file starts from the Mutator again
-__device__ __noinline__ uint64_t ar_file_done(Ctx&, int em_field, uint8_t* side) {
+__device__ __noinline__ uint64_t ar_file_done(Ctx&, int em_field, bptr side) {
   EH_CTX;
-  ArSide* sd = (ArSide*)side;
-  ZipEntry* es = (ZipEntry*)uni64((uint64_t)sd->es);
+  EH_G ArSide* sd = (EH_G ArSide*)side;
+  EH_G ZipEntry* es = (EH_G ZipEntry*)uni64((uint64_t)sd->es);
   const int idx = (int)uni((uint32_t)sd->idx);
   uint64_t tot;
-  uint8_t* nb = gather_emits(c, em_field, &tot);
+  bptr nb = gather_emits(c, em_field, &tot);
   c.pat_ret = -1;
   c.tr_base = uni(sd->tr_base0);
   if (!nb) return 0;
@@ -512,7 +514,7 @@ __device__ __noinline__ uint64_t ar_file_done(Ctx&, int em_field, uint8_t* side)
 // The two container patterns behind one call each, so that the pattern machine (inlined into the kernel) only carries two calls.
 // begin: c.pat_ret 2 = a payload is in bl[cur] and a frame was pushed; 1 = bl[cur..nb) is the pattern's result; 0 = not a
 // container (go on with split/1 and mutate_once_loop); -1 = the case stops.
-__device__ __noinline__ uint64_t pat_container_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, int pat, PatFrame* frames, int nfr, uint32_t ip, int contpat) {
+__device__ __noinline__ uint64_t pat_container_begin(Ctx&, uint32_t e_pri, uint32_t e_meta, int pat, EH_G PatFrame* frames, int nfr, uint32_t ip, int contpat) {
   EH_CTX;
   const uint64_t keep = ((uint64_t)e_pri << 32) | e_meta;
   if (pat == P_CP) {
@@ -525,21 +527,21 @@ __device__ __noinline__ uint64_t pat_container_begin(Ctx&, uint32_t e_pri, uint3
   uint64_t tot = 0; for (int i = c.cur; i < c.nb; i++) tot += blk_load(c.bl, i).len;
   if (tot > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 308); return keep; }
   if (c.nb - c.cur > 1) {
-    uint8_t* all = ws_alloc_grow(c, tot);
+    bptr all = ws_alloc_grow(c, tot);
     if (!all) return keep;
     uint64_t o = 0;
-    for (int i = c.cur; i < c.nb; i++) { Blk x = blk_load(c.bl, i); wave_copy(all + o, (const uint8_t*)x.ptr, x.len); o += x.len; }
+    for (int i = c.cur; i < c.nb; i++) { Blk x = blk_load(c.bl, i); wave_copy(all + o, (cbptr)x.ptr, x.len); o += x.len; }
     wave_sync();
     blk_store(c.bl, c.cur, (uint64_t)all, (uint32_t)tot); c.nb = c.cur + 1;
     wave_sync();
   }
-  uint8_t* side = ar_begin(c, e_pri, e_meta, ip, contpat);
+  bptr side = ar_begin(c, e_pri, e_meta, ip, contpat);
   if (c.pat_ret != 1) return keep;
   return ar_step(c, e_pri, e_meta, side, frames, nfr);
 }
 // end of a payload's evaluation (the frame has been popped): c.pat_ret 2 = the next payload (ar) with a new frame; 1 = bl[cur..nb)
 // is the result; 0 = go on with mutate_once_loop on bl[cur..nb) (split/1 done), c.pat_ip / c.pat_cont; -1 = the case stops.
-__device__ __noinline__ uint64_t pat_container_end(Ctx&, uint32_t e_pri, uint32_t e_meta, int kind, int em_field, uint8_t* side, PatFrame* frames, int nfr) {
+__device__ __noinline__ uint64_t pat_container_end(Ctx&, uint32_t e_pri, uint32_t e_meta, int kind, int em_field, bptr side, EH_G PatFrame* frames, int nfr) {
   EH_CTX;
   uint64_t e;
   if (kind == P_CP) {
@@ -558,7 +560,7 @@ __device__ __noinline__ uint64_t pat_container_end(Ctx&, uint32_t e_pri, uint32_
 EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
   int act = A_RUN_PAT, cont = C_EMIT, contpat = 0; uint32_t ip = 0;
   int guard = 0;
-  PatFrame* frames = (PatFrame*)(c.aux + 1152); int nfr = 0;     // wrapper stack lives in slot memory
+  EH_G PatFrame* frames = (EH_G PatFrame*)(c.aux + 1152); int nfr = 0;     // wrapper stack lives in slot memory
   while (act != A_DONE && c.status == CASE_OK) {
     if (++guard > 1000000) { EH_SET_OVERFLOW(c, 305); break; }
     switch (act) {
@@ -582,7 +584,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
             if (c.gen_pending) { gen_force(c); if (c.status != CASE_OK) break; }      // uncons(Ll, false) calls a fun Ll
             if (c.cur >= c.nb) { c.status = CASE_CRASHED; break; }                    // uncons(Ll, false) -> false -> badarg
             Blk b = blk_load(c.bl, c.cur);
-            const uint8_t* H = (const uint8_t*)b.ptr;
+            cbptr H = (cbptr)b.ptr;
             if (pat == P_SK) {                                                        // mutate_once_skipper :146-161
               uint32_t len = rng_rand(c.rng, b.len / 2);
               if (c.trace) tr_kv_emit(TRK_SKIPPED, 0, 0, 0, 1, len, 0, 0);             // [{skipped, Len/8} | Meta] :154
@@ -607,11 +609,11 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
                 uint32_t nbytes = e.size_bits / 8;
                 if ((uint64_t)e.a + nbytes + e.len > b.len) { c.status = CASE_CRASHED; break; }
                 if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 306); break; }
-                uint8_t* fld = ws_alloc_grow(c, 16);
+                bptr fld = ws_alloc_grow(c, 16);
                 if (!fld) break;
                 emit_ref(c, b.ptr, e.a);                                              // H
                 if (EH_LANE == 0) {
-                  PatFrame& f = frames[nfr];
+                  EH_G PatFrame& f = frames[nfr];
                   f.kind = P_SZ; f.em_field = c.nem; f.field = fld; f.size_bits = e.size_bits; f.big = e.big;
                   f.tail_ptr = b.ptr + e.a + nbytes + e.len; f.tail_len = b.len - (e.a + nbytes + e.len); f.crc = 0;
                 }
@@ -630,7 +632,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
                 if (nfr >= MAX_FRAMES) { EH_SET_OVERFLOW(c, 307); break; }
                 emit_ref(c, b.ptr, plen);                                             // P
                 if (EH_LANE == 0) {
-                  PatFrame& f = frames[nfr];
+                  EH_G PatFrame& f = frames[nfr];
                   f.kind = P_CS; f.em_field = c.nem; f.crc = iscrc; f.field = nullptr; f.size_bits = 0; f.big = 0; f.tail_ptr = 0; f.tail_len = 0;
                 }
                 nfr++;
@@ -688,7 +690,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
         if (nfr == 0) { act = A_DONE; break; }
         wave_sync();
         PatFrame f = frames[--nfr];
-        f.kind = (int)uni((uint32_t)f.kind); f.em_field = (int)uni((uint32_t)f.em_field); f.field = (uint8_t*)uni64((uint64_t)f.field);
+        f.kind = (int)uni((uint32_t)f.kind); f.em_field = (int)uni((uint32_t)f.em_field); f.field = (bptr)uni64((uint64_t)f.field);
         f.size_bits = uni(f.size_bits); f.big = uni(f.big); f.tail_ptr = uni64(f.tail_ptr); f.tail_len = uni(f.tail_len); f.crc = uni(f.crc);
         if (f.kind == P_AR || f.kind == P_CP) {
           uint64_t e = pat_container_end(c, lt.e_pri, lt.e_meta, f.kind, f.em_field, f.field, frames, nfr);
@@ -709,10 +711,10 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
           // NewC = recalc_csum(Type, NewBlob): gather the inner pieces, checksum, append  (:139-143)
           uint64_t tot = 0; for (int k = f.em_field; k < c.nem; k++) tot += blk_load(c.em, k).len;
           if (tot > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 310); break; }
-          uint8_t* blob = ws_alloc_grow(c, tot + 16);
+          bptr blob = ws_alloc_grow(c, tot + 16);
           if (!blob) break;
           uint64_t o = 0;
-          for (int k = f.em_field; k < c.nem; k++) { Blk x = blk_load(c.em, k); wave_copy(blob + o, (const uint8_t*)x.ptr, x.len); o += x.len; }
+          for (int k = f.em_field; k < c.nem; k++) { Blk x = blk_load(c.em, k); wave_copy(blob + o, (cbptr)x.ptr, x.len); o += x.len; }
           wave_sync();
           uint32_t cs = f.crc ? wave_crc32(blob, (uint32_t)tot) : wave_xor8(blob, (uint32_t)tot);
           uint32_t cb = f.crc ? 4u : 1u;
@@ -737,7 +739,7 @@ EH_DEV void gen_finish(Ctx& c, uint32_t len) {
     uint32_t bits = rng_range(c.rng, 1, 16);
     uint32_t nlen = rng_rand(c.rng, 1u << bits);
     if (nlen > 0) {                                                    // check_empty
-      uint8_t* dst = ws_alloc_grow(c, nlen);
+      bptr dst = ws_alloc_grow(c, nlen);
       if (!dst) return;
       random_block_rev(c, dst, nlen);
       if (c.nb >= MAX_BLOCKS) { EH_SET_OVERFLOW(c, 312); return; }
@@ -751,7 +753,7 @@ EH_DEV uint32_t rand_block_size(Ctx& c) {                              // :55-56
   uint32_t r = rng_rand(c.rng, cfg.max_block_scaled);
   return r > cfg.min_block_scaled ? r : cfg.min_block_scaled;
 }
-EH_DEV void gen_direct(Ctx& c, const uint8_t* in, uint32_t L) {       // erlamsa_gen.erl:152-164 (split_binary guard never holds)
+EH_DEV void gen_direct(Ctx& c, cbptr in, uint32_t L) {       // erlamsa_gen.erl:152-164 (split_binary guard never holds)
   (void)rand_block_size(c);
   blk_store(c.bl, 0, (uint64_t)in, L);
   c.nb = 1;
@@ -761,9 +763,9 @@ EH_DEV void gen_direct(Ctx& c, const uint8_t* in, uint32_t L) {       // erlamsa
 // port_stream/2 forced (erlamsa_gen.erl:59-90) over corpus entry e: the blocks point into the arena (nothing is copied), the
 // next block size is drawn after every full block, a short read is followed by eof and finish(Len).  Fills bl[0..nb).
 EH_DEV void gen_stream(Ctx& c, uint32_t e) {
-  const KParams& p = *c.p;
+  const EH_G KParams& p = *c.p;
   uint64_t o0 = uni64(p.coff[e]), o1 = uni64(p.coff[e + 1]);
-  const uint8_t* in = p.corpus + o0;
+  cbptr in = p.corpus + o0;
   uint32_t L = (uint32_t)(o1 - o0), pos = 0;
   c.nb = 0;
   uint32_t wanted = rand_block_size(c);
@@ -797,10 +799,10 @@ __device__ __noinline__ void gen_force(Ctx&) {
   }
   uint32_t s1 = rng_rand(c.rng, dlen[0]), s2 = rng_rand(c.rng, dlen[1]);
   uint32_t l1 = rng_erand(c.rng, dlen[0] - s1), l2 = rng_erand(c.rng, dlen[1] - s2);
-  uint8_t* dst = ws_alloc_grow(c, (uint64_t)l1 + l2);
+  bptr dst = ws_alloc_grow(c, (uint64_t)l1 + l2);
   if (!dst) return;
-  wave_copy(dst, (const uint8_t*)dptr[0] + s1, l1);
-  wave_copy(dst + l1, (const uint8_t*)dptr[1] + s2, l2);
+  wave_copy(dst, (cbptr)dptr[0] + s1, l1);
+  wave_copy(dst + l1, (cbptr)dptr[1] + s2, l2);
   wave_sync();
   blk_store(c.bl, 0, (uint64_t)dst, l1 + l2);                          // uncons(B) when is_binary(B) -> {B, []}
   c.nb = 1;
@@ -811,7 +813,7 @@ EH_DEV void gen_random(Ctx& c) {                                       // random
   c.nb = 0;
   while (c.status == CASE_OK) {
     uint32_t n = rng_range(c.rng, 32, cfg.max_block_scaled);
-    uint8_t* dst = ws_alloc_grow(c, n);
+    bptr dst = ws_alloc_grow(c, n);
     if (!dst) return;
     random_block_rev(c, dst, n);
     if (c.nb >= MAX_BLOCKS) { EH_SET_OVERFLOW(c, 311); return; }
@@ -833,9 +835,10 @@ EH_DEV void gen_random(Ctx& c) {                                       // random
 #endif
 // The argument block lives in device memory: taking the address of a by-value kernel argument (c.p) made the
 // compiler keep a ~700-byte private copy of it per lane.
-__global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const KParams* __restrict__ pp) {
+__global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const KParams* __restrict__ pp_) {
+  const EH_G KParams* pp = (const EH_G KParams*)pp_;
   const int l = EH_LANE;
-  const KParams& p = *pp;
+  const EH_G KParams& p = *pp;
   Ctx& c = g_ctx;
   LaneTab lt;
   c.p = pp;
@@ -846,18 +849,18 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
 #endif
   // this workgroup's slot: block tables + work area
   const uint32_t slot_id = blockIdx.x;
-  uint8_t* slot = p.slot_base + (uint64_t)slot_id * p.slot_stride;
-  c.bl = (Blk*)slot;
+  bptr slot = p.slot_base + (uint64_t)slot_id * p.slot_stride;
+  c.bl = (EH_G Blk*)slot;
   c.bl2 = c.bl + MAX_BLOCKS;
   c.em = c.bl2 + MAX_BLOCKS;
-  c.aux = (uint8_t*)(c.em + MAX_EMITS);
-  uint8_t* const trace0 = c.aux + AUX_BYTES;
-  uint8_t* const ws0 = trace0 + TRACE_CAP;
+  c.aux = (bptr)(c.em + MAX_EMITS);
+  bptr const trace0 = c.aux + AUX_BYTES;
+  bptr const ws0 = trace0 + TRACE_CAP;
 
   // mode 0: the run state is shared by all cases
   Rng parent; int gen0 = 0; uint32_t pri0 = 0, meta0 = 0; int nfs0 = 0;
   if (p.mode == 0) {
-    const RunState* rs = p.run;
+    const EH_G RunState* rs = p.run;
     parent.a1 = rs->a1; parent.a2 = rs->a2; parent.a3 = rs->a3; parent.draws = 0;
     gen0 = rs->gen; nfs0 = rs->nfs;
     if (l < nfs0) {
@@ -892,7 +895,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     c.work = 0; c.depth = 0;
     c.status = CASE_OK; c.lastm = -1; c.nb = 0; c.cur = 0; c.nem = 0; c.ws_used = 0;
     c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r2 = 0;
-    if (l == 0) { ((StState*)c.aux)[0].count = 0; ((StState*)c.aux)[1].count = 0; for (int d = 0; d < LEX_LEVELS; d++) { LexCache& lc = ((LexCache*)(c.aux + AUX_LEXCACHE))[d]; lc.n = -1; lc.tcap = 0; } ((FoState*)(c.aux + 704))->has = 0; }
+    if (l == 0) { ((EH_G StState*)c.aux)[0].count = 0; ((EH_G StState*)c.aux)[1].count = 0; for (int d = 0; d < LEX_LEVELS; d++) { EH_G LexCache& lc = ((EH_G LexCache*)(c.aux + AUX_LEXCACHE))[d]; lc.n = -1; lc.tcap = 0; } ((EH_G FoState*)(c.aux + 704))->has = 0; }
     wave_sync();
     int gen;
     Rng pr;
@@ -948,7 +951,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     }
     if (total > 0) {
       uint64_t pos = base;
-      for (int k = 0; k < c.nem; k++) { Blk b = blk_load(c.em, k); wave_copy(p.out + pos, (const uint8_t*)b.ptr, b.len); pos += b.len; }
+      for (int k = 0; k < c.nem; k++) { Blk b = blk_load(c.em, k); wave_copy(p.out + pos, (cbptr)b.ptr, b.len); pos += b.len; }
     }
     // the case's meta trace goes behind its output in the arena
     unsigned long long tbase = 0;
@@ -981,7 +984,8 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
 // EH_FLAG_ORDERED_OUTPUT: compaction of the completion-ordered arena into case order
 // =============================================================================================
 // ord_off[i] = sum of out_len[0..i): one wavefront, 64 cases per step (n / 64 shuffle scans)
-__global__ void __launch_bounds__(64) eh_order_scan_kernel(const uint64_t* out_len, uint64_t* ord_off, uint64_t n) {
+__global__ void __launch_bounds__(64) eh_order_scan_kernel(const uint64_t* out_len_, uint64_t* ord_off_, uint64_t n) {
+  cqptr out_len = (cqptr)out_len_; qptr ord_off = (qptr)ord_off_;
   const int l = EH_LANE;
   uint64_t run = 0;
   for (uint64_t base = 0; base < n; base += 64) {
@@ -999,8 +1003,9 @@ __global__ void __launch_bounds__(64) eh_order_scan_kernel(const uint64_t* out_l
   if (l == 0) ord_off[n] = run;
 }
 // one wavefront per case (grid-stride): dst[ord_off[i] ..) = src[out_off[i] ..)
-__global__ void __launch_bounds__(64) eh_order_gather_kernel(const uint8_t* src, uint8_t* dst, const uint64_t* out_off, const uint64_t* out_len,
-                                                             const uint64_t* ord_off, uint64_t n, uint64_t ord_base) {
+__global__ void __launch_bounds__(64) eh_order_gather_kernel(const uint8_t* src_, uint8_t* dst_, const uint64_t* out_off_, const uint64_t* out_len_,
+                                                             const uint64_t* ord_off_, uint64_t n, uint64_t ord_base) {
+  cbptr src = (cbptr)src_; bptr dst = (bptr)dst_; cqptr out_off = (cqptr)out_off_, out_len = (cqptr)out_len_, ord_off = (cqptr)ord_off_;
   for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
     uint64_t len = uni64(out_len[i]), so = uni64(out_off[i]), d0 = uni64(ord_off[i]) - ord_base;
     uint64_t done = 0;
@@ -1008,7 +1013,8 @@ __global__ void __launch_bounds__(64) eh_order_gather_kernel(const uint8_t* src,
   }
 }
 
-__global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf, const uint32_t* jobs, uint32_t njobs, uint32_t* eq_out) {
+__global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf_, const uint32_t* jobs_, uint32_t njobs, uint32_t* eq_out_) {
+  bptr buf = (bptr)buf_; cwptr jobs = (cwptr)jobs_; wptr eq_out = (wptr)eq_out_;
   // job = {kind, dst_off, src_off, n, plen}: kind 0 copy, 1 periodic fill, 2 equal
   for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
     uint32_t kind = jobs[5 * j], d = jobs[5 * j + 1], s = jobs[5 * j + 2], n = jobs[5 * j + 3], pl = jobs[5 * j + 4];
@@ -1033,11 +1039,12 @@ __global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf, const ui
 
 // Self test of eh_zlib.h: op 0..2 compress in[0..n) as ZF_RAW / ZF_GZIP / ZF_ZLIB, op 4 / 5 = zlib:gunzip / zlib:inflate semantics
 // (z_uncompress_size + z_uncompress_write); res[0] = bytes written, res[1] = 1 ok / 0 "raises".
-__global__ void __launch_bounds__(64) eh_test_zlib_kernel(int op, const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint8_t* scratch, uint64_t* res) {
+__global__ void __launch_bounds__(64) eh_test_zlib_kernel(int op, const uint8_t* in_, uint64_t n, uint8_t* out_, uint64_t cap, uint8_t* scratch_, uint64_t* res_) {
+  cbptr in = (cbptr)in_; bptr out = (bptr)out_, scratch = (bptr)scratch_; qptr res = (qptr)res_;
   uint64_t len = 0; int ok = 1;
-  if (op <= 2) { len = z_compress((ZDef*)scratch, op, in, n, out, cap); ok = len != 0; }
+  if (op <= 2) { len = z_compress((EH_G ZDef*)scratch, op, in, n, out, cap); ok = len != 0; }
   else {
-    ZInf* zi = (ZInf*)scratch; uint64_t off = 0;
+    EH_G ZInf* zi = (EH_G ZInf*)scratch; uint64_t off = 0;
     ok = z_uncompress_size(zi, op - 3, in, n, &len, &off);
     if (ok && len > cap) ok = 0;
     if (ok) ok = z_uncompress_write(zi, op - 3, in, n, off, out, len);
@@ -1061,6 +1068,11 @@ static const PatInfo PATS[P_COUNT] = {{"od", 1, 1}, {"nd", 2, 1}, {"bu", 1, 1}, 
 }  // namespace eh
 
 using namespace eh;
+
+// Host code fills KParams.  In the device pass of this file its pointer members are address-space qualified (eh_common.h), and
+// the host functions are type-checked there too: dp(x) converts to whatever the member is.
+template <class T> struct DevPtr { T* p; template <class U> operator U() const { return (U)p; } };
+template <class T> static inline DevPtr<T> dp(T* p) { return DevPtr<T>{p}; }
 
 // the work-area pool of a device (see pool_acquire)
 struct DevPool {
@@ -1323,18 +1335,18 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
 
   KParams p;
   memset(&p, 0, sizeof(p));
-  p.corpus = ctx->d_corpus; p.coff = ctx->d_coff; p.corpus_first = corpus_first; p.n_paths = ctx->n_corpus; p.n = n; p.first_case = first_case;
-  p.mode = mode; p.run = ctx->d_run; p.seeds = ctx->d_seeds; p.cfg = ctx->cfg;
+  p.corpus = dp(ctx->d_corpus); p.coff = dp(ctx->d_coff); p.corpus_first = corpus_first; p.n_paths = ctx->n_corpus; p.n = n; p.first_case = first_case;
+  p.mode = mode; p.run = dp(ctx->d_run); p.seeds = dp(ctx->d_seeds); p.cfg = ctx->cfg;
   const DevPool* pl = ctx->pool;
   p.work_cap = pl->work_cap;
   p.work_budget = ctx->work_budget;                                            // 0 = no budget (the default)
   p.fuse_stream_min = ctx->fuse_stream_min;
-  p.out = ctx->d_out; p.out_cap = ctx->out_cap; p.out_cursor = ctx->d_counters + 1;
-  p.out_off = ctx->d_off; p.out_len = ctx->d_len; p.status = ctx->d_status; p.draws = ctx->d_draws; p.lastm = ctx->d_lastm; p.cycles = ctx->d_cycles; p.peak = ctx->d_peak; p.trace_off = ctx->d_toff; p.trace_len = ctx->d_tlen; p.flags = ctx->flags;
-  p.ticket = ctx->d_counters; p.in_bytes = ctx->d_counters + 2; p.prof = ctx->d_counters + 8;   // counters [8, 264) = prof
-  p.slot_base = ctx->d_slots; p.slot_stride = ctx->slot_stride;
-  p.ntiers = pl->ntiers; p.pool_ctr = pl->d_ctr; p.pool_cap[0] = pl->work_cap;
-  for (int t = 1; t <= pl->ntiers; t++) { p.pool_base[t] = pl->base[t]; p.pool_stride[t] = pl->stride[t]; p.pool_cap[t] = pl->cap[t]; p.pool_cnt[t] = pl->cnt[t]; p.pool_ring[t] = pl->ring[t]; }
+  p.out = dp(ctx->d_out); p.out_cap = ctx->out_cap; p.out_cursor = dp(ctx->d_counters + 1);
+  p.out_off = dp(ctx->d_off); p.out_len = dp(ctx->d_len); p.status = dp(ctx->d_status); p.draws = dp(ctx->d_draws); p.lastm = dp(ctx->d_lastm); p.cycles = dp(ctx->d_cycles); p.peak = dp(ctx->d_peak); p.trace_off = dp(ctx->d_toff); p.trace_len = dp(ctx->d_tlen); p.flags = ctx->flags;
+  p.ticket = dp(ctx->d_counters); p.in_bytes = dp(ctx->d_counters + 2); p.prof = dp(ctx->d_counters + 8);   // counters [8, 264) = prof
+  p.slot_base = dp(ctx->d_slots); p.slot_stride = ctx->slot_stride;
+  p.ntiers = pl->ntiers; p.pool_ctr = dp(pl->d_ctr); p.pool_cap[0] = pl->work_cap;
+  for (int t = 1; t <= pl->ntiers; t++) { p.pool_base[t] = dp(pl->base[t]); p.pool_stride[t] = pl->stride[t]; p.pool_cap[t] = pl->cap[t]; p.pool_cnt[t] = pl->cnt[t]; p.pool_ring[t] = dp(pl->ring[t]); }
   // persistent workgroups, each pulling cases from the ticket counter.  Batches in flight on several streams may
   // oversubscribe the device: the dispatcher starts a batch's workgroups as those of earlier ones leave.
   uint32_t grid0 = ctx->nslots < n ? ctx->nslots : (uint32_t)n;

@@ -16,7 +16,7 @@ struct SizerElem { uint32_t size_bits; uint32_t big; uint32_t len; uint32_t a; u
 
 // field value at offset A for clause c (0..5: 16/32/64 big, 16/32/64 little); returns false if the
 // binary is too short for the pattern
-EH_DEV bool field_at(const uint8_t* H, uint32_t L, uint32_t A, int c, uint64_t* v, uint32_t* w) {
+EH_DEV bool field_at(cbptr H, uint32_t L, uint32_t A, int c, uint64_t* v, uint32_t* w) {
   const uint32_t ws[3] = {2, 4, 8};
   uint32_t wd = ws[c % 3]; *w = wd;
   if (A + wd > L) return false;
@@ -40,7 +40,7 @@ EH_DEV int basic_len_clause(const uint64_t fv[6], uint32_t fmask, uint32_t L, ui
 
 // Picks rand_elem(get_possible_simple_lens(Bin)).  Returns 1 and fills *e, 0 when the list is
 // empty (no draw for rand_elem), -1 on allocation failure.  Consumes SubLen+1 draws when L > 10.
-__device__ __noinline__ int pick_simple_len(Ctx&, const uint8_t* H, uint32_t L, SizerElem* e) {
+__device__ __noinline__ int pick_simple_len(Ctx&, cbptr H, uint32_t L, SizerElem* e) {
   EH_CTX;
   const int l = EH_LANE;
   const int64_t adjs[5] = {0, 1, 2, 4, 8};
@@ -73,8 +73,8 @@ __device__ __noinline__ int pick_simple_len(Ctx&, const uint8_t* H, uint32_t L, 
   uint32_t sub = L / 5 < SIZER_MAX_FIRST_BYTES ? L / 5 : SIZER_MAX_FIRST_BYTES;
   uint32_t ny = sub + 1;
   uint64_t mark = c.ws_used;
-  uint32_t* varb = (uint32_t*)ws_alloc(c, (uint64_t)ny * 4);
-  uint32_t* cnt2 = (uint32_t*)ws_alloc(c, (uint64_t)ny * 4);
+  wptr varb = (wptr)ws_alloc(c, (uint64_t)ny * 4);
+  wptr cnt2 = (wptr)ws_alloc(c, (uint64_t)ny * 4);
   if (!varb || !cnt2) return -1;
   // VarBSeq = [rand_range(SubLen, Len) || _ <- FirstSeq]   (:94)
   for (uint32_t base = 0; base < ny; base += 64) {
@@ -163,7 +163,7 @@ __device__ __noinline__ int pick_simple_len(Ctx&, const uint8_t* H, uint32_t L, 
 }
 
 // writes V as a Size-bit big/little endian field (two's-complement truncation) — lane 0
-__device__ inline void put_field(uint8_t* o, uint64_t v, uint32_t bits, bool big) {
+__device__ inline void put_field(bptr o, uint64_t v, uint32_t bits, bool big) {
   uint32_t n = bits / 8;
   for (uint32_t i = 0; i < n; i++) { uint32_t sh = big ? 8 * (n - 1 - i) : 8 * i; o[i] = (uint8_t)(v >> sh); }
 }
@@ -172,7 +172,7 @@ __device__ inline void put_field(uint8_t* o, uint64_t v, uint32_t bits, bool big
 __device__ __noinline__ int muta_len(Ctx&) {
   EH_CTX;
   Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   const int l = EH_LANE;
   c.r_kind = R_SAME;
   SizerElem e;
@@ -199,7 +199,7 @@ __device__ __noinline__ int muta_len(Ctx&) {
   }
   uint32_t newlen = (huge || tmp >= ABSMAX_BINARY_BLOCK) ? ABSMAX_BINARY_BLOCK : (uint32_t)(tmp * 2 > ABSMAX_BINARY_BLOCK ? ABSMAX_BINARY_BLOCK : tmp * 2);
   uint32_t k = rng_rand(c.rng, 7);
-  uint8_t* fld = ws_alloc(c, 16);
+  bptr fld = ws_alloc(c, 16);
   if (!fld) return 0;
   Pieces q; pc_init(q);
   pc_add(q, H, e.a);
@@ -208,7 +208,7 @@ __device__ __noinline__ int muta_len(Ctx&) {
     case 1: if (l == 0) put_field(fld, ~(uint64_t)0, e.size_bits, true); wave_sync(); pc_add(q, fld, nb); pc_add(q, H + blob0, L - blob0); break;
     case 2: {
       // fast_pseudorandom_block(NewLen) (erlamsa_rnd.erl:155-160)
-      uint8_t* rnd; uint32_t rlen;
+      bptr rnd; uint32_t rlen;
       if (newlen < ABSMAXHALF_BINARY_BLOCK) { rlen = newlen; rnd = ws_alloc(c, rlen); if (!rnd) return 0; random_block_rev(c, rnd, rlen); }
       else {
         uint32_t z = newlen - ABSMAXHALF_BINARY_BLOCK;          // <<42:Z8L, RndBlk/binary>>: Z8L is a BIT count

@@ -69,11 +69,11 @@ EH_DEV uint64_t wave_sum64(uint64_t v) {
 #include "eh_fuse_lds.h"
 namespace eh {
 #define FUSE_UNROLL 4
-struct FuseGen { FNode* nd; uint32_t* F; uint32_t* T; };
+struct FuseGen { EH_G FNode* nd; wptr F; wptr T; };
 
 // One refinement round over all nodes of `g` (generation parity par) into `o`; returns the number of children.
 // sym: fuse(H, H) — the target lists are the source lists at every level, only one side is computed.
-EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, const FuseGen& g, uint32_t nn, const FuseGen& o, uint32_t par, bool sym, uint64_t* entries) {
+EH_DEV uint32_t fuse_round(cbptr A, uint32_t la, cbptr B, uint32_t lb, const FuseGen& g, uint32_t nn, const FuseGen& o, uint32_t par, bool sym, uint64_t* entries) {
   const int l = EH_LANE;
   const bool asc = par == 0;
   uint64_t le = 0;                                               // list members of the children made by this lane (work accounting)
@@ -122,9 +122,9 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
       // the entry whose rest is []: its byte' and how many members of its group precede it (array order)
       uint32_t fdb = 0xFFFFFFFFu, fdbefore = 0, tdb = 0xFFFFFFFFu, tdbefore = 0;
       for (int side = 0; side < (sym ? 1 : 2); side++) {
-        const uint8_t* S = side ? B : A; uint32_t slen = side ? lb : la;
+        cbptr S = side ? B : A; uint32_t slen = side ? lb : la;
         uint32_t cnt = side ? b0.tc : b0.fc;
-        const uint32_t* P = side ? g.T + b0.to : g.F + b0.fo;
+        cwptr P = side ? g.T + b0.to : g.F + b0.fo;
         uint32_t single = side ? b0.to : b0.fo;                  // cnt == 1: the position itself
         uint32_t* h = side ? ht : hf;
         for (uint32_t base = 0; base < cnt; base += 64 * FUSE_UNROLL) {      // FUSE_UNROLL chunks in flight: the loads are the cost
@@ -192,11 +192,11 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
       wave_sync();                                               // the child descriptors are patched below
       // stable scatter: rank among the lanes of this chunk with the same byte', behind the bin's cursor
       for (int side = 0; side < (sym ? 1 : 2); side++) {
-        const uint8_t* S = side ? B : A; uint32_t slen = side ? lb : la;
+        cbptr S = side ? B : A; uint32_t slen = side ? lb : la;
         uint32_t cnt = side ? b0.tc : b0.fc;
-        const uint32_t* P = side ? g.T + b0.to : g.F + b0.fo;
+        cwptr P = side ? g.T + b0.to : g.F + b0.fo;
         uint32_t single = side ? b0.to : b0.fo;
-        uint32_t* h = side ? ht : hf; uint32_t* O = side ? o.T : o.F;
+        uint32_t* h = side ? ht : hf; wptr O = side ? o.T : o.F;
         const bool dropped = side ? tdropped : fdropped;
         for (uint32_t base = 0; base < cnt; base += 64 * FUSE_UNROLL) {
           uint32_t ppu[FUSE_UNROLL], btu[FUSE_UNROLL]; bool vu[FUSE_UNROLL];
@@ -241,7 +241,7 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
 #pragma unroll
     for (int side = 0; side < 2; side++) {
       if (side == 1 && sym) { key[1] = key[0]; pos[1] = pos[0]; break; }
-      const uint8_t* S = side ? B : A; uint32_t slen = side ? lb : la;
+      cbptr S = side ? B : A; uint32_t slen = side ? lb : la;
       uint32_t cum = side ? cumt : cumf, cntn = side ? nd.tc : nd.fc, offn = side ? nd.to : nd.fo;
       bool in = (uint32_t)l < tot[side];
       uint32_t nj = lanes_le(cum, nfit, (uint32_t)l);                          // node (of this batch) of entry l
@@ -330,21 +330,21 @@ EH_DEV uint32_t fuse_round(const uint8_t* A, uint32_t la, const uint8_t* B, uint
   return cn;
 }
 
-__device__ bool fuse_jump_stream(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, bool sym, uint32_t* from, uint32_t* tpos, uint32_t* rounds);   // eh_fuse2.h
+__device__ bool fuse_jump_stream(Ctx& c, cbptr A, uint32_t la, cbptr B, uint32_t lb, bool sym, uint32_t* from, uint32_t* tpos, uint32_t* rounds);   // eh_fuse2.h
 }  // namespace eh
 #include "eh_fuse_red.h"
 namespace eh {
 
 // fuse(Al, Bl) -> new byte list in the work area
 #ifdef EH_FUSE_INLINE
-EH_DEV bool fuse_lists(Ctx& c, const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, uint8_t** out, uint32_t* outlen) {
+EH_DEV bool fuse_lists(Ctx& c, cbptr A, uint32_t la, cbptr B, uint32_t lb, bptr* out, uint32_t* outlen) {
 #else
-__device__ __noinline__ bool fuse_lists(Ctx&, const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, uint8_t** out, uint32_t* outlen) {
+__device__ __noinline__ bool fuse_lists(Ctx&, cbptr A, uint32_t la, cbptr B, uint32_t lb, bptr* out, uint32_t* outlen) {
   EH_CTX;
 #endif
   const int l = EH_LANE;
-  if (la == 0) { *out = (uint8_t*)B; *outlen = lb; return true; }   // fuse([], Bl) -> Bl
-  if (lb == 0) { *out = (uint8_t*)A; *outlen = la; return true; }
+  if (la == 0) { *out = (bptr)B; *outlen = lb; return true; }   // fuse([], Bl) -> Bl
+  if (lb == 0) { *out = (bptr)A; *outlen = la; return true; }
   uint64_t mark = c.ws_used;
   const bool sym = A == B && la == lb;                             // sed_fuse_this: fuse(Lst, Lst)
   EH_PT0;
@@ -357,9 +357,9 @@ __device__ __noinline__ bool fuse_lists(Ctx&, const uint8_t* A, uint32_t la, con
     if (rd < 64) {
       const uint32_t R = rd + 2u;
       uint32_t la2 = la, lb2 = lb;
-      const uint8_t* A2 = fr_reduce(c, A, &la2, R);
+      cbptr A2 = fr_reduce(c, A, &la2, R);
       if (!A2) return false;
-      const uint8_t* B2 = A2;
+      cbptr B2 = A2;
       if (sym) lb2 = la2; else { B2 = fr_reduce(c, B, &lb2, R); if (!B2) return false; }
       if ((uint64_t)la2 + lb2 <= ((uint64_t)la + lb) / 4u * 3u) {
         EH_PT(c, 97);                                              // eh_result_prof 97: finding + making the cuts, calls that took them; 98: calls that found none
@@ -375,7 +375,7 @@ __device__ __noinline__ bool fuse_lists(Ctx&, const uint8_t* A, uint32_t la, con
         if (g == 0) { from = rng_rand(c.rng, la); tpos = rng_rand(c.rng, lb); }
         else if (c.fp_special) { (void)rng_rand(c.rng, 1); (void)rng_rand(c.rng, 1); }      // {[[]], [[]]}
         else {
-          const uint8_t* key = A2 + c.fp_keypos;
+          cbptr key = A2 + c.fp_keypos;
           const uint32_t limA = la > g ? la - g : 0u, limB = lb > g ? lb - g : 0u;
           const uint32_t fc0 = fr_occ(A, la, limA, key, g, FR_NONE, nullptr), fc = fc0 + c.fp_bA;
           uint32_t pos = 0;
@@ -396,9 +396,9 @@ __device__ __noinline__ bool fuse_lists(Ctx&, const uint8_t* A, uint32_t la, con
   } else {
     FuseGen g[2];
     for (int k = 0; k < 2; k++) {
-      g[k].nd = (FNode*)ws_alloc(c, ((uint64_t)la + 4) * sizeof(FNode));     // every node owns >= 1 source entry
-      g[k].F = (uint32_t*)ws_alloc(c, ((uint64_t)la + 4) * 4);
-      g[k].T = sym ? g[k].F : (uint32_t*)ws_alloc(c, ((uint64_t)lb + 4) * 4);
+      g[k].nd = (EH_G FNode*)ws_alloc(c, ((uint64_t)la + 4) * sizeof(FNode));     // every node owns >= 1 source entry
+      g[k].F = (wptr)ws_alloc(c, ((uint64_t)la + 4) * 4);
+      g[k].T = sym ? g[k].F : (wptr)ws_alloc(c, ((uint64_t)lb + 4) * 4);
       if (!g[k].nd || !g[k].F || !g[k].T) return false;
     }
     // find_jump_points (:103-107): one node with all non-empty suffixes of both lists
@@ -440,7 +440,7 @@ jump:
   c.ws_used = mark;                                                // release all tables
   // jump/3 (:47-50): Al up to From, then To
   uint32_t nl = from + (lb - tpos);
-  uint8_t* dst = ws_alloc(c, nl);
+  bptr dst = ws_alloc(c, nl);
   if (!dst) return false;
   wave_copy(dst, A, from);
   wave_copy(dst + from, B + tpos, lb - tpos);
@@ -451,12 +451,12 @@ jump:
 
 struct FoState { uint64_t ptr; uint32_t len; uint32_t has; };
 
-__device__ __noinline__ int muta_fuse(Ctx&, int fn, FoState* fo) {
+__device__ __noinline__ int muta_fuse(Ctx&, int fn, EH_G FoState* fo) {
   EH_CTX;
   Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
-  uint8_t* r; uint32_t rl;
+  bptr r; uint32_t rl;
   if (fn == M_FT) {                                               // sed_fuse_this :386-390
     if (!fuse_lists(c, H, L, H, L, &r, &rl)) return 0;
     int d = rng_delta(c.rng);
@@ -467,8 +467,8 @@ __device__ __noinline__ int muta_fuse(Ctx&, int fn, FoState* fo) {
   if (fn == M_FN) {                                               // sed_fuse_next :393-402
     Blk nb = hb; bool have_next = c.cur + 1 < c.nb;
     if (have_next) nb = blk_load(c.bl, c.cur + 1);                // uncons(T, H): next block or H itself
-    uint8_t* abl; uint32_t abll;
-    if (!fuse_lists(c, H, h1, (const uint8_t*)nb.ptr, nb.len, &abl, &abll)) return 0;
+    bptr abl; uint32_t abll;
+    if (!fuse_lists(c, H, h1, (cbptr)nb.ptr, nb.len, &abl, &abll)) return 0;
     if (!fuse_lists(c, abl, abll, H + h1, L - h1, &r, &rl)) return 0;
     int d = rng_delta(c.rng);
     c.r_kind = R_NEW; c.r_ptr = r; c.r_len = rl; c.r_flush = 1; c.r_drop_next = have_next ? 1 : 0;
@@ -478,9 +478,9 @@ __device__ __noinline__ int muta_fuse(Ctx&, int fn, FoState* fo) {
   uint32_t has = uni(fo->has);
   uint64_t optr = has ? uni64(fo->ptr) : hb.ptr; uint32_t olen = has ? uni(fo->len) : L;
   uint32_t o1 = olen / 2;
-  uint8_t* a; uint32_t al; uint8_t* b; uint32_t bl;
-  if (!fuse_lists(c, H, h1, (const uint8_t*)optr, o1, &a, &al)) return 0;              // a -> o
-  if (!fuse_lists(c, (const uint8_t*)optr + o1, olen - o1, H + h1, L - h1, &b, &bl)) return 0;   // o -> a
+  bptr a; uint32_t al; bptr b; uint32_t bl;
+  if (!fuse_lists(c, H, h1, (cbptr)optr, o1, &a, &al)) return 0;              // a -> o
+  if (!fuse_lists(c, (cbptr)optr + o1, olen - o1, H + h1, L - h1, &b, &bl)) return 0;   // o -> a
   uint32_t swap = rng_rand(c.rng, 3);
   int d = rng_delta(c.rng);
   if (EH_LANE == 0) { if (!has || swap == 0) { fo->ptr = hb.ptr; fo->len = L; } fo->has = 1; }

@@ -38,20 +38,20 @@ struct RkWord { uint32_t mask, prefix; };
 
 EH_DEV uint32_t fb_tr(uint32_t b, uint32_t g) { return (g & 1u) ? 255u - b : b; }
 // bitmap words are written by atomics (performed at L2): read them there, not from a stale L1 line
-EH_DEV uint32_t fb_ld(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+EH_DEV uint32_t fb_ld(cwptr p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 EH_DEV uint32_t wave_min(uint32_t v) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { uint32_t t = (uint32_t)__shfl_xor((int)v, d); v = t < v ? t : v; }
   return uni(v);
 }
-EH_DEV void fb_clear(uint32_t* p, uint32_t nwords) {               // nwords is a multiple of 4, p 16-byte aligned
+EH_DEV void fb_clear(wptr p, uint32_t nwords) {               // nwords is a multiple of 4, p 16-byte aligned
   uint4 z; z.x = z.y = z.z = z.w = 0;
-  for (uint32_t i = 4u * (uint32_t)EH_LANE; i < nwords; i += 256) *reinterpret_cast<uint4*>(p + i) = z;
+  for (uint32_t i = 4u * (uint32_t)EH_LANE; i < nwords; i += 256) stg16a(p + i, z);
 }
 
 // Bitmap of generation 0 (one node): the bytes of S[0, len-1) (the member at len-1 is tested separately).  256 LDS flags,
 // packed into 8 words by ballots.
-__device__ __noinline__ void fb_bits0(const uint8_t* S, uint32_t len, uint32_t* M) {
+__device__ __noinline__ void fb_bits0(cbptr S, uint32_t len, wptr M) {
   const uint32_t l = (uint32_t)EH_LANE;
   for (uint32_t i = l; i < 256; i += 64) g_fuse_lds[i] = 0;
   lanes_sync();
@@ -59,7 +59,7 @@ __device__ __noinline__ void fb_bits0(const uint8_t* S, uint32_t len, uint32_t* 
   for (uint32_t base = 0; base < n; base += 4096) {                // 4 vector loads in flight
     uint4 v[4]; uint32_t i0[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { i0[u] = base + 1024u * u + 16u * l; uint4 z; z.x = z.y = z.z = z.w = 0; v[u] = z; if (i0[u] + 16 <= n) __builtin_memcpy(&v[u], S + i0[u], 16); }
+    for (int u = 0; u < 4; u++) { i0[u] = base + 1024u * u + 16u * l; uint4 z; z.x = z.y = z.z = z.w = 0; v[u] = z; if (i0[u] + 16 <= n) v[u] = ldg16(S + i0[u]); }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       if (i0[u] + 16 <= n) {
@@ -90,11 +90,11 @@ constexpr uint32_t FB_MULTI = 0xFFFFFFFFu;
 struct ScEnt { uint32_t mask, meta; };
 
 // the eight mask words of `node` (bitmap row, or decoded from N1), and the tables left ZERO for the next generation
-EH_DEV void fb_row(uint32_t* M, uint32_t* N1, uint32_t node, bool valid, uint32_t w[8]) {
+EH_DEV void fb_row(wptr M, wptr N1, uint32_t node, bool valid, uint32_t w[8]) {
 #pragma unroll
   for (int k = 0; k < 8; k++) w[k] = 0;
   if (!valid) return;
-  uint32_t* row = M + 8u * node;
+  wptr row = M + 8u * node;
   bool full = true;
   if (N1) {
     uint32_t n1 = fb_ld(&N1[node]);
@@ -109,7 +109,7 @@ EH_DEV void fb_row(uint32_t* M, uint32_t* N1, uint32_t node, bool valid, uint32_
 #pragma unroll
     for (int k = 0; k < 8; k++) w[k] = fb_ld(row + k);
     uint4 z; z.x = z.y = z.z = z.w = 0;
-    *reinterpret_cast<uint4*>(row) = z; *reinterpret_cast<uint4*>(row + 4) = z;
+    stg16a(row, z); stg16a(row + 4, z);
   }
 }
 
@@ -118,8 +118,8 @@ EH_DEV void fb_row(uint32_t* M, uint32_t* N1, uint32_t node, bool valid, uint32_
 // dropped one) is a child whatever the target side holds: force_bit in word force_w; *special = its index.  Lane l owns
 // two nodes (16 consecutive words) of every 128-node step.  The bitmap rows and N1 entries it reads are zeroed: the
 // tables of a generation are clean when the next one starts to fill them.
-__device__ __noinline__ uint32_t fb_scan(uint32_t* MA, uint32_t* MB, uint32_t* N1A, uint32_t* N1B, uint32_t nwords, uint32_t force_w, uint32_t force_bit,
-                                         RkWord* RK, ScEnt* SC, uint32_t* special, uint32_t* nfull) {
+__device__ __noinline__ uint32_t fb_scan(wptr MA, wptr MB, wptr N1A, wptr N1B, uint32_t nwords, uint32_t force_w, uint32_t force_bit,
+                                         EH_G RkWord* RK, EH_G ScEnt* SC, uint32_t* special, uint32_t* nfull) {
   const uint32_t l = (uint32_t)EH_LANE;
   uint32_t running = 0, sp = FB_DEAD, full = 0;
   for (uint32_t base = 0; base < nwords; base += 1024) {
@@ -159,7 +159,7 @@ __device__ __noinline__ uint32_t fb_scan(uint32_t* MA, uint32_t* MB, uint32_t* N
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           uint4 s0; s0.x = m[8 * h + 2 * q]; s0.y = pre[2 * q]; s0.z = m[8 * h + 2 * q + 1]; s0.w = pre[2 * q + 1];
-          *reinterpret_cast<uint4*>(RK + node * 8u + 2 * q) = s0;
+          stg16a(RK + node * 8u + 2 * q, s0);
         }
         ScEnt e; e.mask = 0; e.meta = 0;
         if (nz == 1) {
@@ -178,9 +178,9 @@ __device__ __noinline__ uint32_t fb_scan(uint32_t* MA, uint32_t* MB, uint32_t* N
 }
 
 // 8 bytes of S from q (fewer at the end of the block: zero filled)
-EH_DEV uint64_t fb_ld8(const uint8_t* S, uint32_t q, uint32_t len) {
+EH_DEV uint64_t fb_ld8(cbptr S, uint32_t q, uint32_t len) {
   uint64_t by = 0;
-  if (q + 8 <= len) __builtin_memcpy(&by, S + q, 8);
+  if (q + 8 <= len) by = ldg8(S + q);
   else { for (uint32_t k = 0; k < 5; k++) if (q + k < len) by |= (uint64_t)S[q + k] << (8 * k); }
   return by;
 }
@@ -192,7 +192,7 @@ EH_DEV uint64_t fb_ld8(const uint8_t* S, uint32_t q, uint32_t len) {
 // bytes of the NEXT step are requested before this step's 16 lookups, and every kind of access of a step (lookups,
 // tests of the next table) is issued as one batch, so a step costs a few round trips.
 template <int INS>   // how the next table is written: 0 bitmap, global atomics; 1 bitmap in LDS; 2 bitmap, test (at L2) before the atomic; 3 N1 + bitmap rows; 4 N1 in LDS + bitmap rows
-__device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_t* ids, uint32_t g, const RkWord* RK, const ScEnt* SC, bool sc_lds, uint32_t kill, uint32_t e_pos, bool e_kill, uint32_t* Mn, uint32_t* N1n) {
+__device__ __noinline__ uint32_t fb_pass(cbptr S, uint32_t len, wptr ids, uint32_t g, const EH_G RkWord* RK, const EH_G ScEnt* SC, bool sc_lds, uint32_t kill, uint32_t e_pos, bool e_kill, wptr Mn, wptr N1n) {
   const uint32_t l = (uint32_t)EH_LANE;
   constexpr int U = 4;
   uint32_t alive = 0;
@@ -201,7 +201,7 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
   for (int u = 0; u < U; u++) {
     const uint32_t p = 256u * u + 4u * l;
     uint4 z; z.x = z.y = z.z = z.w = 0; idv[u] = z; byv[u] = 0;
-    if (p < len) { if (g > 0) idv[u] = *reinterpret_cast<const uint4*>(ids + p); byv[u] = fb_ld8(S, p + g, len); }
+    if (p < len) { if (g > 0) idv[u] = ldg16a(ids + p); byv[u] = fb_ld8(S, p + g, len); }
   }
   for (uint32_t base = 0; base < len; base += 256u * U) {
     uint4 nidv[U]; uint64_t nbyv[U];
@@ -209,7 +209,7 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
     for (int u = 0; u < U; u++) {                                  // prefetch the next step
       const uint32_t p = base + 256u * U + 256u * u + 4u * l;
       uint4 z; z.x = z.y = z.z = z.w = 0; nidv[u] = z; nbyv[u] = 0;
-      if (p < len) { if (g > 0) nidv[u] = *reinterpret_cast<const uint4*>(ids + p); nbyv[u] = fb_ld8(S, p + g, len); }
+      if (p < len) { if (g > 0) nidv[u] = ldg16a(ids + p); nbyv[u] = fb_ld8(S, p + g, len); }
     }
     RkWord rk[U][4];
     if (SC) {                                                      // compact entries first, rows only for the nodes that need them
@@ -280,7 +280,7 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
           }
         }
       }
-      if (p < len) { uint4 v; v.x = nw[0]; v.y = nw[1]; v.z = nw[2]; v.w = nw[3]; *reinterpret_cast<uint4*>(ids + p) = v; }
+      if (p < len) { uint4 v; v.x = nw[0]; v.y = nw[1]; v.z = nw[2]; v.w = nw[3]; stg16a(ids + p, v); }
     }
     if (Mn) {
       if (INS == 3 || INS == 4) {
@@ -303,7 +303,7 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
             row[u][k] = false;
             if (!bit2v[u][k]) continue;
             const uint32_t key = ((w2v[u][k] & 7u) << 5) + (uint32_t)__builtin_ctz(bit2v[u][k]) + 1u;     // byte' + 1
-            uint32_t* e = INS == 4 ? &g_fuse_lds[FB_LDS_NEXT + nidn[u][k]] : &N1n[nidn[u][k]];
+            uint32_t* e = INS == 4 ? &g_fuse_lds[FB_LDS_NEXT + nidn[u][k]] : (uint32_t*)&N1n[nidn[u][k]];   // (INS is a template argument: one address space per instance)
             uint32_t old = INS == 4 ? *e : have[u][k];
             if (old == key) continue;
             if (old == 0) old = atomicCAS(e, 0u, key);
@@ -348,25 +348,25 @@ __device__ __noinline__ uint32_t fb_pass(const uint8_t* S, uint32_t len, uint32_
 }
 
 // members of `node`: how many, and the position of the k-th (0-based, ascending)
-__device__ __noinline__ uint32_t fb_count(const uint32_t* ids, uint32_t len, uint32_t node) {
+__device__ __noinline__ uint32_t fb_count(cwptr ids, uint32_t len, uint32_t node) {
   const uint32_t l = (uint32_t)EH_LANE;
   uint32_t c = 0;
   for (uint32_t base = 0; base < len; base += 1024) {
     uint4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { uint32_t p = base + 256u * u + 4u * l; uint4 z; z.x = z.y = z.z = z.w = FB_DEAD; v[u] = z; if (p < len) v[u] = *reinterpret_cast<const uint4*>(ids + p); }
+    for (int u = 0; u < 4; u++) { uint32_t p = base + 256u * u + 4u * l; uint4 z; z.x = z.y = z.z = z.w = FB_DEAD; v[u] = z; if (p < len) v[u] = ldg16a(ids + p); }
 #pragma unroll
     for (int u = 0; u < 4; u++) c += (v[u].x == node) + (v[u].y == node) + (v[u].z == node) + (v[u].w == node);
   }
   return wave_sum(c);
 }
-__device__ __noinline__ uint32_t fb_find(const uint32_t* ids, uint32_t len, uint32_t node, uint32_t k) {
+__device__ __noinline__ uint32_t fb_find(cwptr ids, uint32_t len, uint32_t node, uint32_t k) {
   const uint32_t l = (uint32_t)EH_LANE;
   uint32_t before = 0;
   for (uint32_t base = 0; base < len; base += 1024) {
     uint4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { uint32_t p = base + 256u * u + 4u * l; uint4 z; z.x = z.y = z.z = z.w = FB_DEAD; v[u] = z; if (p < len) v[u] = *reinterpret_cast<const uint4*>(ids + p); }
+    for (int u = 0; u < 4; u++) { uint32_t p = base + 256u * u + 4u * l; uint4 z; z.x = z.y = z.z = z.w = FB_DEAD; v[u] = z; if (p < len) v[u] = ldg16a(ids + p); }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const uint32_t p = base + 256u * u + 4u * l;
@@ -390,7 +390,7 @@ __device__ __noinline__ uint32_t fb_find(const uint32_t* ids, uint32_t len, uint
 
 // The member at len-1 of a round: records its (node, byte') in the next-byte tables of the current generation and tells
 // whether another member had put it there already (then it is not alone in its group).
-EH_DEV uint32_t fb_end_member(uint32_t* M, uint32_t* N1, uint32_t id, uint32_t b) {
+EH_DEV uint32_t fb_end_member(wptr M, wptr N1, uint32_t id, uint32_t b) {
   uint32_t was = 0;
   if (EH_LANE == 0) {
     const uint32_t w = id * 8u + (b >> 5), bit = 1u << (b & 31u), key = b + 1u;
@@ -408,15 +408,15 @@ EH_DEV uint32_t fb_end_member(uint32_t* M, uint32_t* N1, uint32_t id, uint32_t b
 
 // find_jump_points/2 + any_position_pair/1: *from / *tpos = the positions jump/3 (:47-50) cuts at.  Same draws, same fuel,
 // same work accounting as fuse_lists' node-list version (eh_fuse.h).  false: work area exhausted / budget.
-__device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, bool sym, uint32_t* from, uint32_t* tpos, uint32_t* rounds) {
+__device__ __noinline__ bool fuse_jump_stream(Ctx&, cbptr A, uint32_t la, cbptr B, uint32_t lb, bool sym, uint32_t* from, uint32_t* tpos, uint32_t* rounds) {
   EH_CTX;
   const uint32_t l = (uint32_t)EH_LANE;
-  uint32_t* ids[2] = {nullptr, nullptr};
-  uint32_t* M[2] = {nullptr, nullptr};
-  uint32_t* N1[2] = {nullptr, nullptr};
-  RkWord* RK = nullptr; ScEnt* SC = nullptr;
+  wptr ids[2] = {nullptr, nullptr};
+  wptr M[2] = {nullptr, nullptr};
+  wptr N1[2] = {nullptr, nullptr};
+  EH_G RkWord* RK = nullptr; EH_G ScEnt* SC = nullptr;
   uint32_t rk_rows = 0, m_rows = 0;                                // nodes RK + SC / M[] + N1[] have room for
-  const uint8_t* S[2] = {A, B};
+  cbptr S[2] = {A, B};
   const uint32_t len[2] = {la, lb};
   const int nside = sym ? 1 : 2;
   uint32_t nn = 1, g = 0;                                          // nodes of generation g
@@ -438,18 +438,18 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t l
     // everything for 100 000 nodes up front made every fuse of a block of 100 KB and more ask for 13 to 21 MB.  The
     // next-byte tables (M, N1) are zero when they are allocated and fb_scan leaves zero what it has read.
     if (!ids[0]) {
-      for (int s = 0; s < nside; s++) { ids[s] = (uint32_t*)ws_alloc(c, ((uint64_t)len[s] + 8) * 4); if (!ids[s]) return false; }
+      for (int s = 0; s < nside; s++) { ids[s] = (wptr)ws_alloc(c, ((uint64_t)len[s] + 8) * 4); if (!ids[s]) return false; }
     }
     if (nn > rk_rows) {
       rk_rows = nn < 1024u ? 1024u : nn;
-      RK = (RkWord*)ws_alloc(c, ((uint64_t)rk_rows + 4) * 64);
-      SC = (ScEnt*)ws_alloc(c, ((uint64_t)rk_rows + 4) * 8);
+      RK = (EH_G RkWord*)ws_alloc(c, ((uint64_t)rk_rows + 4) * 64);
+      SC = (EH_G ScEnt*)ws_alloc(c, ((uint64_t)rk_rows + 4) * 8);
       if (!RK || !SC) return false;
     }
     if (nn > m_rows) {                                             // (only generation 0 comes here: later tables are sized below)
       m_rows = nn < 1024u ? 1024u : nn;
       for (int s = 0; s < nside; s++) {
-        M[s] = (uint32_t*)ws_alloc(c, ((uint64_t)m_rows + 4) * 32); N1[s] = (uint32_t*)ws_alloc(c, ((uint64_t)m_rows + 8) * 4);
+        M[s] = (wptr)ws_alloc(c, ((uint64_t)m_rows + 4) * 32); N1[s] = (wptr)ws_alloc(c, ((uint64_t)m_rows + 8) * 4);
         if (!M[s] || !N1[s]) return false;
         fb_clear(M[s], (m_rows + 4) * 8u); fb_clear(N1[s], (m_rows + 8u) & ~3u);
       }
@@ -487,13 +487,13 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, const uint8_t* A, uint32_t l
     // counts stay small over many rounds; lookups through the compact entries when few nodes spread over several words
     const bool n1 = next && !lds && nchild <= 2u * nn;
     const bool n1_lds = n1 && nchild <= FB_LDS_N1_NODES;
-    const ScEnt* look = nfull * 4u <= nn ? SC : nullptr;
+    const EH_G ScEnt* look = nfull * 4u <= nn ? SC : nullptr;
     const bool sc_lds = look && nn <= FB_LDS_SC_NODES;
-    if (sc_lds) { const uint32_t* scw = (const uint32_t*)SC; lanes_sync(); for (uint32_t i = l; i < 2u * nn; i += 64) g_fuse_lds[i] = scw[i]; lanes_sync(); }
+    if (sc_lds) { cwptr scw = (cwptr)SC; lanes_sync(); for (uint32_t i = l; i < 2u * nn; i += 64) g_fuse_lds[i] = scw[i]; lanes_sync(); }
     if (next && nchild > m_rows) {                                 // the next generation's tables (this one's are in RK now)
       m_rows = nchild;
       for (int s = 0; s < nside; s++) {
-        M[s] = (uint32_t*)ws_alloc(c, ((uint64_t)m_rows + 4) * 32); N1[s] = (uint32_t*)ws_alloc(c, ((uint64_t)m_rows + 8) * 4);
+        M[s] = (wptr)ws_alloc(c, ((uint64_t)m_rows + 4) * 32); N1[s] = (wptr)ws_alloc(c, ((uint64_t)m_rows + 8) * 4);
         if (!M[s] || !N1[s]) return false;
         fb_clear(M[s], (m_rows + 4) * 8u); fb_clear(N1[s], (m_rows + 8u) & ~3u);
       }

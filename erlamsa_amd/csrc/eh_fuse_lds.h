@@ -40,13 +40,13 @@ static_assert(FL_H_OFF + FL_H_WORDS <= EH_FUSE_LDS_WORDS, "g_fuse_lds too small 
 constexpr uint32_t FL_CUR = 0x3FFFu, FL_DEAD = 1u << 14, FL_DROPA = 1u << 15, FL_DROPB = 1u << 30, FL_SP = 1u << 31;
 
 struct FlState {
-  const uint8_t* A; const uint8_t* B; uint32_t la, lb; bool sym;
+  cbptr A; cbptr B; uint32_t la, lb; bool sym;
   uint32_t n, g, nn;        // live entries, generation, nodes
   uint32_t ghost;           // start index of the node without targets, FL_NONE: none
   uint32_t nsp;             // {[[]], [[]]} nodes of this generation (work accounting: they count two members, hold one entry)
   uint32_t multi;           // nodes with more than one entry
   uint32_t dboff;           // byte offset in g_fuse_lds of the staged data (A then B), FL_NONE: read the lists where they are
-  uint32_t* T;              // work-area parking space of a big node (n0 words)
+  wptr T;              // work-area parking space of a big node (n0 words)
   // fuse(H, H) with single-member nodes only: a round retires one known member; it is marked, not removed (see fl_round)
   uint32_t fast, tab_g0, ntomb;
 };
@@ -410,7 +410,7 @@ EH_DEV uint32_t fl_round(FlState& st) {
 }
 
 // find_jump_points/2 + any_position_pair/1 for lists whose members fit FL_NMAX entries; draws are the reference's.
-__device__ __noinline__ bool fuse_jump_lds(Ctx&, const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb, bool sym, uint32_t* from, uint32_t* tpos, uint32_t* rounds) {
+__device__ __noinline__ bool fuse_jump_lds(Ctx&, cbptr A, uint32_t la, cbptr B, uint32_t lb, bool sym, uint32_t* from, uint32_t* tpos, uint32_t* rounds) {
   EH_CTX;
   const uint32_t l = (uint32_t)EH_LANE;
   FlState st;
@@ -419,7 +419,7 @@ __device__ __noinline__ bool fuse_jump_lds(Ctx&, const uint8_t* A, uint32_t la, 
   st.n = n0; st.g = 0; st.nn = 1; st.ghost = FL_NONE; st.nsp = 0; st.multi = n0 > 1 ? 1u : 0u; st.dboff = FL_NONE;
   st.fast = 0; st.tab_g0 = 0; st.ntomb = 0;
   st.T = nullptr;
-  if (n0 > 64) { st.T = (uint32_t*)ws_alloc(c, 4ull * n0); if (!st.T) return false; }
+  if (n0 > 64) { st.T = (wptr)ws_alloc(c, 4ull * n0); if (!st.T) return false; }
   uint16_t* E = fl_E();
   for (uint32_t k = l; k < n0; k += 64) E[k] = (uint16_t)k;
   for (uint32_t k = l; k < FL_M_WORDS; k += 64) fl_M()[k] = k == 0 ? 1u : 0u;

@@ -23,9 +23,9 @@ constexpr uint32_t FR_NONE = 0xFFFFFFFFu;
 constexpr uint32_t FR_MAX_PERIOD = 1u << 16;        // how far the next occurrence of an anchor's 8 bytes is looked for
 constexpr int FR_LEVELS = 4;
 
-EH_DEV uint64_t fr_ld8(const uint8_t* S, uint32_t q, uint32_t len) {      // 8 bytes from q, zero filled past the end
+EH_DEV uint64_t fr_ld8(cbptr S, uint32_t q, uint32_t len) {      // 8 bytes from q, zero filled past the end
   uint64_t by = 0;
-  if (q + 8 <= len) __builtin_memcpy(&by, S + q, 8);
+  if (q + 8 <= len) by = ldg8(S + q);
   else { for (uint32_t k = 0; k < 8; k++) if (q + k < len) by |= (uint64_t)S[q + k] << (8 * k); }
   return by;
 }
@@ -37,7 +37,7 @@ EH_DEV uint32_t fr_peek_rounds(const Rng& r) {
   return z ? (uint32_t)__builtin_ctzll(z) : 64u;
 }
 // first i >= i0 with i + p >= n or S[i] != S[i + p]
-__device__ __noinline__ uint32_t fr_run_fwd(const uint8_t* S, uint32_t i0, uint32_t p, uint32_t n) {
+__device__ __noinline__ uint32_t fr_run_fwd(cbptr S, uint32_t i0, uint32_t p, uint32_t n) {
   const uint32_t l = (uint32_t)EH_LANE;
   const uint32_t lim = n - p;
   for (uint32_t base = i0;; base += 1024) {
@@ -45,7 +45,7 @@ __device__ __noinline__ uint32_t fr_run_fwd(const uint8_t* S, uint32_t i0, uint3
     uint32_t mp = FR_NONE;
     if (q + 16 <= lim) {
       uint4 a, b;
-      __builtin_memcpy(&a, S + q, 16); __builtin_memcpy(&b, S + q + p, 16);
+      a = ldg16(S + q); b = ldg16(S + q + p);
       const uint32_t x[4] = {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w};
 #pragma unroll
       for (int k = 3; k >= 0; k--) if (x[k]) mp = q + 4u * (uint32_t)k + ((uint32_t)__builtin_ctz(x[k]) >> 3);
@@ -57,14 +57,14 @@ __device__ __noinline__ uint32_t fr_run_fwd(const uint8_t* S, uint32_t i0, uint3
   }
 }
 // smallest lo <= i0 with S[k] == S[k + p] for every k in [lo, i0)   (i0 + p <= n)
-__device__ __noinline__ uint32_t fr_run_bwd(const uint8_t* S, uint32_t i0, uint32_t p) {
+__device__ __noinline__ uint32_t fr_run_bwd(cbptr S, uint32_t i0, uint32_t p) {
   const uint32_t l = (uint32_t)EH_LANE;
   for (uint32_t hi = i0;; hi -= 1024) {                              // lane l looks at [hi - 16 (l + 1), hi - 16 l), lane 0 the highest
     uint32_t mp = FR_NONE;                                           // highest mismatching position of this lane
     const uint32_t top = 16u * l < hi ? hi - 16u * l : 0u, bot = 16u * (l + 1u) < hi ? hi - 16u * (l + 1u) : 0u;
     if (top - bot == 16u) {
       uint4 a, b;
-      __builtin_memcpy(&a, S + bot, 16); __builtin_memcpy(&b, S + bot + p, 16);
+      a = ldg16(S + bot); b = ldg16(S + bot + p);
       const uint32_t x[4] = {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w};
 #pragma unroll
       for (int k = 0; k < 4; k++) if (x[k]) mp = bot + 4u * (uint32_t)k + ((31u - (uint32_t)__builtin_clz(x[k])) >> 3);
@@ -78,14 +78,14 @@ __device__ __noinline__ uint32_t fr_run_bwd(const uint8_t* S, uint32_t i0, uint3
 }
 // first y in [from, lim) with y + 8 <= n and the 8 bytes at y equal to key, FR_NONE: none.  1024 positions per step: a lane
 // loads the 24 bytes at its 16 positions and slides an 8-byte window over them.
-__device__ __noinline__ uint32_t fr_find8(const uint8_t* S, uint32_t from, uint32_t lim, uint32_t n, uint64_t key) {
+__device__ __noinline__ uint32_t fr_find8(cbptr S, uint32_t from, uint32_t lim, uint32_t n, uint64_t key) {
   const uint32_t l = (uint32_t)EH_LANE;
   if (n < 8) return FR_NONE;
   if (lim > n - 7) lim = n - 7;
   for (uint32_t base = from; base < lim; base += 1024) {
     const uint32_t q = base + 16u * l;
     uint64_t w0 = 0, w1 = 0, w2 = 0;
-    if (q + 24 <= n) { __builtin_memcpy(&w0, S + q, 8); __builtin_memcpy(&w1, S + q + 8, 8); __builtin_memcpy(&w2, S + q + 16, 8); }
+    if (q + 24 <= n) { w0 = ldg8(S + q); w1 = ldg8(S + q + 8); w2 = ldg8(S + q + 16); }
     else if (q < lim) { w0 = fr_ld8(S, q, n); w1 = fr_ld8(S, q + 8, n); w2 = fr_ld8(S, q + 16, n); }
     uint32_t first = 16;
 #pragma unroll
@@ -103,7 +103,7 @@ __device__ __noinline__ uint32_t fr_find8(const uint8_t* S, uint32_t from, uint3
 // The best cut of S[0, n) for searches of at most R bytes' depth: *u, *D (bytes [u, u + D) can go; *cP: the period: S[k] == S[k + P]
 // for k in [u - P, u + D + R - P)); false: nothing worth it.
 // Anchors at the eighths of the list: the 8 bytes there, their next occurrences as period candidates, the stretch each holds for.
-__device__ __noinline__ bool fr_find_cut(const uint8_t* S, uint32_t n, uint32_t R, uint32_t* cu, uint32_t* cD, uint32_t* cP = nullptr) {
+__device__ __noinline__ bool fr_find_cut(cbptr S, uint32_t n, uint32_t R, uint32_t* cu, uint32_t* cD, uint32_t* cP = nullptr) {
   uint32_t bestD = 0, bestU = 0, blo = 0, bhi = 0, bestP = 0;
   if (n < 4096) return false;
   bool any = false;                                                  // some anchor's bytes came again at all
@@ -140,11 +140,11 @@ __device__ __noinline__ bool fr_find_cut(const uint8_t* S, uint32_t n, uint32_t 
   return true;
 }
 // S[0, *n) -> a shortened copy in the work area (or S itself, untouched, when no cut is worth it); *n its length.  nullptr: work area exhausted.
-__device__ __noinline__ const uint8_t* fr_reduce(Ctx&, const uint8_t* S, uint32_t* n, uint32_t R) {
+__device__ __noinline__ cbptr fr_reduce(Ctx&, cbptr S, uint32_t* n, uint32_t R) {
   EH_CTX;
   uint32_t u = 0, D = 0, len = *n;
   if (!fr_find_cut(S, len, R, &u, &D)) return S;
-  uint8_t* C = ws_alloc(c, (uint64_t)len - D + 16);
+  bptr C = ws_alloc(c, (uint64_t)len - D + 16);
   if (!C) return nullptr;
   wave_copy(C, S, u);
   wave_copy(C + u, S + u + D, len - u - D);
@@ -162,7 +162,7 @@ __device__ __noinline__ const uint8_t* fr_reduce(Ctx&, const uint8_t* S, uint32_
 }
 // Occurrences of key[0, g) in S at positions s < lim (s + g <= len): their number; with want != FR_NONE the position of the
 // want-th one (0-based, ascending) goes to *pos and the scan stops there.
-__device__ __noinline__ uint32_t fr_occ(const uint8_t* S, uint32_t len, uint32_t lim, const uint8_t* key, uint32_t g, uint32_t want, uint32_t* pos) {
+__device__ __noinline__ uint32_t fr_occ(cbptr S, uint32_t len, uint32_t lim, cbptr key, uint32_t g, uint32_t want, uint32_t* pos) {
   const uint32_t l = (uint32_t)EH_LANE;
   uint64_t k8 = 0;
   for (uint32_t k = 0; k < 8 && k < g; k++) k8 |= (uint64_t)key[k] << (8 * k);

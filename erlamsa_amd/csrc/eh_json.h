@@ -35,7 +35,7 @@ EH_DEV void js_load(JsWin& x, uint32_t base) {
 __constant__ uint8_t c_jslit[64] = {'{', '}', '[', ']', ',', ':', '"', 't', 'r', 'u', 'e', 'f', 'a', 'l', 's', 'e', 'n', 'u', 'l', 'l', '-', '1',
                                     '1', '0', '0', '0', '0', '0', '0', '0', '0', '0', '"', '%', 'n', '%', 's', '"', '"', 'A', 'A', 'A', 'A', 'A', 'A', 'A', 'A', 'A', 'A', 'A', 'A', '"', '0'};
 enum { JL_LC = 0, JL_RC = 1, JL_LB = 2, JL_RB = 3, JL_COMMA = 4, JL_COLON = 5, JL_QUOTE = 6, JL_TRUE = 7, JL_FALSE = 11, JL_NULL = 16, JL_M1 = 20, JL_1E9 = 22, JL_FMT = 32, JL_AAA = 38, JL_ZERO = 52 };
-EH_DEV const uint8_t* jslit(int k) { return &c_jslit[k]; }
+EH_DEV cbptr jslit(int k) { return (cbptr)&c_jslit[k]; }   // (constant data is global memory)
 
 enum { J_OBJ = 1, J_ARR = 2, J_PAIR = 3, J_STR = 4, J_JUNK = 5, J_NUM = 6, J_CONST = 7 };
 enum { JX_TOP = 0, JX_MEMBER = 1, JX_PAIRVAL = 2, JX_KEY = 3 };
@@ -50,12 +50,12 @@ __constant__ char c_js_pay3[] = "{\"@class\":\"org.hibernate.jmx.StatisticsServi
 __constant__ char c_js_pay4[] = "{\"@class\":\"com.sun.rowset.JdbcRowSetImpl\", \"dataSourceName\":\"ldap:~suid=somename,ou=someou,dc=somed c\", \"autoCommit\":true}";
 __constant__ char c_js_pay5[] = "{\"@class\":\" com.atomikos.icatch.jta.RemoteClientUserTransaction\", \"name_\":\"ldap~suid=somename,ou=someou,dc=somedc\", \"providerUrl_\":\"ldap~s\"}";
 
-struct JsDoc { JNode* nd; Piece* pc; uint32_t nn, npc, have_top; };
+struct JsDoc { EH_G JNode* nd; EH_G Piece* pc; uint32_t nn, npc, have_top; };
 
 // tokenize/1 :83-188.  0 ok (out->have_top says whether a token was produced); -1 incorrect_json; -2 a
 // case_clause in ws/3 (the worker dies); -3 engine capacity.  build = false only runs the machine (no node or piece is
 // recorded): on most blocks js fails within a token or two, and that verdict then costs one window load.
-__device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, JsDoc* out, bool build) {
+__device__ __noinline__ int json_tokenize(Ctx&, cbptr H, uint32_t L, JsDoc* out, bool build) {
   EH_CTX;
   const int l = EH_LANE;
   // capacity: every node and every structure piece needs one of these bytes, or starts the block
@@ -70,14 +70,14 @@ __device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, Js
   }
   uint32_t cap_n = build ? 2 * nsig + 16 : 0xFFFFFFF0u;
   uint64_t cap_pc = build ? 4ull * cap_n + 16 : ~0ull;
-  JNode* nd = nullptr; Piece* pc = nullptr; uint32_t* nstk = nullptr;
+  EH_G JNode* nd = nullptr; EH_G Piece* pc = nullptr; wptr nstk = nullptr;
   if (build) {
-    nd = (JNode*)ws_alloc(c, (uint64_t)cap_n * sizeof(JNode));
-    pc = (Piece*)ws_alloc(c, cap_pc * sizeof(Piece));
-    nstk = (uint32_t*)ws_alloc(c, (uint64_t)cap_n * 4 + 16);              // open container / pair nodes
+    nd = (EH_G JNode*)ws_alloc(c, (uint64_t)cap_n * sizeof(JNode));
+    pc = (EH_G Piece*)ws_alloc(c, cap_pc * sizeof(Piece));
+    nstk = (wptr)ws_alloc(c, (uint64_t)cap_n * 4 + 16);              // open container / pair nodes
     if (!nd || !pc || !nstk) return -3;
   }
-  uint32_t* cold = (uint32_t*)ws_alloc(c, ((uint64_t)nsig / 2 + 16) * 4);  // spilled context atoms, 8 per word (<= 3 atoms per byte)
+  wptr cold = (wptr)ws_alloc(c, ((uint64_t)nsig / 2 + 16) * 4);  // spilled context atoms, 8 per word (<= 3 atoms per byte)
   if (!cold) return -3;
   uint32_t nn = 0, npc = 0, nns = 0, ncold = 0;
 
@@ -98,7 +98,7 @@ __device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, Js
   bool pushing = false, weird = false, have_top = false, mk = build;   // mk: nodes and pieces are being recorded
   uint32_t pv = 0, inkey_node = 0xFFFFFFFFu;
   int rc = 0;
-  auto put = [&](const uint8_t* p, uint32_t len) { piece_put(pc, npc, p, len); npc++; };
+  auto put = [&](cbptr p, uint32_t len) { piece_put(pc, npc, p, len); npc++; };
   auto value_ctx = [&]() -> uint32_t { uint32_t t = ctop(); return t == 0 ? (uint32_t)JX_TOP : (t == C_ELEMENTS ? (uint32_t)JX_MEMBER : (t == C_PAIR_DELIM ? (uint32_t)JX_KEY : (uint32_t)JX_PAIRVAL)); };
   auto new_node = [&](uint32_t kind, uint32_t ctx, uint32_t a, uint32_t b) -> uint32_t {
     uint32_t ik = (inkey_node != 0xFFFFFFFFu || ctx == JX_KEY) ? 1u : 0u;
@@ -248,7 +248,7 @@ __device__ __noinline__ int json_tokenize(Ctx&, const uint8_t* H, uint32_t L, Js
 
 // index of the k-th (0-based) node for which pred holds; nn if none
 template <class P>
-EH_DEV uint32_t js_find(const JNode* nd, uint32_t nn, uint32_t k, P pred) {
+EH_DEV uint32_t js_find(const EH_G JNode* nd, uint32_t nn, uint32_t k, P pred) {
   uint32_t before = 0;
   for (uint32_t base = 0; base < nn; base += 64) {
     uint32_t i = base + (uint32_t)EH_LANE;
@@ -262,13 +262,13 @@ EH_DEV uint32_t js_find(const JNode* nd, uint32_t nn, uint32_t k, P pred) {
   return nn;
 }
 struct JR { uint32_t i, p0, p1, nend, ctx, kind; };
-EH_DEV JR js_node(const JNode* nd, uint32_t i) { JNode n = nd[i]; JR r; r.i = i; r.p0 = uni(n.p0); r.p1 = uni(n.p1); r.nend = uni(n.nend); r.ctx = uni(n.ctx); r.kind = uni(n.kind); return r; }
+EH_DEV JR js_node(const EH_G JNode* nd, uint32_t i) { JNode n = nd[i]; JR r; r.i = i; r.p0 = uni(n.p0); r.p1 = uni(n.p1); r.nend = uni(n.nend); r.ctx = uni(n.ctx); r.kind = uni(n.kind); return r; }
 
 __device__ __noinline__ int muta_json(Ctx&) {
   EH_CTX;
   const int l = EH_LANE;
   Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
   JsDoc* dh = (JsDoc*)ws_alloc(c, sizeof(JsDoc));
   if (!dh) return 0;
@@ -304,14 +304,14 @@ __device__ __noinline__ int muta_json(Ctx&) {
   if (rc == -1) { tr_aa(c, AT_failed, AT_json); return -1; }               // catch incorrect_json -> [{failed, json} | Meta] :729-730
   if (rc == -2) { c.status = CASE_CRASHED; return 0; }
   if (rc != 0) return 0;
-  JNode* nd = (JNode*)uni64((uint64_t)dh->nd); Piece* pc = (Piece*)uni64((uint64_t)dh->pc);
+  EH_G JNode* nd = (EH_G JNode*)uni64((uint64_t)dh->nd); EH_G Piece* pc = (EH_G Piece*)uni64((uint64_t)dh->pc);
   const uint32_t nn = uni(dh->nn), npc = uni(dh->npc);
   // {NV, NT, N} = count(Tokens) :408-417,717
   uint32_t nt_ = 0, nv_ = 0;
   for (uint32_t i = l; i < nn; i += 64) { JNode n = nd[i]; nt_ += (n.kind == J_OBJ || n.kind == J_ARR); nv_ += n.inkey ? 0u : 1u; }
   const uint32_t N = nn, NT = wave_sum(nt_), NV = wave_sum(nv_);
   uint32_t cap_out = 2 * npc + 64;
-  Piece* out = (Piece*)ws_alloc(c, (uint64_t)cap_out * sizeof(Piece));
+  EH_G Piece* out = (EH_G Piece*)ws_alloc(c, (uint64_t)cap_out * sizeof(Piece));
   if (!out) return 0;
   uint32_t nout = 0;
   auto all = [&](uint32_t a, uint32_t b) { pieces_append(out, &nout, pc, a, b); };
@@ -321,7 +321,7 @@ __device__ __noinline__ int muta_json(Ctx&) {
     return js_node(nd, i);
   };
   auto listy = [&](uint32_t ctx) { return ctx == JX_MEMBER; };              // comma joined; otherwise the list is printed with brackets
-  bool raw = false; uint8_t* rawp = nullptr; uint32_t rawl = 0;            // json_unserialize result (a binary)
+  bool raw = false; bptr rawp = nullptr; uint32_t rawl = 0;            // json_unserialize result (a binary)
   int D = 1;
   uint32_t r;
   bool failed = false;
@@ -361,7 +361,7 @@ __device__ __noinline__ int muta_json(Ctx&) {
       else {
         uint32_t tmp0 = nout;
         lit(JL_COMMA, 1); all(a.p0, a.p1);
-        uint8_t* m; uint32_t ml;
+        bptr m; uint32_t ml;
         if (!pieces_materialize(c, out, tmp0, nout, &m, &ml)) return 0;
         nout = tmp0;
         piece_put(out, nout, m, ml, times); nout++;
@@ -381,7 +381,7 @@ __device__ __noinline__ int muta_json(Ctx&) {
       if (E == 1) all(st.p0, st.p1);
       else {
         JR xr = js_node(nd, st.i + E - 1);
-        uint8_t *ma, *mb; uint32_t la, lb;
+        bptr ma, mb; uint32_t la, lb;
         if (!pieces_materialize(c, pc, st.p0, xr.p0, &ma, &la) || !pieces_materialize(c, pc, xr.p1, st.p1, &mb, &lb)) return 0;
         piece_put(out, nout, ma, la, 4); nout++;
         all(xr.p0, xr.p1);
@@ -406,7 +406,7 @@ __device__ __noinline__ int muta_json(Ctx&) {
       D = -2;
       uint32_t k = rng_rand(c.rng, 6);
       const DevConfig& cfg = c.p->cfg;
-      uint8_t* b = ws_alloc(c, 1024);
+      bptr b = ws_alloc(c, 1024);
       if (!b) return 0;
       uint32_t o = 0;
       if (l == 0) {
@@ -470,7 +470,7 @@ __device__ __noinline__ int muta_json(Ctx&) {
           if (!ok) continue;                                               // error:badarg -> unchanged, no draw
           double rnd = rng_uniform(c.rng);
           if (rnd >= 3.0 / dN) continue;
-          uint8_t* txt; uint32_t tlen;
+          bptr txt; uint32_t tlen;
           if (!num_core(c, H, L, s, b, neg != 0, &txt, &tlen)) return 0;
           // `case .. of Number -> El`: an unchanged value keeps its spelling
           uint32_t same = 0;
@@ -496,7 +496,7 @@ __device__ __noinline__ int muta_json(Ctx&) {
   }
   if (c.status != CASE_OK) return 0;
   wave_sync();
-  uint8_t* dst; uint64_t total;
+  bptr dst; uint64_t total;
   if (raw) { dst = rawp; total = rawl; }
   else {
     nout = pieces_coalesce(out, nout);

@@ -16,14 +16,14 @@ namespace eh {
 // forward-only byte reader over a register window
 // ---------------------------------------------------------------------------------------------
 struct ByteReader {
-  const uint8_t* p; uint32_t n; uint32_t wbase; uint32_t w; bool valid;
+  cbptr p; uint32_t n; uint32_t wbase; uint32_t w; bool valid;
 };
-EH_DEV void br_init(ByteReader& r, const uint8_t* p, uint32_t n) { r.p = p; r.n = n; r.wbase = 0; r.w = 0; r.valid = false; }
+EH_DEV void br_init(ByteReader& r, cbptr p, uint32_t n) { r.p = p; r.n = n; r.wbase = 0; r.w = 0; r.valid = false; }
 EH_DEV void br_fill(ByteReader& r, uint32_t from) {
   r.wbase = from;
   uint32_t off = from + 4u * (uint32_t)EH_LANE;
   uint32_t v = 0;
-  if (off + 4 <= r.n) __builtin_memcpy(&v, r.p + off, 4);
+  if (off + 4 <= r.n) v = ldg4(r.p + off);
   else { for (uint32_t k = 0; k < 4; k++) if (off + k < r.n) v |= (uint32_t)r.p[off + k] << (8 * k); }
   r.w = v; r.valid = true;
 }
@@ -77,7 +77,7 @@ EH_DEV void lw_load(LexWin& x, uint32_t base) {
 //   ST_RAW    raw bytes: hop to the next position where texty_enough holds
 //   ST_TEXT   step_text (:99-112): hop to the next quote or non-texty byte
 //   ST_DELIM  step_delimited (:114-142): hop to the next closing quote, backslash or non-texty byte
-__device__ __noinline__ int lex_block(const uint8_t* H, uint32_t L, LexChunk* tab, uint32_t cap) {
+__device__ __noinline__ int lex_block(cbptr H, uint32_t L, EH_G LexChunk* tab, uint32_t cap) {
   const int l = EH_LANE;
   LexWin x; x.w.p = H; x.w.L = L; x.w.valid = false; x.w.base = 0;
   uint32_t pos = 0, n = 0; uint32_t raw_start = 0xFFFFFFFFu;
@@ -135,13 +135,13 @@ __device__ __noinline__ int lex_block(const uint8_t* H, uint32_t L, LexChunk* ta
 }
 
 // returns chunk count (>= 0) and *tab, or -1 after setting c.status
-EH_DEV int lex_cached(Ctx& c, LexCache& lc, const uint8_t* H, uint32_t L, LexChunk** tab) {
+EH_DEV int lex_cached(Ctx& c, EH_G LexCache& lc, cbptr H, uint32_t L, EH_G LexChunk** tab) {
   if (c.lex_ptr[c.depth] == (uint64_t)H && lc.n >= 0 && lc.ptr == (uint64_t)H && lc.len == L) { *tab = lc.tab; return lc.n; }
   uint32_t cap = L + 2 < (1u << 18) ? L + 2 : (1u << 18);   // every chunk covers >= 1 byte
   // the previous table is reused when it is large enough (a case that keeps lexing changing blocks used to leave one
   // table per miss behind at the top of its work area)
   uint32_t have = uni(lc.tcap);
-  LexChunk* t = have >= cap ? (LexChunk*)uni64((uint64_t)lc.tab) : (LexChunk*)ws_alloc_top(c, (uint64_t)cap * sizeof(LexChunk));
+  EH_G LexChunk* t = have >= cap ? (EH_G LexChunk*)uni64((uint64_t)lc.tab) : (EH_G LexChunk*)ws_alloc_top(c, (uint64_t)cap * sizeof(LexChunk));
   if (!t) return -1;
   wave_sync();
   if (EH_LANE == 0) { lc.n = -1; if (have < cap) { lc.tab = t; lc.tcap = cap; } }
@@ -170,10 +170,10 @@ __constant__ char c_rev_b[7][4] = {" ", " ", ":", " ", "/", " ", "."};
 __constant__ char c_rev_c[7][4] = {" ", "", "", "", "", " ", ""};
 
 // lane-0 helpers writing C strings
-__device__ inline uint32_t put_str(uint8_t* o, uint32_t pos, const char* s) { while (*s) o[pos++] = (uint8_t)*s++; return pos; }
+__device__ inline uint32_t put_str(bptr o, uint32_t pos, const char* s) { while (*s) o[pos++] = (uint8_t)*s++; return pos; }
 
 // random_badness/0 (:468-476): N = rand(20)+1 silly strings, each PREPENDED.  Returns length.
-EH_DEV uint32_t random_badness(Ctx& c, uint8_t* buf /* >= 168 bytes */) {
+EH_DEV uint32_t random_badness(Ctx& c, bptr buf /* >= 168 bytes */) {
   uint32_t n = rng_rand(c.rng, 20) + 1;
   uint32_t idx[20];
 #pragma unroll
@@ -198,7 +198,7 @@ EH_DEV uint32_t rand_as_count(Ctx& c) {                        // :485-499
   return rng_rand(c.rng, 1024);
 }
 // buildrevconnect/0 (:514-519); returns length written to buf (lane 0)
-EH_DEV uint32_t buildrevconnect(Ctx& c, uint8_t* buf) {
+EH_DEV uint32_t buildrevconnect(Ctx& c, bptr buf) {
   uint32_t inj = rng_rand(c.rng, 10), rev = rng_rand(c.rng, 7);
   uint32_t total = 0;
   if (EH_LANE == 0) {
@@ -217,9 +217,9 @@ EH_DEV uint32_t buildrevconnect(Ctx& c, uint8_t* buf) {
 enum TextMuta { T_INSERT_BADNESS, T_REPLACE_BADNESS, T_INSERT_TRAVERSAL, T_INSERT_AAAS, T_INSERT_NULL, T_INSERT_DELIMETER, T_INSERT_SHELLINJ };
 
 // mutate_text/2 (:521-563) on the content range [cs,ce) of H; builds the whole new block.
-EH_DEV void mutate_text_emit(Ctx& c, int tm, const uint8_t* H, uint32_t L, uint32_t cs, uint32_t ce) {
+EH_DEV void mutate_text_emit(Ctx& c, int tm, cbptr H, uint32_t L, uint32_t cs, uint32_t ce) {
   uint32_t n = ce - cs;                                         // length(Lst)
-  uint8_t* lit = ws_alloc(c, 512);
+  bptr lit = ws_alloc(c, 512);
   if (!lit) return;
   Pieces q; pc_init(q);
   pc_add(q, H, cs);
@@ -279,7 +279,7 @@ EH_DEV void mutate_text_emit(Ctx& c, int tm, const uint8_t* H, uint32_t L, uint3
   else {  // 6 pieces already (insert_traversal): emit in two steps
     Pieces q2; pc_init(q2);
     if (!pc_emit(c, q)) return;
-    uint8_t* first = c.r_ptr; uint32_t fl = c.r_len;
+    bptr first = c.r_ptr; uint32_t fl = c.r_len;
     pc_add(q2, first, fl); pc_add(q2, H + ce, L - ce);
     pc_emit(c, q2);
     return;
@@ -289,12 +289,12 @@ EH_DEV void mutate_text_emit(Ctx& c, int tm, const uint8_t* H, uint32_t L, uint3
 
 // construct_ascii_mutator (:585-602) with string_generic_mutate (ab, :571-583) or
 // string_delimeter_mutate (ad, :626-644)
-__device__ __noinline__ int muta_ascii(Ctx&, LexCache& lc, int fn) {
+__device__ __noinline__ int muta_ascii(Ctx&, EH_G LexCache& lc, int fn) {
   EH_CTX;
   Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
-  LexChunk* tab;
+  EH_G LexChunk* tab;
   int n = lex_cached(c, lc, H, L, &tab);
   if (n < 0) return 0;
   // stringy/1 :438-442
@@ -338,7 +338,7 @@ __device__ __noinline__ int muta_ascii(Ctx&, LexCache& lc, int fn) {
 
 // 4-byte history predicate scan (for "://" and the zip EOCD signature)
 template <class Pred>
-EH_DEV uint32_t tile_mask_h(const uint8_t* p, uint32_t n, uint32_t tile_base, Pred pred) {
+EH_DEV uint32_t tile_mask_h(cbptr p, uint32_t n, uint32_t tile_base, Pred pred) {
   uint32_t i0 = tile_base + 16u * (uint32_t)EH_LANE;
   if (i0 >= n) return 0;
   uint32_t cnt = n - i0 < 16 ? n - i0 : 16;
@@ -358,7 +358,7 @@ struct IsEocd { EH_DEV bool operator()(uint32_t b, uint32_t h) const { return b 
 
 // has an end-of-central-directory signature within the last 22+65535 bytes (zip:foldl fails with
 // bad_eocd otherwise)
-EH_DEV bool has_zip_eocd(const uint8_t* H, uint32_t L) {
+EH_DEV bool has_zip_eocd(cbptr H, uint32_t L) {
   if (L < 22) return false;
   uint32_t lo = L > 22 + 65535 ? L - 22 - 65535 : 0;
   uint32_t found = 0;
@@ -377,7 +377,7 @@ EH_DEV bool has_zip_eocd(const uint8_t* H, uint32_t L) {
 // Almost every text chunk fails within its first step, which is what keeps b64 cheap as a failing probe.
 // On acceptance *nalpha = alphabet characters before the padding and *span = the bytes they sit in (offset of the
 // first '=' or n): the decoded length is nalpha / 4 * 3 + {0, -, 1, 2}[nalpha % 4].
-EH_DEV bool b64_accepts(const uint8_t* t, uint32_t n, uint32_t* nalpha_out, uint32_t* span_out) {
+EH_DEV bool b64_accepts(cbptr t, uint32_t n, uint32_t* nalpha_out, uint32_t* span_out) {
   const int l = EH_LANE;
   uint32_t nalpha = 0, eqpos = 0xFFFFFFFFu;
   for (uint32_t base = 0; base < n && eqpos == 0xFFFFFFFFu; base += 64) {
@@ -419,9 +419,9 @@ EH_DEV uint32_t b64_sextet(uint32_t ch) {
 // lane g turns the g-th group of four characters into three bytes, the last lane the "xx" / "xxx" tail.  dst holds
 // b64_decoded_len(nalpha) bytes.  (Round 3 decoded on lane 0, byte by byte: the longest case of the bench workload
 // spent 9 of its 9.2 Gcyc there, on megabytes of repeated base64 lines - profiles/r04_heaviest_cases.txt.)
-EH_DEV void b64_decode_wave(const uint8_t* t, uint32_t span, uint32_t nalpha, uint8_t* dst, uint8_t* pack) {
+EH_DEV void b64_decode_wave(cbptr t, uint32_t span, uint32_t nalpha, bptr dst, bptr pack) {
   const int l = EH_LANE;
-  const uint8_t* src = t;
+  cbptr src = t;
   if (nalpha != span) {
     uint32_t cnt = 0;
     for (uint32_t base = 0; base < span; base += 64) {
@@ -447,7 +447,7 @@ EH_DEV void b64_decode_wave(const uint8_t* t, uint32_t span, uint32_t nalpha, ui
   }
 }
 // base64:encode_to_string/1: lane g encodes the g-th 3-byte group
-EH_DEV void b64_encode(const uint8_t* src, uint32_t n, uint8_t* dst) {
+EH_DEV void b64_encode(cbptr src, uint32_t n, bptr dst) {
   uint32_t ng = (n + 2) / 3;
   for (uint32_t g = EH_LANE; g < ng; g += 64) {
     uint32_t i = 3 * g, rem = n - i;
@@ -460,12 +460,12 @@ EH_DEV void b64_encode(const uint8_t* src, uint32_t n, uint8_t* dst) {
   }
 }
 // uri_mutator :770-784 (+ try_uri_mutate :760-768, rand_uri_mutate :737-758)
-__device__ __noinline__ int muta_uri(Ctx&, LexCache& lc) {
+__device__ __noinline__ int muta_uri(Ctx&, EH_G LexCache& lc) {
   EH_CTX;
   Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
-  LexChunk* tab;
+  EH_G LexChunk* tab;
   int n = lex_cached(c, lc, H, L, &tab);
   if (n < 0) return 0;
   // positions of the last byte of every "://" in the block
@@ -477,7 +477,7 @@ __device__ __noinline__ int muta_uri(Ctx&, LexCache& lc) {
   const DevConfig& cfg = c.p->cfg;
   uint32_t hostlen = 0; while (cfg.ssrf_host[hostlen]) hostlen++;
   uint64_t bound = (uint64_t)L + (uint64_t)nsep * (hostlen + 96) + 64;
-  uint8_t* dst = ws_alloc(c, bound);
+  bptr dst = ws_alloc(c, bound);
   if (!dst) return 0;
   // draws are wave-uniform: iterate chunks uniformly, let lane 0 write
   uint32_t out = 0; int dacc = -1; bool crashed = false;

@@ -21,7 +21,7 @@ EH_DEV uint64_t readlane64(uint64_t v, uint32_t lane_idx) {
 
 template <int K>
 struct MaskWin {
-  const uint8_t* p; uint32_t L;
+  cbptr p; uint32_t L;
   uint32_t base;                                   // absolute offset of bit 0 of word 0 (multiple of 64)
   bool valid;
   uint64_t m[K];                                   // my word (lane = word index) of each class

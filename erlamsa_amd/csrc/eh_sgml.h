@@ -38,7 +38,7 @@ EH_DEV uint32_t sg_class(uint32_t b) {
 // literal pool of fold_ast/2 (:290-331)
 __constant__ uint8_t c_sglit[24] = {'<', '>', ' ', '=', '\'', '"', '<', '/', ' ', '/', '>', '<', '?', '?', '>', '<', '!', '<', '!', '-', '-', '-', '-', '>'};
 enum { SL_LT = 0, SL_GT = 1, SL_SP = 2, SL_EQ = 3, SL_SQ = 4, SL_DQ = 5, SL_LTSL = 6, SL_SPSLGT = 8, SL_LTQ = 11, SL_QGT = 13, SL_LTBANG = 15, SL_CMT = 17, SL_CMTEND = 21 };
-EH_DEV const uint8_t* sglit(int k) { return &c_sglit[k]; }
+EH_DEV cbptr sglit(int k) { return (cbptr)&c_sglit[k]; }   // (constant data is global memory)
 
 enum { TK_OPEN = 1, TK_CLOSE = 2, TK_SC = 3, TK_TEXT = 4, TK_BANG = 5, TK_COMMENT = 6, TK_QUE = 7, TK_KIND = 0xFF, TF_EMPTY = 0x100, TF_PAIRED = 0x200 };
 struct SgTok { uint32_t kind, p0, np, na, nb, par0, npar; int32_t match; };
@@ -47,7 +47,7 @@ struct SgParam { uint32_t na, nb, va, vb, delim, pad; };
 // [" "][name]["="][quote][value][quote] (the last four empty for an empty value, fold_params/2 :297-298), then [">" | " />"]
 constexpr uint32_t SG_TAGHEAD = 3, SG_PARPCS = 6;
 
-struct SgDoc { SgTok* tok; SgParam* par; Piece* pc; uint32_t ntok, npar, npc; };
+struct SgDoc { EH_G SgTok* tok; EH_G SgParam* par; EH_G Piece* pc; uint32_t ntok, npar, npc; };
 
 // ---- one tag attempt PER LANE (round 4) ------------------------------------------------------------------------------------------
 // An attempt of tz/2 from a '<' depends on nothing before that '<' (the machine is in its text state there), so the attempts at
@@ -63,14 +63,14 @@ struct SgDoc { SgTok* tok; SgParam* par; Piece* pc; uint32_t ntok, npar, npc; };
 // finds nothing from a later event) and bad (the attribute loop entered at byte p fails) - both facts about the block, whichever
 // attempt establishes them.
 struct SgLaneTag { uint32_t ok, bail, kind, next, nexte, tag0, lt, npc, npar, na, nb, reach, ffc, fff, unmarked, capped; };
-struct SgLaneMemo { uint32_t gt, qgt, cmt, sq, dq; const uint8_t* bad; const uint32_t* nstop; };
+struct SgLaneMemo { uint32_t gt, qgt, cmt, sq, dq; cbptr bad; cwptr nstop; };
 constexpr uint32_t SG_LANE_BUDGET = 8192;           // events a lane may look at in all,
 constexpr uint32_t SG_LANE_FAR = 64;                // ... of them outside the LDS window (the event list in the work area: a dependent global load each),
 constexpr uint32_t SG_LANE_ATTRS = 48, SG_LANE_ATTRS_MIN = 6;   // ... and attributes it walks (the cap adapts between these, lane_batches): a longer tag is the wave-wide machine's, which takes its attributes one per lane (round 5)
 constexpr uint32_t SG_LANE_SEARCH = 2048;           // ... and in one search for a single class ('>', a quote, "-->", "?>"): the wave-wide machine looks at 64 per step
 // (a function of its own: inlined three times into sgml_tokenize it cost the wave-wide machine there its registers)
 template <int MODE>
-__device__ __noinline__ SgLaneTag sg_lane_attempt(const uint8_t* H, uint32_t L, const uint32_t* ev, uint32_t nev, uint32_t cbase, uint32_t e, const SgLaneMemo& mm, Piece* pc, SgParam* par, uint8_t* mark, uint32_t attr_cap) {
+__device__ __noinline__ SgLaneTag sg_lane_attempt(cbptr H, uint32_t L, cwptr ev, uint32_t nev, uint32_t cbase, uint32_t e, const SgLaneMemo& mm, EH_G Piece* pc, EH_G SgParam* par, bptr mark, uint32_t attr_cap) {
   SgLaneTag R; R.ok = 0; R.bail = 0; R.kind = 0; R.next = 0; R.nexte = 0; R.npc = 0; R.npar = 0; R.ffc = 0; R.fff = 0; R.unmarked = 0; R.capped = 0;
   bool bail = false; uint32_t budget = SG_LANE_BUDGET, reach = e + 1, far = 0;
   auto EV = [&](uint32_t i) -> uint32_t {                                  // (an unconditional LDS read, kept apart from the global one: EH_KEEP)
@@ -115,7 +115,7 @@ __device__ __noinline__ SgLaneTag sg_lane_attempt(const uint8_t* H, uint32_t L, 
     if (!bail) { R.ffc = cls; R.fff = from; reach = nev; }                // ran to the end of the block
     return nev;
   };
-  auto put = [&](const uint8_t* p, uint32_t len) { if (MODE == 1) { Piece q; q.ptr = (uint64_t)p; q.len = len; q.rep = 1; pc[np] = q; } np++; };
+  auto put = [&](cbptr p, uint32_t len) { if (MODE == 1) { Piece q; q.ptr = (uint64_t)p; q.len = len; q.rep = 1; pc[np] = q; } np++; };
   skipws();
   const uint32_t tag0 = pos;
   const bool tight = tag0 == lt + 1;
@@ -216,7 +216,7 @@ __device__ __noinline__ SgLaneTag sg_lane_attempt(const uint8_t* H, uint32_t L, 
       if (MODE == 1) { SgParam q; q.na = an; q.nb = ae; q.va = va; q.vb = vb; q.delim = delim; q.pad = 0; par[nq] = q; }
       nq++;
       const bool has = vb > va;
-      const uint8_t* qp = sglit(delim == 1 ? SL_SQ : SL_DQ);
+      cbptr qp = sglit(delim == 1 ? SL_SQ : SL_DQ);
       put(sp_before ? H + an - 1 : sglit(SL_SP), 1); put(H + an, ae - an);
       put(has ? H + eqpos : sglit(SL_EQ), has ? 1u : 0u); put(has && delim ? H + va - 1 : qp, has && delim ? 1u : 0u);
       put(H + va, has ? vb - va : 0u); put(has && delim ? H + vb : qp, has && delim ? 1u : 0u);
@@ -242,7 +242,7 @@ __device__ __noinline__ SgLaneTag sg_lane_attempt(const uint8_t* H, uint32_t L, 
 // statement as before - so this function only has to be right about the plain case.
 struct SgLaneAttr { uint32_t term, npos, nei, nws, an, ae, va, vb, delim, eqpos, reach; };
 constexpr uint32_t SG_ATTR_BUDGET = 512;            // events one lane may look at for its attribute
-__device__ __noinline__ SgLaneAttr sg_lane_attr(const uint8_t* H, uint32_t L, const uint32_t* ev, uint32_t nev, uint32_t cbase, uint32_t pos, uint32_t ei, uint32_t ws0, const SgLaneMemo& mm) {
+__device__ __noinline__ SgLaneAttr sg_lane_attr(cbptr H, uint32_t L, cwptr ev, uint32_t nev, uint32_t cbase, uint32_t pos, uint32_t ei, uint32_t ws0, const SgLaneMemo& mm) {
   (void)H;
   SgLaneAttr R; R.term = 1; R.npos = pos; R.nei = ei; R.nws = ws0; R.an = pos; R.ae = pos; R.va = pos; R.vb = pos; R.delim = 0; R.eqpos = 0xFFFFFFFFu; R.reach = ei;
   bool bail = false; uint32_t budget = SG_ATTR_BUDGET, reach = ei, far = 0;
@@ -323,20 +323,20 @@ __device__ __noinline__ SgLaneAttr sg_lane_attr(const uint8_t* H, uint32_t L, co
 // loop entered at byte p always ends the same way, whatever tag led there, so the positions at which a FAILED
 // attempt entered it are remembered (after its 16th attribute) and a later attempt arriving at one of them fails
 // at once: same tokens, linear time.
-__device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, SgDoc* out) {
+__device__ __noinline__ int sgml_tokenize(Ctx&, cbptr H, uint32_t L, SgDoc* out) {
   EH_CTX;
   const int l = EH_LANE;
 #ifdef EH_PROF
   const uint64_t ph1_t0 = __builtin_readcyclecounter();
 #endif
   // ---- phase 1: events
-  uint32_t* ev = (uint32_t*)ws_alloc(c, ((uint64_t)L + 80) * 4);
+  wptr ev = (wptr)ws_alloc(c, ((uint64_t)L + 80) * 4);
   if (!ev) return -3;
   uint32_t nev = 0, nlt = 0, nstop = 0;
   for (uint32_t tb = 0; tb < L; tb += 1024) {
     uint32_t i0 = tb + 16u * (uint32_t)l;
     uint8_t b[18];
-    if (i0 + 18 <= L) { uint4 v; __builtin_memcpy(&v, H + i0, 16); __builtin_memcpy(b, &v, 16); b[16] = H[i0 + 16]; b[17] = H[i0 + 17]; }
+    if (i0 + 18 <= L) { uint4 v = ldg16(H + i0); __builtin_memcpy(b, &v, 16); b[16] = H[i0 + 16]; b[17] = H[i0 + 17]; }
     else { for (uint32_t k = 0; k < 18; k++) b[k] = i0 + k < L ? H[i0 + k] : 0; }
     uint32_t cls[16]; uint32_t cnt = 0, lts = 0, stops = 0;
 #pragma unroll
@@ -374,9 +374,9 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   // capacity: tokens <= 2 x '<' + 2; a parameter needs a byte of the stop set after its name
   uint32_t cap_tok = 2 * nlt + 8, cap_par = nstop + 8;
   uint64_t cap_pc = 4ull * cap_tok + (uint64_t)SG_PARPCS * cap_par + nlt + 32;
-  SgTok* tok = (SgTok*)ws_alloc(c, (uint64_t)cap_tok * sizeof(SgTok));
-  SgParam* par = (SgParam*)ws_alloc(c, (uint64_t)cap_par * sizeof(SgParam));
-  Piece* pc = (Piece*)ws_alloc(c, cap_pc * sizeof(Piece));
+  EH_G SgTok* tok = (EH_G SgTok*)ws_alloc(c, (uint64_t)cap_tok * sizeof(SgTok));
+  EH_G SgParam* par = (EH_G SgParam*)ws_alloc(c, (uint64_t)cap_par * sizeof(SgParam));
+  EH_G Piece* pc = (EH_G Piece*)ws_alloc(c, cap_pc * sizeof(Piece));
   if (!tok || !par || !pc) return -3;
   wave_sync();
   uint32_t ntok = 0, npar = 0, npc = 0;
@@ -430,10 +430,10 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
     return j;
   };
   // ... and a name that runs over many events ("<<<<<< ... ") is skipped through a next-stop table, built on first need
-  uint32_t* nstop_tab = nullptr;
+  wptr nstop_tab = nullptr;
   auto build_nstop = [&]() __attribute__((always_inline)) -> bool {                                       // nstop_tab[i] = the first event >= i of the stop set (nev: none)
     EH_CTX;
-    nstop_tab = (uint32_t*)ws_alloc(c, ((uint64_t)nev + 64) * 4);
+    nstop_tab = (wptr)ws_alloc(c, ((uint64_t)nev + 64) * 4);
     if (!nstop_tab) return false;
 #ifdef EH_PROF
     const uint64_t bn_t0 = __builtin_readcyclecounter();
@@ -486,7 +486,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
       if (off + run < 64) break;
     }
   };
-  auto put = [&](const uint8_t* p, uint32_t len) { if (l == 0) { Piece q; q.ptr = (uint64_t)p; q.len = len; q.rep = 1; pc[npc] = q; } npc++; };
+  auto put = [&](cbptr p, uint32_t len) { if (l == 0) { Piece q; q.ptr = (uint64_t)p; q.len = len; q.rep = 1; pc[npc] = q; } npc++; };
 
   // ---- replay of periodic documents.  The heaviest cases of a pass are `sgm` on documents that sr / lr / sgm pumps have grown to
   // megabytes: thousands of copies of one run of elements, ~3 000 cycles of this sequential machine per tag.  Right after an accepted
@@ -535,7 +535,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
   if (L >= 16384 && nlt >= 64 && !(c.p->flags & EH_FLAG_SGML_NO_REPLAY)) rp_load(0);
   uint32_t rp_s0 = 0, rp_tok0 = 0, rp_pc0 = 0, rp_par0 = 0, rp_e0 = 0, rp_dtok = 0, rp_dpc = 0, rp_dpar = 0, rp_de = 0, rp_reach1 = 0;
   // memo of attribute-loop entries of failed attempts (see above)
-  uint8_t* bad = nullptr; uint32_t* chain = nullptr; uint32_t nchain = 0;
+  bptr bad = nullptr; wptr chain = nullptr; uint32_t nchain = 0;
   int rc = 0;
   bool first = true;
   uint32_t lt = 0, seg_start = 0, text_p0 = 0, text_len = 0, seg_slot = 0;
@@ -689,7 +689,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
         if (!bad) {
           bad = ws_alloc(c, (uint64_t)L + 16);
           if (!bad) return -3;
-          for (uint32_t i = 16u * (uint32_t)l; i < L + 16; i += 1024) { uint4 z = {0, 0, 0, 0}; __builtin_memcpy(bad + i, &z, 16); }
+          for (uint32_t i = 16u * (uint32_t)l; i < L + 16; i += 1024) { uint4 z = {0, 0, 0, 0}; stg16(bad + i, z); }
           wave_sync();
         }
         if (R.unmarked != 0) (void)sg_lane_attempt<2>(H, L, ev, nev, cbase, e, mm, nullptr, nullptr, bad, acap);
@@ -860,7 +860,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
             if (!nstop_tab && !build_nstop()) return -3;
             const bool memo = nattr >= 16;
             const uint32_t maxc = memo ? 64u : 16u - nattr;
-            if (memo && !chain) { chain = (uint32_t*)ws_alloc(c, ((uint64_t)nstop + 8) * 4); if (!chain) return -3; }
+            if (memo && !chain) { chain = (wptr)ws_alloc(c, ((uint64_t)nstop + 8) * 4); if (!chain) return -3; }
             if (cbase != 0xFFFFFFFFu && cbase + SG_EVC < nev && ei + 1024u > cbase + SG_EVC) { cbase = 0xFFFFFFFFu; bbase = 0xFFFFFFFFu; }   // little of the window left: move it
             need(ei);
             const uint32_t wend = cbase + SG_EVC < nev ? cbase + SG_EVC : nev;
@@ -915,8 +915,8 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
               if (cm) {
                 SgParam q; q.na = A.an; q.nb = A.ae; q.va = A.va; q.vb = A.vb; q.delim = A.delim; q.pad = 0; par[npar + rank] = q;
                 const bool has = A.vb > A.va, hd = has && A.delim != 0;
-                const uint8_t* qp = sglit(A.delim == 1 ? SL_SQ : SL_DQ);
-                Piece* o = pc + npc + 6u * rank; Piece x; x.rep = 1;
+                cbptr qp = sglit(A.delim == 1 ? SL_SQ : SL_DQ);
+                EH_G Piece* o = pc + npc + 6u * rank; Piece x; x.rep = 1;
                 x.ptr = (uint64_t)(cws ? H + A.an - 1 : sglit(SL_SP)); x.len = 1; o[0] = x;
                 x.ptr = (uint64_t)(H + A.an); x.len = A.ae - A.an; o[1] = x;
                 x.ptr = (uint64_t)(has ? H + A.eqpos : sglit(SL_EQ)); x.len = has ? 1u : 0u; o[2] = x;
@@ -942,7 +942,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
         }
         if (nattr >= 16) {                                                 // quadratic-rescan guard
           if (bad && uni(bad[pos])) break;
-          if (!chain) { chain = (uint32_t*)ws_alloc(c, ((uint64_t)nstop + 8) * 4); if (!chain) return -3; }
+          if (!chain) { chain = (wptr)ws_alloc(c, ((uint64_t)nstop + 8) * 4); if (!chain) return -3; }
           if (l == 0) chain[nchain] = pos;
           nchain++;
         }
@@ -981,7 +981,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
         if (l == 0) { SgParam q; q.na = an; q.nb = ae; q.va = va; q.vb = vb; q.delim = delim; q.pad = 0; par[npar] = q; }
         npar++; nattr++;
         bool has = vb > va;
-        const uint8_t* qp = sglit(delim == 1 ? SL_SQ : SL_DQ);
+        cbptr qp = sglit(delim == 1 ? SL_SQ : SL_DQ);
         put(sp_before ? H + an - 1 : sglit(SL_SP), 1); put(H + an, ae - an);
         put(has ? H + eqpos : sglit(SL_EQ), has ? 1u : 0u); put(has && delim ? H + va - 1 : qp, has && delim ? 1u : 0u);
         put(H + va, has ? vb - va : 0u); put(has && delim ? H + vb : qp, has && delim ? 1u : 0u);
@@ -1012,7 +1012,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
         if (!bad) {
           bad = ws_alloc(c, (uint64_t)L + 16);
           if (!bad) return -3;
-          for (uint32_t i = 16u * (uint32_t)l; i < L + 16; i += 1024) { uint4 z = {0, 0, 0, 0}; __builtin_memcpy(bad + i, &z, 16); }
+          for (uint32_t i = 16u * (uint32_t)l; i < L + 16; i += 1024) { uint4 z = {0, 0, 0, 0}; stg16(bad + i, z); }
         }
         wave_sync();
         for (uint32_t i = l; i < nchain; i += 64) bad[chain[i]] = 1;
@@ -1051,7 +1051,7 @@ __device__ __noinline__ int sgml_tokenize(Ctx&, const uint8_t* H, uint32_t L, Sg
 
 // string:to_lower/1 (ISO 8859-1 rule of the old string module)
 EH_DEV uint32_t latin1_lower(uint32_t ch) { return ((ch >= 'A' && ch <= 'Z') || (ch >= 0xC0 && ch <= 0xD6) || (ch >= 0xD8 && ch <= 0xDE)) ? ch + 32 : ch; }
-EH_DEV uint32_t sg_name_hash(const uint8_t* H, uint32_t a, uint32_t b) {
+EH_DEV uint32_t sg_name_hash(cbptr H, uint32_t a, uint32_t b) {
   uint32_t h = 0;
   for (uint32_t i = a + (uint32_t)EH_LANE; i < b; i += 64) {
     uint32_t v = (latin1_lower(H[i]) + 1u) * (0x9E3779B1u * ((i - a) + 1u) | 1u);
@@ -1060,7 +1060,7 @@ EH_DEV uint32_t sg_name_hash(const uint8_t* H, uint32_t a, uint32_t b) {
   }
   return wave_sum(h) ^ ((b - a) * 0x85EBCA6Bu);
 }
-EH_DEV bool sg_name_eq(const uint8_t* H, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
+EH_DEV bool sg_name_eq(cbptr H, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
   if (b1 - a1 != b2 - a2) return false;
   uint32_t n = b1 - a1; bool ne = false;
   for (uint32_t i = EH_LANE; i < n; i += 64) ne |= latin1_lower(H[a1 + i]) != latin1_lower(H[a2 + i]);
@@ -1069,7 +1069,7 @@ EH_DEV bool sg_name_eq(const uint8_t* H, uint32_t a1, uint32_t b1, uint32_t a2, 
 
 // build_ast2/4 :204-279 as a stack match over the token table: sets .match on paired open / close tokens.
 // stk = scratch for {token index, name hash} pairs.
-EH_DEV void sgml_pair(const uint8_t* H, SgTok* tok, uint32_t ntok, uint32_t* stk) {
+EH_DEV void sgml_pair(cbptr H, EH_G SgTok* tok, uint32_t ntok, wptr stk) {
   const int l = EH_LANE;
   uint32_t depth = 0;
   for (uint32_t base = 0; base < ntok; base += 64) {
@@ -1115,7 +1115,7 @@ EH_DEV void sgml_pair(const uint8_t* H, SgTok* tok, uint32_t ntok, uint32_t* stk
 }
 
 // element flags per token: bit 0 = the token starts an AST element, bit 1 = it is the open half of a {tag,..}
-EH_DEV void sgml_flags(const SgTok* tok, uint32_t ntok, uint8_t* ef, uint32_t* N, uint32_t* NT) {
+EH_DEV void sgml_flags(const EH_G SgTok* tok, uint32_t ntok, bptr ef, uint32_t* N, uint32_t* NT) {
   uint32_t n = 0, nt = 0;
   for (uint32_t i = EH_LANE; i < ntok; i += 64) {
     uint32_t k = tok[i].kind;
@@ -1130,7 +1130,7 @@ EH_DEV void sgml_flags(const SgTok* tok, uint32_t ntok, uint8_t* ef, uint32_t* N
   wave_sync();
 }
 // token index of the k-th (0-based) token whose flag has `bit`; ntok if there is none
-EH_DEV uint32_t sg_find(const uint8_t* ef, uint32_t ntok, uint32_t bit, uint32_t k) {
+EH_DEV uint32_t sg_find(cbptr ef, uint32_t ntok, uint32_t bit, uint32_t k) {
   uint32_t before = 0;
   for (uint32_t base = 0; base < ntok; base += 64) {
     uint32_t i = base + (uint32_t)EH_LANE;
@@ -1147,14 +1147,14 @@ EH_DEV uint32_t sg_find(const uint8_t* ef, uint32_t ntok, uint32_t bit, uint32_t
   return ntok;
 }
 // number of flagged tokens in [a, b]
-EH_DEV uint32_t sg_count(const uint8_t* ef, uint32_t a, uint32_t b, uint32_t bit) {
+EH_DEV uint32_t sg_count(cbptr ef, uint32_t a, uint32_t b, uint32_t bit) {
   uint32_t n = 0;
   for (uint32_t i = a + (uint32_t)EH_LANE; i <= b; i += 64) n += (ef[i] & bit) ? 1u : 0u;
   return wave_sum(n);
 }
 
 struct SgRange { uint32_t s, e, p0, p1; bool tag; };                       // tokens [s, e], pieces [p0, p1)
-EH_DEV SgRange sg_range_of(const SgTok* tok, uint32_t s) {
+EH_DEV SgRange sg_range_of(const EH_G SgTok* tok, uint32_t s) {
   SgTok t = tok[s];
   SgRange r; r.s = s;
   uint32_t k = uni(t.kind);
@@ -1170,7 +1170,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
   EH_CTX;
   const int l = EH_LANE;
   Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
   if (binarish(H, L)) return -1;                                           // parse/2 :198-199
   SgDoc* dh = (SgDoc*)ws_alloc(c, sizeof(SgDoc));
@@ -1181,10 +1181,10 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
   if (rc == -1) return -1;                                                 // catch incorrect_sgml :755-756
   if (rc == -2) { c.status = CASE_CRASHED; return 0; }
   if (rc != 0) return 0;
-  SgTok* tok = (SgTok*)uni64((uint64_t)dh->tok); SgParam* par = (SgParam*)uni64((uint64_t)dh->par); Piece* pc = (Piece*)uni64((uint64_t)dh->pc);
+  EH_G SgTok* tok = (EH_G SgTok*)uni64((uint64_t)dh->tok); EH_G SgParam* par = (EH_G SgParam*)uni64((uint64_t)dh->par); EH_G Piece* pc = (EH_G Piece*)uni64((uint64_t)dh->pc);
   const uint32_t ntok = uni(dh->ntok), npc = uni(dh->npc);
-  uint32_t* stk = (uint32_t*)ws_alloc(c, (uint64_t)ntok * 8 + 16);
-  uint8_t* ef = ws_alloc(c, (uint64_t)ntok + 16);
+  wptr stk = (wptr)ws_alloc(c, (uint64_t)ntok * 8 + 16);
+  bptr ef = ws_alloc(c, (uint64_t)ntok + 16);
   if (!stk || !ef) return 0;
   sgml_pair(H, tok, ntok, stk);
   uint32_t N, NT;
@@ -1192,7 +1192,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
   EH_PT(c, 91);
   // output piece list: worst case every doc piece twice plus a few literals
   uint32_t cap_out = 2 * npc + 64;
-  Piece* out = (Piece*)ws_alloc(c, (uint64_t)cap_out * sizeof(Piece));
+  EH_G Piece* out = (EH_G Piece*)ws_alloc(c, (uint64_t)cap_out * sizeof(Piece));
   if (!out) return 0;
   uint32_t nout = 0;
   auto all = [&](uint32_t a, uint32_t b) { pieces_append(out, &nout, pc, a, b); };
@@ -1222,7 +1222,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
       all(0, a.p1);
       if (times == 1) all(a.p0, a.p1);
       else {
-        uint8_t* m; uint32_t ml;
+        bptr m; uint32_t ml;
         if (!pieces_materialize(c, pc, a.p0, a.p1, &m, &ml)) return 0;
         piece_put(out, nout, m, ml, times); nout++;
       }
@@ -1245,7 +1245,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
       if (pcnt == 0 || E == 1) all(st.p0, st.p1);
       else {
         uint32_t reps = 1u << pcnt;
-        uint8_t *ma, *mb; uint32_t la, lb;
+        bptr ma, mb; uint32_t la, lb;
         if (!pieces_materialize(c, pc, st.p0, xr.p0, &ma, &la) || !pieces_materialize(c, pc, xr.p1, st.p1, &mb, &lb)) return 0;
         piece_put(out, nout, ma, la, reps); nout++;
         all(xr.p0, xr.p1);
@@ -1276,7 +1276,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
       if (npa == 2) { if (rng_rand(c.rng, 2) == 1) { all(p0 + SG_TAGHEAD + SG_PARPCS, p0 + SG_TAGHEAD + 2 * SG_PARPCS); all(p0 + SG_TAGHEAD, p0 + SG_TAGHEAD + SG_PARPCS); } else all(p0 + SG_TAGHEAD, p0 + SG_TAGHEAD + 2 * SG_PARPCS); }
       else if (npa > 0) {
         uint32_t np2 = 1; while (np2 < npa) np2 <<= 1;
-        Key2* keys = (Key2*)ws_alloc(c, (uint64_t)np2 * sizeof(Key2));
+        EH_G Key2* keys = (EH_G Key2*)ws_alloc(c, (uint64_t)np2 * sizeof(Key2));
         if (!keys) return 0;
         for (uint32_t base = 0; base < np2; base += 64) {
           uint32_t idx = base + (uint32_t)l;
@@ -1320,7 +1320,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
       all(0, uni(ot.p0) + uni(ot.np));
       // Internals ++ [{open,..} | Tree] on the reversed accumulator: the children come out in REVERSE order
       uint32_t nch = 0;
-      uint32_t* ch = (uint32_t*)ws_alloc(c, (uint64_t)(st.e - st.s) * 8 + 16);
+      wptr ch = (wptr)ws_alloc(c, (uint64_t)(st.e - st.s) * 8 + 16);
       if (!ch) return 0;
       for (uint32_t t = st.s + 1; t < st.e;) { SgRange k = sg_range_of(tok, t); if (l == 0) { ch[2 * nch] = k.p0; ch[2 * nch + 1] = k.p1; } nch++; t = k.e + 1; }
       wave_sync();
@@ -1335,7 +1335,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
       wave_sync();
       const DevConfig& cfg = c.p->cfg;
       // "http" ++ get_ssrf_uri() (erlamsa_mutations.erl:727-731)
-      uint8_t* uri = ws_alloc(c, 128);
+      bptr uri = ws_alloc(c, 128);
       if (!uri) return 0;
       uint32_t ul = 0;
       if (l == 0) { ul = put_str(uri, 0, "http://"); ul = put_str(uri, ul, cfg.ssrf_host); uri[ul++] = ':'; ul = put_str(uri, ul, cfg.ssrf_port); uri[ul++] = '/'; }
@@ -1360,19 +1360,19 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
           if (!isx) continue;
           uint32_t pi = p0 + SG_TAGHEAD + SG_PARPCS * i;
           uint32_t vl = qvb - qva;
-          const uint8_t* nv = uri; uint32_t nl = ul;
+          cbptr nv = uri; uint32_t nl = ul;
           bool app = rng_erand(c.rng, 2) == 1;
           // `Params =:= NewParams` (:596): replacing a value that already is the URI changes nothing
           if (app || vl != ul || !wave_equal(H + qva, uri, ul)) any = true;
           if (app) {                                                       // Uri ++ " http" ++ get_ssrf_uri()
-            uint8_t* b = ws_alloc(c, (uint64_t)vl + 1 + ul);
+            bptr b = ws_alloc(c, (uint64_t)vl + 1 + ul);
             if (!b) return 0;
             wave_copy(b, H + qva, vl); if (l == 0) b[vl] = ' '; wave_copy(b + vl + 1, uri, ul);
             nv = b; nl = vl + 1 + ul;
           }
           wave_sync();
           if (l == 0) {
-            const uint8_t* qp = sglit(qd == 1 ? SL_SQ : SL_DQ);
+            cbptr qp = sglit(qd == 1 ? SL_SQ : SL_DQ);
             out[pi + 2].len = 1;
             out[pi + 3].ptr = (uint64_t)qp; out[pi + 3].len = qd ? 1 : 0;
             out[pi + 4].ptr = (uint64_t)nv; out[pi + 4].len = nl;
@@ -1380,7 +1380,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
           }
         }
         if (!any) {                                                        // Params =:= NewParams: three new params in front :598-602
-          uint8_t* b = ws_alloc(c, 3ull * ul + 64);
+          bptr b = ws_alloc(c, 3ull * ul + 64);
           if (!b) return 0;
           uint32_t bl = 0;
           if (l == 0) {
@@ -1402,7 +1402,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
       uint32_t e_pri, e_meta; int nfs;
       inner_table(c, false, &e_pri, &e_meta, &nfs);
       // mutate_innertext/3 :674-681 on [vp, vp+vl); returns false to stop (status set)
-      auto inner = [&](const uint8_t* vp, uint32_t vl, uint32_t nt2, const uint8_t** np_, uint32_t* nl_, bool* changed) -> bool {
+      auto inner = [&](cbptr vp, uint32_t vl, uint32_t nt2, cbptr* np_, uint32_t* nl_, bool* changed) -> bool {
         *changed = false;
         uint32_t nw = wave_count(vp, vl, IsInk());
         if (!(nw > 0 && nt2 > 0)) return true;
@@ -1412,7 +1412,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
         if (nres < 0) return false;
         if (nres == 0) { c.status = CASE_CRASHED; return false; }          // hd([])
         Blk rb = blk_load(c.bl, c.nb);
-        *np_ = (const uint8_t*)rb.ptr; *nl_ = rb.len; *changed = true;
+        *np_ = (cbptr)rb.ptr; *nl_ = rb.len; *changed = true;
         return true;
       };
       for (uint32_t t = 0; t < ntok; t++) {
@@ -1420,10 +1420,10 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
         uint32_t k = uni(tk.kind), kk = k & TK_KIND;
         if (kk == TK_TEXT && !(k & TF_EMPTY)) {                            // try_mutate_innertext({text, Binary}, ..) :691-692
           uint32_t p0 = uni(tk.p0), np = uni(tk.np);
-          const uint8_t* vp; uint32_t vl;
-          if (np == 1) { Piece q = out[p0]; vp = (const uint8_t*)uni64(q.ptr); vl = uni(q.len); }
-          else { uint8_t* m; if (!pieces_materialize(c, out, p0, p0 + np, &m, &vl)) return 0; vp = m; }
-          const uint8_t* rp = nullptr; uint32_t rl = 0; bool ch;
+          cbptr vp; uint32_t vl;
+          if (np == 1) { Piece q = out[p0]; vp = (cbptr)uni64(q.ptr); vl = uni(q.len); }
+          else { bptr m; if (!pieces_materialize(c, out, p0, p0 + np, &m, &vl)) return 0; vp = m; }
+          cbptr rp = nullptr; uint32_t rl = 0; bool ch;
           if (!inner(vp, vl, NT, &rp, &rl, &ch)) return 0;
           if (ch) { wave_sync(); if (l == 0) { out[p0].ptr = (uint64_t)rp; out[p0].len = rl; for (uint32_t z = 1; z < np; z++) out[p0 + z].len = 0; } }
         } else if (kk == TK_CLOSE && (k & TF_PAIRED)) {                    // the tag's own params, after its children :683-690
@@ -1432,7 +1432,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
           for (uint32_t i = 0; i < npa; i++) {
             SgParam q = par[pa0 + i];
             uint32_t qva = uni(q.va), qvb = uni(q.vb);
-            const uint8_t* rp = nullptr; uint32_t rl = 0; bool ch;
+            cbptr rp = nullptr; uint32_t rl = 0; bool ch;
             if (!inner(H + qva, qvb - qva, NT + npa, &rp, &rl, &ch)) return 0;
             if (ch) {
               uint32_t pi = p0 + SG_TAGHEAD + SG_PARPCS * i;
@@ -1454,7 +1454,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
   nout = pieces_coalesce(out, nout);
   uint64_t total = pieces_total(out, nout);
   if (total > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 604); return 0; }
-  uint8_t* dst = ws_alloc(c, total ? total : 16);
+  bptr dst = ws_alloc(c, total ? total : 16);
   if (!dst) return 0;
   wave_gather(dst, out, nout);
   wave_sync();

@@ -13,12 +13,12 @@ namespace eh {
 // generic tile scan: pred(byte, prev_byte) with prev_byte = 256 at offset 0
 // ---------------------------------------------------------------------------------------------
 template <class Pred>
-EH_DEV uint32_t tile_mask(const uint8_t* p, uint32_t n, uint32_t tile_base, Pred pred) {
+EH_DEV uint32_t tile_mask(cbptr p, uint32_t n, uint32_t tile_base, Pred pred) {
   uint32_t i0 = tile_base + 16u * (uint32_t)EH_LANE;
   if (i0 >= n) return 0;
   uint32_t cnt = n - i0 < 16 ? n - i0 : 16;
   uint8_t b[16];
-  if (cnt == 16) { uint4 v; __builtin_memcpy(&v, p + i0, 16); __builtin_memcpy(b, &v, 16); }
+  if (cnt == 16) { uint4 v = ldg16(p + i0); __builtin_memcpy(b, &v, 16); }
   else { for (uint32_t k = 0; k < 16; k++) b[k] = k < cnt ? p[i0 + k] : 0; }
   uint32_t prev = i0 > 0 ? p[i0 - 1] : 256u;
   uint32_t m = 0;
@@ -41,14 +41,14 @@ EH_DEV uint32_t wave_sum(uint32_t v) {
   return uni(v);
 }
 template <class Pred>
-EH_DEV uint32_t wave_count(const uint8_t* p, uint32_t n, Pred pred) {
+EH_DEV uint32_t wave_count(cbptr p, uint32_t n, Pred pred) {
   uint32_t c = 0;
   for (uint32_t tb = 0; tb < n; tb += 1024) c += __popc(tile_mask(p, n, tb, pred));
   return wave_sum(c);
 }
 // position of the k-th (0-based) match, or n if there are fewer
 template <class Pred>
-EH_DEV uint32_t wave_find_kth(const uint8_t* p, uint32_t n, uint32_t k, Pred pred) {
+EH_DEV uint32_t wave_find_kth(cbptr p, uint32_t n, uint32_t k, Pred pred) {
   uint32_t before = 0;
   for (uint32_t tb = 0; tb < n; tb += 1024) {
     uint32_t m = tile_mask(p, n, tb, pred);
@@ -74,7 +74,7 @@ EH_DEV uint32_t wave_find_kth(const uint8_t* p, uint32_t n, uint32_t k, Pred pre
 }
 // writes the positions of matches with rank in [r0, r1) to out[rank - r0]
 template <class Pred>
-EH_DEV void wave_collect(const uint8_t* p, uint32_t n, uint32_t r0, uint32_t r1, uint32_t* out, Pred pred) {
+EH_DEV void wave_collect(cbptr p, uint32_t n, uint32_t r0, uint32_t r1, wptr out, Pred pred) {
   uint32_t before = 0;
   for (uint32_t tb = 0; tb < n && before < r1; tb += 1024) {
     uint32_t m = tile_mask(p, n, tb, pred);
@@ -93,7 +93,7 @@ EH_DEV void wave_collect(const uint8_t* p, uint32_t n, uint32_t r0, uint32_t r1,
 
 // erlamsa_utils:binarish/1 (erlamsa_utils.erl:238-247): one load of the first 11 bytes, the
 // clause order is then replayed on registers.
-EH_DEV bool binarish(const uint8_t* p, uint32_t n) {
+EH_DEV bool binarish(cbptr p, uint32_t n) {
   const int l = EH_LANE;
   uint32_t mine = (uint32_t)l < n && l < 11 ? p[l] : 0;
   uint32_t b[11];
@@ -119,19 +119,19 @@ struct Pieces {
   uint64_t p[6]; uint32_t n[6]; uint32_t rep[6]; int k;
 };
 EH_DEV void pc_init(Pieces& q) { q.k = 0; }
-EH_DEV void pc_add(Pieces& q, const uint8_t* p, uint32_t n, uint32_t rep = 1) { q.p[q.k] = (uint64_t)p; q.n[q.k] = n; q.rep[q.k] = rep; q.k++; }
+EH_DEV void pc_add(Pieces& q, cbptr p, uint32_t n, uint32_t rep = 1) { q.p[q.k] = (uint64_t)p; q.n[q.k] = n; q.rep[q.k] = rep; q.k++; }
 EH_DEV bool pc_emit(Ctx& c, const Pieces& q) {
   uint64_t total = 0;
 #pragma unroll
   for (int i = 0; i < 6; i++) if (i < q.k) total += (uint64_t)q.n[i] * q.rep[i];
   if (total > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 701); return false; }
-  uint8_t* dst = ws_alloc(c, total);
+  bptr dst = ws_alloc(c, total);
   if (!dst) return false;
   uint64_t pos = 0;
 #pragma unroll
   for (int i = 0; i < 6; i++) if (i < q.k) {
-    if (q.rep[i] == 1) wave_copy(dst + pos, (const uint8_t*)q.p[i], q.n[i]);
-    else wave_fill_periodic(dst + pos, (const uint8_t*)q.p[i], q.n[i], (uint64_t)q.n[i] * q.rep[i]);
+    if (q.rep[i] == 1) wave_copy(dst + pos, (cbptr)q.p[i], q.n[i]);
+    else wave_fill_periodic(dst + pos, (cbptr)q.p[i], q.n[i], (uint64_t)q.n[i] * q.rep[i]);
     pos += (uint64_t)q.n[i] * q.rep[i];
   }
   wave_sync();
@@ -145,9 +145,9 @@ EH_DEV bool pc_emit(Ctx& c, const Pieces& q) {
 struct IsNl { EH_DEV bool operator()(uint32_t b, uint32_t) const { return b == 10; } };
 
 struct LineIdx {  // lines(Bvec): cut after each \n  (erlamsa_mutations.erl:326-331)
-  const uint8_t* p; uint32_t L, nnl, N;
+  cbptr p; uint32_t L, nnl, N;
 };
-EH_DEV void li_init(LineIdx& li, const uint8_t* p, uint32_t L) {
+EH_DEV void li_init(LineIdx& li, cbptr p, uint32_t L) {
   li.p = p; li.L = L;
   li.nnl = wave_count(p, L, IsNl());
   li.N = li.nnl + ((L > 0 && uni(p[L - 1]) != 10) ? 1u : 0u);
@@ -167,7 +167,7 @@ static_assert(sizeof(StState) == 4 * ST_STATE_WORDS, "ST_STATE_WORDS");
 __device__ __noinline__ int muta_line(Ctx&, int fn) {
   EH_CTX;                       // construct_line_muta :351-362
   Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
   if (L == 0 || binarish(H, L)) return -1;                    // try_lines :341-348
   LineIdx li; li_init(li, H, L);
@@ -215,9 +215,9 @@ __device__ __noinline__ int muta_line(Ctx&, int fn) {
       uint32_t n = A < B ? A : B; if (n < 2) n = 2;
       // line boundaries F .. F+n  (n+1 offsets)
       uint64_t mark = c.ws_used;
-      uint32_t* bnd = (uint32_t*)ws_alloc(c, (uint64_t)(n + 1) * 4);
-      Key2* keys = (Key2*)ws_alloc(c, 512 * sizeof(Key2));
-      uint32_t* order = (uint32_t*)ws_alloc(c, 512 * 4);
+      wptr bnd = (wptr)ws_alloc(c, (uint64_t)(n + 1) * 4);
+      EH_G Key2* keys = (EH_G Key2*)ws_alloc(c, 512 * sizeof(Key2));
+      wptr order = (wptr)ws_alloc(c, 512 * 4);
       if (!bnd || !keys || !order) return 1;
       // newline ranks F-2 .. F+n-2 give the starts of lines F .. F+n (start = pos+1); line 1 starts at 0
       const int l = EH_LANE;
@@ -263,7 +263,7 @@ __device__ __noinline__ int muta_line(Ctx&, int fn) {
         wave_sync();
       }
       uint32_t a = uni(bnd[0]), e = uni(bnd[n]);
-      uint8_t* dst = ws_alloc(c, L);
+      bptr dst = ws_alloc(c, L);
       if (!dst) return 1;
       wave_copy(dst, H, a);
       uint32_t pos = a;
@@ -284,10 +284,10 @@ __device__ __noinline__ int muta_line(Ctx&, int fn) {
   return 1;
 }
 
-__device__ __noinline__ int muta_st_line(Ctx&, int fn, StState* st) {
+__device__ __noinline__ int muta_st_line(Ctx&, int fn, EH_G StState* st) {
   EH_CTX;        // construct_st_line_muta :366-378
   Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
   if (L == 0 || binarish(H, L)) return -1;
   LineIdx li; li_init(li, H, L);
@@ -314,7 +314,7 @@ __device__ __noinline__ int muta_st_line(Ctx&, int fn, StState* st) {
     if (up < 10) {
       uint32_t ep = rng_erand(c.rng, N);
       uint32_t a = li_start(li, ep), b = li_start(li, ep + 1);
-      StLineRef* e = &st->ln[up - 1];
+      EH_G StLineRef* e = &st->ln[up - 1];
       uint32_t hn = uni(e->has_nested), pl = uni(e->plen);
       if (!hn && pl == 0) { c.status = CASE_CRASHED; return 0; }       // fun([_|T], R) on []
       if (l == 0) {
@@ -331,7 +331,7 @@ __device__ __noinline__ int muta_st_line(Ctx&, int fn, StState* st) {
   uint32_t a = li_start(li, P), b = li_start(li, P + 1);
   Pieces q; pc_init(q);
   pc_add(q, H, a);
-  pc_add(q, (const uint8_t*)xn, xnl); pc_add(q, (const uint8_t*)xp, xpl);
+  pc_add(q, (cbptr)xn, xnl); pc_add(q, (cbptr)xp, xpl);
   if (fn == M_LIS) pc_add(q, H + a, L - a); else pc_add(q, H + b, L - b);   // [X, T | R]  /  [X | R]
   pc_emit(c, q);
   return 1;
@@ -343,9 +343,9 @@ __device__ __noinline__ int muta_st_line(Ctx&, int fn, StState* st) {
 struct IsDigitStart { EH_DEV bool operator()(uint32_t b, uint32_t prev) const { return b >= 48 && b <= 57 && !(prev >= 48 && prev <= 57); } };
 
 // Decimal bignum, base 1e9, little endian, lane-0 only.
-struct BD { uint32_t* d; int n; bool neg; };
+struct BD { uint32_t* d; int n; bool neg; };   // (digits in work memory or in a caller's array: generic)
 __device__ inline void bd_trim(BD& a) { while (a.n > 0 && a.d[a.n - 1] == 0) a.n--; if (a.n == 0) a.neg = false; }
-__device__ inline void bd_from_text(BD& r, const uint8_t* t, uint32_t nd) {
+__device__ inline void bd_from_text(BD& r, cbptr t, uint32_t nd) {
   r.n = (int)((nd + 8) / 9); r.neg = false;
   for (int i = 0; i < r.n; i++) {
     uint32_t hi = nd - 9u * (uint32_t)i, lo = hi >= 9 ? hi - 9 : 0, v = 0;
@@ -390,7 +390,7 @@ __device__ inline void bd_add_signed(BD& r, const BD& a, const BD& b, bool bneg)
   }
   bd_trim(r);
 }
-__device__ inline uint32_t bd_to_text(const BD& a, uint8_t* out) {      // integer_to_list/1
+__device__ inline uint32_t bd_to_text(const BD& a, bptr out) {      // integer_to_list/1
   uint32_t pos = 0;
   if (a.n == 0) { out[0] = '0'; return 1; }
   if (a.neg) out[pos++] = '-';
@@ -404,7 +404,7 @@ __device__ inline uint32_t bd_to_text(const BD& a, uint8_t* out) {      // integ
   return pos;
 }
 // |a|*2 as base-2^64 digits (little endian); returns number of digits (<= cap) or -1 if it does not fit
-__device__ inline int bd_times2_to_bin(const BD& a, uint64_t* w, int cap) {
+__device__ inline int bd_times2_to_bin(const BD& a, qptr w, int cap) {
   int n = 0;
   for (int i = a.n - 1; i >= 0; i--) {
     unsigned __int128 carry = a.d[i];
@@ -417,7 +417,7 @@ __device__ inline int bd_times2_to_bin(const BD& a, uint64_t* w, int cap) {
   return n;
 }
 // base-2^64 digits -> BD (destroys w)
-__device__ inline void bd_from_bin(BD& r, uint64_t* w, int n) {
+__device__ inline void bd_from_bin(BD& r, qptr w, int n) {
   r.n = 0; r.neg = false;
   while (n > 0) {
     unsigned __int128 rem = 0;
@@ -429,7 +429,7 @@ __device__ inline void bd_from_bin(BD& r, uint64_t* w, int n) {
 }
 
 // interesting_numbers/0 (erlamsa_mutations.erl:68-75): list index -> (exponent, -1/0/+1)
-__device__ inline void bd_interesting(BD& r, uint32_t idx, uint32_t* t1) {
+__device__ inline void bd_interesting(BD& r, uint32_t idx, wptr t1) {
   const int is[11] = {128, 127, 64, 63, 32, 31, 16, 15, 8, 7, 1};
   int e = 1; for (int k = 0; k < 11; k++) if ((int)(idx / 3) == k) e = is[k];
   int which = (int)(idx % 3);                                  // X-1, X, X+1
@@ -443,7 +443,7 @@ __device__ inline void bd_interesting(BD& r, uint32_t idx, uint32_t* t1) {
 // mutate_num/1,2 (erlamsa_mutations.erl:93-112) on the decimal number whose digits are H[s, e) (sign given
 // separately): draws first, then the arithmetic; the decimal text of the result (integer_to_list/1) is left
 // in *txt / *tlen (work-area memory).  Returns false after setting c.status (crash: float overflow in rand/1).
-__device__ __noinline__ bool num_core(Ctx&, const uint8_t* H, uint32_t L, uint32_t s, uint32_t e, bool negsign, uint8_t** txt_out, uint32_t* tlen_out) {
+__device__ __noinline__ bool num_core(Ctx&, cbptr H, uint32_t L, uint32_t s, uint32_t e, bool negsign, bptr* txt_out, uint32_t* tlen_out) {
   EH_CTX;
   const int l = EH_LANE;
   uint32_t nd = e - s;
@@ -537,7 +537,7 @@ __device__ __noinline__ bool num_core(Ctx&, const uint8_t* H, uint32_t L, uint32
     uint32_t ndig = nzm == 0 ? 1u : 64u - (uint32_t)__builtin_clzll(nzm);
     uint32_t sg = rneg ? 1u : 0u;
     uint32_t tlen = sg + ndig;
-    uint8_t* t = ws_alloc(c, 48);
+    bptr t = ws_alloc(c, 48);
     if (!t) return false;
     if ((uint32_t)l < ndig) t[sg + (ndig - 1 - (uint32_t)l)] = (uint8_t)(48 + dig);
     if (rneg && l == 63) t[0] = 45;
@@ -547,11 +547,11 @@ __device__ __noinline__ bool num_core(Ctx&, const uint8_t* H, uint32_t L, uint32
   }
   // work arrays (lane 0): limbs for value, operand, result
   uint32_t nl = (nd + 8) / 9 + 8;
-  uint32_t* va = (uint32_t*)ws_alloc(c, (uint64_t)nl * 4 + 64);
-  uint32_t* vb = (uint32_t*)ws_alloc(c, (uint64_t)nl * 4 + 256);
-  uint32_t* vr = (uint32_t*)ws_alloc(c, (uint64_t)nl * 4 + 256);
-  uint64_t* wb = (uint64_t*)ws_alloc(c, 20 * 8);
-  uint8_t* txt = ws_alloc(c, (uint64_t)nl * 9 + 64);
+  wptr va = (wptr)ws_alloc(c, (uint64_t)nl * 4 + 64);
+  wptr vb = (wptr)ws_alloc(c, (uint64_t)nl * 4 + 256);
+  wptr vr = (wptr)ws_alloc(c, (uint64_t)nl * 4 + 256);
+  qptr wb = (qptr)ws_alloc(c, 20 * 8);
+  bptr txt = ws_alloc(c, (uint64_t)nl * 9 + 64);
   if (!va || !vb || !vr || !wb || !txt) return false;
   uint32_t tlen = 0, crashed = 0;
   if (l == 0) {
@@ -564,7 +564,7 @@ __device__ __noinline__ bool num_core(Ctx&, const uint8_t* H, uint32_t L, uint32
       case 2: res.n = 0; break;
       case 3: bd_from_u128(res, 1); break;
       case 4: case 5: case 7: case 8: {
-        bd_interesting(opd, ielem, (uint32_t*)wb);
+        bd_interesting(opd, ielem, (wptr)wb);
         if (op == 4 || op == 5) { res.d = opd.d; res.n = opd.n; res.neg = false; }
         else bd_add_signed(res, num, opd, op == 8);
         break;
@@ -624,7 +624,7 @@ __device__ __noinline__ bool num_core(Ctx&, const uint8_t* H, uint32_t L, uint32
 __device__ __noinline__ int muta_num(Ctx&) {
   EH_CTX;                                  // sed_num :154-169
   Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   const int l = EH_LANE;
   c.r_kind = R_SAME;
   // mutate_a_num/2: numbers = maximal digit runs, each extended left over the dashes before it
@@ -634,7 +634,7 @@ __device__ __noinline__ int muta_num(Ctx&) {
   if (nfound == 0) {
     // nothing to change; the data still goes through flush_bvecs (re-chunking counts as a change
     // for blocks >= 2048 bytes, erlamsa_mutations.erl:157 + mux_fuzzers_loop :1278)
-    c.r_kind = R_NEW; c.r_ptr = (uint8_t*)H; c.r_len = L; c.r_flush = 1;
+    c.r_kind = R_NEW; c.r_ptr = (bptr)H; c.r_len = L; c.r_flush = 1;
     uint32_t r = rng_rand(c.rng, 10);
     return r == 0 ? -1 : 0;
   }
@@ -660,10 +660,10 @@ __device__ __noinline__ int muta_num(Ctx&) {
       e = uni(ee); a = uni(aa);
     }
   }
-  uint8_t* txt; uint32_t tlen;
+  bptr txt; uint32_t tlen;
   if (!num_core(c, H, L, s, e, a < s, &txt, &tlen)) return 0;
   uint32_t nlen = a + tlen + (L - e);
-  uint8_t* dst = ws_alloc(c, nlen);
+  bptr dst = ws_alloc(c, nlen);
   if (!dst) return 0;
   wave_copy(dst, H, a);
   wave_copy(dst + a, txt, tlen);

@@ -45,7 +45,7 @@ struct IsOpener { EH_DEV bool operator()(uint32_t b, uint32_t) const { return de
 #define TR_ST(k, v) do { } while (0)
 #endif
 struct IsDelim { EH_DEV bool operator()(uint32_t b, uint32_t) const { return delim_bit(b, (1u << 2) | (1u << 7) | (1u << 8) | (1u << 9) | (1u << 28) | (1u << 30), (1u << 27) | (1u << 29)); } };
-__device__ __noinline__ int tree_parse(Ctx&, const uint8_t* H, uint32_t L, TNode** out) {
+__device__ __noinline__ int tree_parse(Ctx&, cbptr H, uint32_t L, EH_G TNode** out) {
   EH_CTX;
   const int l = EH_LANE;
 #ifdef EH_PROF
@@ -54,9 +54,9 @@ __device__ __noinline__ int tree_parse(Ctx&, const uint8_t* H, uint32_t L, TNode
   // 1. positions of all delimiter bytes, in order (parallel scan + compaction)
   uint32_t nev = wave_count(H, L, IsDelim());
   uint32_t nopen = wave_count(H, L, IsOpener());
-  TNode* tab = (TNode*)ws_alloc(c, (uint64_t)(nopen + 1) * sizeof(TNode));
-  uint32_t* spill = (uint32_t*)ws_alloc(c, (uint64_t)(nopen + 64) * 4);
-  uint32_t* evp = (uint32_t*)ws_alloc(c, (uint64_t)(nev + 64) * 4);
+  EH_G TNode* tab = (EH_G TNode*)ws_alloc(c, (uint64_t)(nopen + 1) * sizeof(TNode));
+  wptr spill = (wptr)ws_alloc(c, (uint64_t)(nopen + 64) * 4);
+  wptr evp = (wptr)ws_alloc(c, (uint64_t)(nev + 64) * 4);
   if (!tab || !spill || !evp) return -1;
   if (nopen >= (1u << 24)) { EH_SET_OVERFLOW(c, 801); return -1; }
   TR_PH(10);
@@ -145,13 +145,13 @@ __device__ __noinline__ int tree_parse(Ctx&, const uint8_t* H, uint32_t L, TNode
   return (int)n;
 }
 
-EH_DEV bool node_eq(const uint8_t* H, TNode a, TNode b) {
+EH_DEV bool node_eq(cbptr H, TNode a, TNode b) {
   uint32_t la = a.close - a.open + 1, lb = b.close - b.open + 1;
   if (la != lb) return false;
   if (a.open == b.open) return true;
   return wave_equal(H + a.open, H + b.open, la);
 }
-EH_DEV TNode node_load(const TNode* t, uint32_t i) { TNode x = t[i]; x.open = uni(x.open); x.close = uni(x.close); x.pend = uni(x.pend); return x; }
+EH_DEV TNode node_load(const EH_G TNode* t, uint32_t i) { TNode x = t[i]; x.open = uni(x.open); x.close = uni(x.close); x.pend = uni(x.pend); return x; }
 
 // edit_sublist/3 sweep (:858-869) over nodes[lo..hi) in pre-order: the first node of a level that
 // equals `sub` is reported and the rest of that level (up to its pend) is skipped.  64 nodes are
@@ -159,7 +159,7 @@ EH_DEV TNode node_load(const TNode* t, uint32_t i) { TNode x = t[i]; x.open = un
 // nodes whose level is the sweep's own top level (sweeps restricted to a subtree pass its end).
 // Lane-parallel equality of up to 64 candidate nodes against `sub` (all slen+1 bytes long): every
 // candidate lane walks its own node 8 bytes at a time.  Returns the mask of equal candidates.
-EH_DEV unsigned long long nodes_equal_mask(const uint8_t* H, uint32_t my_open, bool cand, TNode sub) {
+EH_DEV unsigned long long nodes_equal_mask(cbptr H, uint32_t my_open, bool cand, TNode sub) {
   uint32_t n = sub.close - sub.open + 1;
   if (n > 256) {
     // long nodes: one wave-wide compare per candidate (1 KiB per step); the node itself is trivially equal
@@ -176,8 +176,8 @@ EH_DEV unsigned long long nodes_equal_mask(const uint8_t* H, uint32_t my_open, b
   uint32_t k = 0;
   for (; k + 8 <= n; k += 8) {
     uint64_t a = 0, b;
-    __builtin_memcpy(&b, H + sub.open + k, 8);
-    if (!ne && !self) __builtin_memcpy(&a, H + my_open + k, 8);
+    b = ldg8(H + sub.open + k);
+    if (!ne && !self) a = ldg8(H + my_open + k);
     ne = ne || (!self && a != b);
     if (__ballot(!ne && !self) == 0) break;
   }
@@ -186,7 +186,7 @@ EH_DEV unsigned long long nodes_equal_mask(const uint8_t* H, uint32_t my_open, b
   return __ballot(!ne);
 }
 template <class F>
-EH_DEV void tree_matches(const uint8_t* H, const TNode* nodes, uint32_t lo, uint32_t hi, uint32_t level_end, TNode sub, uint32_t* anc, F f) {
+EH_DEV void tree_matches(cbptr H, const EH_G TNode* nodes, uint32_t lo, uint32_t hi, uint32_t level_end, TNode sub, wptr anc, F f) {
   (void)anc;
   const int l = EH_LANE;
   (void)l;
@@ -218,8 +218,8 @@ EH_DEV void tree_matches(const uint8_t* H, const TNode* nodes, uint32_t lo, uint
 // 64 matches are handled per step: lane k owns a segment, a shuffle scan gives every segment its output
 // offset, short segments are then written byte-per-lane (each output byte finds its segment by a 6-step
 // shuffle search), long ones by a wave-wide copy each.
-EH_DEV uint64_t tree_emit(uint8_t* dst, const uint8_t* H, uint32_t L, const TNode* nodes, const uint32_t* mlist, uint32_t nm,
-                          const uint8_t* R0, uint32_t r0len, const uint8_t* R1, uint32_t r1len, bool keep_node) {
+EH_DEV uint64_t tree_emit(bptr dst, cbptr H, uint32_t L, const EH_G TNode* nodes, cwptr mlist, uint32_t nm,
+                          cbptr R0, uint32_t r0len, cbptr R1, uint32_t r1len, bool keep_node) {
   const int l = EH_LANE;
   uint64_t out = 0; uint32_t cur = 0;
   for (uint32_t base = 0; base < nm; base += 64) {
@@ -277,19 +277,19 @@ __device__ __noinline__ int muta_tree(Ctx&, int fn) {
   uint64_t tph = __builtin_readcyclecounter();
 #endif
   Blk hb = blk_load(c.bl, c.cur);
-  const uint8_t* H = (const uint8_t*)hb.ptr; uint32_t L = hb.len;
+  cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   const int l = EH_LANE;
   c.r_kind = R_SAME;
   if (binarish(H, L)) { TR_PH(0); return -1; }
   TR_PH(0);
   uint64_t mark = c.ws_used;
-  TNode* nodes;
+  EH_G TNode* nodes;
   int n_ = tree_parse(c, H, L, &nodes);
   TR_PH(1);
   if (n_ < 0) return 0;
   TR_ST(5, L); TR_ST(6, n_);
   uint32_t N = (uint32_t)n_;
-  uint32_t* anc = (uint32_t*)ws_alloc(c, (uint64_t)(N + 1) * 4);
+  wptr anc = (wptr)ws_alloc(c, (uint64_t)(N + 1) * 4);
   if (!anc) return 0;
   // Subs = sublists(Lst): list position j (0-based) <-> nodes[N-1-j]
 
@@ -302,7 +302,7 @@ __device__ __noinline__ int muta_tree(Ctx&, int fn) {
     uint32_t nm = 0;
     tree_matches(H, nodes, 0, N, L, sub, anc, [&](TNode, uint32_t idx) { if (l == 0) anc[nm] = idx; nm++; });
     uint64_t nl = fn == M_TR2 ? (uint64_t)L + (uint64_t)nm * slen : (uint64_t)L - (uint64_t)nm * slen;
-    uint8_t* dst = ws_alloc(c, nl);
+    bptr dst = ws_alloc(c, nl);
     if (!dst) return 1;
     wave_sync();
     // tr2: [H | Node] -> the node is written once more in front of itself; td: T -> the node is dropped
@@ -343,7 +343,7 @@ __device__ __noinline__ int muta_tree(Ctx&, int fn) {
       tree_matches(H, nodes, 0, N, L, A, anc, [&](TNode, uint32_t idx) { if (l == 0) anc[nm] = idx; nm++; });
       TR_PH(3); TR_ST(7, nm);
       uint64_t nl = (uint64_t)L + (uint64_t)nm * bl - (uint64_t)nm * al;
-      uint8_t* dst = ws_alloc(c, nl);
+      bptr dst = ws_alloc(c, nl);
       if (!dst) return 1;
       wave_sync();
       uint64_t out = tree_emit(dst, H, L, nodes, anc, nm, H + B.open, bl, nullptr, 0, false);      // [B | Tl]
@@ -384,7 +384,7 @@ __device__ __noinline__ int muta_tree(Ctx&, int fn) {
         }
       }
     }
-    uint8_t* dst = ws_alloc(c, (uint64_t)((int64_t)L + delta));
+    bptr dst = ws_alloc(c, (uint64_t)((int64_t)L + delta));
     if (!dst) return 1;
     wave_sync();
     uint64_t out = tree_emit(dst, H, L, nodes, anc, nm, H + B.open, bl, H + A.open, al, false);
@@ -451,8 +451,8 @@ __device__ __noinline__ int muta_tree(Ctx&, int fn) {
   // size of R_n
   uint64_t rsz = plen;
   for (uint32_t t = 2; t <= nreps; t++) { rsz = (uint64_t)k_in * rsz + fixed; if (rsz > ws_max_request(c)) { EH_SET_OVERFLOW(c, 802); c.ovf_req = rsz; return 1; } }
-  uint8_t* R = nullptr;
-  if (nreps < 2) R = (uint8_t*)(H + P.open);
+  bptr R = nullptr;
+  if (nreps < 2) R = (bptr)(H + P.open);
   else if (k_in == 1) {
     // R_n = pre^(n-1) ++ P ++ suf^(n-1)
     TNode m{0, 0, 0, 0};
@@ -465,10 +465,10 @@ __device__ __noinline__ int muta_tree(Ctx&, int fn) {
     wave_fill_periodic(R + (uint64_t)pre * (nreps - 1) + plen, H + m.close + 1, suf, (uint64_t)suf * (nreps - 1));
     wave_sync();
   } else {
-    const uint8_t* prev = H + P.open; uint64_t prevsz = plen;
+    cbptr prev = H + P.open; uint64_t prevsz = plen;
     for (uint32_t t = 2; t <= nreps; t++) {
       uint64_t sz = (uint64_t)k_in * prevsz + fixed;
-      uint8_t* cur = ws_alloc(c, sz);
+      bptr cur = ws_alloc(c, sz);
       if (!cur) return 1;
       uint32_t from = P.open; uint64_t out = 0;
       tree_matches(H, nodes, pidx + 1, pidx + 1 + ndesc, P.close + 1, C, anc, [&](TNode q, uint32_t) {
@@ -480,14 +480,14 @@ __device__ __noinline__ int muta_tree(Ctx&, int fn) {
       wave_sync();
       prev = cur; prevsz = sz;
     }
-    R = (uint8_t*)prev;
+    R = (bptr)prev;
   }
   // top level: edit_sublist(Lst, Child, [R_N | Tl])
   uint32_t nm = 0; uint64_t mb = 0;
   tree_matches(H, nodes, 0, N, L, C, anc, [&](TNode q, uint32_t) { nm++; mb += q.close - q.open + 1; });
   uint64_t nl = (uint64_t)L - mb + (uint64_t)nm * rsz;
   if (nl > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 803); c.ovf_req = ~0ull; return 1; }
-  uint8_t* dst = ws_alloc(c, nl);
+  bptr dst = ws_alloc(c, nl);
   if (!dst) return 1;
   uint32_t cur = 0; uint64_t out = 0;
   tree_matches(H, nodes, 0, N, L, C, anc, [&](TNode q, uint32_t) {

@@ -24,18 +24,18 @@ struct ZipEntry {
   uint32_t crc, csz, lpos, pad;
 };
 struct ZipRd {
-  const uint8_t* a; uint64_t n; uint32_t entries, idx; uint64_t pos;
+  cbptr a; uint64_t n; uint32_t entries, idx; uint64_t pos;
   int32_t rc; uint32_t method; uint64_t comp; uint32_t comp_len; uint32_t pad;   // lane 0 -> wavefront
   ZipEntry cur;
 };
-EH_DEV uint32_t zle16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
-EH_DEV uint32_t zle32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-EH_DEV void zput16(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
-EH_DEV void zput32(uint8_t* p, uint32_t v) { zput16(p, v & 0xffff); zput16(p + 2, v >> 16); }
-template <bool GROW> EH_DEV uint8_t* zip_alloc(Ctx& c, uint64_t n) { return GROW ? ws_alloc_grow(c, n) : ws_alloc(c, n); }
+EH_DEV uint32_t zle16(cbptr p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+EH_DEV uint32_t zle32(cbptr p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+EH_DEV void zput16(bptr p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+EH_DEV void zput32(bptr p, uint32_t v) { zput16(p, v & 0xffff); zput16(p + 2, v >> 16); }
+template <bool GROW> EH_DEV bptr zip_alloc(Ctx& c, uint64_t n) { return GROW ? ws_alloc_grow(c, n) : ws_alloc(c, n); }
 
 // prim_zip:get_central_dir up to the first entry: get_end_of_central_dir (Sz, Sz + Sz, .. <= 16#ffff), eocd_and_comment_from_bin
-EH_DEV int zip_open(ZipRd* r, const uint8_t* a, uint64_t n) {
+EH_DEV int zip_open(EH_G ZipRd* r, cbptr a, uint64_t n) {
   // almost every block is not an archive: the wavefront looks for a signature first (eh_lex.h; a superset of the windows below)
   if (n > 0xFFFFFFF0ull || !has_zip_eocd(a, (uint32_t)n)) return ZR_ERROR;
   if (EH_LANE == 0) {
@@ -49,7 +49,7 @@ EH_DEV int zip_open(ZipRd* r, const uint8_t* a, uint64_t n) {
         if (start == 0) break;
       }
       if (at != ~0ull) {
-        const uint8_t* e = a + at + 4;
+        cbptr e = a + at + 4;
         uint32_t entries = zle16(e + 6), off = zle32(e + 12), clen = zle16(e + 16);
         if (at + 22 + clen == n) {
           if (entries == 0xffff || off == 0xffffffffu) rc = ZR_UNSUP;
@@ -64,17 +64,17 @@ EH_DEV int zip_open(ZipRd* r, const uint8_t* a, uint64_t n) {
 }
 // get_cd_loop's next entry: the central-directory header and its name (what exists before the fun is called: a broken
 // header fails the fold without the fun having run for this entry)
-EH_DEV int zip_next_header(ZipRd* r) {
+EH_DEV int zip_next_header(EH_G ZipRd* r) {
   if (EH_LANE == 0) {
-    const uint8_t* a = r->a; const uint64_t n = r->n;
+    cbptr a = r->a; const uint64_t n = r->n;
     int rc = ZR_OK;
     if (r->pos + 46 > n || zle32(a + r->pos) != 0x02014b50u) rc = ZR_ERROR;                        // bad_central_directory
     else {
-      const uint8_t* h = a + r->pos;
+      cbptr h = a + r->pos;
       uint32_t gp = zle16(h + 8), fnl = zle16(h + 28), exl = zle16(h + 30), cml = zle16(h + 32), lho = zle32(h + 42);
       if (r->pos + 46 + fnl + exl + cml > n) rc = ZR_ERROR;
       else {
-        ZipEntry& e = r->cur;
+        EH_G ZipEntry& e = r->cur;
         e.name = (uint64_t)(h + 46); e.name_len = fnl; e.up = 0; e.time = (uint16_t)zle16(h + 12); e.date = (uint16_t)zle16(h + 14); e.usize = zle32(h + 24);
         e.data = 0; e.data_len = 0; e.method = 0; e.crc = 0; e.csz = 0; e.lpos = lho; e.pad = 0;
         r->pos += 46 + fnl + exl + cml; r->idx++;
@@ -89,11 +89,11 @@ EH_DEV int zip_next_header(ZipRd* r) {
 }
 // ... and the entry's GetBin() (get_z_file / get_z_all), called from inside the fun.  The entry's bytes are the archive's own for
 // a stored file and a fresh work-area block for a deflated one.
-template <bool GROW> EH_DEV int zip_next_file(Ctx& c, ZipRd* r, ZipEntry* out) {
+template <bool GROW> EH_DEV int zip_next_file(Ctx& c, EH_G ZipRd* r, EH_G ZipEntry* out) {
   if (EH_LANE == 0) {
-    const uint8_t* a = r->a; const uint64_t n = r->n;
+    cbptr a = r->a; const uint64_t n = r->n;
     int rc = ZR_OK;
-    const uint8_t* l = a + r->cur.lpos;
+    cbptr l = a + r->cur.lpos;
     if (zle32(l) != 0x04034b50u) rc = ZR_ERROR;                                                   // bad_local_file_header
     else {
       uint32_t lgp = zle16(l + 6), method = zle16(l + 8), csz = zle32(l + 18), lfn = zle16(l + 26), lex = zle16(l + 28);
@@ -108,17 +108,17 @@ template <bool GROW> EH_DEV int zip_next_file(Ctx& c, ZipRd* r, ZipEntry* out) {
   wave_sync();
   int rc = (int)uni((uint32_t)r->rc);
   if (rc != ZR_OK) return rc;
-  const uint32_t method = uni(r->method); const uint8_t* comp = (const uint8_t*)uni64(r->comp); const uint32_t clen = uni(r->comp_len);
+  const uint32_t method = uni(r->method); cbptr comp = (cbptr)uni64(r->comp); const uint32_t clen = uni(r->comp_len);
   uint64_t dptr = (uint64_t)comp, dlen = clen;
   if (method == 8) {                                                                              // inflateInit(Z, -MAX_WBITS), inflate, (catch) inflateEnd
-    ZInf* zi = (ZInf*)zip_alloc<GROW>(c, sizeof(ZInf));
+    EH_G ZInf* zi = (EH_G ZInf*)zip_alloc<GROW>(c, sizeof(ZInf));
     if (!zi) return ZR_STOP;
     uint64_t end;
     int st = z_inflate_pass(zi, comp, clen, 0, nullptr, &end);
     if (st == ZS_ERROR) return ZR_CRASH;
     dlen = uni64(zi->outn);
     if (dlen > 0xFFFFFF00ull) { EH_SET_OVERFLOW(c, 320); return ZR_STOP; }
-    uint8_t* d = zip_alloc<GROW>(c, dlen + 16);
+    bptr d = zip_alloc<GROW>(c, dlen + 16);
     if (!d) return ZR_STOP;
     (void)z_inflate_pass(zi, comp, clen, 0, d, &end);
     dptr = (uint64_t)d;
@@ -127,24 +127,24 @@ template <bool GROW> EH_DEV int zip_next_file(Ctx& c, ZipRd* r, ZipEntry* out) {
   wave_sync();
   return ZR_OK;
 }
-template <bool GROW> EH_DEV int zip_next(Ctx& c, ZipRd* r, ZipEntry* out) {
+template <bool GROW> EH_DEV int zip_next(Ctx& c, EH_G ZipRd* r, EH_G ZipEntry* out) {
   int rc = zip_next_header(r);
   return rc != ZR_OK ? rc : zip_next_file<GROW>(c, r, out);
 }
 // zip:create(Name, Files, [memory]) over es[0..n) in order; *out / *len: the archive.
-template <bool GROW> EH_DEV int zip_create(Ctx& c, ZipEntry* es, uint32_t n, uint8_t** out, uint64_t* len) {
+template <bool GROW> EH_DEV int zip_create(Ctx& c, EH_G ZipEntry* es, uint32_t n, bptr* out, uint64_t* len) {
   const int l = EH_LANE;
   // sizes first: what each entry takes from its binary, its method, whether the stream can be finished at all
   uint64_t bound = 22; uint32_t bad = 0;
   for (uint32_t i = 0; i < n; i++) {                                                              // (every lane computes the same)
-    ZipEntry& e = es[i];
+    EH_G ZipEntry& e = es[i];
     const uint64_t U = e.usize, S = e.data_len, nl = (uint64_t)e.name_len + 3ull * e.up;
-    const uint8_t* nm = (const uint8_t*)e.name;
+    cbptr nm = (cbptr)e.name;
     int dot = -1;                                                                                // filename:extension/1
     for (uint32_t k = 0; k < e.name_len; k++) { if (nm[k] == '.') dot = (int)k; else if (nm[k] == '/') dot = -1; }
     bool st_ext = false;
     if (dot >= 0) {
-      const uint32_t el = e.name_len - (uint32_t)dot; const uint8_t* x = nm + dot + 1;
+      const uint32_t el = e.name_len - (uint32_t)dot; cbptr x = nm + dot + 1;
       if (el == 2) st_ext = x[0] == 'Z';
       else if (el == 4) st_ext = (x[0] == 'z' && x[1] == 'i' && x[2] == 'p') || (x[0] == 'z' && x[1] == 'o' && x[2] == 'o') || (x[0] == 'a' && x[1] == 'r' && x[2] == 'c') ||
                                  (x[0] == 'l' && x[1] == 'z' && x[2] == 'h') || (x[0] == 'a' && x[1] == 'r' && x[2] == 'j');
@@ -165,17 +165,17 @@ template <bool GROW> EH_DEV int zip_create(Ctx& c, ZipEntry* es, uint32_t n, uin
   if (bad & 2) return ZR_UNSUP;
   if (bad & 1) return ZR_ERROR;
   if (bound > 0xFFFFFF00ull) { EH_SET_OVERFLOW(c, 321); return ZR_STOP; }
-  ZDef* zd = (ZDef*)zip_alloc<GROW>(c, sizeof(ZDef));
+  EH_G ZDef* zd = (EH_G ZDef*)zip_alloc<GROW>(c, sizeof(ZDef));
   if (!zd) return ZR_STOP;
-  uint8_t* dst = zip_alloc<GROW>(c, bound + 16);
+  bptr dst = zip_alloc<GROW>(c, bound + 16);
   if (!dst) return ZR_STOP;
   uint64_t pos = 0;
   for (uint32_t i = 0; i < n; i++) {
-    ZipEntry& e = es[i];
+    EH_G ZipEntry& e = es[i];
     const uint32_t take = uni(e.csz), method = uni(e.method), nl = uni(e.name_len), up = uni(e.up), U = uni(e.usize);
-    const uint8_t* data = (const uint8_t*)uni64(e.data); const uint8_t* nm = (const uint8_t*)uni64(e.name);
+    cbptr data = (cbptr)uni64(e.data); cbptr nm = (cbptr)uni64(e.name);
     const uint32_t fnl = nl + 3 * up;
-    uint8_t* h = dst + pos; uint8_t* body = h + 30 + fnl;
+    bptr h = dst + pos; bptr body = h + 30 + fnl;
     uint32_t crc = 0, csz = 0;
     if (take > 0) {
       crc = wave_crc32(data, take);
@@ -193,10 +193,10 @@ template <bool GROW> EH_DEV int zip_create(Ctx& c, ZipEntry* es, uint32_t n, uin
   }
   const uint64_t cd = pos;
   for (uint32_t i = 0; i < n; i++) {                                                              // put_central_dir: cd_file_header_from_lh_and_pos
-    const ZipEntry& e = es[i];
+    const EH_G ZipEntry& e = es[i];
     const uint32_t nl = uni(e.name_len), up = uni(e.up), fnl = nl + 3 * up;
-    const uint8_t* nm = (const uint8_t*)uni64(e.name);
-    uint8_t* h = dst + pos;
+    cbptr nm = (cbptr)uni64(e.name);
+    bptr h = dst + pos;
     for (uint32_t k = l; k < fnl; k += 64) h[46 + k] = k < 3 * up ? (k % 3 == 2 ? (uint8_t)'/' : (uint8_t)'.') : nm[k - 3 * up];
     if (l == 0) {
       zput32(h, 0x02014b50u); zput16(h + 4, 20); zput16(h + 6, 20); zput16(h + 8, 0); zput16(h + 10, e.method); zput16(h + 12, e.time); zput16(h + 14, e.date);
@@ -206,7 +206,7 @@ template <bool GROW> EH_DEV int zip_create(Ctx& c, ZipEntry* es, uint32_t n, uin
     pos += 46 + fnl;
   }
   if (l == 0) {                                                                                   // put_eocd
-    uint8_t* h = dst + pos;
+    bptr h = dst + pos;
     zput32(h, 0x06054b50u); zput16(h + 4, 0); zput16(h + 6, 0); zput16(h + 8, n); zput16(h + 10, n); zput32(h + 12, (uint32_t)(pos - cd)); zput32(h + 16, (uint32_t)cd); zput16(h + 20, 0);
   }
   pos += 22;
@@ -221,14 +221,14 @@ __device__ __noinline__ int muta_zip(Ctx&) {
   EH_CTX;
   const Blk hb = blk_load(c.bl, c.cur);
   c.r_kind = R_SAME;
-  if (!has_zip_eocd((const uint8_t*)hb.ptr, hb.len)) return -1;                                   // no end record anywhere: {error, bad_eocd} (the common case, nothing allocated)
-  ZipRd* rd = (ZipRd*)ws_alloc(c, sizeof(ZipRd));
+  if (!has_zip_eocd((cbptr)hb.ptr, hb.len)) return -1;                                   // no end record anywhere: {error, bad_eocd} (the common case, nothing allocated)
+  EH_G ZipRd* rd = (EH_G ZipRd*)ws_alloc(c, sizeof(ZipRd));
   if (!rd) return 0;
-  int rc = zip_open(rd, (const uint8_t*)hb.ptr, hb.len);
+  int rc = zip_open(rd, (cbptr)hb.ptr, hb.len);
   if (rc == ZR_UNSUP) { c.status = CASE_UNSUPPORTED; return 0; }
   if (rc != ZR_OK) return -1;
   const uint32_t n = uni(rd->entries);
-  ZipEntry* es = (ZipEntry*)ws_alloc(c, (uint64_t)(n ? n : 1) * sizeof(ZipEntry));
+  EH_G ZipEntry* es = (EH_G ZipEntry*)ws_alloc(c, (uint64_t)(n ? n : 1) * sizeof(ZipEntry));
   if (!es) return 0;
   for (uint32_t i = 0; i < n; i++) {
     rc = zip_next_header(rd);                                                                     // (a broken directory entry ends the fold before the fun runs)
@@ -243,7 +243,7 @@ __device__ __noinline__ int muta_zip(Ctx&) {
     if (EH_LANE == 0) es[i].up = up;
     wave_sync();
   }
-  uint8_t* out; uint64_t len;
+  bptr out; uint64_t len;
   rc = zip_create<false>(c, es, n, &out, &len);
   if (rc == ZR_STOP) return 0;
   if (rc == ZR_UNSUP) { c.status = CASE_UNSUPPORTED; return 0; }

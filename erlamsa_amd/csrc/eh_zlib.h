@@ -53,7 +53,7 @@ EH_DEV uint32_t gf2_xpow8n(uint64_t nbytes) {                      // x^(8*nbyte
   return r;
 }
 // erlang:crc32/1 of a contiguous buffer: 64 lane-local chunk CRCs combined with x^(8*len) shifts
-EH_DEV uint32_t wave_crc32(const uint8_t* p, uint32_t n) {
+EH_DEV uint32_t wave_crc32(cbptr p, uint32_t n) {
   const int l = EH_LANE;
   uint32_t chunk = (n + 63) / 64;
   uint32_t a = (uint32_t)l * chunk, b = a + chunk; if (a > n) a = n; if (b > n) b = n;
@@ -71,7 +71,7 @@ EH_DEV uint32_t wave_crc32(const uint8_t* p, uint32_t n) {
   }
   return total;
 }
-EH_DEV uint32_t wave_xor8(const uint8_t* p, uint32_t n) {
+EH_DEV uint32_t wave_xor8(cbptr p, uint32_t n) {
   uint32_t x = 0;
   for (uint32_t i = EH_LANE; i < n; i += 64) x ^= p[i];
 #pragma unroll
@@ -91,16 +91,16 @@ struct ZDef {
   int32_t heap_len, heap_max;
   uint32_t last_lit; uint64_t opt_len, static_len;
   // bit writer
-  uint8_t* out; uint64_t out_pos, out_cap; uint64_t bi_buf; int32_t bi_valid; int32_t overflow;
+  bptr out; uint64_t out_pos, out_cap; uint64_t bi_buf; int32_t bi_valid; int32_t overflow;
 };
 
 EH_DEV uint32_t z_bi_reverse(uint32_t code, int len) { uint32_t r = 0; do { r |= code & 1; code >>= 1; r <<= 1; } while (--len > 0); return r >> 1; }
-EH_DEV void z_put_byte(ZDef& s, uint32_t b) { if (s.out_pos < s.out_cap) s.out[s.out_pos] = (uint8_t)b; else s.overflow = 1; s.out_pos++; }
-EH_DEV void z_send_bits(ZDef& s, uint32_t value, int length) {
+EH_DEV void z_put_byte(EH_G ZDef& s, uint32_t b) { if (s.out_pos < s.out_cap) s.out[s.out_pos] = (uint8_t)b; else s.overflow = 1; s.out_pos++; }
+EH_DEV void z_send_bits(EH_G ZDef& s, uint32_t value, int length) {
   s.bi_buf |= (uint64_t)value << s.bi_valid; s.bi_valid += length;
   while (s.bi_valid >= 8) { z_put_byte(s, (uint32_t)(s.bi_buf & 0xff)); s.bi_buf >>= 8; s.bi_valid -= 8; }
 }
-EH_DEV void z_bi_windup(ZDef& s) { if (s.bi_valid > 0) z_put_byte(s, (uint32_t)(s.bi_buf & 0xff)); s.bi_buf = 0; s.bi_valid = 0; }
+EH_DEV void z_bi_windup(EH_G ZDef& s) { if (s.bi_valid > 0) z_put_byte(s, (uint32_t)(s.bi_buf & 0xff)); s.bi_buf = 0; s.bi_valid = 0; }
 
 // extra bits / bases of the length and distance codes (extra_lbits, extra_dbits, base_length, base_dist, _length_code, _dist_code of
 // trees.c in closed form): lc = match length - 3, d = distance - 1
@@ -112,13 +112,13 @@ EH_DEV int z_extra_dbits(int code) { return code < 4 ? 0 : (code >> 1) - 1; }
 EH_DEV uint32_t z_base_dist(int code) { if (code < 4) return (uint32_t)code; int e = (code >> 1) - 1; return (2u + (uint32_t)(code & 1)) << e; }
 EH_DEV int z_extra_blbits(int code) { return code < 16 ? 0 : code == 16 ? 2 : code == 17 ? 3 : 7; }
 
-struct ZDesc { ZTree* tree; int elems, extra_base, max_length, kind; /* 0 l, 1 d, 2 bl */ int max_code; };
+struct ZDesc { EH_G ZTree* tree; int elems, extra_base, max_length, kind; /* 0 l, 1 d, 2 bl */ int max_code; };
 EH_DEV int z_desc_extra(const ZDesc& d, int n) { return d.kind == 0 ? z_extra_lbits(n - 257) : d.kind == 1 ? z_extra_dbits(n) : z_extra_blbits(n); }
-EH_DEV int z_desc_static_len(const ZDef& s, const ZDesc& d, int n) { return d.kind == 0 ? s.st_llen[n] : 5; }   // bl_desc has no static tree
+EH_DEV int z_desc_static_len(const EH_G ZDef& s, const ZDesc& d, int n) { return d.kind == 0 ? s.st_llen[n] : 5; }   // bl_desc has no static tree
 
 // trees.c: smaller(), pqdownheap()
-EH_DEV bool z_smaller(const ZDef& s, const ZTree& t, int n, int m) { return t.fc[n] < t.fc[m] || (t.fc[n] == t.fc[m] && s.depth[n] <= s.depth[m]); }
-EH_DEV void z_pqdownheap(ZDef& s, const ZTree& t, int k) {
+EH_DEV bool z_smaller(const EH_G ZDef& s, const EH_G ZTree& t, int n, int m) { return t.fc[n] < t.fc[m] || (t.fc[n] == t.fc[m] && s.depth[n] <= s.depth[m]); }
+EH_DEV void z_pqdownheap(EH_G ZDef& s, const EH_G ZTree& t, int k) {
   int v = s.heap[k], j = k << 1;
   while (j <= s.heap_len) {
     if (j < s.heap_len && z_smaller(s, t, s.heap[j + 1], s.heap[j])) j++;
@@ -128,8 +128,8 @@ EH_DEV void z_pqdownheap(ZDef& s, const ZTree& t, int k) {
   s.heap[k] = v;
 }
 // trees.c: gen_bitlen()
-EH_DEV void z_gen_bitlen(ZDef& s, ZDesc& d) {
-  ZTree& t = *d.tree; const int max_code = d.max_code, max_length = d.max_length;
+EH_DEV void z_gen_bitlen(EH_G ZDef& s, ZDesc& d) {
+  EH_G ZTree& t = *d.tree; const int max_code = d.max_code, max_length = d.max_length;
   int h, n, m, bits, overflow = 0;
   for (bits = 0; bits <= 15; bits++) s.bl_count[bits] = 0;
   t.dl[s.heap[s.heap_max]] = 0;
@@ -163,14 +163,14 @@ EH_DEV void z_gen_bitlen(ZDef& s, ZDesc& d) {
   }
 }
 // trees.c: gen_codes()
-EH_DEV void z_gen_codes(ZTree& t, int max_code, const uint16_t* bl_count, uint16_t* next_code) {   // (next_code lives in the scratch block: no register arrays)
+EH_DEV void z_gen_codes(EH_G ZTree& t, int max_code, const uint16_t* bl_count, uint16_t* next_code) {   // (next_code lives in the scratch block: no register arrays)
   uint32_t code = 0;
   for (int bits = 1; bits <= 15; bits++) { code = (code + bl_count[bits - 1]) << 1; next_code[bits] = (uint16_t)code; }
   for (int n = 0; n <= max_code; n++) { int len = t.dl[n]; if (len == 0) continue; t.fc[n] = (uint16_t)z_bi_reverse(next_code[len]++, len); }
 }
 // trees.c: build_tree()
-__device__ __noinline__ void z_build_tree(ZDef& s, ZDesc& d) {
-  ZTree& t = *d.tree; const int elems = d.elems;
+__device__ __noinline__ void z_build_tree(EH_G ZDef& s, ZDesc& d) {
+  EH_G ZTree& t = *d.tree; const int elems = d.elems;
   int n, m, max_code = -1, node;
   s.heap_len = 0; s.heap_max = Z_HEAP_SIZE;
   for (n = 0; n < elems; n++) {
@@ -200,7 +200,7 @@ __device__ __noinline__ void z_build_tree(ZDef& s, ZDesc& d) {
   z_gen_codes(t, max_code, s.bl_count, s.next_code);
 }
 // trees.c: scan_tree() (send == false) and send_tree() (send == true)
-__device__ __noinline__ void z_scan_send_tree(ZDef& s, ZTree& t, int max_code, bool send) {
+__device__ __noinline__ void z_scan_send_tree(EH_G ZDef& s, EH_G ZTree& t, int max_code, bool send) {
   int prevlen = -1, curlen, nextlen = t.dl[0], count = 0, max_count = 7, min_count = 4;
   if (nextlen == 0) { max_count = 138; min_count = 3; }
   if (!send) t.dl[max_code + 1] = 0xffff;                                              // guard
@@ -223,7 +223,7 @@ __device__ __noinline__ void z_scan_send_tree(ZDef& s, ZTree& t, int max_code, b
     else { max_count = 7; min_count = 4; }
   }
 }
-EH_DEV void z_init_block(ZDef& s) {
+EH_DEV void z_init_block(EH_G ZDef& s) {
   for (int n = 0; n < Z_L_CODES; n++) s.lt.fc[n] = 0;
   for (int n = 0; n < Z_D_CODES; n++) s.dt.fc[n] = 0;
   for (int n = 0; n < Z_BL_CODES; n++) s.bt.fc[n] = 0;
@@ -231,14 +231,14 @@ EH_DEV void z_init_block(ZDef& s) {
   s.opt_len = s.static_len = 0; s.last_lit = 0;
 }
 // trees.c: _tr_tally(); true = the block is full
-EH_DEV bool z_tally(ZDef& s, uint32_t dist, uint32_t lc) {
+EH_DEV bool z_tally(EH_G ZDef& s, uint32_t dist, uint32_t lc) {
   s.d_buf[s.last_lit] = (uint16_t)dist; s.l_buf[s.last_lit++] = (uint8_t)lc;
   if (dist == 0) s.lt.fc[lc]++;
   else { dist--; s.lt.fc[z_length_code(lc) + 257]++; s.dt.fc[z_dist_code(dist)]++; }
   return s.last_lit == Z_LIT_BUFSIZE - 1;
 }
 // trees.c: compress_block() with the static (stat == true) or the dynamic trees
-__device__ __noinline__ void z_compress_block(ZDef& s, bool stat) {
+__device__ __noinline__ void z_compress_block(EH_G ZDef& s, bool stat) {
   for (uint32_t lx = 0; lx < s.last_lit; lx++) {
     uint32_t dist = s.d_buf[lx], lc = s.l_buf[lx];
     if (dist == 0) { if (stat) z_send_bits(s, s.st_lcode[lc], s.st_llen[lc]); else z_send_bits(s, s.lt.fc[lc], s.lt.dl[lc]); continue; }
@@ -256,7 +256,7 @@ __device__ __noinline__ void z_compress_block(ZDef& s, bool stat) {
 }
 // trees.c: _tr_flush_block() (zlib 1.2.11; level 6, Z_DEFAULT_STRATEGY).  buf = nullptr when the block's start has slid out of
 // zlib's window (block_start < 0): no stored block then.
-__device__ __noinline__ void z_flush_block(ZDef& s, const uint8_t* buf, uint64_t stored_len, int last) {
+__device__ __noinline__ void z_flush_block(EH_G ZDef& s, cbptr buf, uint64_t stored_len, int last) {
   ZDesc ld{&s.lt, Z_L_CODES, 257, 15, 0, 0}, dd{&s.dt, Z_D_CODES, 0, 15, 1, 0}, bd{&s.bt, Z_BL_CODES, 0, 7, 2, 0};
   z_build_tree(s, ld); z_build_tree(s, dd);
   z_scan_send_tree(s, s.lt, ld.max_code, false); z_scan_send_tree(s, s.dt, dd.max_code, false);     // build_bl_tree()
@@ -293,7 +293,7 @@ __device__ __noinline__ void z_flush_block(ZDef& s, const uint8_t* buf, uint64_t
 // `base` is the absolute position of its first byte.  Sliding changes nothing a match search can see (entries it clears are
 // farther back than MAX_DIST) except that the window's own first byte cannot start a match - position 0 here, NIL in zlib.
 // Raw deflate stream (no wrapper) of src[0..n) to s.out; lane 0 only.
-__device__ __noinline__ void z_deflate_raw(ZDef& s, const uint8_t* src, uint64_t n) {
+__device__ __noinline__ void z_deflate_raw(EH_G ZDef& s, cbptr src, uint64_t n) {
   for (int i = 0; i < Z_WSIZE; i++) s.head[i] = 0;
   {                                                                                      // tr_static_init(): static_ltree
     uint16_t* blc = s.bl_count; uint16_t* next_code = s.next_code;
@@ -341,13 +341,13 @@ __device__ __noinline__ void z_deflate_raw(ZDef& s, const uint8_t* src, uint64_t
       const uint64_t limit = strstart - base > (uint64_t)Z_MAX_DIST ? strstart - Z_MAX_DIST : base;
       if (prev_length >= (uint32_t)Z_GOOD_MATCH) chain_length >>= 2;
       if ((uint64_t)nice_match > lookahead) nice_match = (int)lookahead;
-      const uint8_t* scan = src + strstart;
+      cbptr scan = src + strstart;
       // zlib compares up to MAX_MATCH bytes inside its window whatever the lookahead is (bytes beyond the input are whatever the
       // window holds) and clips the result to the lookahead afterwards; a candidate either differs inside the lookahead or reaches
       // nice_match <= lookahead, so comparing inside the input only gives the same choice
       const int maxcmp = lookahead < (uint64_t)Z_MAX_MATCH ? (int)lookahead : Z_MAX_MATCH;
       do {
-        const uint8_t* match = src + cur_match;
+        cbptr match = src + cur_match;
         int len = 0;
         if (best_len < maxcmp ? (match[best_len] == scan[best_len] && match[best_len - 1] == scan[best_len - 1] && match[0] == scan[0] && match[1] == scan[1])
                               : false) {
@@ -388,7 +388,7 @@ __device__ __noinline__ void z_deflate_raw(ZDef& s, const uint8_t* src, uint64_t
 EH_DEV uint64_t z_deflate_bound(uint64_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 13 + 64; }
 
 // Adler-32 of a contiguous buffer, wave-parallel: a = 1 + sum(x_i), b = n + sum((n - i) * x_i)  (mod 65521)
-EH_DEV uint32_t wave_adler32(const uint8_t* p, uint64_t n) {
+EH_DEV uint32_t wave_adler32(cbptr p, uint64_t n) {
   uint64_t a = 0, b = 0; uint32_t k = 0;
   for (uint64_t i = EH_LANE; i < n; i += 64) {
     uint64_t x = p[i];
@@ -409,18 +409,18 @@ EH_DEV uint32_t wave_adler32(const uint8_t* p, uint64_t n) {
 // ------------------------------------------------------------------------------------------------------------------------------
 enum ZStatus : int { ZS_END = 0, ZS_TRUNC = 1, ZS_ERROR = 2 };
 struct ZInf {
-  const uint8_t* in; uint64_t n, pos; uint64_t hold; int32_t bits;
-  uint8_t* out; uint64_t outn;                       // out == nullptr: count only
+  cbptr in; uint64_t n, pos; uint64_t hold; int32_t bits;
+  bptr out; uint64_t outn;                       // out == nullptr: count only
   uint16_t lcount[16], lsym[288], dcount[16], dsym[32], ccount[16], csym[19];
   uint16_t lens[19 + 288 + 32];                     // code length code lengths, then literal/length + distance lengths
   int32_t lmax, dmax, cmax;
   int32_t st, early;                                // results handed from lane 0 to the wavefront
 };
-EH_DEV bool zi_need(ZInf& z, int k) {                                                  // NEEDBITS: false = out of input
+EH_DEV bool zi_need(EH_G ZInf& z, int k) {                                                  // NEEDBITS: false = out of input
   while (z.bits < k) { if (z.pos >= z.n) return false; z.hold |= (uint64_t)z.in[z.pos++] << z.bits; z.bits += 8; }
   return true;
 }
-EH_DEV uint32_t zi_bits(ZInf& z, int k) { uint32_t v = (uint32_t)(z.hold & ((1ull << k) - 1)); z.hold >>= k; z.bits -= k; return v; }
+EH_DEV uint32_t zi_bits(EH_G ZInf& z, int k) { uint32_t v = (uint32_t)(z.hold & ((1ull << k) - 1)); z.hold >>= k; z.bits -= k; return v; }
 // inflate_table(): 0 ok, -1 over-subscribed or incomplete set.  lens[0..n) -> count / symbol, *maxlen
 EH_DEV int zi_table(const uint16_t* lens, int n, bool codes_type, uint16_t* count, uint16_t* sym, int32_t* maxlen) {
   uint16_t offs[16];
@@ -437,7 +437,7 @@ EH_DEV int zi_table(const uint16_t* lens, int n, bool codes_type, uint16_t* coun
   return 0;
 }
 // >= 0 symbol, -1 out of input, -2 invalid code
-EH_DEV int zi_decode(ZInf& z, const uint16_t* count, const uint16_t* sym, int maxlen) {
+EH_DEV int zi_decode(EH_G ZInf& z, const uint16_t* count, const uint16_t* sym, int maxlen) {
   int code = 0, first = 0, index = 0;
   const int lim = maxlen == 0 ? 1 : maxlen;
   for (int len = 1; len <= lim; len++) {
@@ -451,7 +451,7 @@ EH_DEV int zi_decode(ZInf& z, const uint16_t* count, const uint16_t* sym, int ma
 }
 // the deflate blocks of a stream; z.in/pos at the first block header.  ZS_END: final block done (bits left in hold are dropped by
 // the caller's BYTEBITS)
-__device__ __noinline__ int zi_blocks(ZInf& z) {
+__device__ __noinline__ int zi_blocks(EH_G ZInf& z) {
   for (;;) {
     if (!zi_need(z, 3)) return ZS_TRUNC;
     int last = (int)zi_bits(z, 1), type = (int)zi_bits(z, 2);
@@ -539,7 +539,7 @@ __device__ __noinline__ int zi_blocks(ZInf& z) {
 // else; everything else is error:data_error for the caller (mutate_once_compressed then tries the zlib path, which fails on the
 // gzip magic, and the block ends as {compressed, failed}).  Until round 4 this was the rule of OTP 18 - 20.0 (first member only,
 // trailing bytes ignored).  Parses one member header at p, returns the offset of its deflate data or 0.
-EH_DEV uint64_t zi_gzip_header(const uint8_t* p, uint64_t n, const uint32_t* crc_table) {
+EH_DEV uint64_t zi_gzip_header(cbptr p, uint64_t n, const uint32_t* crc_table) {
   if (n < 10 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xe0)) return 0;
   uint32_t flags = p[3]; uint64_t pos = 10;
   if (flags & 0x04) { if (pos + 2 > n) return 0; uint64_t xl = p[pos] | ((uint64_t)p[pos + 1] << 8); pos += 2; if (pos + xl > n) return 0; pos += xl; }
@@ -566,7 +566,7 @@ EH_DEV uint64_t z_wrap_bytes(int fmt) { return fmt == ZF_GZIP ? 18 : fmt == ZF_Z
 // endian), zlib:deflateInit(Z, default) + deflate(Z, Data, finish) (ZF_ZLIB: 78 9c, Adler-32 big endian), or the bare stream of
 // deflateInit(.., -15, ..) that zip:create uses (ZF_RAW).  dst needs z_deflate_bound(n) + z_wrap_bytes(fmt) bytes; returns the
 // length written.
-EH_DEV uint64_t z_compress(ZDef* sc, int fmt, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) {
+EH_DEV uint64_t z_compress(EH_G ZDef* sc, int fmt, cbptr src, uint64_t n, bptr dst, uint64_t cap) {
   uint32_t chk = fmt == ZF_GZIP ? wave_crc32(src, (uint32_t)n) : fmt == ZF_ZLIB ? wave_adler32(src, n) : 0u;
   if (EH_LANE == 0) {
     uint64_t h = 0;
@@ -574,7 +574,7 @@ EH_DEV uint64_t z_compress(ZDef* sc, int fmt, const uint8_t* src, uint64_t n, ui
     else if (fmt == ZF_ZLIB) { dst[0] = 0x78; dst[1] = 0x9c; h = 2; }
     sc->out = dst + h; sc->out_pos = 0; sc->out_cap = cap - z_wrap_bytes(fmt); sc->overflow = 0;
     z_deflate_raw(*sc, src, n);
-    uint8_t* t = dst + h + sc->out_pos;
+    bptr t = dst + h + sc->out_pos;
     if (!sc->overflow) {
       if (fmt == ZF_GZIP) { for (int i = 0; i < 4; i++) { t[i] = (uint8_t)(chk >> (8 * i)); t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i)); } }
       else if (fmt == ZF_ZLIB) { for (int i = 0; i < 4; i++) t[i] = (uint8_t)(chk >> (24 - 8 * i)); }
@@ -587,7 +587,7 @@ EH_DEV uint64_t z_compress(ZDef* sc, int fmt, const uint8_t* src, uint64_t n, ui
 }
 // One decoding pass over in[off..n): out == nullptr counts.  Returns the ZStatus; zi->outn bytes (would be) written; *end = offset of
 // the first byte behind the deflate data (after BYTEBITS) when the status is ZS_END.
-EH_DEV int z_inflate_pass(ZInf* zi, const uint8_t* in, uint64_t n, uint64_t off, uint8_t* out, uint64_t* end) {
+EH_DEV int z_inflate_pass(EH_G ZInf* zi, cbptr in, uint64_t n, uint64_t off, bptr out, uint64_t* end) {
   if (EH_LANE == 0) {
     zi->in = in; zi->n = n; zi->pos = off; zi->hold = 0; zi->bits = 0; zi->out = out; zi->outn = 0;
     int st = zi_blocks(*zi);
@@ -603,7 +603,7 @@ EH_DEV int z_inflate_pass(ZInf* zi, const uint8_t* in, uint64_t n, uint64_t off,
 // (gzip: only a complete, so far well-formed member; zlib: also what a stream that just stops decodes to - inflate/2 returns it and
 // nobody calls inflateEnd), 0 when the call raises (data_error, need_dictionary).  Phase 2: z_uncompress_write into a buffer of *outn
 // bytes; checks the trailer (CRC-32 + ISIZE / Adler-32) and returns 0 when it is wrong.
-EH_DEV int z_uncompress_size(ZInf* zi, int fmt, const uint8_t* in, uint64_t n, uint64_t* outn, uint64_t* data_off) {
+EH_DEV int z_uncompress_size(EH_G ZInf* zi, int fmt, cbptr in, uint64_t n, uint64_t* outn, uint64_t* data_off) {
   *data_off = 0; *outn = 0;
   if (fmt == ZF_GZIP) {                                                                  // every member in turn (inflateReset): count
     uint64_t pos = 0, total = 0;
@@ -643,7 +643,7 @@ EH_DEV int z_uncompress_size(ZInf* zi, int fmt, const uint8_t* in, uint64_t n, u
   if (st == ZS_ERROR) return 0;
   return 1;                                                                              // ZS_TRUNC: inflate/2 returns what it decoded, nobody calls inflateEnd
 }
-EH_DEV int z_uncompress_write(ZInf* zi, int fmt, const uint8_t* in, uint64_t n, uint64_t data_off, uint8_t* out, uint64_t outn) {
+EH_DEV int z_uncompress_write(EH_G ZInf* zi, int fmt, cbptr in, uint64_t n, uint64_t data_off, bptr out, uint64_t outn) {
   uint64_t end;
   if (fmt == ZF_GZIP) {                                                                  // the members again, written one behind the other
     uint64_t pos = 0, total = 0;
@@ -656,7 +656,7 @@ EH_DEV int z_uncompress_write(ZInf* zi, int fmt, const uint8_t* in, uint64_t n, 
       const uint64_t mlen = uni64(zi->outn);
       if (st != ZS_END || end + 8 > n - pos || total + mlen > outn) return 0;            // CHECK / LENGTH states starve: inflateEnd -> data_error
       const uint32_t crc = wave_crc32(out + total, (uint32_t)mlen);
-      const uint8_t* t = in + pos + end;
+      cbptr t = in + pos + end;
       uint32_t c0 = 0, l0 = 0; for (int i = 0; i < 4; i++) { c0 |= (uint32_t)uni(t[i]) << (8 * i); l0 |= (uint32_t)uni(t[4 + i]) << (8 * i); }
       if (c0 != crc || l0 != (uint32_t)mlen) return 0;                                   // incorrect data check / incorrect length check
       total += mlen; pos += end + 8;
