@@ -24,8 +24,18 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DESC_BYTES = 24        # per-case descriptor: out_off, out_len, status/draws
 
 
-def cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref=None):
-    """oracle/ timed on the host: the first `--cpu-sample` cases of the same run (same corpus rows, options and work-area
+def parity_windows(args, n_rows, passes_run):
+    """Which cases the oracle leg runs: `--cpu-sample` S = rows 0..S/2 of THREE passes of the run - the first, one in the middle and
+    one near the end of the passes the timed loop ran (0, 7, 19 for the driver's 5 + 20) -, so that the engine build that was timed
+    is checked on case numbers from the whole run, not on its first pass only.  A run of fewer than three passes (or a corpus of
+    its own: --config 5) takes what there is.  -> [(first_case, row0, rows)]"""
+    per = max(1, min(args.cpu_sample // 2, n_rows))
+    want = [0, 7, 19] if passes_run >= 20 else sorted({0, passes_run // 3, max(0, passes_run - 1)})
+    return [(p * n_rows + 1, 0, per) for p in want]
+
+
+def cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref=None, windows=None):
+    """oracle/ timed on the host: the `--cpu-sample` cases of parity_windows() (same corpus rows, options and work-area
     limit as the GPU run), in chunks of 8, handed to `--cpu-threads` worker threads (the ctypes call releases the GIL).
     Every case runs under a wall-clock watchdog of `--cpu-case-seconds` — the reference's own maxrunningtime semantics
     (erlamsa_main.erl:197-204: the worker is killed and the case yields <<>>; its CLI default is 30 s): the time of such a
@@ -41,9 +51,17 @@ def cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref=None):
     import pyoracle as po
     po.lib()
     n = mat.shape[0]
-    limit = min(args.cpu_sample, n)
-    threads = max(1, args.cpu_threads or min(os.cpu_count() or 1, 64))
+    if windows is None:
+        windows = [(1, 0, min(args.cpu_sample, n))]
+    # work items: (index into the flat sample, first case number, first row, rows)
+    items, flat = [], 0
     CH = 8
+    for first_case, row0, rows in windows:
+        for a in range(0, rows, CH):
+            b = min(a + CH, rows)
+            items.append((flat + a, first_case + a, row0 + a, b - a))
+        flat += rows
+    threads = max(1, args.cpu_threads or min(os.cpu_count() or 1, 64))
     whole = synth.as_arena(mat) if args.generators else None      # the Paths of file / jump: the whole corpus, whatever chunk a call runs
     lock = threading.Lock()
     state = {"next": 0, "cases": 0, "bytes": 0, "timeouts": 0, "checked": 0, "skipped": 0, "bad": []}
@@ -52,13 +70,14 @@ def cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref=None):
     def worker():
         while True:
             with lock:
-                a = state["next"]
-                if a >= limit:
+                k = state["next"]
+                if k >= len(items):
                     return
-                state["next"] = a + CH
-            b = min(a + CH, limit)
-            d, o = synth.as_arena(mat[a:b])
-            outs, st, dr, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, generators=args.generators, paths=whole, first_case=a + 1,
+                state["next"] = k + 1
+            a, case0, r0, cnt = items[k]
+            b = a + cnt
+            d, o = synth.as_arena(mat[r0:r0 + cnt])
+            outs, st, dr, _ = po.fuzz_batch(d, o, seed=seed, mutations=muts, patterns=pats, generators=args.generators, paths=whole, first_case=case0,
                                            max_case_bytes=args.big_mib << 20, max_case_work=args.work_mib << 20,
                                            max_case_seconds=args.cpu_case_seconds)
             with lock:
@@ -73,7 +92,7 @@ def cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref=None):
                             state["skipped"] += 1
                         elif int(st[j]) != int(gst[i]) or len(outs[j]) != int(gln[i]) or (st[j] == 0 and int(dr[j]) != int(gdr[i])) \
                                 or hashlib.sha1(outs[j]).digest() != gsha[i]:
-                            state["bad"].append(i + 1)
+                            state["bad"].append(case0 + j)
                         else:
                             state["checked"] += 1
 
@@ -95,9 +114,9 @@ def cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref=None):
             "value": round(state["bytes"] / ct / 1e6, 3), "unit": "MB/s", "cores": threads, "kind": "port", "cpu_model": model,
             "host_cpus": os.cpu_count(),
             "cases_per_s": round(state["cases"] / ct, 2), "cases_cut_by_watchdog": state["timeouts"],
-            "sample": "cases 1..%d of the same run (same corpus rows, seed, mutators, patterns, work-area limit), oracle/ C++ restatement, "
+            "sample": "%d cases of the same run - %s - (same corpus rows, seed, mutators, patterns, work-area limit), oracle/ C++ restatement, "
                       "%d threads, %.1f s wall; per-case watchdog %.0f s (maxrunningtime semantics: time counted, output <<>>)"
-                      % (state["cases"], threads, ct, args.cpu_case_seconds)}
+                      % (state["cases"], ", ".join("%d..%d" % (f, f + r - 1) for f, _, r in windows), threads, ct, args.cpu_case_seconds)}
 
 
 def kernel_source_sha1():
@@ -158,6 +177,8 @@ def main():
                     "strong: a step is ONE run of --cases cases split over the ranks by shard.case_range (erlamsa_main.erl:95-108)")
     ap.add_argument("--extras-seconds", type=int, default=240, help="watchdog of the legs that run after the headline result exists (CPU oracle leg, "
                     "work-budget leg, PCIe leg): the JSON line is printed without a leg that has not come back by then")
+    ap.add_argument("--engine-flags", type=int, default=0, help="eh_options.flags of every context (diagnostic: 64 = EH_FLAG_NO_COOP, every case does all "
+                    "of its work on its own wavefront)")
     ap.add_argument("--inflight", type=int, default=6, help="passes in flight (engine contexts / HIP streams): the tail of a pass — a few "
                     "long single-wavefront cases — overlaps with the bulk of the next ones.  Every context owns its output arena (--out-gib) and its slots "
                     "(--max-slots x --case-mib); larger work areas come from one pool shared by all contexts (--pool-gib)")
@@ -281,7 +302,7 @@ def main():
         e = ea.Engine(local if on_gpu else 0)
         e.configure(mutations=muts, patterns=pats, generators=args.generators, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
                     max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20, big_case_bytes=args.big_mib << 20,
-                    pool_bytes=args.pool_gib << 30)
+                    pool_bytes=args.pool_gib << 30, flags=args.engine_flags)
         engines.append(e)
 
     def sync():
@@ -506,9 +527,10 @@ def main():
                 "seed": list(seed), "cases_per_step_per_gpu": n, "parallelism": "case-range sharding x%d, no collective on the mutation path" % world, "passes_in_flight": nctx, "context_setup": "eh_reserve + one untimed full-size pass per context/stream, one after the other, before the W warm-up steps",
                 "max_case_bytes": args.case_mib << 20, "big_case_bytes": args.big_mib << 20, "max_case_work": args.work_mib << 20,
                 "workgroups_per_pass": args.max_slots or "one per wavefront the device holds (8 per CU)", "pool_gib": args.pool_gib,
-                "max_slots": args.max_slots, "kernel_source_sha1": ksha,
+                "max_slots": args.max_slots, "engine_flags": args.engine_flags, "kernel_source_sha1": ksha,
                 "host": "no torch in this process (corpus: eh_corpus_upload, streams: eh_stream, pinned memory: eh_host_alloc)" if world == 1 else "torch = the RCCL binding (arena broadcast, barrier, reduction)",
                 "work_area_pool": engines[0].pool_stats(),
+                "cooperative_execution": engines[0].coop_stats(),
             },
             "case_status": dict(zip(["ok", "crashed(reference worker dies)", "overflow(big_case_bytes)", "unsupported", "arena_full",
                                      "budget(max_case_work; reference analogue: maxrunningtime -> <<>>)"],
@@ -610,7 +632,7 @@ def main():
             for e in engines:
                 e.configure(mutations=muts, patterns=pats, generators=args.generators, max_slots=args.max_slots, out_capacity=args.out_gib << 30,
                             max_case_bytes=args.case_mib << 20, max_case_work=args.budget_mib << 20, big_case_bytes=args.big_mib << 20,
-                            pool_bytes=args.pool_gib << 30)
+                            pool_bytes=args.pool_gib << 30, flags=args.engine_flags)
             bsteps = min(2 * nctx, args.steps)
             sync()
             tb = time.perf_counter()
@@ -655,24 +677,30 @@ def main():
                 mat = np.concatenate([synth.counter(range(r0, min(r0 + 1024, reduced)), size) for r0 in range(0, reduced, 1024)])
                 ep = ea.Engine(local if on_gpu else 0)
                 ep.configure(mutations=muts, patterns=pats, generators=args.generators, max_slots=args.max_slots, out_capacity=2 << 30,
-                             max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20, big_case_bytes=args.big_mib << 20, pool_bytes=args.pool_gib << 30)
+                             max_case_bytes=args.case_mib << 20, max_case_work=args.work_mib << 20, big_case_bytes=args.big_mib << 20, pool_bytes=args.pool_gib << 30, flags=args.engine_flags)
                 ep.upload_corpus(*synth.as_arena(mat))
             if args.cpu_sample > 0 and mat is not None:
                 state["leg"] = "cpu_baseline"
-                log("parity sample: cases 1..%d once more on context 0, alone on the device" % min(args.cpu_sample, mat.shape[0]))
                 import hashlib
-                e0, m = (engines[0] if reduced is None else ep), min(args.cpu_sample, mat.shape[0])
-                e0.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=m, stream=raw[0] if reduced is None else 0)
-                e0.sync()
-                st0, ln0, dr0 = e0.status()[:m].copy(), e0.lens()[:m].copy(), e0.diag()[0][:m].copy()
-                gpu_ref = (st0, ln0, dr0, [hashlib.sha1(e0.fetch(i, int(ln0[i]))).digest() for i in range(m)])
+                e0 = engines[0] if reduced is None else ep
+                wins = parity_windows(args, mat.shape[0], (args.warmup + args.steps) if reduced is None else 1)
+                log("parity sample: cases %s once more on context 0, alone on the device" % ", ".join("%d..%d" % (f, f + r - 1) for f, _, r in wins))
+                st0, ln0, dr0, sha0 = [], [], [], []
+                for first_case, row0, rows in wins:
+                    e0.fuzz_batch(seed=seed, first_case=first_case, corpus_first=row0, n=rows, stream=raw[0] if reduced is None else 0)
+                    e0.sync()
+                    lw = e0.lens()[:rows].copy()
+                    st0.append(e0.status()[:rows].copy()); ln0.append(lw); dr0.append(e0.diag()[0][:rows].copy())
+                    sha0 += [hashlib.sha1(e0.fetch(i, int(lw[i]))).digest() for i in range(rows)]
+                gpu_ref = (np.concatenate(st0), np.concatenate(ln0), np.concatenate(dr0), sha0)
                 log("CPU oracle leg + parity check")
-                cb = cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref)
+                cb = cpu_baseline_leg(mat, seed, muts, pats, args, gpu_ref, wins)
                 res["parity_checked"] = cb.pop("parity_checked")
                 res["parity"] = {"checked_bit_exact": res["parity_checked"], "not_compared": cb.pop("parity_skipped"),
                                  "corpus": "the run's own arena" if reduced is None else "rows 0..%d of the arena as a corpus of their own (same kernel, options, seed size and generators; the oracle needs the Paths on the host)" % (reduced - 1),
-                                 "what": "cases 1..%d of this run (the case numbers of the set-up passes, run once more on context 0 after the timed steps): status, length, PRNG draw count and SHA-1 of every "
-                                         "output vs the oracle's; not compared = engine-only status (2, 3) or cut by the oracle leg's watchdog" % min(args.cpu_sample, n)}
+                                 "cases": [[f, f + r - 1] for f, _, r in wins],
+                                 "what": "case numbers from three passes of this run (the first, one in the middle, one near the end of the timed steps), run once more on context 0 after the timed steps: status, length, "
+                                         "PRNG draw count and SHA-1 of every output vs the oracle's; not compared = engine-only status (2, 3) or cut by the oracle leg's watchdog"}
                 res["cpu_baseline"] = cb
             if args.pcie and args.steps > 0:
                 state["leg"] = "pcie"

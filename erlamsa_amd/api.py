@@ -8,8 +8,11 @@ Option keys are the reference's Dict keys (erlamsa_main.erl:127-163):
   n           number of cases                    (default 1)
   input       bytes                              (paths = [direct])
   blockscale  float
-  skip        first cases are computed but dropped (erlamsa_main.erl:191-196)
-Only `paths => [direct]`, `output => return` is served by the GPU path.
+  skip        cases numbered <= skip are computed but dropped (erlamsa_main.erl:161,191-196)
+Only `paths => [direct]`, `output => return` is served by the GPU path.  Keys the reference honours and a batch
+on the GPU cannot - external_mutations (custom mutator funs appended to the table, erlamsa_main.erl:128), external_post (a
+post-processor applied per written block, :159), sequence_muta (:223-235) - raise Unsupported: the caller routes that run to
+the BEAM path instead of getting a run WITHOUT what it asked for (erlang/src/erlamsa_hip.erl host_only/1 is the same rule).
 """
 import os
 
@@ -69,9 +72,27 @@ def _configure(eng, opts):
                   max_slots=int(opts.get("max_slots", 0)), max_case_work=int(opts.get("max_case_work", 0)))
 
 
+class Unsupported(ValueError):
+    """The option map carries keys only erlamsa_main:fuzzer/1 on BEAM can honour: `.keys` (the shim's {error, {unsupported, Keys}})."""
+
+    def __init__(self, keys):
+        super().__init__("not served by the GPU path, route this run to erlamsa_main:fuzzer/1: %s" % ", ".join(keys))
+        self.keys = keys
+
+
+def host_only(opts):
+    """keys of the Dict that are set and need the BEAM (erlamsa_hip:host_only/1)"""
+    keys = [k for k in ("external_mutations", "external_post") if opts.get(k) is not None]
+    if opts.get("sequence_muta"):
+        keys.append("sequence_muta")
+    return keys
+
+
 def fuzz_batch(inputs, opts=None, return_status=False, device=0):
     """Case I (1-based) of ONE fuzzer/1 run mutates inputs[I-1].  -> list[bytes] (and statuses)."""
     opts = dict(opts or {})
+    if host_only(opts):
+        raise Unsupported(host_only(opts))
     eng = _engine(device)
     _configure(eng, opts)
     data, off = pack_corpus(list(inputs))
@@ -98,12 +119,14 @@ def fuzzer(opts):
     opts = dict(opts)
     if opts.get("paths", ["direct"]) != ["direct"] or opts.get("output", "return") != "return":
         raise ValueError("only paths=[direct], output=return is served by the GPU path")
+    if host_only(opts):
+        raise Unsupported(host_only(opts))
     n = int(opts.get("n", 1))
-    skip = int(opts.get("skip", 0))
+    skip, first = int(opts.get("skip", 0)), int(opts.get("first_case", 1))
     outs, status = fuzz_batch([bytes(opts.get("input", b""))] * n, opts, return_status=True, device=int(opts.get("device", 0)))
     res, limited = [], []
     for i, (o, s) in enumerate(zip(outs, status)):
-        if i < skip:
+        if first + i <= skip:                                   # `I =< Skip` (erlamsa_main.erl:191): written to the skip port, which keeps nothing
             continue
         if s == CASE_OK and len(o) > 0:
             res.append(o)

@@ -126,6 +126,29 @@ struct DevConfig {
   char ssrf_port[12];
 };
 
+// ---- cooperative execution of a heavy case's bulk loops (eh_device.h co_run / co_help) -------------------
+// A case runs on ONE wavefront.  Loops over hundreds of kilobytes - block copies, the final concatenation, the streaming
+// passes of eh_fuse2.h - are cut into chunks and posted on a board all contexts of the device share; wavefronts that are
+// BETWEEN cases take chunks before they draw their next ticket, the poster takes chunks too and waits for the rest.
+// word[j] = generation << 32 | chunks handed out (odd generation: open); a chunk is claimed by ONE atomic add, so its number and
+// the job it belongs to are read together.
+constexpr uint32_t CO_JOBS = 64, CO_ARGS = 12;
+enum CoKind : uint32_t { CO_COPY = 1, CO_EQUAL = 2, CO_FBPASS = 3, CO_FBCOUNT = 4 };
+struct CoJob {
+  uint64_t a[CO_ARGS];          // arguments of the loop (kind-specific)
+  unsigned long long acc;       // what the chunks add up to (members alive, mismatches found ...)
+  uint32_t kind, nchunks, done, pad;
+};
+struct CoBoard {
+  unsigned long long word[CO_JOBS];
+  uint32_t owner[CO_JOBS];      // 1: a poster holds the entry
+  uint32_t open;                // entries with chunks to hand out
+  uint32_t lingerers;           // wavefronts without a ticket that stay for chunks
+  uint32_t pad[14];
+  unsigned long long stat[8];   // [0] jobs posted, [1] chunks run by helpers, [2] by the posters themselves, [3] cycles posters waited, [4] jobs that found no free entry
+  CoJob job[CO_JOBS];
+};
+
 struct KParams {
   cbptr corpus;
   cqptr coff;
@@ -172,6 +195,9 @@ struct KParams {
   uint32_t pool_cnt[POOL_TIERS + 1];
   wptr pool_ring[POOL_TIERS + 1];
   EH_G unsigned long long* pool_ctr;
+  EH_G CoBoard* board;          // nullptr: every case does all its work itself (EH_FLAG_NO_COOP)
+  uint32_t co_copy_min, co_copy_chunk;   // bytes: copies / compares of co_copy_min and more are posted in chunks of co_copy_chunk
+  uint32_t co_fb_min, co_fb_chunk;       // positions: the same for the streaming passes of eh_fuse2.h (chunk: a multiple of 1024)
 };
 
 struct MutaInfo { const char* name; int pri; int on_gpu; };

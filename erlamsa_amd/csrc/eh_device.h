@@ -192,7 +192,18 @@ EH_DEV uint32_t ldg4(const EH_G void* p) { return *reinterpret_cast<const EH_G e
 // ---------------------------------------------------------------------------------------------
 // wave-parallel byte movers (HBM to HBM: corpus arena, slot and pool work memory, output arena)
 // ---------------------------------------------------------------------------------------------
-EH_DEV void wave_copy(bptr dst, cbptr src, uint32_t n) {
+// Copies of CO_COPY_MIN bytes and more inside a case are posted for several wavefronts (co_copy below); the _raw forms are the
+// loops themselves (one wavefront), for the kernels that are not cases and for the chunks of a posted copy.
+// CO_COPY_MIN: what the inlined test at every call site compares with; the size from which a copy IS posted and its chunks are run-time
+// parameters (KParams co_copy_min >= CO_COPY_MIN, co_copy_chunk; eh_engine.hip co_defaults).
+#ifdef HIPEMU
+constexpr uint32_t CO_COPY_MIN = 8u << 10;         // (the emulator's tests are small: they take the posted path too, one wavefront running every chunk)
+#else
+constexpr uint32_t CO_COPY_MIN = 256u << 10;
+#endif
+__device__ void co_copy(bptr dst, cbptr src, uint32_t n);
+__device__ bool co_equal(cbptr a, cbptr b, uint32_t n);
+EH_DEV void wave_copy_raw(bptr dst, cbptr src, uint32_t n) {
   const int l = EH_LANE;
   // head: bring dst to 16-byte alignment
   uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
@@ -216,6 +227,10 @@ EH_DEV void wave_copy(bptr dst, cbptr src, uint32_t n) {
   }
   uint32_t done = nv << 4;
   if (done + l < n) dst[done + l] = src[done + l];
+}
+EH_DEV void wave_copy(bptr dst, cbptr src, uint32_t n) {
+  if (__builtin_expect(n >= CO_COPY_MIN, 0)) { co_copy(dst, src, n); return; }
+  wave_copy_raw(dst, src, n);
 }
 // memmove towards lower addresses (dst < src, ranges may overlap): every iteration is executed by
 // the whole wave — all loads of a 4 KiB stripe are issued before its stores — so no lane can read
@@ -254,7 +269,7 @@ EH_DEV void wave_fill_periodic(bptr dst, cbptr pat, uint32_t plen, uint64_t tota
   }
 }
 // returns true if the two byte ranges are equal
-EH_DEV bool wave_equal(cbptr a, cbptr b, uint32_t n) {
+EH_DEV bool wave_equal_raw(cbptr a, cbptr b, uint32_t n) {
   const int l = EH_LANE;
   uint32_t nv = n >> 4;
   // uniform trip count (the early exit must be taken by the whole wave)
@@ -272,6 +287,10 @@ EH_DEV bool wave_equal(cbptr a, cbptr b, uint32_t n) {
   bool ne = false;
   if (done + l < n) ne = a[done + l] != b[done + l];
   return __ballot(ne) == 0;
+}
+EH_DEV bool wave_equal(cbptr a, cbptr b, uint32_t n) {
+  if (__builtin_expect(n >= CO_COPY_MIN, 0)) return co_equal(a, b, n);
+  return wave_equal_raw(a, b, n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -457,6 +476,141 @@ EH_DEV void pool_push(const EH_G KParams& p, int t, uint32_t v) {
     wptr e = p.pool_ring[t] + (h % p.pool_cnt[t]);
     while (atomicCAS(e, 0xFFFFFFFFu, v) != 0xFFFFFFFFu) pool_nap();
   }
+}
+
+// ---- cooperative execution (eh_common.h CoBoard) -----------------------------------------------------------------------------
+// co_exec runs chunk t of a posted job with the whole wavefront (eh_engine.hip: it knows every kind of loop).
+struct CoArgs { uint64_t a[CO_ARGS]; };
+__device__ void co_exec(const EH_G CoJob* j, uint32_t t);
+EH_DEV void co_nap() {
+#ifndef HIPEMU
+  __builtin_amdgcn_s_sleep(16);
+#else
+  fprintf(stderr, "hipemu: a wait for a helper's chunk can never end with one wavefront running (block %u)\n", blockIdx.x); abort();
+#endif
+}
+// Agent-scope release / acquire around what changes hands between wavefronts on different compute units and XCDs (the per-XCD L2s
+// are not coherent with each other, a CU's vector L1 is never refreshed by other CUs' stores).  Release: this XCD's dirty L2 lines are
+// written back - and the wait is spelled out: the compiler drops the s_waitcnt vmcnt(0) behind buffer_wbl2 when it believes no
+// memory operation is in flight, and the flag would overtake the data.  Acquire: this CU's L1 is invalidated.  Microseconds each:
+// once per posted loop / per chunk, and chunks are hundreds of kilobytes.
+EH_DEV void co_release() {
+#ifndef HIPEMU
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+EH_DEV void co_acquire() {
+#ifndef HIPEMU
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+EH_DEV uint32_t co_ld32(const EH_G uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+EH_DEV unsigned long long co_ld64(const EH_G unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+// Posts a loop of `nchunks` chunks, takes chunks itself, waits for the ones others took.  false: no board, or no free entry - the
+// caller runs the loop itself.  *acc: what the chunks added up.  Everything the case has written is visible to the helpers (fence
+// before the entry opens), everything they wrote is visible to the case when this returns (fence after the last chunk).
+__device__ __noinline__ bool co_run(uint32_t kind, uint32_t nchunks, CoArgs args, unsigned long long* acc) {
+  Ctx& c = g_ctx;
+  EH_G CoBoard* bd = c.p ? c.p->board : nullptr;
+  const int l = EH_LANE;
+  if (!bd || nchunks < 2) return false;
+  uint32_t slot = CO_JOBS;
+  if (l == 0) {
+    const uint32_t h = (blockIdx.x * 2654435761u) >> 26;
+    for (uint32_t k = 0; k < 4 && slot == CO_JOBS; k++) { const uint32_t s = (h + 17u * k) & (CO_JOBS - 1); if (atomicCAS(&bd->owner[s], 0u, 1u) == 0u) slot = s; }
+    if (slot == CO_JOBS) atomicAdd(&bd->stat[4], 1ull);
+  }
+  slot = uni(slot);
+  if (slot == CO_JOBS) return false;
+  EH_G CoJob* j = &bd->job[slot];
+  unsigned long long gen = 0;
+  if (l == 0) {
+#pragma unroll
+    for (uint32_t k = 0; k < CO_ARGS; k++) j->a[k] = args.a[k];
+    j->kind = kind; j->nchunks = nchunks; j->done = 0; j->acc = 0;
+  }
+  wave_sync();                                                             // every lane's stores of the case so far are issued ...
+  co_release();                                                            // ... and written back: the helpers read the loop's inputs from memory
+  if (l == 0) {
+    gen = ((co_ld64(&bd->word[slot]) >> 32) + 1ull) | 1ull;                 // (closed words carry even generations)
+    atomicExch(&bd->word[slot], gen << 32);
+    atomicAdd(&bd->open, 1u);
+    atomicAdd(&bd->stat[0], 1ull);
+  }
+  uint32_t mine = 0;
+  for (;;) {
+    unsigned long long old = 0;
+    if (l == 0) old = atomicAdd(&bd->word[slot], 1ull);
+    const uint32_t t = uni((uint32_t)old);
+    if (t >= nchunks) break;
+    co_exec(j, t);
+    mine++;
+  }
+  wave_sync();
+  unsigned long long sum = 0;
+  if (l == 0) {
+    atomicAdd(&j->done, mine);
+    const uint64_t w0 = __builtin_readcyclecounter();
+    while (co_ld32(&j->done) < nchunks) co_nap();
+    atomicAdd(&bd->open, 0xFFFFFFFFu);                                       // (- 1)
+    atomicExch(&bd->word[slot], (gen + 1ull) << 32);                        // closed: a chunk number drawn from here on belongs to no job
+    sum = co_ld64(&j->acc);
+    atomicAdd(&bd->stat[2], (unsigned long long)mine);
+    atomicAdd(&bd->stat[3], (unsigned long long)(__builtin_readcyclecounter() - w0));
+  }
+  sum = uni64(sum);
+  co_acquire();                                                            // what the helpers wrote (they released it) is read from memory, not from this CU's L1
+  if (l == 0) atomicExch(&bd->owner[slot], 0u);
+  if (acc) *acc = sum;
+  return true;
+}
+// A wavefront between two cases: up to `most` chunks of whatever is posted (a bound, so that the wavefront's own pass - the
+// kernel the host waits for - is never kept alive by the loops of other passes).
+__device__ __noinline__ void co_help(EH_G CoBoard* bd, uint32_t most) {
+  const int l = EH_LANE;
+  uint32_t ran = 0;
+  for (uint32_t guard = 0; guard < 64 && ran < most; guard++) {
+    if (uni(co_ld32(&bd->open)) == 0) return;
+    const unsigned long long w = co_ld64(&bd->word[l]);
+    const bool cand = ((w >> 32) & 1ull) && (uint32_t)w < co_ld32(&bd->job[l].nchunks);
+    unsigned long long m = __ballot(cand);
+    if (!m) return;
+    const uint32_t rot = blockIdx.x & 63u;                                   // (helpers start at different entries)
+    const unsigned long long mr = rot ? ((m >> rot) | (m << (64u - rot))) : m;
+    const uint32_t s = ((uint32_t)__builtin_ctzll(mr) + rot) & 63u;
+    unsigned long long old = 0;
+    if (l == 0) old = atomicAdd(&bd->word[s], 1ull);
+    old = uni64(old);
+    if (!((old >> 32) & 1ull)) continue;                                     // closed in the meantime
+    co_acquire();                                                            // the job's arguments and what its case wrote
+    const EH_G CoJob* j = &bd->job[s];
+    const uint32_t nchunks = uni(co_ld32(&j->nchunks)), t = (uint32_t)old;
+    if (uni64(co_ld64(&bd->word[s])) >> 32 != old >> 32 || t >= nchunks) continue;   // (nchunks read under the generation the chunk was drawn from)
+    co_exec(j, t);
+    ran++;
+    wave_sync();
+    co_release();
+    if (l == 0) { atomicAdd(&bd->job[s].done, 1u); atomicAdd(&bd->stat[1], 1ull); }
+  }
+}
+__device__ __noinline__ void co_copy(bptr dst, cbptr src, uint32_t n) {
+  const EH_G KParams* kp = g_ctx.p;
+  if (!kp || !kp->board || n < kp->co_copy_min) { wave_copy_raw(dst, src, n); return; }
+  const uint32_t ch = kp->co_copy_chunk;
+  CoArgs a; for (uint32_t k = 0; k < CO_ARGS; k++) a.a[k] = 0;
+  a.a[0] = (uint64_t)dst; a.a[1] = (uint64_t)src; a.a[2] = n; a.a[3] = ch;
+  if (!co_run(CO_COPY, (n + ch - 1) / ch, a, nullptr)) wave_copy_raw(dst, src, n);
+}
+__device__ __noinline__ bool co_equal(cbptr x, cbptr y, uint32_t n) {
+  const EH_G KParams* kp = g_ctx.p;
+  if (!kp || !kp->board || n < 2 * kp->co_copy_min) return wave_equal_raw(x, y, n);
+  const uint32_t ch = kp->co_copy_chunk;
+  CoArgs a; for (uint32_t k = 0; k < CO_ARGS; k++) a.a[k] = 0;
+  a.a[0] = (uint64_t)x; a.a[1] = (uint64_t)y; a.a[2] = n; a.a[3] = ch;
+  unsigned long long ne = 0;
+  if (!co_run(CO_EQUAL, (n + ch - 1) / ch, a, &ne)) return wave_equal_raw(x, y, n);
+  return ne == 0;
 }
 
 // Lex caches (eh_lex.h), one per nesting level of the scheduler: a mutator that walks its block's chunk table may call the

@@ -825,6 +825,23 @@ EH_DEV void gen_random(Ctx& c) {                                       // random
 }
 
 // =============================================================================================
+// cooperative execution: chunk t of a posted loop (eh_device.h co_run / co_help)
+// =============================================================================================
+__device__ __noinline__ void co_exec(const EH_G CoJob* j, uint32_t t) {
+  const uint32_t kind = uni(co_ld32(&j->kind));
+  const uint64_t a0 = uni64(j->a[0]), a1 = uni64(j->a[1]), a2 = uni64(j->a[2]);
+  if (kind == CO_COPY || kind == CO_EQUAL) {
+    const uint32_t ch = uni((uint32_t)j->a[3]);
+    const uint64_t off = (uint64_t)t * ch;
+    const uint32_t len = a2 - off < ch ? (uint32_t)(a2 - off) : ch;
+    if (kind == CO_COPY) wave_copy_raw((bptr)a0 + off, (cbptr)a1 + off, len);
+    else if (!wave_equal_raw((cbptr)a0 + off, (cbptr)a1 + off, len)) { if (EH_LANE == 0) atomicAdd((EH_G unsigned long long*)&j->acc, 1ull); }
+    return;
+  }
+  if (kind == CO_FBPASS) { fb_pass_chunk(j, t); return; }
+}
+
+// =============================================================================================
 // the mutate kernel
 // =============================================================================================
 // 2 wavefronts per SIMD = up to 256 VGPRs: at 4 (128 VGPRs) the scheduler loops and the candidate loop of base64_mutator
@@ -878,6 +895,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
       if (l == 0) t = atomicAdd(p.ticket, (unsigned long long)TICKET_BATCH);
       tk_next = uni64(t); tk_end = tk_next + TICKET_BATCH;
     }
+    if (p.board && uni(co_ld32(&p.board->open)) != 0) co_help(p.board, 2);   // chunks of heavy cases' loops, between two cases of my own
     uint64_t i = tk_next++;
     if (i >= p.n) break;
     uint64_t tick0 = __builtin_readcyclecounter();
@@ -1009,18 +1027,19 @@ __global__ void __launch_bounds__(64) eh_order_gather_kernel(const uint8_t* src_
   for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
     uint64_t len = uni64(out_len[i]), so = uni64(out_off[i]), d0 = uni64(ord_off[i]) - ord_base;
     uint64_t done = 0;
-    while (done < len) { uint32_t c = len - done > 0x40000000ull ? 0x40000000u : (uint32_t)(len - done); wave_copy(dst + d0 + done, src + so + done, c); done += c; }
+    while (done < len) { uint32_t c = len - done > 0x40000000ull ? 0x40000000u : (uint32_t)(len - done); wave_copy_raw(dst + d0 + done, src + so + done, c); done += c; }
   }
 }
 
 __global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf_, const uint32_t* jobs_, uint32_t njobs, uint32_t* eq_out_) {
   bptr buf = (bptr)buf_; cwptr jobs = (cwptr)jobs_; wptr eq_out = (wptr)eq_out_;
+  g_ctx.p = nullptr;                                             // (not a case: nothing is posted for other wavefronts, co_run)
   // job = {kind, dst_off, src_off, n, plen}: kind 0 copy, 1 periodic fill, 2 equal
   for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
     uint32_t kind = jobs[5 * j], d = jobs[5 * j + 1], s = jobs[5 * j + 2], n = jobs[5 * j + 3], pl = jobs[5 * j + 4];
-    if (kind == 0) wave_copy(buf + d, buf + s, n);
+    if (kind == 0) wave_copy_raw(buf + d, buf + s, n);
     else if (kind == 1) wave_fill_periodic(buf + d, buf + s, pl, n);
-    else if (kind == 2) { bool e = wave_equal(buf + d, buf + s, n); if (EH_LANE == 0) eq_out[j] = e ? 1u : 0u; }
+    else if (kind == 2) { bool e = wave_equal_raw(buf + d, buf + s, n); if (EH_LANE == 0) eq_out[j] = e ? 1u : 0u; }
     else {  // kind 3: mask window self check over buf[s, s+n) with window base d (multiple of 64)
       MaskWin<4> a, b; a.p = buf + s; a.L = n; b.p = buf + s; b.L = n;
       mw_load(a, d, LexCls()); mw_load_ref(b, d, LexCls());
@@ -1041,6 +1060,7 @@ __global__ void __launch_bounds__(64) eh_test_copy_kernel(uint8_t* buf_, const u
 // (z_uncompress_size + z_uncompress_write); res[0] = bytes written, res[1] = 1 ok / 0 "raises".
 __global__ void __launch_bounds__(64) eh_test_zlib_kernel(int op, const uint8_t* in_, uint64_t n, uint8_t* out_, uint64_t cap, uint8_t* scratch_, uint64_t* res_) {
   cbptr in = (cbptr)in_; bptr out = (bptr)out_, scratch = (bptr)scratch_; qptr res = (qptr)res_;
+  g_ctx.p = nullptr;
   uint64_t len = 0; int ok = 1;
   if (op <= 2) { len = z_compress((EH_G ZDef*)scratch, op, in, n, out, cap); ok = len != 0; }
   else {
@@ -1081,6 +1101,7 @@ struct DevPool {
   int ntiers = 0;                                       // tiers 1..ntiers
   uint8_t* base[POOL_TIERS + 1] = {}; uint64_t stride[POOL_TIERS + 1] = {}, cap[POOL_TIERS + 1] = {}; uint32_t cnt[POOL_TIERS + 1] = {};
   uint32_t* d_rings = nullptr; uint32_t* ring[POOL_TIERS + 1] = {}; unsigned long long* d_ctr = nullptr;
+  CoBoard* d_board = nullptr;                           // cooperative execution: the board every context of the device posts on (eh_common.h)
 };
 
 struct eh_ctx {
@@ -1220,6 +1241,7 @@ static void pool_free(DevPool* pl) {
   for (int t = 1; t <= pl->ntiers; t++) if (pl->base[t]) (void)hipFree(pl->base[t]);
   if (pl->d_rings) (void)hipFree(pl->d_rings);
   if (pl->d_ctr) (void)hipFree(pl->d_ctr);
+  if (pl->d_board) (void)hipFree(pl->d_board);
   delete pl;
 }
 static void pool_release(eh_ctx* ctx) {
@@ -1285,8 +1307,23 @@ static int pool_acquire(eh_ctx* ctx, uint64_t work_cap, uint64_t big, uint64_t p
   }
   if (hipMemcpy(pl->d_rings, init.data(), nring * 4, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(pl->d_ctr, ctr.data(), 64 * 8, hipMemcpyHostToDevice) != hipSuccess) { pool_free(pl); ctx->err = "work-area pool: hipMemcpy failed"; return EH_E_HIP; }
+  if (hipMalloc(&pl->d_board, sizeof(CoBoard)) != hipSuccess || hipMemset(pl->d_board, 0, sizeof(CoBoard)) != hipSuccess) { pool_free(pl); ctx->err = "work-area pool: no memory for the cooperation board"; return EH_E_NOMEM; }
   pl->refs = 1; g_pools.push_back(pl); ctx->pool = pl;
   return EH_OK;
+}
+
+// From which size a loop of a case is posted for other wavefronts, and in what chunks (KParams co_*).  A chunk costs its runner an
+// agent-scope acquire and a release (microseconds, and the release writes back whatever is dirty in its XCD's L2), so chunks are
+// hundreds of kilobytes; measurement knobs: EH_CO_COPY_MIN / EH_CO_COPY_CHUNK (bytes), EH_CO_FB_MIN / EH_CO_FB_CHUNK (positions).
+static uint32_t co_env(const char* name, uint32_t dflt) { const char* v = getenv(name); if (!v || !*v) return dflt; unsigned long long x = strtoull(v, nullptr, 10); return x > 0 && x < (1ull << 31) ? (uint32_t)x : dflt; }
+static void co_defaults(KParams* p, int cus) {
+  const bool emu = cus < 64;                                                    // (the emulator's tests are small: they take the posted paths too)
+  p->co_copy_min = co_env("EH_CO_COPY_MIN", emu ? (8u << 10) : (2u << 20));
+  p->co_copy_chunk = co_env("EH_CO_COPY_CHUNK", emu ? (2u << 10) : (256u << 10));
+  p->co_fb_min = co_env("EH_CO_FB_MIN", emu ? (16u << 10) : (512u << 10));
+  p->co_fb_chunk = co_env("EH_CO_FB_CHUNK", emu ? (4u << 10) : (64u << 10)) & ~1023u;
+  if (p->co_copy_chunk < 1024) p->co_copy_chunk = 1024;
+  if (p->co_fb_chunk < 1024) p->co_fb_chunk = 1024;
 }
 
 // Device memory for batches of up to `n` cases over `in_bytes` input bytes: result arrays, the work-area pool, output
@@ -1346,6 +1383,8 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.ticket = dp(ctx->d_counters); p.in_bytes = dp(ctx->d_counters + 2); p.prof = dp(ctx->d_counters + 8);   // counters [8, 264) = prof
   p.slot_base = dp(ctx->d_slots); p.slot_stride = ctx->slot_stride;
   p.ntiers = pl->ntiers; p.pool_ctr = dp(pl->d_ctr); p.pool_cap[0] = pl->work_cap;
+  p.board = (ctx->flags & EH_FLAG_NO_COOP) ? dp((CoBoard*)nullptr) : dp(pl->d_board);
+  co_defaults(&p, ctx->cus);
   for (int t = 1; t <= pl->ntiers; t++) { p.pool_base[t] = dp(pl->base[t]); p.pool_stride[t] = pl->stride[t]; p.pool_cap[t] = pl->cap[t]; p.pool_cnt[t] = pl->cnt[t]; p.pool_ring[t] = dp(pl->ring[t]); }
   // persistent workgroups, each pulling cases from the ticket counter.  Batches in flight on several streams may
   // oversubscribe the device: the dispatcher starts a batch's workgroups as those of earlier ones leave.
@@ -1439,7 +1478,12 @@ uint64_t eh_last_error_copy(eh_ctx* ctx, char* buf, uint64_t cap) {
 // 21.7 instead of 33.7 GB/s, profiles/r04_bench_q4.json).  The variable is read when the HIP runtime initialises, i.e. at the first
 // HIP call of the process: set here, when the library is loaded, unless the host has chosen a value itself.  (A process that has
 // used HIP before it loads this library - a torch that came first - keeps what it started with: INTEGRATION.md section 3.)
-__attribute__((constructor)) static void eh_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+__attribute__((constructor)) static void eh_runtime_defaults() {
+  // Only when the variable is not set, and only here - at load time, before this library has made a HIP call.  A host that loads the
+  // library into a process with threads already running (a BEAM: setenv is not safe against a concurrent getenv) exports
+  // GPU_MAX_HW_QUEUES=8 itself before it starts; then nothing is written (note 0).
+  if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
 
 int eh_create(int device, eh_ctx** out) {
   if (!out) return EH_E_INVALID;
@@ -1618,6 +1662,9 @@ int eh_corpus_attach(eh_ctx* ctx, const void* d_data, const void* d_off, uint64_
     if (r_ != 0) { (ctx)->err = std::string(#call) + ": " + ((a)->GetErrorString ? (a)->GetErrorString(r_) : "RCCL error"); return EH_E_HIP; } \
   } while (0)
 
+// a device temporary of the collectives below: freed on every way out of the function
+struct DevTmp { void* p = nullptr; ~DevTmp() { if (p) (void)hipFree(p); } };
+
 // an owned corpus buffer for n entries / nbytes bytes (contents undefined); keeps the one it has when that is large enough
 static int corpus_own_buffers(eh_ctx* ctx, uint64_t n, uint64_t nbytes) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1689,15 +1736,18 @@ int eh_corpus_broadcast(eh_ctx* ctx, int root, const uint8_t* data, const uint64
   HIPCHK(ctx, hipSetDevice(ctx->device));
   void* stv = nullptr; int rc = eh_stream(ctx, &stv); if (rc) return rc;
   hipStream_t st = (hipStream_t)stv;
-  uint64_t* d_hdr = nullptr;
-  HIPCHK(ctx, hipMalloc(&d_hdr, 16));
+  DevTmp hdr_mem;
+  HIPCHK(ctx, hipMalloc(&hdr_mem.p, 16));
+  uint64_t* d_hdr = (uint64_t*)hdr_mem.p;
   uint64_t hdr[2] = {is_root ? n : 0, is_root ? off[n] : 0};
   if (is_root) HIPCHK(ctx, hipMemcpy(d_hdr, hdr, 16, hipMemcpyHostToDevice));
   NCCLCHK(ctx, a, a->Broadcast(d_hdr, d_hdr, 2, ehcomm::kUint64, root, ctx->comm, st));
   HIPCHK(ctx, hipStreamSynchronize(st));
   HIPCHK(ctx, hipMemcpy(hdr, d_hdr, 16, hipMemcpyDeviceToHost));
-  (void)hipFree(d_hdr);
   const uint64_t cn = hdr[0], nbytes = hdr[1];
+  // (A rank that fails locally between the header and the payload - out of memory here - leaves its peers in the next collective:
+  // there is no way to call them back.  The caller's answer to an error from this function is eh_comm_destroy on every rank,
+  // ncclCommAbort's effect on the peers, and a fresh communicator; include/erlamsa_hip.h says so.)
   rc = corpus_own_buffers(ctx, cn, nbytes); if (rc) return rc;
   if (is_root) {
     if (nbytes) HIPCHK(ctx, hipMemcpy(ctx->d_corpus, data, nbytes, hipMemcpyHostToDevice));
@@ -1727,15 +1777,15 @@ int eh_corpus_allgather(eh_ctx* ctx, const uint8_t* data, const uint64_t* off, u
   const int R = ctx->comm_n, me = ctx->comm_rank;
   const uint64_t B = off[n_local];
   // do all ranks bring the same shape?
-  uint64_t* d_sz = nullptr;
-  HIPCHK(ctx, hipMalloc(&d_sz, 16 * (size_t)R));
+  DevTmp sz_mem;
+  HIPCHK(ctx, hipMalloc(&sz_mem.p, 16 * (size_t)R));
+  uint64_t* d_sz = (uint64_t*)sz_mem.p;
   uint64_t mine[2] = {n_local, B};
   HIPCHK(ctx, hipMemcpy(d_sz + 2 * me, mine, 16, hipMemcpyHostToDevice));
   NCCLCHK(ctx, a, a->AllGather(d_sz + 2 * me, d_sz, 2, ehcomm::kUint64, ctx->comm, st));
   HIPCHK(ctx, hipStreamSynchronize(st));
   std::vector<uint64_t> sz(2 * (size_t)R);
   HIPCHK(ctx, hipMemcpy(sz.data(), d_sz, 16 * (size_t)R, hipMemcpyDeviceToHost));
-  (void)hipFree(d_sz);
   for (int r = 0; r < R; r++) if (sz[2 * r] != n_local || sz[2 * r + 1] != B) { ctx->err = "eh_corpus_allgather: shards differ in entries or bytes between ranks (use eh_corpus_broadcast)"; return EH_E_INVALID; }
   const uint64_t cn = n_local * (uint64_t)R, nbytes = B * (uint64_t)R;
   rc = corpus_own_buffers(ctx, cn, nbytes); if (rc) return rc;
@@ -1769,13 +1819,19 @@ int eh_corpus_broadcast_local(eh_ctx** ctxs, int nctx, int root) {
     sts[i] = (hipStream_t)stv;
   }
   NCCLCHK(r, a, a->GroupStart());
-  for (int i = 0; i < nctx; i++) {
+  // (whatever fails inside the group, the group is ENDED before the function returns: an open group swallows every later call)
+  int grc = EH_OK; eh_ctx* gbad = r; std::string gerr;
+  for (int i = 0; i < nctx && grc == EH_OK; i++) {
     eh_ctx* x = ctxs[i];
-    HIPCHK(x, hipSetDevice(x->device));
-    if (nbytes) NCCLCHK(x, a, a->Broadcast(x->d_corpus, x->d_corpus, nbytes, ehcomm::kUint8, root, x->comm, sts[i]));
-    NCCLCHK(x, a, a->Broadcast(x->d_coff, x->d_coff, cn + 1, ehcomm::kUint64, root, x->comm, sts[i]));
+    hipError_t he = hipSetDevice(x->device);
+    if (he != hipSuccess) { grc = EH_E_HIP; gbad = x; gerr = std::string("hipSetDevice: ") + hipGetErrorString(he); break; }
+    int nr = nbytes ? a->Broadcast(x->d_corpus, x->d_corpus, nbytes, ehcomm::kUint8, root, x->comm, sts[i]) : 0;
+    if (nr == 0) nr = a->Broadcast(x->d_coff, x->d_coff, cn + 1, ehcomm::kUint64, root, x->comm, sts[i]);
+    if (nr != 0) { grc = EH_E_HIP; gbad = x; gerr = std::string("ncclBroadcast: ") + (a->GetErrorString ? a->GetErrorString(nr) : "RCCL error"); }
   }
-  NCCLCHK(r, a, a->GroupEnd());
+  const int ge = a->GroupEnd();
+  if (grc != EH_OK) { gbad->err = gerr; if (gbad != ctxs[0]) ctxs[0]->err = gerr; return grc; }
+  if (ge != 0) { r->err = std::string("ncclGroupEnd: ") + (a->GetErrorString ? a->GetErrorString(ge) : "RCCL error"); return EH_E_HIP; }
   for (int i = 0; i < nctx; i++) {
     eh_ctx* x = ctxs[i];
     HIPCHK(x, hipSetDevice(x->device));
@@ -2156,11 +2212,11 @@ int eh_result_meta(eh_ctx* ctx, uint64_t i, uint8_t* buf, uint64_t cap, uint64_t
   uint64_t off = 0; uint32_t len = 0;
   HIPCHK(ctx, hipMemcpy(&off, ctx->d_toff + i, 8, hipMemcpyDeviceToHost));
   HIPCHK(ctx, hipMemcpy(&len, ctx->d_tlen + i, 4, hipMemcpyDeviceToHost));
-  *n_events = len;
-  if (len > cap || (!buf && len)) { ctx->err = "eh_result_meta: buffer too small"; return EH_E_INVALID; }
+  *n_events = len;                                                        // the trace's length whatever the buffer holds: (buf = NULL, cap = 0) asks for it
+  const uint64_t take = buf ? (len < cap ? len : cap) : 0;                // "copied up to cap" (include/erlamsa_hip.h)
   // (with EH_FLAG_ORDERED_OUTPUT the traces stay in the completion-ordered arena, which is d_out2 after the swap)
   const uint8_t* src = (ctx->ordered ? ctx->d_out2 : ctx->d_out) + off;
-  if (len) HIPCHK(ctx, hipMemcpy(buf, src, len, hipMemcpyDeviceToHost));
+  if (take) HIPCHK(ctx, hipMemcpy(buf, src, take, hipMemcpyDeviceToHost));
   return EH_OK;
 }
 int eh_result_peak(eh_ctx* ctx, uint64_t* peak) {
@@ -2249,6 +2305,15 @@ int eh_pool_stats(eh_ctx* ctx, uint64_t* out /* 64 values */) {
     out[51 + t] = t <= ctx->pool->ntiers ? ctx->pool->cap[t] : 0;
   }
   out[61] = (uint64_t)ctx->pool->refs; out[62] = ctx->nslots; out[63] = 0;
+  return EH_OK;
+}
+// Cooperative execution (eh_common.h CoBoard): out[0] loops posted, [1] chunks run by wavefronts between cases, [2] by the posting
+// cases themselves, [3] cycles the posters waited for the last chunks, [4] loops that found the board full (run by their case alone).
+int eh_coop_stats(eh_ctx* ctx, uint64_t* out /* 8 values */) {
+  if (!ctx || !out) return EH_E_INVALID;
+  if (!ctx->pool) { ctx->err = "no work-area pool yet (eh_reserve or a first batch creates it)"; return EH_E_STATE; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpy(out, (const uint8_t*)ctx->pool->d_board + offsetof(CoBoard, stat), 8 * 8, hipMemcpyDeviceToHost));
   return EH_OK;
 }
 // Has the last batch of this context finished (results ready, the context free for the next batch)?  Never blocks: what a host

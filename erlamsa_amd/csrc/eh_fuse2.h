@@ -192,7 +192,7 @@ EH_DEV uint64_t fb_ld8(cbptr S, uint32_t q, uint32_t len) {
 // bytes of the NEXT step are requested before this step's 16 lookups, and every kind of access of a step (lookups,
 // tests of the next table) is issued as one batch, so a step costs a few round trips.
 template <int INS>   // how the next table is written: 0 bitmap, global atomics; 1 bitmap in LDS; 2 bitmap, test (at L2) before the atomic; 3 N1 + bitmap rows; 4 N1 in LDS + bitmap rows
-__device__ __noinline__ uint32_t fb_pass(cbptr S, uint32_t len, wptr ids, uint32_t g, const EH_G RkWord* RK, const EH_G ScEnt* SC, bool sc_lds, uint32_t kill, uint32_t e_pos, bool e_kill, wptr Mn, wptr N1n) {
+__device__ __noinline__ uint32_t fb_pass(cbptr S, uint32_t len, wptr ids, uint32_t g, const EH_G RkWord* RK, const EH_G ScEnt* SC, bool sc_lds, uint32_t kill, uint32_t e_pos, uint32_t lim, wptr Mn, wptr N1n) {   // e_pos: the member at len-1 when it leaves its group (FB_DEAD: it stays); lim: positions [0, lim) are done - len, or where a chunk of a posted pass ends (a multiple of 1024)
   const uint32_t l = (uint32_t)EH_LANE;
   constexpr int U = 4;
   uint32_t alive = 0;
@@ -203,7 +203,7 @@ __device__ __noinline__ uint32_t fb_pass(cbptr S, uint32_t len, wptr ids, uint32
     uint4 z; z.x = z.y = z.z = z.w = 0; idv[u] = z; byv[u] = 0;
     if (p < len) { if (g > 0) idv[u] = ldg16a(ids + p); byv[u] = fb_ld8(S, p + g, len); }
   }
-  for (uint32_t base = 0; base < len; base += 256u * U) {
+  for (uint32_t base = 0; base < lim; base += 256u * U) {
     uint4 nidv[U]; uint64_t nbyv[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {                                  // prefetch the next step
@@ -269,7 +269,7 @@ __device__ __noinline__ uint32_t fb_pass(cbptr S, uint32_t len, wptr ids, uint32
         const uint32_t b = fb_tr((uint32_t)(byv[u] >> (8 * k)) & 255u, g);
         const uint32_t bit = 1u << (b & 31u);
         if (rk[u][k].mask & bit) nid = rk[u][k].prefix + (uint32_t)__popc(rk[u][k].mask & (bit - 1u));
-        if (nid == kill || (pos == e_pos && e_kill)) nid = FB_DEAD;
+        if (nid == kill || pos == e_pos) nid = FB_DEAD;
         nw[k] = nid;
         w2v[u][k] = 0; bit2v[u][k] = 0; nidn[u][k] = 0;            // bit2 == 0: nothing to set
         if (nid != FB_DEAD) {
@@ -345,6 +345,29 @@ __device__ __noinline__ uint32_t fb_pass(cbptr S, uint32_t len, wptr ids, uint32
   }
   wave_sync();
   return wave_sum(alive);
+}
+
+// chunk t of a posted pass (co_exec): positions [t CO_FB_CHUNK, (t + 1) CO_FB_CHUNK) of one side.  The wavefront that runs it may be
+// any wavefront between two cases: the compact lookup entries go into ITS copy of the LDS table first.
+// (from which list length a pass is posted, and its chunks: KParams co_fb_min, co_fb_chunk)
+__device__ __noinline__ void fb_pass_chunk(const EH_G CoJob* j, uint32_t t) {
+  const uint32_t l = (uint32_t)EH_LANE;
+  cbptr S = (cbptr)uni64(j->a[0]); const uint32_t len = uni((uint32_t)j->a[1]), g = uni((uint32_t)(j->a[1] >> 32));
+  wptr ids = (wptr)uni64(j->a[2]); const EH_G RkWord* RK = (const EH_G RkWord*)uni64(j->a[3]); const EH_G ScEnt* SC = (const EH_G ScEnt*)uni64(j->a[4]);
+  const uint32_t kill = uni((uint32_t)j->a[5]), e_pos = uni((uint32_t)(j->a[5] >> 32)), fl = uni((uint32_t)j->a[6]), nn = uni((uint32_t)j->a[9]);
+  wptr Mn = (wptr)uni64(j->a[7]), N1n = (wptr)uni64(j->a[8]);
+  const bool ek = fl & 1u, sc_lds = (fl & 2u) != 0; const uint32_t ins = (fl >> 8) & 7u;
+  if (sc_lds) { cwptr scw = (cwptr)SC; lanes_sync(); for (uint32_t i = l; i < 2u * nn; i += 64) g_fuse_lds[i] = scw[i]; lanes_sync(); }
+  // the chunk's positions count from 0: position p of the chunk is p0 + p of the list, and everything fb_pass asks about a position
+  // (p + k + g < len, the member at len-1) is a difference to len or e_pos, which move with it
+  const uint32_t chunk = uni((uint32_t)j->a[10]);
+  const uint32_t p0 = t * chunk, ln = len - p0, plim = ln < chunk ? ln : chunk;
+  const uint32_t ep = (ek && e_pos != FB_DEAD && e_pos >= p0) ? e_pos - p0 : FB_DEAD;
+  S += p0; ids += p0;
+  const uint32_t alive = ins == 3 ? fb_pass<3>(S, ln, ids, g, RK, SC, sc_lds, kill, ep, plim, Mn, N1n)
+                       : ins == 2 ? fb_pass<2>(S, ln, ids, g, RK, SC, sc_lds, kill, ep, plim, Mn, nullptr)
+                       : fb_pass<0>(S, ln, ids, g, RK, SC, sc_lds, kill, ep, plim, Mn, nullptr);
+  if (l == 0 && alive) atomicAdd((EH_G unsigned long long*)&j->acc, (unsigned long long)alive);
 }
 
 // members of `node`: how many, and the position of the k-th (0-based, ascending)
@@ -424,6 +447,9 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, cbptr A, uint32_t la, cbptr 
   uint64_t gen_entries = (uint64_t)la + lb;
   bool have_bits = false;                                          // M holds the next bytes of generation g
   bool cur_n1 = false;                                             // ... in two levels (N1 + rows of the nodes with several bytes)
+  // lists of CO_FB_MIN positions and more: the streaming passes are posted for several wavefronts (co_run), so the next-byte tables stay in HBM
+  const uint32_t co_min = c.p->co_fb_min, co_chunk = c.p->co_fb_chunk;
+  const bool coop = c.p->board != nullptr && (la >= co_min || lb >= co_min);
   EH_PT0;
   uint32_t special_node = FB_DEAD;                                 // generation g's {[[]], [[]]} node (two distinct lists only)
   while (true) {                                                   // find_jump_points_loop (:115-128)
@@ -482,11 +508,11 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, cbptr A, uint32_t la, cbptr 
     // ---- commit: ids of generation g+1 (+ the next-byte tables of the next round when it is going to run)
     fuel -= (int64_t)nchild;
     const bool next = fuel >= 0 && (uint32_t)(rng_peek(c.rng, 1) * 8.0) != 0;
-    const bool lds = next && nchild * 8u <= FB_LDS_WORDS;
+    const bool lds = next && nchild * 8u <= FB_LDS_WORDS && !coop;
     // two-level tables when the nodes of this round had two children on average at most: low-entropy data, where the node
     // counts stay small over many rounds; lookups through the compact entries when few nodes spread over several words
     const bool n1 = next && !lds && nchild <= 2u * nn;
-    const bool n1_lds = n1 && nchild <= FB_LDS_N1_NODES;
+    const bool n1_lds = n1 && nchild <= FB_LDS_N1_NODES && !coop;
     const EH_G ScEnt* look = nfull * 4u <= nn ? SC : nullptr;
     const bool sc_lds = look && nn <= FB_LDS_SC_NODES;
     if (sc_lds) { cwptr scw = (cwptr)SC; lanes_sync(); for (uint32_t i = l; i < 2u * nn; i += 64) g_fuse_lds[i] = scw[i]; lanes_sync(); }
@@ -508,11 +534,24 @@ __device__ __noinline__ bool fuse_jump_stream(Ctx&, cbptr A, uint32_t la, cbptr 
       // alone = the special node = the member itself, now empty, so it stays.
       bool ek = sym ? (!e_alone[0] && (g & 1u)) : (e_alone[s] || (g & 1u));
       uint32_t kill = (s == 1 && forced) ? sp : FB_DEAD;
-      uint32_t alive = lds ? fb_pass<1>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, e_pos[s], ek, M[s], nullptr)
-                     : n1_lds ? fb_pass<4>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, e_pos[s], ek, M[s], N1[s])
-                     : n1 ? fb_pass<3>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, e_pos[s], ek, M[s], N1[s])
-                     : (next && nchild * 8u <= FB_TEST_WORDS) ? fb_pass<2>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, e_pos[s], ek, M[s], nullptr)
-                     : fb_pass<0>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, e_pos[s], ek, next ? M[s] : nullptr, nullptr);
+      const int ins = lds ? 1 : n1_lds ? 4 : n1 ? 3 : (next && nchild * 8u <= FB_TEST_WORDS) ? 2 : 0;
+      wptr mn = (ins == 0 && !next) ? nullptr : M[s]; wptr n1n = (ins == 3 || ins == 4) ? N1[s] : nullptr;
+      uint32_t alive = 0;
+      bool posted = false;
+      if (coop && len[s] >= co_min) {                               // the pass as chunks for several wavefronts (tables in HBM: ins is 0, 2 or 3 here)
+        CoArgs a; for (uint32_t k = 0; k < CO_ARGS; k++) a.a[k] = 0;
+        a.a[0] = (uint64_t)S[s]; a.a[1] = (uint64_t)len[s] | ((uint64_t)g << 32); a.a[2] = (uint64_t)ids[s]; a.a[3] = (uint64_t)RK; a.a[4] = (uint64_t)look;
+        a.a[5] = (uint64_t)kill | ((uint64_t)e_pos[s] << 32); a.a[6] = (ek ? 1u : 0u) | ((uint32_t)ins << 8) | (sc_lds ? 2u : 0u); a.a[7] = (uint64_t)mn; a.a[8] = (uint64_t)n1n; a.a[9] = nn; a.a[10] = co_chunk;
+        unsigned long long acc = 0;
+        posted = co_run(CO_FBPASS, (len[s] + co_chunk - 1) / co_chunk, a, &acc);
+        alive = (uint32_t)acc;
+      }
+      if (!posted)
+        alive = ins == 1 ? fb_pass<1>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, ek ? e_pos[s] : FB_DEAD, len[s], mn, nullptr)
+              : ins == 4 ? fb_pass<4>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, ek ? e_pos[s] : FB_DEAD, len[s], mn, n1n)
+              : ins == 3 ? fb_pass<3>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, ek ? e_pos[s] : FB_DEAD, len[s], mn, n1n)
+              : ins == 2 ? fb_pass<2>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, ek ? e_pos[s] : FB_DEAD, len[s], mn, nullptr)
+              : fb_pass<0>(S[s], len[s], ids[s], g, RK, look, sc_lds, kill, ek ? e_pos[s] : FB_DEAD, len[s], mn, nullptr);
       entries += alive;
       EH_PT(c, lds ? 105 : (n1_lds ? 96 : (n1 ? 111 : (next ? (nchild * 8u <= FB_TEST_WORDS ? 110 : 106) : 107))));
       if (lds) { lanes_sync(); for (uint32_t i = l; i < nchild * 8u; i += 64) M[s][i] = g_fuse_lds[FB_LDS_NEXT + i]; wave_sync(); }

@@ -1,10 +1,11 @@
-// eh_otp_sort.h — OTP stdlib lists:sort/2, the ONE implementation in this repository (host code).
+// eh_otp_sort.h — OTP stdlib lists:sort/2 as the ENGINE restates it (host code; index cursors over arrays).
 //
 // erlamsa_utils:sort_by_priority/1 (reference src/erlamsa_utils.erl:113-117) hands lists:sort/2 a strict '>' as the
 // ordering fun, so the order among equal priorities — which decides every weighted choice of mutator, pattern and
 // generator — is whatever stdlib's merge sort does with a fun that is not a total "=<".  The engine's host set-up
-// (eh_engine.hip) uses this header; oracle/otp_compat.h includes the same file, and tests/pymodel.py carries an
-// independent Python restatement of the algorithm that tests/test_pymodel.py diffs against it.
+// (eh_engine.hip) uses this header and nothing else does: oracle/otp_compat.h has a restatement of its own (cons lists, clause
+// for clause from stdlib's lists.erl) and tests/pymodel.py a third one in Python; tests/test_pymodel.py
+// (test_three_restatements_of_lists_sort_agree) diffs the three through eh_selftest_sort_by_priority.
 #pragma once
 #include <cstddef>
 #include <functional>

@@ -12,13 +12,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ERLAMSA_HIP_LIB") or os.path.join(_HERE, "liberlamsa_hip.so")
 
-EH_ABI_VERSION = 7
+EH_ABI_VERSION = 8
 EH_FLAG_ORDERED_OUTPUT = 1
 EH_FLAG_META_TRACE = 2
 EH_FLAG_FUSE_NO_LDS = 4
 EH_FLAG_FUSE_NO_REDUCE = 8
 EH_FLAG_SGML_NO_REPLAY = 16
 EH_FLAG_SGML_NO_LANES = 32
+EH_FLAG_NO_COOP = 64
 
 CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BUDGET = 0, 1, 2, 3, 4, 5
 
@@ -26,7 +27,7 @@ CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BU
 ABI_SYMBOLS = [
     "eh_create", "eh_destroy", "eh_configure", "eh_corpus_upload", "eh_corpus_attach", "eh_fuzz_batch",
     "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_fetch", "eh_result_totals", "eh_result_diag", "eh_result_cycles", "eh_result_peak", "eh_result_meta", "eh_result_write_files", "eh_result_prof", "eh_selftest_movers", "eh_selftest_zlib",
-    "eh_last_kernel_ms", "eh_pool_stats", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
+    "eh_last_kernel_ms", "eh_pool_stats", "eh_coop_stats", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
     "eh_coalesce_limits", "eh_submit", "eh_flush", "eh_poll", "eh_cancel",
@@ -95,6 +96,7 @@ def load_library():
     lib.eh_selftest_zlib.argtypes = [vp, C.c_int, vp, C.c_uint64, vp, C.c_uint64, vp, vp]
     lib.eh_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.eh_pool_stats.argtypes = [vp, vp]
+    lib.eh_coop_stats.argtypes = [vp, vp]
     lib.eh_coalesce_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
     lib.eh_submit.argtypes = [vp, vp, C.c_uint64, i64p, u64p]
     lib.eh_flush.argtypes = [vp]
@@ -332,6 +334,12 @@ class Engine:
                 "peak_wanted": [int(v[41 + t]) >> 32 for t in ts],
                 "taken": [int(v[2 * t]) for t in ts], "waits": [int(v[30 + t]) for t in ts], "wait_ticks": [int(v[20 + t]) for t in ts],
                 "contexts": int(v[61])}
+
+    def coop_stats(self):
+        """Cooperative execution of heavy cases on this device (eh_coop_stats)."""
+        v = np.zeros(8, dtype=np.uint64)
+        self._chk(self.lib.eh_coop_stats(self.h, v.ctypes.data_as(C.c_void_p)))
+        return {"loops_posted": int(v[0]), "chunks_by_helpers": int(v[1]), "chunks_by_posters": int(v[2]), "poster_wait_cycles": int(v[3]), "board_full": int(v[4])}
 
     def download(self):
         """-> (list[bytes] per case, status int32[n])"""

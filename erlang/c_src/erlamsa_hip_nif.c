@@ -285,6 +285,10 @@ static int get_ctx_list(ErlNifEnv* env, ERL_NIF_TERM list, ctx_res** rs, eh_ctx*
   for (ERL_NIF_TERM l = list; enif_get_list_cell(env, l, &head, &l); i++) { if (!enif_get_resource(env, head, ctx_type, (void**)&rs[i])) return 0; cs[i] = rs[i]->ctx; }
   return 1;
 }
+/* every context of a list, in the list's order (the same list from every caller: erlamsa_hip:multi_ctxs/0), so two callers cannot
+ * hold one each and wait for the other's */
+static void lock_all(ctx_res** rs, unsigned n) { for (unsigned i = 0; i < n; i++) enif_mutex_lock(rs[i]->lock); }
+static void unlock_all(ctx_res** rs, unsigned n) { for (unsigned i = n; i-- > 0;) enif_mutex_unlock(rs[i]->lock); }
 static ERL_NIF_TERM nif_device_count(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { (void)argc; (void)argv; return enif_make_int(env, eh_device_count()); }
 /* load_corpus_nif(Ctx, Bins) -> ok */
 static ERL_NIF_TERM nif_load_corpus(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
@@ -301,14 +305,20 @@ static ERL_NIF_TERM nif_load_corpus(ErlNifEnv* env, int argc, const ERL_NIF_TERM
 static ERL_NIF_TERM nif_comm_init_local(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res* rs[64]; eh_ctx* cs[64]; unsigned n; (void)argc;
   if (!get_ctx_list(env, argv[0], rs, cs, &n)) return enif_make_badarg(env);
+  lock_all(rs, n);                                         /* (no batch of another process runs on any of them meanwhile) */
   int rc = eh_comm_init_local(cs, (int)n);
-  return rc ? mk_error(env, cs[0], rc) : enif_make_atom(env, "ok");
+  ERL_NIF_TERM ret = rc ? mk_error(env, cs[0], rc) : enif_make_atom(env, "ok");
+  unlock_all(rs, n);
+  return ret;
 }
 static ERL_NIF_TERM nif_broadcast_local(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res* rs[64]; eh_ctx* cs[64]; unsigned n; int root; (void)argc;
   if (!get_ctx_list(env, argv[0], rs, cs, &n) || !enif_get_int(env, argv[1], &root) || root < 0 || root >= (int)n) return enif_make_badarg(env);
+  lock_all(rs, n);
   int rc = eh_corpus_broadcast_local(cs, (int)n, root);
-  return rc ? mk_error(env, cs[root], rc) : enif_make_atom(env, "ok");
+  ERL_NIF_TERM ret = rc ? mk_error(env, cs[root], rc) : enif_make_atom(env, "ok");
+  unlock_all(rs, n);
+  return ret;
 }
 /* one node per GPU: comm_unique_id_nif() -> {ok, <<128 bytes>>} ; comm_init_nif(Ctx, Id, Rank, N) -> ok ; corpus_broadcast_nif(Ctx, Root, Bins | none) -> ok */
 static ERL_NIF_TERM nif_comm_unique_id(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
@@ -381,7 +391,7 @@ static ERL_NIF_TERM nif_meta(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]
   ERL_NIF_TERM bin; uint64_t n = 0;
   static uint8_t dummy;
   enif_mutex_lock(r->lock);
-  int rc = eh_result_meta(r->ctx, i, &dummy, 0, &n);
+  int rc = eh_result_meta(r->ctx, i, &dummy, 0, &n);           /* the length (ABI 8: min(len, cap) bytes are copied, EH_OK either way) */
   unsigned char* p = rc ? NULL : enif_make_new_binary(env, (size_t)n, &bin);
   if (!rc && !p) rc = EH_E_NOMEM;
   if (!rc) rc = eh_result_meta(r->ctx, i, p, n, &n);

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EH_ABI_VERSION 7
+#define EH_ABI_VERSION 8
 
 typedef struct eh_ctx eh_ctx;
 
@@ -116,6 +116,8 @@ typedef struct eh_options {
   uint32_t reserved0;
 } eh_options;
 
+#define EH_FLAG_NO_COOP 64u        /* diagnostic: every case does all of its work on its own wavefront (no cooperative execution of
+                                     the bulk loops of heavy cases, csrc/eh_common.h CoBoard; ABI 8).  Same bytes either way. */
 #define EH_FLAG_ORDERED_OUTPUT 1u /* compact the output arena into case order after the batch */
 #define EH_FLAG_META_TRACE 2u     /* keep every case's meta trace (eh_result_meta) */
 #define EH_FLAG_SGML_NO_LANES 32u  /* diagnostic: the sgm tokenizer makes its tag attempts one after the other instead of 64 at a time, one per
@@ -270,7 +272,8 @@ int eh_result_write_files(eh_ctx* ctx, const char* name_template, uint64_t first
  * Encoding (csrc/eh_common.h TraceKind): a kind byte and its operands - 1 {Atom, Atom}: two atom ids; 2 {Atom, Int}: atom id,
  * zigzag LEB128; 3 sizer: Size/8, big, then LEB128 Len, A, B; 4 csum: crc32?, LEB128 PLen, BLen; 5 skipped: LEB128 bytes (printed
  * as a float); 6 {archiver, Name}: LEB128 n, n bytes.  Atom ids: eh_meta_atom_name (the mutator codes come first, in table order).
- * *n_events = BYTES of the trace (copied up to cap).  At most 32768 bytes per case are kept; the last byte is 0xFF when events
+ * *n_events = BYTES of the trace; min(*n_events, cap) of them are copied into buf and the call returns EH_OK either way, so
+ * (buf = NULL, cap = 0) asks for the length (ABI 8; until ABI 7 a buffer that was too small was EH_E_INVALID).  At most 32768 bytes per case are kept; the last byte is 0xFF when events
  * were dropped.  Renderers to ~p text: erlamsa_amd/meta.py, erlang/src/erlamsa_hip.erl. */
 int eh_meta_atom_count(void);
 const char* eh_meta_atom_name(int id);
@@ -304,6 +307,11 @@ int eh_selftest_sort_by_priority(const uint32_t* pri, uint32_t n, uint32_t* perm
  * out[51+t] = bytes of an area of tier t (out[51] = the slots'), out[61] = contexts sharing the pool, out[62] = slots
  * (= workgroups of a batch) of this context. */
 int eh_pool_stats(eh_ctx* ctx, uint64_t* out);
+/* Cooperative execution of heavy cases (ABI 8): a case's loops over hundreds of kilobytes (block copies, the final concatenation,
+ * the streaming passes of erlamsa_fuse on large lists) are cut into chunks that wavefronts BETWEEN two cases of their own run too.
+ * out[0] loops posted, out[1] chunks run by such helpers, out[2] chunks run by the posting cases, out[3] shader cycles the posters
+ * waited for the last chunks, out[4] loops that found the board full; out[5..7] reserved.  Counted per device since the pool exists. */
+int eh_coop_stats(eh_ctx* ctx, uint64_t* out);
 
 /* Elapsed GPU time of the mutate kernel of the last batch in ms (HIP events on the launch
  * stream), and its name for matching against a rocprofv3 kernel trace. */

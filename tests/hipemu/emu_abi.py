@@ -161,4 +161,21 @@ wb, wsb, _, _ = po.fuzz_batch(d1, o1, seeds=np.array([reqs[1][1]], dtype=np.int6
 assert eo.poll(tb) == (int(wsb[0]), wb[0])
 assert eo.poll(ta) == (int(wstq[0]), wantq[0])         # the first request kept the options it was submitted under
 eo.close()
+# the option-map API: skip => N drops the cases numbered <= N, whose draws still happen (erlamsa_main.erl:161,191-196), also when
+# the run does not start at case 1; keys that need the BEAM are refused
+from erlamsa_amd import api
+base = {"seed": (4, 5, 6), "mutations": "bd,bf,bi,sr", "patterns": "od,nd", "input": b"skip me, the quick brown fox", "n": 12}
+all12 = api.fuzzer(dict(base, on_engine_limit="skip"))
+outs12, st12 = api.fuzz_batch([base["input"]] * 12, base, return_status=True)
+kept = [o for o, s_ in zip(outs12, st12) if s_ == 0 and len(o) > 0]
+assert all12 == kept
+dropped5 = [o for i, (o, s_) in enumerate(zip(outs12, st12)) if i >= 5 and s_ == 0 and len(o) > 0]
+assert api.fuzzer(dict(base, skip=5, on_engine_limit="skip")) == dropped5
+late = api.fuzz_batch([base["input"]] * 6, dict(base, first_case=4), return_status=True)
+assert api.fuzzer(dict(base, n=6, first_case=4, skip=5, on_engine_limit="skip")) == [o for i, (o, s_) in enumerate(zip(*late)) if 4 + i > 5 and s_ == 0 and len(o) > 0]
+try:
+    api.fuzzer(dict(base, external_post="external_post"))
+    raise SystemExit("external_post was not refused")
+except api.Unsupported as e:
+    assert e.keys == ["external_post"]
 print("abi behaviour ok")

@@ -51,6 +51,21 @@ def run(n=24, size=500, seed=(2, 7, 1)):
     return checked
 
 
+def size_query_then_fetch(eng, i):
+    """what erlang/c_src/erlamsa_hip_nif.c nif_meta does: ask for the length with an empty buffer, then fetch into a binary of that
+    size (ABI 8: eh_result_meta copies min(len, cap) bytes and returns EH_OK either way)"""
+    import ctypes as C
+    raw = eng.meta_raw(i)
+    n = C.c_uint64(12345)
+    assert eng.lib.eh_result_meta(eng.h, i, None, 0, C.byref(n)) == 0 and n.value == len(raw), (n.value, len(raw))
+    buf = (C.c_uint8 * max(n.value, 1))()
+    assert eng.lib.eh_result_meta(eng.h, i, buf, n.value, C.byref(n)) == 0 and bytes(buf[:n.value]) == raw
+    if len(raw) > 3:
+        short = (C.c_uint8 * 8)(*([0xAA] * 8))
+        assert eng.lib.eh_result_meta(eng.h, i, short, 3, C.byref(n)) == 0 and n.value == len(raw)
+        assert bytes(short[:3]) == raw[:3] and bytes(short[3:]) == b"\xaa" * 5
+
+
 def run_sets(n=24):
     """the full text on the inputs that reach every kind of entry: documents through js / sgm and their inner runs, the complex
     patterns (skipper, sizer, csum, compressed, archiver, co, nu), gzip / zlib inputs through cp, zip archives through ar and zip"""
@@ -82,6 +97,8 @@ def run_sets(n=24):
             assert got[i] == want[i], i
             assert util.meta_matches(eng, i, lines[i]), "set %s case %d: engine %r oracle %r" % (pats, i, eng.meta_terms(i)[0][:12], lines[i][:300])
             checked += 1
+            if checked % 16 == 1:
+                size_query_then_fetch(eng, i)
         eng.close()
     return checked
 

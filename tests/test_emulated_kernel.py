@@ -141,6 +141,13 @@ def test_emulated_sgml_lane_batches_and_base64_wave_decode(emu_lib):
     assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout + r.stderr
 
 
+def test_emulated_blocks_above_a_million_bytes_are_split(emu_lib):
+    """split/1 + split_into_maxblocks/2 (erlamsa_patterns.erl:44-59) on inputs of 1.0 and 1.6 MB, patterns od / nd / sk"""
+    env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_split.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "split ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_emulated_race_detector_finds_no_cross_lane_access_without_a_rendezvous():
     """The engine built with every load / store of the kernel code instrumented (build_emu.py --race, tests/hipemu/race_hooks.cpp):
     between two rendezvous points no lane reads what another lane wrote or overwrites what another lane read - the class of bug

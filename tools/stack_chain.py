@@ -16,7 +16,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-fPIC", "-S", "--cuda-device-only"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-Xclang", "-target-feature", "-Xclang", "-mai-insts", "-fPIC", "-S", "--cuda-device-only"]
 MAX_NEST, LIMIT = 6, 6144
 
 
