@@ -143,7 +143,7 @@ struct CoBoard {
   unsigned long long word[CO_JOBS];
   uint32_t owner[CO_JOBS];      // 1: a poster holds the entry
   uint32_t open;                // entries with chunks to hand out
-  uint32_t lingerers;           // wavefronts without a ticket that stay for chunks
+  uint32_t posters;             // cases under way that have posted a loop: wavefronts whose pass has run out of tickets stay for chunks while there are any
   uint32_t pad[14];
   unsigned long long stat[8];   // [0] jobs posted, [1] chunks run by helpers, [2] by the posters themselves, [3] cycles posters waited, [4] jobs that found no free entry
   CoJob job[CO_JOBS];
@@ -196,6 +196,8 @@ struct KParams {
   wptr pool_ring[POOL_TIERS + 1];
   EH_G unsigned long long* pool_ctr;
   EH_G CoBoard* board;          // nullptr: every case does all its work itself (EH_FLAG_NO_COOP)
+  EH_G unsigned long long* summary_out;  // page-locked HOST memory: the last workgroup to leave writes the batch's totals there (eh_result_summary reads them without a copy call)
+  uint64_t batch_seq;           // ... stamped with this number
   uint32_t co_copy_min, co_copy_chunk;   // bytes: copies / compares of co_copy_min and more are posted in chunks of co_copy_chunk
   uint32_t co_fb_min, co_fb_chunk;       // positions: the same for the streaming passes of eh_fuse2.h (chunk: a multiple of 1024)
 };

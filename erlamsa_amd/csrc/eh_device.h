@@ -325,6 +325,7 @@ struct Ctx {
   uint64_t lex_ptr[LEX_LEVELS];   // block the lex cache of nesting level d holds a table for (mirror of LexCache::ptr; 0: none)
   bptr trace;      // EH_FLAG_META_TRACE: the case's event bytes (slot memory), nullptr = off
   uint32_t ntrace, tr_base;   // bytes written; where the Meta list in hand begins (tr_drop_before)
+  uint32_t co_posted;  // the case has posted a loop for other wavefronts (counted in CoBoard::posters until it ends)
   uint64_t t_case;     // cycle stamp at which the case began (mux_fuzzers raises the wavefront's issue priority for cases that run long)
   int32_t m_aux;       // set by the mutators whose own Meta entry does not follow from their result alone (num: a number found; ab / ad: stringy)
   uint64_t ws_peak, ws_top;   // diagnostics: highest ws_used, bytes taken from the top of chunks (eh_result_peak)
@@ -533,11 +534,13 @@ __device__ __noinline__ bool co_run(uint32_t kind, uint32_t nchunks, CoArgs args
   wave_sync();                                                             // every lane's stores of the case so far are issued ...
   co_release();                                                            // ... and written back: the helpers read the loop's inputs from memory
   if (l == 0) {
+    if (!c.co_posted) atomicAdd(&bd->posters, 1u);                          // (until the case ends: eh_mutate_kernel)
     gen = ((co_ld64(&bd->word[slot]) >> 32) + 1ull) | 1ull;                 // (closed words carry even generations)
     atomicExch(&bd->word[slot], gen << 32);
     atomicAdd(&bd->open, 1u);
     atomicAdd(&bd->stat[0], 1ull);
   }
+  c.co_posted = 1;
   uint32_t mine = 0;
   for (;;) {
     unsigned long long old = 0;
@@ -1177,6 +1180,15 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
       uint32_t hd_len = c.r_flush && c.r_len >= AVG_BLOCK_SIZE ? AVG_BLOCK_SIZE : c.r_len;
       changed = c.r_changed || hd_len != h0.len || !wave_equal(c.r_ptr, (cbptr)h0.ptr, hd_len);
     }
+#ifdef EH_PROF
+    // work memory an attempt took (what it wrote, nearly: candidates, tables, temporaries): slot 56 attempts that failed, 57 the candidates
+    // that were used, 58 what the used attempts took besides their candidate (eh_result_prof; the write traffic's breakdown)
+    if (l == 0) {
+      const unsigned long long took = c.ws_used > mark ? c.ws_used - mark : 0ull, cand = c.r_kind == R_NEW ? c.r_len : 0u;
+      if (changed) { atomicAdd(&c.p->prof[2 * 57], cand); atomicAdd(&c.p->prof[2 * 57 + 1], 1ull); atomicAdd(&c.p->prof[2 * 58], took > cand ? took - cand : 0ull); atomicAdd(&c.p->prof[2 * 58 + 1], 1ull); }
+      else { atomicAdd(&c.p->prof[2 * 56], took); atomicAdd(&c.p->prof[2 * 56 + 1], 1ull); }
+    }
+#endif
     own_meta(c, fn, delta, h0.len);                                                // the mutator's own entry is in the Meta it returns, used or failed
     tr_aa(c, changed ? AT_used : AT_failed, (int)name);                            // {used, Name} / {failed, Name} :1278-1279
     if (changed) {

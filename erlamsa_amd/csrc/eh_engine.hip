@@ -844,6 +844,15 @@ __device__ __noinline__ void co_exec(const EH_G CoJob* j, uint32_t t) {
 // =============================================================================================
 // the mutate kernel
 // =============================================================================================
+EH_DEV void sys_store(EH_G unsigned long long* p, unsigned long long v) {   // a store the host sees (page-locked host memory)
+#ifdef HIPEMU
+  *p = v;
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+constexpr int CTR_STATUS = 264;              // counters [264, 270): cases of the batch by status ([8, 264) are the EH_PROF slots)
+constexpr unsigned int CO_LINGER = 48;       // wavefronts of a pass that stay for posted chunks once the pass is out of tickets
 // 2 wavefronts per SIMD = up to 256 VGPRs: at 4 (128 VGPRs) the scheduler loops and the candidate loop of base64_mutator
 // reload spilled registers from scratch on every iteration (7.5 M instead of 1.6 M memory instructions for one
 // b64-heavy case, twice the time, profiles/r03_summary.json "occupancy"); the longest cases set the duration of a pass.
@@ -897,7 +906,27 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     }
     if (p.board && uni(co_ld32(&p.board->open)) != 0) co_help(p.board, 2);   // chunks of heavy cases' loops, between two cases of my own
     uint64_t i = tk_next++;
-    if (i >= p.n) break;
+    if (i >= p.n) {
+#ifndef HIPEMU
+      // Out of tickets: the pass ends with its heaviest cases, each on ONE wavefront, and what those post would find nobody between
+      // two cases any more.  Up to CO_LINGER wavefronts of the pass stay for chunks - of any pass's cases - while the pass has
+      // cases under way and some case on the device is posting; the others leave their slots to the workgroups of the next passes.
+      if (p.board) {
+        unsigned int mine = CO_LINGER;
+        if (l == 0) mine = (unsigned int)atomicAdd(p.ticket + 4, 1ull);
+        if (uni(mine) < CO_LINGER) {
+          EH_G CoBoard* bd = p.board;
+          for (uint32_t spins = 0; spins < (1u << 24); spins++) {
+            if (uni64(co_ld64(p.ticket + 3)) >= p.n || uni(co_ld32(&bd->posters)) == 0) break;
+            if (uni(co_ld32(&bd->open)) != 0) co_help(bd, 8);
+            else { for (int z = 0; z < 6; z++) __builtin_amdgcn_s_sleep(127); }   // ~20 us: posted loops last hundreds (every poll is a trip to the L2 of all these wavefronts)
+          }
+        }
+      }
+#endif
+      break;
+    }
+    c.co_posted = 0;
     uint64_t tick0 = __builtin_readcyclecounter();
 #ifndef HIPEMU
     c.t_case = tick0;
@@ -984,6 +1013,12 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
 #ifndef HIPEMU
     __builtin_amdgcn_s_setprio(0);                                      // (mux_fuzzers raises it for cases that run long)
 #endif
+    if (c.co_posted && l == 0) atomicAdd(&p.board->posters, 0xFFFFFFFFu);   // (- 1)
+    if (l == 0) {
+      atomicAdd(p.ticket + 3, 1ull);                                        // cases of the pass that are done (the lingering wavefronts watch it)
+      atomicAdd(p.ticket + 5, (unsigned long long)total);                   // the batch's totals on the device (eh_result_summary: one small copy instead of n lengths and n statuses)
+      atomicAdd(p.ticket + CTR_STATUS + (c.status >= 0 && c.status < 6 ? c.status : 1), 1ull);
+    }
     // larger areas the case borrowed go back to the pool (the output has been copied out of them)
     wave_sync();
     if (c.nchunk > 0) ws_release_to(c, 0);
@@ -994,6 +1029,19 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
       if (p.flags & EH_FLAG_META_TRACE) { p.trace_off[i] = tbase; p.trace_len[i] = c.trace ? c.ntrace : 0u; }
     }
     wave_sync();
+  }
+  // The last workgroup to leave writes the batch's totals into page-locked host memory: a host loop over many batches then needs no
+  // copy call per batch (a hipMemcpy of a few bytes from a device full of persistent workgroups took the bench's host thread 60 - 90
+  // ms per step, during which it launched nothing).  Every wavefront's counter updates are complete before its own increment
+  // returns (the returned value is waited for with vmcnt(0)), so the one that sees all the others reads final values.
+  wave_sync();
+  unsigned long long left = 0;
+  if (l == 0) left = atomicAdd(p.ticket + 6, 1ull);
+  if (uni64(left) + 1 == (unsigned long long)gridDim.x && p.summary_out) {
+    if (l < 6) sys_store(p.summary_out + 3 + l, co_ld64(p.ticket + CTR_STATUS + l));
+    if (l == 6) { sys_store(p.summary_out + 1, co_ld64(p.ticket + 5)); sys_store(p.summary_out + 2, p.n); }
+    wave_sync();
+    if (l == 0) sys_store(p.summary_out + 9, p.batch_seq);
   }
 }
 
@@ -1135,7 +1183,8 @@ struct eh_ctx {
   uint8_t* d_out = nullptr; uint64_t out_cap = 0;
   uint64_t* d_off = nullptr; uint64_t* d_len = nullptr; int32_t* d_status = nullptr; uint64_t* d_draws = nullptr; int32_t* d_lastm = nullptr; uint64_t* d_cycles = nullptr; uint64_t* d_peak = nullptr; uint64_t* d_toff = nullptr; uint32_t* d_tlen = nullptr;
   uint64_t res_cap = 0;
-  unsigned long long* d_counters = nullptr;  // [0] ticket, [1] out cursor
+  unsigned long long* d_counters = nullptr;  // [0] ticket, [1] out cursor, [2] input bytes, [3] cases done, [4] lingering wavefronts, [5] output bytes, [6] workgroups that left, [8, 264) EH_PROF, [264, 270) cases by status
+  unsigned long long* h_sum = nullptr; uint64_t batch_seq = 0;   // page-locked: the last batch's totals, written by the kernel (KParams::summary_out)
   RunState* d_run = nullptr;
   int64_t* d_seeds = nullptr; uint64_t seeds_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1369,6 +1418,7 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   int rc = reserve(ctx, n, in_bytes);
   if (rc) return rc;
   if (!ctx->d_counters) { HIPCHK(ctx, hipMalloc(&ctx->d_counters, 4096)); HIPCHK(ctx, hipMalloc(&ctx->d_run, sizeof(RunState))); HIPCHK(ctx, hipMalloc(&ctx->d_params, sizeof(KParams))); }
+  if (!ctx->h_sum) { HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_sum, 128, hipHostMallocDefault)); memset(ctx->h_sum, 0, 128); }
 
   KParams p;
   memset(&p, 0, sizeof(p));
@@ -1385,6 +1435,8 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.ntiers = pl->ntiers; p.pool_ctr = dp(pl->d_ctr); p.pool_cap[0] = pl->work_cap;
   p.board = (ctx->flags & EH_FLAG_NO_COOP) ? dp((CoBoard*)nullptr) : dp(pl->d_board);
   co_defaults(&p, ctx->cus);
+  p.summary_out = dp(ctx->h_sum); p.batch_seq = ++ctx->batch_seq;
+  if (n == 0) { memset(ctx->h_sum, 0, 128); ctx->h_sum[9] = ctx->batch_seq; }      // (no mutate kernel: nothing else would write it)
   for (int t = 1; t <= pl->ntiers; t++) { p.pool_base[t] = dp(pl->base[t]); p.pool_stride[t] = pl->stride[t]; p.pool_cap[t] = pl->cap[t]; p.pool_cnt[t] = pl->cnt[t]; p.pool_ring[t] = dp(pl->ring[t]); }
   // persistent workgroups, each pulling cases from the ticket counter.  Batches in flight on several streams may
   // oversubscribe the device: the dispatcher starts a batch's workgroups as those of earlier ones leave.
@@ -1524,7 +1576,7 @@ void eh_destroy(eh_ctx* ctx) {
   if (ctx->own_corpus) { (void)hipFree(ctx->d_corpus); (void)hipFree(ctx->d_coff); }
   pool_release(ctx);
   (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
-  (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_peak); (void)hipFree(ctx->d_toff); (void)hipFree(ctx->d_tlen); (void)hipFree(ctx->d_counters);
+  (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_peak); (void)hipFree(ctx->d_toff); (void)hipFree(ctx->d_tlen); (void)hipFree(ctx->d_counters); if (ctx->h_sum) (void)hipHostFree(ctx->h_sum);
   (void)hipFree(ctx->d_run); (void)hipFree(ctx->d_seeds);
   for (int k = 0; k < 2; k++) { if (ctx->d_bounce[k]) (void)hipFree(ctx->d_bounce[k]); if (ctx->ev_g[k]) (void)hipEventDestroy(ctx->ev_g[k]); if (ctx->ev_c[k]) (void)hipEventDestroy(ctx->ev_c[k]); }
   if (ctx->dl_gather) (void)hipStreamDestroy(ctx->dl_gather);
@@ -1994,6 +2046,8 @@ int eh_sync(eh_ctx* ctx) {
 int eh_stream(eh_ctx* ctx, void** stream) {
   if (!ctx || !stream) return EH_E_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  // (streams of different priorities - high / normal / low in turn over the contexts - were measured against the convoy of passes
+  // launched together: 84.6 against 84.9 GB/s, profiles/r06_stream_priorities_and_slots.txt; not kept)
   if (!ctx->own_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
   *stream = (void*)ctx->own_stream;
   return EH_OK;
@@ -2045,6 +2099,19 @@ int eh_result_totals(eh_ctx* ctx, uint64_t* in_bytes, uint64_t* out_bytes, uint6
   }
   if (in_bytes) *in_bytes = ctx->last_in_bytes;
   if (n_cases) *n_cases = n;
+  return EH_OK;
+}
+// out[0] input bytes, out[1] output bytes, out[2] cases, out[3 + s] cases that ended with status s (0..5) - summed by the kernel,
+// one copy of 2 KiB: what a host loop over many small batches reads per batch instead of n lengths and n statuses.
+int eh_result_summary(eh_ctx* ctx, uint64_t* out /* 9 values */) {
+  if (!ctx || !out) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  if (hipEventQuery(ctx->ev1) != hipSuccess) { (void)hipGetLastError(); int rc = eh_sync(ctx); if (rc) return rc; }   // (a batch that eh_batch_done has seen end needs no runtime call at all)
+  // the kernel's last workgroup wrote them into page-locked memory, stamped with the batch's number: no copy call
+  volatile unsigned long long* hs = ctx->h_sum;
+  if (!hs || hs[9] != ctx->batch_seq) { ctx->err = "eh_result_summary: the batch's totals have not arrived in host memory"; return EH_E_HIP; }
+  out[0] = ctx->last_in_bytes; out[1] = hs[1]; out[2] = ctx->last_n;
+  for (int k = 0; k < 6; k++) out[3 + k] = hs[3 + k];
   return EH_OK;
 }
 int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, int32_t* status) {

@@ -369,6 +369,7 @@ __device__ __noinline__ bool fuse_lists(Ctx&, cbptr A, uint32_t la, cbptr B, uin
         else ok = fuse_jump_stream(c, A2, la2, B2, lb2, sym, &from, &tpos, &prof_rounds);
         c.fp_on = 0;
         if (!ok) return false;
+        EH_PT(c, 54);                                              // eh_result_prof 54: the search on the shortened lists; 55: the node's members found in the original lists
         // any_position_pair/1 (:73-77) over the ORIGINAL lists: the members of the node are the occurrences of its g-gram
         const uint32_t g = c.fp_g, par = g & 1u;
         from = la; tpos = lb;
@@ -383,6 +384,7 @@ __device__ __noinline__ bool fuse_lists(Ctx&, cbptr A, uint32_t la, cbptr B, uin
           const uint32_t tc0 = sym ? fc0 : fr_occ(B, lb, limB, key, g, FR_NONE, nullptr), tc = tc0 + c.fp_bB;
           if (tc > 0) { uint32_t j = rng_rand(c.rng, tc); j = par ? tc - 1u - j : j; if (j < tc0) { (void)fr_occ(B, lb, limB, key, g, j, &pos); tpos = uni(pos) + g; } }
         }
+        EH_PT(c, 55);
         goto jump;
       }
     }

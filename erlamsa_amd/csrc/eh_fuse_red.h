@@ -162,30 +162,58 @@ __device__ __noinline__ cbptr fr_reduce(Ctx&, cbptr S, uint32_t* n, uint32_t R) 
 }
 // Occurrences of key[0, g) in S at positions s < lim (s + g <= len): their number; with want != FR_NONE the position of the
 // want-th one (0-based, ascending) goes to *pos and the scan stops there.
+// A lane takes 16 consecutive positions per step: their 8-byte windows come out of 24 bytes it loads once (until round 5 every
+// position was an 8-byte load of its own: eight times the bytes, 256 positions per memory round trip instead of 4 096 - and the four
+// passes a fuse call on shortened lists makes over its ORIGINAL megabyte lists were most of what that call cost).
 __device__ __noinline__ uint32_t fr_occ(cbptr S, uint32_t len, uint32_t lim, cbptr key, uint32_t g, uint32_t want, uint32_t* pos) {
   const uint32_t l = (uint32_t)EH_LANE;
   uint64_t k8 = 0;
   for (uint32_t k = 0; k < 8 && k < g; k++) k8 |= (uint64_t)key[k] << (8 * k);
   const uint64_t mask = g >= 8 ? ~0ull : ((1ull << (8 * g)) - 1ull);
   uint32_t seen = 0;
-  for (uint32_t base = 0; base < lim; base += 256) {
-    uint64_t v[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { uint32_t s = base + 64u * (uint32_t)u + l; v[u] = s < lim ? fr_ld8(S, s, len) : 0; }
+  for (uint32_t base = 0; base < lim; base += 4096) {
+    uint64_t lo[4], hi[4], nx[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      uint32_t s = base + 64u * (uint32_t)u + l;
-      bool m = s < lim && (v[u] & mask) == k8;
-      if (m && g > 8) { for (uint32_t k = 8; k < g; k++) if (S[s + k] != key[k]) { m = false; break; } }
-      unsigned long long hit = __ballot(m);
-      uint32_t cnt = (uint32_t)__popcll(hit);
-      if (want != FR_NONE && want < seen + cnt) {
-        uint32_t r = want - seen;
-        for (uint32_t t = 0; t < r; t++) hit &= hit - 1ull;
-        *pos = base + 64u * (uint32_t)u + (uint32_t)__builtin_ctzll(hit);
-        return seen + cnt;
+      const uint32_t s0 = base + 1024u * (uint32_t)u + 16u * l;
+      lo[u] = hi[u] = nx[u] = 0;
+      if (s0 < lim) {
+        if (s0 + 24 <= len) { const uint4 v = ldg16(S + s0); lo[u] = (uint64_t)v.x | ((uint64_t)v.y << 32); hi[u] = (uint64_t)v.z | ((uint64_t)v.w << 32); nx[u] = ldg8(S + s0 + 16); }
+        else { lo[u] = fr_ld8(S, s0, len); hi[u] = fr_ld8(S, s0 + 8, len); nx[u] = fr_ld8(S, s0 + 16, len); }
       }
-      seen += cnt;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t s0 = base + 1024u * (uint32_t)u + 16u * l;
+      uint32_t bits = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 16; k++) {
+        const uint64_t a = k < 8 ? lo[u] : hi[u], b = k < 8 ? hi[u] : nx[u];
+        const uint32_t sh = 8u * (k & 7u);
+        const uint64_t w = sh ? (a >> sh) | (b << (64u - sh)) : a;
+        if ((w & mask) == k8 && s0 + k < lim) bits |= 1u << k;
+      }
+      if (g > 8 && __ballot(bits != 0)) {                           // the first 8 bytes agree: the rest, byte by byte
+        uint32_t left = bits;
+        while (left) {
+          const uint32_t k = (uint32_t)__builtin_ctz(left); left &= left - 1u;
+          const uint32_t s = s0 + k;
+          for (uint32_t q = 8; q < g; q++) if (S[s + q] != key[q]) { bits &= ~(1u << k); break; }
+        }
+      }
+      const uint32_t cnt = (uint32_t)__popc(bits);
+      const uint32_t inc = wave_incl_scan(cnt);
+      const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+      if (want != FR_NONE && want < seen + tot) {
+        const uint32_t r = want - seen, ex = inc - cnt;
+        const bool mine = r >= ex && r < inc;
+        uint32_t p = 0;
+        if (mine) { uint32_t b = bits; for (uint32_t t = ex; t < r; t++) b &= b - 1u; p = s0 + (uint32_t)__builtin_ctz(b); }
+        const unsigned long long who = __ballot(mine);
+        *pos = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)__builtin_ctzll(who));
+        return seen + tot;
+      }
+      seen += tot;
     }
   }
   return seen;

@@ -243,6 +243,10 @@ int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, 
 int eh_result_fetch(eh_ctx* ctx, uint64_t i, uint8_t* buf, uint64_t cap, uint64_t* out_len);
 /* Totals of the last batch (sum of input bytes read, output bytes written, cases). */
 int eh_result_totals(eh_ctx* ctx, uint64_t* in_bytes, uint64_t* out_bytes, uint64_t* n_cases);
+/* The same and the cases by status, summed on the device (ABI 8): out[0] input bytes, out[1] output bytes, out[2] cases,
+ * out[3 + s] = cases with status s (EH_CASE_OK .. EH_CASE_BUDGET).  One 2 KiB copy whatever the batch size: for host loops over
+ * many small batches (eh_result_totals copies every case's length). */
+int eh_result_summary(eh_ctx* ctx, uint64_t* out);
 /* Per-case diagnostics of the last batch (device->host): PRNG draws consumed by the worker and
  * the id (index in eh_mutator_name) of the last mutator that fired, -1 if none; for an EH_CASE_OVERFLOW case, minus the
  * id of the capacity check that gave up (EH_SET_OVERFLOW sites in csrc/, a diagnostic).  May be NULL. */

@@ -19,7 +19,7 @@ data, off = synth.as_arena(mat)
 names = [m[0] for m in ea.mutator_table()]
 eng = ea.Engine(0)
 eng.configure(fuse_stream_min=int(os.environ.get("FUSE_STREAM_MIN", "0")), patterns="od,nd,bu", out_capacity=40 << 30, max_case_bytes=int(os.environ.get("CASE_MIB", "4")) << 20, big_case_bytes=1024 << 20,
-              max_slots=int(os.environ.get("MAX_SLOTS", "0")))
+              max_slots=int(os.environ.get("MAX_SLOTS", "0")), flags=int(os.environ.get("ENGINE_FLAGS", "0")))
 eng.upload_corpus(data, off)
 eng.fuzz_batch(seed=(1, 2, 3), first_case=base + 1, corpus_first=0, n=n)
 eng.sync()
@@ -35,6 +35,7 @@ pk = eng.peak().astype(np.float64)
 print("work memory high-water MiB 50/90/99/99.9/max:", (np.percentile(pk, [50, 90, 99, 99.9, 100]) / 2**20).round(2).tolist(),
       " cases above 1/2/4/8/16/32/64/256 MiB:", [int((pk > (m << 20)).sum()) for m in (1, 2, 4, 8, 16, 32, 64, 256)])
 print("pool:", eng.pool_stats())
+print("cooperative execution:", eng.coop_stats())
 pct = np.percentile(cyc, [50, 90, 99, 99.9, 99.99])
 print("percentiles Mcyc 50/90/99/99.9/99.99:", (pct / 1e6).round(2).tolist())
 srt = np.sort(cyc)[::-1]
@@ -66,6 +67,10 @@ if pr.sum() > 0:
         if pr[2 * k + 1] > 0:
             print("  slot %3d calls %9d mean %10.1f kcyc total %8.2f Gcyc" % (k, pr[2 * k + 1], pr[2 * k] / pr[2 * k + 1] / 1e3, pr[2 * k] / 1e9))
 
+    print("  work memory taken by mutator attempts (what they wrote, nearly): failed attempts %.2f GB in %d; used candidates %.2f GB in %d; the used attempts' tables and temporaries %.2f GB; output %.2f GB" % (
+        pr[2 * 56] / 1e9, pr[2 * 56 + 1], pr[2 * 57] / 1e9, pr[2 * 57 + 1], pr[2 * 58] / 1e9, ob / 1e9))
+    print("  fuse on shortened lists: the search %d calls mean %.0f kcyc total %.1f Gcyc; the node's members found in the original lists (fr_occ) mean %.0f kcyc total %.1f Gcyc" % (
+        pr[2 * 54 + 1], pr[2 * 54] / max(pr[2 * 54 + 1], 1) / 1e3, pr[2 * 54] / 1e9, pr[2 * 55] / max(pr[2 * 55 + 1], 1) / 1e3, pr[2 * 55] / 1e9))
     print("  large fuse calls that ran on shortened lists (eh_fuse_red.h): %d (finding + making the cuts: mean %.0f kcyc), that found no cut worth it: %d (mean %.0f kcyc)   # fuse_red" % (
         pr[2 * 97 + 1], pr[2 * 97] / max(pr[2 * 97 + 1], 1) / 1e3, pr[2 * 98 + 1], pr[2 * 98] / max(pr[2 * 98 + 1], 1) / 1e3))
     print("  sgm tokenizer replays of periodic documents: %d, tokens written by them: %d" % (pr[2 * 94 + 1], pr[2 * 94]))
