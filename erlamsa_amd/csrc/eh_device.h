@@ -302,6 +302,7 @@ constexpr int MAX_NEST = 6;         // nested scheduler calls (b64 / sgm / js in
 constexpr int LEX_LEVELS = MAX_NEST + 1;
 constexpr int ST_STATE_WORDS = 84;  // sizeof(StState) / 4 (eh_text.h; checked there)
 #define EH_SET_OVERFLOW(c, site) ((c).ovf_line = (site), (c).ovf_need = 0, (c).ovf_req = 0, (c).status = CASE_OVERFLOW)
+struct MuFrame;
 struct Ctx {
   Rng rng;
   const EH_G KParams* p;
@@ -326,6 +327,11 @@ struct Ctx {
   bptr trace;      // EH_FLAG_META_TRACE: the case's event bytes (slot memory), nullptr = off
   uint32_t ntrace, tr_base;   // bytes written; where the Meta list in hand begins (tr_drop_before)
   uint32_t co_posted;  // the case has posted a loop for other wavefronts (counted in CoBoard::posters until it ends)
+  // nested scheduler calls without device recursion (mux_fuzzers): what a mutator that wants Muta([Bin], []) run leaves for the scheduler,
+  // and what the scheduler leaves for the mutator when it calls it again
+  int32_t call_req, mu_phase, call_nres, call_nfs;
+  uint64_t call_bin; uint32_t call_len;
+  EH_G MuFrame* mu;
   uint64_t t_case;     // cycle stamp at which the case began (mux_fuzzers raises the wavefront's issue priority for cases that run long)
   int32_t m_aux;       // set by the mutators whose own Meta entry does not follow from their result alone (num: a number found; ab / ad: stringy)
   uint64_t ws_peak, ws_top;   // diagnostics: highest ws_used, bytes taken from the top of chunks (eh_result_peak)
@@ -1102,98 +1108,185 @@ __device__ __noinline__ void own_meta_emit(uint32_t fn, int delta, uint32_t hlen
 }
 EH_DEV void own_meta(Ctx& c, uint32_t fn, int delta, uint32_t hlen) { if (__builtin_expect(c.trace != nullptr, 0)) own_meta_emit(fn, delta, hlen); }
 
-// One call of the mux_fuzzers closure on the list bl[cur..nb).
-EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
+// Nested scheduler calls WITHOUT device recursion.  base64_mutator, sgml_mutate and json_mutate run Muta([Bin], []) of a fresh
+// mutator list on pieces of their block (erlamsa_mutations.erl:667-670, erlamsa_sgml.erl:669-681, erlamsa_json.erl:633-639), and
+// the mutators down there may do the same - six levels deep at most.  Until round 5 that was a call chain through the scheduler
+// (muta_X -> nested_fuzz -> mux_fuzzers -> muta_X ...): device recursion, a stack the compiler cannot bound, hipLimitStackSize.
+// Now a mutator that wants a nested run RETURNS: it leaves the block, the nested table (one entry per lane) and its own loop state
+// in a MuFrame in work memory and sets call_req; the scheduler below parks the level it is at in an MxFrame, runs the nested level
+// in the same loop, and calls the mutator again with mu_phase = 1 and call_nres = the number of result blocks (at c.bl[c.nb ..),
+// or -1 with the status set).  The call graph has no cycle and the kernel's stack is what the assembler adds up.
+constexpr uint32_t NEST_SAVE = 720;                                          // StState x 2 + FoState (aux + 0 .. 720)
+struct MuFrame {                // a nesting mutator's locals across its nested runs + the table it wants run (v[23]: the MxFrame its nested runs park the level in)
+  uint64_t v[24];
+  uint32_t pri[64], meta[64];
+};
+struct MxFrame {                // a level of the scheduler that waits for a nested one
+  uint32_t e_pri[64], e_meta[64], rank[64];
+  uint32_t aux_save[NEST_SAVE / 4];   // lis / lrs / fo of the waiting level (aux + 0 .. 720): the nested table starts from fresh ones
+  uint32_t state[64];                 // MxState as it was (eh_device.h g_mx)
+};
+
+// One call of the mux_fuzzers closure on the list bl[cur..nb) - and every nested one it leads to.
+// The level in hand: what is the same for all lanes lives in LDS (as locals these two dozen values were live across every call of a
+// mutator and spilled: 200 scratch loads in the scheduler's loop, a measured 8 % of all wave cycles); lane tables and ranks stay in registers.
+struct MxState {
+  Rng rng0; uint64_t work0, mark, pt0; Blk h0;
+  int32_t nfs, r, tried, j, last_tier, delta; uint32_t meta, fn, ntrace0, dropped, stateful, pad;
+  // what a level that waits for a nested one goes back to (filled in when it is parked; the whole struct is parked and brought back
+  // by one lane-parallel copy)
+  uint64_t up, mu; int32_t lastm0, cur0, nb0, nfs0; uint32_t tr_base0, pad2;
+};
+static_assert(sizeof(MxState) % 4 == 0 && sizeof(MxState) <= 256, "MxState is copied one word per lane");
+__shared__ MxState g_mx;
+__device__ __noinline__ void mux_fuzzers(Ctx&, LaneTab& lt) {             // (ONE instance: the pattern code calls it from three places)
+  EH_CTX;
   const int l = EH_LANE;
-  if (c.nb - c.cur == 1 && blk_load(c.bl, c.cur).len == 0) return;   // L([<<>>], Meta)
-  if (c.nb - c.cur <= 0) { c.status = CASE_CRASHED; return; }
-  const int nfs = c.nfs;
-  // --- weighted_permutations: key_i = rand(trunc(Score*Pri)) in list order, lane-parallel jump-ahead
-  uint32_t nkey = (l < nfs) ? em_score(lt.e_meta) * lt.e_pri : 0;
-  unsigned long long drawing = __ballot(nkey > 0);
-  uint32_t my_idx = (uint32_t)__popcll(drawing & ((1ull << l) - 1));
-  uint32_t ndraw = (uint32_t)__popcll(drawing);
-  uint32_t key = 0;
-  if (nkey > 0) key = (uint32_t)(rng_peek(c.rng, my_idx + 1) * (double)nkey);
-  rng_skip(c.rng, ndraw);
-  // --- stable descending sort => rank per lane
-  uint32_t rank = 0;
-  for (int j = 0; j < nfs; j++) {
-    uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
-    rank += (kj > key || (kj == key && j < l)) ? 1u : 0u;
-  }
-  // A case that has been running for long decides when its pass ends (one wavefront, seconds): from 20 M cycles on its wavefront
-  // issues ahead of the other wavefront of its SIMD (s_setprio; the ticket loop puts it back when the case is done).
+  EH_G MxFrame* up = nullptr;                                                // the level that waits for the one in hand (nullptr: the pattern's call)
+  uint32_t e_pri = lt.e_pri, e_meta = lt.e_meta, rank = 0;
+  MxState& m = g_mx;
+  enum { S_ENTER, S_ATTEMPT, S_RUN, S_AFTER, S_FINISH, S_LEAVE };
+  int st = S_ENTER;
+  for (;;) {
+    if (st == S_ENTER) {
+      if (c.nb - c.cur == 1 && blk_load(c.bl, c.cur).len == 0) { st = S_LEAVE; continue; }   // L([<<>>], Meta)
+      if (c.nb - c.cur <= 0) { c.status = CASE_CRASHED; st = S_LEAVE; continue; }
+      m.nfs = c.nfs;
+      // --- weighted_permutations: key_i = rand(trunc(Score*Pri)) in list order, lane-parallel jump-ahead
+      uint32_t nkey = (l < m.nfs) ? em_score(e_meta) * e_pri : 0;
+      unsigned long long drawing = __ballot(nkey > 0);
+      uint32_t my_idx = (uint32_t)__popcll(drawing & ((1ull << l) - 1));
+      uint32_t ndraw = (uint32_t)__popcll(drawing);
+      uint32_t key = 0;
+      if (nkey > 0) key = (uint32_t)(rng_peek(c.rng, my_idx + 1) * (double)nkey);
+      rng_skip(c.rng, ndraw);
+      // --- stable descending sort => rank per lane
+      rank = 0;
+      for (int q = 0; q < m.nfs; q++) {
+        uint32_t kq = (uint32_t)__builtin_amdgcn_readlane((int)key, q);
+        rank += (kq > key || (kq == key && q < l)) ? 1u : 0u;
+      }
+      // A case that has been running for long decides when its pass ends (one wavefront, seconds): from 20 M cycles on its wavefront
+      // issues ahead of the other wavefront of its SIMD (s_setprio; the ticket loop puts it back when the case is done).
 #ifndef HIPEMU
-  if (__builtin_readcyclecounter() - c.t_case > 20000000ull) __builtin_amdgcn_s_setprio(3);
+      if (__builtin_readcyclecounter() - c.t_case > 20000000ull) __builtin_amdgcn_s_setprio(3);
 #endif
-  // --- mux_fuzzers_loop
-  int tried = 0; bool used = false; bool dropped = false;
-  Blk h0 = blk_load(c.bl, c.cur);
-  for (int r = 0; r < nfs; r++) {
-    if (h0.len > ABSMAX_BINARY_BLOCK) { dropped = true; tr_ai(c, AT_skipped_big, (int64_t)h0.len); break; }   // [{skipped_big, byte_size(H)} | Meta] :1269-1270
-    unsigned long long who = __ballot(l < nfs && rank == (uint32_t)r);
-    int j = (int)__builtin_ctzll(who);
-    uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)lt.e_meta, j);
-    uint32_t fn = em_fn(meta), name = em_name(meta);
-    c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
-    uint64_t mark = c.ws_used;
-    // work budget: the reference kills a worker after maxrunningtime and records <<>>
-    // (erlamsa_main.erl:211-220); the engine's deterministic analogue counts bytes
-    if (c.work_budget) {                                                          // optional (eh_options.max_case_work, 0 = off)
-      c.work += (uint64_t)h0.len * work_weight(fn);
-      if (c.work > c.work_budget) { c.status = CASE_BUDGET; return; }
+      // --- mux_fuzzers_loop
+      m.tried = 0; m.dropped = false; m.r = 0;
+      m.h0 = blk_load(c.bl, c.cur);
+      st = S_ATTEMPT;
     }
-#ifdef EH_PROF
-    uint64_t pt0 = __builtin_readcyclecounter();
-#endif
-    // An attempt that runs out of work memory is repeated — that attempt only, from the same PRNG state — after the case
-    // has borrowed a larger area (ws_regrow).  lis / lrs update their store before they allocate: it is put back as well.
-    const Rng rng0 = c.rng; const uint64_t work0 = c.work; const uint32_t ntrace0 = c.ntrace;
-    const bool stateful = fn == M_LIS || fn == M_LRS;
-    if (stateful) { cwptr ax = (cwptr)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) g_st_save[i] = ax[i]; }
-    int delta, last_tier = 0;
-    for (;;) {
-      delta = run_mutator(c, fn, em_mask(meta));
-      if (c.status != CASE_OVERFLOW || c.ovf_need == 0) break;
-      wave_sync();
-      if (!ws_regrow(c, mark, &last_tier)) break;
-      lex_forget_from(c, mark);
-      c.rng = rng0; c.work = work0; c.ntrace = ntrace0;
+    if (st == S_ATTEMPT) {
+      if (m.r >= m.nfs) { st = S_FINISH; continue; }
+      if (m.h0.len > ABSMAX_BINARY_BLOCK) { m.dropped = true; tr_ai(c, AT_skipped_big, (int64_t)m.h0.len); st = S_FINISH; continue; }   // [{skipped_big, byte_size(H)} | Meta] :1269-1270
+      unsigned long long who = __ballot(l < m.nfs && rank == (uint32_t)m.r);
+      m.j = (int)__builtin_ctzll(who);
+      m.meta = (uint32_t)__builtin_amdgcn_readlane((int)e_meta, m.j);
+      m.fn = em_fn(m.meta);
       c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
-      if (stateful) { lanes_sync(); wptr ax = (wptr)c.aux + (fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) ax[i] = g_st_save[i]; }
-      wave_sync();
-    }
+      m.mark = c.ws_used;
+      // work budget: the reference kills a worker after maxrunningtime and records <<>>
+      // (erlamsa_main.erl:211-220); the engine's deterministic analogue counts bytes
+      if (c.work_budget) {                                                          // optional (eh_options.max_case_work, 0 = off)
+        c.work += (uint64_t)m.h0.len * work_weight(m.fn);
+        if (c.work > c.work_budget) { c.status = CASE_BUDGET; st = S_LEAVE; continue; }
+      }
 #ifdef EH_PROF
-    if (l == 0) { atomicAdd(&c.p->prof[2 * fn], (unsigned long long)(__builtin_readcyclecounter() - pt0)); atomicAdd(&c.p->prof[2 * fn + 1], 1ull); }
+      m.pt0 = __builtin_readcyclecounter();
 #endif
-    if (c.status != CASE_OK) return;
-    // adjust_priority :1238-1242
-    uint32_t sc = em_score(meta);
-    if (delta != 0) { int ns = (int)sc + delta; ns = ns < 2 ? 2 : (ns > 10 ? 10 : ns); sc = (uint32_t)ns; }
-    uint32_t nfn = (fn == M_URI) ? (uint32_t)M_B64 : fn;                          // :784 (sic)
-    if (l == j) lt.e_meta = em_pack(sc, nfn, name, em_mask(meta));
-    tried++;
-    bool changed = false;
-    if (c.r_kind == R_NEW) {
-      wave_sync();                                                                  // candidate bytes were written by other lanes
-      uint32_t hd_len = c.r_flush && c.r_len >= AVG_BLOCK_SIZE ? AVG_BLOCK_SIZE : c.r_len;
-      changed = c.r_changed || hd_len != h0.len || !wave_equal(c.r_ptr, (cbptr)h0.ptr, hd_len);
+      // An attempt that runs out of work memory is repeated — that attempt only, from the same PRNG state — after the case
+      // has borrowed a larger area (ws_regrow).  lis / lrs update their store before they allocate: it is put back as well.
+      m.rng0 = c.rng; m.work0 = c.work; m.ntrace0 = c.ntrace;
+      m.stateful = m.fn == M_LIS || m.fn == M_LRS;
+      if (m.stateful) { cwptr ax = (cwptr)c.aux + (m.fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) g_st_save[i] = ax[i]; }
+      m.last_tier = 0;
+      c.mu_phase = 0; c.mu = nullptr;
+      st = S_RUN;
     }
+    if (st == S_RUN) {
+      c.call_req = 0;
+      m.delta = run_mutator(c, m.fn, em_mask(m.meta));
+      if (c.call_req && c.status == CASE_OK) {
+        // ---- the mutator wants Muta([Bin], []) run: park this level, set the nested one up (the inner list [Bin] lives above the
+        // outer block list; lis / lrs / fo of the inner table start from their initial state, as the closures of a fresh
+        // mutators_mutator/1 do - the outer states are parked in the work area for the duration of the nested level)
+        EH_G MxFrame* f = nullptr;
+        if (c.depth >= MAX_NEST || c.nb + 2 > MAX_BLOCKS) EH_SET_OVERFLOW(c, 301);
+        else {                                                                 // (one frame per attempt, however many nested runs it makes)
+          f = (EH_G MxFrame*)uni64(c.mu->v[23]);
+          if (!f) { f = (EH_G MxFrame*)ws_alloc(c, sizeof(MxFrame)); if (f && l == 0) c.mu->v[23] = (uint64_t)f; }
+        }
+        if (f) {
+          EH_G uint32_t* save = f->aux_save;
+          f->e_pri[l] = e_pri; f->e_meta[l] = e_meta; f->rank[l] = rank;
+          EH_G uint32_t* ax = (EH_G uint32_t*)c.aux;
+          for (uint32_t i = l; i < NEST_SAVE / 4; i += 64) save[i] = ax[i];
+          m.up = (uint64_t)up; m.mu = (uint64_t)c.mu; m.lastm0 = c.lastm; m.tr_base0 = c.tr_base; m.cur0 = c.cur; m.nb0 = c.nb; m.nfs0 = c.nfs;
+          lanes_sync();
+          if ((uint32_t)l < sizeof(MxState) / 4) f->state[l] = ((const uint32_t*)&m)[l];
+          wave_sync();
+          // (StState[0].count, StState[1].count, FoState::has: eh_text.h, eh_fuse.h - the same offsets the reclaim test below reads)
+          if (l == 0) { ((EH_G int32_t*)c.aux)[0] = 0; ((EH_G int32_t*)(c.aux + 4 * ST_STATE_WORDS))[0] = 0; ((EH_G uint32_t*)(c.aux + 704))[3] = 0; }
+          const int nb0 = c.nb;
+          blk_store(c.bl, nb0, c.call_bin, c.call_len);
+          e_pri = c.mu->pri[l]; e_meta = c.mu->meta[l];                        // the nested table, lane i = list position i
+          wave_sync();
+          c.cur = nb0; c.nb = nb0 + 1; c.nfs = c.call_nfs; c.depth++;
+          c.tr_base = c.ntrace;                                                // Muta([Bin], []): a Meta list of its own
+          c.lex_ptr[c.depth] = 0;                                              // this level's last lexed block was a temporary of an earlier call
+          if (l == 0) lex_slot(c).n = -1;
+          up = f;
+          st = S_ENTER;
+          continue;
+        }
+        // (no room for the frame, or nested too deep: the attempt ends like one whose mutator ran out of memory)
+      }
+      if (c.status == CASE_OVERFLOW && c.ovf_need != 0) {
+        wave_sync();
+        if (ws_regrow(c, m.mark, &m.last_tier)) {
+          lex_forget_from(c, m.mark);
+          c.rng = m.rng0; c.work = m.work0; c.ntrace = m.ntrace0;
+          c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
+          if (m.stateful) { lanes_sync(); wptr ax = (wptr)c.aux + (m.fn == M_LRS ? ST_STATE_WORDS : 0); for (int i = l; i < ST_STATE_WORDS; i += 64) ax[i] = g_st_save[i]; }
+          wave_sync();
+          c.mu_phase = 0; c.mu = nullptr;
+          continue;                                                            // (st == S_RUN: the same attempt once more)
+        }
+      }
+      st = S_AFTER;
+    }
+    if (st == S_AFTER) {
+#ifdef EH_PROF
+      if (l == 0) { atomicAdd(&c.p->prof[2 * m.fn], (unsigned long long)(__builtin_readcyclecounter() - m.pt0)); atomicAdd(&c.p->prof[2 * m.fn + 1], 1ull); }
+#endif
+      if (c.status != CASE_OK) { st = S_LEAVE; continue; }
+      const uint32_t name = em_name(m.meta);
+      // adjust_priority :1238-1242
+      uint32_t sc = em_score(m.meta);
+      if (m.delta != 0) { int ns = (int)sc + m.delta; ns = ns < 2 ? 2 : (ns > 10 ? 10 : ns); sc = (uint32_t)ns; }
+      uint32_t nfn = (m.fn == M_URI) ? (uint32_t)M_B64 : m.fn;                          // :784 (sic)
+      if (l == m.j) e_meta = em_pack(sc, nfn, name, em_mask(m.meta));
+      m.tried++;
+      bool changed = false;
+      if (c.r_kind == R_NEW) {
+        wave_sync();                                                                  // candidate bytes were written by other lanes
+        uint32_t hd_len = c.r_flush && c.r_len >= AVG_BLOCK_SIZE ? AVG_BLOCK_SIZE : c.r_len;
+        changed = c.r_changed || hd_len != m.h0.len || !wave_equal(c.r_ptr, (cbptr)m.h0.ptr, hd_len);
+      }
 #ifdef EH_PROF
     // work memory an attempt took (what it wrote, nearly: candidates, tables, temporaries): slot 56 attempts that failed, 57 the candidates
     // that were used, 58 what the used attempts took besides their candidate (eh_result_prof; the write traffic's breakdown)
     if (l == 0) {
-      const unsigned long long took = c.ws_used > mark ? c.ws_used - mark : 0ull, cand = c.r_kind == R_NEW ? c.r_len : 0u;
+      const unsigned long long took = c.ws_used > m.mark ? c.ws_used - m.mark : 0ull, cand = c.r_kind == R_NEW ? c.r_len : 0u;
       if (changed) { atomicAdd(&c.p->prof[2 * 57], cand); atomicAdd(&c.p->prof[2 * 57 + 1], 1ull); atomicAdd(&c.p->prof[2 * 58], took > cand ? took - cand : 0ull); atomicAdd(&c.p->prof[2 * 58 + 1], 1ull); }
       else { atomicAdd(&c.p->prof[2 * 56], took); atomicAdd(&c.p->prof[2 * 56 + 1], 1ull); }
     }
 #endif
-    own_meta(c, fn, delta, h0.len);                                                // the mutator's own entry is in the Meta it returns, used or failed
-    tr_aa(c, changed ? AT_used : AT_failed, (int)name);                            // {used, Name} / {failed, Name} :1278-1279
-    if (changed) {
+      own_meta(c, m.fn, m.delta, m.h0.len);                                                // the mutator's own entry is in the Meta it returns, used or failed
+      tr_aa(c, changed ? AT_used : AT_failed, (int)name);                            // {used, Name} / {failed, Name} :1278-1279
+      if (changed) {
       c.lastm = (int)name;
-      // Reclaim work memory before committing: everything between `mark` and the candidate is a
+      // Reclaim work memory before committing: everything between `m.mark` and the candidate is a
       // dead temporary, and the block being replaced is dead too when it is the newest committed
       // allocation and no mutator state (lis/lrs lines, fo block) can point into it.  The
       // candidate slides down (ascending copy, dst < src) so that chains of mutations on one block
@@ -1204,14 +1297,14 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
       // The attempt went on in areas borrowed from the pool (it ran out of memory and was repeated): when the candidate
       // fits where the attempt began, it moves there and the areas go back at once — most borrowers are fuse calls whose
       // tables need tens of megabytes for a result of one or two.
-      if (c.nchunk > 0 && mark <= c.ch_vstart[c.nchunk] && !c.r2) {
-        int j = c.nchunk;
-        while (j > 0 && mark <= c.ch_vstart[j]) j--;
+      if (c.nchunk > 0 && m.mark <= c.ch_vstart[c.nchunk] && !c.r2) {
+        int jc = c.nchunk;
+        while (jc > 0 && m.mark <= c.ch_vstart[jc]) jc--;
         const uint64_t need = ((uint64_t)c.r_len + 15) & ~(uint64_t)15;
-        if (mark + need <= c.ch_vend[j]) {
-          bptr dst = c.ch_base[j] + mark;
+        if (m.mark + need <= c.ch_vend[jc]) {
+          bptr dst = c.ch_base[jc] + m.mark;
           // (the candidate is not always up in a borrowed area: a chunk the PATTERN borrowed for its scans - pick_csum,
-          // pick_simple_len - and gave back by resetting ws_used starts exactly at mark, and the attempt then ran in the chunk
+          // pick_simple_len - and gave back by resetting ws_used starts exactly at m.mark, and the attempt then ran in the chunk
           // below it, a few bytes above dst: overlapping ranges, which wave_copy must not be given)
           if (dst != c.r_ptr) {
             wave_sync();
@@ -1219,45 +1312,77 @@ EH_DEV void mux_fuzzers(Ctx& c, LaneTab& lt) {
             wave_sync();
           }
           c.r_ptr = dst;
-          ws_release_to(c, mark);
-          c.ws_used = mark + need;
+          ws_release_to(c, m.mark);
+          c.ws_used = m.mark + need;
           if (c.ws_used > c.ws_peak) c.ws_peak = c.ws_used;
         }
       }
-      bptr lo = c.ws + mark;
+      bptr lo = c.ws + m.mark;
       // A candidate of more than a few MiB stays where it is: mux_fuzzers never hands out a block above
       // ABSMAX_BINARY_BLOCK again (:1269, split_into_maxblocks), so nothing will copy it as a whole any more, and sliding
-      // a 1 GiB tree-stutter result took a lone wavefront 0.7 s.  (mark below the chunk the candidate is in: the attempt
+      // a 1 GiB tree-stutter result took a lone wavefront 0.7 s.  (m.mark below the chunk the candidate is in: the attempt
       // went on in the next area up; not worth a copy across areas.)
       const uint64_t vs = c.ws_lo;
-      if (mark >= vs && c.ws_used - vs > (c.ws_cap - vs) / 8 && c.r_len <= (4u << 20) && !c.r2 && c.r_ptr >= lo && c.r_ptr + c.r_len <= c.ws + c.ws_used) {
+      if (m.mark >= vs && c.ws_used - vs > (c.ws_cap - vs) / 8 && c.r_len <= (4u << 20) && !c.r2 && c.r_ptr >= lo && c.r_ptr + c.r_len <= c.ws + c.ws_used) {
         bptr dst = lo;
-        bptr hp = (bptr)h0.ptr;
+        bptr hp = (bptr)m.h0.ptr;
         bool state_refs = uni(((cwptr)c.aux)[0]) != 0 || uni(((cwptr)(c.aux + 336))[0]) != 0 || uni(((cwptr)(c.aux + 704))[3]) != 0;
-        if (!state_refs && hp >= c.ws + vs && hp + ((h0.len + 15u) & ~15u) == lo && ((uintptr_t)hp & 15) == 0) dst = hp;
+        if (!state_refs && hp >= c.ws + vs && hp + ((m.h0.len + 15u) & ~15u) == lo && ((uintptr_t)hp & 15) == 0) dst = hp;
         if (dst != c.r_ptr) { wave_sync(); wave_move_down(dst, c.r_ptr, c.r_len); wave_sync(); c.r_ptr = dst; }   // candidate stores must have landed
         c.ws_used = (uint64_t)(dst - c.ws) + (((uint64_t)c.r_len + 15) & ~(uint64_t)15);
         lex_forget_from(c, (uint64_t)(dst - c.ws));                               // (H's own memory included when the candidate took its place)
       }
-      commit_result(c); used = true; break;
+        commit_result(c); st = S_FINISH; continue;
+      }
+      if (c.nchunk > 0) ws_release_to(c, m.mark); else c.ws_used = m.mark;              // discard candidate
+      lex_forget_from(c, m.mark);
+      m.r++;
+      st = S_ATTEMPT;
+      continue;
     }
-    if (c.nchunk > 0) ws_release_to(c, mark); else c.ws_used = mark;              // discard candidate
-    lex_forget_from(c, mark);
+    if (st == S_FINISH) {
+      // --- new list: reverse(m.tried) ++ untried (sorted order)   :1268,1270,1279
+      // m.dropped (:1270): the entry at sorted position `m.tried` leaves the list.
+      int newpos = l;
+      if (l < m.nfs) {
+        int rk = (int)rank;
+        if (rk < m.tried) newpos = m.tried - 1 - rk;
+        else if (!m.dropped) newpos = rk;
+        else newpos = rk == m.tried ? m.nfs - 1 : rk - 1;
+      }
+      // ds_permute (forward): lane i sends its value to lane newpos (a bijection)
+      e_meta = (uint32_t)__builtin_amdgcn_ds_permute(newpos << 2, (int)e_meta);
+      e_pri = (uint32_t)__builtin_amdgcn_ds_permute(newpos << 2, (int)e_pri);
+      if (m.dropped) c.nfs = m.nfs - 1;
+      st = S_LEAVE;
+    }
+    // S_LEAVE
+    if (!up) { lt.e_pri = e_pri; lt.e_meta = e_meta; return; }
+    {
+      // ---- a nested level is over: its result blocks are bl[cur..nb); back to the level that waits, whose mutator goes on
+      EH_G MxFrame* f = up;
+      c.depth--;
+      const int nres = c.nb - c.cur;
+      wave_sync();
+      EH_G uint32_t* ax = (EH_G uint32_t*)c.aux; const EH_G uint32_t* save = f->aux_save;
+      for (uint32_t i = l; i < NEST_SAVE / 4; i += 64) ax[i] = save[i];
+      lanes_sync();
+#ifdef HIPEMU
+      for (uint32_t k = 0; k < sizeof(MxState) / 4; k++) ((uint32_t*)&m)[k] = f->state[k];   // (the emulator keeps a copy of the LDS per lane)
+#else
+      if ((uint32_t)l < sizeof(MxState) / 4) ((uint32_t*)&m)[l] = f->state[l];
+#endif
+      e_pri = f->e_pri[l]; e_meta = f->e_meta[l]; rank = f->rank[l];
+      wave_sync();
+      c.tr_base = m.tr_base0;
+      c.cur = m.cur0; c.nb = m.nb0; c.nfs = m.nfs0; c.lastm = m.lastm0;
+      c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
+      c.call_nres = c.status == CASE_OK ? nres : -1;
+      c.mu = (EH_G MuFrame*)m.mu; c.mu_phase = 1;
+      up = (EH_G MxFrame*)m.up;
+      st = S_RUN;
+    }
   }
-  // --- new list: reverse(tried) ++ untried (sorted order)   :1268,1270,1279
-  // dropped (:1270): the entry at sorted position `tried` leaves the list.
-  (void)used;
-  int newpos = l;
-  if (l < nfs) {
-    int rk = (int)rank;
-    if (rk < tried) newpos = tried - 1 - rk;
-    else if (!dropped) newpos = rk;
-    else newpos = rk == tried ? nfs - 1 : rk - 1;
-  }
-  // ds_permute (forward): lane i sends its value to lane newpos (a bijection)
-  lt.e_meta = (uint32_t)__builtin_amdgcn_ds_permute(newpos << 2, (int)lt.e_meta);
-  lt.e_pri = (uint32_t)__builtin_amdgcn_ds_permute(newpos << 2, (int)lt.e_pri);
-  if (dropped) c.nfs = nfs - 1;
 }
 
 }  // namespace eh

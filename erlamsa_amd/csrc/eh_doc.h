@@ -143,19 +143,25 @@ EH_DEV bool pieces_materialize(Ctx& c, const EH_G Piece* t, uint32_t a, uint32_t
 // number of bytes of [p, p+n) that are not 0, 10, 13 or 32 (mutate_innertext, erlamsa_sgml.erl:675)
 struct IsInk { EH_DEV bool operator()(uint32_t b, uint32_t) const { return b != 0 && b != 10 && b != 13 && b != 32; } };
 
-// Muta([Bin], []) of a freshly scored mutator list: the nested scheduler call of base64_mutator
-// (erlamsa_mutations.erl:669-670), erlamsa_sgml:mutate_innertext_prob/4 (:669-672) and
-// erlamsa_json:mutate_innertext_prob/4 (:633-639).  Lane i holds entry i of the list.  Returns the number
-// of blocks of the resulting list, which sit at c.bl[c.nb .. c.nb + n) until the next nested call, or -1
-// with c.status set.  Defined in eh_engine.hip (it re-enters mux_fuzzers; real device recursion).
-__device__ int nested_fuzz(Ctx&, uint32_t e_pri, uint32_t e_meta, int nfs, cbptr bin, uint32_t len);
+// Muta([Bin], []) of a freshly scored mutator list - the nested scheduler call of base64_mutator (erlamsa_mutations.erl:669-670),
+// erlamsa_sgml:mutate_innertext_prob/4 (:669-672) and erlamsa_json:mutate_innertext_prob/4 (:633-639) - is run by the scheduler
+// itself: the mutator puts the table (lane i = entry i) into its MuFrame, sets c.call_req / call_bin / call_len / call_nfs and
+// returns; it is called again with c.mu_phase == 1 and c.call_nres = the number of blocks of the resulting list, which sit at
+// c.bl[c.nb .. c.nb + n), or -1 with c.status set (eh_device.h mux_fuzzers).
+EH_DEV EH_G MuFrame* mu_frame(Ctx& c) {                                    // the running attempt's frame (made at its first nested run)
+  if (c.mu) return c.mu;
+  EH_G MuFrame* m = (EH_G MuFrame*)ws_alloc(c, sizeof(MuFrame));
+  if (m && EH_LANE == 0) m->v[23] = 0;
+  c.mu = m;
+  return m;
+}
 
 __constant__ uint8_t c_def_pri[M_COUNT] = {10, 3, 1, 2, 1, 1, 1, 1, 3, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 2, 2, 7, 1, 1, 0};
 
 // inner_mutations(sgml | json) (erlamsa_mutations.erl:1342-1356) + mutators_mutator/1 (:1387-1395):
 // mutations([]) is evaluated first (2 draws, :1313-1314), the filtered table is folded into reverse
 // table order, mutators_mutator draws rand(10) along that list and prepends => list in table order.
-EH_DEV void inner_table(Ctx& c, bool json, uint32_t* e_pri, uint32_t* e_meta, int* nfs) {
+EH_DEV void inner_table(Ctx& c, bool json, EH_G MuFrame* mu, int* nfs) {
   const int l = EH_LANE;
   (void)rng_rand(c.rng, 3); (void)rng_rand(c.rng, 1);
   const uint8_t sg[11] = {M_AB, M_AD, M_NUM, M_BD, M_SD, M_LD, M_LRI, M_LR, M_LP, M_B64, M_URI};
@@ -167,63 +173,86 @@ EH_DEV void inner_table(Ctx& c, bool json, uint32_t* e_pri, uint32_t* e_meta, in
   uint32_t score = 0;
   if (l < n) { uint32_t v = (uint32_t)(rng_peek(c.rng, (uint32_t)(n - 1 - l) + 1) * 10.0); score = v < 2 ? 2 : v; }
   rng_skip(c.rng, (uint64_t)n);
-  *e_pri = l < n ? (uint32_t)c_def_pri[name] : 0;
-  *e_meta = em_pack(score, name, name, 3u);
+  mu->pri[l] = l < n ? (uint32_t)c_def_pri[name] : 0;
+  mu->meta[l] = em_pack(score, name, name, 3u);
   *nfs = n;
 }
 
 // base64_mutator/2 (erlamsa_mutations.erl:658-690): every text chunk longer than 6 that base64:decode/1 accepts
 // is decoded, mutated once by a FRESH mutators_mutator over the whole default table (mutas_list(mutations([])):
 // 2 draws for the table itself, then 41 score draws per chunk, list in REVERSE table order) and encoded again.
+// The nested run is the scheduler's (mux_fuzzers, "nested scheduler calls without device recursion"): at a chunk the function leaves
+// its loop state in its MuFrame and returns with call_req set; it is called again (mu_phase 1) with the result blocks.
 __device__ __noinline__ int muta_b64(Ctx&, EH_G LexCache& lc) {
   EH_CTX;
   const int l = EH_LANE;
   Blk hb = blk_load(c.bl, c.cur);
   cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
-  EH_G LexChunk* tab;
+  EH_G LexChunk* tab = nullptr;
+  int n = 0, base = 0, dacc = -1, d = 0;
+  uint32_t snand_mask = 0, nout = 0, cap = 0, done_to = 0, a = 0, b = 0;
+  unsigned long long cand = 0;
+  EH_G Piece* out = nullptr;
+  bool resume = c.mu_phase == 1;
+  EH_G MuFrame* mu = c.mu;
   EH_PT0;
-  int n = lex_cached(c, lc, H, L, &tab);
-  if (n < 0) return 0;
-  EH_PT(c, 48);                                                  // eh_result_prof 48..53: lexing, candidates refused, decode, nested call, encode, gather
-  uint32_t snand_mask = rng_rand(c.rng, 3); (void)rng_rand(c.rng, 1);   // mutations([]) :661 -> :1313-1314
-  EH_G Piece* out = nullptr; uint32_t nout = 0, cap = 0, done_to = 0;
-  int dacc = -1;
+  if (!resume) {
+    n = lex_cached(c, lc, H, L, &tab);
+    if (n < 0) return 0;
+    EH_PT(c, 48);                                                // eh_result_prof 48..53: lexing, candidates refused, decode, nested call, encode, gather
+    snand_mask = rng_rand(c.rng, 3); (void)rng_rand(c.rng, 1);   // mutations([]) :661 -> :1313-1314
+  } else {
+    tab = (EH_G LexChunk*)uni64(mu->v[0]); n = (int)uni((uint32_t)mu->v[1]); base = (int)uni((uint32_t)mu->v[2]); cand = uni64(mu->v[3]);
+    snand_mask = uni((uint32_t)mu->v[4]); nout = uni((uint32_t)mu->v[5]); cap = uni((uint32_t)mu->v[6]); done_to = uni((uint32_t)mu->v[7]);
+    a = uni((uint32_t)mu->v[8]); b = uni((uint32_t)mu->v[9]); dacc = (int)uni((uint32_t)mu->v[10]); d = (int)uni((uint32_t)mu->v[11]);
+    out = (EH_G Piece*)uni64(mu->v[12]);
+  }
   // candidate chunks ({text, A} when length(A) > 6, :664) are picked 64 table entries at a time
-  for (int base = 0; base < n; base += 64) {
+  for (; base < n; base += 64) {
    int ti = base + l;
    uint32_t cty = 1, ca = 0, cb = 0;
    if (ti < n) { LexChunk e = tab[ti]; cty = e.type; ca = e.a; cb = e.b; }
-   unsigned long long cand = __ballot(cty == 0 && cb - ca > 6);
-   while (cand) {
-    int cj = (int)__builtin_ctzll(cand); cand &= cand - 1;
-    int i = base + cj;
-    uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)ca, cj), b = (uint32_t)__builtin_amdgcn_readlane((int)cb, cj);
-    uint32_t nalpha, span;
-    if (!b64_accepts(H + a, b - a, &nalpha, &span)) continue;    // error:badarg / function_clause :677-684
-    uint32_t dl = b64_decoded_len(nalpha);
-    if (!out) {                                                  // first hit: the piece list of unlex(Ms)
-      cap = 2 * (uint32_t)(n - i) + 4;
-      out = (EH_G Piece*)ws_alloc(c, (uint64_t)cap * sizeof(Piece));
-      if (!out) return 0;
+   if (!resume) cand = __ballot(cty == 0 && cb - ca > 6);
+   while (cand || resume) {
+    if (!resume) {
+      int cj = (int)__builtin_ctzll(cand); cand &= cand - 1;
+      a = (uint32_t)__builtin_amdgcn_readlane((int)ca, cj); b = (uint32_t)__builtin_amdgcn_readlane((int)cb, cj);
+      uint32_t nalpha, span;
+      if (!b64_accepts(H + a, b - a, &nalpha, &span)) continue;    // error:badarg / function_clause :677-684
+      uint32_t dl = b64_decoded_len(nalpha);
+      if (!out) {                                                  // first hit: the piece list of unlex(Ms)
+        cap = 2 * (uint32_t)(n - (base + cj)) + 4;
+        out = (EH_G Piece*)ws_alloc(c, (uint64_t)cap * sizeof(Piece));
+        if (!out) return 0;
+      }
+      if (!mu) { mu = mu_frame(c); if (!mu) return 0; }
+      bptr dec = ws_alloc(c, (uint64_t)dl + 16);
+      bptr pack = nalpha != span ? ws_alloc(c, (uint64_t)nalpha + 16) : nullptr;
+      if (!dec || (nalpha != span && !pack)) return 0;
+      EH_PT(c, 49);
+      b64_decode_wave(H + a, span, nalpha, dec, pack);
+      wave_sync();
+      EH_PT(c, 50);
+      d = rng_delta(c.rng);                                        // :666
+      tr_ai(c, AT_base64_mutator, d);                              // [AddedMeta, {base64_mutator, D} | MAcc] :674: D's entry, then what the nested run adds
+      // mutators_mutator(MutasList, []) :667: rand(10) per table entry in table order, each prepended
+      uint32_t name = l < (int)M_COUNT ? (uint32_t)((int)M_COUNT - 1 - l) : 0;
+      uint32_t score = 0;
+      if (l < (int)M_COUNT) { uint32_t v = (uint32_t)(rng_peek(c.rng, name + 1) * 10.0); score = v < 2 ? 2 : v; }
+      rng_skip(c.rng, (uint64_t)M_COUNT);
+      mu->pri[l] = l < (int)M_COUNT ? (uint32_t)c_def_pri[name] : 0;
+      mu->meta[l] = em_pack(score, name, name, name == M_SNAND ? snand_mask : 3u);
+      if (l == 0) {
+        mu->v[0] = (uint64_t)tab; mu->v[1] = (uint32_t)n; mu->v[2] = (uint32_t)base; mu->v[3] = cand; mu->v[4] = snand_mask; mu->v[5] = nout; mu->v[6] = cap;
+        mu->v[7] = done_to; mu->v[8] = a; mu->v[9] = b; mu->v[10] = (uint32_t)dacc; mu->v[11] = (uint32_t)d; mu->v[12] = (uint64_t)out;
+      }
+      wave_sync();
+      c.call_req = 1; c.call_bin = (uint64_t)dec; c.call_len = dl; c.call_nfs = (int)M_COUNT;      // Muta([Bin], []) :668
+      return 0;
     }
-    bptr dec = ws_alloc(c, (uint64_t)dl + 16);
-    bptr pack = nalpha != span ? ws_alloc(c, (uint64_t)nalpha + 16) : nullptr;
-    if (!dec || (nalpha != span && !pack)) return 0;
-    EH_PT(c, 49);
-    b64_decode_wave(H + a, span, nalpha, dec, pack);
-    wave_sync();
-    EH_PT(c, 50);
-    int d = rng_delta(c.rng);                                    // :666
-    tr_ai(c, AT_base64_mutator, d);                              // [AddedMeta, {base64_mutator, D} | MAcc] :674: D's entry, then what the nested run adds
-    // mutators_mutator(MutasList, []) :667: rand(10) per table entry in table order, each prepended
-    uint32_t name = l < (int)M_COUNT ? (uint32_t)((int)M_COUNT - 1 - l) : 0;
-    uint32_t score = 0;
-    if (l < (int)M_COUNT) { uint32_t v = (uint32_t)(rng_peek(c.rng, name + 1) * 10.0); score = v < 2 ? 2 : v; }
-    rng_skip(c.rng, (uint64_t)M_COUNT);
-    uint32_t e_pri = l < (int)M_COUNT ? (uint32_t)c_def_pri[name] : 0;
-    uint32_t e_meta = em_pack(score, name, name, name == M_SNAND ? snand_mask : 3u);
-    int nres = nested_fuzz(c, e_pri, e_meta, (int)M_COUNT, dec, dl);   // Muta([Bin], []) :668
+    resume = false;
+    const int nres = c.call_nres;
     if (nres < 0) return 0;
     EH_PT(c, 51);
     // NewBin = iolist_to_binary(NewLl) :669

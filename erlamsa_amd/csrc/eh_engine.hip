@@ -64,40 +64,6 @@ EH_DEV int run_mutator_ext(Ctx& c, uint32_t fn, uint32_t mask) {
   }
 }
 
-// Nested scheduler call (see eh_doc.h).  The inner list [Bin] lives above the outer block list; the stateful
-// mutators of the inner table (lis, lrs, fo) start from their initial state, as the closures of a fresh
-// mutators_mutator/1 do, so the outer states are parked in the work area for the duration of the call.
-__device__ __noinline__ int nested_fuzz(Ctx&, uint32_t e_pri, uint32_t e_meta, int nfs, cbptr bin, uint32_t len) {
-  EH_CTX;
-  const int l = EH_LANE;
-  if (c.depth >= MAX_NEST || c.nb + 2 > MAX_BLOCKS) { EH_SET_OVERFLOW(c, 301); return -1; }
-  constexpr uint32_t SAVE = 720;                                            // StState x 2 + FoState (aux + 0 .. 720)
-  wptr save = (wptr)ws_alloc(c, SAVE);
-  if (!save) return -1;
-  wptr ax = (wptr)c.aux;
-  for (uint32_t i = l; i < SAVE / 4; i += 64) save[i] = ax[i];
-  wave_sync();
-  if (l == 0) { ((EH_G StState*)c.aux)[0].count = 0; ((EH_G StState*)c.aux)[1].count = 0; ((EH_G FoState*)(c.aux + 704))->has = 0; }
-  const int cur0 = c.cur, nb0 = c.nb, nfs0 = c.nfs, lastm0 = c.lastm;
-  blk_store(c.bl, nb0, (uint64_t)bin, len);
-  wave_sync();
-  c.cur = nb0; c.nb = nb0 + 1; c.nfs = nfs; c.depth++;
-  const uint32_t tr_base0 = c.tr_base; c.tr_base = c.ntrace;                // Muta([Bin], []): a Meta list of its own
-  c.lex_ptr[c.depth] = 0;                                                  // this level's last lexed block was a temporary of an earlier call
-  if (l == 0) lex_slot(c).n = -1;
-  LaneTab lt; lt.e_pri = e_pri; lt.e_meta = e_meta;
-  mux_fuzzers(c, lt);
-  c.depth--;
-  c.tr_base = tr_base0;
-  int nres = c.nb - c.cur;
-  wave_sync();
-  for (uint32_t i = l; i < SAVE / 4; i += 64) ax[i] = save[i];
-  wave_sync();
-  c.cur = cur0; c.nb = nb0; c.nfs = nfs0; c.lastm = lastm0;
-  c.r_kind = R_SAME; c.r_flush = 0; c.r_drop_next = 0; c.r_changed = 0; c.r2 = 0;
-  return c.status == CASE_OK ? nres : -1;
-}
-
 // =============================================================================================
 // device: per-run setup  (erlamsa_main.erl:134-158)
 // =============================================================================================
@@ -1549,16 +1515,9 @@ int eh_create(int device, eh_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return EH_E_NODEVICE; }
   ctx->cus = prop.multiProcessorCount;
-  // eh_mutate_kernel recurses (nested scheduler calls of b64 / sgm / js, depth <= MAX_NEST).  Deepest chain, from the
-  // assembler's private_seg_size expressions (tools/stack_chain.py evaluates them; end of round 4): kernel 448 + MAX_NEST x
-  // (muta_b64 304 + nested_fuzz 384) + the heaviest leaf (muta_sgml 288 + sgml_tokenize 792) = 5 656 bytes per lane, 488
-  // below the limit set here.  The runtime sizes every hardware queue's scratch for all wavefront slots of the device
-  // at this size (16 KiB meant ~8 GiB per queue).
-  size_t stack_bytes = 6144, have = 0;
-  // only ever raised, and only when it has to be: changing the limit makes the runtime re-size the scratch of queues that
-  // may already exist (another context of this process, a co-resident torch)
-  if (hipDeviceGetLimit(&have, hipLimitStackSize) != hipSuccess) have = 0;
-  if (have < stack_bytes && hipDeviceSetLimit(hipLimitStackSize, stack_bytes) != hipSuccess) { delete ctx; return EH_E_HIP; }
+  // (Until round 5 the kernel recursed - nested scheduler calls of b64 / sgm / js - and eh_create raised hipLimitStackSize to 6 KiB per lane
+  // for the whole process.  The scheduler is a loop over explicit frames now (eh_device.h mux_fuzzers): the kernel's stack is the 1.8 KiB
+  // the assembler adds up, and no limit of the process is touched.)
   // (the constant tables - AS183 powers, CRC-32, funny_unicode/0 - are initialised in the code object: eh_device.h, eh_zlib.h)
   if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
     eh_destroy(ctx);

@@ -264,12 +264,119 @@ EH_DEV uint32_t js_find(const EH_G JNode* nd, uint32_t nn, uint32_t k, P pred) {
 struct JR { uint32_t i, p0, p1, nend, ctx, kind; };
 EH_DEV JR js_node(const EH_G JNode* nd, uint32_t i) { JNode n = nd[i]; JR r; r.i = i; r.p0 = uni(n.p0); r.p1 = uni(n.p1); r.nend = uni(n.nend); r.ctx = uni(n.ctx); r.kind = uni(n.kind); return r; }
 
+// the end of json_mutate/2: NewBinStr = fold_ast(..) :720 and its comparison with the block
+EH_DEV int json_finish(Ctx& c, cbptr H, uint32_t L, EH_G Piece* out, uint32_t nout, int D, uint32_t meta0) {
+  nout = pieces_coalesce(out, nout);
+  uint64_t total = pieces_total(out, nout);
+  if (total > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 402); return 0; }
+  bptr dst = ws_alloc(c, total ? total : 16);
+  if (!dst) return 0;
+  wave_gather(dst, out, nout);
+  wave_sync();
+  if ((uint32_t)total == L && wave_equal(dst, H, L)) { tr_drop_before(c, meta0); return -1; }   // NewBinStr =:= H: {fun json_mutate/2, Ll, NewMeta, -1} :722-723 - NewMeta ALONE
+  c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)total; c.r_changed = 1;
+  return D + (int)(total / (AVG_BLOCK_SIZE * 10));
+}
+
+// inner text / basic types :671-706: one draw per string / key / null / bool / number node; a string that is drawn gets a nested
+// scheduler call (mutate_innertext_prob/4 :633-639) - asked of the scheduler like sgml_inner asks (eh_sgml.h): the node's number is
+// left in the MuFrame, and the walk goes on behind it when the function is called again.  v[0..7]: what json_mutate had in hand.
+__device__ __noinline__ int json_inner(Ctx&, cbptr H, uint32_t L) {
+  EH_CTX;
+  const int l = EH_LANE;
+  EH_G MuFrame* mu = c.mu;
+  bool resume = c.mu_phase == 1;
+  EH_G JNode* nd = (EH_G JNode*)uni64(mu->v[0]); EH_G Piece* out = (EH_G Piece*)uni64(mu->v[2]);
+  const uint32_t nn = uni((uint32_t)mu->v[1]), nout = uni((uint32_t)mu->v[3]), N = uni((uint32_t)mu->v[4]), meta0 = uni((uint32_t)mu->v[6]);
+  const int D = (int)uni((uint32_t)mu->v[5]), nfs = (int)uni((uint32_t)mu->v[7]);
+  uint32_t i = uni((uint32_t)mu->v[8]);
+  {
+      const double dN = (double)N;
+      for (; i < nn; i++) {
+        JNode n = nd[i];
+        uint32_t kind = uni(n.kind), p0 = uni(n.p0), ctx = uni(n.ctx), a = uni(n.a), b = uni(n.b);
+        if (kind == J_STR) {                                               // {key, String} 0.6/N ; {string, String} 3/N
+          if (!resume) {
+            double prob = ctx == JX_KEY ? 0.6 / dN : 3.0 / dN;
+            double rnd = rng_uniform(c.rng);
+            if (rnd > prob) continue;                                      // mutate_innertext_prob/4 :633-639
+            if (l == 0) mu->v[8] = i;
+            wave_sync();
+            c.call_req = 1; c.call_bin = (uint64_t)(H + a); c.call_len = b - a; c.call_nfs = nfs;   // Muta([Bin], []): the scheduler runs it (eh_device.h mux_fuzzers)
+            return 0;
+          }
+          resume = false;
+          const int nres = c.call_nres;
+          if (nres < 0) return 0;
+          if (nres == 0) { c.status = CASE_CRASHED; return 0; }
+          Blk rb = blk_load(c.bl, c.nb);
+          wave_sync();
+          if (l == 0) { out[p0 + 1].ptr = rb.ptr; out[p0 + 1].len = rb.len; }
+        } else if (kind == J_CONST) {
+          double rnd = rng_uniform(c.rng);
+          if (rnd >= 3.0 / dN) continue;
+          if (a == 2) {                                                    // mutate_null/2 :641-643
+            uint32_t k = rng_rand(c.rng, 7);
+            const int lk[7] = {JL_M1, JL_1E9, JL_TRUE, JL_LB, JL_FMT, JL_ZERO, JL_AAA};
+            const uint32_t ll[7] = {2, 10, 4, 2, 6, 1, 14};
+            int lit_k = JL_M1; uint32_t lit_l = 2;
+#pragma unroll
+            for (int q = 0; q < 7; q++) if ((uint32_t)q == k) { lit_k = lk[q]; lit_l = ll[q]; }
+            wave_sync();
+            if (l == 0) { out[p0].ptr = (uint64_t)jslit(lit_k); out[p0].len = lit_l; }
+            tr_ai(c, AT_json_innertext, 1); tr_aa(c, AT_json_innertext, AT_null);      // [{json_innertext, null}, {json_innertext, 1} | InnerMeta] :686
+          } else {                                                         // basic_type_mutation(Boolean, ..) :1212-1219
+            tr_ai(c, AT_json_innertext, 1); tr_aa(c, AT_json_innertext, AT_bool);      // :691
+            wave_sync();
+            if (l == 0) { out[p0].ptr = (uint64_t)jslit(a == 0 ? JL_FALSE : JL_TRUE); out[p0].len = a == 0 ? 5u : 4u; }
+          }
+        } else if (kind == J_NUM) {                                        // list_to_integer/1 :694
+          uint32_t s = a, ok = 0, neg = 0;
+          uint32_t idx = a + (uint32_t)l;
+          uint32_t c0 = a < b ? uni(H[a]) : 0;
+          if (c0 == '+' || c0 == '-') { s = a + 1; neg = c0 == '-'; }
+          // digits only, at least one
+          bool bad = false;
+          for (uint32_t q = s + (uint32_t)l; q < b; q += 64) { uint32_t ch = H[q]; bad |= !(ch >= 48 && ch <= 57); }
+          (void)idx;
+          ok = (s < b && __ballot(bad) == 0) ? 1u : 0u;
+          if (!ok) continue;                                               // error:badarg -> unchanged, no draw
+          double rnd = rng_uniform(c.rng);
+          if (rnd >= 3.0 / dN) continue;
+          bptr txt; uint32_t tlen;
+          if (!num_core(c, H, L, s, b, neg != 0, &txt, &tlen)) return 0;
+          // `case .. of Number -> El`: an unchanged value keeps its spelling
+          uint32_t same = 0;
+          if (l == 0) {
+            uint32_t z = s; while (z + 1 < b && H[z] == 48) z++;            // canonical digits of the old value
+            bool zero = (b - z == 1 && H[z] == 48);
+            uint32_t ol = (neg && !zero ? 1u : 0u) + (b - z);
+            if (ol == tlen) {
+              same = 1; uint32_t o = 0;
+              if (neg && !zero) { if (txt[0] != 45) same = 0; o = 1; }
+              for (uint32_t q = z; q < b && same; q++, o++) if (txt[o] != H[q]) same = 0;
+            }
+          }
+          if (uni((uint32_t)__shfl((int)same, 0))) continue;
+          tr_ai(c, AT_json_innertext, 1); tr_aa(c, AT_json_innertext, AT_num);         // :698
+          wave_sync();
+          if (l == 0) { out[p0].ptr = (uint64_t)txt; out[p0].len = tlen; }
+        }
+      }
+      wave_sync();
+  }
+  if (c.status != CASE_OK) return 0;
+  wave_sync();
+  return json_finish(c, H, L, out, nout, D, meta0);
+}
+
 __device__ __noinline__ int muta_json(Ctx&) {
   EH_CTX;
   const int l = EH_LANE;
   Blk hb = blk_load(c.bl, c.cur);
   cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
+  if (c.mu_phase == 1) return json_inner(c, H, L);                         // back from a nested scheduler call of the inner-text walk
   JsDoc* dh = (JsDoc*)ws_alloc(c, sizeof(JsDoc));
   if (!dh) return 0;
   // Quick verdict for the common non-JSON block: a first token that is a "number" (any run of non-separators, :181-188),
@@ -420,93 +527,26 @@ __device__ __noinline__ int muta_json(Ctx&) {
       wave_sync();
       break;
     }
-    default: {                                                             // inner text / basic types :671-706
+    default: {                                                             // inner text / basic types :671-706: json_inner below
       all(0, npc);
       wave_sync();
-      uint32_t e_pri, e_meta; int nfs;
-      inner_table(c, true, &e_pri, &e_meta, &nfs);
-      const double dN = (double)N;
-      for (uint32_t i = 0; i < nn; i++) {
-        JNode n = nd[i];
-        uint32_t kind = uni(n.kind), p0 = uni(n.p0), ctx = uni(n.ctx), a = uni(n.a), b = uni(n.b);
-        if (kind == J_STR) {                                               // {key, String} 0.6/N ; {string, String} 3/N
-          double prob = ctx == JX_KEY ? 0.6 / dN : 3.0 / dN;
-          double rnd = rng_uniform(c.rng);
-          if (rnd > prob) continue;                                        // mutate_innertext_prob/4 :633-639
-          int nres = nested_fuzz(c, e_pri, e_meta, nfs, H + a, b - a);
-          if (nres < 0) return 0;
-          if (nres == 0) { c.status = CASE_CRASHED; return 0; }
-          Blk rb = blk_load(c.bl, c.nb);
-          wave_sync();
-          if (l == 0) { out[p0 + 1].ptr = rb.ptr; out[p0 + 1].len = rb.len; }
-        } else if (kind == J_CONST) {
-          double rnd = rng_uniform(c.rng);
-          if (rnd >= 3.0 / dN) continue;
-          if (a == 2) {                                                    // mutate_null/2 :641-643
-            uint32_t k = rng_rand(c.rng, 7);
-            const int lk[7] = {JL_M1, JL_1E9, JL_TRUE, JL_LB, JL_FMT, JL_ZERO, JL_AAA};
-            const uint32_t ll[7] = {2, 10, 4, 2, 6, 1, 14};
-            int lit_k = JL_M1; uint32_t lit_l = 2;
-#pragma unroll
-            for (int q = 0; q < 7; q++) if ((uint32_t)q == k) { lit_k = lk[q]; lit_l = ll[q]; }
-            wave_sync();
-            if (l == 0) { out[p0].ptr = (uint64_t)jslit(lit_k); out[p0].len = lit_l; }
-            tr_ai(c, AT_json_innertext, 1); tr_aa(c, AT_json_innertext, AT_null);      // [{json_innertext, null}, {json_innertext, 1} | InnerMeta] :686
-          } else {                                                         // basic_type_mutation(Boolean, ..) :1212-1219
-            tr_ai(c, AT_json_innertext, 1); tr_aa(c, AT_json_innertext, AT_bool);      // :691
-            wave_sync();
-            if (l == 0) { out[p0].ptr = (uint64_t)jslit(a == 0 ? JL_FALSE : JL_TRUE); out[p0].len = a == 0 ? 5u : 4u; }
-          }
-        } else if (kind == J_NUM) {                                        // list_to_integer/1 :694
-          uint32_t s = a, ok = 0, neg = 0;
-          uint32_t idx = a + (uint32_t)l;
-          uint32_t c0 = a < b ? uni(H[a]) : 0;
-          if (c0 == '+' || c0 == '-') { s = a + 1; neg = c0 == '-'; }
-          // digits only, at least one
-          bool bad = false;
-          for (uint32_t q = s + (uint32_t)l; q < b; q += 64) { uint32_t ch = H[q]; bad |= !(ch >= 48 && ch <= 57); }
-          (void)idx;
-          ok = (s < b && __ballot(bad) == 0) ? 1u : 0u;
-          if (!ok) continue;                                               // error:badarg -> unchanged, no draw
-          double rnd = rng_uniform(c.rng);
-          if (rnd >= 3.0 / dN) continue;
-          bptr txt; uint32_t tlen;
-          if (!num_core(c, H, L, s, b, neg != 0, &txt, &tlen)) return 0;
-          // `case .. of Number -> El`: an unchanged value keeps its spelling
-          uint32_t same = 0;
-          if (l == 0) {
-            uint32_t z = s; while (z + 1 < b && H[z] == 48) z++;            // canonical digits of the old value
-            bool zero = (b - z == 1 && H[z] == 48);
-            uint32_t ol = (neg && !zero ? 1u : 0u) + (b - z);
-            if (ol == tlen) {
-              same = 1; uint32_t o = 0;
-              if (neg && !zero) { if (txt[0] != 45) same = 0; o = 1; }
-              for (uint32_t q = z; q < b && same; q++, o++) if (txt[o] != H[q]) same = 0;
-            }
-          }
-          if (uni((uint32_t)__shfl((int)same, 0))) continue;
-          tr_ai(c, AT_json_innertext, 1); tr_aa(c, AT_json_innertext, AT_num);         // :698
-          wave_sync();
-          if (l == 0) { out[p0].ptr = (uint64_t)txt; out[p0].len = tlen; }
-        }
+      EH_G MuFrame* mu = mu_frame(c);
+      if (!mu) return 0;
+      int nfs;
+      inner_table(c, true, mu, &nfs);
+      if (l == 0) {
+        mu->v[0] = (uint64_t)nd; mu->v[1] = nn; mu->v[2] = (uint64_t)out; mu->v[3] = nout; mu->v[4] = N; mu->v[5] = (uint32_t)D; mu->v[6] = meta0;
+        mu->v[7] = (uint32_t)nfs; mu->v[8] = 0;
       }
       wave_sync();
-      break;
+      return json_inner(c, H, L);
     }
   }
   if (c.status != CASE_OK) return 0;
   wave_sync();
   bptr dst; uint64_t total;
   if (raw) { dst = rawp; total = rawl; }
-  else {
-    nout = pieces_coalesce(out, nout);
-    total = pieces_total(out, nout);
-    if (total > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 402); return 0; }
-    dst = ws_alloc(c, total ? total : 16);
-    if (!dst) return 0;
-    wave_gather(dst, out, nout);
-    wave_sync();
-  }
+  else return json_finish(c, H, L, out, nout, D, meta0);
   if ((uint32_t)total == L && wave_equal(dst, H, L)) { tr_drop_before(c, meta0); return -1; }   // NewBinStr =:= H: {fun json_mutate/2, Ll, NewMeta, -1} :722-723 - NewMeta ALONE
   c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)total; c.r_changed = 1;
   return D + (int)(total / (AVG_BLOCK_SIZE * 10));

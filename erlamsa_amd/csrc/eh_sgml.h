@@ -1165,6 +1165,93 @@ EH_DEV SgRange sg_range_of(const EH_G SgTok* tok, uint32_t s) {
   return r;
 }
 
+// the end of sgml_mutate/2: NewBinStr = fold_ast(Res, []) :746 and its comparison with the block
+EH_DEV int sgml_finish(Ctx& c, cbptr H, uint32_t L, EH_G Piece* out, uint32_t nout, uint32_t cap_out, int D, uint32_t meta0) {
+  if (c.status != CASE_OK) return 0;
+  if (nout > cap_out) { EH_SET_OVERFLOW(c, 603); return 0; }
+  wave_sync();
+  EH_PT0;
+  nout = pieces_coalesce(out, nout);
+  uint64_t total = pieces_total(out, nout);
+  if (total > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 604); return 0; }
+  bptr dst = ws_alloc(c, total ? total : 16);
+  if (!dst) return 0;
+  wave_gather(dst, out, nout);
+  wave_sync();
+  EH_PT(c, 93);
+  if ((uint32_t)total == L && wave_equal(dst, H, L)) { tr_drop_before(c, meta0); return -1; }   // NewBinStr =:= H: {fun sgml_mutate/2, Ll, NewMeta, -1} :748-749 - NewMeta ALONE
+  c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)total; c.r_changed = 1;
+  return D + (int)(total / (AVG_BLOCK_SIZE * 10));
+}
+
+// inner text :727-737 (walk2acc/3 :363-379).  mutate_innertext/3 :674-681 runs a nested scheduler call on a text or on a
+// parameter's value: the walk leaves its place (token, parameter) in the MuFrame, asks the scheduler for the run (eh_device.h
+// mux_fuzzers) and goes on from there when it is called again (c.mu_phase 1).  v[0..8]: what sgml_mutate had in hand when it came
+// here (tokens, parameters, the piece list, counts, D, where its Meta began), v[9..13]: the place.
+__device__ __noinline__ int sgml_inner(Ctx&, cbptr H, uint32_t L) {
+  EH_CTX;
+  const int l = EH_LANE;
+  EH_G MuFrame* mu = c.mu;
+  bool resume = c.mu_phase == 1;
+  EH_G SgTok* tok = (EH_G SgTok*)uni64(mu->v[0]); EH_G SgParam* par = (EH_G SgParam*)uni64(mu->v[1]); EH_G Piece* out = (EH_G Piece*)uni64(mu->v[2]);
+  const uint32_t ntok = uni((uint32_t)mu->v[3]), nout = uni((uint32_t)mu->v[4]), cap_out = uni((uint32_t)mu->v[5]), NT = uni((uint32_t)mu->v[6]), meta0 = uni((uint32_t)mu->v[8]);
+  const int D = (int)uni((uint32_t)mu->v[7]), nfs = (int)uni((uint32_t)mu->v[11]);
+  uint32_t t = uni((uint32_t)mu->v[9]), i = uni((uint32_t)mu->v[10]);
+  // asks for Muta([Bin], []) on [vp, vp + vl) when mutate_innertext/3 draws it; true: the request is made, the caller returns
+  auto wants = [&](cbptr vp, uint32_t vl, uint32_t nt2) -> bool {
+    uint32_t nw = wave_count(vp, vl, IsInk());
+    if (!(nw > 0 && nt2 > 0)) return false;
+    double rnd = rng_uniform(c.rng);
+    if (rnd > 3.0 / (double)nt2) return false;
+    if (l == 0) { mu->v[9] = t; mu->v[10] = i; }
+    wave_sync();
+    c.call_req = 1; c.call_bin = (uint64_t)vp; c.call_len = vl; c.call_nfs = nfs;
+    return true;
+  };
+  for (; t < ntok; t++, i = 0) {
+    SgTok tk = tok[t];
+    uint32_t k = uni(tk.kind), kk = k & TK_KIND;
+    if (kk == TK_TEXT && !(k & TF_EMPTY)) {                                // try_mutate_innertext({text, Binary}, ..) :691-692
+      uint32_t p0 = uni(tk.p0), np = uni(tk.np);
+      if (!resume) {
+        cbptr vp; uint32_t vl;
+        if (np == 1) { Piece q = out[p0]; vp = (cbptr)uni64(q.ptr); vl = uni(q.len); }
+        else { bptr m; if (!pieces_materialize(c, out, p0, p0 + np, &m, &vl)) return 0; vp = m; }
+        if (wants(vp, vl, NT)) return 0;
+        continue;
+      }
+      resume = false;
+      const int nres = c.call_nres;
+      if (nres < 0) return 0;
+      if (nres == 0) { c.status = CASE_CRASHED; return 0; }                // hd([])
+      Blk rb = blk_load(c.bl, c.nb);
+      wave_sync();
+      if (l == 0) { out[p0].ptr = rb.ptr; out[p0].len = rb.len; for (uint32_t z = 1; z < np; z++) out[p0 + z].len = 0; }
+    } else if (kk == TK_CLOSE && (k & TF_PAIRED)) {                        // the tag's own params, after its children :683-690
+      SgTok ot = tok[(uint32_t)uni((uint32_t)tk.match)];
+      uint32_t p0 = uni(ot.p0), pa0 = uni(ot.par0), npa = uni(ot.npar);
+      for (; i < npa; i++) {
+        if (!resume) {
+          SgParam q = par[pa0 + i];
+          uint32_t qva = uni(q.va), qvb = uni(q.vb);
+          if (wants(H + qva, qvb - qva, NT + npa)) return 0;
+          continue;
+        }
+        resume = false;
+        const int nres = c.call_nres;
+        if (nres < 0) return 0;
+        if (nres == 0) { c.status = CASE_CRASHED; return 0; }
+        Blk rb = blk_load(c.bl, c.nb);
+        uint32_t pi = p0 + SG_TAGHEAD + SG_PARPCS * i;
+        wave_sync();
+        if (l == 0) { out[pi + 4].ptr = rb.ptr; out[pi + 4].len = rb.len; if (rb.len == 0) { out[pi + 2].len = 0; out[pi + 3].len = 0; out[pi + 5].len = 0; } }
+      }
+    }
+  }
+  wave_sync();
+  return sgml_finish(c, H, L, out, nout, cap_out, D, meta0);
+}
+
 // sgml_mutate/2 :739-757
 __device__ __noinline__ int muta_sgml(Ctx&) {
   EH_CTX;
@@ -1172,6 +1259,7 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
   Blk hb = blk_load(c.bl, c.cur);
   cbptr H = (cbptr)hb.ptr; uint32_t L = hb.len;
   c.r_kind = R_SAME;
+  if (c.mu_phase == 1) return sgml_inner(c, H, L);                         // back from a nested scheduler call of the inner-text walk
   if (binarish(H, L)) return -1;                                           // parse/2 :198-199
   SgDoc* dh = (SgDoc*)ws_alloc(c, sizeof(SgDoc));
   if (!dh) return 0;
@@ -1396,72 +1484,24 @@ __device__ __noinline__ int muta_sgml(Ctx&) {
       wave_sync();
       break;
     }
-    default: {                                                             // inner text :727-737 (walk2acc/3 :363-379)
+    default: {                                                             // inner text :727-737 (walk2acc/3 :363-379): sgml_inner below
       all(0, npc);
       wave_sync();                                                         // the list is read back below (other lanes wrote it)
-      uint32_t e_pri, e_meta; int nfs;
-      inner_table(c, false, &e_pri, &e_meta, &nfs);
-      // mutate_innertext/3 :674-681 on [vp, vp+vl); returns false to stop (status set)
-      auto inner = [&](cbptr vp, uint32_t vl, uint32_t nt2, cbptr* np_, uint32_t* nl_, bool* changed) -> bool {
-        *changed = false;
-        uint32_t nw = wave_count(vp, vl, IsInk());
-        if (!(nw > 0 && nt2 > 0)) return true;
-        double rnd = rng_uniform(c.rng);
-        if (rnd > 3.0 / (double)nt2) return true;
-        int nres = nested_fuzz(c, e_pri, e_meta, nfs, vp, vl);
-        if (nres < 0) return false;
-        if (nres == 0) { c.status = CASE_CRASHED; return false; }          // hd([])
-        Blk rb = blk_load(c.bl, c.nb);
-        *np_ = (cbptr)rb.ptr; *nl_ = rb.len; *changed = true;
-        return true;
-      };
-      for (uint32_t t = 0; t < ntok; t++) {
-        SgTok tk = tok[t];
-        uint32_t k = uni(tk.kind), kk = k & TK_KIND;
-        if (kk == TK_TEXT && !(k & TF_EMPTY)) {                            // try_mutate_innertext({text, Binary}, ..) :691-692
-          uint32_t p0 = uni(tk.p0), np = uni(tk.np);
-          cbptr vp; uint32_t vl;
-          if (np == 1) { Piece q = out[p0]; vp = (cbptr)uni64(q.ptr); vl = uni(q.len); }
-          else { bptr m; if (!pieces_materialize(c, out, p0, p0 + np, &m, &vl)) return 0; vp = m; }
-          cbptr rp = nullptr; uint32_t rl = 0; bool ch;
-          if (!inner(vp, vl, NT, &rp, &rl, &ch)) return 0;
-          if (ch) { wave_sync(); if (l == 0) { out[p0].ptr = (uint64_t)rp; out[p0].len = rl; for (uint32_t z = 1; z < np; z++) out[p0 + z].len = 0; } }
-        } else if (kk == TK_CLOSE && (k & TF_PAIRED)) {                    // the tag's own params, after its children :683-690
-          SgTok ot = tok[(uint32_t)uni((uint32_t)tk.match)];
-          uint32_t p0 = uni(ot.p0), pa0 = uni(ot.par0), npa = uni(ot.npar);
-          for (uint32_t i = 0; i < npa; i++) {
-            SgParam q = par[pa0 + i];
-            uint32_t qva = uni(q.va), qvb = uni(q.vb);
-            cbptr rp = nullptr; uint32_t rl = 0; bool ch;
-            if (!inner(H + qva, qvb - qva, NT + npa, &rp, &rl, &ch)) return 0;
-            if (ch) {
-              uint32_t pi = p0 + SG_TAGHEAD + SG_PARPCS * i;
-              wave_sync();
-              if (l == 0) { out[pi + 4].ptr = (uint64_t)rp; out[pi + 4].len = rl; if (rl == 0) { out[pi + 2].len = 0; out[pi + 3].len = 0; out[pi + 5].len = 0; } }
-            }
-          }
-        }
+      EH_G MuFrame* mu = mu_frame(c);
+      if (!mu) return 0;
+      int nfs;
+      inner_table(c, false, mu, &nfs);
+      if (l == 0) {
+        mu->v[0] = (uint64_t)tok; mu->v[1] = (uint64_t)par; mu->v[2] = (uint64_t)out; mu->v[3] = ntok; mu->v[4] = nout; mu->v[5] = cap_out; mu->v[6] = NT;
+        mu->v[7] = (uint32_t)D; mu->v[8] = meta0; mu->v[9] = 0; mu->v[10] = 0; mu->v[11] = (uint32_t)nfs;
       }
       wave_sync();
-      break;
+      return sgml_inner(c, H, L);
     }
   }
   if (c.status != CASE_OK) return 0;
-  if (nout > cap_out) { EH_SET_OVERFLOW(c, 603); return 0; }
-  // NewBinStr = fold_ast(Res, []) :746
-  wave_sync();
   EH_PT(c, 92);
-  nout = pieces_coalesce(out, nout);
-  uint64_t total = pieces_total(out, nout);
-  if (total > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 604); return 0; }
-  bptr dst = ws_alloc(c, total ? total : 16);
-  if (!dst) return 0;
-  wave_gather(dst, out, nout);
-  wave_sync();
-  EH_PT(c, 93);
-  if ((uint32_t)total == L && wave_equal(dst, H, L)) { tr_drop_before(c, meta0); return -1; }   // NewBinStr =:= H: {fun sgml_mutate/2, Ll, NewMeta, -1} :748-749 - NewMeta ALONE
-  c.r_kind = R_NEW; c.r_ptr = dst; c.r_len = (uint32_t)total; c.r_changed = 1;
-  return D + (int)(total / (AVG_BLOCK_SIZE * 10));
+  return sgml_finish(c, H, L, out, nout, cap_out, D, meta0);
 }
 
 }  // namespace eh

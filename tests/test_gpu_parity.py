@@ -13,7 +13,7 @@ BYTE_ALL = "bd,bei,bed,bf,bi,ber,br"
 SEQ = "sp,sr,sd,snand,srnd"
 
 
-def _compare(inputs, mutations, patterns, seed=(1, 2, 3), generators=None, first_case=1, max_report=5, max_skipped=0.01,
+def _compare(inputs, mutations, patterns, seed=(1, 2, 3), generators=None, first_case=1, max_report=5, max_skipped=1,
              oracle_cap=8 << 20, engine_cap=0, work=0, live=False):
     """live=True: the oracle runs here and now on the host's threads (util.oracle_live) instead of through the digest cache that
     travels with the tree - the tests of the default tables and of the bench workload do, so that their green means "engine ==
@@ -62,13 +62,14 @@ def _compare(inputs, mutations, patterns, seed=(1, 2, 3), generators=None, first
     assert not (gst == 3).any() and not (wst == 3).any(), "EH_CASE_UNSUPPORTED on an input that is not a zip archive"
     if os.environ.get("EH_REPORT_SKIPS"):                              # observed counts per test, for setting max_skipped
         with open(os.environ["EH_REPORT_SKIPS"], "a") as fh:
-            fh.write("%s skipped %d of %d (engine-only status: %d, oracle cap: %d) allowed %.4f\n" % (
+            fh.write("%s skipped %d of %d (engine-only status: %d, oracle cap: %d) allowed %d\n" % (
                 os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], skipped, len(inputs), int(((gst == 2) | (gst == 3)).sum()), int(((wst == 2) | (wst == 3)).sum()), max_skipped))
-    # Tolerances are what a GPU run of round 4 showed (gpurun_out/r04m/skips.txt), with a margin: nearly every skipped case is one the
-    # ORACLE's test cap cut (oracle_cap), the engine alone ended at most 5 cases of a test with an engine-only status
-    assert skipped <= max_skipped * len(inputs), "%d cases skipped as overflow/unsupported" % skipped
+    # max_skipped is a COUNT: what the GPU runs of round 6 showed for the test (gpurun_out/r06j/skips.txt = profiles/r06_observed_skips.txt)
+    # plus one - two where the engine's own work-area cap is among the reasons; a test without an entry there skipped nothing and
+    # may skip one.  Nearly every skipped case is one the ORACLE's test cap cut (oracle_cap).
+    assert skipped <= max_skipped, "%d cases skipped as overflow/unsupported (allowed: %d)" % (skipped, max_skipped)
     eng_only = int(((gst == 2) | (gst == 3)).sum())
-    assert eng_only <= max(2, 0.025 * len(inputs)), "%d cases ended with an engine-only status" % eng_only
+    assert eng_only <= max_skipped, "%d cases ended with an engine-only status" % eng_only
     ok = (wst == 0) & (gst == 0)
     assert (gdr[ok] == wdr[ok]).all(), "draw counts differ"
 
@@ -91,7 +92,7 @@ def test_ragged_and_empty_inputs():
 
 
 def test_random_generator_only():
-    _compare(util.corpus_uniform(256, 64), BYTE_ALL + ",sd,sr", "od,nd,bu", generators="random=1")
+    _compare(util.corpus_uniform(256, 64), BYTE_ALL + ",sd,sr", "od,nd,bu", generators="random=1", max_skipped=2)
 
 
 def test_first_case_offset_is_a_pure_function_of_index():
@@ -134,7 +135,7 @@ def test_num_edge_cases():
               b"18446744073709551615 340282366920938463463374607431768211455\n", b"abc", b"0", b"1-2-3",
               b"12345678901234567890123456789012345678901234567890" * 7, b"A\n B\n", b"1\n"] * 40
     _compare(inputs, "num", "od,nd,bu")
-    _compare(inputs, "num," + LINES, "od,nd,bu", seed=(5, 6, 7))
+    _compare(inputs, "num," + LINES, "od,nd,bu", seed=(5, 6, 7), max_skipped=2)
 
 
 def test_lines_small_texts():
@@ -211,7 +212,7 @@ ADVERSARIAL_DOCS = [
 def test_sgml_json_documents(seed):
     """sgm (erlamsa_sgml) and js (erlamsa_json) on well-formed documents: every mutation kind incl. the inner text
     mutations that re-enter the scheduler with inner_mutations(sgml | json)."""
-    _compare(_docs(400, seed[0]), "sgm,js", "od,nd,bu", seed=seed, oracle_cap=4 << 20, engine_cap=4 << 20)
+    _compare(_docs(400, seed[0]), "sgm,js", "od,nd,bu", seed=seed, max_skipped=3, oracle_cap=4 << 20, engine_cap=4 << 20)
 
 
 def test_sgml_json_adversarial():
@@ -222,14 +223,14 @@ def test_sgml_json_adversarial():
 
 def test_b64_nested_default_table():
     """base64_mutator success path: decoded chunks are mutated by a fresh mutators_mutator over the whole default table."""
-    _compare(_docs(300, 9) + [d for d in ADVERSARIAL_DOCS[-2:] for _ in range(50)], "b64", "od,nd,bu", oracle_cap=4 << 20, engine_cap=4 << 20)
+    _compare(_docs(300, 9) + [d for d in ADVERSARIAL_DOCS[-2:] for _ in range(50)], "b64", "od,nd,bu", max_skipped=2, oracle_cap=4 << 20, engine_cap=4 << 20)
 
 
 @pytest.mark.parametrize("kind", ["docs", "mixed"])
 def test_default_tables(kind):
     """eh_options.mutations = patterns = NULL: the reference's full default tables (41 mutators, 10 patterns)."""
     inputs = _docs(240, 3) if kind == "docs" else _texty(150, 1200, 6)
-    _compare(inputs, None, None, seed=(3, 4, 5), max_skipped=0.03, oracle_cap=4 << 20, engine_cap=4 << 20, live=True)
+    _compare(inputs, None, None, seed=(3, 4, 5), max_skipped=7, oracle_cap=4 << 20, engine_cap=4 << 20, live=True)
 
 
 TREES = "tr2,td,ts1,ts2,tr"
@@ -247,11 +248,11 @@ def _bracket_inputs(n, seed):
 
 @pytest.mark.parametrize("seed", [(1, 2, 3), (3, 1, 4), (2, 7, 1)])
 def test_tree_mutators(seed):
-    _compare(_bracket_inputs(300, seed[1]), TREES, "od,nd,bu", seed=seed, max_skipped=0.06, oracle_cap=4 << 20, engine_cap=4 << 20)   # (tr stutters beyond the 4 MiB test cap: 13 of 311 for seed 0)
+    _compare(_bracket_inputs(300, seed[1]), TREES, "od,nd,bu", seed=seed, max_skipped=15, oracle_cap=4 << 20, engine_cap=4 << 20)   # (tr stutters beyond the 4 MiB test cap: 13 of 311 for seed 0)
 
 
 def test_tree_mutators_mixed_corpus():
-    _compare(_texty(150, 2048, 31), TREES + ",bd", "od,nd,bu", max_skipped=0.05, oracle_cap=4 << 20, engine_cap=4 << 20)
+    _compare(_texty(150, 2048, 31), TREES + ",bd", "od,nd,bu", max_skipped=10, oracle_cap=4 << 20, engine_cap=4 << 20)
 
 
 def _framed_inputs(n, size, seed):
@@ -263,14 +264,14 @@ def _framed_inputs(n, size, seed):
 
 def test_len_mutator():
     ins = _framed_inputs(200, 300, 1) + _framed_inputs(100, 64, 2) + [b"\x00\x05hello", b"\x03abc", b"abc", b"\x00\x00\x00\x04abcd\x00"] * 10
-    _compare(ins, "len", "od,nd,bu", max_skipped=0.01, oracle_cap=1 << 20, engine_cap=4 << 20)
-    _compare(ins + util.corpus_uniform(100, 700), "len,bd,bf,sd", "od,nd,bu", seed=(4, 4, 4), max_skipped=0.01, oracle_cap=1 << 20, engine_cap=4 << 20)
+    _compare(ins, "len", "od,nd,bu", max_skipped=1, oracle_cap=1 << 20, engine_cap=4 << 20)
+    _compare(ins + util.corpus_uniform(100, 700), "len,bd,bf,sd", "od,nd,bu", seed=(4, 4, 4), max_skipped=1, oracle_cap=1 << 20, engine_cap=4 << 20)
 
 
 @pytest.mark.parametrize("pats", ["sk", "sz", "cs", "ar", "cp", "od,nd,bu,sk,sz,cs,ar,cp,co,nu"])
 def test_complex_patterns(pats):
     ins = _framed_inputs(150, 400, 3) + util.corpus_uniform(100, 300, seed=8) + _texty(60, 512, 9)
-    _compare(ins, BYTE_ALL + ",sd,sr,num,ld", pats, max_skipped=0.01, oracle_cap=1 << 20, engine_cap=4 << 20)
+    _compare(ins, BYTE_ALL + ",sd,sr,num,ld", pats, max_skipped=3, oracle_cap=1 << 20, engine_cap=4 << 20)
 
 
 FUSE = "ft,fn,fo"
@@ -280,12 +281,12 @@ FUSE = "ft,fn,fo"
 def test_fuse_mutators(seed):
     ins = [b"kittenslartibartfasterthaneelslartibartfastenyourseatbelts", b"a", b"ab", b"aaaaaaaa", b"abcabcabc", b""] * 10
     ins += util.corpus_uniform(80, 200, seed=seed[0]) + _texty(60, 300, seed[1]) + [b"xy" * 300, b"\x00" * 500]
-    _compare(ins, FUSE, "od,nd,bu", seed=seed, max_skipped=0.01, oracle_cap=1 << 20, engine_cap=8 << 20)
+    _compare(ins, FUSE, "od,nd,bu", seed=seed, max_skipped=1, oracle_cap=1 << 20, engine_cap=8 << 20)
 
 
 def test_fuse_with_other_mutators_and_blocks():
     ins = util.corpus_uniform(60, 3000, seed=3) + _texty(60, 2500, 4)
-    _compare(ins, FUSE + ",num,bd,sd,ld", "od,nd,bu", max_skipped=0.01, oracle_cap=1 << 20, engine_cap=8 << 20)
+    _compare(ins, FUSE + ",num,bd,sd,ld", "od,nd,bu", max_skipped=1, oracle_cap=1 << 20, engine_cap=8 << 20)
 
 
 PROD = "uw,ui,ab,ad,tr2,td,num,ts1,tr,ts2,bd,bei,bed,bf,bi,ber,br,sp,sr,sd,snand,srnd,ld,lds,lr2,lri,lr,ls,lp,lis,lrs,len,uri,zip,nil"
@@ -297,7 +298,7 @@ def test_bench_workload_sample_with_bench_limits():
     and the tree/lexer paths see large inputs."""
     from erlamsa_amd import synth
     mat = synth.mixed(8192, 4096)
-    _compare([mat[i].tobytes() for i in range(mat.shape[0])], PROD, "od,nd,bu", max_skipped=0.005,
+    _compare([mat[i].tobytes() for i in range(mat.shape[0])], PROD, "od,nd,bu", max_skipped=25,
              oracle_cap=8 << 20, engine_cap=8 << 20, work=8 << 20)
 
 

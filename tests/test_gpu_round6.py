@@ -59,6 +59,7 @@ def test_cooperative_execution_gives_the_same_bytes_and_is_used():
             eng = ea.Engine(0)
             eng.configure(mutations=muts, patterns="nd,bu", max_case_bytes=4 << 20, big_case_bytes=1 << 30, out_capacity=24 << 30, flags=flags)
             eng.upload_corpus(data, off)
+            eng.reserve(len(inputs))                                       # (the device's pool and board exist from here on)
             before = eng.coop_stats() if name != "alone" else None
             eng.fuzz_batch(seed=(6, 0, 6))
             eng.sync()
