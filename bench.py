@@ -160,7 +160,7 @@ def main():
                     "8 per CU = 2048); passes in flight oversubscribe the device.  1024 x 6 passes keeps ~45 GiB of the device free: with 2048 "
                     "(5 percent faster, profiles/r03_bench.json) the free memory fell below what the runtime wants for the queues' scratch and "
                     "two of six runs never left the set-up passes")
-    ap.add_argument("--pool-gib", type=int, default=60, help="device memory of the work-area pool all contexts share (GiB), eh_options.pool_bytes; "
+    ap.add_argument("--pool-gib", type=int, default=42, help="device memory of the work-area pool all contexts share (GiB), eh_options.pool_bytes; "
                     "0 = the library's own rule (a quarter of the free memory, at most 64 GiB)")
     ap.add_argument("--out-gib", type=int, default=27, help="output arena capacity per context (GiB)")
     ap.add_argument("--case-mib", type=int, default=4, help="work area of a slot (MiB), eh_options.max_case_bytes; every workgroup of a pass owns a slot, a case that "
@@ -179,7 +179,7 @@ def main():
                     "work-budget leg, PCIe leg): the JSON line is printed without a leg that has not come back by then")
     ap.add_argument("--engine-flags", type=int, default=0, help="eh_options.flags of every context (diagnostic: 64 = EH_FLAG_NO_COOP, every case does all "
                     "of its work on its own wavefront)")
-    ap.add_argument("--inflight", type=int, default=6, help="passes in flight (engine contexts / HIP streams): the tail of a pass — a few "
+    ap.add_argument("--inflight", type=int, default=7, help="passes in flight (engine contexts / HIP streams): the tail of a pass — a few "
                     "long single-wavefront cases — overlaps with the bulk of the next ones.  Every context owns its output arena (--out-gib) and its slots "
                     "(--max-slots x --case-mib); larger work areas come from one pool shared by all contexts (--pool-gib)")
     ap.add_argument("--setup-seconds", type=int, default=150, help="single-GPU runs execute in a child process; a child whose set-up passes (the first "
@@ -206,7 +206,8 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.setup_seconds > 0 and not os.environ.get("EH_BENCH_CHILD"):
         import subprocess
         import threading
-        ladder = ([], [], ["--inflight", "3"], ["--inflight", "1"])
+        # (seven passes in flight take 261 of the device's 288 GiB: a child that cannot get them is followed by round 5's six with the larger pool)
+        ladder = ([], ["--inflight", "6", "--pool-gib", "60"], ["--inflight", "3", "--pool-gib", "60"], ["--inflight", "1", "--pool-gib", "60"])
         for attempt, extra in enumerate(ladder):
             env = dict(os.environ, EH_BENCH_CHILD="1")
             proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -399,7 +400,7 @@ def main():
     for e in engines:
         e.reserve(n)
     # one context at a time: the first dispatch on a HIP stream makes the runtime allocate that hardware queue's scratch
-    # (the kernel recurses: 6 KiB of stack per lane for every wavefront slot of the device), which must not have to wait
+    # (1.8 KiB of stack per lane for every wavefront slot of the device; 8 KiB while the kernel still recursed), which must not have to wait
     # for memory or wavefront slots that the persistent workgroups of five other passes are holding
     for k, (e, st) in enumerate(zip(engines, raw)):
         e.fuzz_batch(seed=seed, first_case=1, corpus_first=0, n=n, stream=st)

@@ -129,9 +129,8 @@ typedef struct eh_options {
 #define EH_FLAG_FUSE_NO_LDS 4u    /* diagnostic: erlamsa_fuse:fuse/2 on small lists runs as the node-list refinement (csrc/eh_fuse.h)
                                      instead of the LDS-resident one (csrc/eh_fuse_lds.h); results are identical */
 
-/* One context = one HIP device, its result buffers and slots.  eh_create sets the DEVICE's stack limit (hipLimitStackSize, 6 KiB per
- * lane: the kernel recurses for nested scheduler calls) - a process-wide setting other HIP users of the same device (e.g. a
- * co-resident torch) inherit; the runtime sizes every hardware queue's scratch from it. */
+/* One context = one HIP device, its result buffers and slots.  eh_create touches no process-wide setting (until ABI 7 it raised the
+ * device's hipLimitStackSize to 6 KiB per lane because the kernel recursed; the kernel's stack is static now). */
 int eh_create(int device, eh_ctx** out);
 void eh_destroy(eh_ctx* ctx);
 int eh_configure(eh_ctx* ctx, const eh_options* opts);
