@@ -16,7 +16,7 @@ mat = synth.mixed(65536, 4096)
 data, off = synth.as_arena(mat)
 names = [m[0] for m in ea.mutator_table()]
 eng = ea.Engine(0)
-eng.configure(fuse_stream_min=int(os.environ.get("FUSE_STREAM_MIN", "0")), patterns="od,nd,bu", out_capacity=4 << 30, max_case_bytes=16 << 20, big_case_bytes=1024 << 20, max_slots=8)
+eng.configure(fuse_stream_min=int(os.environ.get("FUSE_STREAM_MIN", "0")), patterns=(os.environ.get("PATTERNS", "od,nd,bu") if os.environ.get("PATTERNS") != "default" else None), out_capacity=4 << 30, max_case_bytes=16 << 20, big_case_bytes=1024 << 20, max_slots=8)
 eng.upload_corpus(data, off)
 for base, i in jobs:
     eng.fuzz_batch(seed=(1, 2, 3), first_case=base + 1 + i, corpus_first=i, n=1)

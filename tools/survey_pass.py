@@ -18,7 +18,7 @@ mat = synth.mixed(65536, 4096)[:n]
 data, off = synth.as_arena(mat)
 names = [m[0] for m in ea.mutator_table()]
 eng = ea.Engine(0)
-eng.configure(fuse_stream_min=int(os.environ.get("FUSE_STREAM_MIN", "0")), patterns="od,nd,bu", out_capacity=40 << 30, max_case_bytes=int(os.environ.get("CASE_MIB", "4")) << 20, big_case_bytes=1024 << 20,
+eng.configure(fuse_stream_min=int(os.environ.get("FUSE_STREAM_MIN", "0")), patterns=(os.environ.get("PATTERNS", "od,nd,bu") if os.environ.get("PATTERNS") != "default" else None), out_capacity=40 << 30, max_case_bytes=int(os.environ.get("CASE_MIB", "4")) << 20, big_case_bytes=1024 << 20,
               max_slots=int(os.environ.get("MAX_SLOTS", "0")), flags=int(os.environ.get("ENGINE_FLAGS", "0")))
 eng.upload_corpus(data, off)
 eng.fuzz_batch(seed=(1, 2, 3), first_case=base + 1, corpus_first=0, n=n)
