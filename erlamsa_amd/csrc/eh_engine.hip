@@ -562,11 +562,13 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               int r;
               {                                                                       // (out of work memory: borrow a larger area, pick again)
                 const Rng rng0 = c.rng; const uint64_t mark = c.ws_used; int last_tier = 0;
+                EH_PT0;
                 for (;;) {
                   r = pick_simple_len(c, H, b.len, &e);
                   if (c.status != CASE_OVERFLOW || c.ovf_need == 0 || !ws_regrow(c, mark, &last_tier)) break;
                   c.rng = rng0;
                 }
+                EH_PT(c, 119);
               }
               if (r < 0) break;
               if (r == 0) tr_aa(c, AT_sizer, AT_failed);                              // [{sizer, failed} | Meta] :85
@@ -590,7 +592,9 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               }
             } else if (pat == P_CS) {                                                 // mutate_once_csum :115-144
               uint32_t iscrc, plen, blen;
+              EH_PT0;
               int r = pick_csum(c, H, b.len, &iscrc, &plen, &blen);
+              EH_PT(c, 118);
               if (r < 0) break;
               if (r == 0) tr_aa(c, AT_csum, AT_failed);                               // :119
               if (r == 1) {
@@ -606,7 +610,9 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
                 wave_sync();
               }
             } else if (pat == P_AR || pat == P_CP) {                                  // mutate_once_archiver :165-214, mutate_once_compressed :216-260
+              EH_PT0;
               uint64_t e = pat_container_begin(c, lt.e_pri, lt.e_meta, pat, frames, nfr, ip, contpat);
+              EH_PT(c, pat == P_CP ? 121 : 123);
               lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
               if (c.pat_ret < 0) break;
               if (c.pat_ret == 2) { nfr++; act = A_LOOP; break; }                     // the rest of the chain on a payload: mutate_once_loop(Mutator, [], NextPat, Ip, Data, [])
@@ -659,7 +665,9 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
         f.kind = (int)uni((uint32_t)f.kind); f.em_field = (int)uni((uint32_t)f.em_field); f.field = (bptr)uni64((uint64_t)f.field);
         f.size_bits = uni(f.size_bits); f.big = uni(f.big); f.tail_ptr = uni64(f.tail_ptr); f.tail_len = uni(f.tail_len); f.crc = uni(f.crc);
         if (f.kind == P_AR || f.kind == P_CP) {
+          EH_PT0;
           uint64_t e = pat_container_end(c, lt.e_pri, lt.e_meta, f.kind, f.em_field, f.field, frames, nfr);
+          EH_PT(c, f.kind == P_CP ? 122 : 124);
           lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
           if (c.pat_ret < 0) break;
           ip = c.pat_ip; cont = C_PAT; contpat = c.pat_cont;
@@ -677,12 +685,15 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
           // NewC = recalc_csum(Type, NewBlob): gather the inner pieces, checksum, append  (:139-143)
           uint64_t tot = 0; for (int k = f.em_field; k < c.nem; k++) tot += blk_load(c.em, k).len;
           if (tot > 0xFFFFFFF0ull) { EH_SET_OVERFLOW(c, 310); break; }
+          EH_PT0;
           bptr blob = ws_alloc_grow(c, tot + 16);
           if (!blob) break;
           uint64_t o = 0;
           for (int k = f.em_field; k < c.nem; k++) { Blk x = blk_load(c.em, k); wave_copy(blob + o, (cbptr)x.ptr, x.len); o += x.len; }
           wave_sync();
+          EH_PT(c, 120);
           uint32_t cs = f.crc ? wave_crc32(blob, (uint32_t)tot) : wave_xor8(blob, (uint32_t)tot);
+          EH_PT(c, 116);
           uint32_t cb = f.crc ? 4u : 1u;
           if (EH_LANE == 0) put_field(blob + tot, cs, cb * 8, true);
           wave_sync();

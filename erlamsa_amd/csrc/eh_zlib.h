@@ -18,6 +18,7 @@
 // wave_crc32 in eh_engine.hip).  All state lives in a scratch block the caller hands in (ZDef: 330 KB, ZInf: 3 KB).
 #pragma once
 #include "eh_device.h"
+#include "eh_fuse.h"      // g_fuse_lds: the CRC tables are staged there
 
 namespace eh {
 
@@ -52,28 +53,71 @@ EH_DEV uint32_t gf2_xpow8n(uint64_t nbytes) {                      // x^(8*nbyte
   while (nbytes) { if (nbytes & 1) r = gf2_multmodp(r, sq); sq = gf2_multmodp(sq, sq); nbytes >>= 1; }
   return r;
 }
-// erlang:crc32/1 of a contiguous buffer: 64 lane-local chunk CRCs combined with x^(8*len) shifts
+// erlang:crc32/1 of a contiguous buffer.  Every lane takes one contiguous piece (a multiple of 16 bytes, so that a lane's
+// dwordx4 loads stay in step with its neighbours'), walks it four bytes per table step with the slicing tables staged in LDS
+// (g_fuse_lds: free outside the fuse mutators - the callers are the csum / container patterns and the zip mutator), and the 64
+// piece CRCs are combined with x^(8*len) shifts.  A whole result of some hundred MB behind a csum frame took a byte per table
+// step out of constant memory before (profiles/r06_c4_tail.txt).
+struct alignas(16) TabU32x1024 { uint32_t v[1024]; };
+constexpr TabU32x1024 crc32_slices() {
+  TabU32x1024 t{};
+  for (uint32_t i = 0; i < 256; i++) { uint32_t cc = i; for (int k = 0; k < 8; k++) cc = (cc & 1) ? 0xEDB88320u ^ (cc >> 1) : cc >> 1; t.v[i] = cc; }
+  for (int k = 1; k < 4; k++) for (uint32_t i = 0; i < 256; i++) { uint32_t q = t.v[(k - 1) * 256 + i]; t.v[k * 256 + i] = (q >> 8) ^ t.v[q & 0xFF]; }
+  return t;
+}
+__constant__ TabU32x1024 c_crc_slices = crc32_slices();
+EH_DEV uint32_t crc32_word(const uint32_t* T, uint32_t crc, uint32_t w) {
+  crc ^= w;
+  return T[768 + (crc & 255u)] ^ T[512 + ((crc >> 8) & 255u)] ^ T[256 + ((crc >> 16) & 255u)] ^ T[crc >> 24];
+}
 EH_DEV uint32_t wave_crc32(cbptr p, uint32_t n) {
   const int l = EH_LANE;
-  uint32_t chunk = (n + 63) / 64;
-  uint32_t a = (uint32_t)l * chunk, b = a + chunk; if (a > n) a = n; if (b > n) b = n;
+  uint32_t* T = g_fuse_lds;
+  wave_sync();
+  for (int i = l; i < 1024; i += 64) T[i] = c_crc_slices.v[i];
+  wave_sync();
+  const uint64_t chunk = ((((uint64_t)n + 63) / 64) + 15) & ~15ull;
+  uint64_t a = (uint64_t)l * chunk, b = a + chunk; if (a > n) a = n; if (b > n) b = n;
   uint32_t crc = 0xFFFFFFFFu;
-  for (uint32_t i = a; i < b; i++) crc = c_crc_table.v[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
-  crc ^= 0xFFFFFFFFu;                                              // crc32 of my chunk (0 for an empty chunk)
-  uint32_t total = 0; uint32_t done = 0;
-  for (int k = 0; k < 64; k++) {                                   // crc32_combine left to right
-    uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)crc, k);
-    uint32_t ak = (uint32_t)k * chunk, bk = ak + chunk; if (ak > n) ak = n; if (bk > n) bk = n;
-    uint32_t lk = bk - ak;
-    if (lk == 0) continue;
-    total = done == 0 ? ck : (gf2_multmodp(gf2_xpow8n(lk), total) ^ ck);
-    done += lk;
+  uint64_t i = a;
+  if (i + 16 <= b) {
+    uint4 w = ldg16(p + i);
+    for (; i + 32 <= b; i += 16) {
+      const uint4 nx = ldg16(p + i + 16);                        // the next load is in flight while this one is folded in
+      crc = crc32_word(T, crc, w.x); crc = crc32_word(T, crc, w.y); crc = crc32_word(T, crc, w.z); crc = crc32_word(T, crc, w.w);
+      w = nx;
+    }
+    crc = crc32_word(T, crc, w.x); crc = crc32_word(T, crc, w.y); crc = crc32_word(T, crc, w.z); crc = crc32_word(T, crc, w.w);
+    i += 16;
   }
+  for (; i < b; i++) crc = T[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+  crc ^= 0xFFFFFFFFu;                                              // crc32 of my piece (0 for an empty one)
+  const uint32_t xp = gf2_xpow8n(chunk);                           // all pieces but the last have this length
+  uint32_t total = 0;
+  for (int k = 0; k < 64; k++) {                                   // crc32_combine left to right
+    const uint64_t ak = (uint64_t)k * chunk;
+    if (ak >= n) break;
+    const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)crc, k);
+    const uint64_t lk = n - ak < chunk ? n - ak : chunk;
+    total = k == 0 ? ck : (gf2_multmodp(lk == chunk ? xp : gf2_xpow8n(lk), total) ^ ck);
+  }
+  wave_sync();
   return total;
 }
+EH_DEV uint32_t fold_xor8(uint4 v) { return v.x ^ v.y ^ v.z ^ v.w; }
 EH_DEV uint32_t wave_xor8(cbptr p, uint32_t n) {
+  const uint32_t l = (uint32_t)EH_LANE;
   uint32_t x = 0;
-  for (uint32_t i = EH_LANE; i < n; i += 64) x ^= p[i];
+  const uint32_t nv = n >> 4;
+  uint32_t i = l;
+  for (; i + 192 < nv; i += 256) {
+    const uint4 v0 = ldg16(p + 16 * (size_t)i), v1 = ldg16(p + 16 * (size_t)(i + 64));
+    const uint4 v2 = ldg16(p + 16 * (size_t)(i + 128)), v3 = ldg16(p + 16 * (size_t)(i + 192));
+    x ^= fold_xor8(v0) ^ fold_xor8(v1) ^ fold_xor8(v2) ^ fold_xor8(v3);
+  }
+  for (; i < nv; i += 64) x ^= fold_xor8(ldg16(p + 16 * (size_t)i));
+  for (uint64_t j = ((uint64_t)nv << 4) + l; j < n; j += 64) x ^= p[j];
+  x ^= x >> 16; x ^= x >> 8;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) x ^= (uint32_t)__shfl_xor((int)x, d);
   return uni(x) & 255u;
@@ -389,12 +433,25 @@ EH_DEV uint64_t z_deflate_bound(uint64_t n) { return n + (n >> 12) + (n >> 14) +
 
 // Adler-32 of a contiguous buffer, wave-parallel: a = 1 + sum(x_i), b = n + sum((n - i) * x_i)  (mod 65521)
 EH_DEV uint32_t wave_adler32(cbptr p, uint64_t n) {
-  uint64_t a = 0, b = 0; uint32_t k = 0;
-  for (uint64_t i = EH_LANE; i < n; i += 64) {
-    uint64_t x = p[i];
-    a += x; b += ((n - i) % 65521u) * x;
-    if (++k == 4096) { a %= 65521u; b %= 65521u; k = 0; }
+  // a = 1 + sum x_i, b = n + sum (n - i) x_i (mod 65521); a lane's 16 bytes at i0: (n - i0) * s - sum j x_j
+  const uint32_t l = (uint32_t)EH_LANE;
+  uint64_t a = 0, b = 0;
+  const uint64_t nv = n >> 4;
+  uint32_t r = (uint32_t)((n - 16 * (uint64_t)(l < nv ? l : 0)) % 65521u);          // (n - i0) mod 65521, stepped down by 1024 a round
+  for (uint64_t i = l; i < nv; i += 64) {
+    const uint4 v = ldg16(p + 16 * (size_t)i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t s = 0, t = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t b0 = w[q] & 255u, b1 = (w[q] >> 8) & 255u, b2 = (w[q] >> 16) & 255u, b3 = w[q] >> 24;
+      s += b0 + b1 + b2 + b3;
+      t += (uint32_t)(4 * q) * (b0 + b1 + b2 + b3) + b1 + 2 * b2 + 3 * b3;
+    }
+    a += s; b += (uint64_t)r * s + 65521u - t;                     // t <= 120 * 255 < 65521; 2^64 is out of reach for n < 2^32
+    r = r >= 1024u ? r - 1024u : r + 65521u - 1024u;
   }
+  for (uint64_t j = (nv << 4) + l; j < n; j += 64) { const uint64_t x = p[j]; a += x; b += ((n - j) % 65521u) * x; }
   a %= 65521u; b %= 65521u;
   uint32_t a32 = wave_sum((uint32_t)a), b32 = wave_sum((uint32_t)b);                    // 64 * 65520 fits
   a32 = (a32 + 1) % 65521u; b32 = (uint32_t)((b32 + n % 65521u) % 65521u);
