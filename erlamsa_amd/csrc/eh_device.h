@@ -379,6 +379,13 @@ __shared__ Ctx g_ctx;
 // program order, so nothing is emitted; on the emulator the ballot is a rendezvous of the lane fibers.
 EH_DEV void lanes_sync() { (void)__ballot(1); }
 #define EH_CTX Ctx& c = g_ctx
+// The LDS band of the fuse mutators (eh_fuse.h, eh_fuse2.h, eh_fuse_lds.h) and the sgm tokenizer.  Outside of them it is free, and
+// the pattern-level finders stage their tables there: the CRC tables of wave_crc32 (eh_zlib.h), the right ends and counts of
+// pick_simple_len (eh_field.h), the prefix CRCs and hit masks of pick_csum (eh_engine.hip).  Nobody keeps anything in it across calls.
+#ifndef EH_FUSE_LDS_WORDS
+#define EH_FUSE_LDS_WORDS 4800
+#endif
+EH_LDS_ARRAY(uint32_t, g_fuse_lds, EH_FUSE_LDS_WORDS);
 EH_LDS_ARRAY(uint32_t, g_st_save, ST_STATE_WORDS);   // lis / lrs store as it was before the running attempt (mux_fuzzers)
 // per-lane mux_fuzzers entry (lane i = list position i); private registers, never in LDS
 struct LaneTab {

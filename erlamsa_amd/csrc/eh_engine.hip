@@ -182,17 +182,20 @@ __device__ __noinline__ int pick_csum(Ctx&, cbptr H, uint32_t L, uint32_t* crc, 
   if (L == 0) return 0;
   uint32_t maxp = (uint32_t)(2.0 * (double)L / 3.0);
   if (maxp > 30 * PREAMBLE_MAX_BYTES) maxp = 30 * PREAMBLE_MAX_BYTES;
-  uint32_t np = maxp + 1;                                          // preambles 0..maxp
+  uint32_t np = maxp + 1;                                          // preambles 0..maxp (<= 961)
+  // LDS (g_fuse_lds is free outside the fuse / sgm mutators): [0, 1024) the CRC tables wave_crc32 stages, [1024, 1024 + np) the
+  // prefix CRCs, [2048, 2112) the hits as ballot masks - 16 of xor8, then 16 of crc32
+  static_assert(30 * PREAMBLE_MAX_BYTES + 1 <= 1024 && 2112 <= EH_FUSE_LDS_WORDS, "pick_csum's tables fit the fuse band");
+  uint32_t* T = g_fuse_lds; uint32_t* pre = g_fuse_lds + 1024; uint32_t* msk = g_fuse_lds + 2048;
+  const uint32_t nbase = (np + 63) / 64;
   // xor8: xor(bytes[A .. L-1)) == byte[L-1]  <=>  prefix_xor(A) == total_xor ^ last
   uint32_t last = uni(H[L - 1]);
   uint32_t tot = wave_xor8(H, L - 1);
   uint32_t target = tot ^ last;
-  uint64_t mark = c.ws_used;
-  bptr flags = ws_alloc_grow(c, (uint64_t)np * 2);                  // [0,np): xor8 hit, [np,2np): crc32 hit
-  if (!flags) return -1;
+  wave_sync();
   uint32_t carry = 0, nx = 0;
-  for (uint32_t base = 0; base < np; base += 64) {
-    uint32_t A = base + (uint32_t)l;
+  for (uint32_t bi = 0; bi < nbase; bi++) {
+    uint32_t A = bi * 64 + (uint32_t)l;
     uint32_t v = (A < np && A < L - 1 + 1 && A > 0) ? H[A - 1] : 0;   // prefix_xor(A) = xor of bytes [0,A)
     if (A == 0 || A > L - 1) v = 0;
     uint32_t inc = v;
@@ -200,50 +203,62 @@ __device__ __noinline__ int pick_csum(Ctx&, cbptr H, uint32_t L, uint32_t* crc, 
     for (int d = 1; d < 64; d <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)inc, d); if (l >= d) inc ^= t; }
     uint32_t px = inc ^ carry;
     bool hit = A < np && A <= L - 1 && px == target;               // has_xor8_checksum: needs Len - A - 1 >= 0
-    if (A < np) flags[A] = hit ? 1 : 0;
-    nx += hit ? 1u : 0u;
+    const unsigned long long m = __ballot(hit);
+    if (l == 0) { msk[2 * bi] = (uint32_t)m; msk[2 * bi + 1] = (uint32_t)(m >> 32); }
+    nx += (uint32_t)__popcll(m);
     carry = uni((uint32_t)__shfl((int)px, 63));
   }
-  nx = wave_sum(nx);
   // crc32: crc(bytes[A .. L-4)) == BE32(last 4), for A with L - A >= 4
   uint32_t nc = 0;
   if (L >= 4) {
     uint32_t stored = (uni(H[L - 4]) << 24) | (uni(H[L - 3]) << 16) | (uni(H[L - 2]) << 8) | uni(H[L - 1]);
     uint32_t E = L - 4;
-    uint32_t whole = wave_crc32(H, E);                             // crc(0..E)
-    // prefix CRCs crc(0..A) for A <= maxp: one sequential table walk shared by the wave ...
-    wptr pre = (wptr)ws_alloc_grow(c, (uint64_t)np * 4);
-    if (!pre) return -1;
-    uint32_t run = 0xFFFFFFFFu;
-    ByteReader r; br_init(r, H, L);
-    for (uint32_t A = 0; A < np; A++) {
-      if (l == 0) pre[A] = run ^ 0xFFFFFFFFu;                       // crc32(bytes[0..A))
-      if (A < L) run = c_crc_table.v[(run ^ br_get(r, A, A)) & 0xFF] ^ (run >> 8);
+    uint32_t whole = wave_crc32(H, E);                             // crc(0..E); the tables stay in T
+    // prefix CRCs crc(0..A) for A <= maxp: one sequential table walk, the same on every lane ...
+    {
+      uint32_t run = 0xFFFFFFFFu;
+      for (uint32_t A0 = 0; A0 < np; A0 += 64) {
+        const uint32_t mine = A0 + (uint32_t)l < L ? H[A0 + (uint32_t)l] : 0u;     // 64 bytes of the block, one per lane
+        const uint32_t n64 = np - A0 < 64 ? np - A0 : 64;
+        for (uint32_t k = 0; k < n64; k++) {
+          if ((uint32_t)l == k) pre[A0 + k] = run ^ 0xFFFFFFFFu;   // crc32(bytes[0..A))
+          const uint32_t byte = (uint32_t)__shfl((int)mine, (int)k);
+          if (A0 + k < L) run = T[(run ^ byte) & 0xFF] ^ (run >> 8);
+        }
+      }
     }
     wave_sync();
-    // ... then every lane tests its own preamble:
-    // crc(A..E) = crc(0..E) ^ shift(crc(0..A), E-A)   (crc32_combine solved for the suffix)
-    for (uint32_t base = 0; base < np; base += 64) {
-      uint32_t A = base + (uint32_t)l;
+    // ... then every lane tests its own preambles, from the last down: crc(A..E) = crc(0..E) ^ crc(0..A) * x^(8(E-A))
+    // (crc32_combine solved for the suffix); 64 preambles further down the multiplier is x^512 times the one before
+    const uint32_t x512 = gf2_xpow8n(64);
+    uint32_t mul = 0; bool have = false;
+    for (int bi = (int)nbase - 1; bi >= 0; bi--) {
+      uint32_t A = (uint32_t)bi * 64 + (uint32_t)l;
       bool hit = false;
       if (A < np && A <= E) {
-        uint32_t suf = A == 0 ? whole : (whole ^ gf2_multmodp(gf2_xpow8n(E - A), pre[A]));
+        if (!have) { mul = gf2_xpow8n(E - A); have = true; } else mul = gf2_multmodp(x512, mul);
+        uint32_t suf = A == 0 ? whole : (whole ^ gf2_multmodp(mul, pre[A]));
         hit = suf == stored;
       }
-      if (A < np) flags[np + A] = hit ? 1 : 0;
-      nc += hit ? 1u : 0u;
+      const unsigned long long m = __ballot(hit);
+      if (l == 0) { msk[32 + 2 * bi] = (uint32_t)m; msk[32 + 2 * bi + 1] = (uint32_t)(m >> 32); }
+      nc += (uint32_t)__popcll(m);
     }
-    nc = wave_sum(nc);
-  } else { for (uint32_t A = l; A < np; A += 64) flags[np + A] = 0; }
+  } else { if (l < 32) msk[32 + l] = 0; }
   wave_sync();
   uint32_t total = nx + nc;
-  if (total == 0) { c.ws_used = mark; return 0; }
+  if (total == 0) return 0;
   uint32_t idx = rng_rand(c.rng, total);
   uint32_t want = idx, off = 0, iscrc = 0;
-  if (idx >= nx) { want = idx - nx; off = np; iscrc = 1; }
-  uint32_t Asel = 0, seen = 0;
-  for (uint32_t A = 0; A < np; A++) { if (uni(flags[off + A])) { if (seen == want) { Asel = A; break; } seen++; } }
-  c.ws_used = mark;
+  if (idx >= nx) { want = idx - nx; off = 32; iscrc = 1; }
+  uint32_t Asel = 0;
+  for (uint32_t bi = 0; bi < nbase; bi++) {
+    unsigned long long m = (unsigned long long)uni(msk[off + 2 * bi]) | ((unsigned long long)uni(msk[off + 2 * bi + 1]) << 32);
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    if (want < cnt) { for (uint32_t t = 0; t < want; t++) m &= m - 1; Asel = bi * 64 + (uint32_t)__builtin_ctzll(m); break; }
+    want -= cnt;
+  }
+  wave_sync();
   *crc = iscrc; *plen = Asel; *blen = iscrc ? L - Asel - 4 : L - Asel - 1;
   return 1;
 }
@@ -568,7 +583,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
                   if (c.status != CASE_OVERFLOW || c.ovf_need == 0 || !ws_regrow(c, mark, &last_tier)) break;
                   c.rng = rng0;
                 }
-                EH_PT(c, 119);
+                EH_PT(c, 60);
               }
               if (r < 0) break;
               if (r == 0) tr_aa(c, AT_sizer, AT_failed);                              // [{sizer, failed} | Meta] :85
@@ -594,7 +609,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
               uint32_t iscrc, plen, blen;
               EH_PT0;
               int r = pick_csum(c, H, b.len, &iscrc, &plen, &blen);
-              EH_PT(c, 118);
+              EH_PT(c, 59);
               if (r < 0) break;
               if (r == 0) tr_aa(c, AT_csum, AT_failed);                               // :119
               if (r == 1) {
@@ -612,7 +627,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
             } else if (pat == P_AR || pat == P_CP) {                                  // mutate_once_archiver :165-214, mutate_once_compressed :216-260
               EH_PT0;
               uint64_t e = pat_container_begin(c, lt.e_pri, lt.e_meta, pat, frames, nfr, ip, contpat);
-              EH_PT(c, pat == P_CP ? 121 : 123);
+              EH_PT(c, pat == P_CP ? 63 : 78);
               lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
               if (c.pat_ret < 0) break;
               if (c.pat_ret == 2) { nfr++; act = A_LOOP; break; }                     // the rest of the chain on a payload: mutate_once_loop(Mutator, [], NextPat, Ip, Data, [])
@@ -667,7 +682,7 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
         if (f.kind == P_AR || f.kind == P_CP) {
           EH_PT0;
           uint64_t e = pat_container_end(c, lt.e_pri, lt.e_meta, f.kind, f.em_field, f.field, frames, nfr);
-          EH_PT(c, f.kind == P_CP ? 122 : 124);
+          EH_PT(c, f.kind == P_CP ? 69 : 79);
           lt.e_pri = (uint32_t)(e >> 32); lt.e_meta = (uint32_t)e;
           if (c.pat_ret < 0) break;
           ip = c.pat_ip; cont = C_PAT; contpat = c.pat_cont;
@@ -691,9 +706,9 @@ EH_DEV void run_patterns(Ctx& c, LaneTab& lt, int pat) {
           uint64_t o = 0;
           for (int k = f.em_field; k < c.nem; k++) { Blk x = blk_load(c.em, k); wave_copy(blob + o, (cbptr)x.ptr, x.len); o += x.len; }
           wave_sync();
-          EH_PT(c, 120);
+          EH_PT(c, 61);
           uint32_t cs = f.crc ? wave_crc32(blob, (uint32_t)tot) : wave_xor8(blob, (uint32_t)tot);
-          EH_PT(c, 116);
+          EH_PT(c, 62);
           uint32_t cb = f.crc ? 4u : 1u;
           if (EH_LANE == 0) put_field(blob + tot, cs, cb * 8, true);
           wave_sync();

@@ -72,10 +72,12 @@ __device__ __noinline__ int pick_simple_len(Ctx&, cbptr H, uint32_t L, SizerElem
   }
   uint32_t sub = L / 5 < SIZER_MAX_FIRST_BYTES ? L / 5 : SIZER_MAX_FIRST_BYTES;
   uint32_t ny = sub + 1;
-  uint64_t mark = c.ws_used;
-  wptr varb = (wptr)ws_alloc(c, (uint64_t)ny * 4);
-  wptr cnt2 = (wptr)ws_alloc(c, (uint64_t)ny * 4);
-  if (!varb || !cnt2) return -1;
+  // the <= 513 right ends in LDS (g_fuse_lds is free outside the fuse / sgm mutators): in draw order, sorted, and the per-offset
+  // counts of parts II and III
+  static_assert(4 * (SIZER_MAX_FIRST_BYTES + 8) <= EH_FUSE_LDS_WORDS, "the sizer's tables fit the fuse band");
+  uint32_t* varb = g_fuse_lds; uint32_t* vsort = g_fuse_lds + (SIZER_MAX_FIRST_BYTES + 8); uint32_t* cnt2 = g_fuse_lds + 2 * (SIZER_MAX_FIRST_BYTES + 8);
+  uint32_t* cnt3 = g_fuse_lds + 3 * (SIZER_MAX_FIRST_BYTES + 8);
+  wave_sync();
   // VarBSeq = [rand_range(SubLen, Len) || _ <- FirstSeq]   (:94)
   for (uint32_t base = 0; base < ny; base += 64) {
     uint32_t j = base + (uint32_t)l;
@@ -83,7 +85,17 @@ __device__ __noinline__ int pick_simple_len(Ctx&, cbptr H, uint32_t L, SizerElem
     rng_skip(c.rng, ny - base < 64 ? ny - base : 64);
   }
   wave_sync();
-  // per-offset data in registers: lane handles offsets A = l, l+64, ... (<= 9 of them)
+  // sorted copy: every lane ranks its own values against all of them (ties by position)
+  for (uint32_t base = 0; base < ny; base += 64) {
+    uint32_t j = base + (uint32_t)l;
+    if (j < ny) {
+      const uint32_t v = varb[j]; uint32_t rank = 0;
+      for (uint32_t i = 0; i < ny; i++) { const uint32_t u = varb[i]; rank += (u < v || (u == v && i < j)) ? 1u : 0u; }
+      vsort[rank] = v;
+    }
+  }
+  wave_sync();
+  // lane handles offsets A = l, l+64, ... (<= 9 of them)
   uint32_t tot1 = 0, tot2 = 0, tot3 = 0;
   for (uint32_t base = 0; base < ny; base += 64) {
     uint32_t A = base + (uint32_t)l;
@@ -95,19 +107,42 @@ __device__ __noinline__ int pick_simple_len(Ctx&, cbptr H, uint32_t L, SizerElem
       { uint32_t v = H[A]; int64_t B = (int64_t)A + 1 + v; int64_t X = (int64_t)L - B; if (v > 2 && X >= 0 && X <= 8 && A < L) c1 = 1; }
       // III: simple_len({A, L})
       for (int a = 0; a < 5; a++) if (basic_len_clause(fv, fm, L, A, (int64_t)L - adjs[a]) >= 0) c3++;
-      // II: simple_len({A, VarB[y]}) for every y
-      for (uint32_t y = 0; y < ny; y++) {
-        int64_t vb = (int64_t)varb[y];
-        for (int a = 0; a < 5; a++) if (basic_len_clause(fv, fm, L, A, vb - adjs[a]) >= 0) c2++;
+      // II: simple_len({A, VarB[y] - adj}) for every y and adj: a pair matches when VarB[y] - adj is one of the (at most six, here
+      // made distinct) right ends A + w_c + field_c(A) the clauses ask for - counted in the sorted copy
+      const uint32_t wsc[6] = {2, 4, 8, 2, 4, 8};
+      uint32_t te[6]; uint32_t use = 0;                            // (indexed by unrolled loops only: registers)
+#pragma unroll
+      for (int cc = 0; cc < 6; cc++) {
+        te[cc] = 0;
+        if (!((fm >> cc) & 1) || fv[cc] <= 2 || fv[cc] > (uint64_t)L) continue;      // want > 2; B <= VarB < L
+        const uint64_t t = (uint64_t)A + wsc[cc] + fv[cc];
+        if (t > (uint64_t)L) continue;
+        te[cc] = (uint32_t)t;
+        bool dup = false;
+#pragma unroll
+        for (int q = 0; q < 6; q++) if (q < cc && ((use >> q) & 1) && te[q] == (uint32_t)t) dup = true;
+        if (!dup) use |= 1u << cc;
       }
-      cnt2[A] = c2;
+#pragma unroll 1
+      for (int cc = 0; cc < 6; cc++) {
+        if (!((use >> cc) & 1)) continue;
+        const uint32_t t = cc == 0 ? te[0] : cc == 1 ? te[1] : cc == 2 ? te[2] : cc == 3 ? te[3] : cc == 4 ? te[4] : te[5];
+        uint32_t lo = 0, hi = ny;                                   // first sorted value >= t
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (vsort[mid] < t) lo = mid + 1; else hi = mid; }
+        for (uint32_t k = lo; k < ny; k++) {
+          const uint32_t d = vsort[k] - t;
+          if (d > 8) break;
+          if (d == 0 || d == 1 || d == 2 || d == 4 || d == 8) c2++;
+        }
+      }
+      cnt2[A] = c2; cnt3[A] = c3;
     }
     tot1 += c1; tot2 += c2; tot3 += c3;
   }
   tot1 = wave_sum(tot1); tot2 = wave_sum(tot2); tot3 = wave_sum(tot3);
   wave_sync();
   uint32_t total = tot1 + tot2 + tot3;
-  if (total == 0) { c.ws_used = mark; return 0; }
+  if (total == 0) return 0;
   uint32_t idx = rng_rand(c.rng, total);                         // rand_elem/1
   SizerElem res{0, 0, 0, 0, 0};
   const uint32_t wsz[6] = {2, 4, 8, 2, 4, 8};
@@ -146,18 +181,18 @@ __device__ __noinline__ int pick_simple_len(Ctx&, cbptr H, uint32_t L, SizerElem
     }
   } else {
     uint32_t k = idx - tot1 - tot2;
+    int64_t Xs = -1;
+    for (int64_t X = (int64_t)sub; X >= 0; X--) { uint32_t cc = uni(cnt3[X]); if (k < cc) { Xs = X; break; } k -= cc; }
+    uint32_t A = (uint32_t)Xs;
+    uint64_t fv[6]; uint32_t fm = 0;
+    for (int cc = 0; cc < 6; cc++) { uint32_t w; uint64_t v = 0; if (field_at(H, L, A, cc, &v, &w)) fm |= 1u << cc; fv[cc] = v; }
     bool done = false;
-    for (int64_t X = (int64_t)sub; X >= 0 && !done; X--) {
-      uint32_t A = (uint32_t)X;
-      uint64_t fv[6]; uint32_t fm = 0;
-      for (int cc = 0; cc < 6; cc++) { uint32_t w; uint64_t v = 0; if (field_at(H, L, A, cc, &v, &w)) fm |= 1u << cc; fv[cc] = v; }
-      for (int a = 0; a < 5 && !done; a++) {
-        int cl = basic_len_clause(fv, fm, L, A, (int64_t)L - adjs[a]);
-        if (cl >= 0) { if (k == 0) { uint32_t B = (uint32_t)((int64_t)L - adjs[a]); res = SizerElem{wsz[cl] * 8, cl < 3 ? 1u : 0u, B - A - wsz[cl], A, B}; done = true; } else k--; }
-      }
+    for (int a = 0; a < 5 && !done; a++) {
+      int cl = basic_len_clause(fv, fm, L, A, (int64_t)L - adjs[a]);
+      if (cl >= 0) { if (k == 0) { uint32_t B = (uint32_t)((int64_t)L - adjs[a]); res = SizerElem{wsz[cl] * 8, cl < 3 ? 1u : 0u, B - A - wsz[cl], A, B}; done = true; } else k--; }
     }
   }
-  c.ws_used = mark;
+  wave_sync();
   e->size_bits = uni(res.size_bits); e->big = uni(res.big); e->len = uni(res.len); e->a = uni(res.a); e->b = uni(res.b);
   return 1;
 }

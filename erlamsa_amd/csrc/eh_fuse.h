@@ -29,10 +29,7 @@ namespace eh {
 // Likewise to / tc / T.  Most nodes are {1,1} after a round or two and then cost one 16-byte load and store per round.
 struct FNode { uint32_t fo, fc, to, tc; };
 // big-node path: [0,256) source count -> cursor, [256,512) target, [512,768) child index of the bin, [768,1024) flags
-#ifndef EH_FUSE_LDS_WORDS
-#define EH_FUSE_LDS_WORDS 4800
-#endif
-EH_LDS_ARRAY(uint32_t, g_fuse_lds, EH_FUSE_LDS_WORDS);     // (eh_fuse2.h: bitmaps of <= EH_FUSE_LDS_WORDS / 8 nodes)
+// (g_fuse_lds, EH_FUSE_LDS_WORDS words: eh_device.h; eh_fuse2.h: bitmaps of <= EH_FUSE_LDS_WORDS / 8 nodes)
 
 // ascending bitonic sort of one 32-bit key per lane
 EH_DEV uint32_t wave_sort64(uint32_t key) {

@@ -18,7 +18,6 @@
 // wave_crc32 in eh_engine.hip).  All state lives in a scratch block the caller hands in (ZDef: 330 KB, ZInf: 3 KB).
 #pragma once
 #include "eh_device.h"
-#include "eh_fuse.h"      // g_fuse_lds: the CRC tables are staged there
 
 namespace eh {
 

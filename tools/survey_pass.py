@@ -63,7 +63,9 @@ if pr.sum() > 0:
         print("  rounds per fuse_lists call: %.2f" % (pr[2 * 126] / pr[2 * 126 + 1]))
     if pr[2 * 127 + 1] > 0:
         print("  workgroup starts: first .. last = %.3f ms (100 MHz clock; all workgroups resident at once when this is far below the pass)" % ((pr[2 * 127 + 1] - pr[2 * 127]) / 1e5))
-    for k in range(64, 127):
+    print("  pattern phase outside the mutators (Gcyc, calls): " + ", ".join("%s %.2f x%d" % (nm, pr[2 * k] / 1e9, pr[2 * k + 1]) for k, nm in (
+        (59, "csum finder"), (60, "length-field finder (sz)"), (61, "cs: gather"), (62, "cs: checksum"), (63, "cp: decode"), (69, "cp: encode + compare"), (78, "ar: open + first file"), (79, "ar: file done / create"))))
+    for k in range(64, 112):
         if pr[2 * k + 1] > 0:
             print("  slot %3d calls %9d mean %10.1f kcyc total %8.2f Gcyc" % (k, pr[2 * k + 1], pr[2 * k] / pr[2 * k + 1] / 1e3, pr[2 * k] / 1e9))
 
