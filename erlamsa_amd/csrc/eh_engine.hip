@@ -214,16 +214,29 @@ __device__ __noinline__ int pick_csum(Ctx&, cbptr H, uint32_t L, uint32_t* crc, 
     uint32_t stored = (uni(H[L - 4]) << 24) | (uni(H[L - 3]) << 16) | (uni(H[L - 2]) << 8) | uni(H[L - 1]);
     uint32_t E = L - 4;
     uint32_t whole = wave_crc32(H, E);                             // crc(0..E); the tables stay in T
-    // prefix CRCs crc(0..A) for A <= maxp: one sequential table walk, the same on every lane ...
+    // prefix CRCs crc(0..A) for A <= maxp < 1024: lane k owns bytes [16k, 16k + 16).  The register state in front of its bytes
+    // follows from the lanes before it (state' = state advanced over 16 zero bytes ^ the zero-start remainder of the 16 bytes:
+    // the CRC register is linear in its start value), then every lane walks its own bytes.
     {
-      uint32_t run = 0xFFFFFFFFu;
-      for (uint32_t A0 = 0; A0 < np; A0 += 64) {
-        const uint32_t mine = A0 + (uint32_t)l < L ? H[A0 + (uint32_t)l] : 0u;     // 64 bytes of the block, one per lane
-        const uint32_t n64 = np - A0 < 64 ? np - A0 : 64;
-        for (uint32_t k = 0; k < n64; k++) {
-          if ((uint32_t)l == k) pre[A0 + k] = run ^ 0xFFFFFFFFu;   // crc32(bytes[0..A))
-          const uint32_t byte = (uint32_t)__shfl((int)mine, (int)k);
-          if (A0 + k < L) run = T[(run ^ byte) & 0xFF] ^ (run >> 8);
+      const uint32_t o = 16u * (uint32_t)l;
+      uint32_t by[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) by[j] = (o + (uint32_t)j < L && o < np) ? (uint32_t)H[o + (uint32_t)j] : 0u;
+      uint32_t z = 0;                                              // zero-start remainder of my 16 bytes
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) z = crc32_word(T, z, by[j] | (by[j + 1] << 8) | (by[j + 2] << 16) | (by[j + 3] << 24));
+      uint32_t run = 0xFFFFFFFFu, mine = 0xFFFFFFFFu;
+      const uint32_t nseg = (np + 15u) / 16u;
+      for (uint32_t k = 0; k < nseg; k++) {
+        if ((uint32_t)l == k) mine = run;
+        const uint32_t zk = (uint32_t)__builtin_amdgcn_readlane((int)z, (int)k);
+        run = crc32_word(T, crc32_word(T, crc32_word(T, crc32_word(T, run, 0u), 0u), 0u), 0u) ^ zk;
+      }
+      if (o < np) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          if (o + (uint32_t)j < np) pre[o + (uint32_t)j] = mine ^ 0xFFFFFFFFu;      // crc32(bytes[0..A))
+          mine = T[(mine ^ by[j]) & 0xFFu] ^ (mine >> 8);
         }
       }
     }

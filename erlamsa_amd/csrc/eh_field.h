@@ -38,6 +38,25 @@ EH_DEV int basic_len_clause(const uint64_t fv[6], uint32_t fmask, uint32_t L, ui
   return -1;
 }
 
+// The offset that holds the k-th element when the per-offset counts cnt[0..top] are walked from `top` down (BigLens is built in
+// reversed range order); k becomes the rank within that offset.  64 offsets a step.
+EH_DEV int64_t sizer_pick_desc(const uint32_t* cnt, uint32_t top, uint32_t& k) {
+  const int l = EH_LANE;
+  for (int64_t xtop = (int64_t)top; xtop >= 0; xtop -= 64) {
+    const int64_t X = xtop - (int64_t)l;
+    const uint32_t m = X >= 0 ? cnt[X] : 0u;
+    const uint32_t inc = wave_incl_scan(m);
+    const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    if (k < all) {
+      const int j = (int)__builtin_ctzll(__ballot(inc > k));
+      k -= (uint32_t)__builtin_amdgcn_readlane((int)(inc - m), j);
+      return xtop - j;
+    }
+    k -= all;
+  }
+  return -1;
+}
+
 // Picks rand_elem(get_possible_simple_lens(Bin)).  Returns 1 and fills *e, 0 when the list is
 // empty (no draw for rand_elem), -1 on allocation failure.  Consumes SubLen+1 draws when L > 10.
 __device__ __noinline__ int pick_simple_len(Ctx&, cbptr H, uint32_t L, SizerElem* e) {
@@ -166,14 +185,27 @@ __device__ __noinline__ int pick_simple_len(Ctx&, cbptr H, uint32_t L, SizerElem
   } else if (idx < tot1 + tot2) {
     // BigLens over {X, VarB[y]}: X from SubLen down to 0, y from last to first, then the 5 offsets
     uint32_t k = idx - tot1;
-    int64_t Xs = -1;
-    for (int64_t X = (int64_t)sub; X >= 0; X--) { uint32_t cc = uni(cnt2[X]); if (k < cc) { Xs = X; break; } k -= cc; }
+    const int64_t Xs = sizer_pick_desc(cnt2, sub, k);
     uint32_t A = (uint32_t)Xs;
     uint64_t fv[6]; uint32_t fm = 0;
     for (int cc = 0; cc < 6; cc++) { uint32_t w; uint64_t v = 0; if (field_at(H, L, A, cc, &v, &w)) fm |= 1u << cc; fv[cc] = v; }
+    // which y: 64 right ends at a time from the last one down, every lane counts the matches of its own (over the five adjustments)
+    int64_t ys = -1;
+    for (int64_t ytop = (int64_t)ny - 1; ytop >= 0 && ys < 0; ytop -= 64) {
+      const int64_t y = ytop - (int64_t)l;
+      uint32_t m = 0;
+      if (y >= 0) { const int64_t vb = (int64_t)varb[y]; for (int a = 0; a < 5; a++) if (basic_len_clause(fv, fm, L, A, vb - adjs[a]) >= 0) m++; }
+      const uint32_t inc = wave_incl_scan(m);
+      const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+      if (k < all) {
+        const int j = (int)__builtin_ctzll(__ballot(inc > k));
+        k -= (uint32_t)__builtin_amdgcn_readlane((int)(inc - m), j);
+        ys = ytop - j;
+      } else k -= all;
+    }
     bool done = false;
-    for (int64_t y = (int64_t)ny - 1; y >= 0 && !done; y--) {
-      int64_t vb = (int64_t)uni(varb[y]);
+    if (ys >= 0) {
+      const int64_t vb = (int64_t)uni(varb[ys]);
       for (int a = 0; a < 5 && !done; a++) {
         int cl = basic_len_clause(fv, fm, L, A, vb - adjs[a]);
         if (cl >= 0) { if (k == 0) { uint32_t B = (uint32_t)(vb - adjs[a]); res = SizerElem{wsz[cl] * 8, cl < 3 ? 1u : 0u, B - A - wsz[cl], A, B}; done = true; } else k--; }
@@ -181,8 +213,7 @@ __device__ __noinline__ int pick_simple_len(Ctx&, cbptr H, uint32_t L, SizerElem
     }
   } else {
     uint32_t k = idx - tot1 - tot2;
-    int64_t Xs = -1;
-    for (int64_t X = (int64_t)sub; X >= 0; X--) { uint32_t cc = uni(cnt3[X]); if (k < cc) { Xs = X; break; } k -= cc; }
+    const int64_t Xs = sizer_pick_desc(cnt3, sub, k);
     uint32_t A = (uint32_t)Xs;
     uint64_t fv[6]; uint32_t fm = 0;
     for (int cc = 0; cc < 6; cc++) { uint32_t w; uint64_t v = 0; if (field_at(H, L, A, cc, &v, &w)) fm |= 1u << cc; fv[cc] = v; }

@@ -91,17 +91,14 @@ EH_DEV uint32_t wave_crc32(cbptr p, uint32_t n) {
   }
   for (; i < b; i++) crc = T[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
   crc ^= 0xFFFFFFFFu;                                              // crc32 of my piece (0 for an empty one)
-  const uint32_t xp = gf2_xpow8n(chunk);                           // all pieces but the last have this length
-  uint32_t total = 0;
-  for (int k = 0; k < 64; k++) {                                   // crc32_combine left to right
-    const uint64_t ak = (uint64_t)k * chunk;
-    if (ak >= n) break;
-    const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)crc, k);
-    const uint64_t lk = n - ak < chunk ? n - ak : chunk;
-    total = k == 0 ? ck : (gf2_multmodp(lk == chunk ? xp : gf2_xpow8n(lk), total) ^ ck);
-  }
+  // crc32_combine over the 64 pieces at once: piece k contributes crc_k * x^(8 * bytes behind it) (the left-to-right chain
+  // ((c0 * x^l1 ^ c1) * x^l2 ^ c2) ... multiplied out; an empty piece has crc 0)
+  uint32_t term = 0;
+  if (a < n) term = b < n ? gf2_multmodp(gf2_xpow8n((uint64_t)n - b), crc) : crc;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) term ^= (uint32_t)__shfl_xor((int)term, d);
   wave_sync();
-  return total;
+  return uni(term);
 }
 EH_DEV uint32_t fold_xor8(uint4 v) { return v.x ^ v.y ^ v.z ^ v.w; }
 EH_DEV uint32_t wave_xor8(cbptr p, uint32_t n) {

@@ -148,6 +148,14 @@ def test_emulated_blocks_above_a_million_bytes_are_split(emu_lib):
     assert r.returncode == 0 and "split ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_emulated_tree_matcher_deep_nesting_quotes_and_stray_closers(emu_lib):
+    """partial_parse/1 + grow/3 (erlamsa_mutations.erl:800-905) on inputs made for the matcher: nesting beyond the 64 stack entries kept
+    in lane registers (spill / refill), quotes, closers that match nothing, openers that never close; tr2, td, ts1, ts2, tr"""
+    env = dict(os.environ, ERLAMSA_HIP_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "emu_tree.py"), "1", "10"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "emu_tree ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_emulated_race_detector_finds_no_cross_lane_access_without_a_rendezvous():
     """The engine built with every load / store of the kernel code instrumented (build_emu.py --race, tests/hipemu/race_hooks.cpp):
     between two rendezvous points no lane reads what another lane wrote or overwrites what another lane read - the class of bug
