@@ -428,10 +428,11 @@ def main():
     overflow_sites = {}
     names = [m for m, _, _ in ea.mutator_table()]
 
-    cyc_pass, len_hist = [], []
+    cyc_pass, len_hist, occ_pass = [], [], []
 
     def on_result(k, e):                                      # which capacity check gave up, for the cases that end as EH_CASE_OVERFLOW
         st = e.status()
+        occ_pass.append(e.occupancy())                          # (page-locked memory the kernel wrote: no copy call)
         if args.case_stats:
             cy = e.cycles()
             cy = np.where(cy > (1 << 60), 0, cy)                # (a case whose end stamp read lower than its start stamp: s_memtime is per-XCD and a wrapped difference is not a duration)
@@ -584,6 +585,14 @@ def main():
             # the stated second metric: cases per second of the cases whose output is at most 64 KiB - what a fuzzing user
             # feels, and what the pump cases that make the MB/s headline do not move.  Same timed region, same cases.
             res["cases_per_s_le_64KiB"] = res["case_stats"]["cases_with_output_le_64KiB"]["cases_per_s"]
+        if occ_pass and dt > 0:
+            # where the device's wave slots were during the timed steps (eh_result_occupancy): 100 MHz ticks of the passes' workgroups over
+            # wall time x slots.  `held` = a workgroup sat in the slot; `in_cases` = it ran a case; the rest of `held` is the stay for other
+            # cases' posted loops, ticket / set-up code and waiting for a work area; 1 - held = slots nobody held
+            slots = occ_pass[0][4]; cap = dt * 1e8 * slots
+            res["wave_slots"] = {"slots": slots, "held": round(sum(o[0] for o in occ_pass) / cap, 4), "in_cases": round(sum(o[1] for o in occ_pass) / cap, 4),
+                                 "lingering_for_posted_loops": round(sum(o[2] for o in occ_pass) / cap, 4),
+                                 "what": "share of (wall time of the timed steps x wave slots of the device); the passes in flight at the start of the timed steps are those of the warm-up (not counted), the last timed ones run to their end inside it"}
         if int(status_counts[4]) > 0:                             # EH_CASE_ARENA_FULL inside the timed steps: those cases' outputs are missing from `value`
             res["warning"] = "%d cases of the timed steps did not fit their pass's output arena (%d GiB): raise --out-gib; value counts the bytes that were produced" % (int(status_counts[4]), args.out_gib)
             log(res["warning"])

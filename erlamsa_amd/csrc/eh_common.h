@@ -200,6 +200,7 @@ struct KParams {
   uint64_t batch_seq;           // ... stamped with this number
   uint32_t co_copy_min, co_copy_chunk;   // bytes: copies / compares of co_copy_min and more are posted in chunks of co_copy_chunk
   uint32_t co_fb_min, co_fb_chunk;       // positions: the same for the streaming passes of eh_fuse2.h (chunk: a multiple of 1024)
+  uint32_t co_linger, pad_co;            // wavefronts of a pass that stay for posted chunks once the pass is out of tickets
 };
 
 struct MutaInfo { const char* name; int pri; int on_gpu; };

@@ -856,8 +856,9 @@ EH_DEV void sys_store(EH_G unsigned long long* p, unsigned long long v) {   // a
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
 }
+constexpr int CTR_OCC = 272;                 // counters [272, 274): 100 MHz ticks of the workgroups in cases, lingering for posted chunks ([7]: their lifetimes)
 constexpr int CTR_STATUS = 264;              // counters [264, 270): cases of the batch by status ([8, 264) are the EH_PROF slots)
-constexpr unsigned int CO_LINGER = 48;       // wavefronts of a pass that stay for posted chunks once the pass is out of tickets
+constexpr unsigned int CO_LINGER = 24;       // wavefronts of a pass that stay for posted chunks once the pass is out of tickets
 // 2 wavefronts per SIMD = up to 256 VGPRs: at 4 (128 VGPRs) the scheduler loops and the candidate loop of base64_mutator
 // reload spilled registers from scratch on every iteration (7.5 M instead of 1.6 M memory instructions for one
 // b64-heavy case, twice the time, profiles/r03_summary.json "occupancy"); the longest cases set the duration of a pass.
@@ -901,6 +902,9 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
     }
   }
 
+  // where the wave slots' time goes (eh_result_occupancy): this workgroup's life, its cases, its stay for posted chunks - 100 MHz ticks
+  const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long case_ticks = 0, linger_ticks = 0;
   const uint64_t TICKET_BATCH = 4;                // cases claimed per atomic (one counter saturates at ~88 dequeues/us)
   uint64_t tk_next = 0, tk_end = 0;
   while (true) {
@@ -917,21 +921,24 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
       // two cases any more.  Up to CO_LINGER wavefronts of the pass stay for chunks - of any pass's cases - while the pass has
       // cases under way and some case on the device is posting; the others leave their slots to the workgroups of the next passes.
       if (p.board) {
-        unsigned int mine = CO_LINGER;
+        unsigned int mine = p.co_linger;
         if (l == 0) mine = (unsigned int)atomicAdd(p.ticket + 4, 1ull);
-        if (uni(mine) < CO_LINGER) {
+        if (uni(mine) < p.co_linger) {
+          const unsigned long long lg0 = __builtin_amdgcn_s_memrealtime();
           EH_G CoBoard* bd = p.board;
           for (uint32_t spins = 0; spins < (1u << 24); spins++) {
             if (uni64(co_ld64(p.ticket + 3)) >= p.n || uni(co_ld32(&bd->posters)) == 0) break;
             if (uni(co_ld32(&bd->open)) != 0) co_help(bd, 8);
             else { for (int z = 0; z < 6; z++) __builtin_amdgcn_s_sleep(127); }   // ~20 us: posted loops last hundreds (every poll is a trip to the L2 of all these wavefronts)
           }
+          linger_ticks = __builtin_amdgcn_s_memrealtime() - lg0;
         }
       }
 #endif
       break;
     }
     c.co_posted = 0;
+    const unsigned long long case_t0 = __builtin_amdgcn_s_memrealtime();
     uint64_t tick0 = __builtin_readcyclecounter();
 #ifndef HIPEMU
     c.t_case = tick0;
@@ -1033,6 +1040,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
       p.peak[i] = c.ws_peak + c.ws_top;
       if (p.flags & EH_FLAG_META_TRACE) { p.trace_off[i] = tbase; p.trace_len[i] = c.trace ? c.ntrace : 0u; }
     }
+    case_ticks += __builtin_amdgcn_s_memrealtime() - case_t0;
     wave_sync();
   }
   // The last workgroup to leave writes the batch's totals into page-locked host memory: a host loop over many batches then needs no
@@ -1041,10 +1049,16 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
   // returns (the returned value is waited for with vmcnt(0)), so the one that sees all the others reads final values.
   wave_sync();
   unsigned long long left = 0;
+  if (l == 0) {
+    atomicAdd(p.ticket + 7, __builtin_amdgcn_s_memrealtime() - wg_t0);
+    atomicAdd(p.ticket + CTR_OCC, case_ticks);
+    atomicAdd(p.ticket + CTR_OCC + 1, linger_ticks);
+  }
   if (l == 0) left = atomicAdd(p.ticket + 6, 1ull);
   if (uni64(left) + 1 == (unsigned long long)gridDim.x && p.summary_out) {
     if (l < 6) sys_store(p.summary_out + 3 + l, co_ld64(p.ticket + CTR_STATUS + l));
     if (l == 6) { sys_store(p.summary_out + 1, co_ld64(p.ticket + 5)); sys_store(p.summary_out + 2, p.n); }
+    if (l == 7) { sys_store(p.summary_out + 10, co_ld64(p.ticket + 7)); sys_store(p.summary_out + 11, co_ld64(p.ticket + CTR_OCC)); sys_store(p.summary_out + 12, co_ld64(p.ticket + CTR_OCC + 1)); sys_store(p.summary_out + 13, (unsigned long long)gridDim.x); }
     wave_sync();
     if (l == 0) sys_store(p.summary_out + 9, p.batch_seq);
   }
@@ -1376,6 +1390,7 @@ static void co_defaults(KParams* p, int cus) {
   p->co_copy_chunk = co_env("EH_CO_COPY_CHUNK", emu ? (2u << 10) : (256u << 10));
   p->co_fb_min = co_env("EH_CO_FB_MIN", emu ? (16u << 10) : (512u << 10));
   p->co_fb_chunk = co_env("EH_CO_FB_CHUNK", emu ? (4u << 10) : (64u << 10)) & ~1023u;
+  { const char* v = getenv("EH_CO_LINGER"); p->co_linger = v && *v ? (uint32_t)strtoul(v, nullptr, 10) : CO_LINGER; p->pad_co = 0; }
   if (p->co_copy_chunk < 1024) p->co_copy_chunk = 1024;
   if (p->co_fb_chunk < 1024) p->co_fb_chunk = 1024;
 }
@@ -2110,6 +2125,16 @@ int eh_result_summary(eh_ctx* ctx, uint64_t* out /* 9 values */) {
   if (!hs || hs[9] != ctx->batch_seq) { ctx->err = "eh_result_summary: the batch's totals have not arrived in host memory"; return EH_E_HIP; }
   out[0] = ctx->last_in_bytes; out[1] = hs[1]; out[2] = ctx->last_n;
   for (int k = 0; k < 6; k++) out[3 + k] = hs[3 + k];
+  return EH_OK;
+}
+int eh_result_occupancy(eh_ctx* ctx, uint64_t* out /* 5 values */) {
+  if (!ctx || !out) return EH_E_INVALID;
+  if (!ctx->have_result) { ctx->err = "no batch has run"; return EH_E_STATE; }
+  if (hipEventQuery(ctx->ev1) != hipSuccess) { (void)hipGetLastError(); int rc = eh_sync(ctx); if (rc) return rc; }
+  volatile unsigned long long* hs = ctx->h_sum;
+  if (!hs || hs[9] != ctx->batch_seq) { ctx->err = "eh_result_occupancy: the batch's totals have not arrived in host memory"; return EH_E_HIP; }
+  for (int k = 0; k < 4; k++) out[k] = ctx->last_n ? hs[10 + k] : 0;
+  out[4] = (uint64_t)ctx->cus * 4u * EH_WAVES_PER_SIMD;
   return EH_OK;
 }
 int eh_result_download(eh_ctx* ctx, uint8_t* data, uint64_t cap, uint64_t* off, int32_t* status) {

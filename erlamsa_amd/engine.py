@@ -26,7 +26,7 @@ CASE_OK, CASE_CRASHED, CASE_OVERFLOW, CASE_UNSUPPORTED, CASE_ARENA_FULL, CASE_BU
 # every symbol include/erlamsa_hip.h declares
 ABI_SYMBOLS = [
     "eh_create", "eh_destroy", "eh_configure", "eh_corpus_upload", "eh_corpus_attach", "eh_fuzz_batch",
-    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_fetch", "eh_result_totals", "eh_result_summary", "eh_result_diag", "eh_result_cycles", "eh_result_peak", "eh_result_meta", "eh_result_write_files", "eh_result_prof", "eh_selftest_movers", "eh_selftest_zlib",
+    "eh_fuzz_calls", "eh_reserve", "eh_sync", "eh_result_device", "eh_result_download", "eh_result_fetch", "eh_result_totals", "eh_result_summary", "eh_result_occupancy", "eh_result_diag", "eh_result_cycles", "eh_result_peak", "eh_result_meta", "eh_result_write_files", "eh_result_prof", "eh_selftest_movers", "eh_selftest_zlib",
     "eh_last_kernel_ms", "eh_pool_stats", "eh_coop_stats", "eh_kernel_name", "eh_abi_version", "eh_mutator_count", "eh_mutator_name",
     "eh_mutator_default_pri", "eh_mutator_on_gpu", "eh_pattern_count", "eh_pattern_name",
     "eh_pattern_default_pri", "eh_pattern_on_gpu", "eh_strerror", "eh_last_error",
@@ -97,6 +97,7 @@ def load_library():
     lib.eh_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.eh_pool_stats.argtypes = [vp, vp]
     lib.eh_result_summary.argtypes = [vp, vp]
+    lib.eh_result_occupancy.argtypes = [vp, vp]
     lib.eh_coop_stats.argtypes = [vp, vp]
     lib.eh_coalesce_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
     lib.eh_submit.argtypes = [vp, vp, C.c_uint64, i64p, u64p]
@@ -325,6 +326,12 @@ class Engine:
         v = np.zeros(9, dtype=np.uint64)
         self._chk(self.lib.eh_result_summary(self.h, v.ctypes.data_as(C.c_void_p)))
         return int(v[0]), int(v[1]), int(v[2]), v[3:9].astype(np.int64)
+
+    def occupancy(self):
+        """(workgroup lifetimes, of that in cases, lingering for posted chunks: 100 MHz ticks summed over the batch's workgroups; workgroups; wave slots of the device) - eh_result_occupancy"""
+        v = np.zeros(5, dtype=np.uint64)
+        self._chk(self.lib.eh_result_occupancy(self.h, v.ctypes.data_as(C.c_void_p)))
+        return tuple(int(x) for x in v)
 
     def kernel_ms(self):
         ms = C.c_float()

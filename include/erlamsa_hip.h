@@ -246,6 +246,12 @@ int eh_result_totals(eh_ctx* ctx, uint64_t* in_bytes, uint64_t* out_bytes, uint6
  * out[3 + s] = cases with status s (EH_CASE_OK .. EH_CASE_BUDGET).  One 2 KiB copy whatever the batch size: for host loops over
  * many small batches (eh_result_totals copies every case's length). */
 int eh_result_summary(eh_ctx* ctx, uint64_t* out);
+/* Where the wave slots' time went in the last batch (diagnostic; written with the summary, no copy call), in ticks of the device's
+ * 100 MHz clock summed over the batch's workgroups: out[0] from a workgroup's start to its end, out[1] of that inside cases, out[2]
+ * staying for other cases' posted loops after the batch ran out of cases; out[3] = workgroups launched, out[4] = wavefronts of this
+ * kernel the device holds at once (its wave slots).  Summed over the batches of a run and divided by (wall time x 1e8 x out[4]),
+ * out[0] says how full the device was and out[1] how much of it did the cases' own work. */
+int eh_result_occupancy(eh_ctx* ctx, uint64_t* out);
 /* Per-case diagnostics of the last batch (device->host): PRNG draws consumed by the worker and
  * the id (index in eh_mutator_name) of the last mutator that fired, -1 if none; for an EH_CASE_OVERFLOW case, minus the
  * id of the capacity check that gave up (EH_SET_OVERFLOW sites in csrc/, a diagnostic).  May be NULL. */

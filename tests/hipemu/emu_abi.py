@@ -53,6 +53,11 @@ g, s = eng.download()
 assert g == want and list(s) == list(wst)
 inb, outb, nc = eng.totals()
 assert nc == 40 and inb == 40 * 200 and outb == sum(map(len, want))
+# the same totals summed by the kernel, and where the wave slots' time went (eh_result_summary / eh_result_occupancy: page-locked memory, no copy)
+sin, sout, sn, sby = eng.summary()
+assert (sin, sout, sn) == (inb, outb, nc) and int(sby[0]) == int((np.asarray(wst) == 0).sum())
+held, in_cases, lingering, wgs, slots = eng.occupancy()
+assert wgs >= 1 and slots >= wgs and held >= in_cases + lingering and in_cases > 0
 # the download path in many chunks (device gather into two alternating bounce buffers)
 eng.configure(mutations="bd=3,bf,bi=7", patterns="od,nd=2", generators="direct=500,random=1", download_chunk_bytes=700)   # results stay valid
 gc, sc = eng.download()
