@@ -85,3 +85,34 @@ def test_cooperative_execution_gives_the_same_bytes_and_is_used():
         assert d["loops_posted"] > 0 and d["chunks_by_helpers"] > 0, "%s: nothing was posted or no other wavefront took a chunk: %s" % (name, d)
     assert int((a[0] == 0).sum()) >= 0.9 * len(inputs)
     print("cooperative execution: %d cases identical with and without it; posted %s; small chunks %s" % (len(inputs), runs["posted"][4], runs["small_chunks"][4]))
+
+
+def test_batches_of_several_contexts_share_the_devices_slots_and_account_for_them():
+    """The wave slots are the device's (tier 0 of the work-area pool): three contexts with batches in flight at the same time, 2 048
+    workgroups each if they like, take their slots from one ring - every case still comes out as the oracle has it - and
+    eh_result_occupancy / eh_pool_stats account for the workgroups: lifetimes >= time in cases + time lingering, no workgroup left
+    on the device afterwards, never more of them than slots."""
+    import erlamsa_amd as ea
+    import pyoracle as po
+    inputs = util.corpus_mixed(3000, 1024, seed=5)
+    data, off = po.pack(inputs)
+    muts, pats = "bd,bf,sr,lr2,tr2,ts1,num,ab,ft,len", "od,nd,bu"
+    engs = []
+    for k in range(3):
+        e = ea.Engine(0)
+        e.configure(mutations=muts, patterns=pats, max_case_bytes=4 << 20, max_slots=0)
+        e.upload_corpus(data, off)
+        engs.append(e)
+    for k, e in enumerate(engs):
+        e.fuzz_batch(seed=(3, 1, 4), first_case=1 + 3000 * k)                 # launched back to back: the three batches run side by side
+    for k, e in enumerate(engs):
+        want, wst, wdr, _ = po.fuzz_batch(data, off, seed=(3, 1, 4), mutations=muts, patterns=pats, first_case=1 + 3000 * k, max_case_bytes=4 << 20)
+        got, gst = e.download()
+        bad = [i for i in range(3000) if gst[i] == 0 and wst[i] == 0 and got[i] != want[i]]
+        assert not bad and int((gst == 0).sum()) >= 2990, (k, bad[:5], int((gst == 0).sum()))
+        held, in_cases, lingering, wgs, slots = e.occupancy()
+        assert wgs == min(slots, 3000) and held >= in_cases + lingering and in_cases > 0, (held, in_cases, lingering, wgs, slots)
+    ps = engs[0].pool_stats()
+    assert ps["contexts"] == 3 and ps["workgroups_resident"]["now"] == 0 and 0 < ps["workgroups_resident"]["most"] <= ps["slots"], ps
+    for e in engs:
+        e.close()
