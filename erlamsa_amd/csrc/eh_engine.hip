@@ -880,11 +880,7 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
   if (l == 0) { unsigned long long t = __builtin_amdgcn_s_memrealtime(); atomicMin(&pp->prof[2 * 127], t ? t : 1ull); atomicMax(&pp->prof[2 * 127 + 1], t); }
 #endif
   // this workgroup's slot: block tables + work area
-  const uint32_t slot_id = pool_pop(p, 0);        // (never waits: the device holds no more of these workgroups than the tier has slots)
-  if (l == 0) {                                   // how many of them the device holds right now (eh_pool_stats: [18] now, [19] the most, [29] / [39] the mean seen by starting workgroups)
-    const unsigned long long r = atomicAdd(&p.pool_ctr[18], 1ull) + 1ull;
-    atomicMax(&p.pool_ctr[19], r); atomicAdd(&p.pool_ctr[29], r); atomicAdd(&p.pool_ctr[39], 1ull);
-  }
+  const uint32_t slot_id = blockIdx.x;
   bptr slot = p.slot_base + (uint64_t)slot_id * p.slot_stride;
   c.bl = (EH_G Blk*)slot;
   c.bl2 = c.bl + MAX_BLOCKS;
@@ -1052,8 +1048,6 @@ __global__ void __launch_bounds__(64, EH_WAVES_PER_SIMD) eh_mutate_kernel(const 
   // ms per step, during which it launched nothing).  Every wavefront's counter updates are complete before its own increment
   // returns (the returned value is waited for with vmcnt(0)), so the one that sees all the others reads final values.
   wave_sync();
-  pool_push(p, 0, slot_id);
-  if (l == 0) atomicAdd(&p.pool_ctr[18], ~0ull);
   unsigned long long left = 0;
   if (l == 0) {
     atomicAdd(p.ticket + 7, __builtin_amdgcn_s_memrealtime() - wg_t0);
@@ -1175,8 +1169,6 @@ struct DevPool {
   uint8_t* base[POOL_TIERS + 1] = {}; uint64_t stride[POOL_TIERS + 1] = {}, cap[POOL_TIERS + 1] = {}; uint32_t cnt[POOL_TIERS + 1] = {};
   uint32_t* d_rings = nullptr; uint32_t* ring[POOL_TIERS + 1] = {}; unsigned long long* d_ctr = nullptr;
   CoBoard* d_board = nullptr;                           // cooperative execution: the board every context of the device posts on (eh_common.h)
-  // tier 0: the slots (block tables + work_cap bytes) of the wavefronts the device holds at once - cnt[0] of them, stride[0] apart
-  // in base[0], handed out through ring[0] like the areas of the tiers above
 };
 
 struct eh_ctx {
@@ -1204,7 +1196,7 @@ struct eh_ctx {
   std::vector<uint64_t> h_coff;  // host copy of offsets (for totals)
   // work areas: a pool shared by every context of the device with the same sizes (DevPool below)
   DevPool* pool = nullptr;
-  uint32_t nslots = 0;                                  // workgroups of a batch (their slots: tier 0 of the pool)
+  uint8_t* d_slots = nullptr; uint64_t slot_stride = 0, slot_cap = 0; uint32_t nslots = 0;   // a slot per workgroup of a batch
   uint64_t big_case_bytes = 0;
   // outputs
   uint8_t* d_out = nullptr; uint64_t out_cap = 0;
@@ -1314,7 +1306,7 @@ static std::vector<DevPool*> g_pools;
 static void pool_free(DevPool* pl) {
   (void)hipSetDevice(pl->device);
   (void)hipDeviceSynchronize();
-  for (int t = 0; t <= pl->ntiers; t++) if (pl->base[t]) (void)hipFree(pl->base[t]);
+  for (int t = 1; t <= pl->ntiers; t++) if (pl->base[t]) (void)hipFree(pl->base[t]);
   if (pl->d_rings) (void)hipFree(pl->d_rings);
   if (pl->d_ctr) (void)hipFree(pl->d_ctr);
   if (pl->d_board) (void)hipFree(pl->d_board);
@@ -1369,20 +1361,13 @@ static int pool_acquire(eh_ctx* ctx, uint64_t work_cap, uint64_t big, uint64_t p
     if (e != hipSuccess) break;
     pl->stride[t] = stride_t; pl->cap[t] = caps[k]; pl->cnt[t] = (uint32_t)cnt; pl->ntiers++;
   }
-  // tier 0: a slot for every wavefront of eh_mutate_kernel the device holds at once (its LDS lets 2 x 4 workgroups onto a compute
-  // unit).  A workgroup takes one when it starts and gives it back when it leaves, whichever batch, context or stream it belongs to:
-  // a pass may bring as many workgroups as the device has slots, and the passes in flight share ONE set of slots (until round 6
-  // every context owned a slot per workgroup it launched: 1 024 workgroups a pass - half the device - at 4.3 GiB a context).
-  pl->cnt[0] = (uint32_t)(ctx->cus < 64 ? 8 : ctx->cus * 4 * EH_WAVES_PER_SIMD);
-  pl->stride[0] = (SLOT_TABLE_BYTES + work_cap + 255) & ~255ull;
-  if (hipMalloc(&pl->base[0], pl->stride[0] * pl->cnt[0]) != hipSuccess) { pl->base[0] = nullptr; pool_free(pl); ctx->err = "work-area pool: out of device memory for the wave slots"; return EH_E_NOMEM; }
   uint64_t nring = 4;
-  for (int t = 0; t <= pl->ntiers; t++) nring += pl->cnt[t];
+  for (int t = 1; t <= pl->ntiers; t++) nring += pl->cnt[t];
   std::vector<uint32_t> init(nring);
   std::vector<unsigned long long> ctr(64, 0ull);
   if (hipMalloc(&pl->d_rings, nring * 4) != hipSuccess || hipMalloc(&pl->d_ctr, 64 * 8) != hipSuccess) { pool_free(pl); ctx->err = "work-area pool: out of device memory"; return EH_E_NOMEM; }
   uint64_t o = 0;
-  for (int t = 0; t <= pl->ntiers; t++) {
+  for (int t = 1; t <= pl->ntiers; t++) {
     pl->ring[t] = pl->d_rings + o;
     for (uint32_t k = 0; k < pl->cnt[t]; k++) init[o + k] = k;
     ctr[2 * t] = 0; ctr[2 * t + 1] = pl->cnt[t];                                   // pop tickets, push tickets
@@ -1422,11 +1407,16 @@ static int reserve(eh_ctx* ctx, uint64_t n, uint64_t in_bytes) {
   if (big < work_cap) big = work_cap;
   rc = pool_acquire(ctx, work_cap, big, ctx->pool_bytes_opt);
   if (rc) return rc;
-  // workgroups of a batch: one per wavefront the device holds (the pool's tier 0 has a slot for each), or max_slots if that is less
-  uint32_t want_slots = ctx->pool->cnt[0];
-  if (ctx->max_slots_opt && ctx->max_slots_opt < want_slots) want_slots = ctx->max_slots_opt;
+  // a slot per workgroup of a batch: one workgroup per wavefront the device holds (EH_WAVES_PER_SIMD), or max_slots
+  uint32_t want_slots = ctx->max_slots_opt ? ctx->max_slots_opt : (uint32_t)ctx->cus * 4u * EH_WAVES_PER_SIMD;
   if (want_slots > n) want_slots = (uint32_t)(n ? n : 1);
-  ctx->nslots = want_slots;
+  uint64_t stride = (SLOT_TABLE_BYTES + work_cap + 255) & ~255ull;
+  if (!ctx->d_slots || ctx->nslots < want_slots || ctx->slot_cap != work_cap) {
+    if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    ctx->d_slots = nullptr;
+    HIPCHK(ctx, hipMalloc(&ctx->d_slots, stride * want_slots));
+    ctx->nslots = want_slots; ctx->slot_cap = work_cap; ctx->slot_stride = stride;
+  }
   uint64_t want_out = ctx->out_capacity_opt ? ctx->out_capacity_opt : (8 * (in_bytes ? in_bytes : ctx->corpus_bytes) + (2048ull << 20));
   if (!ctx->d_out || ctx->out_cap < want_out) {
     if (ctx->d_out) (void)hipFree(ctx->d_out);
@@ -1461,7 +1451,7 @@ static int launch(eh_ctx* ctx, int mode, const int64_t seed[3], uint64_t first_c
   p.out = dp(ctx->d_out); p.out_cap = ctx->out_cap; p.out_cursor = dp(ctx->d_counters + 1);
   p.out_off = dp(ctx->d_off); p.out_len = dp(ctx->d_len); p.status = dp(ctx->d_status); p.draws = dp(ctx->d_draws); p.lastm = dp(ctx->d_lastm); p.cycles = dp(ctx->d_cycles); p.peak = dp(ctx->d_peak); p.trace_off = dp(ctx->d_toff); p.trace_len = dp(ctx->d_tlen); p.flags = ctx->flags;
   p.ticket = dp(ctx->d_counters); p.in_bytes = dp(ctx->d_counters + 2); p.prof = dp(ctx->d_counters + 8);   // counters [8, 264) = prof
-  p.slot_base = dp(pl->base[0]); p.slot_stride = pl->stride[0]; p.pool_cnt[0] = pl->cnt[0]; p.pool_ring[0] = dp(pl->ring[0]);
+  p.slot_base = dp(ctx->d_slots); p.slot_stride = ctx->slot_stride;
   p.ntiers = pl->ntiers; p.pool_ctr = dp(pl->d_ctr); p.pool_cap[0] = pl->work_cap;
   p.board = (ctx->flags & EH_FLAG_NO_COOP) ? dp((CoBoard*)nullptr) : dp(pl->d_board);
   co_defaults(&p, ctx->cus);
@@ -1598,7 +1588,7 @@ void eh_destroy(eh_ctx* ctx) {
   if (ctx->comm) { ehcomm::Api* a = ehcomm::api(); if (a->h) (void)a->CommDestroy(ctx->comm); ctx->comm = nullptr; }
   if (ctx->own_corpus) { (void)hipFree(ctx->d_corpus); (void)hipFree(ctx->d_coff); }
   pool_release(ctx);
-  (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
+  (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_out); (void)hipFree(ctx->d_off); (void)hipFree(ctx->d_len);
   (void)hipFree(ctx->d_status); (void)hipFree(ctx->d_draws); (void)hipFree(ctx->d_lastm); (void)hipFree(ctx->d_cycles); (void)hipFree(ctx->d_peak); (void)hipFree(ctx->d_toff); (void)hipFree(ctx->d_tlen); (void)hipFree(ctx->d_counters); if (ctx->h_sum) (void)hipHostFree(ctx->h_sum);
   (void)hipFree(ctx->d_run); (void)hipFree(ctx->d_seeds);
   for (int k = 0; k < 2; k++) { if (ctx->d_bounce[k]) (void)hipFree(ctx->d_bounce[k]); if (ctx->ev_g[k]) (void)hipEventDestroy(ctx->ev_g[k]); if (ctx->ev_c[k]) (void)hipEventDestroy(ctx->ev_c[k]); }
@@ -2404,7 +2394,7 @@ int eh_pool_stats(eh_ctx* ctx, uint64_t* out /* 64 values */) {
     out[41 + t] = t >= 1 && t <= ctx->pool->ntiers ? (uint64_t)ctx->pool->cnt[t] | (raw[40 + t] << 32) : 0;   // areas | the most that were out at once
     out[51 + t] = t <= ctx->pool->ntiers ? ctx->pool->cap[t] : 0;
   }
-  out[61] = (uint64_t)ctx->pool->refs; out[62] = ctx->pool->cnt[0]; out[63] = ctx->nslots;
+  out[61] = (uint64_t)ctx->pool->refs; out[62] = ctx->nslots; out[63] = 0;
   return EH_OK;
 }
 // Cooperative execution (eh_common.h CoBoard): out[0] loops posted, [1] chunks run by wavefronts between cases, [2] by the posting

@@ -347,8 +347,7 @@ class Engine:
         return {"slot_bytes": int(v[51]), "slots": int(v[62]), "area_bytes": [int(v[51 + t]) for t in ts], "areas": [int(v[41 + t]) & 0xFFFFFFFF for t in ts],
                 "peak_wanted": [int(v[41 + t]) >> 32 for t in ts],
                 "taken": [int(v[2 * t]) for t in ts], "waits": [int(v[30 + t]) for t in ts], "wait_ticks": [int(v[20 + t]) for t in ts],
-                "contexts": int(v[61]),
-                "workgroups_resident": {"now": int(v[18]), "most": int(v[19]), "mean_seen_by_a_starting_workgroup": round(int(v[29]) / max(int(v[39]), 1), 1), "started": int(v[39])}}
+                "contexts": int(v[61])}
 
     def coop_stats(self):
         """Cooperative execution of heavy cases on this device (eh_coop_stats)."""

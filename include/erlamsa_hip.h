@@ -83,11 +83,9 @@ typedef struct eh_options {
   double blockscale;         /* 0 => 1.0 (erlamsa_gen.erl:206) */
   const char* ssrf_host;     /* NULL => "localhost" */
   int32_t ssrf_port;         /* 0 => 51234 */
-  uint64_t max_case_bytes;   /* work area of a slot; 0 => default (8 MiB).  The device's work-area pool has a slot for every wavefront
-                                of the kernel the device holds at once; a workgroup (= wavefront) takes one when it starts and gives
-                                it back when it leaves, whichever batch it belongs to.  A case that outgrows it goes on in larger areas
-                                borrowed from the same pool, which contexts that ask for the same max_case_bytes, big_case_bytes and
-                                pool_bytes share */
+  uint64_t max_case_bytes;   /* work area of a slot; every workgroup (= wavefront) of a batch owns one; 0 => default (8 MiB).
+                                A case that outgrows it goes on in larger areas borrowed from the device's work-area pool,
+                                which contexts that ask for the same max_case_bytes, big_case_bytes and pool_bytes share */
   uint64_t out_capacity;     /* output arena bytes; 0 => 8 x batch input bytes + 2 GiB */
   uint64_t max_case_work;    /* OPTIONAL per-case work budget in bytes (sum over mutator attempts, failed ones
                                 included, of block size x cost weight of the mutator: 8 for parsers and
@@ -315,10 +313,8 @@ int eh_selftest_sort_by_priority(const uint32_t* pri, uint32_t n, uint32_t* perm
  * of tier t taken / returned since the pool was made (+ the tier's size for the latter), out[20+t] = shader-clock ticks
  * wavefronts waited for an area of tier t, out[30+t] = how many had to wait, out[40] = tiers, out[41+t] = areas of tier t (low 32 bits) and the most of them that
  * were wanted at the same time, taken or waited for (high 32 bits),
- * out[51+t] = bytes of an area of tier t (out[51] = the slots'), out[61] = contexts sharing the pool, out[62] = slots of the pool
- * (= wavefronts of the kernel the device holds at once), out[63] = workgroups of a batch of this context; out[18] = workgroups
- * of the kernel on the device right now, out[19] = the most there were, out[29] / out[39] = how many a starting workgroup found
- * (sum / starts). */
+ * out[51+t] = bytes of an area of tier t (out[51] = the slots'), out[61] = contexts sharing the pool, out[62] = slots
+ * (= workgroups of a batch) of this context. */
 int eh_pool_stats(eh_ctx* ctx, uint64_t* out);
 /* Cooperative execution of heavy cases (ABI 8): a case's loops over hundreds of kilobytes (block copies, the final concatenation,
  * the streaming passes of erlamsa_fuse on large lists) are cut into chunks that wavefronts BETWEEN two cases of their own run too.
