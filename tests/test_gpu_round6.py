@@ -4,6 +4,7 @@
   500 000 + rand(500 000) - 1 before the pattern walks them - inputs of 1.0 - 2.6 MB under od / nd / bu / sk.
 * Cooperative execution of heavy cases (csrc/eh_common.h CoBoard): the same batches with and without it give the same bytes, and
   the posted loops are really taken by other wavefronts.
+* Three contexts with batches in flight at once, and eh_result_occupancy's account of the workgroups' time.
 """
 import os
 import sys
